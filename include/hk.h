@@ -1,0 +1,227 @@
+/*
+ * hk.h — C ABI of libhk.so: the MI355X-native batched kart-racing step + feedback LQ Nash-game solve.
+ *
+ * Drop-in boundary for ONE hot path of ribsthakkar/HierarchicalKarting (Unity C#).  The reference has no FFI for
+ * this path (everything is in-process managed calls), so each entry point below names the managed surface it
+ * replaces (reference file:line, paths relative to Assets/Karting/Scripts/).  A C# host binds these with
+ * [DllImport("hk")]; all types are blittable (int32 / uint32 / float / double / pointers).
+ *
+ * Conventions: return 0 on success, negative hk_status on error (never throws across the ABI);
+ * host buffers are caller-owned, device buffers library-owned; one handle = one GPU context, NOT thread-safe
+ * (Unity drives it from FixedUpdate on the main thread, like the reference); row-major arrays.
+ * There is NO CPU fallback: without a HIP device hk_create / hk_lq_solve_batch fail with HK_ERR_NO_DEVICE.
+ */
+#ifndef HK_H
+#define HK_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HK_ABI_VERSION 1
+#define HK_MAX_AGENTS 8      /* ABI capacity; the round-1 kernels accept num_agents <= 4 (largest reference scene) */
+#define HK_MAX_SECTIONS 64   /* Oval 24, Complex 41 */
+#define HK_NUM_SENSORS 9     /* MLAgent_Sensors.prefab */
+
+typedef enum hk_status {
+    HK_OK = 0,
+    HK_ERR_INVALID = -1,      /* bad argument / config */
+    HK_ERR_NO_DEVICE = -2,    /* no HIP device: the product path has no CPU fallback */
+    HK_ERR_HIP = -3,          /* HIP runtime error (see hk_last_error) */
+    HK_ERR_UNSUPPORTED = -4,  /* valid in the reference, not built yet (e.g. num_agents > 4, MCTS, RL policy) */
+    HK_ERR_SINGULAR = -5      /* LQ: zero pivot in the m x m solve */
+} hk_status;
+
+/* HierarchicalKartAgent.cs:21-33 */
+enum { HK_LOW_RL = 0, HK_LOW_MPC = 1, HK_LOW_LQR = 2 };
+enum { HK_HIGH_MCTS = 0, HK_HIGH_FIXED = 1 };
+/* RacingEnvController.cs:24-29 */
+enum { HK_MODE_RACE = 0, HK_MODE_TRAINING = 1, HK_MODE_EXPERIMENT = 2 };
+
+/* agent flag bits (hk_agent_state.flags) */
+enum {
+    HK_F_ACCEL = 1u << 0,             /* KartAgent.m_Acceleration      KA:104 */
+    HK_F_BRAKE = 1u << 1,             /* KartAgent.m_Brake             KA:105 */
+    HK_F_ACTIVE = 1u << 2,            /* KartAgent.is_active           KA:123 */
+    HK_F_FORWARD_COLLISION = 1u << 3, /* KartAgent.forwardCollision    KA:125 */
+    HK_F_HAS_COLLISION = 1u << 4,     /* ArcadeKart.m_HasCollision     AK:202 */
+    HK_F_CAN_MOVE = 1u << 5,          /* ArcadeKart.m_CanMove          AK:195 */
+    HK_F_ENABLED = 1u << 6            /* GameObject.activeSelf (Deactivate(disable) KA:405-416) */
+};
+
+/* ArcadeKart.Stats (KartSystems/ArcadeKart.cs:20-69); values used: SURVEY App. A */
+typedef struct hk_kart_stats {
+    float TopSpeed, Acceleration, ReverseSpeed, ReverseAcceleration, AccelerationCurve, Braking, CoastingDrag, Grip;
+    float MaxSteer, MinSteer, TireWearFactor, MinGs, MaxGs, AddedGravity;
+    float TireWearRate;      /* AK:191 */
+    float reserved;
+} hk_kart_stats;
+
+/* one DiscretePositionTracker (DiscretePositionTracker.cs:20-44) with its Waypoint prefab geometry */
+typedef struct hk_section {
+    float trig_x, trig_z;        /* Trigger box centre (box 10 x 1 x 1, local z +0.407 from the waypoint) */
+    float yaw_deg;               /* Unity Y rotation of the waypoint (0 = +z, 90 = +x) */
+    float marker_y;              /* world y of Trigger / lane markers (0.75): the constant dy of quirk Q13 */
+    float lane_x[4], lane_z[4];  /* Lane1..Lane4 markers */
+    float track_inside_radius, track_length, track_width, turn_degrees;
+    int32_t left_turn, optimal_lane;
+} hk_section;
+
+typedef struct hk_wall_seg { float x0, z0, x1, z1; } hk_wall_seg; /* road-side wall face, world metres */
+
+typedef struct hk_config {
+    int32_t abi_version;         /* HK_ABI_VERSION */
+    int32_t num_envs;            /* E: independent RacingEnvControllers on this device */
+    int32_t num_agents;          /* A: RacingEnvController.Agents.Length (REC:49) */
+    int32_t device_id;
+    /* wiring: KartAgent.teamAgents / otherAgents (KA:63-65), RacingEnvController.Teams (REC:46) */
+    int32_t team_of[HK_MAX_AGENTS];
+    int32_t n_team[HK_MAX_AGENTS];
+    int32_t team_agents[HK_MAX_AGENTS][HK_MAX_AGENTS];
+    int32_t n_other[HK_MAX_AGENTS];
+    int32_t other_agents[HK_MAX_AGENTS][HK_MAX_AGENTS];
+    int32_t high_mode[HK_MAX_AGENTS];          /* HK_HIGH_*  (HKA:64) */
+    int32_t low_mode[HK_MAX_AGENTS];           /* HK_LOW_*   (HKA:62) */
+    int32_t tree_search_depth[HK_MAX_AGENTS];  /* gameParams.treeSearchDepth (HKA:48) */
+    int32_t velocity_bucket_size[HK_MAX_AGENTS];
+    hk_kart_stats stats;                       /* identical on every kart of the Compete scenes */
+    /* rules (REC:110-130) */
+    int32_t laps, max_episode_steps, max_lane_changes, section_horizon, disable_on_end, env_mode;
+    int32_t start_hold_ticks;    /* WaitForSeconds(1.5f) at dt 0.02 = 75 ticks (REC:721-724) */
+    int32_t auto_reset;          /* REC.FixedUpdate resets when every agent is inactive (REC:241-270) */
+    float dt;                    /* Time.fixedDeltaTime 0.02 */
+    float kart_y;                /* spawn height 0.28 (REC:715) */
+    /* sensors (MLAgent_Sensors.prefab, KA:20-26): yaw in degrees, positive = to the right */
+    float sensor_yaw_deg[HK_NUM_SENSORS];
+    float ray_distance[HK_NUM_SENSORS];
+    float wall_hit_validation[HK_NUM_SENSORS];
+    float agent_hit_validation[HK_NUM_SENSORS];
+    /* synthetic de-synchronisation of the start grid (NOT in the reference): Philox-4x32 keyed by
+     * jitter_seed + env_id;  dx,dz ~ U(-jitter_pos, jitter_pos), dyaw ~ U(-jitter_yaw, jitter_yaw) rad. 0 = off. */
+    uint32_t jitter_seed;
+    float jitter_pos, jitter_yaw;
+    int32_t env_id_base;         /* global id of local env 0 (multi-GPU sharding: contiguous ranges per rank) */
+    /* track */
+    int32_t num_sections;
+    int32_t num_walls;
+    const hk_section* sections;
+    const hk_wall_seg* walls;
+} hk_config;
+
+/* Per-agent persistent state: the fields of KartAgent (KA:102-128), ArcadeKart (AK:190-205) and the Rigidbody that
+ * survive a tick.  This IS the device record (one per [env][agent]); hk_get/set_agent_state copy it verbatim, which
+ * gives snapshot/restore for free. */
+typedef struct hk_agent_state {
+    float px, pz;                 /* transform.position (x, z); y is kart_y */
+    float yaw;                    /* Unity Y rotation, radians, kept in [0, 2pi) */
+    float vx, vz;                 /* Rigidbody.velocity */
+    float wy;                     /* Rigidbody.angularVelocity.y (rad/s) */
+    float acc_ang_v;              /* ArcadeKart.m_AccumulatedAngularV (AK:190) */
+    float steering;               /* KartAgent.m_Steering (KA:106) */
+    float avg_lane_diff;          /* KA:116 */
+    float avg_vel_diff;           /* KA:115 */
+    float cum_reward;             /* ML-Agents cumulative reward ("next" row; 0 in round 1) */
+    float contact_nx, contact_nz; /* m_LastCollisionNormal (AK:201), x/z */
+    int32_t section_index;        /* m_SectionIndex KA:107 */
+    int32_t lane;                 /* m_Lane KA:108 */
+    int32_t lane_changes;         /* KA:109 */
+    int32_t illegal_lane_changes; /* KA:110 */
+    int32_t forward_collisions;   /* KA:126 */
+    int32_t last_collision_time;  /* KA:127 */
+    int32_t time_steps;           /* m_timeSteps KA:112 */
+    int32_t init_checkpoint_index;/* KA:49 */
+    uint32_t flags;               /* HK_F_* */
+    uint32_t trig_lo, trig_hi;    /* which Trigger boxes the kart overlapped after the last tick (OnTriggerEnter edge) */
+    uint32_t reserved0;
+    uint8_t plan_lane[HK_MAX_SECTIONS]; /* m_UpcomingLanes keyed by section % L (KA:117); 0 = no entry */
+    float plan_vel[HK_MAX_SECTIONS];    /* m_UpcomingVelocities (KA:118) */
+} hk_agent_state;
+
+typedef struct hk_env_state {
+    int32_t episode_steps;     /* REC:125 */
+    uint32_t inactive_mask;    /* REC.inactiveAgents (REC:118) as a bit set over Agents[] */
+    int32_t experiment_num;    /* REC:63 */
+    int32_t episodes_done;     /* finished episodes since hk_create */
+    uint32_t status;           /* bit0 NaN/Inf seen in a kart state, bit1 timeout ended last episode */
+    int32_t reserved[3];
+} hk_env_state;
+
+/* TelemetryViewer / experiment-log quantities of the last finished episode (TelemetryViewer.cs:49-108) */
+typedef struct hk_episode_result {
+    int32_t time_steps;            /* m_timeSteps at finish; 0 = did not finish (REC:470,476) */
+    int32_t section_index;         /* laps = section_index / L */
+    int32_t illegal_lane_changes;
+    int32_t forward_collisions;
+    float avg_lane_diff;
+    float avg_vel_diff;
+    float reward;
+    int32_t episode;               /* index of the episode these numbers belong to (-1: none finished yet) */
+} hk_episode_result;
+
+/* debug tap: the LQ game one ego assembled on its last solve tick (HKA:699-1201), ego-local player order */
+typedef struct hk_lq_debug {
+    int32_t n_players;
+    int32_t player_agent[HK_MAX_AGENTS]; /* agent index of each player, order [this, team..., other...] filtered (HKA:702-725) */
+    int32_t branch[HK_MAX_AGENTS];       /* heading-heuristic branch id B1..B7 per player */
+    double initial[HK_MAX_AGENTS][4];
+    double target[HK_MAX_AGENTS][4];
+    double target_w[HK_MAX_AGENTS][4];
+    double control_w[HK_MAX_AGENTS];
+    double u0[2];
+} hk_lq_debug;
+
+typedef struct hk_context* hk_handle;
+
+/* replaces: scene instantiation of RacingEnvController + KartAgents (REC.Start :148-168, HKA.Awake :413-426) */
+int hk_create(const hk_config* cfg, hk_handle* out);
+void hk_destroy(hk_handle h);
+const char* hk_last_error(hk_handle h);
+
+/* RacingEnvController.ResetGame (REC:499-719) for the listed envs (env_ids == NULL: all), Experiment/Race grid:
+ * ordering = allOrderings[experiment_num % A!] (REC:528-530).  experiment_num < 0: per-env (env_id_base + env) % A! */
+int hk_reset(hk_handle h, const int32_t* env_ids, int n, int experiment_num);
+
+/* KartAgent.OnActionReceived / InterpretDiscreteActions (KA:440-478, HKA:1371-1379): only read by LowMode == RL agents.
+ * steer[E][A] continuous action 0, branch[E][A] discrete action 0 in {0 brake, 1 coast, 2 accelerate} */
+int hk_set_actions(hk_handle h, const float* steer, const int32_t* branch);
+
+/* n_ticks Unity FixedUpdate ticks: REC.FixedUpdate -> [HKA.FixedUpdate incl. SolveLQR] ->
+ * ArcadeKart.FixedUpdate -> engine step (integrate, contacts, triggers). Asynchronous on the handle's stream. */
+int hk_step(hk_handle h, int n_ticks);
+
+/* HierarchicalKartAgent.CollectObservations (HKA:485-604): obs[E][A][hk_obs_dim], order exactly as the reference adds them */
+int hk_obs_dim(hk_handle h);
+int hk_get_observations(hk_handle h, float* obs);
+
+int hk_get_agent_state(hk_handle h, hk_agent_state* out /*[E][A]*/);
+int hk_set_agent_state(hk_handle h, const hk_agent_state* in /*[E][A]*/);
+int hk_get_env_state(hk_handle h, hk_env_state* out /*[E]*/);
+int hk_set_env_state(hk_handle h, const hk_env_state* in /*[E]*/);
+int hk_get_episode_results(hk_handle h, hk_episode_result* out /*[E][A]*/);
+int hk_get_lq_debug(hk_handle h, int env, int ego, hk_lq_debug* out);
+
+/* KartLQR.solveFeedbackLQR (AI/LQR/KartLQR.cs:17) batched, 1:1 incl. quirks Q1 (block-transposed LHS) and Q2.
+ * A[b][N][4][4], B[b][N][4][2], Q[b][N][n][n], q[b][N][n], R[b][N][2][2], x0[b][n], n = 4N; u0_out[b][2].
+ * Host pointers; h may be NULL (a temporary context on device 0 is used). N <= 4 in round 1. */
+int hk_lq_solve_batch(hk_handle h, int batch, int N, const double* A, const double* B, const double* Q, const double* q,
+                      const double* R, const double* x0, int horizon, double* u0_out);
+
+/* device-resident variants used by bench.py / torch (pointers are HIP device pointers; stream = hipStream_t or NULL) */
+int hk_lq_solve_batch_device(hk_handle h, int batch, int N, const double* dA, const double* dB, const double* dQ,
+                             const double* dq, const double* dR, const double* dx0, int horizon, double* du0, void* stream);
+void* hk_device_results_ptr(hk_handle h);  /* hk_episode_result[E][A] on device: the payload of the RCCL all-gather */
+void* hk_device_agents_ptr(hk_handle h);   /* hk_agent_state[E][A] on device */
+void* hk_stream(hk_handle h);              /* hipStream_t the handle launches on */
+int hk_synchronize(hk_handle h);
+
+/* timing taps for bench.py's roofline object: HIP-event time (ms) and launch count of the dominant kernel since the
+ * last call to hk_prof_reset; events are recorded on the handle's own stream */
+int hk_prof_enable(hk_handle h, int on);
+int hk_prof_reset(hk_handle h);
+int hk_prof_read(hk_handle h, double* solve_ms, int64_t* solve_launches, double* step_ms, int64_t* step_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HK_H */

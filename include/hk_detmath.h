@@ -1,0 +1,179 @@
+/*
+ * hk_detmath.h — the numeric contract for transcendental functions on the kart hot path.
+ *
+ * Why this exists.  The reference evaluates Mathf.Sin/Cos/Atan2/Exp/Pow as the platform's double
+ * libm result rounded to float (e.g. HierarchicalKartAgent.cs:734,821-831,1341-1344,
+ * ArcadeKart.cs:300) and Math.Sin/Cos/Atan2 in double (KartLQRDynamics.cs:45-48, HKA:1343).  No two libm's
+ * (Mono/.NET CRT, glibc, ROCm ocml) agree in the last bit, so "bit-reproducible episode outcomes" is only
+ * definable against ONE pinned implementation.  This header is that implementation: pure IEEE-754
+ * double + - * / (no FMA: build with -ffp-contract=off), identical on the host (gcc) and on gfx950 (hipcc),
+ * so the HIP kernels and the CPU oracle produce the same bits.  tests/test_detmath.py bounds every function
+ * against an 80-digit mpmath reference (<= 2 ulp), i.e. ~1e-16 relative from whatever libm the reference ran
+ * on — nine orders of magnitude inside the 1e-4 parity tolerance of BASELINE.json.
+ *
+ * Domain: arguments that occur on the path (|x| < 1e5 for sin/cos, finite for atan2, x in [-700, 700] for exp).
+ * Constants: tools/gen_detmath.py (mpmath, 80 digits).
+ */
+#ifndef HK_DETMATH_H
+#define HK_DETMATH_H
+
+#if defined(__HIPCC__)
+#define HK_HD __host__ __device__ static inline
+#else
+#define HK_HD static inline
+#endif
+
+#define HK_PI_F 3.14159274f /* UnityEngine.Mathf.PI as float */
+
+HK_HD double hk_fabs(double x) { return x < 0.0 ? -x : x; }
+
+/* r = x - k*pi/2 (3-part Cody-Waite), returns k mod 4 */
+HK_HD int hk__rem_pio2(double x, double* r)
+{
+    const double INV_PIO2 = 0.63661977236758138;
+    const double P1 = 1.5707963267341256, P2 = 6.077100506303966e-11, P3 = 2.0222662487959506e-21;
+    double t = x * INV_PIO2;
+    long long k = (long long)(t < 0.0 ? t - 0.5 : t + 0.5);
+    double fk = (double)k;
+    double y = x - fk * P1;
+    y = y - fk * P2;
+    y = y - fk * P3;
+    *r = y;
+    return (int)(k & 3);
+}
+
+HK_HD double hk__ksin(double r)
+{
+    double z = r * r;
+    double p = 1.9572941063391263e-20;
+    p = p * z + -8.2206352466243295e-18;
+    p = p * z + 2.8114572543455206e-15;
+    p = p * z + -7.6471637318198164e-13;
+    p = p * z + 1.6059043836821613e-10;
+    p = p * z + -2.505210838544172e-08;
+    p = p * z + 2.7557319223985893e-06;
+    p = p * z + -0.00019841269841269841;
+    p = p * z + 0.0083333333333333332;
+    p = p * z + -0.16666666666666666;
+    return r + (r * z) * p;
+}
+
+HK_HD double hk__kcos(double r)
+{
+    double z = r * r;
+    double p = -8.8967913924505741e-22;
+    p = p * z + 4.1103176233121648e-19;
+    p = p * z + -1.5619206968586225e-16;
+    p = p * z + 4.7794773323873853e-14;
+    p = p * z + -1.1470745597729725e-11;
+    p = p * z + 2.08767569878681e-09;
+    p = p * z + -2.7557319223985888e-07;
+    p = p * z + 2.4801587301587302e-05;
+    p = p * z + -0.0013888888888888889;
+    p = p * z + 0.041666666666666664;
+    return (1.0 - 0.5 * z) + (z * z) * p;
+}
+
+HK_HD double hk_sin(double x)
+{
+    double r;
+    int q = hk__rem_pio2(x, &r);
+    switch (q) {
+    case 0: return hk__ksin(r);
+    case 1: return hk__kcos(r);
+    case 2: return -hk__ksin(r);
+    default: return -hk__kcos(r);
+    }
+}
+
+HK_HD double hk_cos(double x)
+{
+    double r;
+    int q = hk__rem_pio2(x, &r);
+    switch (q) {
+    case 0: return hk__kcos(r);
+    case 1: return -hk__ksin(r);
+    case 2: return -hk__kcos(r);
+    default: return hk__ksin(r);
+    }
+}
+
+/* atan(t) for t in [0,1] */
+HK_HD double hk__atan01(double t)
+{
+    /* atan(j/8), j = 0..8, split hi + lo */
+    const double TH[9] = {0, 0.12435499454676144, 0.24497866312686414, 0.35877067027057225, 0.46364760900080609,
+                          0.55859931534356244, 0.64350110879328437, 0.71882999962162453, 0.78539816339744828};
+    const double TL[9] = {0, -3.1253241424539383e-18, 1.0698755618734451e-17, -2.4623815582638635e-17,
+                          2.2698777452961687e-17, -5.4556305485916264e-18, 1.5834785051444286e-17,
+                          -2.1478388444456983e-17, 3.061616997868383e-17};
+    int j = (int)(t * 8.0 + 0.5);
+    double c = (double)j * 0.125;
+    double u = (t - c) / (1.0 + t * c);
+    double z = u * u;
+    double p = 0.058823529411764705;
+    p = p * z + -0.066666666666666666;
+    p = p * z + 0.076923076923076927;
+    p = p * z + -0.090909090909090912;
+    p = p * z + 0.1111111111111111;
+    p = p * z + -0.14285714285714285;
+    p = p * z + 0.20000000000000001;
+    p = p * z + -0.33333333333333331;
+    double a = u + (u * z) * p;
+    return TH[j] + (TL[j] + a);
+}
+
+/* atan2 with the usual quadrant conventions; atan2(0,0) = 0, atan2(+-0, x<0) = +-pi */
+HK_HD double hk_atan2(double y, double x)
+{
+    const double PI_HI = 3.1415926535897931, PI_LO = 1.2246467991473532e-16;
+    const double PIO2_HI = 1.5707963267948966, PIO2_LO = 6.123233995736766e-17;
+    double ax = hk_fabs(x), ay = hk_fabs(y);
+    double r;
+    if (ax == 0.0 && ay == 0.0) {
+        r = 0.0;
+    } else if (ay <= ax) {
+        r = hk__atan01(ay / ax);
+    } else {
+        r = (PIO2_HI - hk__atan01(ax / ay)) + PIO2_LO;
+    }
+    if (x < 0.0) r = (PI_HI - r) + PI_LO;
+    return y < 0.0 ? -r : r;
+}
+
+HK_HD double hk_exp(double x)
+{
+    const double INV_LN2 = 1.4426950408889634, LN2_HI = 0.69314718036912382, LN2_LO = 1.9082149292705877e-10;
+    double t = x * INV_LN2;
+    long long k = (long long)(t < 0.0 ? t - 0.5 : t + 0.5);
+    double fk = (double)k;
+    double r = (x - fk * LN2_HI) - fk * LN2_LO;
+    double p = 1.1470745597729725e-11;
+    p = p * r + 1.6059043836821613e-10;
+    p = p * r + 2.08767569878681e-09;
+    p = p * r + 2.505210838544172e-08;
+    p = p * r + 2.7557319223985888e-07;
+    p = p * r + 2.7557319223985893e-06;
+    p = p * r + 2.4801587301587302e-05;
+    p = p * r + 0.00019841269841269841;
+    p = p * r + 0.0013888888888888889;
+    p = p * r + 0.0083333333333333332;
+    p = p * r + 0.041666666666666664;
+    p = p * r + 0.16666666666666666;
+    p = p * r + 0.5;
+    double e = 1.0 + (r + (r * r) * p);
+    /* scale by 2^k, k in [-1022, 1023] on this path */
+    union { unsigned long long u; double d; } s;
+    if (k < -1022) return 0.0;
+    if (k > 1023) k = 1023;
+    s.u = (unsigned long long)(k + 1023) << 52;
+    return e * s.d;
+}
+
+/* Mathf.* = libm in double, result rounded to float (Q8) */
+HK_HD float hk_sinf(float x) { return (float)hk_sin((double)x); }
+HK_HD float hk_cosf(float x) { return (float)hk_cos((double)x); }
+HK_HD float hk_atan2f(float y, float x) { return (float)hk_atan2((double)y, (double)x); }
+HK_HD float hk_expf(float x) { return (float)hk_exp((double)x); }
+
+#endif /* HK_DETMATH_H */

@@ -1,0 +1,67 @@
+"""include/hk_detmath.h (the pinned transcendental functions) vs an 80-digit mpmath reference: <= 2 ulp."""
+import math
+import numpy as np
+import mpmath as mp
+from oracle_lib import lib
+
+mp.mp.dps = 60
+
+
+def ulp_err(got, exact):
+    exact_f = float(exact)
+    if exact_f == 0.0:
+        return abs(got) / 5e-324
+    u = math.ulp(exact_f)
+    return abs(mp.mpf(got) - exact) / u
+
+
+def test_sin_cos():
+    L = lib(); rng = np.random.default_rng(1)
+    xs = np.concatenate([rng.uniform(-8, 14, 4000), rng.uniform(-1e3, 1e3, 500), [0.0, 1e-9, -1e-9, math.pi / 2, math.pi, 2 * math.pi]])
+    worst = 0
+    for x in xs:
+        x = float(x)
+        es, ec = mp.sin(mp.mpf(x)), mp.cos(mp.mpf(x))
+        # near a zero of the function an absolute bound is the meaningful one
+        for got, ex in ((L.hko_sin(x), es), (L.hko_cos(x), ec)):
+            if abs(ex) > 1e-3:
+                worst = max(worst, float(ulp_err(got, ex)))
+            else:
+                assert abs(mp.mpf(got) - ex) < 1e-18 * max(1.0, abs(x))
+    assert worst <= 2.0, worst
+
+
+def test_atan2():
+    L = lib(); rng = np.random.default_rng(2)
+    worst = 0
+    pts = [(float(a), float(b)) for a, b in rng.uniform(-60, 60, (5000, 2))]
+    pts += [(0.0, 1.0), (1.0, 0.0), (0.0, -1.0), (-1.0, 0.0), (1.0, 1.0), (-1.0, -1.0), (1e-9, 1.0), (1.0, 1e-9), (3.0, -4.0)]
+    for y, x in pts:
+        ex = mp.atan2(mp.mpf(y), mp.mpf(x))
+        got = L.hko_atan2(y, x)
+        if ex == 0:
+            assert got == 0.0
+        else:
+            worst = max(worst, float(ulp_err(got, ex)))
+    assert worst <= 2.0, worst
+    assert L.hko_atan2(0.0, 0.0) == 0.0
+    assert L.hko_atan2(0.0, -1.0) == math.pi
+    assert L.hko_atan2(-1.0, 0.0) == -math.pi / 2
+
+
+def test_exp():
+    L = lib(); rng = np.random.default_rng(3)
+    worst = 0
+    for x in np.concatenate([rng.uniform(-5, 1, 3000), rng.uniform(-700, 700, 300), [0.0]]):
+        x = float(x)
+        worst = max(worst, float(ulp_err(L.hko_exp(x), mp.exp(mp.mpf(x)))))
+    assert worst <= 2.0, worst
+
+
+def test_matches_libm_within_float_rounding():
+    """Mathf.* = (float)libm(double): the pinned functions and glibc agree after rounding to float except on a
+    vanishing fraction of inputs (the reference's own libm is unknowable; see hk_detmath.h)."""
+    L = lib(); rng = np.random.default_rng(4)
+    xs = rng.uniform(-7, 7, 20000)
+    diff = sum(np.float32(L.hko_sin(float(x))) != np.float32(math.sin(float(x))) for x in xs)
+    assert diff <= 2
