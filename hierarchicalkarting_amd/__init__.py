@@ -1,0 +1,6 @@
+"""hierarchicalkarting_amd — MI355X-native batched kart-racing step + feedback LQ Nash-game solve.
+
+The compute lives in libhk.so (hand-written HIP for gfx950 behind the C ABI of include/hk.h); this package is the
+Python host mirror of the reference's operator surface for that path.  Nothing here computes on the CPU."""
+from . import _lib  # noqa: F401
+from .lq import solve_feedback_lqr, solve_feedback_lqr_batch  # noqa: F401

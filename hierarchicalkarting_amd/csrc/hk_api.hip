@@ -1,0 +1,370 @@
+// hk_api.hip — C ABI of libhk.so (include/hk.h) on top of the gfx950 kernels.  No CPU fallback anywhere:
+// without a HIP device every compute entry point returns HK_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <new>
+#include "../../include/hk.h"
+#include "hk_lq_kernels.h"
+#include "hk_env_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct Prof {
+    bool on = false;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double solve_ms = 0, step_ms = 0;
+    int64_t solve_n = 0, step_n = 0;
+};
+
+}  // namespace
+
+struct hk_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool env_ready = false;
+    hk_config cfg{};
+    std::vector<hk_section> sections;
+    std::vector<hk_wall_seg> walls;
+    hk::EnvDevice dev{};           // device-side tables + state
+    int* d_status = nullptr;       // LQ singular flag etc.
+    std::string err;
+    Prof prof;
+    // scratch for the host-pointer LQ entry point
+    void* lq_scratch = nullptr;
+    size_t lq_scratch_bytes = 0;
+};
+
+namespace {
+
+int fail(hk_context* h, int code, const std::string& msg)
+{
+    g_last_error = msg;
+    if (h) h->err = msg;
+    return code;
+}
+
+#define HK_HIP(h, call)                                                                      \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail((h), HK_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int device_count()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ensure_ctx_basics(hk_context* h)
+{
+    HK_HIP(h, hipSetDevice(h->device));
+    if (!h->stream) HK_HIP(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    if (!h->d_status) {
+        HK_HIP(h, hipMalloc(&h->d_status, sizeof(int) * 4));
+        HK_HIP(h, hipMemsetAsync(h->d_status, 0, sizeof(int) * 4, h->stream));
+    }
+    return HK_OK;
+}
+
+hk_context* g_default_ctx = nullptr;   // used by hk_lq_solve_batch(NULL, ...)
+
+}  // namespace
+
+extern "C" {
+
+const char* hk_last_error(hk_handle h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+int hk_create(const hk_config* cfg, hk_handle* out)
+{
+    if (!out) return fail(nullptr, HK_ERR_INVALID, "hk_create: out is NULL");
+    *out = nullptr;
+    if (device_count() <= 0) return fail(nullptr, HK_ERR_NO_DEVICE, "hk_create: no HIP device (libhk has no CPU fallback)");
+    hk_context* h = new (std::nothrow) hk_context();
+    if (!h) return fail(nullptr, HK_ERR_INVALID, "hk_create: out of memory");
+    if (cfg) {
+        if (cfg->abi_version != HK_ABI_VERSION) { delete h; return fail(nullptr, HK_ERR_INVALID, "hk_create: abi_version mismatch"); }
+        h->device = cfg->device_id;
+    }
+    int rc = ensure_ctx_basics(h);
+    if (rc) { g_last_error = h->err; delete h; return rc; }
+    if (cfg) {
+        h->cfg = *cfg;
+        rc = hk::env_create(h->cfg, h->sections, h->walls, h->dev, h->stream, h->err);
+        if (rc) { g_last_error = h->err; hk_destroy(h); return rc; }
+        h->env_ready = true;
+    }
+    *out = h;
+    return HK_OK;
+}
+
+void hk_destroy(hk_handle h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    hk::env_destroy(h->dev);
+    if (h->d_status) (void)hipFree(h->d_status);
+    if (h->lq_scratch) (void)hipFree(h->lq_scratch);
+    if (h->prof.e0) (void)hipEventDestroy(h->prof.e0);
+    if (h->prof.e1) (void)hipEventDestroy(h->prof.e1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h == g_default_ctx) g_default_ctx = nullptr;
+    delete h;
+}
+
+void* hk_stream(hk_handle h) { return h ? (void*)h->stream : nullptr; }
+
+int hk_synchronize(hk_handle h)
+{
+    if (!h) return HK_ERR_INVALID;
+    HK_HIP(h, hipSetDevice(h->device));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    return HK_OK;
+}
+
+// ------------------------------------------------------------------ LQ batch
+int hk_lq_solve_batch_device(hk_handle h, int batch, int N, const double* dA, const double* dB, const double* dQ,
+                             const double* dq, const double* dR, const double* dx0, int horizon, double* du0, void* stream)
+{
+    if (!h) return fail(nullptr, HK_ERR_INVALID, "hk_lq_solve_batch_device: handle required");
+    if (batch < 0 || N < 1 || horizon < 0) return fail(h, HK_ERR_INVALID, "hk_lq_solve_batch: bad batch/N/horizon");
+    if (N > hk::LQ_MAXP) return fail(h, HK_ERR_UNSUPPORTED, "hk_lq_solve_batch: N > 4 players not built yet");
+    if (batch == 0) return HK_OK;
+    HK_HIP(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const int blocks = (batch + 3) / 4;
+    if (h->prof.on) HK_HIP(h, hipEventRecord(h->prof.e0, st));
+    hipLaunchKernelGGL(hk::lq_batch_kernel, dim3(blocks), dim3(64), 0, st, batch, N, dA, dB, dQ, dq, dR, dx0, horizon, du0,
+                       h->d_status);
+    HK_HIP(h, hipGetLastError());
+    if (h->prof.on) {
+        HK_HIP(h, hipEventRecord(h->prof.e1, st));
+        HK_HIP(h, hipEventSynchronize(h->prof.e1));
+        float ms = 0;
+        HK_HIP(h, hipEventElapsedTime(&ms, h->prof.e0, h->prof.e1));
+        h->prof.solve_ms += ms;
+        h->prof.solve_n += 1;
+    }
+    return HK_OK;
+}
+
+int hk_lq_solve_batch(hk_handle h, int batch, int N, const double* A, const double* B, const double* Q, const double* q,
+                      const double* R, const double* x0, int horizon, double* u0_out)
+{
+    if (!h) {
+        if (!g_default_ctx) {
+            int rc = hk_create(nullptr, &g_default_ctx);
+            if (rc) return rc;
+        }
+        h = g_default_ctx;
+    }
+    if (batch < 0 || N < 1) return fail(h, HK_ERR_INVALID, "hk_lq_solve_batch: bad batch/N");
+    if (N > hk::LQ_MAXP) return fail(h, HK_ERR_UNSUPPORTED, "hk_lq_solve_batch: N > 4 players not built yet");
+    if (batch == 0) return HK_OK;
+    if (!A || !B || !Q || !q || !R || !x0 || !u0_out) return fail(h, HK_ERR_INVALID, "hk_lq_solve_batch: NULL pointer");
+    HK_HIP(h, hipSetDevice(h->device));
+    const size_t n = 4 * (size_t)N, b = (size_t)batch;
+    const size_t szA = b * N * 16, szB = b * N * 8, szQ = b * N * n * n, szq = b * N * n, szR = b * N * 4, szx = b * n, szu = b * 2;
+    const size_t total = (szA + szB + szQ + szq + szR + szx + szu) * sizeof(double);
+    if (total > h->lq_scratch_bytes) {
+        if (h->lq_scratch) HK_HIP(h, hipFree(h->lq_scratch));
+        h->lq_scratch = nullptr; h->lq_scratch_bytes = 0;
+        HK_HIP(h, hipMalloc(&h->lq_scratch, total));
+        h->lq_scratch_bytes = total;
+    }
+    double* d = (double*)h->lq_scratch;
+    double *dA = d, *dB = dA + szA, *dQ = dB + szB, *dq = dQ + szQ, *dR = dq + szq, *dx = dR + szR, *du = dx + szx;
+    HK_HIP(h, hipMemcpyAsync(dA, A, szA * 8, hipMemcpyHostToDevice, h->stream));
+    HK_HIP(h, hipMemcpyAsync(dB, B, szB * 8, hipMemcpyHostToDevice, h->stream));
+    HK_HIP(h, hipMemcpyAsync(dQ, Q, szQ * 8, hipMemcpyHostToDevice, h->stream));
+    HK_HIP(h, hipMemcpyAsync(dq, q, szq * 8, hipMemcpyHostToDevice, h->stream));
+    HK_HIP(h, hipMemcpyAsync(dR, R, szR * 8, hipMemcpyHostToDevice, h->stream));
+    HK_HIP(h, hipMemcpyAsync(dx, x0, szx * 8, hipMemcpyHostToDevice, h->stream));
+    HK_HIP(h, hipMemsetAsync(h->d_status, 0, sizeof(int), h->stream));
+    int rc = hk_lq_solve_batch_device(h, batch, N, dA, dB, dQ, dq, dR, dx, horizon, du, h->stream);
+    if (rc) return rc;
+    int st = 0;
+    HK_HIP(h, hipMemcpyAsync(u0_out, du, szu * 8, hipMemcpyDeviceToHost, h->stream));
+    HK_HIP(h, hipMemcpyAsync(&st, h->d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    if (st & 1) return fail(h, HK_ERR_SINGULAR, "hk_lq_solve_batch: zero pivot in the m x m solve");
+    return HK_OK;
+}
+
+// ------------------------------------------------------------------ environment
+#define HK_NEED_ENV(h)                                                                     \
+    do {                                                                                   \
+        if (!(h)) return fail(nullptr, HK_ERR_INVALID, "NULL handle");                     \
+        if (!(h)->env_ready) return fail((h), HK_ERR_INVALID, "handle has no environment"); \
+        HK_HIP((h), hipSetDevice((h)->device));                                            \
+    } while (0)
+
+int hk_reset(hk_handle h, const int32_t* env_ids, int n, int experiment_num)
+{
+    HK_NEED_ENV(h);
+    int rc = hk::env_reset(h->dev, h->cfg, env_ids, n, experiment_num, h->stream, h->err);
+    if (rc) g_last_error = h->err;
+    return rc;
+}
+
+int hk_set_actions(hk_handle h, const float* steer, const int32_t* branch)
+{
+    HK_NEED_ENV(h);
+    if (!steer || !branch) return fail(h, HK_ERR_INVALID, "hk_set_actions: NULL pointer");
+    const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
+    HK_HIP(h, hipMemcpyAsync(h->dev.act_steer, steer, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HK_HIP(h, hipMemcpyAsync(h->dev.act_branch, branch, cnt * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    return HK_OK;
+}
+
+int hk_step(hk_handle h, int n_ticks)
+{
+    HK_NEED_ENV(h);
+    if (n_ticks < 0) return fail(h, HK_ERR_INVALID, "hk_step: n_ticks < 0");
+    for (int t = 0; t < n_ticks; t++) {
+        if (h->prof.on) {
+            float ms;
+            HK_HIP(h, hipEventRecord(h->prof.e0, h->stream));
+            int rc = hk::env_launch_solve(h->dev, h->cfg, h->stream, h->err);
+            if (rc) { g_last_error = h->err; return rc; }
+            HK_HIP(h, hipEventRecord(h->prof.e1, h->stream));
+            HK_HIP(h, hipEventSynchronize(h->prof.e1));
+            HK_HIP(h, hipEventElapsedTime(&ms, h->prof.e0, h->prof.e1));
+            h->prof.solve_ms += ms; h->prof.solve_n++;
+            HK_HIP(h, hipEventRecord(h->prof.e0, h->stream));
+            rc = hk::env_launch_step(h->dev, h->cfg, h->stream, h->err);
+            if (rc) { g_last_error = h->err; return rc; }
+            HK_HIP(h, hipEventRecord(h->prof.e1, h->stream));
+            HK_HIP(h, hipEventSynchronize(h->prof.e1));
+            HK_HIP(h, hipEventElapsedTime(&ms, h->prof.e0, h->prof.e1));
+            h->prof.step_ms += ms; h->prof.step_n++;
+        } else {
+            int rc = hk::env_launch_solve(h->dev, h->cfg, h->stream, h->err);
+            if (!rc) rc = hk::env_launch_step(h->dev, h->cfg, h->stream, h->err);
+            if (rc) { g_last_error = h->err; return rc; }
+        }
+    }
+    return HK_OK;
+}
+
+int hk_obs_dim(hk_handle h)
+{
+    if (!h || !h->env_ready) return HK_ERR_INVALID;
+    // HKA:424  Sensors.Length + sectionHorizon*5 + 8 + 12*(others + team)
+    return HK_NUM_SENSORS + h->cfg.section_horizon * 5 + 8 + 12 * (h->cfg.num_agents - 1);
+}
+
+int hk_get_observations(hk_handle h, float* obs)
+{
+    HK_NEED_ENV(h);
+    if (!obs) return fail(h, HK_ERR_INVALID, "hk_get_observations: NULL pointer");
+    int rc = hk::env_launch_observe(h->dev, h->cfg, h->stream, h->err);
+    if (rc) { g_last_error = h->err; return rc; }
+    const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents * hk_obs_dim(h);
+    HK_HIP(h, hipMemcpyAsync(obs, h->dev.obs, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    return HK_OK;
+}
+
+int hk_get_agent_state(hk_handle h, hk_agent_state* out)
+{
+    HK_NEED_ENV(h);
+    if (!out) return fail(h, HK_ERR_INVALID, "NULL pointer");
+    const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
+    HK_HIP(h, hipMemcpyAsync(out, h->dev.agents, cnt * sizeof(hk_agent_state), hipMemcpyDeviceToHost, h->stream));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    return HK_OK;
+}
+
+int hk_set_agent_state(hk_handle h, const hk_agent_state* in)
+{
+    HK_NEED_ENV(h);
+    if (!in) return fail(h, HK_ERR_INVALID, "NULL pointer");
+    const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
+    HK_HIP(h, hipMemcpyAsync(h->dev.agents, in, cnt * sizeof(hk_agent_state), hipMemcpyHostToDevice, h->stream));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    return HK_OK;
+}
+
+int hk_get_env_state(hk_handle h, hk_env_state* out)
+{
+    HK_NEED_ENV(h);
+    if (!out) return fail(h, HK_ERR_INVALID, "NULL pointer");
+    HK_HIP(h, hipMemcpyAsync(out, h->dev.envs, (size_t)h->cfg.num_envs * sizeof(hk_env_state), hipMemcpyDeviceToHost, h->stream));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    return HK_OK;
+}
+
+int hk_set_env_state(hk_handle h, const hk_env_state* in)
+{
+    HK_NEED_ENV(h);
+    if (!in) return fail(h, HK_ERR_INVALID, "NULL pointer");
+    HK_HIP(h, hipMemcpyAsync(h->dev.envs, in, (size_t)h->cfg.num_envs * sizeof(hk_env_state), hipMemcpyHostToDevice, h->stream));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    return HK_OK;
+}
+
+int hk_get_episode_results(hk_handle h, hk_episode_result* out)
+{
+    HK_NEED_ENV(h);
+    if (!out) return fail(h, HK_ERR_INVALID, "NULL pointer");
+    const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
+    HK_HIP(h, hipMemcpyAsync(out, h->dev.results, cnt * sizeof(hk_episode_result), hipMemcpyDeviceToHost, h->stream));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    return HK_OK;
+}
+
+int hk_get_lq_debug(hk_handle h, int env, int ego, hk_lq_debug* out)
+{
+    HK_NEED_ENV(h);
+    if (!out || env < 0 || env >= h->cfg.num_envs || ego < 0 || ego >= h->cfg.num_agents)
+        return fail(h, HK_ERR_INVALID, "hk_get_lq_debug: bad arguments");
+    if (!h->dev.lq_debug) return fail(h, HK_ERR_INVALID, "hk_get_lq_debug: debug taps are off");
+    HK_HIP(h, hipMemcpyAsync(out, h->dev.lq_debug + ((size_t)env * h->cfg.num_agents + ego), sizeof(hk_lq_debug),
+                             hipMemcpyDeviceToHost, h->stream));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    return HK_OK;
+}
+
+void* hk_device_results_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.results : nullptr; }
+void* hk_device_agents_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.agents : nullptr; }
+
+int hk_prof_enable(hk_handle h, int on)
+{
+    if (!h) return HK_ERR_INVALID;
+    HK_HIP(h, hipSetDevice(h->device));
+    if (on && !h->prof.e0) {
+        HK_HIP(h, hipEventCreate(&h->prof.e0));
+        HK_HIP(h, hipEventCreate(&h->prof.e1));
+    }
+    h->prof.on = on != 0;
+    return HK_OK;
+}
+
+int hk_prof_reset(hk_handle h)
+{
+    if (!h) return HK_ERR_INVALID;
+    h->prof.solve_ms = h->prof.step_ms = 0;
+    h->prof.solve_n = h->prof.step_n = 0;
+    return HK_OK;
+}
+
+int hk_prof_read(hk_handle h, double* solve_ms, int64_t* solve_launches, double* step_ms, int64_t* step_launches)
+{
+    if (!h) return HK_ERR_INVALID;
+    if (solve_ms) *solve_ms = h->prof.solve_ms;
+    if (solve_launches) *solve_launches = h->prof.solve_n;
+    if (step_ms) *step_ms = h->prof.step_ms;
+    if (step_launches) *step_launches = h->prof.step_n;
+    return HK_OK;
+}
+
+}  // extern "C"

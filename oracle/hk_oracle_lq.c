@@ -16,13 +16,24 @@ double hko_exp(double x) { return hk_exp(x); }
 /* KartMPC index constants (AI/MPC/KartMPC.cs:15-18) */
 enum { XI = 0, ZI = 1, VI = 2, HI = 3 };
 
-/* ---- tiny dense helpers; C = A(ra x ca) * B(ca x cb), k ascending, acc starts at +0.0 ---- */
+/* ---- tiny dense helpers; C = A(ra x ca) * B(ca x cb) ----
+ * ARITHMETIC CONTRACT (DESIGN.md "LQ arithmetic"): every inner product on the LQ path is a k-ascending chain of
+ * fused multiply-adds seeded with +0.0, s = fma(a_k, b_k, s).  MathNet's managed loops round the product first;
+ * the two differ by <= 0.5 ulp per term (~1e-16 relative, vs the 1e-4 tolerance), and the fused form is what
+ * gfx950's v_fma_f64 executes at full rate, so the HIP kernels reproduce this oracle bit for bit.  Terms whose
+ * factor is a structural zero leave s unchanged exactly, which lets the kernels skip them.
+ * Build with -DHKO_NO_FMA to get the product-then-add form (tests bound the difference). */
+#ifdef HKO_NO_FMA
+#define HKO_FMA(a, b, c) ((a) * (b) + (c))
+#else
+#define HKO_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#endif
 static void mm(int ra, int ca, int cb, const double* A, const double* B, double* C)
 {
     for (int i = 0; i < ra; i++)
         for (int j = 0; j < cb; j++) {
             double s = 0.0;
-            for (int k = 0; k < ca; k++) s += A[i * ca + k] * B[k * cb + j];
+            for (int k = 0; k < ca; k++) s = HKO_FMA(A[i * ca + k], B[k * cb + j], s);
             C[i * cb + j] = s;
         }
 }
@@ -32,7 +43,7 @@ static void mtm(int ra, int ca, int cb, const double* A, const double* B, double
     for (int i = 0; i < ca; i++)
         for (int j = 0; j < cb; j++) {
             double s = 0.0;
-            for (int k = 0; k < ra; k++) s += A[k * ca + i] * B[k * cb + j];
+            for (int k = 0; k < ra; k++) s = HKO_FMA(A[k * ca + i], B[k * cb + j], s);
             C[i * cb + j] = s;
         }
 }
@@ -259,7 +270,7 @@ int hko_lq_solve(int N, const double* Ain, const double* Bin, const double* Qin,
     /* :121-126 u0 = -P_0 * initial - alpha_0 */
     for (int a = 0; a < 2; a++) {
         double s = 0.0;
-        for (int c = 0; c < n; c++) s += (-P[a * n + c]) * x0[c];
+        for (int c = 0; c < n; c++) s = HKO_FMA(-P[a * n + c], x0[c], s);
         u0[a] = s - alpha[a];
     }
     return 0;
