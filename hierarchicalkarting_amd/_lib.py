@@ -21,7 +21,7 @@ HK_F_ACCEL, HK_F_BRAKE, HK_F_ACTIVE, HK_F_FORWARD_COLLISION, HK_F_HAS_COLLISION,
 class KartStats(C.Structure):
     _fields_ = [(n, C.c_float) for n in (
         "TopSpeed", "Acceleration", "ReverseSpeed", "ReverseAcceleration", "AccelerationCurve", "Braking", "CoastingDrag",
-        "Grip", "MaxSteer", "MinSteer", "TireWearFactor", "MinGs", "MaxGs", "AddedGravity", "TireWearRate", "reserved")]
+        "Grip", "MaxSteer", "MinSteer", "TireWearFactor", "MinGs", "MaxGs", "AddedGravity", "TireWearRate", "AngularDrag")]
 
 
 class Section(C.Structure):
@@ -64,14 +64,14 @@ class AgentState(C.Structure):
         ("section_index", C.c_int32), ("lane", C.c_int32), ("lane_changes", C.c_int32), ("illegal_lane_changes", C.c_int32),
         ("forward_collisions", C.c_int32), ("last_collision_time", C.c_int32), ("time_steps", C.c_int32),
         ("init_checkpoint_index", C.c_int32),
-        ("flags", C.c_uint32), ("trig_lo", C.c_uint32), ("trig_hi", C.c_uint32), ("reserved0", C.c_uint32),
+        ("flags", C.c_uint32), ("trig_lo", C.c_uint32), ("trig_hi", C.c_uint32), ("final_steer", C.c_float),
         ("plan_lane", C.c_uint8 * HK_MAX_SECTIONS), ("plan_vel", C.c_float * HK_MAX_SECTIONS),
     ]
 
 
 class EnvState(C.Structure):
     _fields_ = [("episode_steps", C.c_int32), ("inactive_mask", C.c_uint32), ("experiment_num", C.c_int32),
-                ("episodes_done", C.c_int32), ("status", C.c_uint32), ("reserved", C.c_int32 * 3)]
+                ("episodes_done", C.c_int32), ("status", C.c_uint32), ("initial_started", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class EpisodeResult(C.Structure):

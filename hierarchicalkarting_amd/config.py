@@ -1,0 +1,121 @@
+"""Build an hk_config (include/hk.h) from the committed track table + the constants of SURVEY App. A.
+
+Pure host-side data plumbing; shared by the product host API (env.py) and, in tests, by the oracle bindings."""
+import ctypes as C
+import json
+import os
+from . import _lib
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+# MLAgent_Sensors.prefab: index -> yaw (positive = right)
+SENSOR_YAW_DEG = [0.0, 30.0, 60.0, 90.0, -30.0, -60.0, -90.0, 45.0, -45.0]
+RAY_DISTANCE = [20.0] * 9
+WALL_HIT_VALIDATION = [0.8, 0.9, 1.0, 0.8, 0.6, 0.9, 1.0, 0.8, 0.6]
+AGENT_HIT_VALIDATION = [1.5] * 9
+
+# effective ArcadeKart.Stats of the Compete scenes (class defaults <- prefabs <- scene overrides)
+KART_STATS = dict(TopSpeed=15.0, Acceleration=7.0, ReverseSpeed=10.0, ReverseAcceleration=3.0, AccelerationCurve=0.5,
+                  Braking=16.0, CoastingDrag=5.0, Grip=0.97, MaxSteer=4.0, MinSteer=1.0, TireWearFactor=0.001,
+                  MinGs=0.5, MaxGs=2.0, AddedGravity=1.0, TireWearRate=10000.0, AngularDrag=0.05)
+
+
+def load_track(name="oval"):
+    with open(os.path.join(_DATA, "%s_track.json" % name)) as f:
+        return json.load(f)
+
+
+def default_wiring(num_agents):
+    """teamAgents / otherAgents as in the reference scenes: 1v1 (CompeteAgents-Oval) or 2v2 duos
+    (CompeteAgents-OvalDuosAll: Agents = [M0, M1, F0, F1], Teams[1] = {M0, M1}, Teams[0] = {F0, F1})."""
+    if num_agents == 1:
+        return [0], [[]], [[]]
+    if num_agents == 2:
+        return [0, 1], [[], []], [[1], [0]]
+    if num_agents == 4:
+        return [1, 1, 0, 0], [[1], [0], [3], [2]], [[2, 3], [2, 3], [0, 1], [0, 1]]
+    team_of = list(range(num_agents))
+    return team_of, [[] for _ in range(num_agents)], [[j for j in range(num_agents) if j != i] for i in range(num_agents)]
+
+
+class BuiltConfig:
+    """hk_config plus the ctypes arrays it points into (kept alive with it)."""
+
+    def __init__(self, cfg, sections, walls, track):
+        self.cfg, self.sections, self.walls, self.track = cfg, sections, walls, track
+
+
+def make_config(num_envs, num_agents=4, track="oval", high_mode=_lib.HK_HIGH_FIXED, low_mode=_lib.HK_LOW_LQR,
+                tree_search_depth=5, jitter_seed=0, jitter_pos=0.5, jitter_yaw=0.05, auto_reset=1, env_id_base=0,
+                device_id=0, wiring=None, env_mode=_lib.HK_MODE_EXPERIMENT, max_episode_steps=None, laps=None,
+                stats=None):
+    tr = load_track(track) if isinstance(track, str) else track
+    secs = tr["sections"]
+    L = len(secs)
+    sec_arr = (_lib.Section * L)()
+    for i, s in enumerate(secs):
+        d = sec_arr[i]
+        d.trig_x, d.trig_z = s["Trigger"]["x"], s["Trigger"]["z"]
+        d.yaw_deg = s["waypoint"]["yaw_deg"]
+        d.marker_y = s["Trigger"]["y"]
+        for l in range(4):
+            d.lane_x[l] = s["Lane%d" % (l + 1)]["x"]
+            d.lane_z[l] = s["Lane%d" % (l + 1)]["z"]
+        d.track_inside_radius = s["trackInsideRadius"]
+        d.track_length = s["trackLength"]
+        d.track_width = s["trackWidth"]
+        d.turn_degrees = s["turnDegrees"]
+        d.left_turn = int(s["leftTurn"])
+        d.optimal_lane = int(s["optimalLane"])
+    segs = []
+    for w in tr["walls"]:
+        pts = w["points"]
+        for a, b in zip(pts[:-1], pts[1:]):
+            segs.append((a[0], a[1], b[0], b[1]))
+    wall_arr = (_lib.WallSeg * max(len(segs), 1))()
+    for i, (x0, z0, x1, z1) in enumerate(segs):
+        wall_arr[i].x0, wall_arr[i].z0, wall_arr[i].x1, wall_arr[i].z1 = x0, z0, x1, z1
+    cfg = _lib.Config()
+    cfg.abi_version = _lib.HK_ABI_VERSION
+    cfg.num_envs, cfg.num_agents, cfg.device_id = num_envs, num_agents, device_id
+    team_of, team, other = wiring if wiring is not None else default_wiring(num_agents)
+    for i in range(num_agents):
+        cfg.team_of[i] = team_of[i]
+        cfg.n_team[i] = len(team[i])
+        for j, t in enumerate(team[i]):
+            cfg.team_agents[i][j] = t
+        cfg.n_other[i] = len(other[i])
+        for j, t in enumerate(other[i]):
+            cfg.other_agents[i][j] = t
+        cfg.high_mode[i] = high_mode[i] if isinstance(high_mode, (list, tuple)) else high_mode
+        cfg.low_mode[i] = low_mode[i] if isinstance(low_mode, (list, tuple)) else low_mode
+        cfg.tree_search_depth[i] = tree_search_depth
+        cfg.velocity_bucket_size[i] = 2
+    st = dict(KART_STATS)
+    if stats:
+        st.update(stats)
+    for k, v in st.items():
+        setattr(cfg.stats, k, v)
+    rules = tr["rules"]
+    cfg.laps = int(laps if laps is not None else rules["laps"])
+    cfg.max_episode_steps = int(max_episode_steps if max_episode_steps is not None else rules["maxEpisodeSteps"])
+    cfg.max_lane_changes = int(rules["MaxLaneChanges"])
+    cfg.section_horizon = int(rules["sectionHorizon"])
+    cfg.disable_on_end = int(rules["disableOnEnd"])
+    cfg.env_mode = env_mode
+    cfg.start_hold_ticks = 75
+    cfg.auto_reset = auto_reset
+    cfg.dt = 0.02
+    cfg.kart_y = 0.28
+    for i in range(_lib.HK_NUM_SENSORS):
+        cfg.sensor_yaw_deg[i] = SENSOR_YAW_DEG[i]
+        cfg.ray_distance[i] = RAY_DISTANCE[i]
+        cfg.wall_hit_validation[i] = WALL_HIT_VALIDATION[i]
+        cfg.agent_hit_validation[i] = AGENT_HIT_VALIDATION[i]
+    cfg.jitter_seed = jitter_seed
+    cfg.jitter_pos, cfg.jitter_yaw = jitter_pos, jitter_yaw
+    cfg.env_id_base = env_id_base
+    cfg.num_sections, cfg.num_walls = L, len(segs)
+    cfg.sections = C.cast(sec_arr, C.POINTER(_lib.Section))
+    cfg.walls = C.cast(wall_arr, C.POINTER(_lib.WallSeg))
+    return BuiltConfig(cfg, sec_arr, wall_arr, tr)

@@ -55,7 +55,7 @@ typedef struct hk_kart_stats {
     float TopSpeed, Acceleration, ReverseSpeed, ReverseAcceleration, AccelerationCurve, Braking, CoastingDrag, Grip;
     float MaxSteer, MinSteer, TireWearFactor, MinGs, MaxGs, AddedGravity;
     float TireWearRate;      /* AK:191 */
-    float reserved;
+    float AngularDrag;       /* Rigidbody.angularDrag 0.05 (BaseKartClassic.prefab:173) */
 } hk_kart_stats;
 
 /* one DiscretePositionTracker (DiscretePositionTracker.cs:20-44) with its Waypoint prefab geometry */
@@ -133,7 +133,7 @@ typedef struct hk_agent_state {
     int32_t init_checkpoint_index;/* KA:49 */
     uint32_t flags;               /* HK_F_* */
     uint32_t trig_lo, trig_hi;    /* which Trigger boxes the kart overlapped after the last tick (OnTriggerEnter edge) */
-    uint32_t reserved0;
+    float final_steer;            /* ArcadeKart.m_FinalStats.Steer as of the last UpdateStats (AK:300) */
     uint8_t plan_lane[HK_MAX_SECTIONS]; /* m_UpcomingLanes keyed by section % L (KA:117); 0 = no entry */
     float plan_vel[HK_MAX_SECTIONS];    /* m_UpcomingVelocities (KA:118) */
 } hk_agent_state;
@@ -144,7 +144,8 @@ typedef struct hk_env_state {
     int32_t experiment_num;    /* REC:63 */
     int32_t episodes_done;     /* finished episodes since hk_create */
     uint32_t status;           /* bit0 NaN/Inf seen in a kart state, bit1 timeout ended last episode */
-    int32_t reserved[3];
+    int32_t initial_started;   /* REC.initialStarted (REC:132): the very first all-inactive tick resets without logging */
+    int32_t reserved[2];
 } hk_env_state;
 
 /* TelemetryViewer / experiment-log quantities of the last finished episode (TelemetryViewer.cs:49-108) */

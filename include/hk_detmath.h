@@ -170,10 +170,41 @@ HK_HD double hk_exp(double x)
     return e * s.d;
 }
 
+/* natural log, x > 0 normal:  x = m * 2^e, m in [sqrt(1/2), sqrt(2));  log x = e ln2 + 2 atanh((m-1)/(m+1)) */
+HK_HD double hk_log(double x)
+{
+    const double LN2_HI = 0.69314718036912382, LN2_LO = 1.9082149292705877e-10;
+    union { unsigned long long u; double d; } b;
+    b.d = x;
+    int e = (int)((b.u >> 52) & 0x7ff) - 1023;
+    b.u = (b.u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL; /* m in [1, 2) */
+    double m = b.d;
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    double s = (m - 1.0) / (m + 1.0);
+    double z = s * s;
+    double p = 0.037037037037037035;          /* 1/27 */
+    p = p * z + 0.040000000000000001;         /* 1/25 */
+    p = p * z + 0.043478260869565216;         /* 1/23 */
+    p = p * z + 0.047619047619047616;         /* 1/21 */
+    p = p * z + 0.052631578947368418;         /* 1/19 */
+    p = p * z + 0.058823529411764705;         /* 1/17 */
+    p = p * z + 0.066666666666666666;         /* 1/15 */
+    p = p * z + 0.076923076923076927;         /* 1/13 */
+    p = p * z + 0.090909090909090912;         /* 1/11 */
+    p = p * z + 0.1111111111111111;           /* 1/9 */
+    p = p * z + 0.14285714285714285;          /* 1/7 */
+    p = p * z + 0.20000000000000001;          /* 1/5 */
+    p = p * z + 0.33333333333333331;          /* 1/3 */
+    double l = 2.0 * (s + (s * z) * p);
+    double fe = (double)e;
+    return fe * LN2_HI + (l + fe * LN2_LO);
+}
+
 /* Mathf.* = libm in double, result rounded to float (Q8) */
 HK_HD float hk_sinf(float x) { return (float)hk_sin((double)x); }
 HK_HD float hk_cosf(float x) { return (float)hk_cos((double)x); }
 HK_HD float hk_atan2f(float y, float x) { return (float)hk_atan2((double)y, (double)x); }
 HK_HD float hk_expf(float x) { return (float)hk_exp((double)x); }
+HK_HD float hk_logf(float x) { return (float)hk_log((double)x); }
 
 #endif /* HK_DETMATH_H */

@@ -46,6 +46,7 @@ double hko_sin(double x);
 double hko_cos(double x);
 double hko_atan2(double y, double x);
 double hko_exp(double x);
+double hko_log(double x);
 
 /* ---- whole-environment oracle (components a4-a11) ---- */
 typedef struct hko_env hko_env;

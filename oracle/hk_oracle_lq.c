@@ -12,6 +12,7 @@ double hko_sin(double x) { return hk_sin(x); }
 double hko_cos(double x) { return hk_cos(x); }
 double hko_atan2(double y, double x) { return hk_atan2(y, x); }
 double hko_exp(double x) { return hk_exp(x); }
+double hko_log(double x) { return hk_log(x); }
 
 /* KartMPC index constants (AI/MPC/KartMPC.cs:15-18) */
 enum { XI = 0, ZI = 1, VI = 2, HI = 3 };

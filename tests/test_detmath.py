@@ -58,6 +58,20 @@ def test_exp():
     assert worst <= 2.0, worst
 
 
+def test_log():
+    L = lib(); rng = np.random.default_rng(5)
+    worst = 0
+    for x in np.concatenate([rng.uniform(0.01, 4, 3000), 10.0 ** rng.uniform(-20, 20, 300), [1.0, 0.8125, 2.0]]):
+        x = float(x)
+        ex = mp.log(mp.mpf(x))
+        got = L.hko_log(x)
+        if abs(ex) > 1e-3:
+            worst = max(worst, float(ulp_err(got, ex)))
+        else:
+            assert abs(mp.mpf(got) - ex) < 1e-18
+    assert worst <= 2.0, worst
+
+
 def test_matches_libm_within_float_rounding():
     """Mathf.* = (float)libm(double): the pinned functions and glibc agree after rounding to float except on a
     vanishing fraction of inputs (the reference's own libm is unknowable; see hk_detmath.h)."""
