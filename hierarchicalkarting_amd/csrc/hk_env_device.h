@@ -1,0 +1,251 @@
+// hk_env_device.h — device-side pieces of the kart environment shared by the env kernels.
+//
+// Reference (paths under Assets/Karting/Scripts/): AK = KartSystems/ArcadeKart.cs, HKA = AI/HierarchicalKartAgent.cs,
+// KA = AI/KartAgent.cs, REC = RacingEnvController.cs, DPT = DiscretePositionTracker.cs.
+// Float arithmetic follows the C# expression order; Mathf.* transcendental calls go through include/hk_detmath.h
+// (double, rounded to float).  The TU is compiled with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/hk.h"
+#include "../../include/hk_detmath.h"
+
+namespace hk {
+
+constexpr int ENV_MAXA = 4;             // agents per env handled by the round-1 kernels
+constexpr float DEG2RAD_F = 0.0174532924f;
+constexpr float TWO_PI_F = 2.0f * HK_PI_F;
+constexpr float CAP_R = 0.45f;          // kart capsule (BaseKartClassic.prefab): radius, core segment in kart-local z
+constexpr float CAP_Z0 = -0.107f - 0.55f;
+constexpr float CAP_Z1 = -0.107f + 0.55f;
+constexpr float SENSOR_LZ = 0.1f;       // MLAgent_Sensors origin (0, 0.5, 0.1)
+constexpr float TRIG_HX = 5.0f, TRIG_HZ = 0.5f;
+
+struct SecDev {                         // one DiscretePositionTracker + Waypoint geometry, with forward precomputed
+    float trig_x, trig_z, fx, fz;
+    float yaw_rad, marker_y, inside_radius;
+    int optimal_lane;
+    float lane_x[4], lane_z[4];
+};
+
+struct EnvParams {
+    int E, A, L, NW;
+    float dt, kart_y;
+    hk_kart_stats st;
+    int laps, max_steps, max_lane_changes, H, disable_on_end, hold, auto_reset;
+    int high_mode[ENV_MAXA], low_mode[ENV_MAXA], depth[ENV_MAXA], vbucket[ENV_MAXA];
+    int n_team[ENV_MAXA], team[ENV_MAXA][ENV_MAXA], n_other[ENV_MAXA], other[ENV_MAXA][ENV_MAXA];
+    float sensor_yaw[HK_NUM_SENSORS], ray_dist[HK_NUM_SENSORS];
+    uint32_t jitter_seed;
+    float jitter_pos, jitter_yaw;
+    int env_id_base, nperm;
+    float init_acc, max_speed, ray_agent_r;
+    int debug;
+    const SecDev* sec;
+    const hk_wall_seg* walls;
+    const int* near_off;   // [L+1] candidate walls for contacts of a kart whose section index is s (mod L)
+    const int* near_idx;
+    const int* far_off;    // [L+1] candidate walls for rays up to 8 m
+    const int* far_idx;
+    const unsigned char* cut;   // [L][5][5]: does the ray lane marker -> next lane marker hit a wall (HKA:832)
+    const int* perms;      // [A!][A]
+};
+
+// ------------------------------------------------------------------ float helpers (Unity Mathf semantics, Q10)
+__device__ __forceinline__ float f_min(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float f_max(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ float f_abs(float a) { return a < 0.0f ? -a : a; }
+__device__ __forceinline__ float f_clamp(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ float f_sign(float v) { return v >= 0.0f ? 1.0f : -1.0f; }
+__device__ __forceinline__ float mag2(float x, float z) { return sqrtf(x * x + 0.0f * 0.0f + z * z); }
+__device__ __forceinline__ float mag3(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }
+__device__ __forceinline__ bool f_finite(float x) { return !(isinf(x) || isnan(x)); }
+
+__device__ __forceinline__ bool is_straight(const EnvParams& P, int section) { return P.sec[section % P.L].inside_radius == 0.0f; }
+
+__device__ __forceinline__ float kart_steer(const EnvParams& P, float acc_ang_v)
+{   // AK:300
+    return f_clamp(P.st.MaxSteer * hk_expf(-acc_ang_v / P.st.TireWearRate), P.st.MinSteer, P.st.MaxSteer);
+}
+__device__ __forceinline__ float tire_wear(const EnvParams& P, float steer)
+{   // AK:304-307
+    return (P.st.MaxSteer - steer) / (P.st.MaxSteer - P.st.MinSteer);
+}
+__device__ __forceinline__ float max_lat_gs(const EnvParams& P, float wear)
+{   // AK:517-520
+    return (1 - wear) * (P.st.MaxGs - P.st.MinGs) + P.st.MinGs;
+}
+__device__ __forceinline__ float turning_radius(float vx, float vz, float fx, float fz, float wy)
+{   // AK:522-529
+    float out = (vx * fx + vz * fz) / wy;
+    if (isinf(out) || isnan(out)) return 1000.0f;
+    return out;
+}
+__device__ inline float max_speed_for_state(const EnvParams& P, float yaw, float vx, float vz, float wy, float final_steer)
+{   // AK:531-547
+    float fx = hk_sinf(yaw), fz = hk_cosf(yaw);
+    float radius = turning_radius(vx, vz, fx, fz, wy);
+    float wear = tire_wear(P, final_steer);
+    if (radius == 0) return P.st.TopSpeed;
+    float allowed = sqrtf(max_lat_gs(P, wear) * 9.81f * f_abs(radius));
+    if (isinf(allowed) || isnan(allowed)) allowed = P.st.TopSpeed;
+    return f_clamp(allowed, 0.0001f, P.st.TopSpeed);
+}
+
+// ------------------------------------------------------------------ analytic Physics.Raycast pieces
+#define HK_RAY_SEG_BODY                                      \
+    float ex = w.x1 - w.x0, ez = w.z1 - w.z0;                \
+    float den = dx * ez - dz * ex;                           \
+    if (den == 0.0f) return -1.0f;                           \
+    float wx = w.x0 - ox, wz = w.z0 - oz;                    \
+    float t = (wx * ez - wz * ex) / den;                     \
+    float s = (wx * dz - wz * dx) / den;                     \
+    if (t >= 0.0f && s >= 0.0f && s <= 1.0f) return t;       \
+    return -1.0f;
+// host twin (hk_create precomputes the static lane->lane "cut" rays with the same arithmetic)
+inline float ray_seg_host(float ox, float oz, float dx, float dz, const hk_wall_seg& w) { HK_RAY_SEG_BODY }
+__device__ __forceinline__ float ray_seg(float ox, float oz, float dx, float dz, const hk_wall_seg& w)
+{
+    float ex = w.x1 - w.x0, ez = w.z1 - w.z0;
+    float den = dx * ez - dz * ex;
+    if (den == 0.0f) return -1.0f;
+    float wx = w.x0 - ox, wz = w.z0 - oz;
+    float t = (wx * ez - wz * ex) / den;
+    float s = (wx * dz - wz * dx) / den;
+    if (t >= 0.0f && s >= 0.0f && s <= 1.0f) return t;
+    return -1.0f;
+}
+
+// ray vs another kart's capsule sliced at the ray height (stadium); origin inside -> no hit (Q10)
+__device__ inline float ray_stadium(float ox, float oz, float dx, float dz, float kpx, float kpz, float kyaw, float r)
+{
+    float fx = hk_sinf(kyaw), fz = hk_cosf(kyaw);
+    float rx = fz, rz = -fx;
+    float relx = ox - kpx, relz = oz - kpz;
+    float lx = relx * rx + relz * rz;
+    float lz = relx * fx + relz * fz;
+    float ldx = dx * rx + dz * rz;
+    float ldz = dx * fx + dz * fz;
+    float cz = f_clamp(lz, CAP_Z0, CAP_Z1);
+    float ddz = lz - cz;
+    if (lx * lx + ddz * ddz <= r * r) return -1.0f;
+    float best = -1.0f;
+    {
+        float tmin = 0.0f, tmax = 3.0e38f;
+        bool ok = true;
+        if (ldx == 0.0f) { if (lx < -r || lx > r) ok = false; }
+        else {
+            float t1 = (-r - lx) / ldx, t2 = (r - lx) / ldx;
+            if (t1 > t2) { float tt = t1; t1 = t2; t2 = tt; }
+            tmin = f_max(tmin, t1); tmax = f_min(tmax, t2);
+        }
+        if (ok) {
+            if (ldz == 0.0f) { if (lz < CAP_Z0 || lz > CAP_Z1) ok = false; }
+            else {
+                float t1 = (CAP_Z0 - lz) / ldz, t2 = (CAP_Z1 - lz) / ldz;
+                if (t1 > t2) { float tt = t1; t1 = t2; t2 = tt; }
+                tmin = f_max(tmin, t1); tmax = f_min(tmax, t2);
+            }
+        }
+        if (ok && tmin <= tmax) best = tmin;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        float czc = c == 0 ? CAP_Z0 : CAP_Z1;
+        float mx = lx, mz = lz - czc;
+        float b = mx * ldx + mz * ldz;
+        float cc = mx * mx + mz * mz - r * r;
+        float disc = b * b - cc;
+        if (disc < 0.0f) continue;
+        float t = -b - sqrtf(disc);
+        if (t >= 0.0f && (best < 0.0f || t < best)) best = t;
+    }
+    return best;
+}
+
+// closest points between 2-D segments (p1->q1, p2->q2); returns squared distance
+__device__ inline float seg_seg_closest(float p1x, float p1z, float q1x, float q1z, float p2x, float p2z, float q2x, float q2z,
+                                        float& c1x, float& c1z, float& c2x, float& c2z)
+{
+    float d1x = q1x - p1x, d1z = q1z - p1z;
+    float d2x = q2x - p2x, d2z = q2z - p2z;
+    float rx = p1x - p2x, rz = p1z - p2z;
+    float a = d1x * d1x + d1z * d1z;
+    float ee = d2x * d2x + d2z * d2z;
+    float f = d2x * rx + d2z * rz;
+    float s, t;
+    const float EPS = 1e-12f;
+    if (a <= EPS && ee <= EPS) { s = 0.0f; t = 0.0f; }
+    else if (a <= EPS) { s = 0.0f; t = f_clamp(f / ee, 0.0f, 1.0f); }
+    else {
+        float c = d1x * rx + d1z * rz;
+        if (ee <= EPS) { t = 0.0f; s = f_clamp(-c / a, 0.0f, 1.0f); }
+        else {
+            float b = d1x * d2x + d1z * d2z;
+            float den = a * ee - b * b;
+            if (den != 0.0f) s = f_clamp((b * f - c * ee) / den, 0.0f, 1.0f); else s = 0.0f;
+            t = (b * s + f) / ee;
+            if (t < 0.0f) { t = 0.0f; s = f_clamp(-c / a, 0.0f, 1.0f); }
+            else if (t > 1.0f) { t = 1.0f; s = f_clamp((b - c) / a, 0.0f, 1.0f); }
+        }
+    }
+    c1x = p1x + d1x * s; c1z = p1z + d1z * s;
+    c2x = p2x + d2x * t; c2z = p2z + d2z * t;
+    float ddx = c1x - c2x, ddz = c1z - c2z;
+    return ddx * ddx + ddz * ddz;
+}
+
+__device__ __forceinline__ void kart_core(float yaw, float px, float pz, float& ax, float& az, float& bx, float& bz)
+{
+    float fx = hk_sinf(yaw), fz = hk_cosf(yaw);
+    ax = px + CAP_Z0 * fx; az = pz + CAP_Z0 * fz;
+    bx = px + CAP_Z1 * fx; bz = pz + CAP_Z1 * fz;
+}
+
+// Philox-4x32-10: synthetic start-grid jitter (not in the reference)
+__device__ inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// HKA.planFixed :145-166
+__device__ inline void plan_fixed(const EnvParams& P, int agent, hk_agent_state* a)
+{
+    const int sec = a->section_index;
+    int hi = sec + P.depth[agent]; if (hi > 1000) hi = 1000;
+    for (int i = sec + 1; i < hi + 1; i++) {
+        int key = i % P.L;
+        if (a->plan_lane[key] == 0) {
+            a->plan_lane[key] = (uint8_t)P.sec[(i - 1) % P.L].optimal_lane;
+            a->plan_vel[key] = P.max_speed;
+        }
+    }
+}
+
+// KA.Deactivate :405-416 (+ SetZeroInputs :480-486): returns the new flags, zeroes the motion fields
+__device__ inline uint32_t deactivate_fields(const EnvParams& P, hk_agent_state* a, uint32_t flags)
+{
+    a->steering = 0.0f;
+    a->vx = 0.0f; a->vz = 0.0f; a->wy = 0.0f;
+    flags &= ~(HK_F_ACCEL | HK_F_BRAKE | HK_F_CAN_MOVE | HK_F_ACTIVE);
+    if (P.disable_on_end) flags &= ~HK_F_ENABLED;
+    return flags;
+}
+
+// DPT.getBoxColliderForLane :99-111 (lane 0 -> Trigger)
+__device__ __forceinline__ void lane_marker(const EnvParams& P, int idx, int lane, float& x, float& z)
+{
+    const SecDev& s = P.sec[idx];
+    if (lane >= 1 && lane <= 4) { x = s.lane_x[lane - 1]; z = s.lane_z[lane - 1]; }
+    else { x = s.trig_x; z = s.trig_z; }
+}
+
+}  // namespace hk

@@ -1,9 +1,16 @@
-// hk_env_kernels.h — batched kart environment on gfx950 (placeholder until the env kernels land).
+// hk_env_kernels.h — host side of the batched kart environment: device tables, candidate wall lists, launches.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
 #include <string>
 #include <vector>
 #include "../../include/hk.h"
+#include "hk_env_device.h"
+#include "hk_env_step.h"
+#include "hk_env_solve.h"
+#include "hk_env_observe.h"
 
 namespace hk {
 
@@ -15,14 +22,262 @@ struct EnvDevice {
     float* obs = nullptr;
     float* act_steer = nullptr;
     int32_t* act_branch = nullptr;
+    int* status = nullptr;
+    int* env_ids = nullptr;
+    int env_ids_cap = 0;
+    // tables
+    SecDev* sec = nullptr;
+    hk_wall_seg* walls = nullptr;
+    int *near_off = nullptr, *near_idx = nullptr, *far_off = nullptr, *far_idx = nullptr;
+    unsigned char* cut = nullptr;
+    int* perms = nullptr;
+    EnvParams P{};
 };
 
-inline int env_create(const hk_config&, std::vector<hk_section>&, std::vector<hk_wall_seg>&, EnvDevice&, hipStream_t, std::string& err)
-{ err = "environment kernels not built yet"; return HK_ERR_UNSUPPORTED; }
-inline void env_destroy(EnvDevice&) {}
-inline int env_reset(EnvDevice&, const hk_config&, const int32_t*, int, int, hipStream_t, std::string& err) { err = "n/a"; return HK_ERR_UNSUPPORTED; }
-inline int env_launch_solve(EnvDevice&, const hk_config&, hipStream_t, std::string& err) { err = "n/a"; return HK_ERR_UNSUPPORTED; }
-inline int env_launch_step(EnvDevice&, const hk_config&, hipStream_t, std::string& err) { err = "n/a"; return HK_ERR_UNSUPPORTED; }
-inline int env_launch_observe(EnvDevice&, const hk_config&, hipStream_t, std::string& err) { err = "n/a"; return HK_ERR_UNSUPPORTED; }
+namespace detail {
+
+inline double seg_seg_dist(double p1x, double p1z, double q1x, double q1z, double p2x, double p2z, double q2x, double q2z)
+{   // host-only, used for culling radii (not on the parity path)
+    auto pt_seg = [](double px, double pz, double ax, double az, double bx, double bz) {
+        double dx = bx - ax, dz = bz - az, l2 = dx * dx + dz * dz;
+        double t = l2 > 0 ? ((px - ax) * dx + (pz - az) * dz) / l2 : 0.0;
+        t = std::min(1.0, std::max(0.0, t));
+        double cx = ax + t * dx - px, cz = az + t * dz - pz;
+        return std::sqrt(cx * cx + cz * cz);
+    };
+    auto cross = [](double ax, double az, double bx, double bz) { return ax * bz - az * bx; };
+    double d1 = cross(q1x - p1x, q1z - p1z, p2x - p1x, p2z - p1z), d2 = cross(q1x - p1x, q1z - p1z, q2x - p1x, q2z - p1z);
+    double d3 = cross(q2x - p2x, q2z - p2z, p1x - p2x, p1z - p2z), d4 = cross(q2x - p2x, q2z - p2z, q1x - p2x, q1z - p2z);
+    if (((d1 > 0) != (d2 > 0)) && ((d3 > 0) != (d4 > 0))) return 0.0;
+    return std::min(std::min(pt_seg(p1x, p1z, p2x, p2z, q2x, q2z), pt_seg(q1x, q1z, p2x, p2z, q2x, q2z)),
+                    std::min(pt_seg(p2x, p2z, p1x, p1z, q1x, q1z), pt_seg(q2x, q2z, p1x, p1z, q1x, q1z)));
+}
+
+template <class T>
+int upload(T** dst, const std::vector<T>& v, std::string& err)
+{
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    hipError_t e = hipMalloc((void**)dst, bytes);
+    if (e != hipSuccess) { err = std::string("hipMalloc: ") + hipGetErrorString(e); return HK_ERR_HIP; }
+    if (!v.empty()) {
+        e = hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { err = std::string("hipMemcpy: ") + hipGetErrorString(e); return HK_ERR_HIP; }
+    }
+    return HK_OK;
+}
+
+}  // namespace detail
+
+inline void env_destroy(EnvDevice& d)
+{
+    void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.status, d.env_ids, d.sec,
+                    d.walls, d.near_off, d.near_idx, d.far_off, d.far_idx, d.cut, d.perms};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    d = EnvDevice{};
+}
+
+inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::vector<hk_wall_seg>& walls, EnvDevice& d,
+                      hipStream_t stream, std::string& err)
+{
+    const int A = cfg.num_agents, L = cfg.num_sections, E = cfg.num_envs;
+    if (E < 1 || A < 1 || L < 1 || L > HK_MAX_SECTIONS || cfg.num_walls < 0 || !cfg.sections || (cfg.num_walls > 0 && !cfg.walls)) {
+        err = "hk_create: bad num_envs / num_agents / track table"; return HK_ERR_INVALID;
+    }
+    if (A > ENV_MAXA) { err = "hk_create: num_agents > 4 not built yet (largest reference scene has 4)"; return HK_ERR_UNSUPPORTED; }
+    if (cfg.env_mode == HK_MODE_TRAINING) { err = "hk_create: Training-mode randomised resets not built yet"; return HK_ERR_UNSUPPORTED; }
+    for (int i = 0; i < A; i++) {
+        if (cfg.n_team[i] < 0 || cfg.n_other[i] < 0 || cfg.n_team[i] + cfg.n_other[i] != A - 1) {
+            err = "hk_create: teamAgents + otherAgents of every agent must list every other agent exactly once"; return HK_ERR_INVALID;
+        }
+        if (cfg.high_mode[i] != HK_HIGH_FIXED) { err = "hk_create: HighMode MCTS not built yet"; return HK_ERR_UNSUPPORTED; }
+        if (cfg.low_mode[i] != HK_LOW_LQR && cfg.low_mode[i] != HK_LOW_RL) { err = "hk_create: LowMode MPC is dead code in the reference"; return HK_ERR_UNSUPPORTED; }
+        if (cfg.tree_search_depth[i] < 0 || cfg.tree_search_depth[i] > L) { err = "hk_create: bad tree_search_depth"; return HK_ERR_INVALID; }
+    }
+    sections.assign(cfg.sections, cfg.sections + L);
+    walls.assign(cfg.walls, cfg.walls + cfg.num_walls);
+    cfg.sections = sections.data();
+    cfg.walls = walls.data();
+    EnvParams& P = d.P;
+    std::memset(&P, 0, sizeof(P));
+    P.E = E; P.A = A; P.L = L; P.NW = cfg.num_walls;
+    P.dt = cfg.dt; P.kart_y = cfg.kart_y; P.st = cfg.stats;
+    P.laps = cfg.laps; P.max_steps = cfg.max_episode_steps; P.max_lane_changes = cfg.max_lane_changes;
+    P.H = cfg.section_horizon; P.disable_on_end = cfg.disable_on_end; P.hold = cfg.start_hold_ticks; P.auto_reset = cfg.auto_reset;
+    for (int i = 0; i < A; i++) {
+        P.high_mode[i] = cfg.high_mode[i]; P.low_mode[i] = cfg.low_mode[i]; P.depth[i] = cfg.tree_search_depth[i];
+        P.vbucket[i] = cfg.velocity_bucket_size[i];
+        P.n_team[i] = cfg.n_team[i]; P.n_other[i] = cfg.n_other[i];
+        for (int j = 0; j < ENV_MAXA; j++) { P.team[i][j] = cfg.team_agents[i][j]; P.other[i][j] = cfg.other_agents[i][j]; }
+    }
+    for (int i = 0; i < HK_NUM_SENSORS; i++) { P.sensor_yaw[i] = cfg.sensor_yaw_deg[i]; P.ray_dist[i] = cfg.ray_distance[i]; }
+    P.jitter_seed = cfg.jitter_seed; P.jitter_pos = cfg.jitter_pos; P.jitter_yaw = cfg.jitter_yaw; P.env_id_base = cfg.env_id_base;
+    P.max_speed = cfg.stats.TopSpeed > cfg.stats.ReverseSpeed ? cfg.stats.TopSpeed : cfg.stats.ReverseSpeed;   // AK:210
+    P.init_acc = -cfg.stats.TireWearRate * hk_logf(1 - ((cfg.stats.MaxSteer - cfg.stats.MinSteer) * 0.25f / cfg.stats.MaxSteer));  // REC:588
+    {
+        const float dyc = 0.5f - 0.582f;   // sensor height - capsule centre height (kart-local)
+        P.ray_agent_r = sqrtf(CAP_R * CAP_R - dyc * dyc);
+    }
+    P.debug = 1;
+    // sections with forward precomputed (same float expressions as everywhere else)
+    std::vector<SecDev> sd(L);
+    for (int i = 0; i < L; i++) {
+        const hk_section& s = sections[i];
+        SecDev& o = sd[i];
+        o.trig_x = s.trig_x; o.trig_z = s.trig_z;
+        o.yaw_rad = s.yaw_deg * DEG2RAD_F;
+        o.fx = hk_sinf(o.yaw_rad); o.fz = hk_cosf(o.yaw_rad);
+        o.marker_y = s.marker_y; o.inside_radius = s.track_inside_radius; o.optimal_lane = s.optimal_lane;
+        for (int l = 0; l < 4; l++) { o.lane_x[l] = s.lane_x[l]; o.lane_z[l] = s.lane_z[l]; }
+    }
+    // candidate wall lists per section index: walls within `radius` of the trigger-centre polyline T[s-1..s+2]
+    auto build_list = [&](double radius, std::vector<int>& off, std::vector<int>& idx) {
+        off.assign(L + 1, 0); idx.clear();
+        for (int s = 0; s < L; s++) {
+            off[s] = (int)idx.size();
+            for (int w = 0; w < (int)walls.size(); w++) {
+                const hk_wall_seg& ws = walls[w];
+                bool in = false;
+                for (int q = -1; q <= 1 && !in; q++) {
+                    const hk_section& a = sections[((s + q) % L + L) % L];
+                    const hk_section& b = sections[((s + q + 1) % L + L) % L];
+                    if (detail::seg_seg_dist(ws.x0, ws.z0, ws.x1, ws.z1, a.trig_x, a.trig_z, b.trig_x, b.trig_z) <= radius) in = true;
+                }
+                if (in) idx.push_back(w);
+            }
+        }
+        off[L] = (int)idx.size();
+    };
+    std::vector<int> noff, nidx, foff, fidx;
+    build_list(8.0, noff, nidx);     // contacts: lateral 5.7 (incl. chord sagitta) + capsule reach 1.1 + margin
+    build_list(16.0, foff, fidx);    // rays up to 8 m from the sensor origin
+    // cut table: Physics.Raycast(lane marker -> next lane marker) vs every wall (HKA:832), static geometry
+    std::vector<unsigned char> cut((size_t)L * 25, 0);
+    for (int s = 0; s < L; s++)
+        for (int la = 0; la < 5; la++)
+            for (int lb = 0; lb < 5; lb++) {
+                const hk_section& a = sections[s];
+                const hk_section& b = sections[(s + 1) % L];
+                float lx = la ? a.lane_x[la - 1] : a.trig_x, lz = la ? a.lane_z[la - 1] : a.trig_z;
+                float nx = lb ? b.lane_x[lb - 1] : b.trig_x, nz = lb ? b.lane_z[lb - 1] : b.trig_z;
+                float cdx = nx - lx, cdz = nz - lz;
+                float clen = sqrtf((lx - nx) * (lx - nx) + 0.0f * 0.0f + (lz - nz) * (lz - nz));
+                bool hit = false;
+                if (clen > 0.0f) {
+                    float dx = cdx / clen, dz = cdz / clen;
+                    for (size_t w = 0; w < walls.size() && !hit; w++) {
+                        float t = ray_seg_host(lx, lz, dx, dz, walls[w]);
+                        if (t >= 0.0f && t <= clen) hit = true;
+                    }
+                }
+                cut[((size_t)s * 5 + la) * 5 + lb] = hit ? 1 : 0;
+            }
+    // lexicographic permutations (REC:137-145,166)
+    std::vector<int> perm(A), perms;
+    for (int i = 0; i < A; i++) perm[i] = i;
+    do { perms.insert(perms.end(), perm.begin(), perm.end()); } while (std::next_permutation(perm.begin(), perm.end()));
+    P.nperm = (int)(perms.size() / A);
+    int rc;
+    if ((rc = detail::upload(&d.sec, sd, err))) return rc;
+    if ((rc = detail::upload(&d.walls, walls, err))) return rc;
+    if ((rc = detail::upload(&d.near_off, noff, err))) return rc;
+    if ((rc = detail::upload(&d.near_idx, nidx, err))) return rc;
+    if ((rc = detail::upload(&d.far_off, foff, err))) return rc;
+    if ((rc = detail::upload(&d.far_idx, fidx, err))) return rc;
+    if ((rc = detail::upload(&d.cut, cut, err))) return rc;
+    if ((rc = detail::upload(&d.perms, perms, err))) return rc;
+    P.sec = d.sec; P.walls = d.walls; P.near_off = d.near_off; P.near_idx = d.near_idx; P.far_off = d.far_off; P.far_idx = d.far_idx;
+    P.cut = d.cut; P.perms = d.perms;
+    const size_t na = (size_t)E * A;
+    const int obs_dim = HK_NUM_SENSORS + cfg.section_horizon * 5 + 8 + 12 * (A - 1);
+    hipError_t e;
+#define HK_ALLOC(ptr, bytes)                                                                              \
+    if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) { err = std::string("hipMalloc: ") + hipGetErrorString(e); return HK_ERR_HIP; } \
+    if ((e = hipMemsetAsync((ptr), 0, (bytes), stream)) != hipSuccess) { err = std::string("hipMemset: ") + hipGetErrorString(e); return HK_ERR_HIP; }
+    HK_ALLOC(d.agents, na * sizeof(hk_agent_state));
+    HK_ALLOC(d.envs, (size_t)E * sizeof(hk_env_state));
+    HK_ALLOC(d.results, na * sizeof(hk_episode_result));
+    HK_ALLOC(d.lq_debug, na * sizeof(hk_lq_debug));
+    HK_ALLOC(d.obs, na * obs_dim * sizeof(float));
+    HK_ALLOC(d.act_steer, na * sizeof(float));
+    HK_ALLOC(d.act_branch, na * sizeof(int32_t));
+    HK_ALLOC(d.status, 4 * sizeof(int));
+#undef HK_ALLOC
+    // REC.Start :148-168: every agent starts inactive; results carry episode = -1; RL branch defaults to "coast"
+    {
+        std::vector<hk_env_state> es(E);
+        std::memset(es.data(), 0, sizeof(hk_env_state) * E);
+        for (int i = 0; i < E; i++) es[i].inactive_mask = (1u << A) - 1u;
+        std::vector<hk_episode_result> rs(na);
+        std::memset(rs.data(), 0, sizeof(hk_episode_result) * na);
+        for (size_t i = 0; i < na; i++) rs[i].episode = -1;
+        std::vector<int32_t> br(na, 1);
+        if ((e = hipMemcpyAsync(d.envs, es.data(), sizeof(hk_env_state) * E, hipMemcpyHostToDevice, stream)) != hipSuccess ||
+            (e = hipMemcpyAsync(d.results, rs.data(), sizeof(hk_episode_result) * na, hipMemcpyHostToDevice, stream)) != hipSuccess ||
+            (e = hipMemcpyAsync(d.act_branch, br.data(), sizeof(int32_t) * na, hipMemcpyHostToDevice, stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(stream)) != hipSuccess) {
+            err = std::string("hipMemcpy: ") + hipGetErrorString(e); return HK_ERR_HIP;
+        }
+    }
+    return HK_OK;
+}
+
+inline int launch_check(std::string& err, const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err = std::string(what) + ": " + hipGetErrorString(e); return HK_ERR_HIP; }
+    return HK_OK;
+}
+
+inline int env_reset(EnvDevice& d, const hk_config& cfg, const int32_t* env_ids, int n, int experiment_num, hipStream_t stream,
+                     std::string& err)
+{
+    const int E = cfg.num_envs;
+    int cnt = env_ids ? n : E;
+    if (cnt < 0) { err = "hk_reset: n < 0"; return HK_ERR_INVALID; }
+    if (cnt == 0) return HK_OK;
+    const int* dids = nullptr;
+    if (env_ids) {
+        for (int i = 0; i < n; i++) if (env_ids[i] < 0 || env_ids[i] >= E) { err = "hk_reset: env id out of range"; return HK_ERR_INVALID; }
+        if (n > d.env_ids_cap) {
+            if (d.env_ids) (void)hipFree(d.env_ids);
+            d.env_ids = nullptr; d.env_ids_cap = 0;
+            if (hipMalloc((void**)&d.env_ids, sizeof(int) * n) != hipSuccess) { err = "hipMalloc env ids"; return HK_ERR_HIP; }
+            d.env_ids_cap = n;
+        }
+        if (hipMemcpyAsync(d.env_ids, env_ids, sizeof(int) * n, hipMemcpyHostToDevice, stream) != hipSuccess) { err = "hipMemcpy env ids"; return HK_ERR_HIP; }
+        dids = d.env_ids;
+    }
+    const int threads = cnt * 4;
+    hipLaunchKernelGGL(env_reset_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.envs, dids, cnt, experiment_num);
+    int rc = launch_check(err, "env_reset_kernel");
+    if (rc) return rc;
+    if (hipStreamSynchronize(stream) != hipSuccess) { err = "hk_reset: sync failed"; return HK_ERR_HIP; }
+    return HK_OK;
+}
+
+// REC.FixedUpdate + KA.FixedUpdate, then SolveLQR for every ego (the dominant kernel)
+inline int env_launch_solve(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
+    const int threads = cfg.num_envs * 4;
+    hipLaunchKernelGGL(env_begin_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.envs, d.results);
+    int rc = launch_check(err, "env_begin_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(env_solve_kernel, dim3(cfg.num_envs), dim3(64), 0, stream, d.P, d.agents, d.envs, d.lq_debug, d.status);
+    return launch_check(err, "env_solve_kernel");
+}
+
+inline int env_launch_step(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
+    const int threads = cfg.num_envs * 4;
+    hipLaunchKernelGGL(env_move_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.envs, d.act_steer, d.act_branch);
+    return launch_check(err, "env_move_kernel");
+}
+
+inline int env_launch_observe(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
+    const int threads = cfg.num_envs * cfg.num_agents;
+    hipLaunchKernelGGL(env_observe_kernel, dim3((threads + 127) / 128), dim3(128), 0, stream, d.P, d.agents, d.obs);
+    return launch_check(err, "env_observe_kernel");
+}
 
 }  // namespace hk

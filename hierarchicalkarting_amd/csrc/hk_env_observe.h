@@ -1,0 +1,110 @@
+// hk_env_observe.h — HierarchicalKartAgent.CollectObservations (HKA:485-604): one thread per (env, agent).
+// Layout = the order the reference calls sensor.AddObservation: 8 own, 12 per teammate, 12 per opponent,
+// 5 per upcoming section (sectionHorizon), 9 ray distances.  Rays here are 20 m long, so they scan every wall.
+#pragma once
+#include "hk_env_device.h"
+
+namespace hk {
+
+__device__ inline float local_speed(const EnvParams& P, const hk_agent_state* a)
+{   // AK:325-342
+    if (!(a->flags & HK_F_CAN_MOVE)) return 0.0f;
+    float fx = hk_sinf(a->yaw), fz = hk_cosf(a->yaw);
+    float dot = fx * a->vx + fz * a->vz;
+    if (f_abs(dot) > 0.1f) {
+        float speed = mag3(a->vx, 0.0f, a->vz);
+        return dot < 0 ? -(speed / P.st.ReverseSpeed) : (speed / P.st.TopSpeed);
+    }
+    return 0.0f;
+}
+
+__device__ inline void inv_transform_point(const hk_agent_state* a, float wx, float wy, float wz, float ky, float out[3])
+{   // Transform.InverseTransformPoint of a yaw-only transform
+    float fx = hk_sinf(a->yaw), fz = hk_cosf(a->yaw);
+    float rx = wx - a->px, rz = wz - a->pz;
+    out[0] = rx * fz + rz * (-fx);
+    out[1] = wy - ky;
+    out[2] = rx * fx + rz * fz;
+}
+
+__global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_agent_state* agents, float* obs)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= P.E * P.A) return;
+    const int env = gid / P.A, i = gid % P.A;
+    const int A = P.A, L = P.L, H = P.H;
+    const int dim = HK_NUM_SENSORS + H * 5 + 8 + 12 * (A - 1);
+    const int goal = P.laps * L + 1;
+    const hk_agent_state* ags = agents + (size_t)env * A;
+    const hk_agent_state* a = &ags[i];
+    float* o = obs + (size_t)gid * dim;
+    int p = 0;
+    o[p++] = local_speed(P, a);
+    o[p++] = (a->flags & HK_F_ACCEL) ? 1.0f : 0.0f;
+    o[p++] = (float)a->lane;
+    o[p++] = a->lane_changes * 1.0f / P.max_lane_changes;
+    o[p++] = (a->flags & HK_F_ACTIVE) ? 1.0f : 0.0f;
+    o[p++] = a->section_index * 1.0f / goal;
+    o[p++] = is_straight(P, a->section_index) ? 1.0f : 0.0f;
+    o[p++] = tire_wear(P, a->final_steer);
+    for (int pass = 0; pass < 2; pass++) {
+        const int cnt = pass == 0 ? P.n_team[i] : P.n_other[i];
+        for (int j = 0; j < cnt; j++) {
+            const hk_agent_state* b = &ags[pass == 0 ? P.team[i][j] : P.other[i][j]];
+            o[p++] = local_speed(P, b);
+            o[p++] = (b->flags & HK_F_ACCEL) ? 1.0f : 0.0f;
+            o[p++] = (float)b->lane;
+            o[p++] = b->lane_changes * 1.0f / P.max_lane_changes;
+            o[p++] = (b->flags & HK_F_ACTIVE) ? 1.0f : 0.0f;
+            o[p++] = is_straight(P, b->section_index) ? 1.0f : 0.0f;
+            o[p++] = tire_wear(P, b->final_steer);
+            o[p++] = b->section_index * 1.0f / goal;
+            o[p++] = mag3(b->px - a->px, 0.0f, b->pz - a->pz);
+            float lp[3];
+            inv_transform_point(a, b->px, P.kart_y, b->pz, P.kart_y, lp);
+            o[p++] = lp[0]; o[p++] = lp[1]; o[p++] = lp[2];
+        }
+    }
+    for (int s = a->section_index + 1; s < a->section_index + 1 + H; s++) {
+        const int next = s % L;
+        float lp[3];
+        const int pl = a->plan_lane[next];
+        if (pl != 0) {
+            float mx, mz;
+            lane_marker(P, next, pl, mx, mz);
+            inv_transform_point(a, mx, P.sec[next].marker_y, mz, P.kart_y, lp);
+            o[p++] = lp[0]; o[p++] = lp[1]; o[p++] = lp[2];
+            o[p++] = a->plan_vel[next] / P.max_speed;
+        } else {
+            inv_transform_point(a, P.sec[next].trig_x, P.sec[next].marker_y, P.sec[next].trig_z, P.kart_y, lp);
+            o[p++] = lp[0]; o[p++] = lp[1]; o[p++] = lp[2];
+            o[p++] = 1.0f;
+        }
+        o[p++] = is_straight(P, next) ? 1.0f : 0.0f;
+    }
+    const float fx = hk_sinf(a->yaw), fz = hk_cosf(a->yaw);
+    const float ox = a->px + SENSOR_LZ * fx, oz = a->pz + SENSOR_LZ * fz;
+    for (int si = 0; si < HK_NUM_SENSORS; si++) {
+        const float ang = a->yaw + P.sensor_yaw[si] * DEG2RAD_F;
+        const float dx = hk_sinf(ang), dz = hk_cosf(ang);
+        const float maxd = P.ray_dist[si];
+        float ht = -1.0f;
+        for (int w = 0; w < P.NW; w++) {
+            float t = ray_seg(ox, oz, dx, dz, P.walls[w]);
+            if (t >= 0.0f && t <= maxd && (ht < 0.0f || t < ht)) ht = t;
+        }
+        float ha = -1.0f;
+        if (a->flags & HK_F_ENABLED) {
+            for (int j = 0; j < A; j++) {
+                if (j == i || !(ags[j].flags & HK_F_ENABLED)) continue;
+                float t = ray_stadium(ox, oz, dx, dz, ags[j].px, ags[j].pz, ags[j].yaw, P.ray_agent_r);
+                if (t >= 0.0f && t <= maxd && (ha < 0.0f || t < ha)) ha = t;
+            }
+        }
+        if (ht >= 0.0f && (ha < 0.0f || ht < ha)) o[p++] = ht;
+        else if (ha >= 0.0f) o[p++] = ha;
+        else o[p++] = maxd;
+    }
+}
+
+}  // namespace hk

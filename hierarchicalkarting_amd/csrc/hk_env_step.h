@@ -1,0 +1,469 @@
+// hk_env_step.h — the non-LQ part of a tick: episode controller, sensing, ArcadeKart model, engine restatement.
+//
+// Thread mapping: 4 consecutive lanes (a "quad") own one race instance, lane q = agent q; a 256-thread block holds
+// 64 envs.  Kart-to-kart data moves with quad-wide shuffles; per-env words (episode_steps, inactive set) are
+// recomputed identically by the 4 lanes and written by lane 0.  Wall queries walk the per-section candidate lists
+// (near_*: contacts) that hk_create builds; they are supersets of what can be reached, so results equal a brute
+// force scan over every wall (what the CPU oracle does).
+#pragma once
+#include "hk_env_device.h"
+
+namespace hk {
+
+__device__ __forceinline__ float quad_get(float v, int q) { return __shfl(v, (threadIdx.x & ~3) | q, 64); }
+__device__ __forceinline__ uint32_t quad_get(uint32_t v, int q) { return (uint32_t)__shfl((int)v, (threadIdx.x & ~3) | q, 64); }
+__device__ __forceinline__ int quad_get(int v, int q) { return __shfl(v, (threadIdx.x & ~3) | q, 64); }
+
+// REC.ResetGame :499-719 for one agent (Experiment / Race grid); see oracle reset_env for the line map
+__device__ inline void reset_agent(const EnvParams& P, int env, int i, int experiment_num, hk_agent_state* a)
+{
+    const int expLane[4] = {2, 3, 2, 3};
+    const int expSection[4] = {0, 0, 1, 1};
+    const int pi = ((experiment_num % P.nperm) + P.nperm) % P.nperm;
+    const int* ord = P.perms + (size_t)pi * P.A;
+    int j = 0;
+    for (int q = 0; q < P.A; q++) if (ord[q] == i) j = q;
+    // zero the whole record (plans, counters, trigger overlap set)
+    uint32_t* w = reinterpret_cast<uint32_t*>(a);
+    for (int k = 0; k < (int)(sizeof(hk_agent_state) / 4); k++) w[k] = 0u;
+    const int sec = expSection[j & 3];
+    const int lane = expLane[j & 3];
+    a->section_index = sec;
+    a->init_checkpoint_index = sec;
+    a->acc_ang_v = P.init_acc;
+    a->lane = lane;
+    const SecDev& s = P.sec[sec % P.L];
+    float yaw = s.yaw_rad;
+    float px = s.lane_x[lane - 1] + s.fx * 3.0f;
+    float pz = s.lane_z[lane - 1] + s.fz * 3.0f;
+    if (P.jitter_seed != 0u) {
+        uint32_t r[4];
+        philox4x32((uint32_t)experiment_num, (uint32_t)i, 0u, 0u, P.jitter_seed + (uint32_t)(P.env_id_base + env), 0u, r);
+        px += (2.0f * u01(r[0]) - 1.0f) * P.jitter_pos;
+        pz += (2.0f * u01(r[1]) - 1.0f) * P.jitter_pos;
+        yaw += (2.0f * u01(r[2]) - 1.0f) * P.jitter_yaw;
+        if (yaw < 0.0f) yaw += TWO_PI_F;
+        if (yaw >= TWO_PI_F) yaw -= TWO_PI_F;
+    }
+    a->px = px; a->pz = pz; a->yaw = yaw;
+    a->final_steer = kart_steer(P, a->acc_ang_v);
+    if (P.high_mode[i] == HK_HIGH_FIXED) plan_fixed(P, i, a);
+    a->flags = HK_F_ACTIVE | HK_F_ENABLED;
+}
+
+__device__ inline void snapshot_result(const hk_agent_state* a, hk_episode_result* r, int episode)
+{
+    r->time_steps = a->time_steps;
+    r->section_index = a->section_index;
+    r->illegal_lane_changes = a->illegal_lane_changes;
+    r->forward_collisions = a->forward_collisions;
+    r->avg_lane_diff = a->avg_lane_diff;
+    r->avg_vel_diff = a->avg_vel_diff;
+    r->reward = a->cum_reward;
+    r->episode = episode;
+}
+
+// explicit hk_reset
+__global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
+                                                        const int* env_ids, int n, int experiment_num)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = gid >> 2, i = gid & 3;
+    if (slot >= n || i >= P.A) return;
+    const int env = env_ids ? env_ids[slot] : slot;
+    const int ex = experiment_num >= 0 ? experiment_num : (P.env_id_base + env) % P.nperm;
+    reset_agent(P, env, i, ex, &agents[(size_t)env * P.A + i]);
+    if (i == 0) {
+        hk_env_state* es = &envs[env];
+        es->experiment_num = ex;
+        es->status = 0;
+        es->initial_started = 1;
+        es->episode_steps = 0;
+        es->inactive_mask = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K_A: REC.FixedUpdate (:239-311), StartRaceAfterDelay (:721-744), KA.FixedUpdate forward-collision rays (:135-167)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void env_begin_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
+                                                        hk_episode_result* results)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int env = gid >> 2, i = gid & 3;
+    const bool env_ok = env < P.E;
+    const bool me = env_ok && i < P.A;
+    hk_env_state es;
+    if (env_ok) es = envs[env]; else { es.episode_steps = 0; es.inactive_mask = 0; es.experiment_num = 0; es.episodes_done = 0; es.status = 0; es.initial_started = 0; }
+    hk_agent_state* a = me ? &agents[(size_t)env * P.A + i] : nullptr;
+    const uint32_t all_mask = (1u << P.A) - 1u;
+    bool skip = !env_ok;       // envs that stay parked (auto_reset off and finished)
+    bool finish = false, timeout = false;
+    if (env_ok) {
+        if ((es.inactive_mask & all_mask) == all_mask) {
+            if (!P.auto_reset) {
+                if (!(es.status & 4u)) {
+                    if (me) snapshot_result(a, &results[(size_t)env * P.A + i], es.episodes_done);
+                    es.episodes_done += 1; es.status |= 4u;
+                    if (i == 0) envs[env] = es;
+                }
+                skip = true;
+            } else finish = true;
+        } else {
+            es.episode_steps += 1;
+            if (es.episode_steps >= P.max_steps) {
+                if (!P.auto_reset) {
+                    if (me) {
+                        uint32_t fl = a->flags;
+                        if (fl & HK_F_ACTIVE) a->flags = deactivate_fields(P, a, fl);
+                        snapshot_result(a, &results[(size_t)env * P.A + i], es.episodes_done);
+                    }
+                    es.inactive_mask = all_mask;
+                    es.episodes_done += 1; es.status |= 2u | 4u;
+                    if (i == 0) envs[env] = es;
+                    skip = true;
+                } else { finish = true; timeout = true; }
+            }
+        }
+    }
+    if (finish) {
+        if (me) {
+            uint32_t fl = a->flags;
+            if (fl & HK_F_ACTIVE) a->flags = deactivate_fields(P, a, fl);
+        }
+        if (es.initial_started || timeout) {
+            if (me) snapshot_result(a, &results[(size_t)env * P.A + i], es.episodes_done);
+            es.episodes_done += 1;
+            es.status = (es.status & ~2u) | (timeout ? 2u : 0u);
+            es.experiment_num += 1;
+        }
+        if (me) reset_agent(P, env, i, es.experiment_num, a);
+        es.episode_steps = 0;
+        es.inactive_mask = 0;
+        es.initial_started = 1;
+    }
+    // own pose / flags (after a possible reset)
+    float px = 0, pz = 0, yaw = 0;
+    uint32_t fl = 0;
+    if (me && !skip) { px = a->px; pz = a->pz; yaw = a->yaw; fl = a->flags; }
+    // StartRaceAfterDelay
+    if (me && !skip && es.episode_steps >= P.hold && (fl & HK_F_ACTIVE) && !(fl & HK_F_CAN_MOVE)) fl |= HK_F_CAN_MOVE;
+    // KA.FixedUpdate: three rays against the other karts' capsules
+    bool hitAgent = false;
+    {
+        const float ox = px + SENSOR_LZ * hk_sinf(yaw), oz = pz + SENSOR_LZ * hk_cosf(yaw);
+        const int csens[3] = {0, 1, 5};
+        const float clen[3] = {0.8f, 0.9f, 0.9f};
+        float ddx[3], ddz[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            float ang = yaw + P.sensor_yaw[csens[q]] * DEG2RAD_F;
+            ddx[q] = hk_sinf(ang); ddz[q] = hk_cosf(ang);
+        }
+        for (int j = 0; j < ENV_MAXA; j++) {
+            const float jpx = quad_get(px, j), jpz = quad_get(pz, j), jyaw = quad_get(yaw, j);
+            const uint32_t jfl = quad_get(fl, j);
+            if (j >= P.A || j == i || !(jfl & HK_F_ENABLED)) continue;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                float t = ray_stadium(ox, oz, ddx[q], ddz[q], jpx, jpz, jyaw, P.ray_agent_r);
+                if (t >= 0.0f && t <= clen[q]) hitAgent = true;
+            }
+        }
+    }
+    if (me && !skip) {
+        if (fl & HK_F_ENABLED) {
+            const bool fc = (fl & HK_F_FORWARD_COLLISION) != 0;
+            const int lct = a->last_collision_time;
+            if (hitAgent && !fc && (lct == 0 || es.episode_steps - lct > 75)) {
+                fl |= HK_F_FORWARD_COLLISION; a->forward_collisions += 1; a->last_collision_time = es.episode_steps;
+            } else if (hitAgent) {
+                fl |= HK_F_FORWARD_COLLISION; a->last_collision_time = es.episode_steps;
+            } else {
+                fl &= ~HK_F_FORWARD_COLLISION;
+            }
+        }
+        a->flags = fl;
+        if (i == 0) envs[env] = es;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K_C: RL actions, planFixed (HKA:331-355), ArcadeKart.FixedUpdate (AK:243-503), engine restatement, triggers
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rot_y(float ang_rad, float& x, float& z)
+{
+    float c = hk_cosf(ang_rad), s = hk_sinf(ang_rad);
+    float nx = x * c + z * s;
+    float nz = z * c - x * s;
+    x = nx; z = nz;
+}
+
+__device__ inline int calculate_lane(const EnvParams& P, const SecDev& s, float px, float pz)
+{   // DPT.CalculateLane :116-148
+    float dy = P.kart_y - s.marker_y;
+    float d[4];
+#pragma unroll
+    for (int l = 0; l < 4; l++) d[l] = mag3(px - s.lane_x[l], dy, pz - s.lane_z[l]);
+    float mn = f_min(f_min(d[0], d[1]), f_min(d[2], d[3]));
+#pragma unroll
+    for (int l = 0; l < 4; l++) if (mn == d[l]) return l + 1;
+    return -1;
+}
+
+__global__ __launch_bounds__(256) void env_move_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
+                                                       const float* act_steer, const int* act_branch)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int env = gid >> 2, i = gid & 3;
+    const bool env_ok = env < P.E;
+    const bool me = env_ok && i < P.A;
+    int episode_steps = 0;
+    uint32_t inactive_mask = 0, status = 0;
+    if (env_ok) { episode_steps = envs[env].episode_steps; inactive_mask = envs[env].inactive_mask; status = envs[env].status; }
+    const uint32_t all_mask = (1u << P.A) - 1u;
+    // parked env (auto_reset off, finished): nothing moves
+    const bool parked = env_ok && !P.auto_reset && (inactive_mask & all_mask) == all_mask && (status & 4u);
+    hk_agent_state* a = me ? &agents[(size_t)env * P.A + i] : nullptr;
+    uint32_t fl = 0;
+    float px = 0, pz = 0, yaw = 0, vx = 0, vz = 0, wy = 0;
+    bool live = me && !parked;
+    if (live) { fl = a->flags; px = a->px; pz = a->pz; yaw = a->yaw; vx = a->vx; vz = a->vz; wy = a->wy; }
+    const bool enabled = live && (fl & HK_F_ENABLED);
+    const bool inactive_before = (inactive_mask >> i) & 1u;
+    if (enabled) {
+        // KA.OnActionReceived / InterpretDiscreteActions (HKA:1371-1379) for RL agents
+        if (P.low_mode[i] == HK_LOW_RL && (fl & HK_F_ACTIVE)) {
+            a->steering = act_steer[(size_t)env * P.A + i];
+            int br = act_branch[(size_t)env * P.A + i];
+            if (br > 1) fl |= HK_F_ACCEL; else fl &= ~HK_F_ACCEL;
+            if (br < 1) fl |= HK_F_BRAKE; else fl &= ~HK_F_BRAKE;
+        }
+        if (episode_steps % 100 == 0 && episode_steps < P.max_steps && episode_steps > 0 && !inactive_before)
+            if (P.high_mode[i] == HK_HIGH_FIXED) plan_fixed(P, i, a);
+        // ---- ArcadeKart.FixedUpdate
+        bool accelerate = false, brake = false; float turnInput = 0.0f;
+        if (fl & HK_F_ACTIVE) { accelerate = (fl & HK_F_ACCEL) != 0; brake = (fl & HK_F_BRAKE) != 0; turnInput = a->steering; }
+        float acc_ang_v = a->acc_ang_v;
+        const float final_steer = kart_steer(P, acc_ang_v);               // UpdateStats AK:295-302
+        a->final_steer = final_steer;
+        if (fl & HK_F_CAN_MOVE) {                                         // MoveVehicle AK:363-503
+            const float dt = P.dt;
+            const float fx = hk_sinf(yaw), fz = hk_cosf(yaw);
+            float accelInput = (accelerate ? 1.0f : 0.0f) - (brake ? 1.0f : 0.0f);
+            float localVelZ = vx * fx + vz * fz;
+            bool accelDirectionIsFwd = accelInput >= 0;
+            bool localVelDirectionIsFwd = localVelZ >= 0;
+            float maxSpeed = localVelDirectionIsFwd ? P.st.TopSpeed : P.st.ReverseSpeed;
+            float wear = tire_wear(P, final_steer);
+            float maxAllowedSpeed = sqrtf(max_lat_gs(P, wear) * 9.81f * f_abs(turning_radius(vx, vz, fx, fz, wy)));
+            if (!(isinf(maxAllowedSpeed) || isnan(maxAllowedSpeed)))
+                maxSpeed = f_clamp(maxSpeed, 0.001f, f_max(maxAllowedSpeed, 0.001f));
+            float accelPower = accelDirectionIsFwd ? P.st.Acceleration : P.st.ReverseAcceleration;
+            float currentSpeed = mag3(vx, 0.0f, vz);
+            float accelRampT = currentSpeed / maxSpeed;
+            float multipliedAccelerationCurve = P.st.AccelerationCurve * 5;
+            float tt = accelRampT * accelRampT;
+            tt = f_clamp(tt, 0.0f, 1.0f);
+            float accelRamp = multipliedAccelerationCurve + (1 - multipliedAccelerationCurve) * tt;
+            bool isBraking = (localVelDirectionIsFwd && brake) || (!localVelDirectionIsFwd && accelerate);
+            float finalAccelPower = isBraking ? P.st.Braking : accelPower;
+            float finalAcceleration = finalAccelPower * accelRamp;
+            float turningPower = turnInput * final_steer * (f_abs(currentSpeed) > 0.5f ? 1.0f : 0.0f);
+            float fwx = fx, fwz = fz;
+            rot_y(turningPower * DEG2RAD_F, fwx, fwz);
+            float accx = fwx * accelInput * finalAcceleration * 1.0f;
+            float accz = fwz * accelInput * finalAcceleration * 1.0f;
+            bool wasOverMaxSpeed = currentSpeed >= maxSpeed;
+            if (wasOverMaxSpeed && !isBraking) { accx *= 0.0f; accz *= 0.0f; }
+            float nvx = vx + accx * dt, nvz = vz + accz * dt;
+            if (wasOverMaxSpeed) {
+                float sq = nvx * nvx + nvz * nvz;
+                if (sq > maxSpeed * maxSpeed) {
+                    float mg = sqrtf(sq);
+                    nvx = (nvx / mg) * maxSpeed; nvz = (nvz / mg) * maxSpeed;
+                }
+            }
+            if (f_abs(accelInput) < 0.01f) {
+                float maxDelta = dt * P.st.CoastingDrag;
+                float tx = 0.0f - nvx, tz = 0.0f - nvz;
+                float sq = tx * tx + tz * tz;
+                if (sq == 0.0f || sq <= maxDelta * maxDelta) { nvx = 0.0f; nvz = 0.0f; }
+                else { float d = sqrtf(sq); nvx = nvx + tx / d * maxDelta; nvz = nvz + tz / d * maxDelta; }
+            }
+            vx = nvx; vz = nvz;
+            float angularVelocitySteering = 0.4f;
+            if (!localVelDirectionIsFwd && !accelDirectionIsFwd) angularVelocitySteering *= -1.0f;
+            {
+                float target = turningPower * angularVelocitySteering, maxDelta = dt * 20.0f;
+                if (f_abs(target - wy) <= maxDelta) wy = target;
+                else wy = wy + f_sign(target - wy) * maxDelta;
+            }
+            acc_ang_v += f_abs(wy);
+            a->acc_ang_v = acc_ang_v;
+            rot_y(turningPower * f_sign(localVelZ) * 25.0f * P.st.Grip * dt * DEG2RAD_F, vx, vz);
+            // ---- engine: integrate
+            wy = wy * (1.0f - P.st.AngularDrag * dt);
+            yaw = yaw + wy * dt;
+            if (yaw < 0.0f) yaw += TWO_PI_F;
+            if (yaw >= TWO_PI_F) yaw -= TWO_PI_F;
+            px = px + vx * dt;
+            pz = pz + vz * dt;
+        }
+    }
+    // ---- kart-kart contacts (Jacobi over one snapshot)
+    {
+        float ax = 0, az = 0, bx = 0, bz = 0;
+        kart_core(yaw, px, pz, ax, az, bx, bz);
+        float cpx = 0, cpz = 0, cvx = 0, cvz = 0;
+        bool touched = false;
+        for (int j = 0; j < ENV_MAXA; j++) {
+            const float jpx = quad_get(px, j), jpz = quad_get(pz, j), jyaw = quad_get(yaw, j);
+            const float jvx = quad_get(vx, j), jvz = quad_get(vz, j);
+            const uint32_t jfl = quad_get(fl, j);
+            if (j >= P.A || j == i || !enabled || !(jfl & HK_F_ENABLED)) continue;
+            float cx, cz, dx, dz, c1x, c1z, c2x, c2z;
+            kart_core(jyaw, jpx, jpz, cx, cz, dx, dz);
+            float d2 = seg_seg_closest(ax, az, bx, bz, cx, cz, dx, dz, c1x, c1z, c2x, c2z);
+            const float rr = 2.0f * CAP_R;
+            if (d2 < rr * rr) {
+                float d = sqrtf(d2);
+                float nx, nz;
+                if (d > 1e-6f) { nx = (c1x - c2x) / d; nz = (c1z - c2z) / d; }
+                else {
+                    float ex = px - jpx, ez = pz - jpz;
+                    float el = sqrtf(ex * ex + ez * ez);
+                    if (el > 1e-6f) { nx = ex / el; nz = ez / el; } else { nx = (i < j) ? 1.0f : -1.0f; nz = 0.0f; }
+                }
+                float pen = rr - d;
+                float share = (jfl & HK_F_CAN_MOVE) ? 0.5f : 1.0f;
+                cpx += nx * (pen * share); cpz += nz * (pen * share);
+                float vrel = (vx - jvx) * nx + (vz - jvz) * nz;
+                if (vrel < 0.0f) { cvx -= nx * (vrel * share); cvz -= nz * (vrel * share); }
+                touched = true;
+            }
+        }
+        if (live) {
+            if (touched && (fl & HK_F_CAN_MOVE)) { px += cpx; pz += cpz; vx += cvx; vz += cvz; }
+            if (touched) fl |= HK_F_HAS_COLLISION; else fl &= ~HK_F_HAS_COLLISION;
+        }
+    }
+    // ---- kart-wall contacts: deepest penetration, two passes
+    if (enabled && (fl & HK_F_CAN_MOVE)) {
+        const int sidx = a->section_index % P.L;
+        const int w0 = P.near_off[sidx], w1 = P.near_off[sidx + 1];
+        for (int pass = 0; pass < 2; pass++) {
+            float ax, az, bx, bz;
+            kart_core(yaw, px, pz, ax, az, bx, bz);
+            float bestpen = 0.0f, bnx = 0.0f, bnz = 0.0f;
+            bool found = false;
+            for (int q = w0; q < w1; q++) {
+                const hk_wall_seg ws = P.walls[P.near_idx[q]];
+                float c1x, c1z, c2x, c2z;
+                float d2 = seg_seg_closest(ax, az, bx, bz, ws.x0, ws.z0, ws.x1, ws.z1, c1x, c1z, c2x, c2z);
+                if (d2 < CAP_R * CAP_R) {
+                    float d = sqrtf(d2);
+                    float pen = CAP_R - d;
+                    float nx, nz;
+                    if (d > 1e-6f) { nx = (c1x - c2x) / d; nz = (c1z - c2z) / d; }
+                    else {
+                        float ex = ws.x1 - ws.x0, ez = ws.z1 - ws.z0;
+                        float el = sqrtf(ex * ex + ez * ez);
+                        nx = -ez / el; nz = ex / el;
+                        if ((px - ws.x0) * nx + (pz - ws.z0) * nz < 0.0f) { nx = -nx; nz = -nz; }
+                    }
+                    // near_idx is ascending, so "first strictly deeper" == the oracle's lowest-index tie break
+                    if (!found || pen > bestpen) { found = true; bestpen = pen; bnx = nx; bnz = nz; }
+                }
+            }
+            if (!found) break;
+            px += bnx * bestpen; pz += bnz * bestpen;
+            float vn = vx * bnx + vz * bnz;
+            if (vn < 0.0f) { vx -= bnx * vn; vz -= bnz * vn; }
+            fl |= HK_F_HAS_COLLISION;
+            a->contact_nx = bnx; a->contact_nz = bnz;
+        }
+    }
+    bool bad = false;
+    if (live) bad = !f_finite(px) || !f_finite(pz) || !f_finite(vx) || !f_finite(vz) || !f_finite(yaw) || !f_finite(wy);
+    // ---- trigger dispatch (HKA.OnTriggerEnter :611-675) on the post-contact pose
+    uint32_t newly_inactive = 0;
+    if (enabled) {
+        a->px = px; a->pz = pz; a->yaw = yaw; a->vx = vx; a->vz = vz; a->wy = wy;
+        float ax, az, bx, bz;
+        kart_core(yaw, px, pz, ax, az, bx, bz);
+        uint32_t lo = 0, hi = 0;
+        for (int t = 0; t < P.L; t++) {
+            const SecDev& s = P.sec[t];
+            float rax = ax - s.trig_x, raz = az - s.trig_z, rbx = bx - s.trig_x, rbz = bz - s.trig_z;
+            float lax = rax * s.fz - raz * s.fx, laz = rax * s.fx + raz * s.fz;
+            float lbx = rbx * s.fz - rbz * s.fx, lbz = rbx * s.fx + rbz * s.fz;
+            float zlo = f_min(laz, lbz) - CAP_R, zhi = f_max(laz, lbz) + CAP_R;
+            float xlo = f_min(lax, lbx) - CAP_R, xhi = f_max(lax, lbx) + CAP_R;
+            if (zlo <= TRIG_HZ && zhi >= -TRIG_HZ && xlo <= TRIG_HX && xhi >= -TRIG_HX) {
+                if (t < 32) lo |= 1u << t; else hi |= 1u << (t - 32);
+            }
+        }
+        const uint32_t nlo = lo & ~a->trig_lo, nhi = hi & ~a->trig_hi;
+        a->trig_lo = lo; a->trig_hi = hi;
+        if (nlo | nhi) {
+            for (int t = 0; t < P.L; t++) {
+                const bool ent = t < 32 ? ((nlo >> t) & 1u) : ((nhi >> (t - 32)) & 1u);
+                if (!ent || !(fl & HK_F_ACTIVE)) continue;
+                const int L = P.L, H = P.H;
+                const int sec = a->section_index, init = a->init_checkpoint_index;
+                int index = -1, lane = -1;
+                int lo_i = sec - H; if (lo_i < init) lo_i = init;
+                for (int ii = lo_i; ii < sec + H; ii++) {                  // KA.FindSectionIndex :348-364
+                    int idx = ii < 0 ? ii + L : ii;
+                    if (idx % L == t) { index = idx; lane = calculate_lane(P, P.sec[idx % L], px, pz); break; }
+                }
+                if (index != -1 && ((index > sec) || (index % L == 0 && sec % L == L - 1))) {
+                    const int key = index % L;
+                    const int pl = a->plan_lane[key];
+                    if (pl != 0) {
+                        float lmx, lmz;
+                        lane_marker(P, key, pl, lmx, lmz);
+                        float dist = mag3(px - lmx, P.kart_y - P.sec[key].marker_y, pz - lmz);
+                        a->avg_lane_diff = (f_max(dist - 1.3f, 0.0f) + a->avg_lane_diff * (index - init - 1)) / (index - init);
+                        float velocity = mag3(vx, 0.0f, vz);
+                        a->avg_vel_diff = ((velocity - a->plan_vel[key]) + a->avg_vel_diff * (index - init - 1)) / (index - init);
+                        a->plan_lane[key] = 0; a->plan_vel[key] = 0.0f;
+                    }
+                    const int cur_lane = a->lane;
+                    int dl = cur_lane - lane; if (dl < 0) dl = -dl;
+                    int lc = a->lane_changes;
+                    if (lc + dl > P.max_lane_changes && is_straight(P, sec)) a->illegal_lane_changes += 1;
+                    if (is_straight(P, sec) != is_straight(P, index)) lc = 0;
+                    else if (cur_lane != lane) lc += dl;
+                    a->lane_changes = lc;
+                    a->section_index = index; a->lane = lane;
+                    if (index == P.laps * L + 1) {                         // ReachGoalSection REC:469-474
+                        a->time_steps = episode_steps;
+                        fl = deactivate_fields(P, a, fl);
+                        vx = 0; vz = 0; wy = 0;
+                        newly_inactive |= 1u << i;
+                    }
+                } else if (index != -1 && ((index < sec) || (sec % L == 0 && index % L == L - 1))) {
+                    a->section_index = index;
+                } else if (index == -1) {                                  // DroveReverseLimit REC:475-479
+                    a->time_steps = P.max_steps * 6;
+                    fl = deactivate_fields(P, a, fl);
+                    vx = 0; vz = 0; wy = 0;
+                    newly_inactive |= 1u << i;
+                }
+            }
+        }
+    }
+    if (live) a->flags = fl;
+    // per-env words: OR over the quad
+    uint32_t ni = newly_inactive, bd = bad ? 1u : 0u;
+    ni |= (uint32_t)__shfl_xor((int)ni, 1, 64); ni |= (uint32_t)__shfl_xor((int)ni, 2, 64);
+    bd |= (uint32_t)__shfl_xor((int)bd, 1, 64); bd |= (uint32_t)__shfl_xor((int)bd, 2, 64);
+    if (env_ok && i == 0 && (ni | bd)) {
+        envs[env].inactive_mask = inactive_mask | ni;
+        if (bd) envs[env].status = status | 1u;
+    }
+}
+
+}  // namespace hk

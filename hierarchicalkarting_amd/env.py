@@ -1,0 +1,112 @@
+"""Host mirror of the reference's environment surface for the hot path, on top of libhk.so.
+
+RacingEnv  <->  RacingEnvController (+ its KartAgents / ArcadeKarts), E independent instances on one GPU:
+    reset(env_ids, experiment_num)   REC.ResetGame            (RacingEnvController.cs:499-719)
+    step(n)                          n Unity FixedUpdate ticks
+    observations()                   HierarchicalKartAgent.CollectObservations (HKA:485-604)
+    set_actions(steer, branch)       KartAgent.OnActionReceived (KA:440-478) for LowMode == RL agents
+    agent_state() / set_agent_state  snapshot / restore of every KartAgent + ArcadeKart + Rigidbody field
+    episode_results()                TelemetryViewer quantities of the last finished episode
+All arrays are numpy views of the ABI structs; all compute happens in the HIP kernels."""
+import ctypes as C
+import numpy as np
+from . import _lib
+from .config import make_config, BuiltConfig
+
+AGENT_DT = np.dtype(_lib.AgentState)
+ENV_DT = np.dtype(_lib.EnvState)
+RESULT_DT = np.dtype(_lib.EpisodeResult)
+
+
+class RacingEnv:
+    def __init__(self, built=None, **kw):
+        self.built = built if isinstance(built, BuiltConfig) else make_config(**kw)
+        self.L = _lib.load()
+        self.h = C.c_void_p()
+        rc = self.L.hk_create(C.byref(self.built.cfg), C.byref(self.h))
+        _lib.check(rc, None)
+        self.E, self.A = self.built.cfg.num_envs, self.built.cfg.num_agents
+        self.obs_dim = self.L.hk_obs_dim(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.hk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        return _lib.check(rc, self.h)
+
+    def reset(self, env_ids=None, experiment_num=-1):
+        if env_ids is None:
+            self._ck(self.L.hk_reset(self.h, None, 0, int(experiment_num)))
+        else:
+            ids = np.ascontiguousarray(env_ids, np.int32)
+            self._ck(self.L.hk_reset(self.h, ids.ctypes.data_as(C.POINTER(C.c_int32)), len(ids), int(experiment_num)))
+
+    def step(self, n=1):
+        self._ck(self.L.hk_step(self.h, int(n)))
+
+    def synchronize(self):
+        self._ck(self.L.hk_synchronize(self.h))
+
+    def agent_state(self):
+        out = np.zeros((self.E, self.A), AGENT_DT)
+        self._ck(self.L.hk_get_agent_state(self.h, out.ctypes.data_as(C.POINTER(_lib.AgentState))))
+        return out
+
+    def set_agent_state(self, st):
+        st = np.ascontiguousarray(st, AGENT_DT)
+        assert st.shape == (self.E, self.A)
+        self._ck(self.L.hk_set_agent_state(self.h, st.ctypes.data_as(C.POINTER(_lib.AgentState))))
+
+    def env_state(self):
+        out = np.zeros(self.E, ENV_DT)
+        self._ck(self.L.hk_get_env_state(self.h, out.ctypes.data_as(C.POINTER(_lib.EnvState))))
+        return out
+
+    def set_env_state(self, st):
+        st = np.ascontiguousarray(st, ENV_DT)
+        assert st.shape == (self.E,)
+        self._ck(self.L.hk_set_env_state(self.h, st.ctypes.data_as(C.POINTER(_lib.EnvState))))
+
+    def episode_results(self):
+        out = np.zeros((self.E, self.A), RESULT_DT)
+        self._ck(self.L.hk_get_episode_results(self.h, out.ctypes.data_as(C.POINTER(_lib.EpisodeResult))))
+        return out
+
+    def observations(self):
+        out = np.zeros((self.E, self.A, self.obs_dim), np.float32)
+        self._ck(self.L.hk_get_observations(self.h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def set_actions(self, steer, branch):
+        s = np.ascontiguousarray(steer, np.float32).reshape(self.E, self.A)
+        b = np.ascontiguousarray(branch, np.int32).reshape(self.E, self.A)
+        self._ck(self.L.hk_set_actions(self.h, s.ctypes.data_as(C.POINTER(C.c_float)), b.ctypes.data_as(C.POINTER(C.c_int32))))
+
+    def lq_debug(self, env, ego):
+        d = _lib.LqDebug()
+        self._ck(self.L.hk_get_lq_debug(self.h, env, ego, C.byref(d)))
+        return d
+
+    # ---- profiling taps used by bench.py
+    def prof_enable(self, on=True):
+        self._ck(self.L.hk_prof_enable(self.h, 1 if on else 0))
+
+    def prof_reset(self):
+        self._ck(self.L.hk_prof_reset(self.h))
+
+    def prof_read(self):
+        sm, st = C.c_double(), C.c_double()
+        sn, tn = C.c_int64(), C.c_int64()
+        self._ck(self.L.hk_prof_read(self.h, C.byref(sm), C.byref(sn), C.byref(st), C.byref(tn)))
+        return dict(solve_ms=sm.value, solve_launches=sn.value, step_ms=st.value, step_launches=tn.value)
+
+    def device_results_ptr(self):
+        return self.L.hk_device_results_ptr(self.h)
