@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the 4-agent Oval Fixed-LQNG race, 65 536 parallel envs per GPU (BASELINE.json configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W
+A "step" is one Unity FixedUpdate tick of EVERY env on the rank (K_A begin + K_B SolveLQR + K_C vehicle/engine kernels),
+state resident in HBM.  For N > 1 the driver launches one rank per GPU with torch.distributed.run; envs shard
+contiguously over ranks (no data-path collective), and the episode results are all-gathered over RCCL after the timed
+region (the path's only exchange step).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_ENV_STEP = 1056.0       # state in + state out at A = 4 (2 x 528 B)
+ALGO_FLOP_PER_ENV_STEP = 330e3         # dense-equivalent fp64 flop (4 ego solves x 322 kflop / 4-tick cadence + physics)
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VECTOR_PEAK_TFLOPS = 78.6         # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
+
+
+def cpu_baseline(num_agents, warmup, seed):
+    """The CPU oracle (a line-by-line port of the reference C#, NOT the reference itself: no dotnet/Unity on the box)
+    timed on the host cores with OpenMP over envs, on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    import hierarchicalkarting_amd as hk
+    E, ticks = 512, 200
+    b = hk.make_config(E, num_agents, jitter_seed=seed)
+    o = O.OracleEnv(b)
+    o.reset()
+    o.step(warmup)
+    t0 = time.perf_counter()
+    o.step(ticks)
+    dt = time.perf_counter() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": E * ticks / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "CPU oracle (C port of the reference C#), %d envs x %d ticks after %d warmup ticks, OpenMP over envs" % (E, ticks, warmup)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs-per-gpu", type=int, default=65536)
+    ap.add_argument("--agents", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libhk has no CPU fallback")
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if dist:
+        dist.barrier()
+    import hierarchicalkarting_amd as hk
+    from hierarchicalkarting_amd.parallel import gather_episode_results
+
+    E = a.envs_per_gpu
+    seed = 0x5EED0000
+    env = hk.RacingEnv(hk.make_config(E, a.agents, jitter_seed=seed, env_id_base=rank * E, device_id=local_rank))
+    env.reset()
+    env.step(a.warmup)
+    env.synchronize()
+
+    def barrier():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        env.synchronize()
+
+    env.prof_enable(True)
+    env.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    env.step(a.steps)
+    env.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = env.prof_read()
+    env.prof_enable(False)
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # the path's one exchange step: all-gather of the episode results (RCCL over xGMI), off the timed region
+    results = gather_episode_results(env, dist)
+    total_envs = E * world
+    value = total_envs * a.steps / dt
+
+    if rank == 0:
+        solve_ms = prof["solve_ms"] / max(prof["solve_launches"], 1)
+        step_ms = prof["step_ms"] / max(prof["step_launches"], 1)
+        algo_gb = ALGO_BYTES_PER_ENV_STEP * E / 1e9
+        achieved = algo_gb / (solve_ms * 1e-3) if solve_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("env_solve_kernel", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env-steps/sec (4-agent Oval, batch=65k)" if (a.agents == 4 and E == 65536) else "env-steps/sec",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d-agent Oval, Fixed-LQNG vs Fixed-LQNG (2v2), %d parallel envs per GPU, seeded start jitter, auto-reset"
+                                   % (a.agents, E), "envs_per_gpu": E, "agents": a.agents, "sharding": "envs split contiguously over ranks",
+                       "finished_episodes_seen": int((results["episode"] >= 0).any(axis=1).sum())},
+            "roofline": {"bound": "hbm", "kernel": "env_solve_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": solve_ms, "launches": prof["solve_launches"],
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * E,
+                         "note": "the path is fp64-VALU/latency bound, not HBM bound (SURVEY §8d); binding roof below",
+                         "fp64_valu": {"achieved_tflops": ALGO_FLOP_PER_ENV_STEP * E / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else 0.0,
+                                       "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                                       "frac": (ALGO_FLOP_PER_ENV_STEP * E / (solve_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if solve_ms > 0 else 0.0,
+                                       "unit": "dense-equivalent TFLOP/s"},
+                         "other_kernels": {"env_move_kernel_avg_ms": step_ms}},
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.agents, a.warmup, seed)
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

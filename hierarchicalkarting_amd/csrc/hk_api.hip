@@ -5,6 +5,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <utility>
 #include <new>
 #include "../../include/hk.h"
 #include "hk_lq_kernels.h"
@@ -14,11 +15,34 @@ namespace {
 
 thread_local std::string g_last_error;
 
+// HIP-event timing of the kernels on the handle's own stream, without a host sync per launch: every profiled launch is
+// bracketed by an event pair taken from a pool; hk_prof_read synchronises once and folds the elapsed times.
 struct Prof {
     bool on = false;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<hipEvent_t> pool;                       // free events
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> solve, step;   // recorded, not yet folded
     double solve_ms = 0, step_ms = 0;
     int64_t solve_n = 0, step_n = 0;
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+    void fold()
+    {
+        for (auto* v : {&solve, &step}) {
+            for (auto& pr : *v) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                    if (v == &solve) { solve_ms += ms; solve_n++; } else { step_ms += ms; step_n++; }
+                }
+                pool.push_back(pr.first); pool.push_back(pr.second);
+            }
+            v->clear();
+        }
+    }
 };
 
 }  // namespace
@@ -112,8 +136,8 @@ void hk_destroy(hk_handle h)
     hk::env_destroy(h->dev);
     if (h->d_status) (void)hipFree(h->d_status);
     if (h->lq_scratch) (void)hipFree(h->lq_scratch);
-    if (h->prof.e0) (void)hipEventDestroy(h->prof.e0);
-    if (h->prof.e1) (void)hipEventDestroy(h->prof.e1);
+    h->prof.fold();
+    for (hipEvent_t e : h->prof.pool) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h == g_default_ctx) g_default_ctx = nullptr;
     delete h;
@@ -140,17 +164,15 @@ int hk_lq_solve_batch_device(hk_handle h, int batch, int N, const double* dA, co
     HK_HIP(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     const int blocks = (batch + 3) / 4;
-    if (h->prof.on) HK_HIP(h, hipEventRecord(h->prof.e0, st));
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    if (h->prof.on) { pe0 = h->prof.get(); pe1 = h->prof.get(); }
+    if (pe0) HK_HIP(h, hipEventRecord(pe0, st));
     hipLaunchKernelGGL(hk::lq_batch_kernel, dim3(blocks), dim3(64), 0, st, batch, N, dA, dB, dQ, dq, dR, dx0, horizon, du0,
                        h->d_status);
     HK_HIP(h, hipGetLastError());
-    if (h->prof.on) {
-        HK_HIP(h, hipEventRecord(h->prof.e1, st));
-        HK_HIP(h, hipEventSynchronize(h->prof.e1));
-        float ms = 0;
-        HK_HIP(h, hipEventElapsedTime(&ms, h->prof.e0, h->prof.e1));
-        h->prof.solve_ms += ms;
-        h->prof.solve_n += 1;
+    if (pe0 && pe1) {
+        HK_HIP(h, hipEventRecord(pe1, st));
+        h->prof.solve.emplace_back(pe0, pe1);
     }
     return HK_OK;
 }
@@ -230,27 +252,19 @@ int hk_step(hk_handle h, int n_ticks)
     HK_NEED_ENV(h);
     if (n_ticks < 0) return fail(h, HK_ERR_INVALID, "hk_step: n_ticks < 0");
     for (int t = 0; t < n_ticks; t++) {
-        if (h->prof.on) {
-            float ms;
-            HK_HIP(h, hipEventRecord(h->prof.e0, h->stream));
-            int rc = hk::env_launch_solve(h->dev, h->cfg, h->stream, h->err);
-            if (rc) { g_last_error = h->err; return rc; }
-            HK_HIP(h, hipEventRecord(h->prof.e1, h->stream));
-            HK_HIP(h, hipEventSynchronize(h->prof.e1));
-            HK_HIP(h, hipEventElapsedTime(&ms, h->prof.e0, h->prof.e1));
-            h->prof.solve_ms += ms; h->prof.solve_n++;
-            HK_HIP(h, hipEventRecord(h->prof.e0, h->stream));
-            rc = hk::env_launch_step(h->dev, h->cfg, h->stream, h->err);
-            if (rc) { g_last_error = h->err; return rc; }
-            HK_HIP(h, hipEventRecord(h->prof.e1, h->stream));
-            HK_HIP(h, hipEventSynchronize(h->prof.e1));
-            HK_HIP(h, hipEventElapsedTime(&ms, h->prof.e0, h->prof.e1));
-            h->prof.step_ms += ms; h->prof.step_n++;
-        } else {
-            int rc = hk::env_launch_solve(h->dev, h->cfg, h->stream, h->err);
-            if (!rc) rc = hk::env_launch_step(h->dev, h->cfg, h->stream, h->err);
-            if (rc) { g_last_error = h->err; return rc; }
-        }
+        // K_A (episode controller + sensing), then K_B (SolveLQR, the dominant kernel), then K_C (vehicle + engine)
+        int rc = hk::env_launch_begin(h->dev, h->cfg, h->stream, h->err);
+        if (rc) { g_last_error = h->err; return rc; }
+        hipEvent_t a0 = nullptr, a1 = nullptr, b0 = nullptr, b1 = nullptr;
+        if (h->prof.on) { a0 = h->prof.get(); a1 = h->prof.get(); b0 = h->prof.get(); b1 = h->prof.get(); }
+        if (a0) HK_HIP(h, hipEventRecord(a0, h->stream));
+        rc = hk::env_launch_solve(h->dev, h->cfg, h->stream, h->err);
+        if (rc) { g_last_error = h->err; return rc; }
+        if (a0 && a1) { HK_HIP(h, hipEventRecord(a1, h->stream)); h->prof.solve.emplace_back(a0, a1); }
+        if (b0) HK_HIP(h, hipEventRecord(b0, h->stream));
+        rc = hk::env_launch_step(h->dev, h->cfg, h->stream, h->err);
+        if (rc) { g_last_error = h->err; return rc; }
+        if (b0 && b1) { HK_HIP(h, hipEventRecord(b1, h->stream)); h->prof.step.emplace_back(b0, b1); }
     }
     return HK_OK;
 }
@@ -341,10 +355,6 @@ int hk_prof_enable(hk_handle h, int on)
 {
     if (!h) return HK_ERR_INVALID;
     HK_HIP(h, hipSetDevice(h->device));
-    if (on && !h->prof.e0) {
-        HK_HIP(h, hipEventCreate(&h->prof.e0));
-        HK_HIP(h, hipEventCreate(&h->prof.e1));
-    }
     h->prof.on = on != 0;
     return HK_OK;
 }
@@ -352,6 +362,9 @@ int hk_prof_enable(hk_handle h, int on)
 int hk_prof_reset(hk_handle h)
 {
     if (!h) return HK_ERR_INVALID;
+    HK_HIP(h, hipSetDevice(h->device));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    h->prof.fold();
     h->prof.solve_ms = h->prof.step_ms = 0;
     h->prof.solve_n = h->prof.step_n = 0;
     return HK_OK;
@@ -360,6 +373,9 @@ int hk_prof_reset(hk_handle h)
 int hk_prof_read(hk_handle h, double* solve_ms, int64_t* solve_launches, double* step_ms, int64_t* step_launches)
 {
     if (!h) return HK_ERR_INVALID;
+    HK_HIP(h, hipSetDevice(h->device));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    h->prof.fold();
     if (solve_ms) *solve_ms = h->prof.solve_ms;
     if (solve_launches) *solve_launches = h->prof.solve_n;
     if (step_ms) *step_ms = h->prof.step_ms;

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include "../../include/hk.h"
@@ -117,7 +118,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         const float dyc = 0.5f - 0.582f;   // sensor height - capsule centre height (kart-local)
         P.ray_agent_r = sqrtf(CAP_R * CAP_R - dyc * dyc);
     }
-    P.debug = 1;
+    { const char* dbg = std::getenv("HK_LQ_DEBUG"); P.debug = (dbg && dbg[0] == '1') ? 1 : 0; }   // hk_get_lq_debug taps
     // sections with forward precomputed (same float expressions as everywhere else)
     std::vector<SecDev> sd(L);
     for (int i = 0; i < L; i++) {
@@ -255,13 +256,17 @@ inline int env_reset(EnvDevice& d, const hk_config& cfg, const int32_t* env_ids,
     return HK_OK;
 }
 
-// REC.FixedUpdate + KA.FixedUpdate, then SolveLQR for every ego (the dominant kernel)
-inline int env_launch_solve(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+// K_A: REC.FixedUpdate + KA.FixedUpdate
+inline int env_launch_begin(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
 {
     const int threads = cfg.num_envs * 4;
     hipLaunchKernelGGL(env_begin_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.envs, d.results);
-    int rc = launch_check(err, "env_begin_kernel");
-    if (rc) return rc;
+    return launch_check(err, "env_begin_kernel");
+}
+
+// K_B: SolveLQR for every ego (the dominant kernel)
+inline int env_launch_solve(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
     hipLaunchKernelGGL(env_solve_kernel, dim3(cfg.num_envs), dim3(64), 0, stream, d.P, d.agents, d.envs, d.lq_debug, d.status);
     return launch_check(err, "env_solve_kernel");
 }
