@@ -52,3 +52,75 @@ def test_full_episode_with_auto_reset_two_agents():
     for name in gr.dtype.names:
         assert np.array_equal(gr[name], orr[name]), name
     assert (gr["episode"] >= 0).any()
+
+
+def test_trajectory_hash_matches_the_committed_pin():
+    """BASELINE.md parity gate: 4 096-tick 2-agent Fixed-vs-Fixed Oval trajectory hash equal to the CPU oracle's."""
+    import hashlib, json, os
+    import hierarchicalkarting_amd as hk
+    g = hk.RacingEnv(hk.make_config(1, 2, jitter_seed=0))
+    g.reset(experiment_num=0)
+    hashes = []
+    for _ in range(8):
+        g.step(512)
+        hashes.append(hashlib.sha256(g.agent_state().tobytes()).hexdigest())
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oval_2agent_4096_hash.json")))["sha256"]
+    assert hashes == want
+
+
+def test_lq_debug_taps_and_decoded_controls(monkeypatch):
+    """single-step a4 check: players, branch ids, targets, weights and u0 of every ego's game equal the oracle's"""
+    monkeypatch.setenv("HK_LQ_DEBUG", "1")
+    import hierarchicalkarting_amd as hk
+    b = hk.make_config(16, 4, jitter_seed=0x5EED0000)
+    g = hk.RacingEnv(b)
+    o = O.OracleEnv(b)
+    g.reset(); o.reset()
+    seen = set()
+    for _ in range(60):
+        g.step(8); o.step(8)
+        for env in (0, 5, 15):
+            for ego in range(4):
+                dg, do = g.lq_debug(env, ego), o.lq_debug(env, ego)
+                assert dg.n_players == do.n_players
+                for i in range(dg.n_players):
+                    assert dg.player_agent[i] == do.player_agent[i] and dg.branch[i] == do.branch[i]
+                    assert list(dg.initial[i]) == list(do.initial[i]) and list(dg.target[i]) == list(do.target[i])
+                    assert list(dg.target_w[i]) == list(do.target_w[i]) and dg.control_w[i] == do.control_w[i]
+                    seen.add(dg.branch[i])
+                assert list(dg.u0) == list(do.u0)
+    assert len(seen) >= 4, seen          # the race exercises several branches of the heading heuristic
+
+
+def test_rl_actions_and_partial_reset():
+    """LowMode == RL agents take hk_set_actions (KA:440-478); hk_reset of a subset leaves the other envs untouched"""
+    import hierarchicalkarting_amd as hk
+    from hierarchicalkarting_amd import _lib
+    b = hk.make_config(6, 2, low_mode=[_lib.HK_LOW_RL, _lib.HK_LOW_LQR], jitter_seed=7)
+    g = hk.RacingEnv(b)
+    o = O.OracleEnv(b)
+    g.reset(); o.reset()
+    rng = np.random.default_rng(0)
+    for k in range(12):
+        steer = rng.uniform(-1, 1, (6, 2)).astype(np.float32)
+        branch = rng.integers(0, 3, (6, 2)).astype(np.int32)
+        g.set_actions(steer, branch); o.set_actions(steer, branch)
+        g.step(20); o.step(20)
+        if k == 6:
+            g.reset([1, 4], experiment_num=3); o.reset([1, 4], experiment_num=3)
+        _cmp(g.agent_state(), o.agent_state(), g.env_state(), o.env_state(), k)
+    assert (g.env_state()["experiment_num"][[1, 4]] == 3).all()
+
+
+def test_invalid_configs_are_refused():
+    import hierarchicalkarting_amd as hk
+    from hierarchicalkarting_amd import _lib
+    with pytest.raises(_lib.HkError) as e:
+        hk.RacingEnv(hk.make_config(2, 4, high_mode=_lib.HK_HIGH_MCTS))
+    assert e.value.code == _lib.HK_ERR_UNSUPPORTED
+    with pytest.raises(_lib.HkError) as e:
+        hk.RacingEnv(hk.make_config(2, 4, env_mode=_lib.HK_MODE_TRAINING))
+    assert e.value.code == _lib.HK_ERR_UNSUPPORTED
+    with pytest.raises(_lib.HkError) as e:
+        hk.RacingEnv(hk.make_config(2, 4, wiring=([0, 0, 1, 1], [[1], [0], [3], []], [[2, 3], [2, 3], [0, 1], [0, 1]])))
+    assert e.value.code == _lib.HK_ERR_INVALID

@@ -1,0 +1,189 @@
+"""Behaviour of the CPU oracle of the environment tick: the restated reference semantics (reset grid, start hold,
+cadence, checkpoint rules, quirks) and the distributional pin against the reference's experiment logs."""
+import hashlib
+import json
+import os
+import numpy as np
+import pytest
+import oracle_lib as O
+from hierarchicalkarting_amd import _lib as HL
+from hierarchicalkarting_amd.config import make_config
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_reset_grid_follows_the_permutation():
+    """REC:526-530,583-614: j-th placed agent gets section {0,0,1,1}[j], lane {2,3,2,3}[j], 3 m past the marker."""
+    b = make_config(1, 4)
+    o = O.OracleEnv(b)
+    secs = b.track["sections"]
+    for ex, order in ((0, [0, 1, 2, 3]), (1, [0, 1, 3, 2]), (23, [3, 2, 1, 0]), (24, [0, 1, 2, 3])):
+        o.reset(experiment_num=ex)
+        st = o.agent_state()[0]
+        for j, i in enumerate(order):
+            sec, lane = [0, 0, 1, 1][j], [2, 3, 2, 3][j]
+            assert st[i]["section_index"] == sec and st[i]["lane"] == lane and st[i]["init_checkpoint_index"] == sec
+            m = secs[sec]["Lane%d" % lane]
+            assert abs(st[i]["px"] - m["x"]) < 1e-4 and abs(st[i]["pz"] - (m["z"] + 3.0)) < 1e-4
+            assert st[i]["flags"] == (HL.HK_F_ACTIVE | HL.HK_F_ENABLED)
+            assert abs(st[i]["acc_ang_v"] - 2076.39) < 0.01            # tire wear 0.25
+            # planFixed: next 5 sections, lane = optimalLane of the section before, velocity = GetMaxSpeed()
+            for k in range(sec + 1, sec + 6):
+                assert st[i]["plan_lane"][k % 24] == secs[(k - 1) % 24]["optimalLane"] and st[i]["plan_vel"][k % 24] == 15.0
+            assert st[i]["plan_lane"][(sec + 6) % 24] == 0
+
+
+def test_start_hold_and_cadence():
+    b = make_config(2, 4)
+    o = O.OracleEnv(b)
+    o.reset(experiment_num=0)
+    p0 = o.agent_state()[["px", "pz"]].copy()
+    o.step(74)
+    st = o.agent_state()
+    assert np.array_equal(st[["px", "pz"]], p0) and not (st["flags"] & HL.HK_F_CAN_MOVE).any()
+    assert (st["flags"] & (HL.HK_F_ACCEL | HL.HK_F_BRAKE)).all() or (st["flags"] & HL.HK_F_ACCEL).any()   # SolveLQR already ran
+    o.step(1)
+    assert (o.agent_state()["flags"] & HL.HK_F_CAN_MOVE).all() and o.env_state()["episode_steps"][0] == 75
+    # 4 agents: controls only change on ticks with episode_steps % 4 == 0 (HKA:317)
+    o.step(1)                                   # tick 76: solve
+    s76 = o.agent_state()["steering"].copy()
+    o.step(3)                                   # 77..79: no solve
+    assert np.array_equal(o.agent_state()["steering"], s76)
+    o.step(1)                                   # tick 80: solve
+    assert not np.array_equal(o.agent_state()["steering"], s76)
+
+
+def test_two_agents_solve_every_tick():
+    o = O.OracleEnv(make_config(1, 2))
+    o.reset(experiment_num=0)
+    o.step(100)
+    a = o.agent_state()["steering"].copy()
+    o.step(1)
+    assert not np.array_equal(o.agent_state()["steering"], a)
+
+
+def test_lq_debug_branches_and_player_order():
+    o = O.OracleEnv(make_config(1, 4))
+    o.reset(experiment_num=0)
+    o.step(4)                                   # first solve tick: episode_steps % 4 == 0 (HKA:317)
+    # grid: agents 0,1 at section 0 (z = 0.49), agents 2,3 at section 1 (z = 10.49): |dz| = 10 > 8, dx = 2.5
+    d0 = o.lq_debug(0, 0)
+    assert d0.n_players == 2 and list(d0.player_agent)[:2] == [0, 1]      # [this, team] (HKA:702), others filtered out
+    d2 = o.lq_debug(0, 2)
+    assert d2.n_players == 2 and list(d2.player_agent)[:2] == [2, 3]
+    assert d0.target[0][2] == 0.0 and d0.target_w[0][2] == -2.0            # standing start: v target 0, weight -2*nearby
+    assert d0.control_w[0] == 0.115                                        # N <= 2 players
+    assert 0.0 <= d0.initial[0][3] < 2 * np.pi
+    for i in range(2):
+        assert d0.branch[i] in (1, 2, 3, 4, 5, 6, 7)
+
+
+def test_raycast_against_the_walls():
+    o = O.OracleEnv(make_config(1, 2))
+    # from the middle of the first straight (x = 15.88), walls at 11.28 and 20.48
+    assert abs(o.raycast_track(15.88, 2.0, 1.0, 0.0, 20.0) - 4.6) < 1e-4
+    assert abs(o.raycast_track(15.88, 2.0, -1.0, 0.0, 20.0) - 4.6) < 1e-4
+    assert o.raycast_track(15.88, 2.0, 1.0, 0.0, 4.0) == -1.0              # maxDistance
+    assert o.raycast_track(15.88, 2.0, 0.0, 1.0, 20.0) == -1.0             # along the straight: nothing within 20 m
+
+
+def _race(A, ex):
+    b = make_config(1, A, auto_reset=0)
+    o = O.OracleEnv(b)
+    o.reset(experiment_num=ex)
+    for _ in range(62):
+        o.step(100)
+        if o.env_state()["inactive_mask"][0] == (1 << A) - 1:
+            break
+    o.step(1)
+    return o.episode_results()[0], o.agent_state()[0]
+
+
+@pytest.mark.parametrize("A,ex", [(2, 0), (2, 1), (4, 0), (4, 7)])
+def test_race_finishes_inside_the_reference_band(A, ex):
+    """Fixed-LQNG Oval, 4 laps: reference mean 3972 ticks (1v1) / 4127 (2v2), best lap 18.6-19.8 s.  The
+    engine is restated (not PhysX), so the pin is distributional: every kart finishes, in 3.6-4.4 k ticks."""
+    res, st = _race(A, ex)
+    assert (res["section_index"] == 97).all()                       # goalSection = 4*24 + 1 (REC:165)
+    assert (res["time_steps"] > 3600).all() and (res["time_steps"] < 4400).all(), res["time_steps"]
+    assert (res["episode"] == 0).all()
+    assert not (st["flags"] & (HL.HK_F_ACTIVE | HL.HK_F_ENABLED | HL.HK_F_CAN_MOVE)).any()
+    assert (st["vx"] == 0).all() and (st["vz"] == 0).all()
+
+
+def test_deterministic_and_snapshot_restore():
+    b = make_config(3, 4, jitter_seed=0x5EED0000)
+    o1, o2 = O.OracleEnv(b), O.OracleEnv(b)
+    o1.reset(); o2.reset()
+    o1.step(300)
+    o2.step(150)
+    snap_a, snap_e = o2.agent_state(), o2.env_state()
+    o3 = O.OracleEnv(b)
+    o3.set_agent_state(snap_a); o3.set_env_state(snap_e)
+    o2.step(150); o3.step(150)
+    for name in snap_a.dtype.names:
+        assert np.array_equal(o1.agent_state()[name], o2.agent_state()[name])
+        assert np.array_equal(o1.agent_state()[name], o3.agent_state()[name])
+    # jitter de-synchronises the envs, and differs per env id
+    s = o1.agent_state()
+    assert not np.array_equal(s["px"][0], s["px"][1])
+
+
+def test_timeout_and_auto_reset():
+    b = make_config(2, 2, max_episode_steps=200, auto_reset=1)
+    o = O.OracleEnv(b)
+    o.reset(experiment_num=0)
+    o.step(199)
+    assert (o.env_state()["episodes_done"] == 0).all()
+    o.step(1)                                  # episode_steps reaches 200 -> deactivate, log, experiment++, reset
+    es = o.env_state()
+    assert (es["episodes_done"] == 1).all() and (es["experiment_num"] == 1).all() and (es["episode_steps"] == 0).all()
+    assert (es["status"] & 2).all()
+    res = o.episode_results()
+    assert (res["time_steps"] == 0).all() and (res["episode"] == 0).all()       # nobody finished (REC:470 never ran)
+    st = o.agent_state()
+    assert (st["flags"] & HL.HK_F_ACTIVE).all() and (st["section_index"][:, 0] == 0).all()
+
+
+def test_observation_layout():
+    A = 4
+    o = O.OracleEnv(make_config(1, A))
+    o.reset(experiment_num=0)
+    o.step(120)
+    obs = o.observations()
+    assert obs.shape == (1, A, 9 + 5 * 5 + 8 + 12 * 3)              # HKA:424 -> 78 at A = 4, H = 5
+    st = o.agent_state()[0]
+    for i in range(A):
+        v = obs[0, i]
+        assert v[2] == st[i]["lane"] and v[4] == 1.0 and abs(v[5] - st[i]["section_index"] / 97.0) < 1e-6
+        assert 0.0 <= v[7] <= 1.0                                   # tire wear proportion
+        rays = v[-9:]
+        assert (rays > 0).all() and (rays <= 20.0).all()
+    # two karts side by side on the grid (x = 14.62 / 17.12, walls at 11.28 / 20.48): the +-90 degree rays see the
+    # neighbour's capsule (2.5 - 0.4425) on one side and the wall on the other (HKA:580-598, nearer hit wins)
+    o2 = O.OracleEnv(make_config(1, 2))
+    o2.reset(experiment_num=0)
+    o2.step(10)
+    r = o2.observations()[0][:, -9:]
+    assert abs(r[0][3] - (2.5 - 0.4425)) < 5e-3 and abs(r[0][6] - (14.62 - 11.28)) < 5e-3
+    assert abs(r[1][6] - (2.5 - 0.4425)) < 5e-3 and abs(r[1][3] - (20.48 - 17.12)) < 5e-3
+    assert r[0][0] == 20.0                                            # nothing ahead within RayDistance
+
+
+def test_trajectory_hash_pin():
+    """Episode-level bit-reproducibility pin: 2-agent Fixed-vs-Fixed Oval, 4 096 ticks, hash of the raw
+    agent records every 512 ticks.  The GPU test compares the same hashes."""
+    b = make_config(1, 2, jitter_seed=0)
+    o = O.OracleEnv(b)
+    o.reset(experiment_num=0)
+    hashes = []
+    for _ in range(8):
+        o.step(512)
+        hashes.append(hashlib.sha256(o.agent_state().tobytes()).hexdigest())
+    path = os.path.join(GOLD, "oval_2agent_4096_hash.json")
+    if os.environ.get("HK_REGEN_GOLDEN") == "1":
+        with open(path, "w") as f:
+            json.dump({"generator": "tests/test_oracle_env.py::test_trajectory_hash_pin (HK_REGEN_GOLDEN=1), CPU oracle",
+                       "config": "make_config(1, 2, jitter_seed=0), reset(experiment_num=0)", "every": 512, "sha256": hashes}, f, indent=1)
+    want = json.load(open(path))["sha256"]
+    assert hashes == want
