@@ -24,6 +24,9 @@ struct EnvDevice {
     float* act_steer = nullptr;
     int32_t* act_branch = nullptr;
     int* status = nullptr;
+    GameDesc* games = nullptr;     // [E][A] compact LQ games written by K_B1
+    int* queue_cnt = nullptr;      // [8] number of multi-player games per player count (this tick)
+    int* queue = nullptr;          // [3][E*A] game ids with N = 2, 3, 4
     int* env_ids = nullptr;
     int env_ids_cap = 0;
     // tables
@@ -71,7 +74,7 @@ int upload(T** dst, const std::vector<T>& v, std::string& err)
 
 inline void env_destroy(EnvDevice& d)
 {
-    void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.status, d.env_ids, d.sec,
+    void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.status, d.games, d.queue_cnt, d.queue, d.env_ids, d.sec,
                     d.walls, d.near_off, d.near_idx, d.far_off, d.far_idx, d.cut, d.perms};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = EnvDevice{};
@@ -149,7 +152,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         off[L] = (int)idx.size();
     };
     std::vector<int> noff, nidx, foff, fidx;
-    build_list(8.0, noff, nidx);     // contacts: lateral 5.7 (incl. chord sagitta) + capsule reach 1.1 + margin
+    build_list(8.5, noff, nidx);     // contacts (reach 1.1 m) and the 2 m side rays: lateral 5.7 (incl. chord sagitta) + 0.1 + 2.0 + margin
     build_list(16.0, foff, fidx);    // rays up to 8 m from the sensor origin
     // cut table: Physics.Raycast(lane marker -> next lane marker) vs every wall (HKA:832), static geometry
     std::vector<unsigned char> cut((size_t)L * 25, 0);
@@ -202,6 +205,9 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     HK_ALLOC(d.act_steer, na * sizeof(float));
     HK_ALLOC(d.act_branch, na * sizeof(int32_t));
     HK_ALLOC(d.status, 4 * sizeof(int));
+    HK_ALLOC(d.games, na * sizeof(GameDesc));
+    HK_ALLOC(d.queue_cnt, 8 * sizeof(int));
+    HK_ALLOC(d.queue, 3 * na * sizeof(int));
 #undef HK_ALLOC
     // REC.Start :148-168: every agent starts inactive; results carry episode = -1; RL branch defaults to "coast"
     {
@@ -260,15 +266,35 @@ inline int env_reset(EnvDevice& d, const hk_config& cfg, const int32_t* env_ids,
 inline int env_launch_begin(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
 {
     const int threads = cfg.num_envs * 4;
-    hipLaunchKernelGGL(env_begin_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.envs, d.results);
+    hipLaunchKernelGGL(env_begin_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.envs, d.results, d.queue_cnt);
     return launch_check(err, "env_begin_kernel");
 }
 
-// K_B: SolveLQR for every ego (the dominant kernel)
+// K_B: SolveLQR for every ego = game assembly (K_B1), then the Riccati solves binned by player count (K_B2)
 inline int env_launch_solve(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
 {
-    hipLaunchKernelGGL(env_solve_kernel, dim3(cfg.num_envs), dim3(64), 0, stream, d.P, d.agents, d.envs, d.lq_debug, d.status);
-    return launch_check(err, "env_solve_kernel");
+    const int ngames = cfg.num_envs * cfg.num_agents;
+    const int threads = cfg.num_envs * 4;
+    hipLaunchKernelGGL(env_assemble_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.envs, d.games,
+                       d.queue_cnt, d.queue, d.lq_debug);
+    int rc = launch_check(err, "env_assemble_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(lq1_kernel, dim3((ngames + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.games, ngames, d.lq_debug, d.status);
+    if ((rc = launch_check(err, "lq1_kernel"))) return rc;
+    if (cfg.num_agents >= 2) {
+        const int blocks = std::min((ngames + 3) / 4, 4096);
+        hipLaunchKernelGGL(lqn_kernel<2>, dim3(blocks), dim3(64), 0, stream, d.P, d.agents, d.games, d.queue_cnt, d.queue, d.lq_debug, d.status);
+        if ((rc = launch_check(err, "lqn_kernel<2>"))) return rc;
+        if (cfg.num_agents >= 3) {
+            hipLaunchKernelGGL(lqn_kernel<3>, dim3(blocks), dim3(64), 0, stream, d.P, d.agents, d.games, d.queue_cnt, d.queue, d.lq_debug, d.status);
+            if ((rc = launch_check(err, "lqn_kernel<3>"))) return rc;
+        }
+        if (cfg.num_agents >= 4) {
+            hipLaunchKernelGGL(lqn_kernel<4>, dim3(blocks), dim3(64), 0, stream, d.P, d.agents, d.games, d.queue_cnt, d.queue, d.lq_debug, d.status);
+            if ((rc = launch_check(err, "lqn_kernel<4>"))) return rc;
+        }
+    }
+    return HK_OK;
 }
 
 inline int env_launch_step(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)

@@ -1,39 +1,46 @@
-// hk_env_solve.h — HierarchicalKartAgent.SolveLQR (HKA:699-1236) for every ego of a race instance: one wavefront
-// per env, 16-lane group g = ego g.  Game assembly (players within 8 m, targets, the 7-branch heading heuristic with
-// analytic wall raycasts, weights, reach-avoid costs) runs lane-per-player; the coupled Riccati solve is hk_lq_core.h.
+// hk_env_solve.h — HierarchicalKartAgent.SolveLQR (HKA:699-1236) on gfx950, split in two stages so that each runs
+// at full lane utilisation:
+//
+//   K_B1 env_assemble_kernel   quad per env, lane = ego.  Sensor rays of the ego's own kart, then the ego's game:
+//                              players within 8 m, per player initial/target/weights and the 7-branch heading heuristic
+//                              (HKA:726-1198).  Writes one compact GameDesc per ego and bins the game by player count.
+//   K_B2 lq1_kernel            one THREAD per single-player game (n = 4, m = 2): the whole Riccati recursion in
+//                              registers.  Once the field has spread out (> 8 m apart) ~99 % of all games are of this kind.
+//        lqn_kernel<N>         multi-player games (N = 2..4) from the per-N queues, 4 games per wave, 16-lane group per
+//                              game, through hk_lq_core.h.
+//   both decode u0 -> (Accelerate, Brake, Steering) (HKA:1206-1224).
+//
+// Results are bit-identical to the CPU oracle's dense restatement: see the arithmetic contract in hk_lq_core.h.
 #pragma once
 #include "hk_env_device.h"
 #include "hk_lq_core.h"
 
 namespace hk {
 
-struct KartL {                 // per-kart quantities staged in LDS for the assembly
-    float px, pz, yaw, fx, fz, speed, heading, final_steer, msfs;
-    int sec, straight;
-    uint32_t flags;
-    int pl1, pl2;              // plan_lane at (sec+1)%L, (sec+2)%L
-    float pv1, pv2;
-    float ray[5];              // nearest wall distance along sensors 0, 2, 4, 8, 6 (3e38 = none)
-    float dC;                  // distance to the Trigger box of section (sec+1)%L
+struct GamePlayer {            // one player's share of a game, ego-local order (Q3)
+    double x0[4];              // initial (x, z, v, heading)                                  HKA:730-736
+    double a4[4];              // A[x,v], A[z,v], A[x,h], A[z,h]                              KartLQRDynamics.cs:45-48
+    double tw[4];              // target weights                                              HKA:930-964
+    double tgt[4];             // target state                                                HKA:808-926
+    double rc;                 // control weight                                              HKA:1192-1196
+    double aw[3];              // avoid weight per other player (x and z share it)            HKA:1019,1114
+    double opw[3][3];          // opponent-target weights (x, z, v)                           HKA:1073-1093,1168-1188
+    double opt[3][3];          // opponent target (x, z, v); heading entry is never set -> 0  HKA:1065-1067
+    int M, agent, branch, pad_;
 };
-
-struct AsmGroup {              // per-ego assembly scratch (compact cost description)
-    double QC[LQ_MAXP][4][LQ_MAXN];   // QC[i][b'][r] = Q_i[r][4b' + (r&3)]
-    double QV[LQ_MAXP][LQ_MAXN];
-    double tw[LQ_MAXP][4];
-    double tgt[LQ_MAXP][4];
-    double aw[LQ_MAXP][3];
-    double opw[LQ_MAXP][3][3];
-    double opt[LQ_MAXP][3][4];
-    int M[LQ_MAXP];
+struct GameDesc {
+    int N;                     // 0: this ego does not solve on this tick
     int pad_;
+    GamePlayer p[LQ_MAXP];
 };
 
-struct QCompact {
-    const double* QC;
-    const double* QV;
-    __device__ double Q(int i, int r, int c) const { return ((c & 3) == (r & 3)) ? QC[(i * 4 + (c >> 2)) * LQ_MAXN + r] : 0.0; }
-    __device__ double q(int i, int r) const { return QV[i * LQ_MAXN + r]; }
+struct KartS {                 // per-kart staging (LDS), filled by the kart's own lane
+    float px, pz, yaw, fx, fz, speed, heading, msfs, dC;
+    float ray[5];              // nearest wall distance along sensors 0, 2, 4, 8, 6 (3e38 = none)
+    int sec, straight, pl1, pl2;
+    float pv1, pv2;
+    uint32_t flags;
+    int pad_;
 };
 
 __device__ __forceinline__ double angle_difference(double a1, double a2)
@@ -41,42 +48,50 @@ __device__ __forceinline__ double angle_difference(double a1, double a2)
     return hk_atan2(hk_sin(a2 - a1), hk_cos(a2 - a1));
 }
 
-__global__ __launch_bounds__(64) void env_solve_kernel(EnvParams P, hk_agent_state* agents, const hk_env_state* envs,
-                                                       hk_lq_debug* dbg_out, int* status)
+// ---------------------------------------------------------------------------------------------------------------
+// K_B1
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void env_assemble_kernel(EnvParams P, const hk_agent_state* agents, const hk_env_state* envs,
+                                                           GameDesc* games, int* queue_cnt, int* queue, hk_lq_debug* dbg_out)
 {
-    __shared__ LqGroupLds lds[4];
-    __shared__ AsmGroup asg[4];
-    __shared__ KartL kl[ENV_MAXA];
-    const int env = blockIdx.x;
-    const int lane = threadIdx.x & 63;
-    const int g = lane >> 4, r = lane & 15;
+    __shared__ KartS ks[256];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int env = gid >> 2, ego = gid & 3;
     const int A = P.A, L = P.L;
-    const hk_env_state es = envs[env];
-    const uint32_t all_mask = (1u << A) - 1u;
-    if ((es.episode_steps % (A > 2 ? 4 : 1)) != 0) return;                       // HKA:317 cadence (Q9)
-    if (!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u)) return;
-    hk_agent_state* ags = agents + (size_t)env * A;
-    // ---- 1. stage karts
-    if (lane < A) {
-        const hk_agent_state* a = &ags[lane];
-        KartL k;
+    const bool env_ok = env < P.E;
+    bool act = false;            // does this env solve on this tick?
+    hk_env_state es;
+    es.episode_steps = 0; es.inactive_mask = 0; es.status = 0;
+    if (env_ok) {
+        es = envs[env];
+        const uint32_t all_mask = (1u << A) - 1u;
+        act = (es.episode_steps % (A > 2 ? 4 : 1)) == 0;                              // HKA:317 (Q9)
+        if (!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u)) act = false;
+    }
+    const bool me = act && ego < A;
+    if (env_ok && ego < A && !act) games[(size_t)env * A + ego].N = 0;      // nothing to solve for this env on this tick
+    const hk_agent_state* a = me ? &agents[(size_t)env * A + ego] : nullptr;
+    KartS k;
+    k.px = k.pz = k.yaw = k.fx = k.fz = k.speed = k.heading = k.msfs = k.dC = 0.0f;
+    k.sec = 0; k.straight = 1; k.pl1 = k.pl2 = 0; k.pv1 = k.pv2 = 0.0f; k.flags = 0; k.pad_ = 0;
+#pragma unroll
+    for (int q = 0; q < 5; q++) k.ray[q] = 3.0e38f;
+    if (me) {
         k.px = a->px; k.pz = a->pz; k.yaw = a->yaw;
         k.fx = hk_sinf(k.yaw); k.fz = hk_cosf(k.yaw);
         const float vx = a->vx, vz = a->vz;
         k.speed = mag3(vx, 0.0f, vz);
-        float heading = hk_atan2f(k.fz, k.fx);                                    // HKA:734
+        float heading = hk_atan2f(k.fz, k.fx);                                        // HKA:734
         if (heading < 0) heading += TWO_PI_F;
         k.heading = heading;
-        k.final_steer = a->final_steer;
-        k.msfs = max_speed_for_state(P, k.yaw, vx, vz, a->wy, k.final_steer);
+        k.msfs = max_speed_for_state(P, k.yaw, vx, vz, a->wy, a->final_steer);
         k.sec = a->section_index;
         k.straight = is_straight(P, k.sec) ? 1 : 0;
         k.flags = a->flags;
         const int i1 = (k.sec + 1) % L, i2 = (k.sec + 2) % L;
         k.pl1 = a->plan_lane[i1]; k.pv1 = a->plan_vel[i1];
         k.pl2 = a->plan_lane[i2]; k.pv2 = a->plan_vel[i2];
-        // BoxCollider.ClosestPoint distance to the next section's Trigger (HKA:846,876)
-        {
+        {   // BoxCollider.ClosestPoint distance to the next section's Trigger (HKA:846,876)
             const SecDev& s = P.sec[i1];
             float relx = k.px - s.trig_x, relz = k.pz - s.trig_z;
             float lx = relx * s.fz + relz * (-s.fx);
@@ -85,115 +100,100 @@ __global__ __launch_bounds__(64) void env_solve_kernel(EnvParams P, hk_agent_sta
             float dz = lz - f_clamp(lz, -TRIG_HZ, TRIG_HZ);
             k.dC = sqrtf(dx * dx + dz * dz);
         }
-        for (int q = 0; q < 5; q++) k.ray[q] = 3.0e38f;
-        kl[lane] = k;
-    }
-    __syncthreads();
-    // ---- 2. sensor rays of kart g against the candidate walls, 16 lanes wide
-    if (g < A) {
-        const int ssel[5] = {0, 2, 4, 8, 6};
-        const KartL& k = kl[g];
+        // sensor rays of the own kart (Physics.Raycast vs TrackMask, HKA:834-844,906): sensor 0 may reach 8 m (far
+        // list), sensors 2, 4, 8, 6 at most 2 m (near list); both lists are supersets of what the ray can reach
         const float ox = k.px + SENSOR_LZ * k.fx, oz = k.pz + SENSOR_LZ * k.fz;
-        float ddx[5], ddz[5], best[5];
-#pragma unroll
-        for (int q = 0; q < 5; q++) {
-            float ang = k.yaw + P.sensor_yaw[ssel[q]] * DEG2RAD_F;
-            ddx[q] = hk_sinf(ang); ddz[q] = hk_cosf(ang);
-            best[q] = 3.0e38f;
-        }
         const int sidx = k.sec % L;
-        const int w0 = P.far_off[sidx], w1 = P.far_off[sidx + 1];
-        for (int w = w0 + r; w < w1; w += 16) {
-            const hk_wall_seg ws = P.walls[P.far_idx[w]];
-#pragma unroll
-            for (int q = 0; q < 5; q++) {
-                float t = ray_seg(ox, oz, ddx[q], ddz[q], ws);
-                if (t >= 0.0f && t < best[q]) best[q] = t;
+        {
+            const float dx = k.fx, dz = k.fz;       // sensor 0: yaw + 0
+            const float ang0 = k.yaw + P.sensor_yaw[0] * DEG2RAD_F;
+            const float d0x = hk_sinf(ang0), d0z = hk_cosf(ang0);
+            (void)dx; (void)dz;
+            float best = 3.0e38f;
+            const int w0 = P.far_off[sidx], w1 = P.far_off[sidx + 1];
+            for (int w = w0; w < w1; w++) {
+                float t = ray_seg(ox, oz, d0x, d0z, P.walls[P.far_idx[w]]);
+                if (t >= 0.0f && t < best) best = t;
             }
+            k.ray[0] = best;
         }
+        {
+            const int ssel[4] = {2, 4, 8, 6};
+            float ddx[4], ddz[4], best[4];
 #pragma unroll
-        for (int q = 0; q < 5; q++) {
-            float b = best[q];
-            b = f_min(b, __shfl_xor(b, 1, 64)); b = f_min(b, __shfl_xor(b, 2, 64));
-            b = f_min(b, __shfl_xor(b, 4, 64)); b = f_min(b, __shfl_xor(b, 8, 64));
-            if (r == 0) kl[g].ray[q] = b;
+            for (int q = 0; q < 4; q++) {
+                float ang = k.yaw + P.sensor_yaw[ssel[q]] * DEG2RAD_F;
+                ddx[q] = hk_sinf(ang); ddz[q] = hk_cosf(ang);
+                best[q] = 3.0e38f;
+            }
+            const int w0 = P.near_off[sidx], w1 = P.near_off[sidx + 1];
+            for (int w = w0; w < w1; w++) {
+                const hk_wall_seg ws = P.walls[P.near_idx[w]];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float t = ray_seg(ox, oz, ddx[q], ddz[q], ws);
+                    if (t >= 0.0f && t < best[q]) best[q] = t;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) k.ray[1 + q] = best[q];
         }
     }
+    ks[threadIdx.x] = k;
     __syncthreads();
-    // ---- 3. game assembly: group g = ego g, lane r = player slot
-    LqGroupLds& LG = lds[g];
-    AsmGroup& AG = asg[g];
-    const int ego = g;
-    int N = 0, nearbyAgents = -1;
+    if (!me) return;
+    const KartS* kq = &ks[threadIdx.x & ~3];          // the env's four karts
+    GameDesc* G = &games[(size_t)env * A + ego];
+    const bool solving = (k.flags & HK_F_ENABLED) && P.low_mode[ego] == HK_LOW_LQR && !((es.inactive_mask >> ego) & 1u);
+    if (!solving) { G->N = 0; return; }
+    // ---- players (HKA:702-725)
     int pl[ENV_MAXA] = {0, 0, 0, 0};
-    bool solving = false;
-    if (ego < A) {
-        const uint32_t efl = kl[ego].flags;
-        solving = (efl & HK_F_ENABLED) && P.low_mode[ego] == HK_LOW_LQR && !((es.inactive_mask >> ego) & 1u);
-    }
-    if (solving) {
-        int all[ENV_MAXA], nall = 0;                                              // HKA:702
+    int N = 0, nearbyAgents = -1;
+    {
+        int all[ENV_MAXA], nall = 0;
         all[nall++] = ego;
         for (int j = 0; j < P.n_team[ego]; j++) all[nall++] = P.team[ego][j];
         for (int j = 0; j < P.n_other[ego]; j++) all[nall++] = P.other[ego][j];
-        if (A > 2) {                                                              // :709-720
+        if (A > 2) {
             for (int q = 0; q < nall; q++) {
-                const KartL& k = kl[all[q]];
-                if (mag3(k.px - kl[ego].px, 0.0f, k.pz - kl[ego].pz) < 8) { nearbyAgents += 1; pl[N++] = all[q]; }
+                const KartS& o = kq[all[q]];
+                if (mag3(o.px - k.px, 0.0f, o.pz - k.pz) < 8) { nearbyAgents += 1; pl[N++] = all[q]; }
             }
         } else {
             for (int q = 0; q < nall; q++) pl[N++] = all[q];
         }
-        nearbyAgents = nearbyAgents > 1 ? nearbyAgents : 1;                       // :725
+        nearbyAgents = nearbyAgents > 1 ? nearbyAgents : 1;
     }
-    const bool fixed = ego < A ? (P.high_mode[ego] == HK_HIGH_FIXED) : true;
-    // zero the game inputs, then let the player lanes fill theirs
-#pragma unroll
-    for (int i = 0; i < LQ_MAXP; i++) {
-        LG.Ab[i][r] = 0.0;
-        if (r < 8) LG.Bb[i][r] = 0.0;
-        if (r < 4) LG.Rb[i][r] = 0.0;
-    }
-    LG.x0[r] = 0.0;
-    __syncthreads();
-    int branch = 0;
-    double controlcost = 0.0;
-    if (solving && r < N) {
-        const int i = r;
+    const bool fixed = P.high_mode[ego] == HK_HIGH_FIXED;
+    const float dy = P.sec[0].marker_y - P.kart_y;                                    // Q13
+    const KartS& mek = kq[ego];
+    for (int i = 0; i < N; i++) {                                                     // HKA:726
         const int ki = pl[i];
-        const KartL& k = kl[ki];
-        const KartL& me = kl[ego];
-        const float dy = P.sec[0].marker_y - P.kart_y;                            // Q13
-        const float speed = k.speed;
+        const KartS& kk = kq[ki];
+        GamePlayer* gp = &G->p[i];
+        const float speed = kk.speed;
         double initial[4];
-        initial[0] = k.px; initial[1] = k.pz; initial[2] = speed; initial[3] = k.heading;   // :731-736
+        initial[0] = kk.px; initial[1] = kk.pz; initial[2] = speed; initial[3] = kk.heading;
         {   // LinearizedBicycle (KartLQRDynamics.cs:40-62), dt = Time.fixedDeltaTime widened to double (HKA:707)
             const double dt = (double)P.dt;
-            double* Am = LG.Ab[i];
-            double* Bm = LG.Bb[i];
-            Am[0] = 1.0; Am[5] = 1.0; Am[10] = 1.0; Am[15] = 1.0;
-            Am[0 * 4 + 2] = hk_cos(initial[3]) * dt;
-            Am[1 * 4 + 2] = hk_sin(initial[3]) * dt;
-            Am[0 * 4 + 3] = -hk_sin(initial[3]) * dt * initial[2];
-            Am[1 * 4 + 3] = hk_cos(initial[3]) * dt * initial[2];
-            Bm[2 * 2 + 0] = dt;
-            Bm[3 * 2 + 1] = dt;
-#pragma unroll
-            for (int c = 0; c < 4; c++) LG.x0[4 * i + c] = initial[c];
+            gp->a4[0] = hk_cos(initial[3]) * dt;
+            gp->a4[1] = hk_sin(initial[3]) * dt;
+            gp->a4[2] = -hk_sin(initial[3]) * dt * initial[2];
+            gp->a4[3] = hk_cos(initial[3]) * dt * initial[2];
         }
-        const int s = k.sec + 1;                                                  // :746
+        const int s = kk.sec + 1;                                                     // :746
         const int idx = s % L, idx2 = (s + 1) % L;
         int laneSel = 0, nextSel = 0;
         double vel = P.max_speed, nextVel = P.max_speed;
-        if (ki == ego) {                                                          // :752-764, :782-794
-            if (me.pl1 != 0) {
-                laneSel = me.pl1;
-                double pv = me.pv1 + (fixed ? 0 : P.vbucket[ego] * 2);
+        if (ki == ego) {                                                              // :752-764, :782-794
+            if (mek.pl1 != 0) {
+                laneSel = mek.pl1;
+                double pv = mek.pv1 + (fixed ? 0 : P.vbucket[ego] * 2);
                 vel = (double)P.max_speed < pv ? (double)P.max_speed : pv;
             }
-            if (me.pl2 != 0) {
-                nextSel = me.pl2;
-                double pv = me.pv2 + (fixed ? 0 : P.vbucket[ego] * 2);
+            if (mek.pl2 != 0) {
+                nextSel = mek.pl2;
+                double pv = mek.pv2 + (fixed ? 0 : P.vbucket[ego] * 2);
                 nextVel = (double)P.max_speed < pv ? (double)P.max_speed : pv;
             }
         }   // else: the ego's belief about k's plan is only ever filled by the MCTS planner -> Trigger / max speed
@@ -203,48 +203,48 @@ __global__ __launch_bounds__(64) void env_solve_kernel(EnvParams P, hk_agent_sta
         lane_marker(P, idx, 0, cx, cz);
         double target[4];
         target[0] = lx; target[1] = lz;
-        target[2] = (speed <= 5.0f) ? 0.0f : vel;                                  // :810-817
+        target[2] = (speed <= 5.0f) ? 0.0f : vel;                                     // :810-817
         double fth;
-        float targetHeading = hk_atan2f(lz - k.pz, lx - k.px);                     // :821
+        int branch;
+        float targetHeading = hk_atan2f(lz - kk.pz, lx - kk.px);                      // :821
         if (targetHeading < 0) targetHeading += TWO_PI_F;
-        if (mag3(lx - k.px, dy, lz - k.pz) <= (k.straight ? 10.5f : 7.5f)) {       // :823
-            float h1 = hk_atan2f(lz - k.pz, lx - k.px);
-            float h2 = hk_atan2f(nz - lz, nx - lx);
-            float h5 = hk_atan2f(cz - k.pz, cx - k.px);
-            float h6 = hk_atan2f(nz - k.pz, nx - k.px);
-            const bool cutTrack = P.cut[(idx * 5 + laneSel) * 5 + nextSel] != 0;   // :832 (static geometry)
-            const bool hit0 = k.ray[0] <= speed * 0.5f;                            // :834
-            const bool hit1 = k.ray[1] <= 2.0f, hit2 = k.ray[2] <= 1.5f, hit3 = k.ray[3] <= 1.5f, hit4 = k.ray[4] <= 2.0f;
-            const float dC = k.dC;
-            const bool side = hit1 || hit2 || hit3 || hit4;
-            if (cutTrack && dC > 4.0f) {                                           // B1 :846
+        if (mag3(lx - kk.px, dy, lz - kk.pz) <= (kk.straight ? 10.5f : 7.5f)) {       // :823
+            float h1 = hk_atan2f(lz - kk.pz, lx - kk.px);
+            float h5 = hk_atan2f(cz - kk.pz, cx - kk.px);
+            const bool cutTrack = P.cut[(idx * 5 + laneSel) * 5 + nextSel] != 0;      // :832 (static geometry)
+            const bool hit0 = kk.ray[0] <= speed * 0.5f;                              // :834
+            const bool side = (kk.ray[1] <= 2.0f) || (kk.ray[2] <= 1.5f) || (kk.ray[3] <= 1.5f) || (kk.ray[4] <= 2.0f);
+            const float dC = kk.dC;
+            if (cutTrack && dC > 4.0f) {                                              // B1 :846
                 branch = 1;
                 if (h5 < 0) h5 += TWO_PI_F;
                 fth = h5;
                 if (fth < 0) fth += TWO_PI_F;
                 fth = initial[3] - angle_difference(initial[3], fth);
-            } else if ((side && (f_sign(h1) == f_sign(h5))) || hit0) {             // B2 :857 (Q12)
+            } else if ((side && (f_sign(h1) == f_sign(h5))) || hit0) {                // B2 :857 (Q12)
                 branch = 2;
                 if (h5 < 0) h5 += TWO_PI_F;
                 fth = h5 - angle_difference(h1, h5) * 0.7f;
                 if (fth < 0) fth += TWO_PI_F;
                 fth = initial[3] - angle_difference(initial[3], fth);
-            } else if (side && (f_sign(h1) != f_sign(h5))) {                       // B3 :867
+            } else if (side && (f_sign(h1) != f_sign(h5))) {                          // B3 :867
                 branch = 3;
                 if (h5 < 0) h5 += TWO_PI_F;
                 fth = h5;
                 if (fth < 0) fth += TWO_PI_F;
                 fth = initial[3] - angle_difference(initial[3], fth);
-            } else if (dC <= 4.0f) {                                               // B4 :876
+            } else if (dC <= 4.0f) {                                                  // B4 :876
                 branch = 4;
+                float h6 = hk_atan2f(nz - kk.pz, nx - kk.px);
                 target[0] = nx; target[1] = nz;
                 if (speed > 5.0f) target[2] = nextVel;
                 if (h6 < 0) h6 += TWO_PI_F;
                 fth = h6;
                 if (fth < 0) fth += TWO_PI_F;
                 fth = initial[3] - angle_difference(initial[3], fth);
-            } else {                                                               // B5 :891
+            } else {                                                                  // B5 :891
                 branch = 5;
+                float h2 = hk_atan2f(nz - lz, nx - lx);
                 if (h1 < 0) h1 += TWO_PI_F;
                 if (h2 < 0) h2 += TWO_PI_F;
                 fth = h1 - angle_difference(h2, h1) * 0.4f;
@@ -252,19 +252,19 @@ __global__ __launch_bounds__(64) void env_solve_kernel(EnvParams P, hk_agent_sta
                 fth = initial[3] - angle_difference(initial[3], fth);
             }
         } else {
-            const bool hit = k.ray[0] <= (k.straight ? 8.0f : 5.0f);               // :906
-            if (hit) {                                                             // B6
+            const bool hit = kk.ray[0] <= (kk.straight ? 8.0f : 5.0f);                // :906
+            if (hit) {                                                                // B6
                 branch = 6;
-                float h1 = hk_atan2f(cz - k.pz, cx - k.px);
+                float h1 = hk_atan2f(cz - kk.pz, cx - kk.px);
                 if (h1 < 0) h1 += TWO_PI_F;
                 fth = initial[3] - angle_difference(initial[3], h1) * 0.85f;
-            } else {                                                               // B7
+            } else {                                                                  // B7
                 branch = 7;
                 fth = initial[3] - angle_difference(initial[3], targetHeading);
             }
         }
-        target[3] = fth;                                                           // :926
-        double tw[4];                                                              // :930-964
+        target[3] = fth;                                                              // :926
+        double tw[4];                                                                 // :930-964
         if (N > 2) tw[3] = (fixed ? 2.5 : 3.5) * nearbyAgents; else tw[3] = (fixed ? 1.9 : 3.5);
         if (speed <= 5.0f) {
             tw[0] = nearbyAgents * 0.3 * 3.1; tw[1] = nearbyAgents * 0.3 * 3.1; tw[2] = nearbyAgents * -2;
@@ -272,42 +272,42 @@ __global__ __launch_bounds__(64) void env_solve_kernel(EnvParams P, hk_agent_sta
             double mx = initial[2] > 1 ? initial[2] : 1;
             tw[0] = nearbyAgents * 0.3 * 3.1 / mx; tw[1] = nearbyAgents * 0.3 * 3.1 / mx; tw[2] = nearbyAgents * 5e-4;
         }
-        float multiplier;                                                          // :976-1003
+        float multiplier;                                                             // :976-1003
         if (A > 2 && N > 2) multiplier = (ki == ego ? (fixed ? 0.55f : 1.0f) : 1.7f) / nearbyAgents;
         else multiplier = (ki == ego ? (fixed ? 0.45f : 1.0f) : 1.3f);
         int M = 0, nearbyOpponents = 0;
         const int no = P.n_other[ki], nt = P.n_team[ki];
-        for (int j = 0; j < no + nt; j++) {                                        // :1004-1190, k's own order (Q3)
+        for (int j = 0; j < no + nt; j++) {                                           // :1004-1190, k's own order (Q3)
             const bool isteam = j >= no;
             const int oi = isteam ? P.team[ki][j - no] : P.other[ki][j];
             bool member = false;
             for (int q = 0; q < N; q++) if (pl[q] == oi) member = true;
             if (!member) continue;
-            const KartL& o = kl[oi];
-            const float dist = mag3(o.px - k.px, 0.0f, o.pz - k.pz);
+            const KartS& o = kq[oi];
+            const float dist = mag3(o.px - kk.px, 0.0f, o.pz - kk.pz);
             const bool far = (dist > 8) || !(o.flags & HK_F_ACTIVE);
             double w = 0.0;
             if (!far) {
                 float mult = isteam ? multiplier / 2.0f : multiplier;
-                float pw = (float)((double)dist * sqrt((double)dist));            // Mathf.Pow(d, 1.5f)
+                float pw = (float)((double)dist * sqrt((double)dist));                // Mathf.Pow(d, 1.5f)
                 w = 1.0f / (pw * mult);
                 if (!isteam) nearbyOpponents += 1;
             }
-            AG.aw[i][M] = w;
+            gp->aw[M] = w;
             const int io = (o.sec + 1) % L;
             float olx, olz; double ov;
             if (oi == ego) {
-                lane_marker(P, io, me.pl1, olx, olz);
-                if (isteam) ov = me.msfs;
-                else if (me.pl1 != 0) {
-                    double pv = me.pv1 + (fixed ? 0 : P.vbucket[ego] * 2);
+                lane_marker(P, io, mek.pl1, olx, olz);
+                if (isteam) ov = mek.msfs;
+                else if (mek.pl1 != 0) {
+                    double pv = mek.pv1 + (fixed ? 0 : P.vbucket[ego] * 2);
                     ov = (double)P.max_speed < pv ? (double)P.max_speed : pv;
                 } else ov = P.max_speed;
             } else {
                 lane_marker(P, io, 0, olx, olz);
                 ov = isteam ? o.msfs : P.max_speed;
             }
-            AG.opt[i][M][0] = olx; AG.opt[i][M][1] = olz; AG.opt[i][M][2] = ov; AG.opt[i][M][3] = 0.0;
+            gp->opt[M][0] = olx; gp->opt[M][1] = olz; gp->opt[M][2] = ov;
             double mx = initial[2] > 1 ? initial[2] : 1;
             double w0, w1, w2;
             if (!isteam) {
@@ -319,90 +319,315 @@ __global__ __launch_bounds__(64) void env_solve_kernel(EnvParams P, hk_agent_sta
                 else if (N > 2) { w0 = -(fixed ? 0 : 3e-5) / (mx * nearbyAgents); w1 = -(fixed ? 0 : 3e-5) / (mx * nearbyAgents); w2 = 0 / nearbyAgents; }
                 else { w0 = -(fixed ? 1e-4 : 2e-4) / mx; w1 = -(fixed ? 1e-4 : 2e-4) / mx; w2 = 0; }
             }
-            AG.opw[i][M][0] = w0; AG.opw[i][M][1] = w1; AG.opw[i][M][2] = w2;
+            gp->opw[M][0] = w0; gp->opw[M][1] = w1; gp->opw[M][2] = w2;
             M++;
         }
-        AG.M[i] = M;
-        controlcost = 0.115;                                                       // :1192-1196
+        double controlcost = 0.115;                                                   // :1192-1196
         if (N > 2) controlcost = fixed ? 0.135 : 0.25;
-        LG.Rb[i][0] = 1.0 * controlcost; LG.Rb[i][3] = 1.0 * controlcost;          // getRMatrix KartLQRCosts.cs:132-140
+        gp->rc = 1.0 * controlcost;                                                   // getRMatrix: SparseIdentity * w
+        gp->M = M; gp->agent = ki; gp->branch = branch;
 #pragma unroll
-        for (int c = 0; c < 4; c++) { AG.tw[i][c] = tw[c]; AG.tgt[i][c] = target[c]; }
+        for (int c = 0; c < 4; c++) { gp->x0[c] = initial[c]; gp->tw[c] = tw[c]; gp->tgt[c] = target[c]; }
         if (dbg_out && P.debug) {
             hk_lq_debug* d = &dbg_out[(size_t)env * A + ego];
             d->player_agent[i] = ki; d->branch[i] = branch; d->control_w[i] = controlcost;
             for (int c = 0; c < 4; c++) { d->initial[i][c] = initial[c]; d->target[i][c] = target[c]; d->target_w[i][c] = tw[c]; }
         }
     }
-    __syncthreads();
-    // ---- 3b. expand the compact reach-avoid cost (KartLQRCosts.cs:57-127) row by row: lane r = row r
-    {
-        const int b = r >> 2, sidx = r & 3;
-        const int n = 4 * N;
+    G->N = N;
+    if (dbg_out && P.debug) dbg_out[(size_t)env * A + ego].n_players = N;
+    if (N >= 2) {                                                                     // bin multi-player games by N
+        const int pos = atomicAdd(&queue_cnt[N], 1);
+        queue[(size_t)(N - 2) * P.E * A + pos] = env * A + ego;
+    }
+}
+
+// HKA:1206-1224
+__device__ inline void decode_controls(const EnvParams& P, hk_agent_state* me, double u0a, double u0b, hk_lq_debug* dbg)
+{
+    const float fs = me->final_steer;
+    const float maxAng = fs * 0.4f;                                                   // getMaxAngularVelocity AK:505
+    float angVel = f_clamp((float)u0b, -maxAng, maxAng);
+    uint32_t fl = me->flags;
+    if (u0a < 0) { fl &= ~HK_F_ACCEL; fl |= HK_F_BRAKE; }
+    else if (u0a > 0) { fl |= HK_F_ACCEL; fl &= ~HK_F_BRAKE; }
+    else { fl &= ~(HK_F_ACCEL | HK_F_BRAKE); angVel = 0.0f; }                         // Q7
+    me->flags = fl;
+    me->steering = angVel / (0.4f * fs);
+    if (dbg) { dbg->u0[0] = u0a; dbg->u0[1] = u0b; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K_B2a: single-player games, one thread each.  Dense 4x4 / 2x2 algebra with the SAME fma chains as the generic
+// algorithm (k ascending, seeded +0.0); entries of A, B that are structural zeros are skipped (exact), entries
+// that are 1.0 enter through fma(z, 1.0, s) like any other value.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lq1_kernel(EnvParams P, hk_agent_state* agents, const GameDesc* games, int ngames,
+                                                  hk_lq_debug* dbg_out, int* status)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngames) return;
+    const GameDesc* G = &games[g];
+    if (G->N != 1) return;
+    const GamePlayer& gp = G->p[0];
+    const double dt = (double)P.dt;
+    double A[4][4] = {{1.0, 0.0, gp.a4[0], gp.a4[2]}, {0.0, 1.0, gp.a4[1], gp.a4[3]}, {0.0, 0.0, 1.0, 0.0}, {0.0, 0.0, 0.0, 1.0}};
+    const double R[2][2] = {{gp.rc, 0.0}, {0.0, gp.rc}};
+    double Q[4], qv[4], x0[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        double d = 0.0;                       // total of the (empty) avoid list, KartLQRCosts.cs:67-79
+        d += gp.tw[s];                        // :81-84
+        Q[s] = d;
+        double t = -gp.tgt[s];                // getQVec :109-113
+        qv[s] = t * gp.tw[s];
+        x0[s] = gp.x0[s];
+    }
+    double Z[4][4], eta[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) Z[r][c] = (r == c) ? Q[r] : 0.0;
+        eta[r] = qv[r];
+    }
+    double Pm[2][4], alpha[2];
+    int singular = 0;
+#pragma unroll 1
+    for (int t = 3; t >= 0; t--) {
+        // T1 = Z B (4x2): B[2][0] = B[3][1] = dt
+        double T1[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { T1[r][0] = fma64(Z[r][2], dt, 0.0); T1[r][1] = fma64(Z[r][3], dt, 0.0); }
+        // LHS = R + B'(ZB)
+        double L00 = R[0][0] + fma64(dt, T1[2][0], 0.0), L01 = R[0][1] + fma64(dt, T1[2][1], 0.0);
+        double L10 = R[1][0] + fma64(dt, T1[3][0], 0.0), L11 = R[1][1] + fma64(dt, T1[3][1], 0.0);
+        // ZA rows 2, 3 (the only rows B' picks), then RHS = B'(ZA) (2x4) and B' eta
+        double b0[5], b1[5];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            double s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool nz = (k == c) || (k < 2 && c >= 2);      // structural non-zeros of A
+                if (nz) { s2 = fma64(Z[2][k], A[k][c], s2); s3 = fma64(Z[3][k], A[k][c], s3); }
+            }
+            b0[c] = fma64(dt, s2, 0.0);
+            b1[c] = fma64(dt, s3, 0.0);
+        }
+        b0[4] = fma64(dt, eta[2], 0.0);
+        b1[4] = fma64(dt, eta[3], 0.0);
+        // 2x2 LU, MathNet/JAMA order: column 0 pivot, then column 1 with s = L10*u01 subtracted once
+        if (fabs(L10) > fabs(L00)) {
+            double tmp = L00; L00 = L10; L10 = tmp;
+            tmp = L01; L01 = L11; L11 = tmp;
+#pragma unroll
+            for (int c = 0; c < 5; c++) { tmp = b0[c]; b0[c] = b1[c]; b1[c] = tmp; }
+        }
+        if (L00 == 0.0) singular = 1;
+        if (L00 != 0.0) L10 = L10 / L00;
+        {
+            double s = 0.0;
+            s += L10 * L01;
+            L11 = L11 - s;
+        }
+        if (L11 == 0.0) singular = 1;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            double temp = b0[c] * L10;
+            b1[c] = b1[c] - temp;
+            b1[c] = b1[c] / L11;
+            temp = b1[c] * L01;
+            b0[c] = b0[c] - temp;
+            b0[c] = b0[c] / L00;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) { Pm[0][c] = b0[c]; Pm[1][c] = b1[c]; }
+        alpha[0] = b0[4]; alpha[1] = b1[4];
+        // F = A - (0 + B P): rows x, z keep A; rows v, h subtract dt * P
+        double F[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            F[0][c] = A[0][c] - 0.0;
+            F[1][c] = A[1][c] - 0.0;
+            F[2][c] = A[2][c] - (0.0 + fma64(dt, Pm[0][c], 0.0));
+            F[3][c] = A[3][c] - (0.0 + fma64(dt, Pm[1][c], 0.0));
+        }
+        double beta[4];
+        beta[0] = 0.0; beta[1] = 0.0;
+        beta[2] = 0.0 - fma64(dt, alpha[0], 0.0);
+        beta[3] = 0.0 - fma64(dt, alpha[1], 0.0);
+        // Z <- (Q + P'(R P)) + F'(Z F)
+        double W[4][4], RP[2][4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) s = fma64(Z[r][k], F[k][c], s);
+                W[r][c] = s;
+            }
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                double s = 0.0;
+                s = fma64(R[a][0], Pm[0][c], s);
+                s = fma64(R[a][1], Pm[1][c], s);
+                RP[a][c] = s;
+            }
+        double Zn[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                double o = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) o = fma64(F[k][r], W[k][c], o);
+                double t2 = 0.0;
+                t2 = fma64(Pm[0][r], RP[0][c], t2);
+                t2 = fma64(Pm[1][r], RP[1][c], t2);
+                const double qq = (r == c) ? Q[r] : 0.0;
+                Zn[r][c] = (qq + t2) + o;
+            }
+        // eta <- (q + P'(R alpha)) + F'(eta + Z_new beta)
+        double v1[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double zb = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) zb = fma64(Zn[r][k], beta[k], zb);
+            v1[r] = eta[r] + zb;
+        }
+        double ra0 = 0.0, ra1 = 0.0;
+        ra0 = fma64(R[0][0], alpha[0], ra0); ra0 = fma64(R[0][1], alpha[1], ra0);
+        ra1 = fma64(R[1][0], alpha[0], ra1); ra1 = fma64(R[1][1], alpha[1], ra1);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double v3 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v3 = fma64(F[k][r], v1[k], v3);
+            double v2 = 0.0;
+            v2 = fma64(Pm[0][r], ra0, v2);
+            v2 = fma64(Pm[1][r], ra1, v2);
+            eta[r] = (qv[r] + v2) + v3;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) Z[r][c] = Zn[r][c];
+    }
+    double u0[2];
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) s = fma64(-Pm[a][c], x0[c], s);
+        u0[a] = s - alpha[a];
+    }
+    if (singular) atomicOr(status, 1);
+    decode_controls(P, &agents[g], u0[0], u0[1], (dbg_out && P.debug) ? &dbg_out[g] : nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K_B2b: multi-player games of one size NP from queue[NP-2], 4 per wave
+// ---------------------------------------------------------------------------------------------------------------
+struct AsmGroup {              // compact cost rows of one game: QC[i][b'][r] = Q_i[r][4b' + (r&3)]
+    double QC[LQ_MAXP][4][LQ_MAXN];
+    double QV[LQ_MAXP][LQ_MAXN];
+};
+struct QCompact {
+    const double* QC;
+    const double* QV;
+    __device__ double Q(int i, int r, int c) const { return ((c & 3) == (r & 3)) ? QC[(i * 4 + (c >> 2)) * LQ_MAXN + r] : 0.0; }
+    __device__ double q(int i, int r) const { return QV[i * LQ_MAXN + r]; }
+};
+
+template <int NP>
+__global__ __launch_bounds__(64) void lqn_kernel(EnvParams P, hk_agent_state* agents, const GameDesc* games, const int* queue_cnt,
+                                                 const int* queue, hk_lq_debug* dbg_out, int* status)
+{
+    __shared__ LqGroupLds lds[4];
+    __shared__ AsmGroup asg[4];
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, r = lane & 15;
+    const int count = queue_cnt[NP];
+    const int* qbase = queue + (size_t)(NP - 2) * P.E * P.A;
+    LqGroupLds& LG = lds[g];
+    AsmGroup& AG = asg[g];
+    for (int base = blockIdx.x * 4; base < count; base += gridDim.x * 4) {
+        const int slot = base + g;
+        const bool live = slot < count;
+        const int game = live ? qbase[slot] : 0;
+        const GameDesc* G = &games[game];
+        const int N = live ? NP : 0;
+        __syncthreads();
+        // game inputs -> LDS
 #pragma unroll
         for (int i = 0; i < LQ_MAXP; i++) {
-            double qc0 = 0.0, qc1 = 0.0, qc2 = 0.0, qc3 = 0.0, qv = 0.0;
-            if (i < N && r < n) {
-                const int M = AG.M[i];
-                if (b == 0) {
-                    double d = 0.0;
-                    if (sidx < 2) {
-                        double total = 0.0;                                        // :67-79
-                        for (int j = 0; j < M; j++) total -= AG.aw[i][j];
-                        d = total;
-                    }
-                    d += AG.tw[i][sidx];                                           // :81-84
-                    qc0 = d;
-                    if (sidx < 2) {
-                        if (M > 0) qc1 = AG.aw[i][0];
-                        if (M > 1) qc2 = AG.aw[i][1];
-                        if (M > 2) qc3 = AG.aw[i][2];
-                    }
-                    double t = -AG.tgt[i][sidx];                                   // getQVec :109-113
-                    qv = t * AG.tw[i][sidx];
-                } else {
-                    const int j = b - 1;
-                    if (sidx < 2) qc0 = AG.aw[i][j];                               // :74
-                    double dg = 0.0;
-                    if (sidx < 3) dg = -AG.opw[i][j][sidx];                        // :91 assignment (Q4)
-                    if (b == 1) qc1 = dg; else if (b == 2) qc2 = dg; else qc3 = dg;
-                    qv = AG.opt[i][j][sidx];                                       // :117
-                    if (sidx < 3) qv = qv * -AG.opw[i][j][sidx];                   // :121
-                }
+            double av = 0.0;
+            if (i < N) {
+                const int rr = r >> 2, cc = r & 3;
+                if (rr == cc) av = 1.0;
+                else if (rr == 0 && cc == 2) av = G->p[i].a4[0];
+                else if (rr == 1 && cc == 2) av = G->p[i].a4[1];
+                else if (rr == 0 && cc == 3) av = G->p[i].a4[2];
+                else if (rr == 1 && cc == 3) av = G->p[i].a4[3];
             }
-            AG.QC[i][0][r] = qc0; AG.QC[i][1][r] = qc1; AG.QC[i][2][r] = qc2; AG.QC[i][3][r] = qc3;
-            AG.QV[i][r] = qv;
+            LG.Ab[i][r] = av;
+            if (r < 8) LG.Bb[i][r] = (i < N && (r == 4 || r == 7)) ? (double)P.dt : 0.0;     // B[v][0] = B[h][1] = dt
+            if (r < 4) LG.Rb[i][r] = (i < N && (r == 0 || r == 3)) ? G->p[i].rc : 0.0;
         }
-    }
-    __syncthreads();
-    // ---- 4. coupled Riccati solve
-    int Nmax = N;
-    Nmax = max(Nmax, __shfl_xor(Nmax, 16, 64));
-    Nmax = max(Nmax, __shfl_xor(Nmax, 32, 64));
-    Nmax = __builtin_amdgcn_readfirstlane(Nmax);
-    if (Nmax == 0) return;
-    QCompact qp;
-    qp.QC = &AG.QC[0][0][0];
-    qp.QV = &AG.QV[0][0];
-    double u0[2];
-    int singular = 0;
-    lq_solve_group(r, N, Nmax, LG, qp, 3, u0, singular);                            // HKA:1201 horizon literal 3 (Q6)
-    // ---- 5. decode (HKA:1206-1224)
-    if (solving && r == 0) {
-        hk_agent_state* me = &ags[ego];
-        const float fs = kl[ego].final_steer;
-        const float maxAng = fs * 0.4f;
-        float angVel = f_clamp((float)u0[1], -maxAng, maxAng);
-        uint32_t fl = me->flags;
-        if (u0[0] < 0) { fl &= ~HK_F_ACCEL; fl |= HK_F_BRAKE; }
-        else if (u0[0] > 0) { fl |= HK_F_ACCEL; fl &= ~HK_F_BRAKE; }
-        else { fl &= ~(HK_F_ACCEL | HK_F_BRAKE); angVel = 0.0f; }                   // Q7
-        me->flags = fl;
-        me->steering = angVel / (0.4f * fs);
-        if (singular) atomicOr(status, 1);
-        if (dbg_out && P.debug) {
-            hk_lq_debug* d = &dbg_out[(size_t)env * A + ego];
-            d->n_players = N; d->u0[0] = u0[0]; d->u0[1] = u0[1];
+        LG.x0[r] = (r < 4 * N) ? G->p[r >> 2].x0[r & 3] : 0.0;
+        // compact reach-avoid cost rows (KartLQRCosts.cs:57-127): lane r = row r
+        {
+            const int b = r >> 2, sidx = r & 3;
+            const int n = 4 * N;
+#pragma unroll
+            for (int i = 0; i < LQ_MAXP; i++) {
+                double qc0 = 0.0, qc1 = 0.0, qc2 = 0.0, qc3 = 0.0, qv = 0.0;
+                if (i < N && r < n) {
+                    const GamePlayer& gp = G->p[i];
+                    const int M = gp.M;
+                    if (b == 0) {
+                        double d = 0.0;
+                        if (sidx < 2) {
+                            double total = 0.0;                                    // :67-79
+                            for (int j = 0; j < M; j++) total -= gp.aw[j];
+                            d = total;
+                        }
+                        d += gp.tw[sidx];                                          // :81-84
+                        qc0 = d;
+                        if (sidx < 2) {
+                            if (M > 0) qc1 = gp.aw[0];
+                            if (M > 1) qc2 = gp.aw[1];
+                            if (M > 2) qc3 = gp.aw[2];
+                        }
+                        double t = -gp.tgt[sidx];                                  // getQVec :109-113
+                        qv = t * gp.tw[sidx];
+                    } else {
+                        const int j = b - 1;
+                        if (sidx < 2) qc0 = gp.aw[j];                              // :74
+                        double dg = 0.0;
+                        if (sidx < 3) dg = -gp.opw[j][sidx];                       // :91 assignment (Q4)
+                        if (b == 1) qc1 = dg; else if (b == 2) qc2 = dg; else qc3 = dg;
+                        if (sidx < 3) { qv = gp.opt[j][sidx]; qv = qv * -gp.opw[j][sidx]; }   // :117,:121 (heading entry 0)
+                    }
+                }
+                AG.QC[i][0][r] = qc0; AG.QC[i][1][r] = qc1; AG.QC[i][2][r] = qc2; AG.QC[i][3][r] = qc3;
+                AG.QV[i][r] = qv;
+            }
+        }
+        __syncthreads();
+        QCompact qp;
+        qp.QC = &AG.QC[0][0][0];
+        qp.QV = &AG.QV[0][0];
+        double u0[2];
+        int singular = 0;
+        lq_solve_group(r, N, NP, LG, qp, 3, u0, singular);                          // HKA:1201 horizon literal 3 (Q6)
+        if (live && r == 0) {
+            if (singular) atomicOr(status, 1);
+            decode_controls(P, &agents[game], u0[0], u0[1], (dbg_out && P.debug) ? &dbg_out[game] : nullptr);
         }
     }
 }

@@ -87,9 +87,10 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_st
 // K_A: REC.FixedUpdate (:239-311), StartRaceAfterDelay (:721-744), KA.FixedUpdate forward-collision rays (:135-167)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void env_begin_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
-                                                        hk_episode_result* results)
+                                                        hk_episode_result* results, int* queue_cnt)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < 8) queue_cnt[gid] = 0;          // per-N game queues of this tick's solve stage (hk_env_solve.h)
     const int env = gid >> 2, i = gid & 3;
     const bool env_ok = env < P.E;
     const bool me = env_ok && i < P.A;
