@@ -163,12 +163,19 @@ int hk_lq_solve_batch_device(hk_handle h, int batch, int N, const double* dA, co
     if (batch == 0) return HK_OK;
     HK_HIP(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    const int blocks = (batch + 3) / 4;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (h->prof.on) { pe0 = h->prof.get(); pe1 = h->prof.get(); }
     if (pe0) HK_HIP(h, hipEventRecord(pe0, st));
-    hipLaunchKernelGGL(hk::lq_batch_kernel, dim3(blocks), dim3(64), 0, st, batch, N, dA, dB, dQ, dq, dR, dx0, horizon, du0,
-                       h->d_status);
+    switch (N) {
+#define HK_LQ_CASE(NP)                                                                                                   \
+    case NP: {                                                                                                           \
+        const int gpw = hk::LqDims<NP>::GPW;                                                                             \
+        hipLaunchKernelGGL(hk::lq_batch_kernel<NP>, dim3((batch + gpw - 1) / gpw), dim3(64), 0, st, batch, dA, dB, dQ, dq, dR, \
+                           dx0, horizon, du0, h->d_status);                                                              \
+    } break;
+        HK_LQ_CASE(1) HK_LQ_CASE(2) HK_LQ_CASE(3) HK_LQ_CASE(4)
+#undef HK_LQ_CASE
+    }
     HK_HIP(h, hipGetLastError());
     if (pe0 && pe1) {
         HK_HIP(h, hipEventRecord(pe1, st));

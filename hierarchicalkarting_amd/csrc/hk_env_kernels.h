@@ -282,7 +282,7 @@ inline int env_launch_solve(EnvDevice& d, const hk_config& cfg, hipStream_t stre
     hipLaunchKernelGGL(lq1_kernel, dim3((ngames + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.games, ngames, d.lq_debug, d.status);
     if ((rc = launch_check(err, "lq1_kernel"))) return rc;
     if (cfg.num_agents >= 2) {
-        const int blocks = std::min((ngames + 3) / 4, 4096);
+        const int blocks = std::min((ngames + 3) / 4, 8192);
         hipLaunchKernelGGL(lqn_kernel<2>, dim3(blocks), dim3(64), 0, stream, d.P, d.agents, d.games, d.queue_cnt, d.queue, d.lq_debug, d.status);
         if ((rc = launch_check(err, "lqn_kernel<2>"))) return rc;
         if (cfg.num_agents >= 3) {

@@ -530,101 +530,102 @@ __global__ __launch_bounds__(256) void lq1_kernel(EnvParams P, hk_agent_state* a
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// K_B2b: multi-player games of one size NP from queue[NP-2], 4 per wave
+// K_B2b: multi-player games of one size NP from queue[NP-2], 64/(4*NP) per wave
 // ---------------------------------------------------------------------------------------------------------------
-struct AsmGroup {              // compact cost rows of one game: QC[i][b'][r] = Q_i[r][4b' + (r&3)]
-    double QC[LQ_MAXP][4][LQ_MAXN];
-    double QV[LQ_MAXP][LQ_MAXN];
+template <int NP>
+struct CostRows {              // compact cost rows of one game: QC[i][b'][r] = Q_i[r][4b' + (r&3)]
+    double QC[NP][NP][4 * NP];
+    double QV[NP][4 * NP];
 };
+template <int NP>
 struct QCompact {
-    const double* QC;
-    const double* QV;
-    __device__ double Q(int i, int r, int c) const { return ((c & 3) == (r & 3)) ? QC[(i * 4 + (c >> 2)) * LQ_MAXN + r] : 0.0; }
-    __device__ double q(int i, int r) const { return QV[i * LQ_MAXN + r]; }
+    const CostRows<NP>* C;
+    __device__ double Q(int i, int r, int c) const { return ((c & 3) == (r & 3)) ? C->QC[i][c >> 2][r] : 0.0; }
+    __device__ double q(int i, int r) const { return C->QV[i][r]; }
 };
 
 template <int NP>
 __global__ __launch_bounds__(64) void lqn_kernel(EnvParams P, hk_agent_state* agents, const GameDesc* games, const int* queue_cnt,
                                                  const int* queue, hk_lq_debug* dbg_out, int* status)
 {
-    __shared__ LqGroupLds lds[4];
-    __shared__ AsmGroup asg[4];
+    constexpr int n = LqDims<NP>::n, GPW = LqDims<NP>::GPW, SLOTS = LqDims<NP>::SLOTS;
+    __shared__ LqGameLds<NP> lds[SLOTS];
+    __shared__ CostRows<NP> rows[SLOTS];
     const int lane = threadIdx.x & 63;
-    const int g = lane >> 4, r = lane & 15;
+    const int gs = lane / n, r = lane % n;
     const int count = queue_cnt[NP];
     const int* qbase = queue + (size_t)(NP - 2) * P.E * P.A;
-    LqGroupLds& LG = lds[g];
-    AsmGroup& AG = asg[g];
-    for (int base = blockIdx.x * 4; base < count; base += gridDim.x * 4) {
-        const int slot = base + g;
-        const bool live = slot < count;
-        const int game = live ? qbase[slot] : 0;
+    LqGameLds<NP>& LG = lds[gs];
+    CostRows<NP>& CR = rows[gs];
+    for (int base = blockIdx.x * GPW; base < count; base += gridDim.x * GPW) {
+        const int slot = base + gs;
+        const bool live = gs < GPW && slot < count;
+        const int game = qbase[live ? slot : count - 1];      // idle slots recompute the last game and discard it
         const GameDesc* G = &games[game];
-        const int N = live ? NP : 0;
         __syncthreads();
         // game inputs -> LDS
 #pragma unroll
-        for (int i = 0; i < LQ_MAXP; i++) {
-            double av = 0.0;
-            if (i < N) {
-                const int rr = r >> 2, cc = r & 3;
+        for (int i = 0; i < NP; i++) {
+            for (int e = r; e < 16; e += n) {
+                const int rr = e >> 2, cc = e & 3;
+                double av = 0.0;
                 if (rr == cc) av = 1.0;
                 else if (rr == 0 && cc == 2) av = G->p[i].a4[0];
                 else if (rr == 1 && cc == 2) av = G->p[i].a4[1];
                 else if (rr == 0 && cc == 3) av = G->p[i].a4[2];
                 else if (rr == 1 && cc == 3) av = G->p[i].a4[3];
+                LG.Ab[i][e] = av;
             }
-            LG.Ab[i][r] = av;
-            if (r < 8) LG.Bb[i][r] = (i < N && (r == 4 || r == 7)) ? (double)P.dt : 0.0;     // B[v][0] = B[h][1] = dt
-            if (r < 4) LG.Rb[i][r] = (i < N && (r == 0 || r == 3)) ? G->p[i].rc : 0.0;
+            for (int e = r; e < 8; e += n) LG.Bb[i][e] = (e == 4 || e == 7) ? (double)P.dt : 0.0;      // B[v][0] = B[h][1] = dt
+            if (r < 4) LG.Rb[i][r] = (r == 0 || r == 3) ? G->p[i].rc : 0.0;
         }
-        LG.x0[r] = (r < 4 * N) ? G->p[r >> 2].x0[r & 3] : 0.0;
+        LG.x0[r] = G->p[r >> 2].x0[r & 3];
         // compact reach-avoid cost rows (KartLQRCosts.cs:57-127): lane r = row r
         {
             const int b = r >> 2, sidx = r & 3;
-            const int n = 4 * N;
 #pragma unroll
-            for (int i = 0; i < LQ_MAXP; i++) {
-                double qc0 = 0.0, qc1 = 0.0, qc2 = 0.0, qc3 = 0.0, qv = 0.0;
-                if (i < N && r < n) {
-                    const GamePlayer& gp = G->p[i];
-                    const int M = gp.M;
-                    if (b == 0) {
-                        double d = 0.0;
-                        if (sidx < 2) {
-                            double total = 0.0;                                    // :67-79
-                            for (int j = 0; j < M; j++) total -= gp.aw[j];
-                            d = total;
-                        }
-                        d += gp.tw[sidx];                                          // :81-84
-                        qc0 = d;
-                        if (sidx < 2) {
-                            if (M > 0) qc1 = gp.aw[0];
-                            if (M > 1) qc2 = gp.aw[1];
-                            if (M > 2) qc3 = gp.aw[2];
-                        }
-                        double t = -gp.tgt[sidx];                                  // getQVec :109-113
-                        qv = t * gp.tw[sidx];
-                    } else {
-                        const int j = b - 1;
-                        if (sidx < 2) qc0 = gp.aw[j];                              // :74
-                        double dg = 0.0;
-                        if (sidx < 3) dg = -gp.opw[j][sidx];                       // :91 assignment (Q4)
-                        if (b == 1) qc1 = dg; else if (b == 2) qc2 = dg; else qc3 = dg;
-                        if (sidx < 3) { qv = gp.opt[j][sidx]; qv = qv * -gp.opw[j][sidx]; }   // :117,:121 (heading entry 0)
+            for (int i = 0; i < NP; i++) {
+                double qc[NP];
+#pragma unroll
+                for (int q = 0; q < NP; q++) qc[q] = 0.0;
+                double qv = 0.0;
+                const GamePlayer& gp = G->p[i];
+                const int M = gp.M;
+                if (b == 0) {
+                    double d = 0.0;
+                    if (sidx < 2) {
+                        double total = 0.0;                                    // :67-79
+                        for (int j = 0; j < M; j++) total -= gp.aw[j];
+                        d = total;
                     }
+                    d += gp.tw[sidx];                                          // :81-84
+                    qc[0] = d;
+                    if (sidx < 2) {
+#pragma unroll
+                        for (int q = 1; q < NP; q++) if (M > q - 1) qc[q] = gp.aw[q - 1];
+                    }
+                    double t = -gp.tgt[sidx];                                  // getQVec :109-113
+                    qv = t * gp.tw[sidx];
+                } else {
+                    const int j = b - 1;
+                    if (sidx < 2) qc[0] = gp.aw[j];                            // :74
+                    double dg = 0.0;
+                    if (sidx < 3) dg = -gp.opw[j][sidx];                       // :91 assignment (Q4)
+#pragma unroll
+                    for (int q = 1; q < NP; q++) if (b == q) qc[q] = dg;
+                    if (sidx < 3) { qv = gp.opt[j][sidx]; qv = qv * -gp.opw[j][sidx]; }   // :117,:121 (heading entry 0)
                 }
-                AG.QC[i][0][r] = qc0; AG.QC[i][1][r] = qc1; AG.QC[i][2][r] = qc2; AG.QC[i][3][r] = qc3;
-                AG.QV[i][r] = qv;
+#pragma unroll
+                for (int q = 0; q < NP; q++) CR.QC[i][q][r] = qc[q];
+                CR.QV[i][r] = qv;
             }
         }
         __syncthreads();
-        QCompact qp;
-        qp.QC = &AG.QC[0][0][0];
-        qp.QV = &AG.QV[0][0];
+        QCompact<NP> qp;
+        qp.C = &CR;
         double u0[2];
         int singular = 0;
-        lq_solve_group(r, N, NP, LG, qp, 3, u0, singular);                          // HKA:1201 horizon literal 3 (Q6)
+        lq_solve_game<NP>(r, LG, qp, 3, u0, singular);                          // HKA:1201 horizon literal 3 (Q6)
         if (live && r == 0) {
             if (singular) atomicOr(status, 1);
             decode_controls(P, &agents[game], u0[0], u0[1], (dbg_out && P.debug) ? &dbg_out[game] : nullptr);

@@ -13,37 +13,36 @@ struct QDenseP {
     __device__ double q(int i, int r) const { return qg[(size_t)i * n + r]; }
 };
 
-// one wave (64 threads) per block, 4 games per wave
-__global__ __launch_bounds__(64) void lq_batch_kernel(int batch, int N, const double* __restrict__ A,
-                                                       const double* __restrict__ B, const double* __restrict__ Q,
-                                                       const double* __restrict__ q, const double* __restrict__ R,
-                                                       const double* __restrict__ x0, int horizon,
+// one wave (64 threads) per block, 64/(4*NP) games per wave
+template <int NP>
+__global__ __launch_bounds__(64) void lq_batch_kernel(int batch, const double* __restrict__ A, const double* __restrict__ B,
+                                                       const double* __restrict__ Q, const double* __restrict__ q,
+                                                       const double* __restrict__ R, const double* __restrict__ x0, int horizon,
                                                        double* __restrict__ u0_out, int* __restrict__ status)
 {
-    __shared__ LqGroupLds lds[4];
+    constexpr int n = LqDims<NP>::n, GPW = LqDims<NP>::GPW, SLOTS = LqDims<NP>::SLOTS;
+    __shared__ LqGameLds<NP> lds[SLOTS];
     const int lane = threadIdx.x & 63;
-    const int g = lane >> 4, r = lane & 15;
-    const long game = (long)blockIdx.x * 4 + g;
-    const bool live = game < batch;
-    const int n = 4 * N;
-    LqGroupLds& L = lds[g];
-    const int Ng = live ? N : 0;
+    const int gs = lane / n, r = lane % n;
+    long game = (long)blockIdx.x * GPW + gs;
+    const bool live = gs < GPW && game < batch;
+    if (!live) game = batch - 1;                 // idle slots recompute the last game and discard it
+    LqGameLds<NP>& L = lds[gs];
 #pragma unroll
-    for (int i = 0; i < LQ_MAXP; i++) {
-        const bool ok = live && i < N;
-        L.Ab[i][r] = ok ? A[((size_t)game * N + i) * 16 + r] : 0.0;
-        if (r < 8) L.Bb[i][r] = ok ? B[((size_t)game * N + i) * 8 + r] : 0.0;
-        if (r < 4) L.Rb[i][r] = ok ? R[((size_t)game * N + i) * 4 + r] : 0.0;
+    for (int i = 0; i < NP; i++) {
+        for (int e = r; e < 16; e += n) L.Ab[i][e] = A[((size_t)game * NP + i) * 16 + e];
+        for (int e = r; e < 8; e += n) L.Bb[i][e] = B[((size_t)game * NP + i) * 8 + e];
+        if (r < 4) L.Rb[i][r] = R[((size_t)game * NP + i) * 4 + r];
     }
-    L.x0[r] = (live && r < n) ? x0[(size_t)game * n + r] : 0.0;
+    L.x0[r] = x0[(size_t)game * n + r];
     __syncthreads();
     QDenseP qp;
-    qp.Qg = Q + (live ? (size_t)game * N * n * n : 0);
-    qp.qg = q + (live ? (size_t)game * N * n : 0);
+    qp.Qg = Q + (size_t)game * NP * n * n;
+    qp.qg = q + (size_t)game * NP * n;
     qp.n = n;
     double u0[2];
     int singular;
-    lq_solve_group(r, Ng, N, L, qp, horizon, u0, singular);
+    lq_solve_game<NP>(r, L, qp, horizon, u0, singular);
     if (live && r == 0) {
         u0_out[game * 2 + 0] = u0[0];
         u0_out[game * 2 + 1] = u0[1];
