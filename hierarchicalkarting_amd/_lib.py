@@ -115,6 +115,7 @@ SYMBOLS = {
     "hk_prof_enable": (C.c_int, [_H, C.c_int]),
     "hk_prof_reset": (C.c_int, [_H]),
     "hk_prof_read": (C.c_int, [_H, _dp, C.POINTER(C.c_int64), _dp, C.POINTER(C.c_int64)]),
+    "hk_debug_cycles": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

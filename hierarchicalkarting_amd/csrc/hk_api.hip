@@ -355,6 +355,15 @@ int hk_get_lq_debug(hk_handle h, int env, int ego, hk_lq_debug* out)
     return HK_OK;
 }
 
+// diagnostic: in-kernel cycle stamps accumulated by the assemble kernel when HK_LQ_DEBUG has bit 7 set
+int hk_debug_cycles(hk_handle h, unsigned long long* out16)
+{
+    HK_NEED_ENV(h);
+    HK_HIP(h, hipMemcpyAsync(out16, h->dev.cyc, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    return HK_OK;
+}
+
 void* hk_device_results_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.results : nullptr; }
 void* hk_device_agents_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.agents : nullptr; }
 

@@ -40,15 +40,48 @@ struct EnvParams {
     int env_id_base, nperm;
     float init_acc, max_speed, ray_agent_r;
     int debug;
-    const SecDev* sec;
-    const hk_wall_seg* walls;
-    const int* near_off;   // [L+1] candidate walls for contacts of a kart whose section index is s (mod L)
-    const int* near_idx;
-    const int* far_off;    // [L+1] candidate walls for rays up to 8 m
-    const int* far_idx;
-    const unsigned char* cut;   // [L][5][5]: does the ray lane marker -> next lane marker hit a wall (HKA:832)
+    // the read-only track tables live in ONE packed buffer (16-B aligned segments); kernels copy it to LDS
+    const unsigned char* tab;   // packed tables in global memory
+    int tab_bytes, o_walls, o_goff, o_gidx, o_cut;
+    // uniform grid over the walls' bounding box: cell (ix, iz) lists every wall segment within GRID_REACH of the cell
+    float grid_x0, grid_z0, grid_inv;   // origin and 1 / cell size
+    int grid_nx, grid_nz;
     const int* perms;      // [A!][A]
 };
+constexpr float GRID_CELL = 2.0f;       // cell size (m)
+constexpr float GRID_REACH = 2.2f;      // list radius: 2 m side rays / 1 m half-spacing of the long-ray samples / 1.11 m
+                                        // contact reach, plus slack for float rounding of the cell index
+
+// where a kernel reads the track tables from: the packed global buffer, or its per-block LDS copy
+struct TabView {
+    const SecDev* sec;            // [L]
+    const hk_wall_seg* walls;     // [NW]
+    const unsigned short* grid_off;   // [nx*nz + 1] candidate wall segments per grid cell (ascending wall index)
+    const unsigned short* grid_idx;
+    const unsigned char* cut;     // [L][5][5]: does the ray lane marker -> next lane marker hit a wall (HKA:832)
+};
+__host__ __device__ inline TabView tab_view(const EnvParams& P, const unsigned char* base)
+{
+    TabView T;
+    T.sec = reinterpret_cast<const SecDev*>(base);
+    T.walls = reinterpret_cast<const hk_wall_seg*>(base + P.o_walls);
+    T.grid_off = reinterpret_cast<const unsigned short*>(base + P.o_goff);
+    T.grid_idx = reinterpret_cast<const unsigned short*>(base + P.o_gidx);
+    T.cut = base + P.o_cut;
+    return T;
+}
+// copy the packed tables into dynamic LDS (all threads of the block), or fall back to global memory when the launch
+// passed no dynamic LDS (tables larger than the budget)
+__device__ inline TabView tab_stage(const EnvParams& P, unsigned char* smem, bool use_lds)
+{
+    if (!use_lds) return tab_view(P, P.tab);
+    const int n16 = P.tab_bytes >> 4;
+    const uint4* src = reinterpret_cast<const uint4*>(P.tab);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    return tab_view(P, smem);
+}
 
 // ------------------------------------------------------------------ float helpers (Unity Mathf semantics, Q10)
 __device__ __forceinline__ float f_min(float a, float b) { return a < b ? a : b; }
@@ -60,7 +93,7 @@ __device__ __forceinline__ float mag2(float x, float z) { return sqrtf(x * x + 0
 __device__ __forceinline__ float mag3(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }
 __device__ __forceinline__ bool f_finite(float x) { return !(isinf(x) || isnan(x)); }
 
-__device__ __forceinline__ bool is_straight(const EnvParams& P, int section) { return P.sec[section % P.L].inside_radius == 0.0f; }
+__device__ __forceinline__ bool is_straight(const EnvParams& P, const TabView& T, int section) { return T.sec[section % P.L].inside_radius == 0.0f; }
 
 __device__ __forceinline__ float kart_steer(const EnvParams& P, float acc_ang_v)
 {   // AK:300
@@ -89,6 +122,15 @@ __device__ inline float max_speed_for_state(const EnvParams& P, float yaw, float
     float allowed = sqrtf(max_lat_gs(P, wear) * 9.81f * f_abs(radius));
     if (isinf(allowed) || isnan(allowed)) allowed = P.st.TopSpeed;
     return f_clamp(allowed, 0.0001f, P.st.TopSpeed);
+}
+
+// grid cell of a point (clamped to the grid): every wall within GRID_REACH of the point is in the cell's list
+__device__ __forceinline__ int grid_cell(const EnvParams& P, float x, float z)
+{
+    int ix = (int)((x - P.grid_x0) * P.grid_inv), iz = (int)((z - P.grid_z0) * P.grid_inv);
+    ix = ix < 0 ? 0 : (ix >= P.grid_nx ? P.grid_nx - 1 : ix);
+    iz = iz < 0 ? 0 : (iz >= P.grid_nz ? P.grid_nz - 1 : iz);
+    return iz * P.grid_nx + ix;
 }
 
 // ------------------------------------------------------------------ analytic Physics.Raycast pieces
@@ -217,14 +259,14 @@ __device__ inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
 // HKA.planFixed :145-166
-__device__ inline void plan_fixed(const EnvParams& P, int agent, hk_agent_state* a)
+__device__ inline void plan_fixed(const EnvParams& P, const TabView& T, int agent, hk_agent_state* a)
 {
     const int sec = a->section_index;
     int hi = sec + P.depth[agent]; if (hi > 1000) hi = 1000;
     for (int i = sec + 1; i < hi + 1; i++) {
         int key = i % P.L;
         if (a->plan_lane[key] == 0) {
-            a->plan_lane[key] = (uint8_t)P.sec[(i - 1) % P.L].optimal_lane;
+            a->plan_lane[key] = (uint8_t)T.sec[(i - 1) % P.L].optimal_lane;
             a->plan_vel[key] = P.max_speed;
         }
     }
@@ -241,9 +283,9 @@ __device__ inline uint32_t deactivate_fields(const EnvParams& P, hk_agent_state*
 }
 
 // DPT.getBoxColliderForLane :99-111 (lane 0 -> Trigger)
-__device__ __forceinline__ void lane_marker(const EnvParams& P, int idx, int lane, float& x, float& z)
+__device__ __forceinline__ void lane_marker(const TabView& T, int idx, int lane, float& x, float& z)
 {
-    const SecDev& s = P.sec[idx];
+    const SecDev& s = T.sec[idx];
     if (lane >= 1 && lane <= 4) { x = s.lane_x[lane - 1]; z = s.lane_z[lane - 1]; }
     else { x = s.trig_x; z = s.trig_z; }
 }

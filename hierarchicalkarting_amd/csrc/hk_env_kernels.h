@@ -27,14 +27,13 @@ struct EnvDevice {
     GameDesc* games = nullptr;     // [E][A] compact LQ games written by K_B1
     int* queue_cnt = nullptr;      // [8] number of multi-player games per player count (this tick)
     int* queue = nullptr;          // [3][E*A] game ids with N = 2, 3, 4
+    unsigned long long* cyc = nullptr;   // [16] in-kernel cycle stamps (diagnostic builds: HK_LQ_DEBUG & 128)
     int* env_ids = nullptr;
     int env_ids_cap = 0;
     // tables
-    SecDev* sec = nullptr;
-    hk_wall_seg* walls = nullptr;
-    int *near_off = nullptr, *near_idx = nullptr, *far_off = nullptr, *far_idx = nullptr;
-    unsigned char* cut = nullptr;
+    unsigned char* tab = nullptr;  // packed track tables (EnvParams::tab)
     int* perms = nullptr;
+    int tab_lds = 0;               // dynamic LDS bytes the env kernels are launched with (0: read tables from global)
     EnvParams P{};
 };
 
@@ -74,8 +73,7 @@ int upload(T** dst, const std::vector<T>& v, std::string& err)
 
 inline void env_destroy(EnvDevice& d)
 {
-    void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.status, d.games, d.queue_cnt, d.queue, d.env_ids, d.sec,
-                    d.walls, d.near_off, d.near_idx, d.far_off, d.far_idx, d.cut, d.perms};
+    void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.status, d.games, d.queue_cnt, d.queue, d.cyc, d.env_ids, d.tab, d.perms};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = EnvDevice{};
 }
@@ -121,7 +119,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         const float dyc = 0.5f - 0.582f;   // sensor height - capsule centre height (kart-local)
         P.ray_agent_r = sqrtf(CAP_R * CAP_R - dyc * dyc);
     }
-    { const char* dbg = std::getenv("HK_LQ_DEBUG"); P.debug = (dbg && dbg[0] == '1') ? 1 : 0; }   // hk_get_lq_debug taps
+    { const char* dbg = std::getenv("HK_LQ_DEBUG"); P.debug = dbg ? std::atoi(dbg) : 0; }   // hk_get_lq_debug taps
     // sections with forward precomputed (same float expressions as everywhere else)
     std::vector<SecDev> sd(L);
     for (int i = 0; i < L; i++) {
@@ -133,27 +131,41 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         o.marker_y = s.marker_y; o.inside_radius = s.track_inside_radius; o.optimal_lane = s.optimal_lane;
         for (int l = 0; l < 4; l++) { o.lane_x[l] = s.lane_x[l]; o.lane_z[l] = s.lane_z[l]; }
     }
-    // candidate wall lists per section index: walls within `radius` of the trigger-centre polyline T[s-1..s+2]
-    auto build_list = [&](double radius, std::vector<int>& off, std::vector<int>& idx) {
-        off.assign(L + 1, 0); idx.clear();
-        for (int s = 0; s < L; s++) {
-            off[s] = (int)idx.size();
-            for (int w = 0; w < (int)walls.size(); w++) {
-                const hk_wall_seg& ws = walls[w];
-                bool in = false;
-                for (int q = -1; q <= 1 && !in; q++) {
-                    const hk_section& a = sections[((s + q) % L + L) % L];
-                    const hk_section& b = sections[((s + q + 1) % L + L) % L];
-                    if (detail::seg_seg_dist(ws.x0, ws.z0, ws.x1, ws.z1, a.trig_x, a.trig_z, b.trig_x, b.trig_z) <= radius) in = true;
-                }
-                if (in) idx.push_back(w);
-            }
+    // uniform wall grid: per cell every wall segment within GRID_REACH of the cell rectangle, ascending wall index
+    std::vector<unsigned short> goff, gidx;
+    {
+        float x0 = 0, x1 = 1, z0 = 0, z1 = 1;
+        for (size_t w = 0; w < walls.size(); w++) {
+            const hk_wall_seg& s = walls[w];
+            float lx = std::min(s.x0, s.x1), hx = std::max(s.x0, s.x1), lz = std::min(s.z0, s.z1), hz = std::max(s.z0, s.z1);
+            if (w == 0) { x0 = lx; x1 = hx; z0 = lz; z1 = hz; }
+            x0 = std::min(x0, lx); x1 = std::max(x1, hx); z0 = std::min(z0, lz); z1 = std::max(z1, hz);
         }
-        off[L] = (int)idx.size();
-    };
-    std::vector<int> noff, nidx, foff, fidx;
-    build_list(8.5, noff, nidx);     // contacts (reach 1.1 m) and the 2 m side rays: lateral 5.7 (incl. chord sagitta) + 0.1 + 2.0 + margin
-    build_list(16.0, foff, fidx);    // rays up to 8 m from the sensor origin
+        P.grid_x0 = std::floor(x0) - 1.0f; P.grid_z0 = std::floor(z0) - 1.0f;
+        P.grid_inv = 1.0f / GRID_CELL;
+        P.grid_nx = (int)std::ceil((x1 + 1.0f - P.grid_x0) / GRID_CELL) + 1;
+        P.grid_nz = (int)std::ceil((z1 + 1.0f - P.grid_z0) / GRID_CELL) + 1;
+        const size_t ncell = (size_t)P.grid_nx * P.grid_nz;
+        goff.assign(ncell + 1, 0);
+        for (int iz = 0; iz < P.grid_nz; iz++)
+            for (int ix = 0; ix < P.grid_nx; ix++) {
+                const double cx0 = P.grid_x0 + ix * (double)GRID_CELL, cz0 = P.grid_z0 + iz * (double)GRID_CELL;
+                const double cx1 = cx0 + GRID_CELL, cz1 = cz0 + GRID_CELL;
+                const size_t c = (size_t)iz * P.grid_nx + ix;
+                if (gidx.size() > 65000) { err = "hk_create: wall grid too large"; return HK_ERR_UNSUPPORTED; }
+                goff[c] = (unsigned short)gidx.size();
+                for (size_t w = 0; w < walls.size(); w++) {
+                    const hk_wall_seg& s = walls[w];
+                    auto inside = [&](double x, double z) { return x >= cx0 && x <= cx1 && z >= cz0 && z <= cz1; };
+                    double dmin = (inside(s.x0, s.z0) || inside(s.x1, s.z1)) ? 0.0 : 1e30;
+                    const double ex[5] = {cx0, cx1, cx1, cx0, cx0}, ez[5] = {cz0, cz0, cz1, cz1, cz0};
+                    for (int q = 0; q < 4 && dmin > 0.0; q++)
+                        dmin = std::min(dmin, detail::seg_seg_dist(s.x0, s.z0, s.x1, s.z1, ex[q], ez[q], ex[q + 1], ez[q + 1]));
+                    if (dmin <= (double)GRID_REACH) gidx.push_back((unsigned short)w);
+                }
+            }
+        goff[ncell] = (unsigned short)gidx.size();
+    }
     // cut table: Physics.Raycast(lane marker -> next lane marker) vs every wall (HKA:832), static geometry
     std::vector<unsigned char> cut((size_t)L * 25, 0);
     for (int s = 0; s < L; s++)
@@ -180,17 +192,31 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     for (int i = 0; i < A; i++) perm[i] = i;
     do { perms.insert(perms.end(), perm.begin(), perm.end()); } while (std::next_permutation(perm.begin(), perm.end()));
     P.nperm = (int)(perms.size() / A);
+    // pack the tables: [SecDev L][walls NW][grid_off u16][grid_idx u16][cut u8], 16-B aligned
+    {
+        if (walls.size() > 65535) { err = "hk_create: more than 65535 wall segments"; return HK_ERR_UNSUPPORTED; }
+        std::vector<unsigned char> pk;
+        auto seg = [&](const void* src, size_t bytes) {
+            size_t off = (pk.size() + 15) & ~size_t(15);
+            pk.resize(off + bytes);
+            if (bytes) std::memcpy(pk.data() + off, src, bytes);
+            return (int)off;
+        };
+        seg(sd.data(), sd.size() * sizeof(SecDev));
+        P.o_walls = seg(walls.data(), walls.size() * sizeof(hk_wall_seg));
+        P.o_goff = seg(goff.data(), goff.size() * sizeof(unsigned short));
+        P.o_gidx = seg(gidx.data(), gidx.size() * sizeof(unsigned short));
+        P.o_cut = seg(cut.data(), cut.size());
+        pk.resize((pk.size() + 15) & ~size_t(15));
+        P.tab_bytes = (int)pk.size();
+        int rc0;
+        if ((rc0 = detail::upload(&d.tab, pk, err))) return rc0;
+        P.tab = d.tab;
+        d.tab_lds = P.tab_bytes <= 48 * 1024 ? P.tab_bytes : 0;      // Oval: ~20 KB per block
+    }
     int rc;
-    if ((rc = detail::upload(&d.sec, sd, err))) return rc;
-    if ((rc = detail::upload(&d.walls, walls, err))) return rc;
-    if ((rc = detail::upload(&d.near_off, noff, err))) return rc;
-    if ((rc = detail::upload(&d.near_idx, nidx, err))) return rc;
-    if ((rc = detail::upload(&d.far_off, foff, err))) return rc;
-    if ((rc = detail::upload(&d.far_idx, fidx, err))) return rc;
-    if ((rc = detail::upload(&d.cut, cut, err))) return rc;
     if ((rc = detail::upload(&d.perms, perms, err))) return rc;
-    P.sec = d.sec; P.walls = d.walls; P.near_off = d.near_off; P.near_idx = d.near_idx; P.far_off = d.far_off; P.far_idx = d.far_idx;
-    P.cut = d.cut; P.perms = d.perms;
+    P.perms = d.perms;
     const size_t na = (size_t)E * A;
     const int obs_dim = HK_NUM_SENSORS + cfg.section_horizon * 5 + 8 + 12 * (A - 1);
     hipError_t e;
@@ -208,6 +234,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     HK_ALLOC(d.games, na * sizeof(GameDesc));
     HK_ALLOC(d.queue_cnt, 8 * sizeof(int));
     HK_ALLOC(d.queue, 3 * na * sizeof(int));
+    HK_ALLOC(d.cyc, 16 * sizeof(unsigned long long));
 #undef HK_ALLOC
     // REC.Start :148-168: every agent starts inactive; results carry episode = -1; RL branch defaults to "coast"
     {
@@ -275,12 +302,10 @@ inline int env_launch_solve(EnvDevice& d, const hk_config& cfg, hipStream_t stre
 {
     const int ngames = cfg.num_envs * cfg.num_agents;
     const int threads = cfg.num_envs * 4;
-    hipLaunchKernelGGL(env_assemble_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.envs, d.games,
-                       d.queue_cnt, d.queue, d.lq_debug);
+    hipLaunchKernelGGL(env_assemble_kernel, dim3((threads + 255) / 256), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs, d.games,
+                       d.queue_cnt, d.queue, d.lq_debug, d.status, d.cyc, d.tab_lds ? 1 : 0);
     int rc = launch_check(err, "env_assemble_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(lq1_kernel, dim3((ngames + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.games, ngames, d.lq_debug, d.status);
-    if ((rc = launch_check(err, "lq1_kernel"))) return rc;
     if (cfg.num_agents >= 2) {
         const int blocks = std::min((ngames + 3) / 4, 8192);
         hipLaunchKernelGGL(lqn_kernel<2>, dim3(blocks), dim3(64), 0, stream, d.P, d.agents, d.games, d.queue_cnt, d.queue, d.lq_debug, d.status);
@@ -300,7 +325,8 @@ inline int env_launch_solve(EnvDevice& d, const hk_config& cfg, hipStream_t stre
 inline int env_launch_step(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
 {
     const int threads = cfg.num_envs * 4;
-    hipLaunchKernelGGL(env_move_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.envs, d.act_steer, d.act_branch);
+    hipLaunchKernelGGL(env_move_kernel, dim3((threads + 255) / 256), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs, d.act_steer, d.act_branch,
+                       d.tab_lds ? 1 : 0);
     return launch_check(err, "env_move_kernel");
 }
 

@@ -29,6 +29,7 @@ __device__ inline void inv_transform_point(const hk_agent_state* a, float wx, fl
 
 __global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_agent_state* agents, float* obs)
 {
+    const TabView T = tab_view(P, P.tab);
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= P.E * P.A) return;
     const int env = gid / P.A, i = gid % P.A;
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_
     o[p++] = a->lane_changes * 1.0f / P.max_lane_changes;
     o[p++] = (a->flags & HK_F_ACTIVE) ? 1.0f : 0.0f;
     o[p++] = a->section_index * 1.0f / goal;
-    o[p++] = is_straight(P, a->section_index) ? 1.0f : 0.0f;
+    o[p++] = is_straight(P, T, a->section_index) ? 1.0f : 0.0f;
     o[p++] = tire_wear(P, a->final_steer);
     for (int pass = 0; pass < 2; pass++) {
         const int cnt = pass == 0 ? P.n_team[i] : P.n_other[i];
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_
             o[p++] = (float)b->lane;
             o[p++] = b->lane_changes * 1.0f / P.max_lane_changes;
             o[p++] = (b->flags & HK_F_ACTIVE) ? 1.0f : 0.0f;
-            o[p++] = is_straight(P, b->section_index) ? 1.0f : 0.0f;
+            o[p++] = is_straight(P, T, b->section_index) ? 1.0f : 0.0f;
             o[p++] = tire_wear(P, b->final_steer);
             o[p++] = b->section_index * 1.0f / goal;
             o[p++] = mag3(b->px - a->px, 0.0f, b->pz - a->pz);
@@ -71,16 +72,16 @@ __global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_
         const int pl = a->plan_lane[next];
         if (pl != 0) {
             float mx, mz;
-            lane_marker(P, next, pl, mx, mz);
-            inv_transform_point(a, mx, P.sec[next].marker_y, mz, P.kart_y, lp);
+            lane_marker(T, next, pl, mx, mz);
+            inv_transform_point(a, mx, T.sec[next].marker_y, mz, P.kart_y, lp);
             o[p++] = lp[0]; o[p++] = lp[1]; o[p++] = lp[2];
             o[p++] = a->plan_vel[next] / P.max_speed;
         } else {
-            inv_transform_point(a, P.sec[next].trig_x, P.sec[next].marker_y, P.sec[next].trig_z, P.kart_y, lp);
+            inv_transform_point(a, T.sec[next].trig_x, T.sec[next].marker_y, T.sec[next].trig_z, P.kart_y, lp);
             o[p++] = lp[0]; o[p++] = lp[1]; o[p++] = lp[2];
             o[p++] = 1.0f;
         }
-        o[p++] = is_straight(P, next) ? 1.0f : 0.0f;
+        o[p++] = is_straight(P, T, next) ? 1.0f : 0.0f;
     }
     const float fx = hk_sinf(a->yaw), fz = hk_cosf(a->yaw);
     const float ox = a->px + SENSOR_LZ * fx, oz = a->pz + SENSOR_LZ * fz;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_
         const float maxd = P.ray_dist[si];
         float ht = -1.0f;
         for (int w = 0; w < P.NW; w++) {
-            float t = ray_seg(ox, oz, dx, dz, P.walls[w]);
+            float t = ray_seg(ox, oz, dx, dz, T.walls[w]);
             if (t >= 0.0f && t <= maxd && (ht < 0.0f || t < ht)) ht = t;
         }
         float ha = -1.0f;

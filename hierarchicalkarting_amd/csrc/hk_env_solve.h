@@ -48,300 +48,6 @@ __device__ __forceinline__ double angle_difference(double a1, double a2)
     return hk_atan2(hk_sin(a2 - a1), hk_cos(a2 - a1));
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// K_B1
-// ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void env_assemble_kernel(EnvParams P, const hk_agent_state* agents, const hk_env_state* envs,
-                                                           GameDesc* games, int* queue_cnt, int* queue, hk_lq_debug* dbg_out)
-{
-    __shared__ KartS ks[256];
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int env = gid >> 2, ego = gid & 3;
-    const int A = P.A, L = P.L;
-    const bool env_ok = env < P.E;
-    bool act = false;            // does this env solve on this tick?
-    hk_env_state es;
-    es.episode_steps = 0; es.inactive_mask = 0; es.status = 0;
-    if (env_ok) {
-        es = envs[env];
-        const uint32_t all_mask = (1u << A) - 1u;
-        act = (es.episode_steps % (A > 2 ? 4 : 1)) == 0;                              // HKA:317 (Q9)
-        if (!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u)) act = false;
-    }
-    const bool me = act && ego < A;
-    if (env_ok && ego < A && !act) games[(size_t)env * A + ego].N = 0;      // nothing to solve for this env on this tick
-    const hk_agent_state* a = me ? &agents[(size_t)env * A + ego] : nullptr;
-    KartS k;
-    k.px = k.pz = k.yaw = k.fx = k.fz = k.speed = k.heading = k.msfs = k.dC = 0.0f;
-    k.sec = 0; k.straight = 1; k.pl1 = k.pl2 = 0; k.pv1 = k.pv2 = 0.0f; k.flags = 0; k.pad_ = 0;
-#pragma unroll
-    for (int q = 0; q < 5; q++) k.ray[q] = 3.0e38f;
-    if (me) {
-        k.px = a->px; k.pz = a->pz; k.yaw = a->yaw;
-        k.fx = hk_sinf(k.yaw); k.fz = hk_cosf(k.yaw);
-        const float vx = a->vx, vz = a->vz;
-        k.speed = mag3(vx, 0.0f, vz);
-        float heading = hk_atan2f(k.fz, k.fx);                                        // HKA:734
-        if (heading < 0) heading += TWO_PI_F;
-        k.heading = heading;
-        k.msfs = max_speed_for_state(P, k.yaw, vx, vz, a->wy, a->final_steer);
-        k.sec = a->section_index;
-        k.straight = is_straight(P, k.sec) ? 1 : 0;
-        k.flags = a->flags;
-        const int i1 = (k.sec + 1) % L, i2 = (k.sec + 2) % L;
-        k.pl1 = a->plan_lane[i1]; k.pv1 = a->plan_vel[i1];
-        k.pl2 = a->plan_lane[i2]; k.pv2 = a->plan_vel[i2];
-        {   // BoxCollider.ClosestPoint distance to the next section's Trigger (HKA:846,876)
-            const SecDev& s = P.sec[i1];
-            float relx = k.px - s.trig_x, relz = k.pz - s.trig_z;
-            float lx = relx * s.fz + relz * (-s.fx);
-            float lz = relx * s.fx + relz * s.fz;
-            float dx = lx - f_clamp(lx, -TRIG_HX, TRIG_HX);
-            float dz = lz - f_clamp(lz, -TRIG_HZ, TRIG_HZ);
-            k.dC = sqrtf(dx * dx + dz * dz);
-        }
-        // sensor rays of the own kart (Physics.Raycast vs TrackMask, HKA:834-844,906): sensor 0 may reach 8 m (far
-        // list), sensors 2, 4, 8, 6 at most 2 m (near list); both lists are supersets of what the ray can reach
-        const float ox = k.px + SENSOR_LZ * k.fx, oz = k.pz + SENSOR_LZ * k.fz;
-        const int sidx = k.sec % L;
-        {
-            const float dx = k.fx, dz = k.fz;       // sensor 0: yaw + 0
-            const float ang0 = k.yaw + P.sensor_yaw[0] * DEG2RAD_F;
-            const float d0x = hk_sinf(ang0), d0z = hk_cosf(ang0);
-            (void)dx; (void)dz;
-            float best = 3.0e38f;
-            const int w0 = P.far_off[sidx], w1 = P.far_off[sidx + 1];
-            for (int w = w0; w < w1; w++) {
-                float t = ray_seg(ox, oz, d0x, d0z, P.walls[P.far_idx[w]]);
-                if (t >= 0.0f && t < best) best = t;
-            }
-            k.ray[0] = best;
-        }
-        {
-            const int ssel[4] = {2, 4, 8, 6};
-            float ddx[4], ddz[4], best[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                float ang = k.yaw + P.sensor_yaw[ssel[q]] * DEG2RAD_F;
-                ddx[q] = hk_sinf(ang); ddz[q] = hk_cosf(ang);
-                best[q] = 3.0e38f;
-            }
-            const int w0 = P.near_off[sidx], w1 = P.near_off[sidx + 1];
-            for (int w = w0; w < w1; w++) {
-                const hk_wall_seg ws = P.walls[P.near_idx[w]];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    float t = ray_seg(ox, oz, ddx[q], ddz[q], ws);
-                    if (t >= 0.0f && t < best[q]) best[q] = t;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) k.ray[1 + q] = best[q];
-        }
-    }
-    ks[threadIdx.x] = k;
-    __syncthreads();
-    if (!me) return;
-    const KartS* kq = &ks[threadIdx.x & ~3];          // the env's four karts
-    GameDesc* G = &games[(size_t)env * A + ego];
-    const bool solving = (k.flags & HK_F_ENABLED) && P.low_mode[ego] == HK_LOW_LQR && !((es.inactive_mask >> ego) & 1u);
-    if (!solving) { G->N = 0; return; }
-    // ---- players (HKA:702-725)
-    int pl[ENV_MAXA] = {0, 0, 0, 0};
-    int N = 0, nearbyAgents = -1;
-    {
-        int all[ENV_MAXA], nall = 0;
-        all[nall++] = ego;
-        for (int j = 0; j < P.n_team[ego]; j++) all[nall++] = P.team[ego][j];
-        for (int j = 0; j < P.n_other[ego]; j++) all[nall++] = P.other[ego][j];
-        if (A > 2) {
-            for (int q = 0; q < nall; q++) {
-                const KartS& o = kq[all[q]];
-                if (mag3(o.px - k.px, 0.0f, o.pz - k.pz) < 8) { nearbyAgents += 1; pl[N++] = all[q]; }
-            }
-        } else {
-            for (int q = 0; q < nall; q++) pl[N++] = all[q];
-        }
-        nearbyAgents = nearbyAgents > 1 ? nearbyAgents : 1;
-    }
-    const bool fixed = P.high_mode[ego] == HK_HIGH_FIXED;
-    const float dy = P.sec[0].marker_y - P.kart_y;                                    // Q13
-    const KartS& mek = kq[ego];
-    for (int i = 0; i < N; i++) {                                                     // HKA:726
-        const int ki = pl[i];
-        const KartS& kk = kq[ki];
-        GamePlayer* gp = &G->p[i];
-        const float speed = kk.speed;
-        double initial[4];
-        initial[0] = kk.px; initial[1] = kk.pz; initial[2] = speed; initial[3] = kk.heading;
-        {   // LinearizedBicycle (KartLQRDynamics.cs:40-62), dt = Time.fixedDeltaTime widened to double (HKA:707)
-            const double dt = (double)P.dt;
-            gp->a4[0] = hk_cos(initial[3]) * dt;
-            gp->a4[1] = hk_sin(initial[3]) * dt;
-            gp->a4[2] = -hk_sin(initial[3]) * dt * initial[2];
-            gp->a4[3] = hk_cos(initial[3]) * dt * initial[2];
-        }
-        const int s = kk.sec + 1;                                                     // :746
-        const int idx = s % L, idx2 = (s + 1) % L;
-        int laneSel = 0, nextSel = 0;
-        double vel = P.max_speed, nextVel = P.max_speed;
-        if (ki == ego) {                                                              // :752-764, :782-794
-            if (mek.pl1 != 0) {
-                laneSel = mek.pl1;
-                double pv = mek.pv1 + (fixed ? 0 : P.vbucket[ego] * 2);
-                vel = (double)P.max_speed < pv ? (double)P.max_speed : pv;
-            }
-            if (mek.pl2 != 0) {
-                nextSel = mek.pl2;
-                double pv = mek.pv2 + (fixed ? 0 : P.vbucket[ego] * 2);
-                nextVel = (double)P.max_speed < pv ? (double)P.max_speed : pv;
-            }
-        }   // else: the ego's belief about k's plan is only ever filled by the MCTS planner -> Trigger / max speed
-        float lx, lz, nx, nz, cx, cz;
-        lane_marker(P, idx, laneSel, lx, lz);
-        lane_marker(P, idx2, nextSel, nx, nz);
-        lane_marker(P, idx, 0, cx, cz);
-        double target[4];
-        target[0] = lx; target[1] = lz;
-        target[2] = (speed <= 5.0f) ? 0.0f : vel;                                     // :810-817
-        double fth;
-        int branch;
-        float targetHeading = hk_atan2f(lz - kk.pz, lx - kk.px);                      // :821
-        if (targetHeading < 0) targetHeading += TWO_PI_F;
-        if (mag3(lx - kk.px, dy, lz - kk.pz) <= (kk.straight ? 10.5f : 7.5f)) {       // :823
-            float h1 = hk_atan2f(lz - kk.pz, lx - kk.px);
-            float h5 = hk_atan2f(cz - kk.pz, cx - kk.px);
-            const bool cutTrack = P.cut[(idx * 5 + laneSel) * 5 + nextSel] != 0;      // :832 (static geometry)
-            const bool hit0 = kk.ray[0] <= speed * 0.5f;                              // :834
-            const bool side = (kk.ray[1] <= 2.0f) || (kk.ray[2] <= 1.5f) || (kk.ray[3] <= 1.5f) || (kk.ray[4] <= 2.0f);
-            const float dC = kk.dC;
-            if (cutTrack && dC > 4.0f) {                                              // B1 :846
-                branch = 1;
-                if (h5 < 0) h5 += TWO_PI_F;
-                fth = h5;
-                if (fth < 0) fth += TWO_PI_F;
-                fth = initial[3] - angle_difference(initial[3], fth);
-            } else if ((side && (f_sign(h1) == f_sign(h5))) || hit0) {                // B2 :857 (Q12)
-                branch = 2;
-                if (h5 < 0) h5 += TWO_PI_F;
-                fth = h5 - angle_difference(h1, h5) * 0.7f;
-                if (fth < 0) fth += TWO_PI_F;
-                fth = initial[3] - angle_difference(initial[3], fth);
-            } else if (side && (f_sign(h1) != f_sign(h5))) {                          // B3 :867
-                branch = 3;
-                if (h5 < 0) h5 += TWO_PI_F;
-                fth = h5;
-                if (fth < 0) fth += TWO_PI_F;
-                fth = initial[3] - angle_difference(initial[3], fth);
-            } else if (dC <= 4.0f) {                                                  // B4 :876
-                branch = 4;
-                float h6 = hk_atan2f(nz - kk.pz, nx - kk.px);
-                target[0] = nx; target[1] = nz;
-                if (speed > 5.0f) target[2] = nextVel;
-                if (h6 < 0) h6 += TWO_PI_F;
-                fth = h6;
-                if (fth < 0) fth += TWO_PI_F;
-                fth = initial[3] - angle_difference(initial[3], fth);
-            } else {                                                                  // B5 :891
-                branch = 5;
-                float h2 = hk_atan2f(nz - lz, nx - lx);
-                if (h1 < 0) h1 += TWO_PI_F;
-                if (h2 < 0) h2 += TWO_PI_F;
-                fth = h1 - angle_difference(h2, h1) * 0.4f;
-                if (fth < 0) fth += TWO_PI_F;
-                fth = initial[3] - angle_difference(initial[3], fth);
-            }
-        } else {
-            const bool hit = kk.ray[0] <= (kk.straight ? 8.0f : 5.0f);                // :906
-            if (hit) {                                                                // B6
-                branch = 6;
-                float h1 = hk_atan2f(cz - kk.pz, cx - kk.px);
-                if (h1 < 0) h1 += TWO_PI_F;
-                fth = initial[3] - angle_difference(initial[3], h1) * 0.85f;
-            } else {                                                                  // B7
-                branch = 7;
-                fth = initial[3] - angle_difference(initial[3], targetHeading);
-            }
-        }
-        target[3] = fth;                                                              // :926
-        double tw[4];                                                                 // :930-964
-        if (N > 2) tw[3] = (fixed ? 2.5 : 3.5) * nearbyAgents; else tw[3] = (fixed ? 1.9 : 3.5);
-        if (speed <= 5.0f) {
-            tw[0] = nearbyAgents * 0.3 * 3.1; tw[1] = nearbyAgents * 0.3 * 3.1; tw[2] = nearbyAgents * -2;
-        } else {
-            double mx = initial[2] > 1 ? initial[2] : 1;
-            tw[0] = nearbyAgents * 0.3 * 3.1 / mx; tw[1] = nearbyAgents * 0.3 * 3.1 / mx; tw[2] = nearbyAgents * 5e-4;
-        }
-        float multiplier;                                                             // :976-1003
-        if (A > 2 && N > 2) multiplier = (ki == ego ? (fixed ? 0.55f : 1.0f) : 1.7f) / nearbyAgents;
-        else multiplier = (ki == ego ? (fixed ? 0.45f : 1.0f) : 1.3f);
-        int M = 0, nearbyOpponents = 0;
-        const int no = P.n_other[ki], nt = P.n_team[ki];
-        for (int j = 0; j < no + nt; j++) {                                           // :1004-1190, k's own order (Q3)
-            const bool isteam = j >= no;
-            const int oi = isteam ? P.team[ki][j - no] : P.other[ki][j];
-            bool member = false;
-            for (int q = 0; q < N; q++) if (pl[q] == oi) member = true;
-            if (!member) continue;
-            const KartS& o = kq[oi];
-            const float dist = mag3(o.px - kk.px, 0.0f, o.pz - kk.pz);
-            const bool far = (dist > 8) || !(o.flags & HK_F_ACTIVE);
-            double w = 0.0;
-            if (!far) {
-                float mult = isteam ? multiplier / 2.0f : multiplier;
-                float pw = (float)((double)dist * sqrt((double)dist));                // Mathf.Pow(d, 1.5f)
-                w = 1.0f / (pw * mult);
-                if (!isteam) nearbyOpponents += 1;
-            }
-            gp->aw[M] = w;
-            const int io = (o.sec + 1) % L;
-            float olx, olz; double ov;
-            if (oi == ego) {
-                lane_marker(P, io, mek.pl1, olx, olz);
-                if (isteam) ov = mek.msfs;
-                else if (mek.pl1 != 0) {
-                    double pv = mek.pv1 + (fixed ? 0 : P.vbucket[ego] * 2);
-                    ov = (double)P.max_speed < pv ? (double)P.max_speed : pv;
-                } else ov = P.max_speed;
-            } else {
-                lane_marker(P, io, 0, olx, olz);
-                ov = isteam ? o.msfs : P.max_speed;
-            }
-            gp->opt[M][0] = olx; gp->opt[M][1] = olz; gp->opt[M][2] = ov;
-            double mx = initial[2] > 1 ? initial[2] : 1;
-            double w0, w1, w2;
-            if (!isteam) {
-                if (far) { w0 = 0.0; w1 = 0.0; w2 = 0; }
-                else if (N > 2) { w0 = (fixed ? 0.1 : 0.2) / (mx * nearbyAgents); w1 = (fixed ? 0.1 : 0.2) / (mx * nearbyAgents); w2 = 0.08 / nearbyAgents; }
-                else { w0 = (fixed ? 0.1 : 0.2) / mx; w1 = (fixed ? 0.1 : 0.2) / mx; w2 = 0.08; }
-            } else {
-                if (far || nearbyOpponents < 1) { w0 = 0.0; w1 = 0.0; w2 = 0; }
-                else if (N > 2) { w0 = -(fixed ? 0 : 3e-5) / (mx * nearbyAgents); w1 = -(fixed ? 0 : 3e-5) / (mx * nearbyAgents); w2 = 0 / nearbyAgents; }
-                else { w0 = -(fixed ? 1e-4 : 2e-4) / mx; w1 = -(fixed ? 1e-4 : 2e-4) / mx; w2 = 0; }
-            }
-            gp->opw[M][0] = w0; gp->opw[M][1] = w1; gp->opw[M][2] = w2;
-            M++;
-        }
-        double controlcost = 0.115;                                                   // :1192-1196
-        if (N > 2) controlcost = fixed ? 0.135 : 0.25;
-        gp->rc = 1.0 * controlcost;                                                   // getRMatrix: SparseIdentity * w
-        gp->M = M; gp->agent = ki; gp->branch = branch;
-#pragma unroll
-        for (int c = 0; c < 4; c++) { gp->x0[c] = initial[c]; gp->tw[c] = tw[c]; gp->tgt[c] = target[c]; }
-        if (dbg_out && P.debug) {
-            hk_lq_debug* d = &dbg_out[(size_t)env * A + ego];
-            d->player_agent[i] = ki; d->branch[i] = branch; d->control_w[i] = controlcost;
-            for (int c = 0; c < 4; c++) { d->initial[i][c] = initial[c]; d->target[i][c] = target[c]; d->target_w[i][c] = tw[c]; }
-        }
-    }
-    G->N = N;
-    if (dbg_out && P.debug) dbg_out[(size_t)env * A + ego].n_players = N;
-    if (N >= 2) {                                                                     // bin multi-player games by N
-        const int pos = atomicAdd(&queue_cnt[N], 1);
-        queue[(size_t)(N - 2) * P.E * A + pos] = env * A + ego;
-    }
-}
-
 // HKA:1206-1224
 __device__ inline void decode_controls(const EnvParams& P, hk_agent_state* me, double u0a, double u0b, hk_lq_debug* dbg)
 {
@@ -358,18 +64,12 @@ __device__ inline void decode_controls(const EnvParams& P, hk_agent_state* me, d
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// K_B2a: single-player games, one thread each.  Dense 4x4 / 2x2 algebra with the SAME fma chains as the generic
+// single-player games, solved by the assembling thread itself (lq1_solve).  Dense 4x4 / 2x2 algebra with the SAME fma chains as the generic
 // algorithm (k ascending, seeded +0.0); entries of A, B that are structural zeros are skipped (exact), entries
 // that are 1.0 enter through fma(z, 1.0, s) like any other value.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lq1_kernel(EnvParams P, hk_agent_state* agents, const GameDesc* games, int ngames,
-                                                  hk_lq_debug* dbg_out, int* status)
+__device__ inline void lq1_solve(const EnvParams& P, const GamePlayer& gp, hk_agent_state* me, hk_lq_debug* dbg, int* status)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ngames) return;
-    const GameDesc* G = &games[g];
-    if (G->N != 1) return;
-    const GamePlayer& gp = G->p[0];
     const double dt = (double)P.dt;
     double A[4][4] = {{1.0, 0.0, gp.a4[0], gp.a4[2]}, {0.0, 1.0, gp.a4[1], gp.a4[3]}, {0.0, 0.0, 1.0, 0.0}, {0.0, 0.0, 0.0, 1.0}};
     const double R[2][2] = {{gp.rc, 0.0}, {0.0, gp.rc}};
@@ -526,7 +226,344 @@ __global__ __launch_bounds__(256) void lq1_kernel(EnvParams P, hk_agent_state* a
         u0[a] = s - alpha[a];
     }
     if (singular) atomicOr(status, 1);
-    decode_controls(P, &agents[g], u0[0], u0[1], (dbg_out && P.debug) ? &dbg_out[g] : nullptr);
+    decode_controls(P, me, u0[0], u0[1], dbg);
+}
+
+// one player's share of the ego's game (HKA:726-1198); `out` is a register struct for single-player games and the
+// global descriptor otherwise
+template <bool SINGLE>
+__device__ __forceinline__ void assemble_player(const EnvParams& P, const TabView& T, const int env, const int ego, const int i, const int N,
+                                                const int nearbyAgents, const int* pl, const KartS* kq, const bool fixed,
+                                                const float dy, GamePlayer* gp, hk_lq_debug* dbg_out)
+{
+    const int A = P.A, L = P.L;
+    const KartS& mek = kq[ego];
+        const int ki = pl[i];
+        const KartS& kk = kq[ki];
+        const float speed = kk.speed;
+        double initial[4];
+        initial[0] = kk.px; initial[1] = kk.pz; initial[2] = speed; initial[3] = kk.heading;
+        {   // LinearizedBicycle (KartLQRDynamics.cs:40-62), dt = Time.fixedDeltaTime widened to double (HKA:707)
+            const double dt = (double)P.dt;
+            gp->a4[0] = hk_cos(initial[3]) * dt;
+            gp->a4[1] = hk_sin(initial[3]) * dt;
+            gp->a4[2] = -hk_sin(initial[3]) * dt * initial[2];
+            gp->a4[3] = hk_cos(initial[3]) * dt * initial[2];
+        }
+        const int s = kk.sec + 1;                                                     // :746
+        const int idx = s % L, idx2 = (s + 1) % L;
+        int laneSel = 0, nextSel = 0;
+        double vel = P.max_speed, nextVel = P.max_speed;
+        if (ki == ego) {                                                              // :752-764, :782-794
+            if (mek.pl1 != 0) {
+                laneSel = mek.pl1;
+                double pv = mek.pv1 + (fixed ? 0 : P.vbucket[ego] * 2);
+                vel = (double)P.max_speed < pv ? (double)P.max_speed : pv;
+            }
+            if (mek.pl2 != 0) {
+                nextSel = mek.pl2;
+                double pv = mek.pv2 + (fixed ? 0 : P.vbucket[ego] * 2);
+                nextVel = (double)P.max_speed < pv ? (double)P.max_speed : pv;
+            }
+        }   // else: the ego's belief about k's plan is only ever filled by the MCTS planner -> Trigger / max speed
+        float lx, lz, nx, nz, cx, cz;
+        lane_marker(T, idx, laneSel, lx, lz);
+        lane_marker(T, idx2, nextSel, nx, nz);
+        lane_marker(T, idx, 0, cx, cz);
+        double target[4];
+        target[0] = lx; target[1] = lz;
+        target[2] = (speed <= 5.0f) ? 0.0f : vel;                                     // :810-817
+        double fth;
+        int branch;
+        float targetHeading = hk_atan2f(lz - kk.pz, lx - kk.px);                      // :821
+        if (targetHeading < 0) targetHeading += TWO_PI_F;
+        if (mag3(lx - kk.px, dy, lz - kk.pz) <= (kk.straight ? 10.5f : 7.5f)) {       // :823
+            float h1 = hk_atan2f(lz - kk.pz, lx - kk.px);
+            float h5 = hk_atan2f(cz - kk.pz, cx - kk.px);
+            const bool cutTrack = T.cut[(idx * 5 + laneSel) * 5 + nextSel] != 0;      // :832 (static geometry)
+            const bool hit0 = kk.ray[0] <= speed * 0.5f;                              // :834
+            const bool side = (kk.ray[1] <= 2.0f) || (kk.ray[2] <= 1.5f) || (kk.ray[3] <= 1.5f) || (kk.ray[4] <= 2.0f);
+            const float dC = kk.dC;
+            if (cutTrack && dC > 4.0f) {                                              // B1 :846
+                branch = 1;
+                if (h5 < 0) h5 += TWO_PI_F;
+                fth = h5;
+                if (fth < 0) fth += TWO_PI_F;
+                fth = initial[3] - angle_difference(initial[3], fth);
+            } else if ((side && (f_sign(h1) == f_sign(h5))) || hit0) {                // B2 :857 (Q12)
+                branch = 2;
+                if (h5 < 0) h5 += TWO_PI_F;
+                fth = h5 - angle_difference(h1, h5) * 0.7f;
+                if (fth < 0) fth += TWO_PI_F;
+                fth = initial[3] - angle_difference(initial[3], fth);
+            } else if (side && (f_sign(h1) != f_sign(h5))) {                          // B3 :867
+                branch = 3;
+                if (h5 < 0) h5 += TWO_PI_F;
+                fth = h5;
+                if (fth < 0) fth += TWO_PI_F;
+                fth = initial[3] - angle_difference(initial[3], fth);
+            } else if (dC <= 4.0f) {                                                  // B4 :876
+                branch = 4;
+                float h6 = hk_atan2f(nz - kk.pz, nx - kk.px);
+                target[0] = nx; target[1] = nz;
+                if (speed > 5.0f) target[2] = nextVel;
+                if (h6 < 0) h6 += TWO_PI_F;
+                fth = h6;
+                if (fth < 0) fth += TWO_PI_F;
+                fth = initial[3] - angle_difference(initial[3], fth);
+            } else {                                                                  // B5 :891
+                branch = 5;
+                float h2 = hk_atan2f(nz - lz, nx - lx);
+                if (h1 < 0) h1 += TWO_PI_F;
+                if (h2 < 0) h2 += TWO_PI_F;
+                fth = h1 - angle_difference(h2, h1) * 0.4f;
+                if (fth < 0) fth += TWO_PI_F;
+                fth = initial[3] - angle_difference(initial[3], fth);
+            }
+        } else {
+            const bool hit = kk.ray[0] <= (kk.straight ? 8.0f : 5.0f);                // :906
+            if (hit) {                                                                // B6
+                branch = 6;
+                float h1 = hk_atan2f(cz - kk.pz, cx - kk.px);
+                if (h1 < 0) h1 += TWO_PI_F;
+                fth = initial[3] - angle_difference(initial[3], h1) * 0.85f;
+            } else {                                                                  // B7
+                branch = 7;
+                fth = initial[3] - angle_difference(initial[3], targetHeading);
+            }
+        }
+        target[3] = fth;                                                              // :926
+        double tw[4];                                                                 // :930-964
+        if (N > 2) tw[3] = (fixed ? 2.5 : 3.5) * nearbyAgents; else tw[3] = (fixed ? 1.9 : 3.5);
+        if (speed <= 5.0f) {
+            tw[0] = nearbyAgents * 0.3 * 3.1; tw[1] = nearbyAgents * 0.3 * 3.1; tw[2] = nearbyAgents * -2;
+        } else {
+            double mx = initial[2] > 1 ? initial[2] : 1;
+            tw[0] = nearbyAgents * 0.3 * 3.1 / mx; tw[1] = nearbyAgents * 0.3 * 3.1 / mx; tw[2] = nearbyAgents * 5e-4;
+        }
+        float multiplier;                                                             // :976-1003
+        if (A > 2 && N > 2) multiplier = (ki == ego ? (fixed ? 0.55f : 1.0f) : 1.7f) / nearbyAgents;
+        else multiplier = (ki == ego ? (fixed ? 0.45f : 1.0f) : 1.3f);
+        int M = 0, nearbyOpponents = 0;
+        const int no = P.n_other[ki], nt = P.n_team[ki];
+        // a single-player game has no other members: the loop below would skip every j
+        for (int j = 0; j < (SINGLE ? 0 : no + nt); j++) {                                           // :1004-1190, k's own order (Q3)
+            const bool isteam = j >= no;
+            const int oi = isteam ? P.team[ki][j - no] : P.other[ki][j];
+            bool member = false;
+            for (int q = 0; q < N; q++) if (pl[q] == oi) member = true;
+            if (!member) continue;
+            const KartS& o = kq[oi];
+            const float dist = mag3(o.px - kk.px, 0.0f, o.pz - kk.pz);
+            const bool far = (dist > 8) || !(o.flags & HK_F_ACTIVE);
+            double w = 0.0;
+            if (!far) {
+                float mult = isteam ? multiplier / 2.0f : multiplier;
+                float pw = (float)((double)dist * sqrt((double)dist));                // Mathf.Pow(d, 1.5f)
+                w = 1.0f / (pw * mult);
+                if (!isteam) nearbyOpponents += 1;
+            }
+            gp->aw[M] = w;
+            const int io = (o.sec + 1) % L;
+            float olx, olz; double ov;
+            if (oi == ego) {
+                lane_marker(T, io, mek.pl1, olx, olz);
+                if (isteam) ov = mek.msfs;
+                else if (mek.pl1 != 0) {
+                    double pv = mek.pv1 + (fixed ? 0 : P.vbucket[ego] * 2);
+                    ov = (double)P.max_speed < pv ? (double)P.max_speed : pv;
+                } else ov = P.max_speed;
+            } else {
+                lane_marker(T, io, 0, olx, olz);
+                ov = isteam ? o.msfs : P.max_speed;
+            }
+            gp->opt[M][0] = olx; gp->opt[M][1] = olz; gp->opt[M][2] = ov;
+            double mx = initial[2] > 1 ? initial[2] : 1;
+            double w0, w1, w2;
+            if (!isteam) {
+                if (far) { w0 = 0.0; w1 = 0.0; w2 = 0; }
+                else if (N > 2) { w0 = (fixed ? 0.1 : 0.2) / (mx * nearbyAgents); w1 = (fixed ? 0.1 : 0.2) / (mx * nearbyAgents); w2 = 0.08 / nearbyAgents; }
+                else { w0 = (fixed ? 0.1 : 0.2) / mx; w1 = (fixed ? 0.1 : 0.2) / mx; w2 = 0.08; }
+            } else {
+                if (far || nearbyOpponents < 1) { w0 = 0.0; w1 = 0.0; w2 = 0; }
+                else if (N > 2) { w0 = -(fixed ? 0 : 3e-5) / (mx * nearbyAgents); w1 = -(fixed ? 0 : 3e-5) / (mx * nearbyAgents); w2 = 0 / nearbyAgents; }
+                else { w0 = -(fixed ? 1e-4 : 2e-4) / mx; w1 = -(fixed ? 1e-4 : 2e-4) / mx; w2 = 0; }
+            }
+            gp->opw[M][0] = w0; gp->opw[M][1] = w1; gp->opw[M][2] = w2;
+            M++;
+        }
+        double controlcost = 0.115;                                                   // :1192-1196
+        if (N > 2) controlcost = fixed ? 0.135 : 0.25;
+        gp->rc = 1.0 * controlcost;                                                   // getRMatrix: SparseIdentity * w
+        gp->M = M; gp->agent = ki; gp->branch = branch;
+#pragma unroll
+        for (int c = 0; c < 4; c++) { gp->x0[c] = initial[c]; gp->tw[c] = tw[c]; gp->tgt[c] = target[c]; }
+        if (dbg_out && (P.debug & 1)) {
+            hk_lq_debug* d = &dbg_out[(size_t)env * A + ego];
+            d->player_agent[i] = ki; d->branch[i] = branch; d->control_w[i] = controlcost;
+            for (int c = 0; c < 4; c++) { d->initial[i][c] = initial[c]; d->target[i][c] = target[c]; d->target_w[i][c] = tw[c]; }
+        }
+    }
+
+// ---------------------------------------------------------------------------------------------------------------
+// K_B1
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void env_assemble_kernel(EnvParams P, const hk_agent_state* agents, const hk_env_state* envs,
+                                                           GameDesc* games, int* queue_cnt, int* queue, hk_lq_debug* dbg_out,
+                                                           int* status, unsigned long long* cyc, int use_lds)
+{
+    __shared__ KartS ks[256];
+    extern __shared__ __align__(16) unsigned char smem[];
+    const TabView T = tab_stage(P, smem, use_lds != 0);
+    const bool stamp = (P.debug & 128) && cyc && (threadIdx.x & 63) == 0;
+    unsigned long long tc0 = stamp ? clock64() : 0ull, tc1 = 0, tc2 = 0, tc3 = 0, tc4 = 0;
+#define HK_STAMP(v) do { if (stamp) v = clock64(); } while (0)
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int env = gid >> 2, ego = gid & 3;
+    const int A = P.A, L = P.L;
+    const bool env_ok = env < P.E;
+    bool act = false;            // does this env solve on this tick?
+    hk_env_state es;
+    es.episode_steps = 0; es.inactive_mask = 0; es.status = 0;
+    if (env_ok) {
+        es = envs[env];
+        const uint32_t all_mask = (1u << A) - 1u;
+        act = (es.episode_steps % (A > 2 ? 4 : 1)) == 0;                              // HKA:317 (Q9)
+        if (!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u)) act = false;
+    }
+    const bool me = act && ego < A;
+    if (env_ok && ego < A && !act) games[(size_t)env * A + ego].N = 0;      // nothing to solve for this env on this tick
+    const hk_agent_state* a = me ? &agents[(size_t)env * A + ego] : nullptr;
+    KartS k;
+    k.px = k.pz = k.yaw = k.fx = k.fz = k.speed = k.heading = k.msfs = k.dC = 0.0f;
+    k.sec = 0; k.straight = 1; k.pl1 = k.pl2 = 0; k.pv1 = k.pv2 = 0.0f; k.flags = 0; k.pad_ = 0;
+#pragma unroll
+    for (int q = 0; q < 5; q++) k.ray[q] = 3.0e38f;
+    if (me) {
+        k.px = a->px; k.pz = a->pz; k.yaw = a->yaw;
+        k.fx = hk_sinf(k.yaw); k.fz = hk_cosf(k.yaw);
+        const float vx = a->vx, vz = a->vz;
+        k.speed = mag3(vx, 0.0f, vz);
+        float heading = hk_atan2f(k.fz, k.fx);                                        // HKA:734
+        if (heading < 0) heading += TWO_PI_F;
+        k.heading = heading;
+        k.msfs = max_speed_for_state(P, k.yaw, vx, vz, a->wy, a->final_steer);
+        k.sec = a->section_index;
+        k.straight = is_straight(P, T, k.sec) ? 1 : 0;
+        k.flags = a->flags;
+        const int i1 = (k.sec + 1) % L, i2 = (k.sec + 2) % L;
+        k.pl1 = a->plan_lane[i1]; k.pv1 = a->plan_vel[i1];
+        k.pl2 = a->plan_lane[i2]; k.pv2 = a->plan_vel[i2];
+        {   // BoxCollider.ClosestPoint distance to the next section's Trigger (HKA:846,876)
+            const SecDev& s = T.sec[i1];
+            float relx = k.px - s.trig_x, relz = k.pz - s.trig_z;
+            float lx = relx * s.fz + relz * (-s.fx);
+            float lz = relx * s.fx + relz * s.fz;
+            float dx = lx - f_clamp(lx, -TRIG_HX, TRIG_HX);
+            float dz = lz - f_clamp(lz, -TRIG_HZ, TRIG_HZ);
+            k.dC = sqrtf(dx * dx + dz * dz);
+        }
+        HK_STAMP(tc1);
+        // sensor rays of the own kart (Physics.Raycast vs TrackMask, HKA:834-844,906) through the wall grid.  Sensors
+        // 2, 4, 8, 6 are at most 2 m long: every wall they can hit is in the list of the origin's cell.  Sensor 0 is
+        // compared with up to 8 m: a hit at distance t <= 9 lies within 1 m of one of the samples o + {0,2,4,6,8} d,
+        // so the union of those five cells' lists contains it.  Lists are supersets; the minimum is what a scan of
+        // every wall (the oracle) returns.
+        const float ox = k.px + SENSOR_LZ * k.fx, oz = k.pz + SENSOR_LZ * k.fz;
+        {
+            const float ang0 = k.yaw + P.sensor_yaw[0] * DEG2RAD_F;
+            const float d0x = hk_sinf(ang0), d0z = hk_cosf(ang0);
+            float best = 3.0e38f;
+            int prev = -1;
+#pragma unroll 1
+            for (int sm = 0; sm < 5; sm++) {
+                const float sd = 2.0f * (float)sm;
+                const int cell = grid_cell(P, ox + d0x * sd, oz + d0z * sd);
+                if (cell == prev) continue;
+                prev = cell;
+                const int w0 = T.grid_off[cell], w1 = T.grid_off[cell + 1];
+                for (int w = w0; w < w1; w++) {
+                    float t = ray_seg(ox, oz, d0x, d0z, T.walls[T.grid_idx[w]]);
+                    if (t >= 0.0f && t < best) best = t;
+                }
+            }
+            k.ray[0] = best;
+        }
+        {
+            const int ssel[4] = {2, 4, 8, 6};
+            float ddx[4], ddz[4], best[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float ang = k.yaw + P.sensor_yaw[ssel[q]] * DEG2RAD_F;
+                ddx[q] = hk_sinf(ang); ddz[q] = hk_cosf(ang);
+                best[q] = 3.0e38f;
+            }
+            const int cell = grid_cell(P, ox, oz);
+            const int w0 = T.grid_off[cell], w1 = T.grid_off[cell + 1];
+            for (int w = w0; w < w1; w++) {
+                const hk_wall_seg ws = T.walls[T.grid_idx[w]];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float t = ray_seg(ox, oz, ddx[q], ddz[q], ws);
+                    if (t >= 0.0f && t < best[q]) best[q] = t;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) k.ray[1 + q] = best[q];
+        }
+    }
+    HK_STAMP(tc2);
+    ks[threadIdx.x] = k;
+    __syncthreads();
+    if (!me) return;
+    const KartS* kq = &ks[threadIdx.x & ~3];          // the env's four karts
+    GameDesc* G = &games[(size_t)env * A + ego];
+    const bool solving = (k.flags & HK_F_ENABLED) && P.low_mode[ego] == HK_LOW_LQR && !((es.inactive_mask >> ego) & 1u);
+    if (!solving) { G->N = 0; return; }
+    // ---- players (HKA:702-725)
+    int pl[ENV_MAXA] = {0, 0, 0, 0};
+    int N = 0, nearbyAgents = -1;
+    {
+        int all[ENV_MAXA], nall = 0;
+        all[nall++] = ego;
+        for (int j = 0; j < P.n_team[ego]; j++) all[nall++] = P.team[ego][j];
+        for (int j = 0; j < P.n_other[ego]; j++) all[nall++] = P.other[ego][j];
+        if (A > 2) {
+            for (int q = 0; q < nall; q++) {
+                const KartS& o = kq[all[q]];
+                if (mag3(o.px - k.px, 0.0f, o.pz - k.pz) < 8) { nearbyAgents += 1; pl[N++] = all[q]; }
+            }
+        } else {
+            for (int q = 0; q < nall; q++) pl[N++] = all[q];
+        }
+        nearbyAgents = nearbyAgents > 1 ? nearbyAgents : 1;
+    }
+    const bool fixed = P.high_mode[ego] == HK_HIGH_FIXED;
+    const float dy = T.sec[0].marker_y - P.kart_y;                                    // Q13
+    if (N == 1) {
+        // single-player game: assemble into registers and run the whole Riccati recursion right here
+        GamePlayer loc;
+        HK_STAMP(tc3);
+        assemble_player<true>(P, T, env, ego, 0, N, nearbyAgents, pl, kq, fixed, dy, &loc, dbg_out);
+        HK_STAMP(tc4);
+        G->N = 1;
+        if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = 1;
+        lq1_solve(P, loc, const_cast<hk_agent_state*>(&agents[(size_t)env * A + ego]),
+                  (dbg_out && (P.debug & 1)) ? &dbg_out[(size_t)env * A + ego] : nullptr, status);
+        if (stamp) {
+            unsigned long long tc5 = clock64();
+            atomicAdd(&cyc[0], tc1 - tc0); atomicAdd(&cyc[1], tc2 - tc1); atomicAdd(&cyc[2], tc3 - tc2);
+            atomicAdd(&cyc[3], tc4 - tc3); atomicAdd(&cyc[4], tc5 - tc4); atomicAdd(&cyc[5], 1ull);
+        }
+        return;
+    }
+    for (int i = 0; i < N; i++) assemble_player<false>(P, T, env, ego, i, N, nearbyAgents, pl, kq, fixed, dy, &G->p[i], dbg_out);
+    G->N = N;
+    if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = N;
+    if (N >= 2) {                                                                     // bin multi-player games by N
+        const int pos = atomicAdd(&queue_cnt[N], 1);
+        queue[(size_t)(N - 2) * P.E * A + pos] = env * A + ego;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -628,7 +665,7 @@ __global__ __launch_bounds__(64) void lqn_kernel(EnvParams P, hk_agent_state* ag
         lq_solve_game<NP>(r, LG, qp, 3, u0, singular);                          // HKA:1201 horizon literal 3 (Q6)
         if (live && r == 0) {
             if (singular) atomicOr(status, 1);
-            decode_controls(P, &agents[game], u0[0], u0[1], (dbg_out && P.debug) ? &dbg_out[game] : nullptr);
+            decode_controls(P, &agents[game], u0[0], u0[1], (dbg_out && (P.debug & 1)) ? &dbg_out[game] : nullptr);
         }
     }
 }

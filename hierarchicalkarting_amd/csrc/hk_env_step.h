@@ -2,9 +2,9 @@
 //
 // Thread mapping: 4 consecutive lanes (a "quad") own one race instance, lane q = agent q; a 256-thread block holds
 // 64 envs.  Kart-to-kart data moves with quad-wide shuffles; per-env words (episode_steps, inactive set) are
-// recomputed identically by the 4 lanes and written by lane 0.  Wall queries walk the per-section candidate lists
-// (near_*: contacts) that hk_create builds; they are supersets of what can be reached, so results equal a brute
-// force scan over every wall (what the CPU oracle does).
+// recomputed identically by the 4 lanes and written by lane 0.  Wall queries read the uniform wall grid that
+// hk_create builds (per 2 m cell: every segment within 2.2 m), staged in LDS with the other track tables; the lists
+// are supersets of what can be reached, so results equal a brute force scan over every wall (what the CPU oracle does).
 #pragma once
 #include "hk_env_device.h"
 
@@ -15,7 +15,7 @@ __device__ __forceinline__ uint32_t quad_get(uint32_t v, int q) { return (uint32
 __device__ __forceinline__ int quad_get(int v, int q) { return __shfl(v, (threadIdx.x & ~3) | q, 64); }
 
 // REC.ResetGame :499-719 for one agent (Experiment / Race grid); see oracle reset_env for the line map
-__device__ inline void reset_agent(const EnvParams& P, int env, int i, int experiment_num, hk_agent_state* a)
+__device__ inline void reset_agent(const EnvParams& P, const TabView& T, int env, int i, int experiment_num, hk_agent_state* a)
 {
     const int expLane[4] = {2, 3, 2, 3};
     const int expSection[4] = {0, 0, 1, 1};
@@ -32,7 +32,7 @@ __device__ inline void reset_agent(const EnvParams& P, int env, int i, int exper
     a->init_checkpoint_index = sec;
     a->acc_ang_v = P.init_acc;
     a->lane = lane;
-    const SecDev& s = P.sec[sec % P.L];
+    const SecDev& s = T.sec[sec % P.L];
     float yaw = s.yaw_rad;
     float px = s.lane_x[lane - 1] + s.fx * 3.0f;
     float pz = s.lane_z[lane - 1] + s.fz * 3.0f;
@@ -47,7 +47,7 @@ __device__ inline void reset_agent(const EnvParams& P, int env, int i, int exper
     }
     a->px = px; a->pz = pz; a->yaw = yaw;
     a->final_steer = kart_steer(P, a->acc_ang_v);
-    if (P.high_mode[i] == HK_HIGH_FIXED) plan_fixed(P, i, a);
+    if (P.high_mode[i] == HK_HIGH_FIXED) plan_fixed(P, T, i, a);
     a->flags = HK_F_ACTIVE | HK_F_ENABLED;
 }
 
@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_st
     if (slot >= n || i >= P.A) return;
     const int env = env_ids ? env_ids[slot] : slot;
     const int ex = experiment_num >= 0 ? experiment_num : (P.env_id_base + env) % P.nperm;
-    reset_agent(P, env, i, ex, &agents[(size_t)env * P.A + i]);
+    const TabView T = tab_view(P, P.tab);
+    reset_agent(P, T, env, i, ex, &agents[(size_t)env * P.A + i]);
     if (i == 0) {
         hk_env_state* es = &envs[env];
         es->experiment_num = ex;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void env_begin_kernel(EnvParams P, hk_agent_st
             es.status = (es.status & ~2u) | (timeout ? 2u : 0u);
             es.experiment_num += 1;
         }
-        if (me) reset_agent(P, env, i, es.experiment_num, a);
+        if (me) { const TabView T = tab_view(P, P.tab); reset_agent(P, T, env, i, es.experiment_num, a); }
         es.episode_steps = 0;
         es.inactive_mask = 0;
         es.initial_started = 1;
@@ -213,8 +214,10 @@ __device__ inline int calculate_lane(const EnvParams& P, const SecDev& s, float 
 }
 
 __global__ __launch_bounds__(256) void env_move_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
-                                                       const float* act_steer, const int* act_branch)
+                                                       const float* act_steer, const int* act_branch, int use_lds)
 {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const TabView T = tab_stage(P, smem, use_lds != 0);
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int env = gid >> 2, i = gid & 3;
     const bool env_ok = env < P.E;
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void env_move_kernel(EnvParams P, hk_agent_sta
             if (br < 1) fl |= HK_F_BRAKE; else fl &= ~HK_F_BRAKE;
         }
         if (episode_steps % 100 == 0 && episode_steps < P.max_steps && episode_steps > 0 && !inactive_before)
-            if (P.high_mode[i] == HK_HIGH_FIXED) plan_fixed(P, i, a);
+            if (P.high_mode[i] == HK_HIGH_FIXED) plan_fixed(P, T, i, a);
         // ---- ArcadeKart.FixedUpdate
         bool accelerate = false, brake = false; float turnInput = 0.0f;
         if (fl & HK_F_ACTIVE) { accelerate = (fl & HK_F_ACCEL) != 0; brake = (fl & HK_F_BRAKE) != 0; turnInput = a->steering; }
@@ -351,15 +354,16 @@ __global__ __launch_bounds__(256) void env_move_kernel(EnvParams P, hk_agent_sta
     }
     // ---- kart-wall contacts: deepest penetration, two passes
     if (enabled && (fl & HK_F_CAN_MOVE)) {
-        const int sidx = a->section_index % P.L;
-        const int w0 = P.near_off[sidx], w1 = P.near_off[sidx + 1];
         for (int pass = 0; pass < 2; pass++) {
             float ax, az, bx, bz;
             kart_core(yaw, px, pz, ax, az, bx, bz);
+            // a contact needs a wall within CAP_R of the core, i.e. within 1.11 m of the kart origin: the cell's list
+            const int cell = grid_cell(P, px, pz);
+            const int w0 = T.grid_off[cell], w1 = T.grid_off[cell + 1];
             float bestpen = 0.0f, bnx = 0.0f, bnz = 0.0f;
             bool found = false;
             for (int q = w0; q < w1; q++) {
-                const hk_wall_seg ws = P.walls[P.near_idx[q]];
+                const hk_wall_seg ws = T.walls[T.grid_idx[q]];
                 float c1x, c1z, c2x, c2z;
                 float d2 = seg_seg_closest(ax, az, bx, bz, ws.x0, ws.z0, ws.x1, ws.z1, c1x, c1z, c2x, c2z);
                 if (d2 < CAP_R * CAP_R) {
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(256) void env_move_kernel(EnvParams P, hk_agent_sta
                         nx = -ez / el; nz = ex / el;
                         if ((px - ws.x0) * nx + (pz - ws.z0) * nz < 0.0f) { nx = -nx; nz = -nz; }
                     }
-                    // near_idx is ascending, so "first strictly deeper" == the oracle's lowest-index tie break
+                    // grid_idx is ascending per cell, so "first strictly deeper" == the oracle's lowest-index tie break
                     if (!found || pen > bestpen) { found = true; bestpen = pen; bnx = nx; bnz = nz; }
                 }
             }
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(256) void env_move_kernel(EnvParams P, hk_agent_sta
         kart_core(yaw, px, pz, ax, az, bx, bz);
         uint32_t lo = 0, hi = 0;
         for (int t = 0; t < P.L; t++) {
-            const SecDev& s = P.sec[t];
+            const SecDev& s = T.sec[t];
             float rax = ax - s.trig_x, raz = az - s.trig_z, rbx = bx - s.trig_x, rbz = bz - s.trig_z;
             float lax = rax * s.fz - raz * s.fx, laz = rax * s.fx + raz * s.fz;
             float lbx = rbx * s.fz - rbz * s.fx, lbz = rbx * s.fx + rbz * s.fz;
@@ -417,15 +421,15 @@ __global__ __launch_bounds__(256) void env_move_kernel(EnvParams P, hk_agent_sta
                 int lo_i = sec - H; if (lo_i < init) lo_i = init;
                 for (int ii = lo_i; ii < sec + H; ii++) {                  // KA.FindSectionIndex :348-364
                     int idx = ii < 0 ? ii + L : ii;
-                    if (idx % L == t) { index = idx; lane = calculate_lane(P, P.sec[idx % L], px, pz); break; }
+                    if (idx % L == t) { index = idx; lane = calculate_lane(P, T.sec[idx % L], px, pz); break; }
                 }
                 if (index != -1 && ((index > sec) || (index % L == 0 && sec % L == L - 1))) {
                     const int key = index % L;
                     const int pl = a->plan_lane[key];
                     if (pl != 0) {
                         float lmx, lmz;
-                        lane_marker(P, key, pl, lmx, lmz);
-                        float dist = mag3(px - lmx, P.kart_y - P.sec[key].marker_y, pz - lmz);
+                        lane_marker(T, key, pl, lmx, lmz);
+                        float dist = mag3(px - lmx, P.kart_y - T.sec[key].marker_y, pz - lmz);
                         a->avg_lane_diff = (f_max(dist - 1.3f, 0.0f) + a->avg_lane_diff * (index - init - 1)) / (index - init);
                         float velocity = mag3(vx, 0.0f, vz);
                         a->avg_vel_diff = ((velocity - a->plan_vel[key]) + a->avg_vel_diff * (index - init - 1)) / (index - init);
@@ -434,8 +438,8 @@ __global__ __launch_bounds__(256) void env_move_kernel(EnvParams P, hk_agent_sta
                     const int cur_lane = a->lane;
                     int dl = cur_lane - lane; if (dl < 0) dl = -dl;
                     int lc = a->lane_changes;
-                    if (lc + dl > P.max_lane_changes && is_straight(P, sec)) a->illegal_lane_changes += 1;
-                    if (is_straight(P, sec) != is_straight(P, index)) lc = 0;
+                    if (lc + dl > P.max_lane_changes && is_straight(P, T, sec)) a->illegal_lane_changes += 1;
+                    if (is_straight(P, T, sec) != is_straight(P, T, index)) lc = 0;
                     else if (cur_lane != lane) lc += dl;
                     a->lane_changes = lc;
                     a->section_index = index; a->lane = lane;

@@ -221,6 +221,8 @@ int hk_synchronize(hk_handle h);
 int hk_prof_enable(hk_handle h, int on);
 int hk_prof_reset(hk_handle h);
 int hk_prof_read(hk_handle h, double* solve_ms, int64_t* solve_launches, double* step_ms, int64_t* step_launches);
+/* diagnostic builds only (env HK_LQ_DEBUG bit 7): in-kernel cycle stamps of the assemble kernel, 16 counters */
+int hk_debug_cycles(hk_handle h, unsigned long long* out16);
 
 #ifdef __cplusplus
 }
