@@ -166,6 +166,9 @@ __global__ __launch_bounds__(256) void env_begin_kernel(EnvParams P, hk_agent_st
             const float jpx = quad_get(px, j), jpz = quad_get(pz, j), jyaw = quad_get(yaw, j);
             const uint32_t jfl = quad_get(fl, j);
             if (j >= P.A || j == i || !(jfl & HK_F_ENABLED)) continue;
+            // exact cull: a 0.9 m ray from 0.1 m ahead of this kart cannot reach a capsule whose origin is > 2.2 m away
+            // (0.1 + 0.9 + core half length 0.657 + slice radius 0.4425 = 2.10)
+            if ((jpx - px) * (jpx - px) + (jpz - pz) * (jpz - pz) > 2.2f * 2.2f) continue;
 #pragma unroll
             for (int q = 0; q < 3; q++) {
                 float t = ray_stadium(ox, oz, ddx[q], ddz[q], jpx, jpz, jyaw, P.ray_agent_r);
@@ -326,6 +329,8 @@ __global__ __launch_bounds__(256) void env_move_kernel(EnvParams P, hk_agent_sta
             const float jvx = quad_get(vx, j), jvz = quad_get(vz, j);
             const uint32_t jfl = quad_get(fl, j);
             if (j >= P.A || j == i || !enabled || !(jfl & HK_F_ENABLED)) continue;
+            // exact cull: two capsules (reach 0.657 + 0.45 from their origins) cannot touch when the origins are > 2.3 m apart
+            if ((jpx - px) * (jpx - px) + (jpz - pz) * (jpz - pz) > 2.3f * 2.3f) continue;
             float cx, cz, dx, dz, c1x, c1z, c2x, c2z;
             kart_core(jyaw, jpx, jpz, cx, cz, dx, dz);
             float d2 = seg_seg_closest(ax, az, bx, bz, cx, cz, dx, dz, c1x, c1z, c2x, c2z);
@@ -400,6 +405,8 @@ __global__ __launch_bounds__(256) void env_move_kernel(EnvParams P, hk_agent_sta
         uint32_t lo = 0, hi = 0;
         for (int t = 0; t < P.L; t++) {
             const SecDev& s = T.sec[t];
+            // exact cull: box half diagonal 5.03 + capsule reach 1.11 < 6.5
+            if ((px - s.trig_x) * (px - s.trig_x) + (pz - s.trig_z) * (pz - s.trig_z) > 6.5f * 6.5f) continue;
             float rax = ax - s.trig_x, raz = az - s.trig_z, rbx = bx - s.trig_x, rbz = bz - s.trig_z;
             float lax = rax * s.fz - raz * s.fx, laz = rax * s.fx + raz * s.fz;
             float lbx = rbx * s.fz - rbz * s.fx, lbz = rbx * s.fx + rbz * s.fz;
