@@ -258,16 +258,20 @@ __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const
         // ---------------- S6: per player Z_i, eta_i update (:113-119) ----------------
 #pragma unroll
         for (int i = 0; i < NP; i++) {
-            // W = Z_i F (row r)
-            for (int c = 0; c < n; c += 2) {
-                double s0 = 0.0, s1 = 0.0;
+            // W = Z_i F (row r): four independent fma chains per pass (columns c..c+3)
+            for (int c = 0; c < n; c += 4) {
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
                 for (int k = 0; k < n; k++) {
                     const double2 f = *reinterpret_cast<const double2*>(&L.F[k][c]);
+                    const double2 g = *reinterpret_cast<const double2*>(&L.F[k][c + 2]);
                     s0 = fma64(Z[i][k], f.x, s0);
                     s1 = fma64(Z[i][k], f.y, s1);
+                    s2 = fma64(Z[i][k], g.x, s2);
+                    s3 = fma64(Z[i][k], g.y, s3);
                 }
                 *reinterpret_cast<double2*>(&L.W[r][c]) = make_double2(s0, s1);
+                *reinterpret_cast<double2*>(&L.W[r][c + 2]) = make_double2(s2, s3);
             }
             // R_i P_i (column r): (RP)[a][r] = R[a][0] P[2i][r] + R[a][1] P[2i+1][r]
 #pragma unroll
@@ -279,14 +283,22 @@ __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const
             }
             __syncthreads();
             // Z_i <- (Q_i + P_i'(R_i P_i)) + F'(Z_i F)   (row r), written in place over W[r][*]
-            for (int c = 0; c < n; c++) {
-                double o = 0.0;
+            for (int c = 0; c < n; c += 2) {
+                double o0 = 0.0, o1 = 0.0;               // two independent chains (columns c, c+1)
 #pragma unroll
-                for (int k = 0; k < n; k++) o = fma64(Fcol[k], L.W[k][c], o);
-                double t2 = 0.0;
-                t2 = fma64(pc[2 * i + 0], L.RP[0][c], t2);
-                t2 = fma64(pc[2 * i + 1], L.RP[1][c], t2);
-                L.W[r][c] = (qp.Q(i, r, c) + t2) + o;
+                for (int k = 0; k < n; k++) {
+                    const double2 w = *reinterpret_cast<const double2*>(&L.W[k][c]);
+                    o0 = fma64(Fcol[k], w.x, o0);
+                    o1 = fma64(Fcol[k], w.y, o1);
+                }
+                double t20 = 0.0, t21 = 0.0;
+                t20 = fma64(pc[2 * i + 0], L.RP[0][c], t20);
+                t20 = fma64(pc[2 * i + 1], L.RP[1][c], t20);
+                t21 = fma64(pc[2 * i + 0], L.RP[0][c + 1], t21);
+                t21 = fma64(pc[2 * i + 1], L.RP[1][c + 1], t21);
+                const double z0 = (qp.Q(i, r, c) + t20) + o0;
+                const double z1 = (qp.Q(i, r, c + 1) + t21) + o1;
+                *reinterpret_cast<double2*>(&L.W[r][c]) = make_double2(z0, z1);
             }
             __syncthreads();
 #pragma unroll
