@@ -19,10 +19,10 @@ thread_local std::string g_last_error;
 // bracketed by an event pair taken from a pool; hk_prof_read synchronises once and folds the elapsed times.
 struct Prof {
     bool on = false;
-    std::vector<hipEvent_t> pool;                       // free events
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> solve, step;   // recorded, not yet folded
-    double solve_ms = 0, step_ms = 0;
-    int64_t solve_n = 0, step_n = 0;
+    std::vector<hipEvent_t> pool;                                         // free events
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> rec[HK_PROF_STAGES];   // recorded, not yet folded
+    double ms[HK_PROF_STAGES] = {0, 0, 0, 0, 0};
+    int64_t n[HK_PROF_STAGES] = {0, 0, 0, 0, 0};
     hipEvent_t get()
     {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
@@ -30,17 +30,30 @@ struct Prof {
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
         return e;
     }
+    // bracket helpers: begin() records the first event of a pair on `st`, end() the second
+    hipEvent_t begin(hipStream_t st)
+    {
+        if (!on) return nullptr;
+        hipEvent_t e = get();
+        if (e && hipEventRecord(e, st) != hipSuccess) { pool.push_back(e); return nullptr; }
+        return e;
+    }
+    void end(int stage, hipEvent_t e0, hipStream_t st)
+    {
+        if (!e0) return;
+        hipEvent_t e1 = get();
+        if (!e1 || hipEventRecord(e1, st) != hipSuccess) { pool.push_back(e0); if (e1) pool.push_back(e1); return; }
+        rec[stage].emplace_back(e0, e1);
+    }
     void fold()
     {
-        for (auto* v : {&solve, &step}) {
-            for (auto& pr : *v) {
-                float ms = 0;
-                if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
-                    if (v == &solve) { solve_ms += ms; solve_n++; } else { step_ms += ms; step_n++; }
-                }
+        for (int s = 0; s < HK_PROF_STAGES; s++) {
+            for (auto& pr : rec[s]) {
+                float t = 0;
+                if (hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) { ms[s] += t; n[s]++; }
                 pool.push_back(pr.first); pool.push_back(pr.second);
             }
-            v->clear();
+            rec[s].clear();
         }
     }
 };
@@ -163,9 +176,7 @@ int hk_lq_solve_batch_device(hk_handle h, int batch, int N, const double* dA, co
     if (batch == 0) return HK_OK;
     HK_HIP(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    hipEvent_t pe0 = nullptr, pe1 = nullptr;
-    if (h->prof.on) { pe0 = h->prof.get(); pe1 = h->prof.get(); }
-    if (pe0) HK_HIP(h, hipEventRecord(pe0, st));
+    hipEvent_t pe0 = h->prof.begin(st);
     switch (N) {
 #define HK_LQ_CASE(NP)                                                                                                   \
     case NP: {                                                                                                           \
@@ -177,10 +188,7 @@ int hk_lq_solve_batch_device(hk_handle h, int batch, int N, const double* dA, co
 #undef HK_LQ_CASE
     }
     HK_HIP(h, hipGetLastError());
-    if (pe0 && pe1) {
-        HK_HIP(h, hipEventRecord(pe1, st));
-        h->prof.solve.emplace_back(pe0, pe1);
-    }
+    h->prof.end(4, pe0, st);
     return HK_OK;
 }
 
@@ -259,19 +267,24 @@ int hk_step(hk_handle h, int n_ticks)
     HK_NEED_ENV(h);
     if (n_ticks < 0) return fail(h, HK_ERR_INVALID, "hk_step: n_ticks < 0");
     for (int t = 0; t < n_ticks; t++) {
-        // K_A (episode controller + sensing), then K_B (SolveLQR, the dominant kernel), then K_C (vehicle + engine)
+        // K_A (episode controller + sensing), K_B1 (game assembly + single-player solves), K_B2 (multi-player solves),
+        // K_C (vehicle model + engine restatement + triggers)
+        hipEvent_t e = h->prof.begin(h->stream);
         int rc = hk::env_launch_begin(h->dev, h->cfg, h->stream, h->err);
         if (rc) { g_last_error = h->err; return rc; }
-        hipEvent_t a0 = nullptr, a1 = nullptr, b0 = nullptr, b1 = nullptr;
-        if (h->prof.on) { a0 = h->prof.get(); a1 = h->prof.get(); b0 = h->prof.get(); b1 = h->prof.get(); }
-        if (a0) HK_HIP(h, hipEventRecord(a0, h->stream));
-        rc = hk::env_launch_solve(h->dev, h->cfg, h->stream, h->err);
+        h->prof.end(0, e, h->stream);
+        e = h->prof.begin(h->stream);
+        rc = hk::env_launch_assemble(h->dev, h->cfg, h->stream, h->err);
         if (rc) { g_last_error = h->err; return rc; }
-        if (a0 && a1) { HK_HIP(h, hipEventRecord(a1, h->stream)); h->prof.solve.emplace_back(a0, a1); }
-        if (b0) HK_HIP(h, hipEventRecord(b0, h->stream));
+        h->prof.end(1, e, h->stream);
+        e = h->prof.begin(h->stream);
+        rc = hk::env_launch_lqn(h->dev, h->cfg, h->stream, h->err);
+        if (rc) { g_last_error = h->err; return rc; }
+        h->prof.end(2, e, h->stream);
+        e = h->prof.begin(h->stream);
         rc = hk::env_launch_step(h->dev, h->cfg, h->stream, h->err);
         if (rc) { g_last_error = h->err; return rc; }
-        if (b0 && b1) { HK_HIP(h, hipEventRecord(b1, h->stream)); h->prof.step.emplace_back(b0, b1); }
+        h->prof.end(3, e, h->stream);
     }
     return HK_OK;
 }
@@ -381,21 +394,20 @@ int hk_prof_reset(hk_handle h)
     HK_HIP(h, hipSetDevice(h->device));
     HK_HIP(h, hipStreamSynchronize(h->stream));
     h->prof.fold();
-    h->prof.solve_ms = h->prof.step_ms = 0;
-    h->prof.solve_n = h->prof.step_n = 0;
+    for (int s = 0; s < HK_PROF_STAGES; s++) { h->prof.ms[s] = 0; h->prof.n[s] = 0; }
     return HK_OK;
 }
 
-int hk_prof_read(hk_handle h, double* solve_ms, int64_t* solve_launches, double* step_ms, int64_t* step_launches)
+int hk_prof_read(hk_handle h, double* ms, int64_t* launches)
 {
     if (!h) return HK_ERR_INVALID;
     HK_HIP(h, hipSetDevice(h->device));
     HK_HIP(h, hipStreamSynchronize(h->stream));
     h->prof.fold();
-    if (solve_ms) *solve_ms = h->prof.solve_ms;
-    if (solve_launches) *solve_launches = h->prof.solve_n;
-    if (step_ms) *step_ms = h->prof.step_ms;
-    if (step_launches) *step_launches = h->prof.step_n;
+    for (int s = 0; s < HK_PROF_STAGES; s++) {
+        if (ms) ms[s] = h->prof.ms[s];
+        if (launches) launches[s] = h->prof.n[s];
+    }
     return HK_OK;
 }
 

@@ -297,15 +297,20 @@ inline int env_launch_begin(EnvDevice& d, const hk_config& cfg, hipStream_t stre
     return launch_check(err, "env_begin_kernel");
 }
 
-// K_B: SolveLQR for every ego = game assembly (K_B1), then the Riccati solves binned by player count (K_B2)
-inline int env_launch_solve(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+// K_B1: SolveLQR game assembly for every ego (single-player games are solved on the spot)
+inline int env_launch_assemble(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
 {
-    const int ngames = cfg.num_envs * cfg.num_agents;
     const int threads = cfg.num_envs * 4;
     hipLaunchKernelGGL(env_assemble_kernel, dim3((threads + 255) / 256), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs, d.games,
                        d.queue_cnt, d.queue, d.lq_debug, d.status, d.cyc, d.tab_lds ? 1 : 0);
-    int rc = launch_check(err, "env_assemble_kernel");
-    if (rc) return rc;
+    return launch_check(err, "env_assemble_kernel");
+}
+
+// K_B2: the Riccati solves of the multi-player games, binned by player count
+inline int env_launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
+    const int ngames = cfg.num_envs * cfg.num_agents;
+    int rc = HK_OK;
     if (cfg.num_agents >= 2) {
         const int blocks = std::min((ngames + 3) / 4, 8192);
         hipLaunchKernelGGL(lqn_kernel<2>, dim3(blocks), dim3(64), 0, stream, d.P, d.agents, d.games, d.queue_cnt, d.queue, d.lq_debug, d.status);

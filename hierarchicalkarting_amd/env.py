@@ -103,10 +103,11 @@ class RacingEnv:
         self._ck(self.L.hk_prof_reset(self.h))
 
     def prof_read(self):
-        sm, st = C.c_double(), C.c_double()
-        sn, tn = C.c_int64(), C.c_int64()
-        self._ck(self.L.hk_prof_read(self.h, C.byref(sm), C.byref(sn), C.byref(st), C.byref(tn)))
-        return dict(solve_ms=sm.value, solve_launches=sn.value, step_ms=st.value, step_launches=tn.value)
+        """-> {stage name: (total ms, launches)} since the last prof_reset (HIP events on the handle's stream)"""
+        ms = (C.c_double * _lib.HK_PROF_STAGES)()
+        n = (C.c_int64 * _lib.HK_PROF_STAGES)()
+        self._ck(self.L.hk_prof_read(self.h, ms, n))
+        return {name: (ms[i], n[i]) for i, name in enumerate(_lib.PROF_STAGE_NAMES)}
 
     def device_results_ptr(self):
         return self.L.hk_device_results_ptr(self.h)

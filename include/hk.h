@@ -216,11 +216,14 @@ void* hk_device_agents_ptr(hk_handle h);   /* hk_agent_state[E][A] on device */
 void* hk_stream(hk_handle h);              /* hipStream_t the handle launches on */
 int hk_synchronize(hk_handle h);
 
-/* timing taps for bench.py's roofline object: HIP-event time (ms) and launch count of the dominant kernel since the
- * last call to hk_prof_reset; events are recorded on the handle's own stream */
+/* timing taps for bench.py's roofline object: accumulated HIP-event time (ms) and launch count per kernel stage since
+ * the last hk_prof_reset.  Stages: [0] env_begin_kernel, [1] env_assemble_kernel, [2] the three lqn_kernel launches of a
+ * tick (one bracket), [3] env_move_kernel, [4] lq_batch_kernel.  Event pairs are recorded on the handle's own stream
+ * around every launch (no host sync per launch) and folded when read. */
+#define HK_PROF_STAGES 5
 int hk_prof_enable(hk_handle h, int on);
 int hk_prof_reset(hk_handle h);
-int hk_prof_read(hk_handle h, double* solve_ms, int64_t* solve_launches, double* step_ms, int64_t* step_launches);
+int hk_prof_read(hk_handle h, double* ms /*[HK_PROF_STAGES]*/, int64_t* launches /*[HK_PROF_STAGES]*/);
 /* diagnostic builds only (env HK_LQ_DEBUG bit 7): in-kernel cycle stamps of the assemble kernel, 16 counters */
 int hk_debug_cycles(hk_handle h, unsigned long long* out16);
 
