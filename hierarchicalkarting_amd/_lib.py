@@ -67,6 +67,8 @@ class AgentState(C.Structure):
         ("forward_collisions", C.c_int32), ("last_collision_time", C.c_int32), ("time_steps", C.c_int32),
         ("init_checkpoint_index", C.c_int32),
         ("flags", C.c_uint32), ("trig_lo", C.c_uint32), ("trig_hi", C.c_uint32), ("final_steer", C.c_float),
+        ("tele_completed_laps", C.c_int32), ("tele_lap_end_step", C.c_int32), ("tele_last_lap", C.c_float),
+        ("tele_best_lap", C.c_float), ("tele_total_time", C.c_float),
         ("plan_lane", C.c_uint8 * HK_MAX_SECTIONS), ("plan_vel", C.c_float * HK_MAX_SECTIONS),
     ]
 
@@ -79,7 +81,9 @@ class EnvState(C.Structure):
 class EpisodeResult(C.Structure):
     _fields_ = [("time_steps", C.c_int32), ("section_index", C.c_int32), ("illegal_lane_changes", C.c_int32),
                 ("forward_collisions", C.c_int32), ("avg_lane_diff", C.c_float), ("avg_vel_diff", C.c_float),
-                ("reward", C.c_float), ("episode", C.c_int32)]
+                ("reward", C.c_float), ("episode", C.c_int32), ("last_lap", C.c_float), ("best_lap", C.c_float),
+                ("total_time", C.c_float), ("laps_completed", C.c_int32), ("lap_end_step", C.c_int32), ("speed", C.c_float),
+                ("active", C.c_int32), ("reserved", C.c_int32)]
 
 
 class LqDebug(C.Structure):

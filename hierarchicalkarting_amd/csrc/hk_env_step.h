@@ -23,9 +23,14 @@ __device__ inline void reset_agent(const EnvParams& P, const TabView& T, int env
     const int* ord = P.perms + (size_t)pi * P.A;
     int j = 0;
     for (int q = 0; q < P.A; q++) if (ord[q] == i) j = q;
-    // zero the whole record (plans, counters, trigger overlap set)
+    // zero the whole record (plans, counters, trigger overlap set) except the TelemetryViewer arrays, which the
+    // reference never resets with the game (the viewer notices the lower lap count itself)
+    const int t_laps = a->tele_completed_laps, t_step = a->tele_lap_end_step;
+    const float t_last = a->tele_last_lap, t_best = a->tele_best_lap, t_total = a->tele_total_time;
     uint32_t* w = reinterpret_cast<uint32_t*>(a);
     for (int k = 0; k < (int)(sizeof(hk_agent_state) / 4); k++) w[k] = 0u;
+    a->tele_completed_laps = t_laps; a->tele_lap_end_step = t_step;
+    a->tele_last_lap = t_last; a->tele_best_lap = t_best; a->tele_total_time = t_total;
     const int sec = expSection[j & 3];
     const int lane = expLane[j & 3];
     a->section_index = sec;
@@ -61,6 +66,11 @@ __device__ inline void snapshot_result(const hk_agent_state* a, hk_episode_resul
     r->avg_vel_diff = a->avg_vel_diff;
     r->reward = a->cum_reward;
     r->episode = episode;
+    r->last_lap = a->tele_last_lap; r->best_lap = a->tele_best_lap; r->total_time = a->tele_total_time;
+    r->laps_completed = a->tele_completed_laps; r->lap_end_step = a->tele_lap_end_step;
+    r->speed = mag3(a->vx, 0.0f, a->vz);
+    r->active = (a->flags & HK_F_ACTIVE) ? 1 : 0;
+    r->reserved = 0;
 }
 
 // explicit hk_reset
@@ -467,7 +477,24 @@ __global__ __launch_bounds__(256) void env_move_kernel(EnvParams P, hk_agent_sta
             }
         }
     }
-    if (live) a->flags = fl;
+    if (live) {
+        a->flags = fl;
+        // TelemetryViewer.Update :49-88 (once per tick)
+        const int currentLap = a->section_index / P.L;
+        const int done = a->tele_completed_laps;
+        if (currentLap > done) {
+            a->tele_completed_laps = currentLap;
+            const float last = P.dt * (episode_steps - a->tele_lap_end_step);
+            a->tele_last_lap = last;
+            const float best = a->tele_best_lap;
+            if (best < 10 || last < best) a->tele_best_lap = last;
+            a->tele_lap_end_step = episode_steps;
+        } else if (currentLap < done) {
+            a->tele_completed_laps = currentLap;
+            a->tele_last_lap = 0.0f; a->tele_best_lap = 0.0f; a->tele_lap_end_step = 0;
+        }
+        if (fl & HK_F_ACTIVE) a->tele_total_time = episode_steps * P.dt;
+    }
     // per-env words: OR over the quad
     uint32_t ni = newly_inactive, bd = bad ? 1u : 0u;
     ni |= (uint32_t)__shfl_xor((int)ni, 1, 64); ni |= (uint32_t)__shfl_xor((int)ni, 2, 64);

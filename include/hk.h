@@ -134,6 +134,12 @@ typedef struct hk_agent_state {
     uint32_t flags;               /* HK_F_* */
     uint32_t trig_lo, trig_hi;    /* which Trigger boxes the kart overlapped after the last tick (OnTriggerEnter edge) */
     float final_steer;            /* ArcadeKart.m_FinalStats.Steer as of the last UpdateStats (AK:300) */
+    /* TelemetryViewer per-agent arrays (TelemetryViewer.cs:12-16), advanced once per tick after the engine step */
+    int32_t tele_completed_laps;  /* lastCompletedLaps */
+    int32_t tele_lap_end_step;    /* lastEpisodeSteps */
+    float tele_last_lap;          /* lastLapTimes (s) */
+    float tele_best_lap;          /* bestLapTimes (s) */
+    float tele_total_time;        /* lastOverallTimes (s) */
     uint8_t plan_lane[HK_MAX_SECTIONS]; /* m_UpcomingLanes keyed by section % L (KA:117); 0 = no entry */
     float plan_vel[HK_MAX_SECTIONS];    /* m_UpcomingVelocities (KA:118) */
 } hk_agent_state;
@@ -156,8 +162,14 @@ typedef struct hk_episode_result {
     int32_t forward_collisions;
     float avg_lane_diff;
     float avg_vel_diff;
-    float reward;
+    float reward;                  /* Agent.GetCumulativeReward() at the end of the episode */
     int32_t episode;               /* index of the episode these numbers belong to (-1: none finished yet) */
+    float last_lap, best_lap, total_time;   /* TelemetryViewer.cs:58-79 (seconds) */
+    int32_t laps_completed;        /* lastCompletedLaps */
+    int32_t lap_end_step;          /* lastEpisodeSteps (enters the reference's winner rule, TelemetryViewer.cs:80) */
+    float speed;                   /* Rigidbody.velocity.magnitude when the block was written */
+    int32_t active;                /* is_active when the block was written */
+    int32_t reserved;
 } hk_episode_result;
 
 /* debug tap: the LQ game one ego assembled on its last solve tick (HKA:699-1201), ego-local player order */

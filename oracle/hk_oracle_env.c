@@ -294,7 +294,12 @@ static void reset_env(hko_env* e, int env)
     for (int j = 0; j < e->A; j++) {
         int i = ord[j];
         hk_agent_state* a = &ags[i];
+        const int t_laps = a->tele_completed_laps, t_step = a->tele_lap_end_step;
+        const float t_last = a->tele_last_lap, t_best = a->tele_best_lap, t_total = a->tele_total_time;
         memset(a, 0, sizeof(*a));
+        /* the TelemetryViewer is not reset with the game: its arrays survive (it notices the lower lap count itself) */
+        a->tele_completed_laps = t_laps; a->tele_lap_end_step = t_step;
+        a->tele_last_lap = t_last; a->tele_best_lap = t_best; a->tele_total_time = t_total;
         a->section_index = expSectionChoices[j & 3];         /* :583 / :634 */
         a->init_checkpoint_index = a->section_index;         /* :586 */
         a->acc_ang_v = e->init_acc_ang_v;                    /* :588 */
@@ -336,6 +341,11 @@ static void snapshot_results(hko_env* e, int env)
         r->avg_vel_diff = a->avg_vel_diff;
         r->reward = a->cum_reward;
         r->episode = es->episodes_done;
+        r->last_lap = a->tele_last_lap; r->best_lap = a->tele_best_lap; r->total_time = a->tele_total_time;
+        r->laps_completed = a->tele_completed_laps; r->lap_end_step = a->tele_lap_end_step;
+        r->speed = mag3(a->vx, 0.0f, a->vz);
+        r->active = (a->flags & HK_F_ACTIVE) ? 1 : 0;
+        r->reserved = 0;
     }
 }
 
@@ -768,6 +778,8 @@ static int overlaps_trigger(const hko_env* e, const hk_agent_state* a, int t)
     return zlo <= TRIG_HZ && zhi >= -TRIG_HZ && xlo <= TRIG_HX && xhi >= -TRIG_HX;
 }
 
+static void telemetry_update(const hko_env* e, const hk_env_state* es, hk_agent_state* a);
+
 /* ------------------------------------------------------------------ one tick of one env */
 static void finish_episode(hko_env* e, int env, int timeout)
 {
@@ -974,6 +986,25 @@ static void step_env(hko_env* e, int env)
             if (ent) on_trigger_enter(e, env, i, t);
         }
     }
+    /* TelemetryViewer.Update (once per tick here; the reference runs it once per rendered frame) */
+    for (int i = 0; i < A; i++) telemetry_update(e, es, &ags[i]);
+}
+
+/* TelemetryViewer.Update :49-88 for one agent (the viewer keeps its arrays across episodes; a lower lap count = reset) */
+static void telemetry_update(const hko_env* e, const hk_env_state* es, hk_agent_state* a)
+{
+    const float dt = e->cfg.dt;
+    int currentLap = a->section_index / e->L;                                           /* :58 */
+    if (currentLap > a->tele_completed_laps) {                                          /* :59-68 */
+        a->tele_completed_laps = currentLap;
+        a->tele_last_lap = dt * (es->episode_steps - a->tele_lap_end_step);
+        if (a->tele_best_lap < 10 || a->tele_last_lap < a->tele_best_lap) a->tele_best_lap = a->tele_last_lap;
+        a->tele_lap_end_step = es->episode_steps;
+    } else if (currentLap < a->tele_completed_laps) {                                   /* :69-75 */
+        a->tele_completed_laps = currentLap;
+        a->tele_last_lap = 0.0f; a->tele_best_lap = 0.0f; a->tele_lap_end_step = 0;
+    }
+    if (a->flags & HK_F_ACTIVE) a->tele_total_time = es->episode_steps * dt;            /* :76-79 */
 }
 
 /* ------------------------------------------------------------------ API */
