@@ -27,8 +27,7 @@ __device__ inline void reset_agent(const EnvParams& P, const TabView& T, int env
     // reference never resets with the game (the viewer notices the lower lap count itself)
     const int t_laps = a->tele_completed_laps, t_step = a->tele_lap_end_step;
     const float t_last = a->tele_last_lap, t_best = a->tele_best_lap, t_total = a->tele_total_time;
-    uint32_t* w = reinterpret_cast<uint32_t*>(a);
-    for (int k = 0; k < (int)(sizeof(hk_agent_state) / 4); k++) w[k] = 0u;
+    __builtin_memset(a, 0, sizeof(hk_agent_state));     // (not a uint32_t* loop: that would violate type-based aliasing)
     a->tele_completed_laps = t_laps; a->tele_lap_end_step = t_step;
     a->tele_last_lap = t_last; a->tele_best_lap = t_best; a->tele_total_time = t_total;
     const int sec = expSection[j & 3];
