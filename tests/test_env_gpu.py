@@ -124,3 +124,11 @@ def test_invalid_configs_are_refused():
     with pytest.raises(_lib.HkError) as e:
         hk.RacingEnv(hk.make_config(2, 4, wiring=([0, 0, 1, 1], [[1], [0], [3], []], [[2, 3], [2, 3], [0, 1], [0, 1]])))
     assert e.value.code == _lib.HK_ERR_INVALID
+
+
+def test_complex_track_four_agents():
+    """the 41-section Complex track (straights, large / medium / small curves, S-curves), 3 laps,
+    MaxLaneChanges 4; 842 wall segments through the LDS-staged wall grid vs the oracle's brute force."""
+    g, o = _run(4, 24, 1200, 150, track="complex", jitter_seed=0x5EED0000)
+    assert np.array_equal(g.observations(), o.observations())
+    _run(2, 8, 600, 1, track="complex", jitter_seed=11)

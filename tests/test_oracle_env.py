@@ -111,6 +111,22 @@ def test_race_finishes_inside_the_reference_band(A, ex):
     assert (st["vx"] == 0).all() and (st["vz"] == 0).all()
 
 
+def test_complex_track_race_band():
+    """Complex 1v1 Fixed-LQR, 3 laps: reference mean total 101.9 s (5095 ticks), median best lap 32.84 s"""
+    b = make_config(1, 2, track="complex", auto_reset=0)
+    o = O.OracleEnv(b)
+    o.reset(experiment_num=0)
+    for _ in range(62):
+        o.step(100)
+        if o.env_state()["inactive_mask"][0] == 3:
+            break
+    o.step(1)
+    res = o.episode_results()[0]
+    assert (res["section_index"] == 3 * 41 + 1).all()
+    assert (res["time_steps"] > 4700).all() and (res["time_steps"] < 5600).all(), res["time_steps"]
+    assert (res["best_lap"] > 30.0).all() and (res["best_lap"] < 36.0).all(), res["best_lap"]
+
+
 def test_deterministic_and_snapshot_restore():
     b = make_config(3, 4, jitter_seed=0x5EED0000)
     o1, o2 = O.OracleEnv(b), O.OracleEnv(b)

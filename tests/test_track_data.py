@@ -30,6 +30,23 @@ def test_walls():
     w = b.walls
     assert abs(abs(w[0].x0 - 15.88) - 4.6) < 1e-3
     # curve wall radius about the nominal turn centre bulges 15.40 -> 15.91 (Bezier sweep, not an arc)
-    curve = [x for x in tr["walls"] if len(x["points"]) == 33][0]
-    r = [math.hypot(p[0] - (15.88 - 20.0), p[1] - 37.0) for p in curve["points"]]
-    assert abs(min(r) - 15.40) < 0.02 and abs(max(r) - 15.91) < 0.02
+    curves = [x for x in tr["walls"] if len(x["points"]) == 33][:2]          # the two faces of the first curve piece
+    rr = sorted((min(r), max(r)) for r in ([math.hypot(p[0] - (15.88 - 20.0), p[1] - 37.0) for p in c["points"]] for c in curves))
+    assert abs(rr[0][0] - 15.40) < 0.02 and abs(rr[0][1] - 15.91) < 0.02
+    assert abs(rr[1][0] - 24.60) < 0.02 and abs(rr[1][1] - 25.51) < 0.02
+
+
+def test_complex_table():
+    tr = load_track("complex")
+    s = tr["sections"]
+    assert len(s) == 41 and tr["rules"]["laps"] == 3 and tr["rules"]["MaxLaneChanges"] == 4
+    kinds = [x["piece"].replace("ModularTrack", "") for x in s]
+    # SURVEY App. A piece sequence: S,S,S,S,CLR x2,CLR x2,CMR x2,S,CSL,S,SCL x2,SCL x2,CSR,S,CML x2,CML x2,CLR x2,S,CLR x2,SCL x2,CSR,S x5,SCR x2,S,S,S
+    want = (["Straight"] * 4 + ["CurveLargeRight"] * 4 + ["CurveMediumRight"] * 2 + ["Straight", "CurveSmallLeft", "Straight"] +
+            ["SCurveLeft"] * 4 + ["CurveSmallRight", "Straight"] + ["CurveMediumLeft"] * 4 + ["CurveLargeRight"] * 2 + ["Straight"] +
+            ["CurveLargeRight"] * 2 + ["SCurveLeft"] * 2 + ["CurveSmallRight"] + ["Straight"] * 5 + ["SCurveRight"] * 2 + ["Straight"] * 3)
+    assert kinds == want
+    assert len(tr["walls"]) == 2 * len({x["piece_instance"] for x in s})       # two road-side faces per piece
+    for x in s:
+        d = [math.hypot(x["Lane%d" % (l + 1)]["x"] - x["waypoint"]["x"], x["Lane%d" % (l + 1)]["z"] - x["waypoint"]["z"]) for l in range(4)]
+        assert np.allclose(d, [3.5, 1.25, 1.25, 3.5], atol=1e-3)

@@ -215,21 +215,49 @@ def chain_len(ch):
     return sum(math.dist(ch[i], ch[i+1]) for i in range(len(ch)-1))
 
 
-def road_side_walls(chains, inside_radius, width, left_turn):
-    """pick the two road-facing wall polylines of a piece (piece-local)."""
-    long = [c for c in chains if chain_len(c) > 2.0]
-    if inside_radius == 0:
-        off = lambda p: p[0]                       # signed lateral offset from the centre line x = 0
-    else:
-        rc = inside_radius + width/2.0
-        cx = -rc if left_turn else rc
-        off = lambda p: (math.hypot(p[0]-cx, p[1]) - rc)
-    best = {}
-    for c in long:
-        o = np.mean([off(p) for p in c]); side = 1 if o > 0 else -1
-        if side not in best or abs(o) < abs(best[side][0]):
-            best[side] = (o, c)
-    return [best[s][1] for s in sorted(best)]
+def _poly_dist(p, poly):
+    best = 1e30
+    for i in range(len(poly) - 1):
+        ax, az = poly[i]; bx, bz = poly[i + 1]
+        dx, dz = bx - ax, bz - az
+        l2 = dx * dx + dz * dz
+        t = 0.0 if l2 == 0 else max(0.0, min(1.0, ((p[0] - ax) * dx + (p[1] - az) * dz) / l2))
+        best = min(best, math.hypot(ax + t * dx - p[0], az + t * dz - p[1]))
+    return best
+
+
+def _mean_dist(a, b):
+    return sum(_poly_dist(p, b) for p in a) / len(a)
+
+
+def road_side_walls(chains, inside_radius=None, width=None, left_turn=None):
+    """pick the two road-facing wall polylines of a piece (piece-local), for ANY piece shape.  A wall outline at the slice
+    height is a loop: two long faces 0.4 m apart plus two 0.4 m end caps.  Pair the long faces that belong to one wall
+    (mean distance < 0.6 m); of each pair, the road-side face is the one nearer to the other wall."""
+    long = [c for c in chains if chain_len(c) > 1.0]
+    pairs, used = [], set()
+    for i, a in enumerate(long):
+        if i in used:
+            continue
+        best, bj = 1e30, -1
+        for j, b in enumerate(long):
+            if j == i or j in used:
+                continue
+            d = max(_mean_dist(a, b), _mean_dist(b, a))
+            if d < best:
+                best, bj = d, j
+        if bj >= 0 and best < 0.6:
+            pairs.append((i, bj)); used.add(i); used.add(bj)
+    if len(pairs) != 2 or len(used) != len(long):
+        raise RuntimeError("unexpected wall outline structure: %d long faces, %d pairs" % (len(long), len(pairs)))
+    out = []
+    for k, (i, j) in enumerate(pairs):
+        oi, oj = pairs[1 - k]
+        other = long[oi] + long[oj]
+        di = sum(_poly_dist(p, long[oi]) + _poly_dist(p, long[oj]) for p in long[i]) / len(long[i])
+        dj = sum(_poly_dist(p, long[oi]) + _poly_dist(p, long[oj]) for p in long[j]) / len(long[j])
+        out.append(long[i] if di < dj else long[j])
+    return out
 
 
 def main():
