@@ -10,8 +10,8 @@ HK_MAX_AGENTS = 8
 HK_MAX_SECTIONS = 64
 HK_NUM_SENSORS = 9
 HK_ABI_VERSION = 1
-HK_PROF_STAGES = 5
-PROF_STAGE_NAMES = ("env_begin_kernel", "env_assemble_kernel", "lqn_kernel<2,3,4>", "env_move_kernel", "lq_batch_kernel")
+HK_PROF_STAGES = 3
+PROF_STAGE_NAMES = ("env_run_kernel", "lqn_kernel<2,3,4>", "lq_batch_kernel")
 
 HK_OK, HK_ERR_INVALID, HK_ERR_NO_DEVICE, HK_ERR_HIP, HK_ERR_UNSUPPORTED, HK_ERR_SINGULAR = 0, -1, -2, -3, -4, -5
 HK_LOW_RL, HK_LOW_MPC, HK_LOW_LQR = 0, 1, 2
@@ -121,7 +121,6 @@ SYMBOLS = {
     "hk_prof_enable": (C.c_int, [_H, C.c_int]),
     "hk_prof_reset": (C.c_int, [_H]),
     "hk_prof_read": (C.c_int, [_H, _dp, C.POINTER(C.c_int64)]),
-    "hk_debug_cycles": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

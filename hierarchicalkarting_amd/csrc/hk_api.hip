@@ -21,8 +21,8 @@ struct Prof {
     bool on = false;
     std::vector<hipEvent_t> pool;                                         // free events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> rec[HK_PROF_STAGES];   // recorded, not yet folded
-    double ms[HK_PROF_STAGES] = {0, 0, 0, 0, 0};
-    int64_t n[HK_PROF_STAGES] = {0, 0, 0, 0, 0};
+    double ms[HK_PROF_STAGES] = {0, 0, 0};
+    int64_t n[HK_PROF_STAGES] = {0, 0, 0};
     hipEvent_t get()
     {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
@@ -188,7 +188,7 @@ int hk_lq_solve_batch_device(hk_handle h, int batch, int N, const double* dA, co
 #undef HK_LQ_CASE
     }
     HK_HIP(h, hipGetLastError());
-    h->prof.end(4, pe0, st);
+    h->prof.end(2, pe0, st);
     return HK_OK;
 }
 
@@ -266,25 +266,20 @@ int hk_step(hk_handle h, int n_ticks)
 {
     HK_NEED_ENV(h);
     if (n_ticks < 0) return fail(h, HK_ERR_INVALID, "hk_step: n_ticks < 0");
-    for (int t = 0; t < n_ticks; t++) {
-        // K_A (episode controller + sensing), K_B1 (game assembly + single-player solves), K_B2 (multi-player solves),
-        // K_C (vehicle model + engine restatement + triggers)
+    if (n_ticks == 0) return HK_OK;
+    int rc = hk::env_launch_arm(h->dev, h->cfg, n_ticks, h->stream, h->err);
+    if (rc) { g_last_error = h->err; return rc; }
+    const int rounds = hk::env_rounds_for(h->cfg, n_ticks);
+    for (int r = 0; r < rounds; r++) {
+        // the fused tick kernel (up to RUN_CAP ticks per env), then the queued multi-player solves
         hipEvent_t e = h->prof.begin(h->stream);
-        int rc = hk::env_launch_begin(h->dev, h->cfg, h->stream, h->err);
+        rc = hk::env_launch_run(h->dev, h->cfg, h->stream, h->err);
         if (rc) { g_last_error = h->err; return rc; }
         h->prof.end(0, e, h->stream);
         e = h->prof.begin(h->stream);
-        rc = hk::env_launch_assemble(h->dev, h->cfg, h->stream, h->err);
-        if (rc) { g_last_error = h->err; return rc; }
-        h->prof.end(1, e, h->stream);
-        e = h->prof.begin(h->stream);
         rc = hk::env_launch_lqn(h->dev, h->cfg, h->stream, h->err);
         if (rc) { g_last_error = h->err; return rc; }
-        h->prof.end(2, e, h->stream);
-        e = h->prof.begin(h->stream);
-        rc = hk::env_launch_step(h->dev, h->cfg, h->stream, h->err);
-        if (rc) { g_last_error = h->err; return rc; }
-        h->prof.end(3, e, h->stream);
+        h->prof.end(1, e, h->stream);
     }
     return HK_OK;
 }
@@ -364,15 +359,6 @@ int hk_get_lq_debug(hk_handle h, int env, int ego, hk_lq_debug* out)
     if (!h->dev.lq_debug) return fail(h, HK_ERR_INVALID, "hk_get_lq_debug: debug taps are off");
     HK_HIP(h, hipMemcpyAsync(out, h->dev.lq_debug + ((size_t)env * h->cfg.num_agents + ego), sizeof(hk_lq_debug),
                              hipMemcpyDeviceToHost, h->stream));
-    HK_HIP(h, hipStreamSynchronize(h->stream));
-    return HK_OK;
-}
-
-// diagnostic: in-kernel cycle stamps accumulated by the assemble kernel when HK_LQ_DEBUG has bit 7 set
-int hk_debug_cycles(hk_handle h, unsigned long long* out16)
-{
-    HK_NEED_ENV(h);
-    HK_HIP(h, hipMemcpyAsync(out16, h->dev.cyc, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HK_HIP(h, hipStreamSynchronize(h->stream));
     return HK_OK;
 }

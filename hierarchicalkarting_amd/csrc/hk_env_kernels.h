@@ -11,6 +11,7 @@
 #include "hk_env_device.h"
 #include "hk_env_step.h"
 #include "hk_env_solve.h"
+#include "hk_env_run.h"
 #include "hk_env_observe.h"
 
 namespace hk {
@@ -25,9 +26,9 @@ struct EnvDevice {
     int32_t* act_branch = nullptr;
     int* status = nullptr;
     GameDesc* games = nullptr;     // [E][A] compact LQ games written by K_B1
-    int* queue_cnt = nullptr;      // [8] number of multi-player games per player count (this tick)
-    int* queue = nullptr;          // [3][E*A] game ids with N = 2, 3, 4
-    unsigned long long* cyc = nullptr;   // [16] in-kernel cycle stamps (diagnostic builds: HK_LQ_DEBUG & 128)
+    int* queue_cnt = nullptr;      // [2 sets][8] number of queued multi-player games per player count
+    int* queue = nullptr;          // [2 sets][3][E*A] game ids with N = 2, 3, 4
+    int round = 0;                 // launches so far: round & 1 selects the queue set (double buffered over rounds)
     int* env_ids = nullptr;
     int env_ids_cap = 0;
     // tables
@@ -73,7 +74,7 @@ int upload(T** dst, const std::vector<T>& v, std::string& err)
 
 inline void env_destroy(EnvDevice& d)
 {
-    void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.status, d.games, d.queue_cnt, d.queue, d.cyc, d.env_ids, d.tab, d.perms};
+    void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.status, d.games, d.queue_cnt, d.queue, d.env_ids, d.tab, d.perms};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = EnvDevice{};
 }
@@ -232,9 +233,8 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     HK_ALLOC(d.act_branch, na * sizeof(int32_t));
     HK_ALLOC(d.status, 4 * sizeof(int));
     HK_ALLOC(d.games, na * sizeof(GameDesc));
-    HK_ALLOC(d.queue_cnt, 8 * sizeof(int));
-    HK_ALLOC(d.queue, 3 * na * sizeof(int));
-    HK_ALLOC(d.cyc, 16 * sizeof(unsigned long long));
+    HK_ALLOC(d.queue_cnt, 2 * 8 * sizeof(int));
+    HK_ALLOC(d.queue, 2 * 3 * na * sizeof(int));
 #undef HK_ALLOC
     // REC.Start :148-168: every agent starts inactive; results carry episode = -1; RL branch defaults to "coast"
     {
@@ -289,50 +289,52 @@ inline int env_reset(EnvDevice& d, const hk_config& cfg, const int32_t* env_ids,
     return HK_OK;
 }
 
-// K_A: REC.FixedUpdate + KA.FixedUpdate
-inline int env_launch_begin(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+// arm hk_step(n): every env gets n ticks to run
+inline int env_launch_arm(EnvDevice& d, const hk_config& cfg, int n_ticks, hipStream_t stream, std::string& err)
 {
-    const int threads = cfg.num_envs * 4;
-    hipLaunchKernelGGL(env_begin_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.envs, d.results, d.queue_cnt);
-    return launch_check(err, "env_begin_kernel");
+    hipLaunchKernelGGL(env_arm_kernel, dim3((cfg.num_envs + 255) / 256), dim3(256), 0, stream, d.envs, cfg.num_envs, n_ticks);
+    return launch_check(err, "env_arm_kernel");
 }
 
-// K_B1: SolveLQR game assembly for every ego (single-player games are solved on the spot)
-inline int env_launch_assemble(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+// number of {run, lqn} rounds that always suffice for n ticks (see hk_env_run.h)
+inline int env_rounds_for(const hk_config& cfg, int n_ticks)
 {
-    const int threads = cfg.num_envs * 4;
-    hipLaunchKernelGGL(env_assemble_kernel, dim3((threads + 255) / 256), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs, d.games,
-                       d.queue_cnt, d.queue, d.lq_debug, d.status, d.cyc, d.tab_lds ? 1 : 0);
-    return launch_check(err, "env_assemble_kernel");
+    const int cadence = cfg.num_agents > 2 ? 4 : 1;
+    return (n_ticks + cadence - 1) / cadence + 1;
 }
 
-// K_B2: the Riccati solves of the multi-player games, binned by player count
+// one round, part 1: the fused tick kernel (fills queue set round & 1)
+inline int env_launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
+    const int threads = cfg.num_envs * 4;
+    hipLaunchKernelGGL(env_run_kernel, dim3((threads + 255) / 256), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs, d.results,
+                       d.games, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status, d.tab_lds ? 1 : 0);
+    return launch_check(err, "env_run_kernel");
+}
+
+// one round, part 2: the Riccati solves of the queued multi-player games, binned by player count
 inline int env_launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
 {
     const int ngames = cfg.num_envs * cfg.num_agents;
+    const int set = d.round & 1;
+    const int* qc = d.queue_cnt + set * 8;
+    const int* qu = d.queue + (size_t)set * 3 * ngames;
     int rc = HK_OK;
     if (cfg.num_agents >= 2) {
         const int blocks = std::min((ngames + 3) / 4, 8192);
-        hipLaunchKernelGGL(lqn_kernel<2>, dim3(blocks), dim3(64), 0, stream, d.P, d.agents, d.games, d.queue_cnt, d.queue, d.lq_debug, d.status);
+        hipLaunchKernelGGL(lqn_kernel<2>, dim3(blocks), dim3(64), 0, stream, d.P, d.agents, d.games, qc, qu, d.lq_debug, d.status);
         if ((rc = launch_check(err, "lqn_kernel<2>"))) return rc;
         if (cfg.num_agents >= 3) {
-            hipLaunchKernelGGL(lqn_kernel<3>, dim3(blocks), dim3(64), 0, stream, d.P, d.agents, d.games, d.queue_cnt, d.queue, d.lq_debug, d.status);
+            hipLaunchKernelGGL(lqn_kernel<3>, dim3(blocks), dim3(64), 0, stream, d.P, d.agents, d.games, qc, qu, d.lq_debug, d.status);
             if ((rc = launch_check(err, "lqn_kernel<3>"))) return rc;
         }
         if (cfg.num_agents >= 4) {
-            hipLaunchKernelGGL(lqn_kernel<4>, dim3(blocks), dim3(64), 0, stream, d.P, d.agents, d.games, d.queue_cnt, d.queue, d.lq_debug, d.status);
+            hipLaunchKernelGGL(lqn_kernel<4>, dim3(blocks), dim3(64), 0, stream, d.P, d.agents, d.games, qc, qu, d.lq_debug, d.status);
             if ((rc = launch_check(err, "lqn_kernel<4>"))) return rc;
         }
     }
+    d.round += 1;
     return HK_OK;
-}
-
-inline int env_launch_step(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
-{
-    const int threads = cfg.num_envs * 4;
-    hipLaunchKernelGGL(env_move_kernel, dim3((threads + 255) / 256), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs, d.act_steer, d.act_branch,
-                       d.tab_lds ? 1 : 0);
-    return launch_check(err, "env_move_kernel");
 }
 
 inline int env_launch_observe(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)

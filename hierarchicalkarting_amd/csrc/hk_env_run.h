@@ -1,0 +1,87 @@
+// hk_env_run.h — the fused tick kernel.
+//
+// env_run_kernel advances every race instance by up to RUN_CAP Unity FixedUpdate ticks in ONE launch: a quad of lanes
+// (lane = agent) loops  phase A (episode controller + kart-vs-kart rays)  ->  phase B1 (wall rays, game assembly,
+// single-player Riccati solve)  ->  phase C (ArcadeKart model, engine restatement, triggers)  with the env words in
+// registers and the agent records hot in L1/L2.  The only thing a quad cannot do alone is a multi-player LQ game
+// (2-4 players, 8-16 cooperating lanes): it writes the game, queues it by player count, stores its progress and
+// leaves the loop; lqn_kernel<N> solves the queues, and the next launch resumes the env at phase C.  Once the field
+// has spread out ~99 % of all games are single-player, so almost every env runs its RUN_CAP ticks without leaving.
+//
+// Progress words live in hk_env_state.reserved[]: [0] = ticks still to run for the current hk_step, [1] = phase
+// (0: at a tick boundary, 1: waiting for a queued game of this tick).  hk_step(n) arms [0] = n and launches
+// ceil(n / cadence) + 1 rounds of {env_run_kernel, lqn_kernel<2,3,4>}: a round always retires at least one solve
+// cadence (4 ticks for A > 2, 1 tick otherwise) of every env that is not finished, so that many rounds always suffice;
+// rounds that find nothing to do cost a few microseconds.
+#pragma once
+#include "hk_env_device.h"
+#include "hk_env_step.h"
+#include "hk_env_solve.h"
+
+namespace hk {
+
+constexpr int RUN_CAP = 32;     // ticks per env per launch: lets the queued envs' solve rounds overlap with the bulk
+
+__global__ __launch_bounds__(256) void env_arm_kernel(hk_env_state* envs, int E, int n_ticks)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env < E) envs[env].reserved[0] = n_ticks;
+}
+
+__global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
+                                                      hk_episode_result* results, GameDesc* games, int* queue_cnt_all,
+                                                      int* queue_all, int set, const float* act_steer, const int* act_branch,
+                                                      hk_lq_debug* dbg_out, int* status, int use_lds)
+{
+    __shared__ KartS ks[256];
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int env = gid >> 2, i = gid & 3;
+    const bool env_ok = env < P.E;
+    // the game queues are double buffered over rounds: this launch fills `set`, and clears the other one, which the
+    // previous round's lqn kernels have finished reading
+    int* queue_cnt = queue_cnt_all + set * 8;
+    int* queue = queue_all + (size_t)set * 3 * P.E * P.A;
+    if (gid < 8) queue_cnt_all[(set ^ 1) * 8 + gid] = 0;
+    hk_env_state es;
+    if (env_ok) es = envs[env];
+    else { es.episode_steps = 0; es.inactive_mask = 0; es.experiment_num = 0; es.episodes_done = 0; es.status = 0; es.initial_started = 0; es.reserved[0] = 0; es.reserved[1] = 0; }
+    int left = es.reserved[0];
+    int phase = es.reserved[1];
+    // nothing to do in this block? (every env finished its ticks): skip the table staging too
+    if (__syncthreads_or(left > 0 || phase != 0) == 0) return;
+    const TabView T = tab_stage(P, smem, use_lds != 0);
+    const int cadence = P.A > 2 ? 4 : 1;
+    const uint32_t all_mask = (1u << P.A) - 1u;
+    int budget = RUN_CAP;
+    bool dirty = false;
+    while (env_ok && (phase != 0 || (left > 0 && budget > 0))) {
+        dirty = true;
+        if (phase == 0) {
+            const bool parked = phase_begin(P, env, i, env_ok, es, agents, results);
+            bool queued = false;
+            if (!parked) {
+                const bool act = (es.episode_steps % cadence) == 0 &&                                  // HKA:317 (Q9)
+                                 !(!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u));
+                queued = phase_assemble(P, T, ks, env, i, act, es, agents, games, queue_cnt, queue, dbg_out, status);
+            } else {
+                left -= 1; budget -= 1;         // a parked env lets the tick pass
+                continue;
+            }
+            // does any ego of this env wait for a multi-player solve?
+            int q = queued ? 1 : 0;
+            q |= __shfl_xor(q, 1, 64); q |= __shfl_xor(q, 2, 64);
+            if (q) { phase = 1; break; }
+        }
+        phase_move(P, T, env, i, env_ok, es, agents, act_steer, act_branch);
+        phase = 0;
+        left -= 1; budget -= 1;
+    }
+    if (env_ok && dirty && i == 0) {
+        es.reserved[0] = left;
+        es.reserved[1] = phase;
+        envs[env] = es;
+    }
+}
+
+}  // namespace hk

@@ -405,34 +405,27 @@ __device__ __forceinline__ void assemble_player(const EnvParams& P, const TabVie
         }
     }
 
-// ---------------------------------------------------------------------------------------------------------------
-// K_B1
-// ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void env_assemble_kernel(EnvParams P, const hk_agent_state* agents, const hk_env_state* envs,
-                                                           GameDesc* games, int* queue_cnt, int* queue, hk_lq_debug* dbg_out,
-                                                           int* status, unsigned long long* cyc, int use_lds)
+// LDS writes by the lanes of a quad, then reads by the other lanes of the SAME quad: one wave, so ordering the
+// compiler is all that is needed (the LDS serves a wave's requests in order).  No block barrier: quads leave the
+// fused tick loop at different times.
+__device__ __forceinline__ void wave_lds_sync()
 {
-    __shared__ KartS ks[256];
-    extern __shared__ __align__(16) unsigned char smem[];
-    const TabView T = tab_stage(P, smem, use_lds != 0);
-    const bool stamp = (P.debug & 128) && cyc && (threadIdx.x & 63) == 0;
-    unsigned long long tc0 = stamp ? clock64() : 0ull, tc1 = 0, tc2 = 0, tc3 = 0, tc4 = 0;
-#define HK_STAMP(v) do { if (stamp) v = clock64(); } while (0)
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int env = gid >> 2, ego = gid & 3;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// phase B1 of a tick: the ego's sensor rays, game assembly; a single-player game is solved on the spot, a multi-player
+// game is written to games[] and queued by player count.  Returns true when the ego's game was queued.
+// `act`: this env solves on this tick (cadence, not parked); it is quad-uniform.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ inline bool phase_assemble(const EnvParams& P, const TabView& T, KartS* ks, const int env, const int ego,
+                                      const bool act, const hk_env_state& es, hk_agent_state* agents, GameDesc* games,
+                                      int* queue_cnt, int* queue, hk_lq_debug* dbg_out, int* status)
+{
     const int A = P.A, L = P.L;
-    const bool env_ok = env < P.E;
-    bool act = false;            // does this env solve on this tick?
-    hk_env_state es;
-    es.episode_steps = 0; es.inactive_mask = 0; es.status = 0;
-    if (env_ok) {
-        es = envs[env];
-        const uint32_t all_mask = (1u << A) - 1u;
-        act = (es.episode_steps % (A > 2 ? 4 : 1)) == 0;                              // HKA:317 (Q9)
-        if (!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u)) act = false;
-    }
     const bool me = act && ego < A;
-    if (env_ok && ego < A && !act) games[(size_t)env * A + ego].N = 0;      // nothing to solve for this env on this tick
     const hk_agent_state* a = me ? &agents[(size_t)env * A + ego] : nullptr;
     KartS k;
     k.px = k.pz = k.yaw = k.fx = k.fz = k.speed = k.heading = k.msfs = k.dC = 0.0f;
@@ -463,7 +456,6 @@ __global__ __launch_bounds__(256) void env_assemble_kernel(EnvParams P, const hk
             float dz = lz - f_clamp(lz, -TRIG_HZ, TRIG_HZ);
             k.dC = sqrtf(dx * dx + dz * dz);
         }
-        HK_STAMP(tc1);
         // sensor rays of the own kart (Physics.Raycast vs TrackMask, HKA:834-844,906) through the wall grid.  Sensors
         // 2, 4, 8, 6 are at most 2 m long: every wall they can hit is in the list of the origin's cell.  Sensor 0 is
         // compared with up to 8 m: a hit at distance t <= 9 lies within 1 m of one of the samples o + {0,2,4,6,8} d,
@@ -512,14 +504,13 @@ __global__ __launch_bounds__(256) void env_assemble_kernel(EnvParams P, const hk
             for (int q = 0; q < 4; q++) k.ray[1 + q] = best[q];
         }
     }
-    HK_STAMP(tc2);
     ks[threadIdx.x] = k;
-    __syncthreads();
-    if (!me) return;
+    wave_lds_sync();
+    if (!me) return false;
     const KartS* kq = &ks[threadIdx.x & ~3];          // the env's four karts
     GameDesc* G = &games[(size_t)env * A + ego];
     const bool solving = (k.flags & HK_F_ENABLED) && P.low_mode[ego] == HK_LOW_LQR && !((es.inactive_mask >> ego) & 1u);
-    if (!solving) { G->N = 0; return; }
+    if (!solving) return false;
     // ---- players (HKA:702-725)
     int pl[ENV_MAXA] = {0, 0, 0, 0};
     int N = 0, nearbyAgents = -1;
@@ -543,27 +534,18 @@ __global__ __launch_bounds__(256) void env_assemble_kernel(EnvParams P, const hk
     if (N == 1) {
         // single-player game: assemble into registers and run the whole Riccati recursion right here
         GamePlayer loc;
-        HK_STAMP(tc3);
         assemble_player<true>(P, T, env, ego, 0, N, nearbyAgents, pl, kq, fixed, dy, &loc, dbg_out);
-        HK_STAMP(tc4);
-        G->N = 1;
         if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = 1;
-        lq1_solve(P, loc, const_cast<hk_agent_state*>(&agents[(size_t)env * A + ego]),
-                  (dbg_out && (P.debug & 1)) ? &dbg_out[(size_t)env * A + ego] : nullptr, status);
-        if (stamp) {
-            unsigned long long tc5 = clock64();
-            atomicAdd(&cyc[0], tc1 - tc0); atomicAdd(&cyc[1], tc2 - tc1); atomicAdd(&cyc[2], tc3 - tc2);
-            atomicAdd(&cyc[3], tc4 - tc3); atomicAdd(&cyc[4], tc5 - tc4); atomicAdd(&cyc[5], 1ull);
-        }
-        return;
+        lq1_solve(P, loc, &agents[(size_t)env * A + ego], (dbg_out && (P.debug & 1)) ? &dbg_out[(size_t)env * A + ego] : nullptr, status);
+        return false;
     }
     for (int i = 0; i < N; i++) assemble_player<false>(P, T, env, ego, i, N, nearbyAgents, pl, kq, fixed, dy, &G->p[i], dbg_out);
     G->N = N;
     if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = N;
-    if (N >= 2) {                                                                     // bin multi-player games by N
-        const int pos = atomicAdd(&queue_cnt[N], 1);
-        queue[(size_t)(N - 2) * P.E * A + pos] = env * A + ego;
-    }
+    // bin the multi-player game by N
+    const int pos = atomicAdd(&queue_cnt[N], 1);
+    queue[(size_t)(N - 2) * P.E * A + pos] = env * A + ego;
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -94,18 +94,14 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_st
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// K_A: REC.FixedUpdate (:239-311), StartRaceAfterDelay (:721-744), KA.FixedUpdate forward-collision rays (:135-167)
+// phase A of a tick: REC.FixedUpdate (:239-311), StartRaceAfterDelay (:721-744), KA.FixedUpdate forward-collision
+// rays (:135-167).  `es` is the quad's register copy of the env words (identical in the 4 lanes).  Returns true when the
+// env is parked (auto_reset off and the episode is over): nothing else happens on this tick.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void env_begin_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
-                                                        hk_episode_result* results, int* queue_cnt)
+__device__ inline bool phase_begin(const EnvParams& P, const int env, const int i, const bool env_ok, hk_env_state& es,
+                                   hk_agent_state* agents, hk_episode_result* results)
 {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid < 8) queue_cnt[gid] = 0;          // per-N game queues of this tick's solve stage (hk_env_solve.h)
-    const int env = gid >> 2, i = gid & 3;
-    const bool env_ok = env < P.E;
     const bool me = env_ok && i < P.A;
-    hk_env_state es;
-    if (env_ok) es = envs[env]; else { es.episode_steps = 0; es.inactive_mask = 0; es.experiment_num = 0; es.episodes_done = 0; es.status = 0; es.initial_started = 0; }
     hk_agent_state* a = me ? &agents[(size_t)env * P.A + i] : nullptr;
     const uint32_t all_mask = (1u << P.A) - 1u;
     bool skip = !env_ok;       // envs that stay parked (auto_reset off and finished)
@@ -116,7 +112,6 @@ __global__ __launch_bounds__(256) void env_begin_kernel(EnvParams P, hk_agent_st
                 if (!(es.status & 4u)) {
                     if (me) snapshot_result(a, &results[(size_t)env * P.A + i], es.episodes_done);
                     es.episodes_done += 1; es.status |= 4u;
-                    if (i == 0) envs[env] = es;
                 }
                 skip = true;
             } else finish = true;
@@ -131,7 +126,6 @@ __global__ __launch_bounds__(256) void env_begin_kernel(EnvParams P, hk_agent_st
                     }
                     es.inactive_mask = all_mask;
                     es.episodes_done += 1; es.status |= 2u | 4u;
-                    if (i == 0) envs[env] = es;
                     skip = true;
                 } else { finish = true; timeout = true; }
             }
@@ -198,12 +192,12 @@ __global__ __launch_bounds__(256) void env_begin_kernel(EnvParams P, hk_agent_st
             }
         }
         a->flags = fl;
-        if (i == 0) envs[env] = es;
     }
+    return skip;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// K_C: RL actions, planFixed (HKA:331-355), ArcadeKart.FixedUpdate (AK:243-503), engine restatement, triggers
+// phase C: RL actions, planFixed (HKA:331-355), ArcadeKart.FixedUpdate (AK:243-503), engine restatement, triggers
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void rot_y(float ang_rad, float& x, float& z)
 {
@@ -225,18 +219,13 @@ __device__ inline int calculate_lane(const EnvParams& P, const SecDev& s, float 
     return -1;
 }
 
-__global__ __launch_bounds__(256) void env_move_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
-                                                       const float* act_steer, const int* act_branch, int use_lds)
+// phase C of a tick (after every ego's controls are known)
+__device__ inline void phase_move(const EnvParams& P, const TabView& T, const int env, const int i, const bool env_ok,
+                                  hk_env_state& es, hk_agent_state* agents, const float* act_steer, const int* act_branch)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const TabView T = tab_stage(P, smem, use_lds != 0);
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int env = gid >> 2, i = gid & 3;
-    const bool env_ok = env < P.E;
     const bool me = env_ok && i < P.A;
-    int episode_steps = 0;
-    uint32_t inactive_mask = 0, status = 0;
-    if (env_ok) { episode_steps = envs[env].episode_steps; inactive_mask = envs[env].inactive_mask; status = envs[env].status; }
+    const int episode_steps = es.episode_steps;
+    const uint32_t inactive_mask = es.inactive_mask, status = es.status;
     const uint32_t all_mask = (1u << P.A) - 1u;
     // parked env (auto_reset off, finished): nothing moves
     const bool parked = env_ok && !P.auto_reset && (inactive_mask & all_mask) == all_mask && (status & 4u);
@@ -498,10 +487,8 @@ __global__ __launch_bounds__(256) void env_move_kernel(EnvParams P, hk_agent_sta
     uint32_t ni = newly_inactive, bd = bad ? 1u : 0u;
     ni |= (uint32_t)__shfl_xor((int)ni, 1, 64); ni |= (uint32_t)__shfl_xor((int)ni, 2, 64);
     bd |= (uint32_t)__shfl_xor((int)bd, 1, 64); bd |= (uint32_t)__shfl_xor((int)bd, 2, 64);
-    if (env_ok && i == 0 && (ni | bd)) {
-        envs[env].inactive_mask = inactive_mask | ni;
-        if (bd) envs[env].status = status | 1u;
-    }
+    es.inactive_mask = inactive_mask | ni;      // identical in the 4 lanes (quad-reduced)
+    if (bd) es.status = status | 1u;
 }
 
 }  // namespace hk

@@ -151,7 +151,7 @@ typedef struct hk_env_state {
     int32_t episodes_done;     /* finished episodes since hk_create */
     uint32_t status;           /* bit0 NaN/Inf seen in a kart state, bit1 timeout ended last episode */
     int32_t initial_started;   /* REC.initialStarted (REC:132): the very first all-inactive tick resets without logging */
-    int32_t reserved[2];
+    int32_t reserved[2];       /* library-internal progress words of hk_step ([0] ticks left, [1] phase); 0 between calls */
 } hk_env_state;
 
 /* TelemetryViewer / experiment-log quantities of the last finished episode (TelemetryViewer.cs:49-108) */
@@ -229,15 +229,13 @@ void* hk_stream(hk_handle h);              /* hipStream_t the handle launches on
 int hk_synchronize(hk_handle h);
 
 /* timing taps for bench.py's roofline object: accumulated HIP-event time (ms) and launch count per kernel stage since
- * the last hk_prof_reset.  Stages: [0] env_begin_kernel, [1] env_assemble_kernel, [2] the three lqn_kernel launches of a
- * tick (one bracket), [3] env_move_kernel, [4] lq_batch_kernel.  Event pairs are recorded on the handle's own stream
- * around every launch (no host sync per launch) and folded when read. */
-#define HK_PROF_STAGES 5
+ * the last hk_prof_reset.  Stages: [0] env_run_kernel (the fused tick kernel), [1] the lqn_kernel<2,3,4> launches of a
+ * round (one bracket), [2] lq_batch_kernel.  Event pairs are recorded on the handle's own stream around every launch
+ * (no host sync per launch) and folded when read. */
+#define HK_PROF_STAGES 3
 int hk_prof_enable(hk_handle h, int on);
 int hk_prof_reset(hk_handle h);
 int hk_prof_read(hk_handle h, double* ms /*[HK_PROF_STAGES]*/, int64_t* launches /*[HK_PROF_STAGES]*/);
-/* diagnostic builds only (env HK_LQ_DEBUG bit 7): in-kernel cycle stamps of the assemble kernel, 16 counters */
-int hk_debug_cycles(hk_handle h, unsigned long long* out16);
 
 #ifdef __cplusplus
 }
