@@ -281,6 +281,8 @@ int hk_step(hk_handle h, int n_ticks)
         if (rc) { g_last_error = h->err; return rc; }
         h->prof.end(1, e, h->stream);
     }
+    rc = hk::env_launch_check(h->dev, h->cfg, h->stream, h->err);
+    if (rc) { g_last_error = h->err; return rc; }
     return HK_OK;
 }
 
@@ -303,10 +305,21 @@ int hk_get_observations(hk_handle h, float* obs)
     return HK_OK;
 }
 
+// after a sync: did every env finish the ticks of the last hk_step, did an LQ solve hit a zero pivot?
+static int check_device_status(hk_handle h)
+{
+    int st[4] = {0, 0, 0, 0};
+    HK_HIP(h, hipMemcpyAsync(st, h->dev.status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    if (st[0] & 4) return fail(h, HK_ERR_HIP, "hk_step: an env did not complete its ticks (internal scheduling error)");
+    return HK_OK;
+}
+
 int hk_get_agent_state(hk_handle h, hk_agent_state* out)
 {
     HK_NEED_ENV(h);
     if (!out) return fail(h, HK_ERR_INVALID, "NULL pointer");
+    { int rc = check_device_status(h); if (rc) return rc; }
     const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
     HK_HIP(h, hipMemcpyAsync(out, h->dev.agents, cnt * sizeof(hk_agent_state), hipMemcpyDeviceToHost, h->stream));
     HK_HIP(h, hipStreamSynchronize(h->stream));
@@ -327,6 +340,7 @@ int hk_get_env_state(hk_handle h, hk_env_state* out)
 {
     HK_NEED_ENV(h);
     if (!out) return fail(h, HK_ERR_INVALID, "NULL pointer");
+    { int rc = check_device_status(h); if (rc) return rc; }
     HK_HIP(h, hipMemcpyAsync(out, h->dev.envs, (size_t)h->cfg.num_envs * sizeof(hk_env_state), hipMemcpyDeviceToHost, h->stream));
     HK_HIP(h, hipStreamSynchronize(h->stream));
     return HK_OK;

@@ -258,10 +258,109 @@ __device__ inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_
 }
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
-// HKA.planFixed :145-166
-__device__ inline void plan_fixed(const EnvParams& P, const TabView& T, int agent, hk_agent_state* a)
+// the fields of hk_agent_state that change every tick, kept in registers across the ticks of the fused kernel
+// (the plan arrays and the reward stay in the global record)
+struct Hot {
+    float px;
+    float pz;
+    float yaw;
+    float vx;
+    float vz;
+    float wy;
+    float acc_ang_v;
+    float steering;
+    float avg_lane_diff;
+    float avg_vel_diff;
+    float final_steer;
+    float contact_nx;
+    float contact_nz;
+    int section_index;
+    int lane;
+    int lane_changes;
+    int illegal_lane_changes;
+    int forward_collisions;
+    int last_collision_time;
+    int time_steps;
+    int init_checkpoint_index;
+    uint32_t flags;
+    uint32_t trig_lo;
+    uint32_t trig_hi;
+    int tele_completed_laps;
+    int tele_lap_end_step;
+    float tele_last_lap;
+    float tele_best_lap;
+    float tele_total_time;
+};
+__device__ __forceinline__ Hot load_hot(const hk_agent_state* a)
 {
-    const int sec = a->section_index;
+    Hot h;
+    h.px = a->px;
+    h.pz = a->pz;
+    h.yaw = a->yaw;
+    h.vx = a->vx;
+    h.vz = a->vz;
+    h.wy = a->wy;
+    h.acc_ang_v = a->acc_ang_v;
+    h.steering = a->steering;
+    h.avg_lane_diff = a->avg_lane_diff;
+    h.avg_vel_diff = a->avg_vel_diff;
+    h.final_steer = a->final_steer;
+    h.contact_nx = a->contact_nx;
+    h.contact_nz = a->contact_nz;
+    h.section_index = a->section_index;
+    h.lane = a->lane;
+    h.lane_changes = a->lane_changes;
+    h.illegal_lane_changes = a->illegal_lane_changes;
+    h.forward_collisions = a->forward_collisions;
+    h.last_collision_time = a->last_collision_time;
+    h.time_steps = a->time_steps;
+    h.init_checkpoint_index = a->init_checkpoint_index;
+    h.flags = a->flags;
+    h.trig_lo = a->trig_lo;
+    h.trig_hi = a->trig_hi;
+    h.tele_completed_laps = a->tele_completed_laps;
+    h.tele_lap_end_step = a->tele_lap_end_step;
+    h.tele_last_lap = a->tele_last_lap;
+    h.tele_best_lap = a->tele_best_lap;
+    h.tele_total_time = a->tele_total_time;
+    return h;
+}
+__device__ __forceinline__ void store_hot(hk_agent_state* a, const Hot& h)
+{
+    a->px = h.px;
+    a->pz = h.pz;
+    a->yaw = h.yaw;
+    a->vx = h.vx;
+    a->vz = h.vz;
+    a->wy = h.wy;
+    a->acc_ang_v = h.acc_ang_v;
+    a->steering = h.steering;
+    a->avg_lane_diff = h.avg_lane_diff;
+    a->avg_vel_diff = h.avg_vel_diff;
+    a->final_steer = h.final_steer;
+    a->contact_nx = h.contact_nx;
+    a->contact_nz = h.contact_nz;
+    a->section_index = h.section_index;
+    a->lane = h.lane;
+    a->lane_changes = h.lane_changes;
+    a->illegal_lane_changes = h.illegal_lane_changes;
+    a->forward_collisions = h.forward_collisions;
+    a->last_collision_time = h.last_collision_time;
+    a->time_steps = h.time_steps;
+    a->init_checkpoint_index = h.init_checkpoint_index;
+    a->flags = h.flags;
+    a->trig_lo = h.trig_lo;
+    a->trig_hi = h.trig_hi;
+    a->tele_completed_laps = h.tele_completed_laps;
+    a->tele_lap_end_step = h.tele_lap_end_step;
+    a->tele_last_lap = h.tele_last_lap;
+    a->tele_best_lap = h.tele_best_lap;
+    a->tele_total_time = h.tele_total_time;
+}
+
+// HKA.planFixed :145-166
+__device__ inline void plan_fixed(const EnvParams& P, const TabView& T, int agent, int sec, hk_agent_state* a)
+{
     int hi = sec + P.depth[agent]; if (hi > 1000) hi = 1000;
     for (int i = sec + 1; i < hi + 1; i++) {
         int key = i % P.L;
@@ -273,10 +372,10 @@ __device__ inline void plan_fixed(const EnvParams& P, const TabView& T, int agen
 }
 
 // KA.Deactivate :405-416 (+ SetZeroInputs :480-486): returns the new flags, zeroes the motion fields
-__device__ inline uint32_t deactivate_fields(const EnvParams& P, hk_agent_state* a, uint32_t flags)
+__device__ inline uint32_t deactivate_fields(const EnvParams& P, Hot& h, uint32_t flags)
 {
-    a->steering = 0.0f;
-    a->vx = 0.0f; a->vz = 0.0f; a->wy = 0.0f;
+    h.steering = 0.0f;
+    h.vx = 0.0f; h.vz = 0.0f; h.wy = 0.0f;
     flags &= ~(HK_F_ACCEL | HK_F_BRAKE | HK_F_CAN_MOVE | HK_F_ACTIVE);
     if (P.disable_on_end) flags &= ~HK_F_ENABLED;
     return flags;

@@ -296,10 +296,17 @@ inline int env_launch_arm(EnvDevice& d, const hk_config& cfg, int n_ticks, hipSt
     return launch_check(err, "env_arm_kernel");
 }
 
+inline int env_launch_check(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
+    hipLaunchKernelGGL(env_check_kernel, dim3((cfg.num_envs + 255) / 256), dim3(256), 0, stream, d.envs, cfg.num_envs, d.status);
+    return launch_check(err, "env_check_kernel");
+}
+
 // number of {run, lqn} rounds that always suffice for n ticks (see hk_env_run.h)
 inline int env_rounds_for(const hk_config& cfg, int n_ticks)
 {
     const int cadence = cfg.num_agents > 2 ? 4 : 1;
+    static_assert(RUN_CAP > 4, "RUN_CAP must exceed the solve cadence");
     return (n_ticks + cadence - 1) / cadence + 1;
 }
 

@@ -2,8 +2,8 @@
 //
 // env_run_kernel advances every race instance by up to RUN_CAP Unity FixedUpdate ticks in ONE launch: a quad of lanes
 // (lane = agent) loops  phase A (episode controller + kart-vs-kart rays)  ->  phase B1 (wall rays, game assembly,
-// single-player Riccati solve)  ->  phase C (ArcadeKart model, engine restatement, triggers)  with the env words in
-// registers and the agent records hot in L1/L2.  The only thing a quad cannot do alone is a multi-player LQ game
+// single-player Riccati solve)  ->  phase C (ArcadeKart model, engine restatement, triggers)  with the env words and
+// the per-tick agent fields (Hot) in registers; only the plan arrays are touched in memory.  The only thing a quad cannot do alone is a multi-player LQ game
 // (2-4 players, 8-16 cooperating lanes): it writes the game, queues it by player count, stores its progress and
 // leaves the loop; lqn_kernel<N> solves the queues, and the next launch resumes the env at phase C.  Once the field
 // has spread out ~99 % of all games are single-player, so almost every env runs its RUN_CAP ticks without leaving.
@@ -12,7 +12,9 @@
 // (0: at a tick boundary, 1: waiting for a queued game of this tick).  hk_step(n) arms [0] = n and launches
 // ceil(n / cadence) + 1 rounds of {env_run_kernel, lqn_kernel<2,3,4>}: a round always retires at least one solve
 // cadence (4 ticks for A > 2, 1 tick otherwise) of every env that is not finished, so that many rounds always suffice;
-// rounds that find nothing to do cost a few microseconds.
+// rounds that find nothing to do cost a few microseconds.  (RUN_CAP must exceed the cadence: a resumed env finishes its
+// pending tick and must be able to reach its next solve tick within the same launch.)  env_check_kernel flags any env
+// that still has ticks left after the last round (a bug guard: hk_get_* then fail instead of returning stale state).
 #pragma once
 #include "hk_env_device.h"
 #include "hk_env_step.h"
@@ -20,12 +22,20 @@
 
 namespace hk {
 
-constexpr int RUN_CAP = 32;     // ticks per env per launch: lets the queued envs' solve rounds overlap with the bulk
+constexpr int RUN_CAP = 8;      // ticks per env per launch (> cadence).  Measured at E = 65 536, 4-agent Oval: 8 -> 533 M env-steps/s,
+                                // 6 -> 456 M, 5 -> 408 M (misaligned with the 4-tick cadence), 16 -> 503 M, 32 -> 450 M, 128 -> 264 M: a quad that
+                                // queues a game idles its lanes until the launch ends, so long launches waste lanes
 
 __global__ __launch_bounds__(256) void env_arm_kernel(hk_env_state* envs, int E, int n_ticks)
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env < E) envs[env].reserved[0] = n_ticks;
+}
+
+__global__ __launch_bounds__(256) void env_check_kernel(const hk_env_state* envs, int E, int* status)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env < E && (envs[env].reserved[0] != 0 || envs[env].reserved[1] != 0)) atomicOr(status, 4);
 }
 
 __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
@@ -55,15 +65,18 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
     const uint32_t all_mask = (1u << P.A) - 1u;
     int budget = RUN_CAP;
     bool dirty = false;
+    hk_agent_state* arec = (env_ok && i < P.A) ? &agents[(size_t)env * P.A + i] : nullptr;
+    Hot h;
+    if (arec) h = load_hot(arec); else { Hot z = {}; h = z; }
     while (env_ok && (phase != 0 || (left > 0 && budget > 0))) {
         dirty = true;
         if (phase == 0) {
-            const bool parked = phase_begin(P, env, i, env_ok, es, agents, results);
+            const bool parked = phase_begin(P, env, i, env_ok, es, h, agents, results);
             bool queued = false;
             if (!parked) {
                 const bool act = (es.episode_steps % cadence) == 0 &&                                  // HKA:317 (Q9)
                                  !(!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u));
-                queued = phase_assemble(P, T, ks, env, i, act, es, agents, games, queue_cnt, queue, dbg_out, status);
+                queued = phase_assemble(P, T, ks, env, i, act, es, h, agents, games, queue_cnt, queue, dbg_out, status);
             } else {
                 left -= 1; budget -= 1;         // a parked env lets the tick pass
                 continue;
@@ -73,10 +86,11 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
             q |= __shfl_xor(q, 1, 64); q |= __shfl_xor(q, 2, 64);
             if (q) { phase = 1; break; }
         }
-        phase_move(P, T, env, i, env_ok, es, agents, act_steer, act_branch);
+        phase_move(P, T, env, i, env_ok, es, h, agents, act_steer, act_branch);
         phase = 0;
         left -= 1; budget -= 1;
     }
+    if (arec && dirty) store_hot(arec, h);
     if (env_ok && dirty && i == 0) {
         es.reserved[0] = left;
         es.reserved[1] = phase;

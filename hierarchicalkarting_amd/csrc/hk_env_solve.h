@@ -49,17 +49,17 @@ __device__ __forceinline__ double angle_difference(double a1, double a2)
 }
 
 // HKA:1206-1224
-__device__ inline void decode_controls(const EnvParams& P, hk_agent_state* me, double u0a, double u0b, hk_lq_debug* dbg)
+__device__ inline void decode_controls(const float fs /*final_steer*/, uint32_t& flags, float& steering, double u0a, double u0b,
+                                       hk_lq_debug* dbg)
 {
-    const float fs = me->final_steer;
     const float maxAng = fs * 0.4f;                                                   // getMaxAngularVelocity AK:505
     float angVel = f_clamp((float)u0b, -maxAng, maxAng);
-    uint32_t fl = me->flags;
+    uint32_t fl = flags;
     if (u0a < 0) { fl &= ~HK_F_ACCEL; fl |= HK_F_BRAKE; }
     else if (u0a > 0) { fl |= HK_F_ACCEL; fl &= ~HK_F_BRAKE; }
     else { fl &= ~(HK_F_ACCEL | HK_F_BRAKE); angVel = 0.0f; }                         // Q7
-    me->flags = fl;
-    me->steering = angVel / (0.4f * fs);
+    flags = fl;
+    steering = angVel / (0.4f * fs);
     if (dbg) { dbg->u0[0] = u0a; dbg->u0[1] = u0b; }
 }
 
@@ -68,7 +68,7 @@ __device__ inline void decode_controls(const EnvParams& P, hk_agent_state* me, d
 // algorithm (k ascending, seeded +0.0); entries of A, B that are structural zeros are skipped (exact), entries
 // that are 1.0 enter through fma(z, 1.0, s) like any other value.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ inline void lq1_solve(const EnvParams& P, const GamePlayer& gp, hk_agent_state* me, hk_lq_debug* dbg, int* status)
+__device__ inline void lq1_solve(const EnvParams& P, const GamePlayer& gp, Hot& h, hk_lq_debug* dbg, int* status)
 {
     const double dt = (double)P.dt;
     double A[4][4] = {{1.0, 0.0, gp.a4[0], gp.a4[2]}, {0.0, 1.0, gp.a4[1], gp.a4[3]}, {0.0, 0.0, 1.0, 0.0}, {0.0, 0.0, 0.0, 1.0}};
@@ -226,7 +226,7 @@ __device__ inline void lq1_solve(const EnvParams& P, const GamePlayer& gp, hk_ag
         u0[a] = s - alpha[a];
     }
     if (singular) atomicOr(status, 1);
-    decode_controls(P, me, u0[0], u0[1], dbg);
+    decode_controls(h.final_steer, h.flags, h.steering, u0[0], u0[1], dbg);
 }
 
 // one player's share of the ego's game (HKA:726-1198); `out` is a register struct for single-player games and the
@@ -421,7 +421,7 @@ __device__ __forceinline__ void wave_lds_sync()
 // `act`: this env solves on this tick (cadence, not parked); it is quad-uniform.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ inline bool phase_assemble(const EnvParams& P, const TabView& T, KartS* ks, const int env, const int ego,
-                                      const bool act, const hk_env_state& es, hk_agent_state* agents, GameDesc* games,
+                                      const bool act, const hk_env_state& es, Hot& h, hk_agent_state* agents, GameDesc* games,
                                       int* queue_cnt, int* queue, hk_lq_debug* dbg_out, int* status)
 {
     const int A = P.A, L = P.L;
@@ -433,17 +433,17 @@ __device__ inline bool phase_assemble(const EnvParams& P, const TabView& T, Kart
 #pragma unroll
     for (int q = 0; q < 5; q++) k.ray[q] = 3.0e38f;
     if (me) {
-        k.px = a->px; k.pz = a->pz; k.yaw = a->yaw;
+        k.px = h.px; k.pz = h.pz; k.yaw = h.yaw;
         k.fx = hk_sinf(k.yaw); k.fz = hk_cosf(k.yaw);
-        const float vx = a->vx, vz = a->vz;
+        const float vx = h.vx, vz = h.vz;
         k.speed = mag3(vx, 0.0f, vz);
         float heading = hk_atan2f(k.fz, k.fx);                                        // HKA:734
         if (heading < 0) heading += TWO_PI_F;
         k.heading = heading;
-        k.msfs = max_speed_for_state(P, k.yaw, vx, vz, a->wy, a->final_steer);
-        k.sec = a->section_index;
+        k.msfs = max_speed_for_state(P, k.yaw, vx, vz, h.wy, h.final_steer);
+        k.sec = h.section_index;
         k.straight = is_straight(P, T, k.sec) ? 1 : 0;
-        k.flags = a->flags;
+        k.flags = h.flags;
         const int i1 = (k.sec + 1) % L, i2 = (k.sec + 2) % L;
         k.pl1 = a->plan_lane[i1]; k.pv1 = a->plan_vel[i1];
         k.pl2 = a->plan_lane[i2]; k.pv2 = a->plan_vel[i2];
@@ -536,7 +536,7 @@ __device__ inline bool phase_assemble(const EnvParams& P, const TabView& T, Kart
         GamePlayer loc;
         assemble_player<true>(P, T, env, ego, 0, N, nearbyAgents, pl, kq, fixed, dy, &loc, dbg_out);
         if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = 1;
-        lq1_solve(P, loc, &agents[(size_t)env * A + ego], (dbg_out && (P.debug & 1)) ? &dbg_out[(size_t)env * A + ego] : nullptr, status);
+        lq1_solve(P, loc, h, (dbg_out && (P.debug & 1)) ? &dbg_out[(size_t)env * A + ego] : nullptr, status);
         return false;
     }
     for (int i = 0; i < N; i++) assemble_player<false>(P, T, env, ego, i, N, nearbyAgents, pl, kq, fixed, dy, &G->p[i], dbg_out);
@@ -647,7 +647,10 @@ __global__ __launch_bounds__(64) void lqn_kernel(EnvParams P, hk_agent_state* ag
         lq_solve_game<NP>(r, LG, qp, 3, u0, singular);                          // HKA:1201 horizon literal 3 (Q6)
         if (live && r == 0) {
             if (singular) atomicOr(status, 1);
-            decode_controls(P, &agents[game], u0[0], u0[1], (dbg_out && (P.debug & 1)) ? &dbg_out[game] : nullptr);
+            hk_agent_state* me = &agents[game];
+            uint32_t fl = me->flags; float st = me->steering;
+            decode_controls(me->final_steer, fl, st, u0[0], u0[1], (dbg_out && (P.debug & 1)) ? &dbg_out[game] : nullptr);
+            me->flags = fl; me->steering = st;
         }
     }
 }

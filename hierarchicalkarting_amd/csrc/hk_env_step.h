@@ -51,24 +51,24 @@ __device__ inline void reset_agent(const EnvParams& P, const TabView& T, int env
     }
     a->px = px; a->pz = pz; a->yaw = yaw;
     a->final_steer = kart_steer(P, a->acc_ang_v);
-    if (P.high_mode[i] == HK_HIGH_FIXED) plan_fixed(P, T, i, a);
+    if (P.high_mode[i] == HK_HIGH_FIXED) plan_fixed(P, T, i, a->section_index, a);
     a->flags = HK_F_ACTIVE | HK_F_ENABLED;
 }
 
-__device__ inline void snapshot_result(const hk_agent_state* a, hk_episode_result* r, int episode)
+__device__ inline void snapshot_result(const Hot& h, float cum_reward, hk_episode_result* r, int episode)
 {
-    r->time_steps = a->time_steps;
-    r->section_index = a->section_index;
-    r->illegal_lane_changes = a->illegal_lane_changes;
-    r->forward_collisions = a->forward_collisions;
-    r->avg_lane_diff = a->avg_lane_diff;
-    r->avg_vel_diff = a->avg_vel_diff;
-    r->reward = a->cum_reward;
+    r->time_steps = h.time_steps;
+    r->section_index = h.section_index;
+    r->illegal_lane_changes = h.illegal_lane_changes;
+    r->forward_collisions = h.forward_collisions;
+    r->avg_lane_diff = h.avg_lane_diff;
+    r->avg_vel_diff = h.avg_vel_diff;
+    r->reward = cum_reward;
     r->episode = episode;
-    r->last_lap = a->tele_last_lap; r->best_lap = a->tele_best_lap; r->total_time = a->tele_total_time;
-    r->laps_completed = a->tele_completed_laps; r->lap_end_step = a->tele_lap_end_step;
-    r->speed = mag3(a->vx, 0.0f, a->vz);
-    r->active = (a->flags & HK_F_ACTIVE) ? 1 : 0;
+    r->last_lap = h.tele_last_lap; r->best_lap = h.tele_best_lap; r->total_time = h.tele_total_time;
+    r->laps_completed = h.tele_completed_laps; r->lap_end_step = h.tele_lap_end_step;
+    r->speed = mag3(h.vx, 0.0f, h.vz);
+    r->active = (h.flags & HK_F_ACTIVE) ? 1 : 0;
     r->reserved = 0;
 }
 
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_st
 // env is parked (auto_reset off and the episode is over): nothing else happens on this tick.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ inline bool phase_begin(const EnvParams& P, const int env, const int i, const bool env_ok, hk_env_state& es,
-                                   hk_agent_state* agents, hk_episode_result* results)
+                                   Hot& h, hk_agent_state* agents, hk_episode_result* results)
 {
     const bool me = env_ok && i < P.A;
     hk_agent_state* a = me ? &agents[(size_t)env * P.A + i] : nullptr;
@@ -110,7 +110,7 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
         if ((es.inactive_mask & all_mask) == all_mask) {
             if (!P.auto_reset) {
                 if (!(es.status & 4u)) {
-                    if (me) snapshot_result(a, &results[(size_t)env * P.A + i], es.episodes_done);
+                    if (me) snapshot_result(h, a->cum_reward, &results[(size_t)env * P.A + i], es.episodes_done);
                     es.episodes_done += 1; es.status |= 4u;
                 }
                 skip = true;
@@ -120,9 +120,9 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
             if (es.episode_steps >= P.max_steps) {
                 if (!P.auto_reset) {
                     if (me) {
-                        uint32_t fl = a->flags;
-                        if (fl & HK_F_ACTIVE) a->flags = deactivate_fields(P, a, fl);
-                        snapshot_result(a, &results[(size_t)env * P.A + i], es.episodes_done);
+                        uint32_t fl = h.flags;
+                        if (fl & HK_F_ACTIVE) h.flags = deactivate_fields(P, h, fl);
+                        snapshot_result(h, a->cum_reward, &results[(size_t)env * P.A + i], es.episodes_done);
                     }
                     es.inactive_mask = all_mask;
                     es.episodes_done += 1; es.status |= 2u | 4u;
@@ -133,16 +133,22 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
     }
     if (finish) {
         if (me) {
-            uint32_t fl = a->flags;
-            if (fl & HK_F_ACTIVE) a->flags = deactivate_fields(P, a, fl);
+            uint32_t fl = h.flags;
+            if (fl & HK_F_ACTIVE) h.flags = deactivate_fields(P, h, fl);
         }
         if (es.initial_started || timeout) {
-            if (me) snapshot_result(a, &results[(size_t)env * P.A + i], es.episodes_done);
+            if (me) snapshot_result(h, a->cum_reward, &results[(size_t)env * P.A + i], es.episodes_done);
             es.episodes_done += 1;
             es.status = (es.status & ~2u) | (timeout ? 2u : 0u);
             es.experiment_num += 1;
         }
-        if (me) { const TabView T = tab_view(P, P.tab); reset_agent(P, T, env, i, es.experiment_num, a); }
+        if (me) {
+            // REC.ResetGame rewrites the whole record (plans included): through memory, then back into registers
+            store_hot(a, h);
+            const TabView T = tab_view(P, P.tab);
+            reset_agent(P, T, env, i, es.experiment_num, a);
+            h = load_hot(a);
+        }
         es.episode_steps = 0;
         es.inactive_mask = 0;
         es.initial_started = 1;
@@ -150,7 +156,7 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
     // own pose / flags (after a possible reset)
     float px = 0, pz = 0, yaw = 0;
     uint32_t fl = 0;
-    if (me && !skip) { px = a->px; pz = a->pz; yaw = a->yaw; fl = a->flags; }
+    if (me && !skip) { px = h.px; pz = h.pz; yaw = h.yaw; fl = h.flags; }
     // StartRaceAfterDelay
     if (me && !skip && es.episode_steps >= P.hold && (fl & HK_F_ACTIVE) && !(fl & HK_F_CAN_MOVE)) fl |= HK_F_CAN_MOVE;
     // KA.FixedUpdate: three rays against the other karts' capsules
@@ -182,16 +188,16 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
     if (me && !skip) {
         if (fl & HK_F_ENABLED) {
             const bool fc = (fl & HK_F_FORWARD_COLLISION) != 0;
-            const int lct = a->last_collision_time;
+            const int lct = h.last_collision_time;
             if (hitAgent && !fc && (lct == 0 || es.episode_steps - lct > 75)) {
-                fl |= HK_F_FORWARD_COLLISION; a->forward_collisions += 1; a->last_collision_time = es.episode_steps;
+                fl |= HK_F_FORWARD_COLLISION; h.forward_collisions += 1; h.last_collision_time = es.episode_steps;
             } else if (hitAgent) {
-                fl |= HK_F_FORWARD_COLLISION; a->last_collision_time = es.episode_steps;
+                fl |= HK_F_FORWARD_COLLISION; h.last_collision_time = es.episode_steps;
             } else {
                 fl &= ~HK_F_FORWARD_COLLISION;
             }
         }
-        a->flags = fl;
+        h.flags = fl;
     }
     return skip;
 }
@@ -221,7 +227,7 @@ __device__ inline int calculate_lane(const EnvParams& P, const SecDev& s, float 
 
 // phase C of a tick (after every ego's controls are known)
 __device__ inline void phase_move(const EnvParams& P, const TabView& T, const int env, const int i, const bool env_ok,
-                                  hk_env_state& es, hk_agent_state* agents, const float* act_steer, const int* act_branch)
+                                  hk_env_state& es, Hot& h, hk_agent_state* agents, const float* act_steer, const int* act_branch)
 {
     const bool me = env_ok && i < P.A;
     const int episode_steps = es.episode_steps;
@@ -233,25 +239,25 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
     uint32_t fl = 0;
     float px = 0, pz = 0, yaw = 0, vx = 0, vz = 0, wy = 0;
     bool live = me && !parked;
-    if (live) { fl = a->flags; px = a->px; pz = a->pz; yaw = a->yaw; vx = a->vx; vz = a->vz; wy = a->wy; }
+    if (live) { fl = h.flags; px = h.px; pz = h.pz; yaw = h.yaw; vx = h.vx; vz = h.vz; wy = h.wy; }
     const bool enabled = live && (fl & HK_F_ENABLED);
     const bool inactive_before = (inactive_mask >> i) & 1u;
     if (enabled) {
         // KA.OnActionReceived / InterpretDiscreteActions (HKA:1371-1379) for RL agents
         if (P.low_mode[i] == HK_LOW_RL && (fl & HK_F_ACTIVE)) {
-            a->steering = act_steer[(size_t)env * P.A + i];
+            h.steering = act_steer[(size_t)env * P.A + i];
             int br = act_branch[(size_t)env * P.A + i];
             if (br > 1) fl |= HK_F_ACCEL; else fl &= ~HK_F_ACCEL;
             if (br < 1) fl |= HK_F_BRAKE; else fl &= ~HK_F_BRAKE;
         }
         if (episode_steps % 100 == 0 && episode_steps < P.max_steps && episode_steps > 0 && !inactive_before)
-            if (P.high_mode[i] == HK_HIGH_FIXED) plan_fixed(P, T, i, a);
+            if (P.high_mode[i] == HK_HIGH_FIXED) plan_fixed(P, T, i, h.section_index, a);
         // ---- ArcadeKart.FixedUpdate
         bool accelerate = false, brake = false; float turnInput = 0.0f;
-        if (fl & HK_F_ACTIVE) { accelerate = (fl & HK_F_ACCEL) != 0; brake = (fl & HK_F_BRAKE) != 0; turnInput = a->steering; }
-        float acc_ang_v = a->acc_ang_v;
+        if (fl & HK_F_ACTIVE) { accelerate = (fl & HK_F_ACCEL) != 0; brake = (fl & HK_F_BRAKE) != 0; turnInput = h.steering; }
+        float acc_ang_v = h.acc_ang_v;
         const float final_steer = kart_steer(P, acc_ang_v);               // UpdateStats AK:295-302
-        a->final_steer = final_steer;
+        h.final_steer = final_steer;
         if (fl & HK_F_CAN_MOVE) {                                         // MoveVehicle AK:363-503
             const float dt = P.dt;
             const float fx = hk_sinf(yaw), fz = hk_cosf(yaw);
@@ -305,7 +311,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                 else wy = wy + f_sign(target - wy) * maxDelta;
             }
             acc_ang_v += f_abs(wy);
-            a->acc_ang_v = acc_ang_v;
+            h.acc_ang_v = acc_ang_v;
             rot_y(turningPower * f_sign(localVelZ) * 25.0f * P.st.Grip * dt * DEG2RAD_F, vx, vz);
             // ---- engine: integrate
             wy = wy * (1.0f - P.st.AngularDrag * dt);
@@ -389,7 +395,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             float vn = vx * bnx + vz * bnz;
             if (vn < 0.0f) { vx -= bnx * vn; vz -= bnz * vn; }
             fl |= HK_F_HAS_COLLISION;
-            a->contact_nx = bnx; a->contact_nz = bnz;
+            h.contact_nx = bnx; h.contact_nz = bnz;
         }
     }
     bool bad = false;
@@ -397,7 +403,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
     // ---- trigger dispatch (HKA.OnTriggerEnter :611-675) on the post-contact pose
     uint32_t newly_inactive = 0;
     if (enabled) {
-        a->px = px; a->pz = pz; a->yaw = yaw; a->vx = vx; a->vz = vz; a->wy = wy;
+        h.px = px; h.pz = pz; h.yaw = yaw; h.vx = vx; h.vz = vz; h.wy = wy;
         float ax, az, bx, bz;
         kart_core(yaw, px, pz, ax, az, bx, bz);
         uint32_t lo = 0, hi = 0;
@@ -414,14 +420,14 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                 if (t < 32) lo |= 1u << t; else hi |= 1u << (t - 32);
             }
         }
-        const uint32_t nlo = lo & ~a->trig_lo, nhi = hi & ~a->trig_hi;
-        a->trig_lo = lo; a->trig_hi = hi;
+        const uint32_t nlo = lo & ~h.trig_lo, nhi = hi & ~h.trig_hi;
+        h.trig_lo = lo; h.trig_hi = hi;
         if (nlo | nhi) {
             for (int t = 0; t < P.L; t++) {
                 const bool ent = t < 32 ? ((nlo >> t) & 1u) : ((nhi >> (t - 32)) & 1u);
                 if (!ent || !(fl & HK_F_ACTIVE)) continue;
                 const int L = P.L, H = P.H;
-                const int sec = a->section_index, init = a->init_checkpoint_index;
+                const int sec = h.section_index, init = h.init_checkpoint_index;
                 int index = -1, lane = -1;
                 int lo_i = sec - H; if (lo_i < init) lo_i = init;
                 for (int ii = lo_i; ii < sec + H; ii++) {                  // KA.FindSectionIndex :348-364
@@ -435,30 +441,30 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                         float lmx, lmz;
                         lane_marker(T, key, pl, lmx, lmz);
                         float dist = mag3(px - lmx, P.kart_y - T.sec[key].marker_y, pz - lmz);
-                        a->avg_lane_diff = (f_max(dist - 1.3f, 0.0f) + a->avg_lane_diff * (index - init - 1)) / (index - init);
+                        h.avg_lane_diff = (f_max(dist - 1.3f, 0.0f) + h.avg_lane_diff * (index - init - 1)) / (index - init);
                         float velocity = mag3(vx, 0.0f, vz);
-                        a->avg_vel_diff = ((velocity - a->plan_vel[key]) + a->avg_vel_diff * (index - init - 1)) / (index - init);
+                        h.avg_vel_diff = ((velocity - a->plan_vel[key]) + h.avg_vel_diff * (index - init - 1)) / (index - init);
                         a->plan_lane[key] = 0; a->plan_vel[key] = 0.0f;
                     }
-                    const int cur_lane = a->lane;
+                    const int cur_lane = h.lane;
                     int dl = cur_lane - lane; if (dl < 0) dl = -dl;
-                    int lc = a->lane_changes;
-                    if (lc + dl > P.max_lane_changes && is_straight(P, T, sec)) a->illegal_lane_changes += 1;
+                    int lc = h.lane_changes;
+                    if (lc + dl > P.max_lane_changes && is_straight(P, T, sec)) h.illegal_lane_changes += 1;
                     if (is_straight(P, T, sec) != is_straight(P, T, index)) lc = 0;
                     else if (cur_lane != lane) lc += dl;
-                    a->lane_changes = lc;
-                    a->section_index = index; a->lane = lane;
+                    h.lane_changes = lc;
+                    h.section_index = index; h.lane = lane;
                     if (index == P.laps * L + 1) {                         // ReachGoalSection REC:469-474
-                        a->time_steps = episode_steps;
-                        fl = deactivate_fields(P, a, fl);
+                        h.time_steps = episode_steps;
+                        fl = deactivate_fields(P, h, fl);
                         vx = 0; vz = 0; wy = 0;
                         newly_inactive |= 1u << i;
                     }
                 } else if (index != -1 && ((index < sec) || (sec % L == 0 && index % L == L - 1))) {
-                    a->section_index = index;
+                    h.section_index = index;
                 } else if (index == -1) {                                  // DroveReverseLimit REC:475-479
-                    a->time_steps = P.max_steps * 6;
-                    fl = deactivate_fields(P, a, fl);
+                    h.time_steps = P.max_steps * 6;
+                    fl = deactivate_fields(P, h, fl);
                     vx = 0; vz = 0; wy = 0;
                     newly_inactive |= 1u << i;
                 }
@@ -466,22 +472,22 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
         }
     }
     if (live) {
-        a->flags = fl;
+        h.flags = fl;
         // TelemetryViewer.Update :49-88 (once per tick)
-        const int currentLap = a->section_index / P.L;
-        const int done = a->tele_completed_laps;
+        const int currentLap = h.section_index / P.L;
+        const int done = h.tele_completed_laps;
         if (currentLap > done) {
-            a->tele_completed_laps = currentLap;
-            const float last = P.dt * (episode_steps - a->tele_lap_end_step);
-            a->tele_last_lap = last;
-            const float best = a->tele_best_lap;
-            if (best < 10 || last < best) a->tele_best_lap = last;
-            a->tele_lap_end_step = episode_steps;
+            h.tele_completed_laps = currentLap;
+            const float last = P.dt * (episode_steps - h.tele_lap_end_step);
+            h.tele_last_lap = last;
+            const float best = h.tele_best_lap;
+            if (best < 10 || last < best) h.tele_best_lap = last;
+            h.tele_lap_end_step = episode_steps;
         } else if (currentLap < done) {
-            a->tele_completed_laps = currentLap;
-            a->tele_last_lap = 0.0f; a->tele_best_lap = 0.0f; a->tele_lap_end_step = 0;
+            h.tele_completed_laps = currentLap;
+            h.tele_last_lap = 0.0f; h.tele_best_lap = 0.0f; h.tele_lap_end_step = 0;
         }
-        if (fl & HK_F_ACTIVE) a->tele_total_time = episode_steps * P.dt;
+        if (fl & HK_F_ACTIVE) h.tele_total_time = episode_steps * P.dt;
     }
     // per-env words: OR over the quad
     uint32_t ni = newly_inactive, bd = bad ? 1u : 0u;

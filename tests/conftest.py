@@ -8,3 +8,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _fresh_build():
+    """never test a stale libhk.so / oracle: rebuild both when any source is newer (no-op otherwise)"""
+    import __graft_entry__ as ge
+    ge.build()
