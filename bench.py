@@ -162,7 +162,7 @@ def main():
                                        "frac_at_measured_N": exec_flop * value / world / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                                        "note": "SURVEY §8d priced the path at N = 4 players per game; once the field spreads (> 8 m) ~99 % of the games are single-player"}},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.agents, a.warmup, seed)
         print(json.dumps(out), flush=True)
     if dist:

@@ -34,7 +34,8 @@ struct EnvParams {
     int laps, max_steps, max_lane_changes, H, disable_on_end, hold, auto_reset;
     int high_mode[ENV_MAXA], low_mode[ENV_MAXA], depth[ENV_MAXA], vbucket[ENV_MAXA];
     int n_team[ENV_MAXA], team[ENV_MAXA][ENV_MAXA], n_other[ENV_MAXA], other[ENV_MAXA][ENV_MAXA];
-    float sensor_yaw[HK_NUM_SENSORS], ray_dist[HK_NUM_SENSORS];
+    float sens_c[HK_NUM_SENSORS], sens_s[HK_NUM_SENSORS];   // cos / sin of the sensors' local yaw (MLAgent_Sensors.prefab)
+    float ray_dist[HK_NUM_SENSORS];
     uint32_t jitter_seed;
     float jitter_pos, jitter_yaw;
     int env_id_base, nperm;
@@ -113,9 +114,8 @@ __device__ __forceinline__ float turning_radius(float vx, float vz, float fx, fl
     if (isinf(out) || isnan(out)) return 1000.0f;
     return out;
 }
-__device__ inline float max_speed_for_state(const EnvParams& P, float yaw, float vx, float vz, float wy, float final_steer)
+__device__ inline float max_speed_for_state(const EnvParams& P, float fx, float fz, float vx, float vz, float wy, float final_steer)
 {   // AK:531-547
-    float fx = hk_sinf(yaw), fz = hk_cosf(yaw);
     float radius = turning_radius(vx, vz, fx, fz, wy);
     float wear = tire_wear(P, final_steer);
     if (radius == 0) return P.st.TopSpeed;
@@ -158,9 +158,8 @@ __device__ __forceinline__ float ray_seg(float ox, float oz, float dx, float dz,
 }
 
 // ray vs another kart's capsule sliced at the ray height (stadium); origin inside -> no hit (Q10)
-__device__ inline float ray_stadium(float ox, float oz, float dx, float dz, float kpx, float kpz, float kyaw, float r)
-{
-    float fx = hk_sinf(kyaw), fz = hk_cosf(kyaw);
+__device__ inline float ray_stadium(float ox, float oz, float dx, float dz, float kpx, float kpz, float fx, float fz, float r)
+{   // (fx, fz) = the other kart's forward
     float rx = fz, rz = -fx;
     float relx = ox - kpx, relz = oz - kpz;
     float lx = relx * rx + relz * rz;
@@ -236,9 +235,8 @@ __device__ inline float seg_seg_closest(float p1x, float p1z, float q1x, float q
     return ddx * ddx + ddz * ddz;
 }
 
-__device__ __forceinline__ void kart_core(float yaw, float px, float pz, float& ax, float& az, float& bx, float& bz)
+__device__ __forceinline__ void kart_core(float fx, float fz, float px, float pz, float& ax, float& az, float& bx, float& bz)
 {
-    float fx = hk_sinf(yaw), fz = hk_cosf(yaw);
     ax = px + CAP_Z0 * fx; az = pz + CAP_Z0 * fz;
     bx = px + CAP_Z1 * fx; bz = pz + CAP_Z1 * fz;
 }
@@ -356,6 +354,13 @@ __device__ __forceinline__ void store_hot(hk_agent_state* a, const Hot& h)
     a->tele_last_lap = h.tele_last_lap;
     a->tele_best_lap = h.tele_best_lap;
     a->tele_total_time = h.tele_total_time;
+}
+
+// Sensor.Transform.forward: the kart's forward (fx, fz) turned by the sensor's local yaw (Unity Y rotation, +z toward +x)
+__device__ __forceinline__ void sensor_dir(const EnvParams& P, int si, float fx, float fz, float& dx, float& dz)
+{
+    dx = fx * P.sens_c[si] + fz * P.sens_s[si];
+    dz = fz * P.sens_c[si] - fx * P.sens_s[si];
 }
 
 // HKA.planFixed :145-166

@@ -112,7 +112,10 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         P.n_team[i] = cfg.n_team[i]; P.n_other[i] = cfg.n_other[i];
         for (int j = 0; j < ENV_MAXA; j++) { P.team[i][j] = cfg.team_agents[i][j]; P.other[i][j] = cfg.other_agents[i][j]; }
     }
-    for (int i = 0; i < HK_NUM_SENSORS; i++) { P.sensor_yaw[i] = cfg.sensor_yaw_deg[i]; P.ray_dist[i] = cfg.ray_distance[i]; }
+    for (int i = 0; i < HK_NUM_SENSORS; i++) {
+        const float dl = cfg.sensor_yaw_deg[i] * DEG2RAD_F;
+        P.sens_c[i] = hk_cosf(dl); P.sens_s[i] = hk_sinf(dl); P.ray_dist[i] = cfg.ray_distance[i];
+    }
     P.jitter_seed = cfg.jitter_seed; P.jitter_pos = cfg.jitter_pos; P.jitter_yaw = cfg.jitter_yaw; P.env_id_base = cfg.env_id_base;
     P.max_speed = cfg.stats.TopSpeed > cfg.stats.ReverseSpeed ? cfg.stats.TopSpeed : cfg.stats.ReverseSpeed;   // AK:210
     P.init_acc = -cfg.stats.TireWearRate * hk_logf(1 - ((cfg.stats.MaxSteer - cfg.stats.MinSteer) * 0.25f / cfg.stats.MaxSteer));  // REC:588

@@ -86,8 +86,8 @@ __global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_
     const float fx = hk_sinf(a->yaw), fz = hk_cosf(a->yaw);
     const float ox = a->px + SENSOR_LZ * fx, oz = a->pz + SENSOR_LZ * fz;
     for (int si = 0; si < HK_NUM_SENSORS; si++) {
-        const float ang = a->yaw + P.sensor_yaw[si] * DEG2RAD_F;
-        const float dx = hk_sinf(ang), dz = hk_cosf(ang);
+        float dx, dz;
+        sensor_dir(P, si, fx, fz, dx, dz);
         const float maxd = P.ray_dist[si];
         float ht = -1.0f;
         for (int w = 0; w < P.NW; w++) {
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_
         if (a->flags & HK_F_ENABLED) {
             for (int j = 0; j < A; j++) {
                 if (j == i || !(ags[j].flags & HK_F_ENABLED)) continue;
-                float t = ray_stadium(ox, oz, dx, dz, ags[j].px, ags[j].pz, ags[j].yaw, P.ray_agent_r);
+                float t = ray_stadium(ox, oz, dx, dz, ags[j].px, ags[j].pz, hk_sinf(ags[j].yaw), hk_cosf(ags[j].yaw), P.ray_agent_r);
                 if (t >= 0.0f && t <= maxd && (ha < 0.0f || t < ha)) ha = t;
             }
         }

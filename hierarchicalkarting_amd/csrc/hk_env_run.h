@@ -68,15 +68,16 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
     hk_agent_state* arec = (env_ok && i < P.A) ? &agents[(size_t)env * P.A + i] : nullptr;
     Hot h;
     if (arec) h = load_hot(arec); else { Hot z = {}; h = z; }
+    float hfx = hk_sinf(h.yaw), hfz = hk_cosf(h.yaw);    // the kart's forward, carried across ticks (changes only when yaw does)
     while (env_ok && (phase != 0 || (left > 0 && budget > 0))) {
         dirty = true;
         if (phase == 0) {
-            const bool parked = phase_begin(P, env, i, env_ok, es, h, agents, results);
+            const bool parked = phase_begin(P, env, i, env_ok, es, h, hfx, hfz, agents, results);
             bool queued = false;
             if (!parked) {
                 const bool act = (es.episode_steps % cadence) == 0 &&                                  // HKA:317 (Q9)
                                  !(!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u));
-                queued = phase_assemble(P, T, ks, env, i, act, es, h, agents, games, queue_cnt, queue, dbg_out, status);
+                queued = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status);
             } else {
                 left -= 1; budget -= 1;         // a parked env lets the tick pass
                 continue;
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
             q |= __shfl_xor(q, 1, 64); q |= __shfl_xor(q, 2, 64);
             if (q) { phase = 1; break; }
         }
-        phase_move(P, T, env, i, env_ok, es, h, agents, act_steer, act_branch);
+        phase_move(P, T, env, i, env_ok, es, h, hfx, hfz, agents, act_steer, act_branch);
         phase = 0;
         left -= 1; budget -= 1;
     }

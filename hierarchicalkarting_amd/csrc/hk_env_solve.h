@@ -421,7 +421,8 @@ __device__ __forceinline__ void wave_lds_sync()
 // `act`: this env solves on this tick (cadence, not parked); it is quad-uniform.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ inline bool phase_assemble(const EnvParams& P, const TabView& T, KartS* ks, const int env, const int ego,
-                                      const bool act, const hk_env_state& es, Hot& h, hk_agent_state* agents, GameDesc* games,
+                                      const bool act, const hk_env_state& es, Hot& h, const float hfx, const float hfz, hk_agent_state* agents,
+                                      GameDesc* games,
                                       int* queue_cnt, int* queue, hk_lq_debug* dbg_out, int* status)
 {
     const int A = P.A, L = P.L;
@@ -434,13 +435,13 @@ __device__ inline bool phase_assemble(const EnvParams& P, const TabView& T, Kart
     for (int q = 0; q < 5; q++) k.ray[q] = 3.0e38f;
     if (me) {
         k.px = h.px; k.pz = h.pz; k.yaw = h.yaw;
-        k.fx = hk_sinf(k.yaw); k.fz = hk_cosf(k.yaw);
+        k.fx = hfx; k.fz = hfz;
         const float vx = h.vx, vz = h.vz;
         k.speed = mag3(vx, 0.0f, vz);
         float heading = hk_atan2f(k.fz, k.fx);                                        // HKA:734
         if (heading < 0) heading += TWO_PI_F;
         k.heading = heading;
-        k.msfs = max_speed_for_state(P, k.yaw, vx, vz, h.wy, h.final_steer);
+        k.msfs = max_speed_for_state(P, k.fx, k.fz, vx, vz, h.wy, h.final_steer);
         k.sec = h.section_index;
         k.straight = is_straight(P, T, k.sec) ? 1 : 0;
         k.flags = h.flags;
@@ -463,8 +464,8 @@ __device__ inline bool phase_assemble(const EnvParams& P, const TabView& T, Kart
         // every wall (the oracle) returns.
         const float ox = k.px + SENSOR_LZ * k.fx, oz = k.pz + SENSOR_LZ * k.fz;
         {
-            const float ang0 = k.yaw + P.sensor_yaw[0] * DEG2RAD_F;
-            const float d0x = hk_sinf(ang0), d0z = hk_cosf(ang0);
+            float d0x, d0z;
+            sensor_dir(P, 0, k.fx, k.fz, d0x, d0z);
             float best = 3.0e38f;
             int prev = -1;
 #pragma unroll 1
@@ -486,8 +487,7 @@ __device__ inline bool phase_assemble(const EnvParams& P, const TabView& T, Kart
             float ddx[4], ddz[4], best[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                float ang = k.yaw + P.sensor_yaw[ssel[q]] * DEG2RAD_F;
-                ddx[q] = hk_sinf(ang); ddz[q] = hk_cosf(ang);
+                sensor_dir(P, ssel[q], k.fx, k.fz, ddx[q], ddz[q]);
                 best[q] = 3.0e38f;
             }
             const int cell = grid_cell(P, ox, oz);

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_st
 // env is parked (auto_reset off and the episode is over): nothing else happens on this tick.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ inline bool phase_begin(const EnvParams& P, const int env, const int i, const bool env_ok, hk_env_state& es,
-                                   Hot& h, hk_agent_state* agents, hk_episode_result* results)
+                                   Hot& h, float& hfx, float& hfz, hk_agent_state* agents, hk_episode_result* results)
 {
     const bool me = env_ok && i < P.A;
     hk_agent_state* a = me ? &agents[(size_t)env * P.A + i] : nullptr;
@@ -148,31 +148,29 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
             const TabView T = tab_view(P, P.tab);
             reset_agent(P, T, env, i, es.experiment_num, a);
             h = load_hot(a);
+            hfx = hk_sinf(h.yaw); hfz = hk_cosf(h.yaw);
         }
         es.episode_steps = 0;
         es.inactive_mask = 0;
         es.initial_started = 1;
     }
     // own pose / flags (after a possible reset)
-    float px = 0, pz = 0, yaw = 0;
+    float px = 0, pz = 0, fx = 0, fz = 1;
     uint32_t fl = 0;
-    if (me && !skip) { px = h.px; pz = h.pz; yaw = h.yaw; fl = h.flags; }
+    if (me && !skip) { px = h.px; pz = h.pz; fx = hfx; fz = hfz; fl = h.flags; }
     // StartRaceAfterDelay
     if (me && !skip && es.episode_steps >= P.hold && (fl & HK_F_ACTIVE) && !(fl & HK_F_CAN_MOVE)) fl |= HK_F_CAN_MOVE;
     // KA.FixedUpdate: three rays against the other karts' capsules
     bool hitAgent = false;
     {
-        const float ox = px + SENSOR_LZ * hk_sinf(yaw), oz = pz + SENSOR_LZ * hk_cosf(yaw);
+        const float ox = px + SENSOR_LZ * fx, oz = pz + SENSOR_LZ * fz;
         const int csens[3] = {0, 1, 5};
         const float clen[3] = {0.8f, 0.9f, 0.9f};
         float ddx[3], ddz[3];
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            float ang = yaw + P.sensor_yaw[csens[q]] * DEG2RAD_F;
-            ddx[q] = hk_sinf(ang); ddz[q] = hk_cosf(ang);
-        }
+        for (int q = 0; q < 3; q++) sensor_dir(P, csens[q], fx, fz, ddx[q], ddz[q]);
         for (int j = 0; j < ENV_MAXA; j++) {
-            const float jpx = quad_get(px, j), jpz = quad_get(pz, j), jyaw = quad_get(yaw, j);
+            const float jpx = quad_get(px, j), jpz = quad_get(pz, j), jfx = quad_get(fx, j), jfz = quad_get(fz, j);
             const uint32_t jfl = quad_get(fl, j);
             if (j >= P.A || j == i || !(jfl & HK_F_ENABLED)) continue;
             // exact cull: a 0.9 m ray from 0.1 m ahead of this kart cannot reach a capsule whose origin is > 2.2 m away
@@ -180,7 +178,7 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
             if ((jpx - px) * (jpx - px) + (jpz - pz) * (jpz - pz) > 2.2f * 2.2f) continue;
 #pragma unroll
             for (int q = 0; q < 3; q++) {
-                float t = ray_stadium(ox, oz, ddx[q], ddz[q], jpx, jpz, jyaw, P.ray_agent_r);
+                float t = ray_stadium(ox, oz, ddx[q], ddz[q], jpx, jpz, jfx, jfz, P.ray_agent_r);
                 if (t >= 0.0f && t <= clen[q]) hitAgent = true;
             }
         }
@@ -227,7 +225,8 @@ __device__ inline int calculate_lane(const EnvParams& P, const SecDev& s, float 
 
 // phase C of a tick (after every ego's controls are known)
 __device__ inline void phase_move(const EnvParams& P, const TabView& T, const int env, const int i, const bool env_ok,
-                                  hk_env_state& es, Hot& h, hk_agent_state* agents, const float* act_steer, const int* act_branch)
+                                  hk_env_state& es, Hot& h, float& hfx, float& hfz, hk_agent_state* agents, const float* act_steer,
+                                  const int* act_branch)
 {
     const bool me = env_ok && i < P.A;
     const int episode_steps = es.episode_steps;
@@ -238,6 +237,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
     hk_agent_state* a = me ? &agents[(size_t)env * P.A + i] : nullptr;
     uint32_t fl = 0;
     float px = 0, pz = 0, yaw = 0, vx = 0, vz = 0, wy = 0;
+    float cfx = hfx, cfz = hfz;          // forward of the kart (sin yaw, cos yaw), refreshed after the integration
     bool live = me && !parked;
     if (live) { fl = h.flags; px = h.px; pz = h.pz; yaw = h.yaw; vx = h.vx; vz = h.vz; wy = h.wy; }
     const bool enabled = live && (fl & HK_F_ENABLED);
@@ -260,7 +260,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
         h.final_steer = final_steer;
         if (fl & HK_F_CAN_MOVE) {                                         // MoveVehicle AK:363-503
             const float dt = P.dt;
-            const float fx = hk_sinf(yaw), fz = hk_cosf(yaw);
+            const float fx = cfx, fz = cfz;
             float accelInput = (accelerate ? 1.0f : 0.0f) - (brake ? 1.0f : 0.0f);
             float localVelZ = vx * fx + vz * fz;
             bool accelDirectionIsFwd = accelInput >= 0;
@@ -320,23 +320,24 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             if (yaw >= TWO_PI_F) yaw -= TWO_PI_F;
             px = px + vx * dt;
             pz = pz + vz * dt;
+            cfx = hk_sinf(yaw); cfz = hk_cosf(yaw);
         }
     }
     // ---- kart-kart contacts (Jacobi over one snapshot)
     {
         float ax = 0, az = 0, bx = 0, bz = 0;
-        kart_core(yaw, px, pz, ax, az, bx, bz);
+        kart_core(cfx, cfz, px, pz, ax, az, bx, bz);
         float cpx = 0, cpz = 0, cvx = 0, cvz = 0;
         bool touched = false;
         for (int j = 0; j < ENV_MAXA; j++) {
-            const float jpx = quad_get(px, j), jpz = quad_get(pz, j), jyaw = quad_get(yaw, j);
+            const float jpx = quad_get(px, j), jpz = quad_get(pz, j), jfx = quad_get(cfx, j), jfz = quad_get(cfz, j);
             const float jvx = quad_get(vx, j), jvz = quad_get(vz, j);
             const uint32_t jfl = quad_get(fl, j);
             if (j >= P.A || j == i || !enabled || !(jfl & HK_F_ENABLED)) continue;
             // exact cull: two capsules (reach 0.657 + 0.45 from their origins) cannot touch when the origins are > 2.3 m apart
             if ((jpx - px) * (jpx - px) + (jpz - pz) * (jpz - pz) > 2.3f * 2.3f) continue;
             float cx, cz, dx, dz, c1x, c1z, c2x, c2z;
-            kart_core(jyaw, jpx, jpz, cx, cz, dx, dz);
+            kart_core(jfx, jfz, jpx, jpz, cx, cz, dx, dz);
             float d2 = seg_seg_closest(ax, az, bx, bz, cx, cz, dx, dz, c1x, c1z, c2x, c2z);
             const float rr = 2.0f * CAP_R;
             if (d2 < rr * rr) {
@@ -365,7 +366,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
     if (enabled && (fl & HK_F_CAN_MOVE)) {
         for (int pass = 0; pass < 2; pass++) {
             float ax, az, bx, bz;
-            kart_core(yaw, px, pz, ax, az, bx, bz);
+            kart_core(cfx, cfz, px, pz, ax, az, bx, bz);
             // a contact needs a wall within CAP_R of the core, i.e. within 1.11 m of the kart origin: the cell's list
             const int cell = grid_cell(P, px, pz);
             const int w0 = T.grid_off[cell], w1 = T.grid_off[cell + 1];
@@ -405,7 +406,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
     if (enabled) {
         h.px = px; h.pz = pz; h.yaw = yaw; h.vx = vx; h.vz = vz; h.wy = wy;
         float ax, az, bx, bz;
-        kart_core(yaw, px, pz, ax, az, bx, bz);
+        kart_core(cfx, cfz, px, pz, ax, az, bx, bz);
         uint32_t lo = 0, hi = 0;
         for (int t = 0; t < P.L; t++) {
             const SecDev& s = T.sec[t];
@@ -471,6 +472,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             }
         }
     }
+    hfx = cfx; hfz = cfz;
     if (live) {
         h.flags = fl;
         // TelemetryViewer.Update :49-88 (once per tick)

@@ -33,7 +33,7 @@ HK_HD int hk__rem_pio2(double x, double* r)
     const double INV_PIO2 = 0.63661977236758138;
     const double P1 = 1.5707963267341256, P2 = 6.077100506303966e-11, P3 = 2.0222662487959506e-21;
     double t = x * INV_PIO2;
-    long long k = (long long)(t < 0.0 ? t - 0.5 : t + 0.5);
+    int k = (int)(t < 0.0 ? t - 0.5 : t + 0.5);      /* |x| < 1e9 on this path (32-bit convert: native on gfx950) */
     double fk = (double)k;
     double y = x - fk * P1;
     y = y - fk * P2;
@@ -145,7 +145,9 @@ HK_HD double hk_exp(double x)
 {
     const double INV_LN2 = 1.4426950408889634, LN2_HI = 0.69314718036912382, LN2_LO = 1.9082149292705877e-10;
     double t = x * INV_LN2;
-    long long k = (long long)(t < 0.0 ? t - 0.5 : t + 0.5);
+    if (t > 2000.0) t = 2000.0;
+    if (t < -2000.0) t = -2000.0;
+    int k = (int)(t < 0.0 ? t - 0.5 : t + 0.5);
     double fk = (double)k;
     double r = (x - fk * LN2_HI) - fk * LN2_LO;
     double p = 1.1470745597729725e-11;

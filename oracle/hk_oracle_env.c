@@ -54,6 +54,7 @@ struct hko_env {
     int nperm;
     int* perms;            /* [A!][A] lexicographic (REC:137-145,166) */
     float ray_agent_r;     /* stadium radius of a kart capsule sliced at the sensor height */
+    float sens_c[HK_NUM_SENSORS], sens_s[HK_NUM_SENSORS];   /* cos / sin of the sensors' local yaw */
 };
 
 /* ------------------------------------------------------------------ small float helpers */
@@ -194,9 +195,10 @@ static inline void sensor_ray(const hko_env* e, const hk_agent_state* k, int si,
     float fx = hk_sinf(k->yaw), fz = hk_cosf(k->yaw);
     *ox = k->px + SENSOR_LZ * fx;
     *oz = k->pz + SENSOR_LZ * fz;
-    float a = k->yaw + e->cfg.sensor_yaw_deg[si] * DEG2RAD_F;
-    *dx = hk_sinf(a);
-    *dz = hk_cosf(a);
+    /* Sensor.Transform.forward = parent rotation * local rotation * (0,0,1): the kart's forward turned by the sensor's
+     * local yaw (Unity Y rotation: +z toward +x) */
+    *dx = fx * e->sens_c[si] + fz * e->sens_s[si];
+    *dz = fz * e->sens_c[si] - fx * e->sens_s[si];
 }
 
 /* ------------------------------------------------------------------ closest points between 2-D segments */
@@ -835,13 +837,13 @@ static void step_env(hko_env* e, int env)
         hk_agent_state* a = &ags[i];
         if (!(a->flags & HK_F_ENABLED)) continue;            /* disabled GameObject: no FixedUpdate */
         /* KA.FixedUpdate :135-167 */
-        float ox = a->px + SENSOR_LZ * hk_sinf(a->yaw), oz = a->pz + SENSOR_LZ * hk_cosf(a->yaw);
         static const int csens[3] = {0, 1, 5};
         static const float clen[3] = {0.8f, 0.9f, 0.9f};
         int hitAgent = 0;
         for (int q = 0; q < 3; q++) {
-            float ang = a->yaw + cfg->sensor_yaw_deg[csens[q]] * DEG2RAD_F;
-            hitAgent |= raycast_agents(e, ags, i, ox, oz, hk_sinf(ang), hk_cosf(ang), clen[q], NULL) >= 0.0f;
+            float ox, oz, rdx, rdz;
+            sensor_ray(e, a, csens[q], &ox, &oz, &rdx, &rdz);
+            hitAgent |= raycast_agents(e, ags, i, ox, oz, rdx, rdz, clen[q], NULL) >= 0.0f;
         }
         const int fc = (a->flags & HK_F_FORWARD_COLLISION) != 0;
         if (hitAgent && !fc && (a->last_collision_time == 0 || es->episode_steps - a->last_collision_time > 75)) {   /* :150 */
@@ -1054,6 +1056,10 @@ hko_env* hko_create(const hk_config* cfg)
     {
         float dyc = SENSOR_LY - CAP_CENTER_LY;
         e->ray_agent_r = sqrtf(KART_CAP_R * KART_CAP_R - dyc * dyc);
+    }
+    for (int i = 0; i < HK_NUM_SENSORS; i++) {
+        float d = cfg->sensor_yaw_deg[i] * DEG2RAD_F;
+        e->sens_c[i] = hk_cosf(d); e->sens_s[i] = hk_sinf(d);
     }
     e->nperm = 1;
     for (int i = 2; i <= e->A; i++) e->nperm *= i;
