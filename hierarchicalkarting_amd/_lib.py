@@ -10,8 +10,12 @@ HK_MAX_AGENTS = 8
 HK_MAX_SECTIONS = 64
 HK_NUM_SENSORS = 9
 HK_ABI_VERSION = 1
-HK_PROF_STAGES = 3
-PROF_STAGE_NAMES = ("env_run_kernel", "lqn_kernel<2,3,4>", "lq_batch_kernel")
+HK_PROF_STAGES = 4
+PROF_STAGE_NAMES = ("env_run_kernel", "lqn_kernel<2,3,4>", "lq_batch_kernel", "policy_mlp_kernel")
+HK_MAX_POLICIES = 4
+HK_POLICY_MAX_LAYERS = 4
+HK_POLICY_MAX_IN = 1280
+HK_POLICY_MAX_HIDDEN = 256
 
 HK_OK, HK_ERR_INVALID, HK_ERR_NO_DEVICE, HK_ERR_HIP, HK_ERR_UNSUPPORTED, HK_ERR_SINGULAR = 0, -1, -2, -3, -4, -5
 HK_LOW_RL, HK_LOW_MPC, HK_LOW_LQR = 0, 1, 2
@@ -96,6 +100,16 @@ class LqDebug(C.Structure):
 # every symbol include/hk.h declares: (restype, argtypes)
 _dp = C.POINTER(C.c_double)
 _H = C.c_void_p
+_fp = C.POINTER(C.c_float)
+
+
+class PolicyDesc(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("stack", C.c_int32), ("hidden", C.c_int32), ("n_layers", C.c_int32),
+                ("n_branch", C.c_int32), ("normalize", C.c_int32), ("deterministic", C.c_int32), ("seed", C.c_uint32),
+                ("norm_mean", _fp), ("norm_std", _fp), ("W", _fp * HK_POLICY_MAX_LAYERS), ("b", _fp * HK_POLICY_MAX_LAYERS),
+                ("W_mu", _fp), ("b_mu", _fp), ("log_sigma", _fp), ("W_branch", _fp), ("b_branch", _fp)]
+
+
 SYMBOLS = {
     "hk_create": (C.c_int, [C.POINTER(Config), C.POINTER(_H)]),
     "hk_destroy": (None, [_H]),
@@ -118,6 +132,9 @@ SYMBOLS = {
     "hk_device_agents_ptr": (C.c_void_p, [_H]),
     "hk_stream": (C.c_void_p, [_H]),
     "hk_synchronize": (C.c_int, [_H]),
+    "hk_policy_attach": (C.c_int, [_H, C.POINTER(PolicyDesc), C.POINTER(C.c_int32), C.c_int, C.c_int]),
+    "hk_policy_forward": (C.c_int, [_H, C.c_int, C.c_int, _fp, _fp, _fp]),
+    "hk_get_actions": (C.c_int, [_H, _fp, C.POINTER(C.c_int32)]),
     "hk_prof_enable": (C.c_int, [_H, C.c_int]),
     "hk_prof_reset": (C.c_int, [_H]),
     "hk_prof_read": (C.c_int, [_H, _dp, C.POINTER(C.c_int64)]),

@@ -10,6 +10,7 @@
 #include "../../include/hk.h"
 #include "hk_lq_kernels.h"
 #include "hk_env_kernels.h"
+#include "hk_policy.h"
 
 namespace {
 
@@ -21,8 +22,8 @@ struct Prof {
     bool on = false;
     std::vector<hipEvent_t> pool;                                         // free events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> rec[HK_PROF_STAGES];   // recorded, not yet folded
-    double ms[HK_PROF_STAGES] = {0, 0, 0};
-    int64_t n[HK_PROF_STAGES] = {0, 0, 0};
+    double ms[HK_PROF_STAGES] = {};
+    int64_t n[HK_PROF_STAGES] = {};
     hipEvent_t get()
     {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
@@ -74,6 +75,13 @@ struct hk_context {
     // scratch for the host-pointer LQ entry point
     void* lq_scratch = nullptr;
     size_t lq_scratch_bytes = 0;
+    // RL policies (hk_policy.h)
+    hk::PolicyDevice policy[HK_MAX_POLICIES];
+    int n_policies = 0;
+    int decision_period = 1;
+    long long academy_step = 0;    // ticks stepped since hk_create (Academy.StepCount)
+    void* pol_scratch = nullptr;   // hk_policy_forward staging
+    size_t pol_scratch_bytes = 0;
 };
 
 namespace {
@@ -149,6 +157,8 @@ void hk_destroy(hk_handle h)
     hk::env_destroy(h->dev);
     if (h->d_status) (void)hipFree(h->d_status);
     if (h->lq_scratch) (void)hipFree(h->lq_scratch);
+    if (h->pol_scratch) (void)hipFree(h->pol_scratch);
+    for (int p = 0; p < HK_MAX_POLICIES; p++) hk::policy_free(h->policy[p]);
     h->prof.fold();
     for (hipEvent_t e : h->prof.pool) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -247,8 +257,16 @@ int hk_reset(hk_handle h, const int32_t* env_ids, int n, int experiment_num)
 {
     HK_NEED_ENV(h);
     int rc = hk::env_reset(h->dev, h->cfg, env_ids, n, experiment_num, h->stream, h->err);
-    if (rc) g_last_error = h->err;
-    return rc;
+    if (rc) { g_last_error = h->err; return rc; }
+    // the agents were reset: their observation stacks start from zeros again (env_reset left the ids in dev.env_ids)
+    for (int p = 0; p < h->n_policies; p++) {
+        const int cnt = (env_ids ? n : h->cfg.num_envs) * h->policy[p].q.n_slots;
+        if (cnt <= 0) continue;
+        hipLaunchKernelGGL(hk::policy_invalidate_kernel, dim3((cnt + 255) / 256), dim3(256), 0, h->stream, h->policy[p].q,
+                           env_ids ? h->dev.env_ids : nullptr, env_ids ? n : h->cfg.num_envs);
+        HK_HIP(h, hipGetLastError());
+    }
+    return HK_OK;
 }
 
 int hk_set_actions(hk_handle h, const float* steer, const int32_t* branch)
@@ -262,11 +280,9 @@ int hk_set_actions(hk_handle h, const float* steer, const int32_t* branch)
     return HK_OK;
 }
 
-int hk_step(hk_handle h, int n_ticks)
+// n_ticks of every env: arm, rounds of {fused tick kernel, queued multi-player solves}, check
+static int step_ticks(hk_handle h, int n_ticks)
 {
-    HK_NEED_ENV(h);
-    if (n_ticks < 0) return fail(h, HK_ERR_INVALID, "hk_step: n_ticks < 0");
-    if (n_ticks == 0) return HK_OK;
     int rc = hk::env_launch_arm(h->dev, h->cfg, n_ticks, h->stream, h->err);
     if (rc) { g_last_error = h->err; return rc; }
     const int rounds = hk::env_rounds_for(h->cfg, n_ticks);
@@ -283,6 +299,120 @@ int hk_step(hk_handle h, int n_ticks)
     }
     rc = hk::env_launch_check(h->dev, h->cfg, h->stream, h->err);
     if (rc) { g_last_error = h->err; return rc; }
+    return HK_OK;
+}
+
+// Academy step of a decision tick: CollectObservations -> StackingSensor -> actor -> OnActionReceived latch
+static int policy_decide(hk_handle h)
+{
+    int rc = hk::env_launch_observe(h->dev, h->cfg, h->stream, h->err);
+    if (rc) { g_last_error = h->err; return rc; }
+    const unsigned long long decision = (unsigned long long)(h->academy_step / h->decision_period);
+    const int E = h->cfg.num_envs, A = h->cfg.num_agents;
+    for (int p = 0; p < h->n_policies; p++) {
+        const hk::PolicyDevice& pd = h->policy[p];
+        const int pairs = E * pd.q.n_slots;
+        const int w = (int)(decision % (unsigned long long)pd.q.stack);
+        hipLaunchKernelGGL(hk::policy_stack_kernel, dim3((pairs + 1) / 2), dim3(256), 0, h->stream, pd.q, E, A, h->dev.envs,
+                           h->dev.obs, w);
+        HK_HIP(h, hipGetLastError());
+        hipEvent_t e = h->prof.begin(h->stream);
+        rc = hk::policy_launch_mlp(pd, pairs, pd.q.ring, w, decision, h->cfg.env_id_base, A, nullptr, nullptr, h->dev.act_steer,
+                                   h->dev.act_branch, h->stream, h->err);
+        if (rc) { g_last_error = h->err; return rc; }
+        h->prof.end(3, e, h->stream);
+    }
+    return HK_OK;
+}
+
+int hk_step(hk_handle h, int n_ticks)
+{
+    HK_NEED_ENV(h);
+    if (n_ticks < 0) return fail(h, HK_ERR_INVALID, "hk_step: n_ticks < 0");
+    if (n_ticks == 0) return HK_OK;
+    if (h->n_policies == 0) {
+        h->academy_step += n_ticks;
+        return step_ticks(h, n_ticks);
+    }
+    // with policies attached the Academy steps first in a decision tick; the ticks up to the next decision run fused
+    int left = n_ticks;
+    while (left > 0) {
+        const int phase = (int)(h->academy_step % h->decision_period);
+        if (phase == 0) { int rc = policy_decide(h); if (rc) return rc; }
+        int chunk = h->decision_period - phase;
+        if (chunk > left) chunk = left;
+        int rc = step_ticks(h, chunk);
+        if (rc) return rc;
+        h->academy_step += chunk;
+        left -= chunk;
+    }
+    return HK_OK;
+}
+
+int hk_policy_attach(hk_handle h, const hk_policy_desc* desc, const int32_t* agent_slots, int n_slots, int decision_period)
+{
+    HK_NEED_ENV(h);
+    int rc = hk::policy_validate(desc, h->err);
+    if (rc) { g_last_error = h->err; return rc; }
+    if (!agent_slots || n_slots < 1 || n_slots > h->cfg.num_agents || decision_period < 1)
+        return fail(h, HK_ERR_INVALID, "hk_policy_attach: bad agent_slots / decision_period");
+    if (h->n_policies >= HK_MAX_POLICIES) return fail(h, HK_ERR_INVALID, "hk_policy_attach: HK_MAX_POLICIES policies already attached");
+    if (desc->in_dim != hk_obs_dim(h) * desc->stack)
+        return fail(h, HK_ERR_INVALID, "hk_policy_attach: in_dim != hk_obs_dim * stack (a model trained for another agent count / horizon)");
+    for (int j = 0; j < n_slots; j++) {
+        const int a = agent_slots[j];
+        if (a < 0 || a >= h->cfg.num_agents || h->cfg.low_mode[a] != HK_LOW_RL)
+            return fail(h, HK_ERR_INVALID, "hk_policy_attach: agent slot out of range or not LowMode RL");
+        for (int p = 0; p < h->n_policies; p++)
+            for (int q = 0; q < h->policy[p].q.n_slots; q++)
+                if (h->policy[p].q.slots[q] == a) return fail(h, HK_ERR_INVALID, "hk_policy_attach: agent slot already has a policy");
+        for (int q = 0; q < j; q++) if (agent_slots[q] == a) return fail(h, HK_ERR_INVALID, "hk_policy_attach: duplicate agent slot");
+    }
+    const int idx = h->n_policies;
+    rc = hk::policy_upload(h->policy[idx], desc, idx, hk_obs_dim(h), agent_slots, n_slots, h->cfg.num_envs, h->stream, h->err);
+    if (rc) { hk::policy_free(h->policy[idx]); g_last_error = h->err; return rc; }
+    h->decision_period = decision_period;
+    h->n_policies = idx + 1;
+    return idx;
+}
+
+int hk_policy_forward(hk_handle h, int policy, int rows, const float* obs, float* mu, float* logits)
+{
+    HK_NEED_ENV(h);
+    if (policy < 0 || policy >= h->n_policies || rows < 0) return fail(h, HK_ERR_INVALID, "hk_policy_forward: bad policy / rows");
+    if (rows == 0) return HK_OK;
+    if (!obs || !mu || !logits) return fail(h, HK_ERR_INVALID, "hk_policy_forward: NULL pointer");
+    const hk::PolicyDevice& pd = h->policy[policy];
+    const size_t n_in = (size_t)rows * pd.q.in_dim, n_lg = (size_t)rows * pd.q.n_branch;
+    const size_t total = (n_in + rows + n_lg) * sizeof(float);
+    if (total > h->pol_scratch_bytes) {
+        if (h->pol_scratch) HK_HIP(h, hipFree(h->pol_scratch));
+        h->pol_scratch = nullptr; h->pol_scratch_bytes = 0;
+        HK_HIP(h, hipMalloc(&h->pol_scratch, total));
+        h->pol_scratch_bytes = total;
+    }
+    float* d_in = (float*)h->pol_scratch;
+    float* d_mu = d_in + n_in;
+    float* d_lg = d_mu + rows;
+    HK_HIP(h, hipMemcpyAsync(d_in, obs, n_in * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    hipEvent_t e = h->prof.begin(h->stream);
+    int rc = hk::policy_launch_mlp(pd, rows, d_in, pd.q.stack - 1, 0ull, 0, h->cfg.num_agents, d_mu, d_lg, nullptr, nullptr, h->stream, h->err);
+    if (rc) { g_last_error = h->err; return rc; }
+    h->prof.end(3, e, h->stream);
+    HK_HIP(h, hipMemcpyAsync(mu, d_mu, rows * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HK_HIP(h, hipMemcpyAsync(logits, d_lg, n_lg * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    return HK_OK;
+}
+
+int hk_get_actions(hk_handle h, float* steer, int32_t* branch)
+{
+    HK_NEED_ENV(h);
+    if (!steer || !branch) return fail(h, HK_ERR_INVALID, "hk_get_actions: NULL pointer");
+    const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
+    HK_HIP(h, hipMemcpyAsync(steer, h->dev.act_steer, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HK_HIP(h, hipMemcpyAsync(branch, h->dev.act_branch, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
     return HK_OK;
 }
 

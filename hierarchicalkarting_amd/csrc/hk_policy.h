@@ -1,0 +1,363 @@
+// hk_policy.h — on-device inference of the ML-Agents PPO actor that drives LowMode == RL agents (contract
+// in include/hk.h).  Three steps per decision tick, all on the handle's stream:
+//   env_observe_kernel      CollectObservations of every agent                      (hk_env_observe.h)
+//   policy_stack_kernel     StackingSensor: push the newest observation into the agent's ring, zero the ring first when
+//                           the episode changed since the last decision
+//   policy_mlp_kernel       normalise -> n x (Linear + Swish) -> {mu, logits} -> sample -> latch steer / branch
+//
+// policy_mlp_kernel: one workgroup (8 waves) per tile of 64 rows (row = one agent's stacked observation).  The tile's
+// activations live TRANSPOSED in LDS (At[k][row], row stride 65 floats: conflict-free for the column writes of the loader
+// and of the layer epilogue, and for the 32-consecutive-row reads of the MFMA A operand) and are overwritten in place
+// layer by layer (the first layer streams its inputs through in chunks of <= 320, so stacks of 8 observations fit); weights are pre-transposed once at attach time (Wt[k][out]) so the MFMA B operand is a coalesced
+// 128-byte read per half-wave straight from L2 (all layers together are <= 0.6 MB).  The GEMMs run on the f32-input
+// matrix instruction v_mfma_f32_32x32x2_f32: a 64 x H layer is (H/32) x 2 blocks of 32 x 32, two per wave at H = 256.
+// Its result is bit-for-bit a k-ascending fmaf chain seeded with the accumulator input, which we seed with the bias —
+// exactly the chain the CPU oracle evaluates, so mu / logits agree bit for bit.  The two heads (1 + n_branch outputs)
+// are plain fmaf chains on the vector ALU (N = 4 is not MFMA-shaped).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "../../include/hk.h"
+#include "../../include/hk_detmath.h"
+#include "hk_env_device.h"
+
+namespace hk {
+
+constexpr int PM_TILE = 64;                 // rows per workgroup
+constexpr int PM_LD = PM_TILE + 1;          // LDS row stride of At (floats)
+constexpr int PM_THREADS = 512;
+constexpr int PM_MAX_OUT = 8;               // 1 + n_branch
+constexpr int PM_KC_MAX = 320;              // 320 x 65 floats = 83 KB of LDS
+
+struct PolicyParams {
+    int in_dim, obs_dim, stack, hidden, n_layers, n_branch, normalize, deterministic;
+    int kc;                     // layer-0 inputs staged through LDS per chunk (even, <= PM_KC_MAX); later layers use hidden
+    uint32_t seed;
+    int index;                  // policy index (Philox key word)
+    int n_slots;
+    int slots[HK_MAX_AGENTS];
+    const float* mean;
+    const float* std;
+    const float* Wt[HK_POLICY_MAX_LAYERS];   // [k][hidden]
+    const float* b[HK_POLICY_MAX_LAYERS];
+    const float* W_mu;                       // [hidden]
+    const float* b_mu;
+    const float* log_sigma;
+    const float* W_branch;                   // [n_branch][hidden]
+    const float* b_branch;
+    float* ring;                             // [E][n_slots][stack][obs_dim]
+    int32_t* epoch;                          // [E][n_slots]
+};
+
+struct PolicyDevice {
+    PolicyParams q{};
+    float* weights = nullptr;                // one allocation behind every const float* above
+    bool used = false;
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------------------------
+// StackingSensor.  128 threads per (env, slot); w = ring slot that receives the newest observation.
+__global__ __launch_bounds__(256) void policy_stack_kernel(PolicyParams Q, int E, int A, const hk_env_state* envs,
+                                                           const float* obs, int w)
+{
+    const int pair = blockIdx.x * 2 + (threadIdx.x >> 7);
+    const int t = threadIdx.x & 127;
+    const bool ok = pair < E * Q.n_slots;
+    const int env = ok ? pair / Q.n_slots : 0, j = ok ? pair % Q.n_slots : 0;
+    const int ep = envs[env].episodes_done + envs[env].initial_started;
+    const bool stale = ok && Q.epoch[pair] != ep;
+    __syncthreads();                 // everyone has read the epoch word before it is rewritten
+    float* ring = Q.ring + (size_t)(ok ? pair : 0) * Q.in_dim;
+    if (stale) {
+        for (int k = t; k < Q.in_dim; k += 128) ring[k] = 0.0f;
+        if (t == 0) Q.epoch[pair] = ep;
+    }
+    __syncthreads();                 // zero fill before the newest observation lands in slot w
+    if (ok) {
+        const float* o = obs + ((size_t)env * A + Q.slots[j]) * Q.obs_dim;
+        for (int k = t; k < Q.obs_dim; k += 128) ring[(size_t)w * Q.obs_dim + k] = o[k];
+    }
+}
+
+// hk_reset: force the rings of the listed envs (all when env_ids == nullptr) to be cleared at the next decision
+__global__ __launch_bounds__(256) void policy_invalidate_kernel(PolicyParams Q, const int* env_ids, int n)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * Q.n_slots) return;
+    const int env = env_ids ? env_ids[idx / Q.n_slots] : idx / Q.n_slots;
+    Q.epoch[(size_t)env * Q.n_slots + idx % Q.n_slots] = -1;
+}
+
+__device__ inline float swish(float s)
+{   // Sigmoid then Mul in the exported graph
+    const float sg = 1.0f / (1.0f + hk_expf(-s));
+    return s * sg;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// src: [rows][in_dim]; logical element k of a row lives at ((w + 1 + k / obs_dim) % stack) * obs_dim + k % obs_dim
+// (w = stack - 1 for plain oldest-first rows).  Outputs: mu_out / logit_out when non-null; act_steer / act_branch
+// (indexed [env][agent], row = env * n_slots + j) when non-null.
+__global__ __launch_bounds__(PM_THREADS, 1) void policy_mlp_kernel(PolicyParams Q, int rows, const float* src, int w,
+                                                                   unsigned long long decision, int env_id_base, int A,
+                                                                   float* mu_out, float* logit_out, float* act_steer, int* act_branch)
+{
+    extern __shared__ __align__(16) float At[];        // [max(kc, hidden)][PM_LD] then head[PM_MAX_OUT][PM_TILE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * PM_TILE;
+    const int K0 = Q.in_dim, H = Q.hidden, KC = Q.kc;
+    float* head = At + (size_t)(KC > H ? KC : H) * PM_LD;
+
+    // Blocks of 32 x 32 of a 64 x H layer: cb = column block, rb = row block (0, 1); <= 16 blocks, two per wave at most.
+    const int ncb = H >> 5;
+    const int nunits = ncb * 2;
+    const int half = lane >> 5, c = lane & 31;
+    const int u0 = wave, u1 = wave + 8;
+    const bool has0 = u0 < nunits, has1 = u1 < nunits;
+    const int cb0 = u0 % ncb, rb0 = u0 / ncb;
+    const int cb1 = has1 ? u1 % ncb : cb0, rb1 = has1 ? u1 / ncb : rb0;
+    const float* a0p = At + (size_t)half * PM_LD + rb0 * 32 + c;
+    const float* a1p = At + (size_t)half * PM_LD + rb1 * 32 + c;
+
+    for (int l = 0; l < Q.n_layers; l++) {
+        const int K = l == 0 ? K0 : H;
+        f32x16 acc0, acc1;
+        {
+            const float bias0 = has0 ? Q.b[l][cb0 * 32 + c] : 0.0f;
+            const float bias1 = has1 ? Q.b[l][cb1 * 32 + c] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { acc0[r] = bias0; acc1[r] = bias1; }
+        }
+        // layer 0 streams its K0 inputs through LDS in chunks of KC (the accumulators carry the fmaf chain across chunks);
+        // the later layers read the activations the previous epilogue left in LDS
+        for (int kb = 0; kb < K; kb += KC) {
+            const int kc = (K - kb) < KC ? (K - kb) : KC;
+            if (l == 0) {
+                if (kb > 0) __syncthreads();                      // the previous chunk has been consumed
+                // ---- load + normalise the tile chunk, transposed
+                for (int idx = tid; idx < PM_TILE * kc; idx += PM_THREADS) {
+                    const int r = idx / kc, k = kb + idx - r * kc;
+                    float v = 0.0f;
+                    if (row0 + r < rows) {
+                        const int i = k / Q.obs_dim, kk = k - i * Q.obs_dim;
+                        int slot = w + 1 + i; slot -= (slot >= Q.stack) ? Q.stack : 0;
+                        v = src[(size_t)(row0 + r) * K0 + (size_t)slot * Q.obs_dim + kk];
+                        if (Q.normalize) {
+                            v = (v - Q.mean[k]) / Q.std[k];
+                            v = v < -5.0f ? -5.0f : (v > 5.0f ? 5.0f : v);
+                        }
+                    }
+                    At[(size_t)(k - kb) * PM_LD + r] = v;
+                }
+                __syncthreads();
+            }
+            if (has0) {
+                const float* __restrict__ Wt = Q.Wt[l] + (size_t)kb * H;
+                const float* b0p = Wt + (size_t)half * H + cb0 * 32 + c;
+                const float* b1p = Wt + (size_t)half * H + cb1 * 32 + c;
+                if (has1 && cb1 == cb0) {
+                    // H = 256: both blocks of this wave share the B operand
+#pragma unroll 8
+                    for (int k0 = 0; k0 < kc; k0 += 2) {
+                        const float bv = b0p[(size_t)k0 * H];
+                        const float av0 = a0p[(size_t)k0 * PM_LD];
+                        const float av1 = a1p[(size_t)k0 * PM_LD];
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv, acc1, 0, 0, 0);
+                    }
+                } else if (has1) {
+#pragma unroll 8
+                    for (int k0 = 0; k0 < kc; k0 += 2) {
+                        const float bv0 = b0p[(size_t)k0 * H], bv1 = b1p[(size_t)k0 * H];
+                        const float av0 = a0p[(size_t)k0 * PM_LD];
+                        const float av1 = a1p[(size_t)k0 * PM_LD];
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1, acc1, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll 8
+                    for (int k0 = 0; k0 < kc; k0 += 2) {
+                        const float bv = b0p[(size_t)k0 * H];
+                        const float av0 = a0p[(size_t)k0 * PM_LD];
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv, acc0, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (has0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) { acc0[r] = swish(acc0[r]); if (has1) acc1[r] = swish(acc1[r]); }
+        }
+        __syncthreads();            // every wave has finished reading this layer's input
+        if (has0) {
+            // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+                At[(size_t)(cb0 * 32 + c) * PM_LD + rb0 * 32 + rr] = acc0[r];
+                if (has1) At[(size_t)(cb1 * 32 + c) * PM_LD + rb1 * 32 + rr] = acc1[r];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- heads: out 0 = mu, 1.. = branch logits; thread -> (out = tid / 64, row = tid % 64)
+    {
+        const int out = tid >> 6, r = tid & 63;
+        if (out < 1 + Q.n_branch) {
+            const float* wv = out == 0 ? Q.W_mu : Q.W_branch + (size_t)(out - 1) * H;
+            float s = out == 0 ? Q.b_mu[0] : Q.b_branch[out - 1];
+            for (int k = 0; k < H; k++) s = __builtin_fmaf(At[(size_t)k * PM_LD + r], wv[k], s);
+            head[out * PM_TILE + r] = s;
+        }
+    }
+    __syncthreads();
+    if (tid < PM_TILE && row0 + tid < rows) {
+        const int row = row0 + tid;
+        const float mu = head[tid];
+        float lg[PM_MAX_OUT];
+        for (int b = 0; b < Q.n_branch; b++) lg[b] = head[(1 + b) * PM_TILE + tid];
+        if (mu_out) mu_out[row] = mu;
+        if (logit_out) for (int b = 0; b < Q.n_branch; b++) logit_out[(size_t)row * Q.n_branch + b] = lg[b];
+        if (act_steer) {
+            const int env = row / Q.n_slots, agent = Q.slots[row % Q.n_slots];
+            const uint32_t grow = (uint32_t)(env_id_base + env) * (uint32_t)A + (uint32_t)agent;
+            uint32_t rnd[4];
+            philox4x32((uint32_t)decision, (uint32_t)(decision >> 32), grow, 0x504F4C49u, Q.seed, (uint32_t)Q.index, rnd);
+            float eps = 0.0f;
+            if (!Q.deterministic) {
+                const float u1 = (float)((rnd[0] >> 8) + 1u) * (1.0f / 16777216.0f);
+                const float u2 = u01(rnd[1]);
+                eps = sqrtf(-2.0f * hk_logf(u1)) * hk_cosf((2.0f * HK_PI_F) * u2);
+            }
+            const float sigma = hk_expf(Q.log_sigma[0]);
+            float v = mu + eps * sigma;
+            v = v < -3.0f ? -3.0f : (v > 3.0f ? 3.0f : v);
+            int best = 0;
+            for (int b = 1; b < Q.n_branch; b++) if (lg[b] > lg[best]) best = b;
+            int pick = best;
+            if (!Q.deterministic) {
+                float ex[PM_MAX_OUT], tot = 0.0f;
+                for (int b = 0; b < Q.n_branch; b++) { ex[b] = hk_expf(lg[b] - lg[best]); tot += ex[b]; }
+                const float thr = u01(rnd[2]) * tot;
+                float cum = 0.0f;
+                pick = Q.n_branch - 1;
+                for (int b = 0; b < Q.n_branch; b++) { cum += ex[b]; if (thr < cum) { pick = b; break; } }
+            }
+            act_steer[(size_t)env * A + agent] = v / 3.0f;
+            act_branch[(size_t)env * A + agent] = pick;
+        }
+    }
+}
+
+inline size_t policy_lds_bytes(const PolicyParams& q)
+{
+    const int kmax = q.kc > q.hidden ? q.kc : q.hidden;
+    return ((size_t)kmax * PM_LD + (size_t)PM_MAX_OUT * PM_TILE) * sizeof(float);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+inline int policy_validate(const hk_policy_desc* d, std::string& err)
+{
+    if (!d) { err = "hk_policy_attach: NULL desc"; return HK_ERR_INVALID; }
+    if (d->in_dim < 2 || (d->in_dim & 1) || d->stack < 1 || d->in_dim % d->stack) { err = "hk_policy_attach: bad in_dim / stack"; return HK_ERR_INVALID; }
+    if (d->in_dim > HK_POLICY_MAX_IN) { err = "hk_policy_attach: in_dim > HK_POLICY_MAX_IN"; return HK_ERR_UNSUPPORTED; }
+    if (d->hidden < 32 || d->hidden > HK_POLICY_MAX_HIDDEN || d->hidden % 32) { err = "hk_policy_attach: hidden must be a multiple of 32 in [32, 256]"; return HK_ERR_INVALID; }
+    if (d->n_layers < 1 || d->n_layers > HK_POLICY_MAX_LAYERS || d->n_branch < 1 || d->n_branch > PM_MAX_OUT - 1) { err = "hk_policy_attach: bad n_layers / n_branch"; return HK_ERR_INVALID; }
+    if (d->normalize && (!d->norm_mean || !d->norm_std)) { err = "hk_policy_attach: normalize without mean / std"; return HK_ERR_INVALID; }
+    for (int l = 0; l < d->n_layers; l++) if (!d->W[l] || !d->b[l]) { err = "hk_policy_attach: NULL layer weights"; return HK_ERR_INVALID; }
+    if (!d->W_mu || !d->b_mu || !d->log_sigma || !d->W_branch || !d->b_branch) { err = "hk_policy_attach: NULL head weights"; return HK_ERR_INVALID; }
+    return HK_OK;
+}
+
+// upload (weights of the hidden layers transposed to [k][hidden]); E == 0: no ring (a forward-only policy)
+inline int policy_upload(PolicyDevice& pd, const hk_policy_desc* d, int index, int obs_dim, const int32_t* slots, int n_slots,
+                         int E, hipStream_t stream, std::string& err)
+{
+    const int H = d->hidden, K0 = d->in_dim;
+    std::vector<float> host;
+    auto put = [&](const float* src, size_t n) { size_t off = host.size(); host.insert(host.end(), src, src + n); return off; };
+    size_t o_mean = 0, o_std = 0, o_W[HK_POLICY_MAX_LAYERS], o_b[HK_POLICY_MAX_LAYERS];
+    if (d->normalize) { o_mean = put(d->norm_mean, K0); o_std = put(d->norm_std, K0); }
+    for (int l = 0; l < d->n_layers; l++) {
+        const int K = l == 0 ? K0 : H;
+        o_W[l] = host.size();
+        host.resize(host.size() + (size_t)K * H);
+        float* wt = host.data() + o_W[l];
+        for (int j = 0; j < H; j++)
+            for (int k = 0; k < K; k++) wt[(size_t)k * H + j] = d->W[l][(size_t)j * K + k];
+        o_b[l] = put(d->b[l], H);
+    }
+    const size_t o_wmu = put(d->W_mu, H), o_bmu = put(d->b_mu, 1), o_ls = put(d->log_sigma, 1);
+    const size_t o_wbr = put(d->W_branch, (size_t)d->n_branch * H), o_bbr = put(d->b_branch, d->n_branch);
+    hipError_t e;
+    if ((e = hipMalloc(&pd.weights, host.size() * sizeof(float))) != hipSuccess ||
+        (e = hipMemcpyAsync(pd.weights, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(stream)) != hipSuccess) {
+        err = std::string("hk_policy_attach: ") + hipGetErrorString(e);
+        return HK_ERR_HIP;
+    }
+    PolicyParams& q = pd.q;
+    q.in_dim = K0; q.obs_dim = obs_dim; q.stack = d->stack; q.hidden = H; q.n_layers = d->n_layers; q.n_branch = d->n_branch;
+    q.normalize = d->normalize; q.deterministic = d->deterministic; q.seed = d->seed; q.index = index;
+    {   // equal even chunks of at most PM_KC_MAX inputs
+        const int nch = (K0 + PM_KC_MAX - 1) / PM_KC_MAX;
+        q.kc = (K0 + nch - 1) / nch;
+        q.kc += q.kc & 1;
+        if (q.kc < H) q.kc = H;      // later layers run as one chunk of `hidden`
+    }
+    q.n_slots = n_slots;
+    for (int j = 0; j < HK_MAX_AGENTS; j++) q.slots[j] = j < n_slots ? slots[j] : 0;
+    q.mean = d->normalize ? pd.weights + o_mean : nullptr;
+    q.std = d->normalize ? pd.weights + o_std : nullptr;
+    for (int l = 0; l < HK_POLICY_MAX_LAYERS; l++) {
+        q.Wt[l] = l < d->n_layers ? pd.weights + o_W[l] : nullptr;
+        q.b[l] = l < d->n_layers ? pd.weights + o_b[l] : nullptr;
+    }
+    q.W_mu = pd.weights + o_wmu; q.b_mu = pd.weights + o_bmu; q.log_sigma = pd.weights + o_ls;
+    q.W_branch = pd.weights + o_wbr; q.b_branch = pd.weights + o_bbr;
+    q.ring = nullptr; q.epoch = nullptr;
+    if (E > 0) {
+        const size_t pairs = (size_t)E * n_slots;
+        if ((e = hipMalloc(&q.ring, pairs * K0 * sizeof(float))) != hipSuccess ||
+            (e = hipMalloc(&q.epoch, pairs * sizeof(int32_t))) != hipSuccess ||
+            (e = hipMemsetAsync(q.ring, 0, pairs * K0 * sizeof(float), stream)) != hipSuccess ||
+            (e = hipMemsetAsync(q.epoch, 0xFF, pairs * sizeof(int32_t), stream)) != hipSuccess) {
+            err = std::string("hk_policy_attach: ") + hipGetErrorString(e);
+            return HK_ERR_HIP;
+        }
+    }
+    pd.used = true;
+    return HK_OK;
+}
+
+inline void policy_free(PolicyDevice& pd)
+{
+    if (pd.weights) (void)hipFree(pd.weights);
+    if (pd.q.ring) (void)hipFree(pd.q.ring);
+    if (pd.q.epoch) (void)hipFree(pd.q.epoch);
+    pd = PolicyDevice{};
+}
+
+inline int policy_launch_mlp(const PolicyDevice& pd, int rows, const float* src, int w, unsigned long long decision,
+                             int env_id_base, int A, float* mu_out, float* logit_out, float* act_steer, int* act_branch,
+                             hipStream_t stream, std::string& err)
+{
+    if (rows <= 0) return HK_OK;
+    const size_t lds = policy_lds_bytes(pd.q);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)policy_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(policy_mlp_kernel, dim3((rows + PM_TILE - 1) / PM_TILE), dim3(PM_THREADS), lds, stream, pd.q, rows, src, w,
+                       decision, env_id_base, A, mu_out, logit_out, act_steer, act_branch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err = std::string("policy_mlp_kernel: ") + hipGetErrorString(e); return HK_ERR_HIP; }
+    return HK_OK;
+}
+
+}  // namespace hk

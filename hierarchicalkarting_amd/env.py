@@ -5,6 +5,7 @@ RacingEnv  <->  RacingEnvController (+ its KartAgents / ArcadeKarts), E independ
     step(n)                          n Unity FixedUpdate ticks
     observations()                   HierarchicalKartAgent.CollectObservations (HKA:485-604)
     set_actions(steer, branch)       KartAgent.OnActionReceived (KA:440-478) for LowMode == RL agents
+    attach_policy(policy, slots)     BehaviorParameters.Model: the ML-Agents actor runs on device every DecisionPeriod ticks
     agent_state() / set_agent_state  snapshot / restore of every KartAgent + ArcadeKart + Rigidbody field
     episode_results()                TelemetryViewer quantities of the last finished episode
 All arrays are numpy views of the ABI structs; all compute happens in the HIP kernels."""
@@ -89,6 +90,34 @@ class RacingEnv:
         s = np.ascontiguousarray(steer, np.float32).reshape(self.E, self.A)
         b = np.ascontiguousarray(branch, np.int32).reshape(self.E, self.A)
         self._ck(self.L.hk_set_actions(self.h, s.ctypes.data_as(C.POINTER(C.c_float)), b.ctypes.data_as(C.POINTER(C.c_int32))))
+
+    def get_actions(self):
+        s = np.zeros((self.E, self.A), np.float32)
+        b = np.zeros((self.E, self.A), np.int32)
+        self._ck(self.L.hk_get_actions(self.h, s.ctypes.data_as(C.POINTER(C.c_float)), b.ctypes.data_as(C.POINTER(C.c_int32))))
+        return s, b
+
+    # ---- RL low-level policy on device
+    def attach_policy(self, policy, agent_slots, decision_period=2):
+        """policy: hierarchicalkarting_amd.policy.Policy (e.g. Policy.from_onnx(path)); agent_slots: LowMode RL agents it
+        drives; decision_period: DecisionRequester.DecisionPeriod (2 in the reference scenes).  -> policy index"""
+        d, _keep = policy.desc()
+        slots = np.ascontiguousarray(agent_slots, np.int32)
+        rc = self.L.hk_policy_attach(self.h, C.byref(d), slots.ctypes.data_as(C.POINTER(C.c_int32)), len(slots), int(decision_period))
+        if rc < 0:
+            self._ck(rc)
+        self._policies = getattr(self, "_policies", []) + [policy]
+        return rc
+
+    def policy_forward(self, index, obs):
+        """the actor alone on stacked observations [rows, in_dim] -> (mu [rows], logits [rows, n_branch])"""
+        pol = self._policies[index]
+        obs = np.ascontiguousarray(obs, np.float32).reshape(-1, pol.in_dim)
+        mu = np.zeros(obs.shape[0], np.float32)
+        lg = np.zeros((obs.shape[0], pol.n_branch), np.float32)
+        fp = C.POINTER(C.c_float)
+        self._ck(self.L.hk_policy_forward(self.h, int(index), obs.shape[0], obs.ctypes.data_as(fp), mu.ctypes.data_as(fp), lg.ctypes.data_as(fp)))
+        return mu, lg
 
     def lq_debug(self, env, ego):
         d = _lib.LqDebug()

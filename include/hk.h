@@ -228,11 +228,59 @@ void* hk_device_agents_ptr(hk_handle h);   /* hk_agent_state[E][A] on device */
 void* hk_stream(hk_handle h);              /* hipStream_t the handle launches on */
 int hk_synchronize(hk_handle h);
 
+/* ---- RL low-level policy inference on device ---------------------------------------------------------
+ * Replaces the Barracuda execution of the ML-Agents 2.0.1 PPO actor that drives LowMode == RL agents
+ * (BehaviorParameters.Model -> Agent.OnActionReceived KA:440 -> InterpretDiscreteActions HKA:1371-1379).  The network
+ * is what mlagents-learn exports (the .onnx files under Assets/Karting/Prefabs/AI/, graph probed with
+ * tools/onnx_read.py):  x = clip((obs - mean) / std, -5, 5);  n_layers x { x = swish(W x + b) };
+ * mu = W_mu x + b_mu;  logits = W_br x + b_br;
+ *   continuous_actions[0] = clip(mu + eps * exp(log_sigma), -3, 3) / 3,  eps ~ N(0,1)   (deterministic: eps = 0)
+ *   discrete_actions[0]   ~ Categorical(softmax(logits))                                (deterministic: argmax)
+ * obs = the agent's last `stack` CollectObservations vectors, oldest first, zero-filled after an episode reset
+ * (ML-Agents StackingSensor).  A decision is taken on every tick t of the handle with t % decision_period == 0
+ * (DecisionRequester, scene override DecisionPeriod = 2) and the action is repeated in between (TakeActionsBetweenDecisions).
+ * Barracuda's random stream is not reproducible outside Unity: eps and the categorical draw come from Philox-4x32
+ * keyed by `seed` (counter = decision index, row) instead — "parity unpinned" for the sampled outputs, exact for mu/logits.
+ * All arithmetic is fp32: the GEMMs run on the f32-input MFMA, whose result is bit-for-bit a k-ascending fmaf chain
+ * seeded with the bias, which is what the CPU oracle computes. */
+#define HK_MAX_POLICIES 4
+#define HK_POLICY_MAX_LAYERS 4
+#define HK_POLICY_MAX_IN 1280     /* obs_dim * stack; HierarchicalKartAgent models: 216 (A = 2), 312 (A = 4), 624 (A = 4, stack 8) */
+#define HK_POLICY_MAX_HIDDEN 256
+
+typedef struct hk_policy_desc {
+    int32_t in_dim;            /* obs_dim * stack; even */
+    int32_t stack;             /* NumStackedVectorObservations (4) */
+    int32_t hidden;            /* 32..256, multiple of 32 */
+    int32_t n_layers;          /* 1..HK_POLICY_MAX_LAYERS */
+    int32_t n_branch;          /* size of discrete branch 0 (3: brake / coast / accelerate) */
+    int32_t normalize;         /* 1: apply (obs - mean) / std and the +-5 clip */
+    int32_t deterministic;     /* 1: deterministic_continuous_actions / deterministic_discrete_actions */
+    uint32_t seed;
+    const float* norm_mean;    /* [in_dim] */
+    const float* norm_std;     /* [in_dim] the exported divisor sqrt(variance / steps) */
+    const float* W[HK_POLICY_MAX_LAYERS];  /* [hidden][k] row-major (torch Linear.weight); k = in_dim for layer 0, else hidden */
+    const float* b[HK_POLICY_MAX_LAYERS];  /* [hidden] */
+    const float* W_mu;         /* [hidden] */
+    const float* b_mu;         /* [1] */
+    const float* log_sigma;    /* [1] */
+    const float* W_branch;     /* [n_branch][hidden] */
+    const float* b_branch;     /* [n_branch] */
+} hk_policy_desc;
+
+/* Upload a policy and bind it to the agent slots listed (all must be LowMode == RL; hk_obs_dim * stack must equal
+ * in_dim).  Returns the policy index (>= 0) or a negative hk_status.  decision_period is per handle (last call wins). */
+int hk_policy_attach(hk_handle h, const hk_policy_desc* desc, const int32_t* agent_slots, int n_slots, int decision_period);
+/* The MLP alone on caller-supplied stacked observations (host pointers): mu[rows], logits[rows][n_branch]. */
+int hk_policy_forward(hk_handle h, int policy, int rows, const float* obs /*[rows][in_dim]*/, float* mu, float* logits);
+/* The actions currently latched for every agent (what the policies / hk_set_actions wrote): steer[E][A], branch[E][A] */
+int hk_get_actions(hk_handle h, float* steer, int32_t* branch);
+
 /* timing taps for bench.py's roofline object: accumulated HIP-event time (ms) and launch count per kernel stage since
  * the last hk_prof_reset.  Stages: [0] env_run_kernel (the fused tick kernel), [1] the lqn_kernel<2,3,4> launches of a
- * round (one bracket), [2] lq_batch_kernel.  Event pairs are recorded on the handle's own stream around every launch
+ * round (one bracket), [2] lq_batch_kernel, [3] policy_mlp_kernel.  Event pairs are recorded on the handle's own stream around every launch
  * (no host sync per launch) and folded when read. */
-#define HK_PROF_STAGES 3
+#define HK_PROF_STAGES 4
 int hk_prof_enable(hk_handle h, int on);
 int hk_prof_reset(hk_handle h);
 int hk_prof_read(hk_handle h, double* ms /*[HK_PROF_STAGES]*/, int64_t* launches /*[HK_PROF_STAGES]*/);

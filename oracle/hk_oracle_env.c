@@ -18,6 +18,7 @@
 #include <math.h>
 #include "hk_oracle.h"
 #include "../include/hk_detmath.h"
+#include "hk_oracle_internal.h"
 
 enum { XI = 0, ZI = 1, VI = 2, HI = 3 };
 
@@ -31,31 +32,6 @@ enum { XI = 0, ZI = 1, VI = 2, HI = 3 };
 #define CAP_CENTER_LY 0.582f         /* capsule centre height above the kart origin */
 #define TRIG_HX 5.0f                 /* Trigger box half extents (10 x 1 x 1) */
 #define TRIG_HZ 0.5f
-
-typedef struct {
-    float fx, fz;     /* forward = (sin yaw, cos yaw) */
-    float yaw_rad;
-} sec_pre;
-
-struct hko_env {
-    hk_config cfg;
-    hk_section* sec;
-    sec_pre* sp;
-    hk_wall_seg* walls;
-    int E, A, L, NW;
-    hk_agent_state* ag;    /* [E][A] */
-    hk_env_state* es;      /* [E] */
-    hk_episode_result* res;/* [E][A] */
-    hk_lq_debug* dbg;      /* [E][A] */
-    float* act_steer;      /* [E][A] */
-    int32_t* act_branch;
-    float init_acc_ang_v;
-    float max_speed;       /* ArcadeKart.GetMaxSpeed AK:210 */
-    int nperm;
-    int* perms;            /* [A!][A] lexicographic (REC:137-145,166) */
-    float ray_agent_r;     /* stadium radius of a kart capsule sliced at the sensor height */
-    float sens_c[HK_NUM_SENSORS], sens_s[HK_NUM_SENSORS];   /* cos / sin of the sensors' local yaw */
-};
 
 /* ------------------------------------------------------------------ small float helpers */
 static inline float f_min(float a, float b) { return a < b ? a : b; }
@@ -240,20 +216,6 @@ static inline void kart_core(const hk_agent_state* k, float px, float pz, float*
     *ax = px + KART_CAP_Z0 * fx; *az = pz + KART_CAP_Z0 * fz;
     *bx = px + KART_CAP_Z1 * fx; *bz = pz + KART_CAP_Z1 * fz;
 }
-
-/* ------------------------------------------------------------------ Philox-4x32-10 (synthetic start jitter) */
-static void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
-{
-    for (int r = 0; r < 10; r++) {
-        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-static inline float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
 /* ------------------------------------------------------------------ plans */
 /* HKA.planFixed :145-166 */
@@ -1077,6 +1039,7 @@ void hko_destroy(hko_env* e)
 {
     if (!e) return;
     free(e->sec); free(e->sp); free(e->walls); free(e->ag); free(e->es); free(e->res); free(e->dbg);
+    hko_policy_free(e);
     free(e->act_steer); free(e->act_branch); free(e->perms); free(e);
 }
 
@@ -1092,6 +1055,7 @@ int hko_reset(hko_env* e, const int32_t* env_ids, int n, int experiment_num)
         e->es[env].status = 0;
         e->es[env].initial_started = 1;
         reset_env(e, env);
+        hko_policy_invalidate(e, env);
     }
     return 0;
 }
@@ -1099,9 +1063,20 @@ int hko_reset(hko_env* e, const int32_t* env_ids, int n, int experiment_num)
 int hko_step(hko_env* e, int n_ticks)
 {
     if (!e || n_ticks < 0) return HK_ERR_INVALID;
+    if (e->n_policies == 0) {
 #pragma omp parallel for schedule(dynamic, 8)
-    for (int env = 0; env < e->E; env++)
-        for (int t = 0; t < n_ticks; t++) step_env(e, env);
+        for (int env = 0; env < e->E; env++)
+            for (int t = 0; t < n_ticks; t++) step_env(e, env);
+        e->academy_step += n_ticks;
+        return 0;
+    }
+    /* with policies attached the Academy steps first in every tick (decision -> OnActionReceived), then the scripts */
+    for (int t = 0; t < n_ticks; t++) {
+        hko_policy_decide(e);
+#pragma omp parallel for schedule(dynamic, 8)
+        for (int env = 0; env < e->E; env++) step_env(e, env);
+        e->academy_step += 1;
+    }
     return 0;
 }
 
@@ -1145,17 +1120,19 @@ static float local_speed(const hko_env* e, const hk_agent_state* a)
     return 0.0f;
 }
 
-int hko_get_observations(hko_env* e, float* obs)
+int hko_obs_dim(const hko_env* e) { return HK_NUM_SENSORS + e->cfg.section_horizon * 5 + 8 + 12 * (e->A - 1); }   /* HKA:424 */
+
+void hko_observe_env(hko_env* e, int env, float* obs)
 {
     const hk_config* cfg = &e->cfg;
     const int A = e->A, L = e->L, H = cfg->section_horizon;
-    const int dim = HK_NUM_SENSORS + H * 5 + 8 + 12 * (A - 1);
+    const int dim = hko_obs_dim(e);
     const int goal = cfg->laps * L + 1;
-    for (int env = 0; env < e->E; env++) {
-        hk_agent_state* ags = &e->ag[(size_t)env * A];
+    {
+        const hk_agent_state* ags = &e->ag[(size_t)env * A];
         for (int i = 0; i < A; i++) {
             const hk_agent_state* a = &ags[i];
-            float* o = obs + ((size_t)env * A + i) * dim;
+            float* o = obs + (size_t)i * dim;
             int p = 0;
             o[p++] = local_speed(e, a);                                                 /* :489 */
             o[p++] = (a->flags & HK_F_ACCEL) ? 1.0f : 0.0f;                             /* :490 bool -> 1/0 */
@@ -1209,5 +1186,11 @@ int hko_get_observations(hko_env* e, float* obs)
             }
         }
     }
+}
+
+int hko_get_observations(hko_env* e, float* obs)
+{
+    const int dim = hko_obs_dim(e);
+    for (int env = 0; env < e->E; env++) hko_observe_env(e, env, obs + (size_t)env * e->A * dim);
     return 0;
 }

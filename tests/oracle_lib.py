@@ -105,6 +105,13 @@ def _env_api():
         L.hko_debug_last_game.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(HL.LqDebug)]
         L.hko_raycast_track.restype = C.c_float
         L.hko_raycast_track.argtypes = [C.c_void_p] + [C.c_float] * 5
+        fp = C.POINTER(C.c_float)
+        L.hko_policy_attach.restype = C.c_int
+        L.hko_policy_attach.argtypes = [C.c_void_p, C.POINTER(HL.PolicyDesc), C.POINTER(C.c_int32), C.c_int, C.c_int]
+        L.hko_policy_forward.restype = C.c_int
+        L.hko_policy_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, fp, fp, fp]
+        L.hko_get_actions.restype = C.c_int
+        L.hko_get_actions.argtypes = [C.c_void_p, fp, C.POINTER(C.c_int32)]
         L._env_bound = True
     return L
 
@@ -175,6 +182,27 @@ class OracleEnv:
     def set_actions(self, steer, branch):
         s = np.ascontiguousarray(steer, np.float32); b = np.ascontiguousarray(branch, np.int32)
         self.L.hko_set_actions(self.h, s.ctypes.data_as(C.POINTER(C.c_float)), b.ctypes.data_as(C.POINTER(C.c_int32)))
+
+    def get_actions(self):
+        s = np.zeros((self.E, self.A), np.float32); b = np.zeros((self.E, self.A), np.int32)
+        self.L.hko_get_actions(self.h, s.ctypes.data_as(C.POINTER(C.c_float)), b.ctypes.data_as(C.POINTER(C.c_int32)))
+        return s, b
+
+    def attach_policy(self, policy, agent_slots, decision_period=2):
+        d, _keep = policy.desc()
+        slots = np.ascontiguousarray(agent_slots, np.int32)
+        rc = self.L.hko_policy_attach(self.h, C.byref(d), slots.ctypes.data_as(C.POINTER(C.c_int32)), len(slots), decision_period)
+        assert rc >= 0, rc
+        self._policies = getattr(self, "_policies", []) + [policy]
+        return rc
+
+    def policy_forward(self, index, obs):
+        pol = self._policies[index]
+        obs = np.ascontiguousarray(obs, np.float32).reshape(-1, pol.in_dim)
+        mu = np.zeros(obs.shape[0], np.float32); lg = np.zeros((obs.shape[0], pol.n_branch), np.float32)
+        fp = C.POINTER(C.c_float)
+        assert self.L.hko_policy_forward(self.h, index, obs.shape[0], obs.ctypes.data_as(fp), mu.ctypes.data_as(fp), lg.ctypes.data_as(fp)) == 0
+        return mu, lg
 
     def lq_debug(self, env, ego):
         d = HL.LqDebug()
