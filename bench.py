@@ -41,6 +41,68 @@ def cpu_baseline(num_agents, warmup, seed):
             "sample": "CPU oracle (C port of the reference C#), %d envs x %d ticks after %d warmup ticks, OpenMP over envs" % (E, ticks, warmup)}
 
 
+FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32-input MFMA = the fp32 vector rate
+
+
+def bench_rl(a, rank, local_rank, world, dist, torch, hk):
+    """2v2 Oval, every agent LowMode RL (HighMode Fixed): per 2-tick decision the actor of the reference's
+    HierarchicalAgent-Team-*scaledown* models (312 -> 256 x 3 Swish -> {mu, 3 logits}; random-init weights of that
+    architecture) runs on device for all E x 4 agents.  One JSON line, roofline of policy_mlp_kernel against the f32 MFMA."""
+    from hierarchicalkarting_amd import _lib
+    from hierarchicalkarting_amd.policy import Policy
+    E = a.envs_per_gpu
+    A = 4
+    env = hk.RacingEnv(hk.make_config(E, A, low_mode=[_lib.HK_LOW_RL] * A, jitter_seed=0x5EED0000, env_id_base=rank * E, device_id=local_rank))
+    in_dim = env.obs_dim * 4
+    p1 = Policy.random(in_dim, 256, 3, seed=101)
+    p2 = Policy.random(in_dim, 256, 3, seed=202)
+    env.attach_policy(p1, [0, 1], 2)
+    env.attach_policy(p2, [2, 3], 2)
+    env.reset()
+    env.step(a.warmup)
+    env.synchronize()
+
+    def barrier():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        env.synchronize()
+
+    env.prof_enable(True)
+    env.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    env.step(a.steps)
+    env.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = env.prof_read()
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        avg = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in prof.items()}
+        rows = E * 2                                   # rows per launch (one launch per team policy)
+        flop_row = 2.0 * (in_dim * 256 + 2 * 256 * 256 + 4 * 256)
+        ms = avg["policy_mlp_kernel"]
+        ach = rows * flop_row / 1e12 / (ms * 1e-3) if ms > 0 else 0.0
+        out = {"metric": "env-steps/sec (2v2 Oval, RL low-level on device)", "value": E * world * a.steps / dt, "unit": "env-steps/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "2v2 Oval, 4 agents LowMode RL / HighMode Fixed, %d envs per GPU, DecisionPeriod 2, one actor per team "
+                                      "(%d -> 256 x 3 Swish -> mu + 3 logits, random-init weights of the reference architecture)" % (E, in_dim),
+                          "envs_per_gpu": E, "agents": A},
+               "roofline": {"bound": "mfma", "kernel": "policy_mlp_kernel", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms, "launches": prof["policy_mlp_kernel"][1],
+                            "flop_per_launch": rows * flop_row, "kernel_avg_ms": avg,
+                            "kernel_total_ms": {k: v[0] for k, v in prof.items()}}}
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -50,6 +112,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--agents", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=("lqng", "rl"), default="lqng",
+                    help="lqng: BASELINE.json configs[1] (the headline); rl: 2v2 Oval with the RL low-level actor on device (configs[3] shape)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -73,6 +137,8 @@ def main():
     import hierarchicalkarting_amd as hk
     from hierarchicalkarting_amd.parallel import gather_episode_results
 
+    if a.workload == "rl":
+        return bench_rl(a, rank, local_rank, world, dist, torch, hk)
     E = a.envs_per_gpu
     seed = 0x5EED0000
     env = hk.RacingEnv(hk.make_config(E, a.agents, jitter_seed=seed, env_id_base=rank * E, device_id=local_rank))

@@ -4,14 +4,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhk.so")
+LIB_PATH = os.environ.get("HK_LIB_PATH") or os.path.join(_HERE, "libhk.so")   # HK_LIB_PATH: kernel-variant experiments (tools/)
 
 HK_MAX_AGENTS = 8
 HK_MAX_SECTIONS = 64
 HK_NUM_SENSORS = 9
 HK_ABI_VERSION = 1
-HK_PROF_STAGES = 4
-PROF_STAGE_NAMES = ("env_run_kernel", "lqn_kernel<2,3,4>", "lq_batch_kernel", "policy_mlp_kernel")
+HK_PROF_STAGES = 5
+PROF_STAGE_NAMES = ("env_run_kernel", "lqn_kernel<2,3,4>", "lq_batch_kernel", "policy_mlp_kernel", "observe+stack")
 HK_MAX_POLICIES = 4
 HK_POLICY_MAX_LAYERS = 4
 HK_POLICY_MAX_IN = 1280

@@ -305,6 +305,7 @@ static int step_ticks(hk_handle h, int n_ticks)
 // Academy step of a decision tick: CollectObservations -> StackingSensor -> actor -> OnActionReceived latch
 static int policy_decide(hk_handle h)
 {
+    hipEvent_t eo = h->prof.begin(h->stream);
     int rc = hk::env_launch_observe(h->dev, h->cfg, h->stream, h->err);
     if (rc) { g_last_error = h->err; return rc; }
     const unsigned long long decision = (unsigned long long)(h->academy_step / h->decision_period);
@@ -316,6 +317,12 @@ static int policy_decide(hk_handle h)
         hipLaunchKernelGGL(hk::policy_stack_kernel, dim3((pairs + 1) / 2), dim3(256), 0, h->stream, pd.q, E, A, h->dev.envs,
                            h->dev.obs, w);
         HK_HIP(h, hipGetLastError());
+    }
+    h->prof.end(4, eo, h->stream);
+    for (int p = 0; p < h->n_policies; p++) {
+        const hk::PolicyDevice& pd = h->policy[p];
+        const int pairs = E * pd.q.n_slots;
+        const int w = (int)(decision % (unsigned long long)pd.q.stack);
         hipEvent_t e = h->prof.begin(h->stream);
         rc = hk::policy_launch_mlp(pd, pairs, pd.q.ring, w, decision, h->cfg.env_id_base, A, nullptr, nullptr, h->dev.act_steer,
                                    h->dev.act_branch, h->stream, h->err);

@@ -1,6 +1,6 @@
 // hk_env_observe.h — HierarchicalKartAgent.CollectObservations (HKA:485-604): one thread per (env, agent).
 // Layout = the order the reference calls sensor.AddObservation: 8 own, 12 per teammate, 12 per opponent,
-// 5 per upcoming section (sectionHorizon), 9 ray distances.  Rays here are 20 m long, so they scan every wall.
+// 5 per upcoming section (sectionHorizon), 9 ray distances (up to 20 m long: walked through the wall grid).
 #pragma once
 #include "hk_env_device.h"
 
@@ -85,20 +85,40 @@ __global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_
     }
     const float fx = hk_sinf(a->yaw), fz = hk_cosf(a->yaw);
     const float ox = a->px + SENSOR_LZ * fx, oz = a->pz + SENSOR_LZ * fz;
+    // the other karts' forward vectors, once (not per sensor)
+    float bfx[HK_MAX_AGENTS], bfz[HK_MAX_AGENTS];
+    const bool see = (a->flags & HK_F_ENABLED) != 0;
+    for (int j = 0; j < A; j++) {
+        bfx[j] = 0.0f; bfz[j] = 0.0f;
+        if (see && j != i && (ags[j].flags & HK_F_ENABLED)) { bfx[j] = hk_sinf(ags[j].yaw); bfz[j] = hk_cosf(ags[j].yaw); }
+    }
     for (int si = 0; si < HK_NUM_SENSORS; si++) {
         float dx, dz;
         sensor_dir(P, si, fx, fz, dx, dz);
         const float maxd = P.ray_dist[si];
+        // Physics.Raycast vs TrackMask through the wall grid: a hit at distance t lies within 1 m of one of the samples
+        // o + {0, 2, 4, ...} d, whose cells list every wall within GRID_REACH (2.2 m) of them; once the samples up to
+        // distance sd are done, every hit with t <= sd + 1 has been seen, so a best hit that near is final.  The lists
+        // are supersets and the minimum over them is what a scan of every wall (the oracle) returns.
         float ht = -1.0f;
-        for (int w = 0; w < P.NW; w++) {
-            float t = ray_seg(ox, oz, dx, dz, T.walls[w]);
-            if (t >= 0.0f && t <= maxd && (ht < 0.0f || t < ht)) ht = t;
+        int prev = -1;
+        for (float sd = 0.0f; sd < maxd + 1.0f; sd += GRID_CELL) {
+            const int cell = grid_cell(P, ox + dx * sd, oz + dz * sd);
+            if (cell != prev) {
+                prev = cell;
+                const int w0 = T.grid_off[cell], w1 = T.grid_off[cell + 1];
+                for (int q = w0; q < w1; q++) {
+                    float t = ray_seg(ox, oz, dx, dz, T.walls[T.grid_idx[q]]);
+                    if (t >= 0.0f && t <= maxd && (ht < 0.0f || t < ht)) ht = t;
+                }
+            }
+            if (ht >= 0.0f && ht <= sd + 1.0f) break;
         }
         float ha = -1.0f;
-        if (a->flags & HK_F_ENABLED) {
+        if (see) {
             for (int j = 0; j < A; j++) {
                 if (j == i || !(ags[j].flags & HK_F_ENABLED)) continue;
-                float t = ray_stadium(ox, oz, dx, dz, ags[j].px, ags[j].pz, hk_sinf(ags[j].yaw), hk_cosf(ags[j].yaw), P.ray_agent_r);
+                float t = ray_stadium(ox, oz, dx, dz, ags[j].px, ags[j].pz, bfx[j], bfz[j], P.ray_agent_r);
                 if (t >= 0.0f && t <= maxd && (ha < 0.0f || t < ha)) ha = t;
             }
         }

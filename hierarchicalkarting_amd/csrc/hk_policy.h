@@ -9,7 +9,8 @@
 // activations live TRANSPOSED in LDS (At[k][row], row stride 65 floats: conflict-free for the column writes of the loader
 // and of the layer epilogue, and for the 32-consecutive-row reads of the MFMA A operand) and are overwritten in place
 // layer by layer (the first layer streams its inputs through in chunks of <= 320, so stacks of 8 observations fit); weights are pre-transposed once at attach time (Wt[k][out]) so the MFMA B operand is a coalesced
-// 128-byte read per half-wave straight from L2 (all layers together are <= 0.6 MB).  The GEMMs run on the f32-input
+// 128-byte read per half-wave straight from L2 (all layers together are <= 0.6 MB).  At 66.5 KB of LDS and <= 128 VGPRs
+// two workgroups share a CU, so one's loader / Swish epilogue / barriers overlap the other's matrix work.  The GEMMs run on the f32-input
 // matrix instruction v_mfma_f32_32x32x2_f32: a 64 x H layer is (H/32) x 2 blocks of 32 x 32, two per wave at H = 256.
 // Its result is bit-for-bit a k-ascending fmaf chain seeded with the accumulator input, which we seed with the bias —
 // exactly the chain the CPU oracle evaluates, so mu / logits agree bit for bit.  The two heads (1 + n_branch outputs)
@@ -28,7 +29,8 @@ constexpr int PM_TILE = 64;                 // rows per workgroup
 constexpr int PM_LD = PM_TILE + 1;          // LDS row stride of At (floats)
 constexpr int PM_THREADS = 512;
 constexpr int PM_MAX_OUT = 8;               // 1 + n_branch
-constexpr int PM_KC_MAX = 320;              // 320 x 65 floats = 83 KB of LDS
+constexpr int PM_TRIP = 4;                  // k-steps per operand set of the gemm's ping-pong (8 spills at 128 VGPRs)
+constexpr int PM_KC_MAX = 256;              // 256 x 65 floats = 66.5 KB of LDS: two workgroups per CU
 
 struct PolicyParams {
     int in_dim, obs_dim, stack, hidden, n_layers, n_branch, normalize, deterministic;
@@ -93,20 +95,74 @@ __global__ __launch_bounds__(256) void policy_invalidate_kernel(PolicyParams Q, 
 
 __device__ inline float swish(float s)
 {   // Sigmoid then Mul in the exported graph
-    const float sg = 1.0f / (1.0f + hk_expf(-s));
+    const float sg = 1.0f / (1.0f + hk_expf_fast(-s));
     return s * sg;
+}
+
+// One wave's share of a layer over kc inputs: acc0 (+ acc1 when HAS1) += A[32 rows][kc] * B[kc][32 cols], as MFMA
+// 32x32x2 f32 steps in ascending k.  a?p / b?p already point at this lane's first element (A from LDS, row stride PM_LD
+// per k; B from global, row stride H per k); SAMEB: both blocks use the same B columns (H = 256).
+// 8 k-steps (16 inputs) per trip with ping-pong operand sets: while the 8 / 16 MFMAs of one trip issue, the loads of the
+// next trip are in flight; then the remainder (kc % 16 inputs) one k-step at a time.
+template <bool HAS1, bool SAMEB>
+__device__ __forceinline__ void pm_gemm(f32x16& acc0, f32x16& acc1, const float* a0p, const float* a1p,
+                                        const float* __restrict__ b0p, const float* __restrict__ b1p, int kc, int H)
+{
+    auto ld = [&](int k0, float (&B0)[PM_TRIP], float (&B1)[PM_TRIP], float (&A0)[PM_TRIP], float (&A1)[PM_TRIP]) {
+#pragma unroll
+        for (int j = 0; j < PM_TRIP; j++) {
+            B0[j] = b0p[(size_t)(k0 + 2 * j) * H];
+            A0[j] = a0p[(size_t)(k0 + 2 * j) * PM_LD];
+            if (HAS1) {
+                A1[j] = a1p[(size_t)(k0 + 2 * j) * PM_LD];
+                if (!SAMEB) B1[j] = b1p[(size_t)(k0 + 2 * j) * H];
+            }
+        }
+    };
+    auto mm = [&](float (&B0)[PM_TRIP], float (&B1)[PM_TRIP], float (&A0)[PM_TRIP], float (&A1)[PM_TRIP]) {
+#pragma unroll
+        for (int j = 0; j < PM_TRIP; j++) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[j], B0[j], acc0, 0, 0, 0);
+            if (HAS1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[j], SAMEB ? B0[j] : B1[j], acc1, 0, 0, 0);
+        }
+    };
+    const int kfull = kc - kc % (2 * PM_TRIP);
+    if (kfull > 0) {
+        float pB0[PM_TRIP], pB1[PM_TRIP], pA0[PM_TRIP], pA1[PM_TRIP], qB0[PM_TRIP], qB1[PM_TRIP], qA0[PM_TRIP], qA1[PM_TRIP];
+        ld(0, pB0, pB1, pA0, pA1);
+        int k0 = 0;
+        while (true) {
+            if (k0 + 2 * PM_TRIP < kfull) ld(k0 + 2 * PM_TRIP, qB0, qB1, qA0, qA1);
+            mm(pB0, pB1, pA0, pA1);
+            k0 += 2 * PM_TRIP;
+            if (k0 >= kfull) break;
+            if (k0 + 2 * PM_TRIP < kfull) ld(k0 + 2 * PM_TRIP, pB0, pB1, pA0, pA1);
+            mm(qB0, qB1, qA0, qA1);
+            k0 += 2 * PM_TRIP;
+            if (k0 >= kfull) break;
+        }
+    }
+    for (int k0 = kfull; k0 < kc; k0 += 2) {
+        const float bv0 = b0p[(size_t)k0 * H];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0p[(size_t)k0 * PM_LD], bv0, acc0, 0, 0, 0);
+        if (HAS1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1p[(size_t)k0 * PM_LD], SAMEB ? bv0 : b1p[(size_t)k0 * H], acc1, 0, 0, 0);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // src: [rows][in_dim]; logical element k of a row lives at ((w + 1 + k / obs_dim) % stack) * obs_dim + k % obs_dim
 // (w = stack - 1 for plain oldest-first rows).  Outputs: mu_out / logit_out when non-null; act_steer / act_branch
 // (indexed [env][agent], row = env * n_slots + j) when non-null.
-__global__ __launch_bounds__(PM_THREADS, 1) void policy_mlp_kernel(PolicyParams Q, int rows, const float* src, int w,
+// MODE: how the (H / 32) x 2 blocks of a layer fall on the 8 waves — 0: one block per wave (H <= 128), 1: two blocks per
+// wave sharing their B columns (H = 256), 2: mixed (other H), decided per wave.
+template <int MODE>
+__global__ __launch_bounds__(PM_THREADS, 4) void policy_mlp_kernel(PolicyParams Q, int rows, const float* src, int w,
                                                                    unsigned long long decision, int env_id_base, int A,
                                                                    float* mu_out, float* logit_out, float* act_steer, int* act_branch)
 {
     extern __shared__ __align__(16) float At[];        // [max(kc, hidden)][PM_LD] then head[PM_MAX_OUT][PM_TILE]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: block / unit selection stays scalar
     const int row0 = blockIdx.x * PM_TILE;
     const int K0 = Q.in_dim, H = Q.hidden, KC = Q.kc;
     float* head = At + (size_t)(KC > H ? KC : H) * PM_LD;
@@ -116,7 +172,7 @@ __global__ __launch_bounds__(PM_THREADS, 1) void policy_mlp_kernel(PolicyParams 
     const int nunits = ncb * 2;
     const int half = lane >> 5, c = lane & 31;
     const int u0 = wave, u1 = wave + 8;
-    const bool has0 = u0 < nunits, has1 = u1 < nunits;
+    const bool has0 = u0 < nunits, has1 = MODE == 0 ? false : (MODE == 1 ? true : u1 < nunits);
     const int cb0 = u0 % ncb, rb0 = u0 / ncb;
     const int cb1 = has1 ? u1 % ncb : cb0, rb1 = has1 ? u1 / ncb : rb0;
     const float* a0p = At + (size_t)half * PM_LD + rb0 * 32 + c;
@@ -137,20 +193,38 @@ __global__ __launch_bounds__(PM_THREADS, 1) void policy_mlp_kernel(PolicyParams 
             const int kc = (K - kb) < KC ? (K - kb) : KC;
             if (l == 0) {
                 if (kb > 0) __syncthreads();                      // the previous chunk has been consumed
-                // ---- load + normalise the tile chunk, transposed
-                for (int idx = tid; idx < PM_TILE * kc; idx += PM_THREADS) {
-                    const int r = idx / kc, k = kb + idx - r * kc;
-                    float v = 0.0f;
-                    if (row0 + r < rows) {
+                // ---- load + normalise the tile chunk, transposed.  Lanes run over k (coalesced reads, conflict-free
+                // LDS column writes), waves over rows; the per-k constants (ring offset, mean, std) are set up once.
+                constexpr int MMAX = (PM_KC_MAX + 63) / 64;
+                int soff[MMAX];
+                float mean[MMAX], sdev[MMAX];
+#pragma unroll
+                for (int m = 0; m < MMAX; m++) {
+                    const int kl = lane + 64 * m, k = kb + kl;
+                    soff[m] = -1; mean[m] = 0.0f; sdev[m] = 1.0f;
+                    if (kl < kc) {
                         const int i = k / Q.obs_dim, kk = k - i * Q.obs_dim;
                         int slot = w + 1 + i; slot -= (slot >= Q.stack) ? Q.stack : 0;
-                        v = src[(size_t)(row0 + r) * K0 + (size_t)slot * Q.obs_dim + kk];
-                        if (Q.normalize) {
-                            v = (v - Q.mean[k]) / Q.std[k];
-                            v = v < -5.0f ? -5.0f : (v > 5.0f ? 5.0f : v);
-                        }
+                        soff[m] = slot * Q.obs_dim + kk;
+                        if (Q.normalize) { mean[m] = Q.mean[k]; sdev[m] = Q.std[k]; }
                     }
-                    At[(size_t)(k - kb) * PM_LD + r] = v;
+                }
+                for (int r = wave; r < PM_TILE; r += PM_THREADS / 64) {
+                    const bool rowok = row0 + r < rows;
+                    const float* srow = src + (size_t)(row0 + r) * K0;
+                    float v[MMAX];
+#pragma unroll
+                    for (int m = 0; m < MMAX; m++) v[m] = (rowok && soff[m] >= 0) ? srow[soff[m]] : 0.0f;
+#pragma unroll
+                    for (int m = 0; m < MMAX; m++) {
+                        if (soff[m] < 0) continue;
+                        float x = v[m];
+                        if (Q.normalize && rowok) {
+                            x = (x - mean[m]) / sdev[m];
+                            x = x < -5.0f ? -5.0f : (x > 5.0f ? 5.0f : x);
+                        }
+                        At[(size_t)(lane + 64 * m) * PM_LD + r] = x;
+                    }
                 }
                 __syncthreads();
             }
@@ -158,38 +232,16 @@ __global__ __launch_bounds__(PM_THREADS, 1) void policy_mlp_kernel(PolicyParams 
                 const float* __restrict__ Wt = Q.Wt[l] + (size_t)kb * H;
                 const float* b0p = Wt + (size_t)half * H + cb0 * 32 + c;
                 const float* b1p = Wt + (size_t)half * H + cb1 * 32 + c;
-                if (has1 && cb1 == cb0) {
-                    // H = 256: both blocks of this wave share the B operand
-#pragma unroll 8
-                    for (int k0 = 0; k0 < kc; k0 += 2) {
-                        const float bv = b0p[(size_t)k0 * H];
-                        const float av0 = a0p[(size_t)k0 * PM_LD];
-                        const float av1 = a1p[(size_t)k0 * PM_LD];
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv, acc1, 0, 0, 0);
-                    }
-                } else if (has1) {
-#pragma unroll 8
-                    for (int k0 = 0; k0 < kc; k0 += 2) {
-                        const float bv0 = b0p[(size_t)k0 * H], bv1 = b1p[(size_t)k0 * H];
-                        const float av0 = a0p[(size_t)k0 * PM_LD];
-                        const float av1 = a1p[(size_t)k0 * PM_LD];
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1, acc1, 0, 0, 0);
-                    }
-                } else {
-#pragma unroll 8
-                    for (int k0 = 0; k0 < kc; k0 += 2) {
-                        const float bv = b0p[(size_t)k0 * H];
-                        const float av0 = a0p[(size_t)k0 * PM_LD];
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv, acc0, 0, 0, 0);
-                    }
-                }
+                if (MODE == 0) pm_gemm<false, false>(acc0, acc1, a0p, a1p, b0p, b1p, kc, H);
+                else if (MODE == 1) pm_gemm<true, true>(acc0, acc1, a0p, a1p, b0p, b1p, kc, H);
+                else if (!has1) pm_gemm<false, false>(acc0, acc1, a0p, a1p, b0p, b1p, kc, H);
+                else if (cb1 == cb0) pm_gemm<true, true>(acc0, acc1, a0p, a1p, b0p, b1p, kc, H);
+                else pm_gemm<true, false>(acc0, acc1, a0p, a1p, b0p, b1p, kc, H);
             }
         }
         if (has0) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) { acc0[r] = swish(acc0[r]); if (has1) acc1[r] = swish(acc1[r]); }
+            for (int r = 0; r < 16; r++) { acc0[r] = swish(acc0[r]); if (MODE != 0 && has1) acc1[r] = swish(acc1[r]); }
         }
         __syncthreads();            // every wave has finished reading this layer's input
         if (has0) {
@@ -198,7 +250,7 @@ __global__ __launch_bounds__(PM_THREADS, 1) void policy_mlp_kernel(PolicyParams 
             for (int r = 0; r < 16; r++) {
                 const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
                 At[(size_t)(cb0 * 32 + c) * PM_LD + rb0 * 32 + rr] = acc0[r];
-                if (has1) At[(size_t)(cb1 * 32 + c) * PM_LD + rb1 * 32 + rr] = acc1[r];
+                if (MODE != 0 && has1) At[(size_t)(cb1 * 32 + c) * PM_LD + rb1 * 32 + rr] = acc1[r];
             }
         }
         __syncthreads();
@@ -350,11 +402,18 @@ inline int policy_launch_mlp(const PolicyDevice& pd, int rows, const float* src,
     const size_t lds = policy_lds_bytes(pd.q);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)policy_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)policy_mlp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)policy_mlp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)policy_mlp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(policy_mlp_kernel, dim3((rows + PM_TILE - 1) / PM_TILE), dim3(PM_THREADS), lds, stream, pd.q, rows, src, w,
-                       decision, env_id_base, A, mu_out, logit_out, act_steer, act_branch);
+    const dim3 grid((rows + PM_TILE - 1) / PM_TILE), block(PM_THREADS);
+    if (pd.q.hidden <= 128)
+        hipLaunchKernelGGL(policy_mlp_kernel<0>, grid, block, lds, stream, pd.q, rows, src, w, decision, env_id_base, A, mu_out, logit_out, act_steer, act_branch);
+    else if (pd.q.hidden == 256)
+        hipLaunchKernelGGL(policy_mlp_kernel<1>, grid, block, lds, stream, pd.q, rows, src, w, decision, env_id_base, A, mu_out, logit_out, act_steer, act_branch);
+    else
+        hipLaunchKernelGGL(policy_mlp_kernel<2>, grid, block, lds, stream, pd.q, rows, src, w, decision, env_id_base, A, mu_out, logit_out, act_steer, act_branch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("policy_mlp_kernel: ") + hipGetErrorString(e); return HK_ERR_HIP; }
     return HK_OK;

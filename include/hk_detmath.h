@@ -209,4 +209,28 @@ HK_HD float hk_atan2f(float y, float x) { return (float)hk_atan2((double)y, (dou
 HK_HD float hk_expf(float x) { return (float)hk_exp((double)x); }
 HK_HD float hk_logf(float x) { return (float)hk_log((double)x); }
 
+/* Pure-fp32 exp for the RL actor's Swish (x * 1 / (1 + exp(-x))): Cody-Waite reduction + degree-5 polynomial (the classic
+ * cephes expf scheme), every multiply-add an explicit fmaf, so the oracle (gcc) and the kernels (hipcc) agree bit for bit.
+ * <= 2 ulp of fp32 on [-87, 88] (tests/test_detmath.py); inputs are clamped to that range.  NOT used where the reference
+ * calls Math.Exp / Mathf.Exp (those go through hk_exp): the exp inside Barracuda's Sigmoid kernel is not bit-defined, so
+ * here only oracle == GPU matters. */
+HK_HD float hk_expf_fast(float x)
+{
+    x = x > 88.0f ? 88.0f : (x < -87.0f ? -87.0f : x);
+    const float fk = __builtin_rintf(x * 1.44269504f);
+    float r = __builtin_fmaf(fk, -0.693359375f, x);
+    r = __builtin_fmaf(fk, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float e = __builtin_fmaf(p, r * r, r);
+    e = e + 1.0f;
+    union { unsigned int u; float f; } sc;
+    sc.u = (unsigned int)((int)fk + 127) << 23;
+    return e * sc.f;
+}
+
 #endif /* HK_DETMATH_H */

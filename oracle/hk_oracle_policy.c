@@ -96,7 +96,7 @@ void hko_policy_invalidate(hko_env* e, int env)
 
 static inline float swish(float s)
 {   /* Sigmoid then Mul in the graph */
-    float sg = 1.0f / (1.0f + hk_expf(-s));
+    float sg = 1.0f / (1.0f + hk_expf_fast(-s));
     return s * sg;
 }
 

@@ -79,3 +79,19 @@ def test_matches_libm_within_float_rounding():
     xs = rng.uniform(-7, 7, 20000)
     diff = sum(np.float32(L.hko_sin(float(x))) != np.float32(math.sin(float(x))) for x in xs)
     assert diff <= 2
+
+
+def test_expf_fast_within_2ulp_and_saturates():
+    """the fp32 exp of the RL actor's Swish: <= 2 ulp on its clamped domain, monotone at the clamps"""
+    import ctypes as C
+    L = lib()
+    L.hko_expf_fast.restype = C.c_float
+    L.hko_expf_fast.argtypes = [C.c_float]
+    r = np.random.default_rng(0)
+    xs = np.concatenate([r.uniform(-87, 88, 20000), r.uniform(-2, 2, 20000), [0.0, -0.0, 1.0, -1.0, 88.0, -87.0]]).astype(np.float32)
+    got = np.array([L.hko_expf_fast(float(x)) for x in xs], np.float32)
+    ref = np.exp(xs.astype(np.float64))
+    ulp = np.spacing(ref.astype(np.float32)).astype(np.float64)
+    assert (np.abs(got.astype(np.float64) - ref) / ulp).max() <= 2.0
+    assert L.hko_expf_fast(1000.0) == L.hko_expf_fast(88.0) and L.hko_expf_fast(-1000.0) == L.hko_expf_fast(-87.0)
+    assert L.hko_expf_fast(0.0) == 1.0
