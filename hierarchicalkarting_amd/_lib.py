@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("HK_LIB_PATH") or os.path.join(_HERE, "libhk.so")   # 
 HK_MAX_AGENTS = 8
 HK_MAX_SECTIONS = 64
 HK_NUM_SENSORS = 9
-HK_ABI_VERSION = 1
+HK_ABI_VERSION = 2
 HK_PROF_STAGES = 5
 PROF_STAGE_NAMES = ("env_run_kernel", "lqn_kernel<2,3,4>", "lq_batch_kernel", "policy_mlp_kernel", "observe+stack")
 HK_MAX_POLICIES = 4
@@ -59,7 +59,27 @@ class Config(C.Structure):
         ("jitter_seed", C.c_uint32), ("jitter_pos", C.c_float), ("jitter_yaw", C.c_float), ("env_id_base", C.c_int32),
         ("num_sections", C.c_int32), ("num_walls", C.c_int32),
         ("sections", C.POINTER(Section)), ("walls", C.POINTER(WallSeg)),
+        ("time_precision", _I8), ("section_window", _I8), ("mcts_iterations", C.c_int32),
+        ("mcts_initial_iterations", C.c_int32), ("mcts_latency_ticks", C.c_int32), ("mcts_initial_latency_ticks", C.c_int32),
+        ("mcts_seed", C.c_uint32), ("reserved_cfg", C.c_int32 * 3),
     ]
+
+
+HK_MCTS_MAX_DEPTH = 8
+HK_MCTS_MAX_ACTIONS = 20
+_U8A = C.c_uint8 * HK_MAX_AGENTS
+
+
+class MctsPlan(C.Structure):
+    _fields_ = [("n_states", C.c_int32), ("n_players", C.c_int32), ("section", C.c_int32 * HK_MCTS_MAX_DEPTH),
+                ("player_agent", _U8A), ("lane", _U8A * HK_MCTS_MAX_DEPTH), ("vel", _U8A * HK_MCTS_MAX_DEPTH)]
+
+
+class MctsState(C.Structure):
+    _fields_ = [("sec_time", C.c_int32 * 4), ("ready_step", C.c_int32), ("searches", C.c_int32),
+                ("best", MctsPlan), ("pend", MctsPlan),
+                ("belief_lane", (C.c_uint8 * HK_MAX_SECTIONS) * HK_MAX_AGENTS),
+                ("belief_vel", (C.c_uint8 * HK_MAX_SECTIONS) * HK_MAX_AGENTS)]
 
 
 class AgentState(C.Structure):
@@ -125,6 +145,7 @@ SYMBOLS = {
     "hk_set_env_state": (C.c_int, [_H, C.POINTER(EnvState)]),
     "hk_get_episode_results": (C.c_int, [_H, C.POINTER(EpisodeResult)]),
     "hk_get_lq_debug": (C.c_int, [_H, C.c_int, C.c_int, C.POINTER(LqDebug)]),
+    "hk_get_mcts_state": (C.c_int, [_H, C.POINTER(MctsState)]),
     "hk_lq_solve_batch": (C.c_int, [_H, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp]),
     "hk_lq_solve_batch_device": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -48,7 +48,8 @@ class BuiltConfig:
 def make_config(num_envs, num_agents=4, track="oval", high_mode=_lib.HK_HIGH_FIXED, low_mode=_lib.HK_LOW_LQR,
                 tree_search_depth=5, jitter_seed=0, jitter_pos=0.5, jitter_yaw=0.05, auto_reset=1, env_id_base=0,
                 device_id=0, wiring=None, env_mode=_lib.HK_MODE_EXPERIMENT, max_episode_steps=None, laps=None,
-                stats=None):
+                stats=None, time_precision=100, section_window=2, mcts_iterations=128, mcts_initial_iterations=None,
+                mcts_latency_ticks=45, mcts_initial_latency_ticks=75, mcts_seed=0x4D435453):
     tr = load_track(track) if isinstance(track, str) else track
     secs = tr["sections"]
     L = len(secs)
@@ -89,8 +90,10 @@ def make_config(num_envs, num_agents=4, track="oval", high_mode=_lib.HK_HIGH_FIX
             cfg.other_agents[i][j] = t
         cfg.high_mode[i] = high_mode[i] if isinstance(high_mode, (list, tuple)) else high_mode
         cfg.low_mode[i] = low_mode[i] if isinstance(low_mode, (list, tuple)) else low_mode
-        cfg.tree_search_depth[i] = tree_search_depth
+        cfg.tree_search_depth[i] = tree_search_depth[i] if isinstance(tree_search_depth, (list, tuple)) else tree_search_depth
         cfg.velocity_bucket_size[i] = 2
+        cfg.time_precision[i] = time_precision
+        cfg.section_window[i] = section_window
     st = dict(KART_STATS)
     if stats:
         st.update(stats)
@@ -112,6 +115,11 @@ def make_config(num_envs, num_agents=4, track="oval", high_mode=_lib.HK_HIGH_FIX
         cfg.ray_distance[i] = RAY_DISTANCE[i]
         cfg.wall_hit_validation[i] = WALL_HIT_VALIDATION[i]
         cfg.agent_hit_validation[i] = AGENT_HIT_VALIDATION[i]
+    # MCTS planner budget: iterations stand for the reference's wall-clock T (0.9 s per replan, 1.5 s at reset)
+    cfg.mcts_iterations = int(mcts_iterations)
+    cfg.mcts_initial_iterations = int(mcts_initial_iterations if mcts_initial_iterations is not None else (mcts_iterations * 5 + 2) // 3)
+    cfg.mcts_latency_ticks, cfg.mcts_initial_latency_ticks = int(mcts_latency_ticks), int(mcts_initial_latency_ticks)
+    cfg.mcts_seed = mcts_seed
     cfg.jitter_seed = jitter_seed
     cfg.jitter_pos, cfg.jitter_yaw = jitter_pos, jitter_yaw
     cfg.env_id_base = env_id_base

@@ -502,6 +502,18 @@ int hk_get_episode_results(hk_handle h, hk_episode_result* out)
     return HK_OK;
 }
 
+int hk_get_mcts_state(hk_handle h, hk_mcts_state* out)
+{
+    HK_NEED_ENV(h);
+    if (!out) return fail(h, HK_ERR_INVALID, "NULL pointer");
+    { int rc = check_device_status(h); if (rc) return rc; }
+    const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
+    if (!h->dev.mcts.st) { std::memset(out, 0, cnt * sizeof(hk_mcts_state)); return HK_OK; }
+    HK_HIP(h, hipMemcpyAsync(out, h->dev.mcts.st, cnt * sizeof(hk_mcts_state), hipMemcpyDeviceToHost, h->stream));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    return HK_OK;
+}
+
 int hk_get_lq_debug(hk_handle h, int env, int ego, hk_lq_debug* out)
 {
     HK_NEED_ENV(h);

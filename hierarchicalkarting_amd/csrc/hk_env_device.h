@@ -27,6 +27,8 @@ struct SecDev {                         // one DiscretePositionTracker + Waypoin
     float lane_x[4], lane_z[4];
 };
 
+struct SecGeo { float track_width, track_length, turn_degrees; int left_turn; };   // DPT fields only the MCTS planner reads
+
 struct EnvParams {
     int E, A, L, NW;
     float dt, kart_y;
@@ -48,6 +50,11 @@ struct EnvParams {
     float grid_x0, grid_z0, grid_inv;   // origin and 1 / cell size
     int grid_nx, grid_nz;
     const int* perms;      // [A!][A]
+    // MCTS planner (hk_env_mcts.h)
+    const SecGeo* sec_geo; // [L]
+    int team_of[ENV_MAXA], time_precision[ENV_MAXA], section_window[ENV_MAXA];
+    int mcts_iter, mcts_iter0, mcts_lat, mcts_lat0, any_mcts;
+    uint32_t mcts_seed;
 };
 constexpr float GRID_CELL = 2.0f;       // cell size (m)
 constexpr float GRID_REACH = 2.2f;      // list radius: 2 m side rays / 1 m half-spacing of the long-ray samples / 1.11 m

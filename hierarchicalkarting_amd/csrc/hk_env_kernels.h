@@ -35,6 +35,9 @@ struct EnvDevice {
     unsigned char* tab = nullptr;  // packed track tables (EnvParams::tab)
     int* perms = nullptr;
     int tab_lds = 0;               // dynamic LDS bytes the env kernels are launched with (0: read tables from global)
+    // MCTS planner (hk_env_mcts.h): all null / 0 when no agent is HighMode MCTS
+    MctsDev mcts{};
+    SecGeo* sec_geo = nullptr;
     EnvParams P{};
 };
 
@@ -74,7 +77,8 @@ int upload(T** dst, const std::vector<T>& v, std::string& err)
 
 inline void env_destroy(EnvDevice& d)
 {
-    void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.status, d.games, d.queue_cnt, d.queue, d.env_ids, d.tab, d.perms};
+    void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.status, d.games, d.queue_cnt, d.queue, d.env_ids, d.tab, d.perms,
+                    d.mcts.st, d.mcts.req, d.mcts.queue, d.mcts.nodes, d.sec_geo};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = EnvDevice{};
 }
@@ -92,7 +96,17 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         if (cfg.n_team[i] < 0 || cfg.n_other[i] < 0 || cfg.n_team[i] + cfg.n_other[i] != A - 1) {
             err = "hk_create: teamAgents + otherAgents of every agent must list every other agent exactly once"; return HK_ERR_INVALID;
         }
-        if (cfg.high_mode[i] != HK_HIGH_FIXED) { err = "hk_create: HighMode MCTS not built yet"; return HK_ERR_UNSUPPORTED; }
+        if (cfg.high_mode[i] != HK_HIGH_FIXED && cfg.high_mode[i] != HK_HIGH_MCTS) { err = "hk_create: bad high_mode"; return HK_ERR_INVALID; }
+        if (cfg.high_mode[i] == HK_HIGH_MCTS) {
+            if (cfg.tree_search_depth[i] < 1 || cfg.tree_search_depth[i] > HK_MCTS_MAX_DEPTH || cfg.velocity_bucket_size[i] < 1 ||
+                cfg.time_precision[i] < 1 || cfg.section_window[i] < 1) { err = "hk_create: bad MCTS gameParams (depth 1..8, bucket, precision, window >= 1)"; return HK_ERR_INVALID; }
+            // a search requested on tick t runs between two launches of the tick kernel (<= RUN_CAP ticks each) and must be
+            // finished before tick t + latency; it must also have been consumed before the next request (every 100 ticks)
+            if (cfg.mcts_iterations < 1 || cfg.mcts_initial_iterations < 1 || cfg.mcts_latency_ticks <= RUN_CAP || cfg.mcts_latency_ticks >= 100 ||
+                cfg.mcts_initial_latency_ticks <= RUN_CAP || cfg.mcts_initial_latency_ticks >= 100) {
+                err = "hk_create: MCTS budget / latency out of range (iterations >= 1, RUN_CAP < latency ticks < 100)"; return HK_ERR_INVALID;
+            }
+        }
         if (cfg.low_mode[i] != HK_LOW_LQR && cfg.low_mode[i] != HK_LOW_RL) { err = "hk_create: LowMode MPC is dead code in the reference"; return HK_ERR_UNSUPPORTED; }
         if (cfg.tree_search_depth[i] < 0 || cfg.tree_search_depth[i] > L) { err = "hk_create: bad tree_search_depth"; return HK_ERR_INVALID; }
     }
@@ -109,6 +123,8 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     for (int i = 0; i < A; i++) {
         P.high_mode[i] = cfg.high_mode[i]; P.low_mode[i] = cfg.low_mode[i]; P.depth[i] = cfg.tree_search_depth[i];
         P.vbucket[i] = cfg.velocity_bucket_size[i];
+        P.team_of[i] = cfg.team_of[i]; P.time_precision[i] = cfg.time_precision[i]; P.section_window[i] = cfg.section_window[i];
+        if (cfg.high_mode[i] == HK_HIGH_MCTS) P.any_mcts += 1;
         P.n_team[i] = cfg.n_team[i]; P.n_other[i] = cfg.n_other[i];
         for (int j = 0; j < ENV_MAXA; j++) { P.team[i][j] = cfg.team_agents[i][j]; P.other[i][j] = cfg.other_agents[i][j]; }
     }
@@ -116,6 +132,8 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         const float dl = cfg.sensor_yaw_deg[i] * DEG2RAD_F;
         P.sens_c[i] = hk_cosf(dl); P.sens_s[i] = hk_sinf(dl); P.ray_dist[i] = cfg.ray_distance[i];
     }
+    P.mcts_iter = cfg.mcts_iterations; P.mcts_iter0 = cfg.mcts_initial_iterations; P.mcts_lat = cfg.mcts_latency_ticks;
+    P.mcts_lat0 = cfg.mcts_initial_latency_ticks; P.mcts_seed = cfg.mcts_seed;
     P.jitter_seed = cfg.jitter_seed; P.jitter_pos = cfg.jitter_pos; P.jitter_yaw = cfg.jitter_yaw; P.env_id_base = cfg.env_id_base;
     P.max_speed = cfg.stats.TopSpeed > cfg.stats.ReverseSpeed ? cfg.stats.TopSpeed : cfg.stats.ReverseSpeed;   // AK:210
     P.init_acc = -cfg.stats.TireWearRate * hk_logf(1 - ((cfg.stats.MaxSteer - cfg.stats.MinSteer) * 0.25f / cfg.stats.MaxSteer));  // REC:588
@@ -238,6 +256,22 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     HK_ALLOC(d.games, na * sizeof(GameDesc));
     HK_ALLOC(d.queue_cnt, 2 * 8 * sizeof(int));
     HK_ALLOC(d.queue, 2 * 3 * na * sizeof(int));
+    if (P.any_mcts) {
+        if (na >= (1u << 24)) { err = "hk_create: MCTS planner queues address at most 2^24 agents per device"; return HK_ERR_UNSUPPORTED; }
+        std::vector<SecGeo> geo(L);
+        for (int i = 0; i < L; i++) geo[i] = SecGeo{sections[i].track_width, sections[i].track_length, sections[i].turn_degrees, sections[i].left_turn};
+        if ((rc = detail::upload(&d.sec_geo, geo, err))) return rc;
+        P.sec_geo = d.sec_geo;
+        int max_depth = 1;
+        for (int i = 0; i < A; i++) if (cfg.high_mode[i] == HK_HIGH_MCTS) max_depth = std::max(max_depth, cfg.tree_search_depth[i]);
+        d.mcts.pool_cap = 1 + std::max(cfg.mcts_iterations, cfg.mcts_initial_iterations) * (max_depth * A + 1);
+        d.mcts.slots = E * P.any_mcts;
+        HK_ALLOC(d.mcts.st, na * sizeof(hk_mcts_state));
+        HK_ALLOC(d.mcts.req, na * sizeof(MctsReq));
+        HK_ALLOC(d.mcts.queue, 2 * 2 * na * sizeof(int));
+        HK_ALLOC(d.mcts.nodes, (size_t)d.mcts.slots * d.mcts.pool_cap * sizeof(MNode));
+        d.mcts.qcnt = d.queue_cnt + 7;
+    }
 #undef HK_ALLOC
     // REC.Start :148-168: every agent starts inactive; results carry episode = -1; RL branch defaults to "coast"
     {
@@ -265,6 +299,14 @@ inline int launch_check(std::string& err, const char* what)
     return HK_OK;
 }
 
+// the planner searches queued in set `set` (a no-op kernel when the queue is empty)
+inline int env_launch_mcts(EnvDevice& d, int set, hipStream_t stream, std::string& err)
+{
+    if (!d.mcts.st) return HK_OK;
+    hipLaunchKernelGGL(mcts_search_kernel, dim3((2 * d.mcts.slots + 63) / 64), dim3(64), 0, stream, d.P, d.mcts, set);
+    return launch_check(err, "mcts_search_kernel");
+}
+
 inline int env_reset(EnvDevice& d, const hk_config& cfg, const int32_t* env_ids, int n, int experiment_num, hipStream_t stream,
                      std::string& err)
 {
@@ -285,9 +327,14 @@ inline int env_reset(EnvDevice& d, const hk_config& cfg, const int32_t* env_ids,
         dids = d.env_ids;
     }
     const int threads = cnt * 4;
-    hipLaunchKernelGGL(env_reset_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.envs, dids, cnt, experiment_num);
+    // first plans of MCTS agents go to the queue set the NEXT tick-kernel launch clears (its own set is filled by that launch)
+    const int mset = (d.round & 1) ^ 1;
+    if (d.mcts.st && hipMemsetAsync(d.mcts.qcnt + mset * 8 - 1, 0, 2 * sizeof(int), stream) != hipSuccess) { err = "hk_reset: memset"; return HK_ERR_HIP; }
+    hipLaunchKernelGGL(env_reset_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.envs, dids, cnt, experiment_num,
+                       d.mcts, mset);
     int rc = launch_check(err, "env_reset_kernel");
     if (rc) return rc;
+    if ((rc = env_launch_mcts(d, mset, stream, err))) return rc;
     if (hipStreamSynchronize(stream) != hipSuccess) { err = "hk_reset: sync failed"; return HK_ERR_HIP; }
     return HK_OK;
 }
@@ -318,7 +365,7 @@ inline int env_launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream
 {
     const int threads = cfg.num_envs * 4;
     hipLaunchKernelGGL(env_run_kernel, dim3((threads + 255) / 256), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs, d.results,
-                       d.games, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status, d.tab_lds ? 1 : 0);
+                       d.games, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status, d.tab_lds ? 1 : 0, d.mcts);
     return launch_check(err, "env_run_kernel");
 }
 
@@ -327,6 +374,7 @@ inline int env_launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream
 {
     const int ngames = cfg.num_envs * cfg.num_agents;
     const int set = d.round & 1;
+    { int rcm = env_launch_mcts(d, set, stream, err); if (rcm) return rcm; }      // planner searches requested in this round
     const int* qc = d.queue_cnt + set * 8;
     const int* qu = d.queue + (size_t)set * 3 * ngames;
     int rc = HK_OK;

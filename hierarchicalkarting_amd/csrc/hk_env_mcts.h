@@ -1,0 +1,549 @@
+// hk_env_mcts.h — the MCTS high-level planner on device (contract: include/hk.h "MCTS high-level planner").
+//
+// Reference: AI/MCTS/KartMCTS.cs (tree search), AI/MCTS/KartDiscreteGame.cs (the discrete racing game),
+// HierarchicalKartAgent.planWithMCTS HKA:172-263 (game construction) and HKA:366-402 (how bestStates feed the
+// low-level planner).  The reference plans on a background thread under a wall-clock budget; here (see hk.h):
+//   * when an agent's planning tick comes (reset, or episodeSteps % 100 == 0) the fused tick kernel SNAPSHOTS what the
+//     planner reads (section, lane, lane changes, tire age, section times of every kart) into an MctsReq, queues the
+//     (env, agent) pair and keeps ticking;
+//   * mcts_search_kernel, launched after every round of the tick kernel, runs the queued searches (iteration budget)
+//     and stores the result as hk_mcts_state.pend;
+//   * mcts_latency ticks after the request the tick kernel promotes pend to best and, every tick, copies best into the
+//     agent's plan and its beliefs about the other karts (HKA:366-402).
+// One lane per search in this first version.  Data layout differs from the reference (and from the CPU oracle, which
+// follows the C#): ONE running game state per search instead of a state per tree node, nodes are 32-byte records in a
+// first-child / next-sibling arena, and the legal-move scan of a position is done once and shared by isOver, nextMoves
+// and the rollout ordering (the reference recomputes it three times).  The draws (Philox) and every float expression
+// are the same, so the plans agree with the oracle's bit for bit.
+#pragma once
+#include "hk_env_device.h"
+
+namespace hk {
+
+constexpr int MC_MAXP = 4;                    // players of a discrete game (<= agents of an env)
+constexpr int MC_MAXA = HK_MCTS_MAX_ACTIONS;  // 20
+
+struct MctsKartSnap { int section, lane, lane_changes, tire_age; int sec_time[4]; };
+struct MctsReq {
+    int episode_steps, epoch, iterations, gen;      // gen: bumped by every request of this ego (stale queue entries are skipped)
+    MctsKartSnap k[MC_MAXP];
+};
+struct MNode {
+    int parent, first_child, last_child, next_sibling;
+    int numEpisodes;
+    float totalValue;
+    unsigned char action, upnext, n_children, pad;
+    int pad2;
+};
+static_assert(sizeof(MNode) == 32, "MNode layout");
+
+struct MctsDev {
+    hk_mcts_state* st;      // [E][A]; nullptr: no agent plans with MCTS
+    MctsReq* req;           // [E][A]
+    int* qcnt;              // &queue_cnt[7]; set s counts at [s * 8] (double buffered over rounds with the LQ game queues)
+    int* queue;             // [2][2*E*A]: (env * A + agent) | generation << 24
+    MNode* nodes;           // [slots][pool_cap]
+    int pool_cap;
+    int slots;              // searches the arena can hold at once (E * number of MCTS agents)
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pieces used by the tick kernel
+
+// prepareForReuse (HKA:428-452, KA:212): beliefs and bestStates cleared, sectionTimes[m_SectionIndex] = 0
+__device__ inline void mcts_reset_state(hk_mcts_state* m)
+{
+    const int searches = m->searches;
+    __builtin_memset(m, 0, sizeof(hk_mcts_state));
+    m->searches = searches;
+    m->ready_step = -1;
+}
+
+__device__ inline int mcts_tire_age(const EnvParams& P, float final_steer)
+{   // HKA:236
+    return (int)((P.st.MaxSteer - final_steer) / (P.st.MaxSteer - P.st.MinSteer) * 10000.0f);
+}
+
+// Every lane of the quad calls this with the same req_mask (bit e: ego e plans on this tick).  Lane i contributes its
+// own kart's snapshot to every requesting ego's record; a requesting ego also writes the header and queues itself.
+__device__ inline void mcts_post_request(const EnvParams& P, const MctsDev& M, int set, int env, int i, uint32_t req_mask,
+                                         int episode_steps, int epoch, int iterations, int ready_step,
+                                         int section, int lane, int lane_changes, float final_steer)
+{
+    if (i >= P.A) return;
+    hk_mcts_state* mine = &M.st[(size_t)env * P.A + i];
+    MctsKartSnap s;
+    s.section = section; s.lane = lane; s.lane_changes = lane_changes; s.tire_age = mcts_tire_age(P, final_steer);
+    for (int q = 0; q < 4; q++) s.sec_time[q] = mine->sec_time[q];
+    for (int e = 0; e < P.A; e++)
+        if (req_mask & (1u << e)) M.req[(size_t)env * P.A + e].k[i] = s;
+    if (req_mask & (1u << i)) {
+        MctsReq* r = &M.req[(size_t)env * P.A + i];
+        r->episode_steps = episode_steps; r->epoch = epoch; r->iterations = iterations; r->gen += 1;
+        mine->searches += 1;
+        mine->ready_step = ready_step;
+        const int slot = atomicAdd(&M.qcnt[set * 8], 1);
+        // an ego can post twice in one launch (a replan tick, then the episode ends and the reset plans again): the queue set
+        // holds 2 entries per agent and the entry carries the request generation, so the search kernel skips the stale one
+        M.queue[(size_t)set * 2 * P.E * P.A + slot] = (env * P.A + i) | ((r->gen & 0xFF) << 24);
+    }
+}
+
+// HKA.FixedUpdate :366-402, every tick: promote a finished search, then copy bestStates into the own plan and beliefs
+__device__ inline void mcts_consume(const EnvParams& P, hk_mcts_state* m, hk_agent_state* a, int i, int episode_steps, int section_index)
+{
+    if (m->ready_step >= 0 && episode_steps >= m->ready_step) { m->best = m->pend; m->ready_step = -1; }
+    const hk_mcts_plan& b = m->best;
+    const int L = P.L;
+    for (int q = 0; q < b.n_states; q++) {
+        const int sec = b.section[q];
+        for (int p = 0; p < b.n_players; p++) {
+            const int who = b.player_agent[p];
+            if (who == i) {
+                if (sec > section_index + (section_index == 0 ? 0 : 1)) {
+                    a->plan_lane[sec % L] = b.lane[q][p];
+                    a->plan_vel[sec % L] = (float)b.vel[q][p];
+                }
+            } else {
+                m->belief_lane[who][sec % L] = b.lane[q][p];
+                m->belief_vel[who][sec % L] = b.vel[q][p];
+            }
+        }
+    }
+}
+
+// HKA.FixedUpdate :330-402 for one tick (after SolveLQR): request a replan every 100 ticks, consume bestStates.
+// `flags` / `section` ... are the calling lane's own kart; every lane of the quad must call this.
+__device__ inline void phase_plan(const EnvParams& P, const MctsDev& M, int set, int env, int i, const hk_env_state& es,
+                                  uint32_t flags, int section, int lane, int lane_changes, float final_steer, hk_agent_state* arec)
+{
+    const bool me = i < P.A;
+    const bool enabled = me && (flags & HK_F_ENABLED);
+    const bool inactive = (es.inactive_mask >> i) & 1u;
+    uint32_t req = 0;
+    if (enabled && P.high_mode[i] == HK_HIGH_MCTS && es.episode_steps % 100 == 0 && es.episode_steps < P.max_steps &&
+        es.episode_steps > 0 && !inactive)
+        req = 1u << i;
+    req |= __shfl_xor(req, 1, 64); req |= __shfl_xor(req, 2, 64);
+    if (req) mcts_post_request(P, M, set, env, i, req, es.episode_steps, es.episodes_done, P.mcts_iter, es.episode_steps + P.mcts_lat,
+                               section, lane, lane_changes, final_steer);
+    if (enabled && P.high_mode[i] == HK_HIGH_MCTS) mcts_consume(P, &M.st[(size_t)env * P.A + i], arec, i, es.episode_steps, section);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the discrete game (KartDiscreteGame.cs), one running state per search
+
+struct DKart { int section, time, minv, maxv, lane, tire, lchg; };
+struct DGame {
+    int P;
+    DKart k[MC_MAXP];
+    int team[MC_MAXP];
+    int last, fin;              // lastCompletedSection, finalSection
+};
+struct MoveEval {               // the legal moves of the player who is up next, in canonical (velocity-major) order
+    int n;
+    unsigned char idx[MC_MAXA];
+    int dt[MC_MAXA];            // time the move adds to that player's timeAtSection
+};
+struct MctsCtx {
+    const EnvParams* P;
+    const TabView* T;
+    int bucket, precision, vmax, nact;
+    uint32_t key0, key1, c1, c2, draw;
+};
+
+__device__ inline void mc_draw(MctsCtx& C, uint32_t r[4]) { philox4x32(C.draw++, C.c1, C.c2, 0x4D435453u, C.key0, C.key1, r); }
+__device__ inline int mc_rand_next(MctsCtx& C, int n)
+{
+    uint32_t r[4]; mc_draw(C, r);
+    return (int)(((unsigned long long)r[0] * (unsigned long long)n) >> 32);
+}
+__device__ inline float mc_normal(MctsCtx& C)
+{
+    uint32_t r[4]; mc_draw(C, r);
+    const float u1 = (float)((r[0] >> 8) + 1u) * (1.0f / 16777216.0f);
+    const float u2 = u01(r[1]);
+    return sqrtf(-2.0f * hk_logf(u1)) * hk_cosf((2.0f * HK_PI_F) * u2);
+}
+__device__ inline float mc_gauss_bounded(MctsCtx& C, float mean, float sd, float lo, float hi)
+{   // KartMCTS.NextGaussian(mean, sd, min, max) :225-240
+    float x; int attempts = 0;
+    do { x = mean + mc_normal(C) * sd; attempts += 1; } while ((x < lo || x > hi) && attempts < 10);
+    if (attempts == 10 && (x < lo || x > hi)) return mean;
+    return x;
+}
+
+__device__ inline void mc_action(const MctsCtx& C, int a, int& minv, int& maxv, int& lane)
+{   // KDG:325-338: for (i = 6; i < maxSpeed; i += bucket) for (lane = 1..4)
+    const int vi = a >> 2;
+    minv = 6 + vi * C.bucket;
+    maxv = (minv + C.bucket) < C.vmax ? (minv + C.bucket) : C.vmax;
+    lane = (a & 3) + 1;
+}
+
+__device__ inline float mc_lane_radius(const SecDev& s, const SecGeo& G, int lane)
+{   // DPT.Start :72-88
+    const int q = G.left_turn ? (lane - 1) : (4 - lane);
+    return s.inside_radius + G.track_width * ((float)q / 4.0f);
+}
+__device__ inline float mc_radius(const MctsCtx& C, int section, int l0, int l1)
+{   // DPT.radiusOfLane :153-158
+    const SecDev& s = C.T->sec[section % C.P->L];
+    if (s.inside_radius == 0.0f) return 0.0f;
+    const SecGeo& G = C.P->sec_geo[section % C.P->L];
+    return (mc_lane_radius(s, G, l0) + mc_lane_radius(s, G, l1)) / 2.0f;
+}
+__device__ inline float mc_distance(const MctsCtx& C, int section, int l0, int l1)
+{   // DPT.distanceToTravel :163-175
+    const SecDev& s = C.T->sec[section % C.P->L];
+    const SecGeo& G = C.P->sec_geo[section % C.P->L];
+    const int dl = l0 > l1 ? l0 - l1 : l1 - l0;
+    if (s.inside_radius == 0.0f) {
+        const float w = ((float)dl * 1.0f / 3.0f) * G.track_width;
+        return sqrtf(w * w + G.track_length * G.track_length);
+    }
+    return (HK_PI_F / 180.0f) * G.turn_degrees * mc_radius(C, section, l0, l1);
+}
+__device__ inline float mc_tire_load(const MctsCtx& C, int section, float velocity, int l0, int l1)
+{   // DPT.tireLoad :180-192
+    const SecDev& s = C.T->sec[section % C.P->L];
+    if (s.inside_radius == 0.0f) return mc_distance(C, section, l0, l1) * 0.01f;
+    const float gs = (velocity * velocity) / mc_radius(C, section, l0, l1);
+    return gs * mc_distance(C, section, l0, l1) * 0.01f;
+}
+__device__ inline float mc_max_speed(const MctsCtx& C, float radius, float wear)
+{   // ArcadeKart.getMaxSpeedForRadiusAndWear :536-547
+    const hk_kart_stats& st = C.P->st;
+    if (radius == 0.0f) return st.TopSpeed;
+    const float gsw = (1 - wear) * (st.MaxGs - st.MinGs) + st.MinGs;
+    float v = sqrtf(gsw * 9.81f * f_abs(radius));
+    if (__builtin_isinf(v) || __builtin_isnan(v)) v = st.TopSpeed;
+    return v < 0.0001f ? 0.0001f : (v > st.TopSpeed ? st.TopSpeed : v);
+}
+__device__ inline bool mc_straight(const MctsCtx& C, int section) { return C.T->sec[section % C.P->L].inside_radius == 0.0f; }
+__device__ inline float mc_avgv(int minv, int maxv) { return (1.0f * (float)(minv + maxv)) / 2.0f; }
+
+__device__ inline float mc_toc(const MctsCtx& C, float distance, float radius, float wear, float initV, float finalV)
+{   // DiscreteKartState.computeTOC KDG:66-117
+    const float acc = C.P->st.Acceleration, brk = C.P->st.Braking;
+    if (finalV > initV && (finalV * finalV - initV * initV) / (2 * acc) > distance) return -1.0f;
+    if (initV > finalV && (initV * initV - finalV * finalV) / (2 * brk) > distance) return -1.0f;
+    const float vmax = mc_max_speed(C, radius, wear);
+    float t1 = vmax >= initV ? (vmax - initV) / acc : (initV - vmax) / brk;
+    float t3 = vmax >= finalV ? (vmax - finalV) / brk : (finalV - vmax) / acc;
+    const float x1 = 0.5f * (initV + vmax) * t1;
+    const float x3 = 0.5f * (finalV + vmax) * t3;
+    const float x2 = distance - x1 - x3;
+    const float t2 = x2 / vmax;
+    if ((double)t2 > 0.001) return t1 + t2 + t3;
+    if (initV <= vmax) {
+        const float ms = sqrtf((2 * distance * -brk * acc + -brk * initV * initV - acc * finalV * finalV) / (-acc - brk));
+        t1 = (ms - initV) / acc;
+        t3 = (ms - finalV) / brk;
+        return t1 + t3;
+    }
+    return -1.0f;
+}
+
+// applyAction KDG:122-167 on kart k; returns false when the move is infeasible.  dt = the time it adds.
+__device__ inline bool mc_apply(const MctsCtx& C, const DKart& k, int minv, int maxv, int lane, DKart& n, int& dt)
+{
+    n.section = k.section + 1;
+    n.minv = minv; n.maxv = maxv; n.lane = lane;
+    const int dl = lane > k.lane ? lane - k.lane : k.lane - lane;
+    if (mc_straight(C, k.section) != mc_straight(C, k.section + 1)) n.lchg = 0;
+    else if (lane != k.lane) n.lchg = k.lchg + dl;
+    else n.lchg = k.lchg;
+    const float dist = mc_distance(C, k.section, k.lane, lane);
+    const float rad = mc_radius(C, k.section, k.lane, lane);
+    // the reference reads newState.tireAge here, which is still 0 (KDG:150)
+    dt = (int)(mc_toc(C, dist, rad, 0.0f / 10000.0f, mc_avgv(k.minv, k.maxv), mc_avgv(minv, maxv)) * (float)C.precision);
+    n.time = k.time + dt;
+    const float load = mc_tire_load(C, k.section, (float)maxv, k.lane, lane);
+    n.tire = (int)(((float)k.tire / 10000.0f + load * C.P->st.TireWearFactor) * 10000.0f);
+    return dt >= 0;
+}
+
+__device__ inline int mc_cmp(const DKart& a, const DKart& b)
+{   // the Comparison of upNext KDG:186-223
+    if (a.section < b.section) return -1;
+    if (a.section > b.section) return 1;
+    if (a.time < b.time) return -1;
+    if (a.time == b.time) {
+        const float va = mc_avgv(a.minv, a.maxv), vb = mc_avgv(b.minv, b.maxv);
+        if (va > vb) return -1;
+        if (va == vb) return 0;
+        return 1;
+    }
+    return 1;
+}
+__device__ inline int mc_up_next(const DGame& g)
+{   // KDG:183-238.  List.Sort on <= 16 elements: 2 -> one compare-swap, 3 -> (0,1) (0,2) (1,2), else insertion sort
+    int o[MC_MAXP];
+    for (int i = 0; i < MC_MAXP; i++) o[i] = i;
+    auto sig = [&](int i, int j) { if (mc_cmp(g.k[o[i]], g.k[o[j]]) > 0) { const int t = o[i]; o[i] = o[j]; o[j] = t; } };
+    if (g.P == 2) sig(0, 1);
+    else if (g.P == 3) { sig(0, 1); sig(0, 2); sig(1, 2); }
+    else if (g.P > 3) {
+        for (int i = 0; i < g.P - 1; i++) {
+            const int t = o[i + 1];
+            int j = i;
+            while (j >= 0 && mc_cmp(g.k[t], g.k[o[j]]) < 0) { o[j + 1] = o[j]; j--; }
+            o[j + 1] = t;
+        }
+    }
+    for (int i = 0; i < g.P; i++)
+        if (g.k[o[i]].section != g.last + 1) return o[i];
+    return -1;
+}
+
+// nextMoves KDG:318-411 for the player who is up next (np), with the time each legal move adds
+__device__ inline void mc_eval_moves(const MctsCtx& C, const DGame& g, int np, MoveEval& mv)
+{
+    const DKart& cur = g.k[np];
+    const bool str = mc_straight(C, cur.section);
+    mv.n = 0;
+    for (int a = 0; a < C.nact; a++) {
+        int minv, maxv, lane;
+        mc_action(C, a, minv, maxv, lane);
+        const int dl = lane > cur.lane ? lane - cur.lane : cur.lane - lane;
+        if (str && cur.lchg + dl > C.P->max_lane_changes) continue;
+        const float radius = mc_radius(C, cur.section, cur.lane, lane);
+        if (mc_max_speed(C, radius, (float)cur.tire / 10000.0f) < (float)minv) continue;
+        DKart nk; int dt;
+        if (!mc_apply(C, cur, minv, maxv, lane, nk, dt)) continue;
+        mv.idx[mv.n] = (unsigned char)a; mv.dt[mv.n] = dt; mv.n++;
+    }
+}
+
+// makeMove KDG:416-443 on the running state
+__device__ inline void mc_make_move(const MctsCtx& C, DGame& g, int np, int a)
+{
+    int minv, maxv, lane, dt;
+    mc_action(C, a, minv, maxv, lane);
+    DKart nk;
+    mc_apply(C, g.k[np], minv, maxv, lane, nk, dt);
+    g.k[np] = nk;
+    bool allAhead = true;
+    for (int i = 0; i < g.P; i++) allAhead = allAhead && (g.k[i].section > g.last);
+    if (allAhead) g.last += 1;
+}
+
+// isOver KDG:246-313 given the legal-move count of the position.  scores: the reference's List<float> (can exceed P)
+__device__ inline bool mc_is_over(const MctsCtx& C, const DGame& g, int np, int n_legal, float* scores)
+{
+    if (n_legal == 0) {
+        int n = 0;
+        for (int i = 0; i < g.P; i++) {
+            if (i == np || g.team[i] == g.team[np]) scores[n++] = 0.0f;
+            scores[n++] = 0.5f;                                     // the reference has no `else` here
+        }
+        return true;
+    }
+    if (g.last != g.fin) return false;
+    if (g.P > 1) {
+        const float tsm = 0.75f;                                    // RacingEnvController.TeamScoreRewardMultiplier
+        float maxScore = (float)C.precision * -1000.0f, minScore = (float)C.precision * 1000.0f;
+        float raw[MC_MAXP];
+        float teamScore = 0.0f, opponentScore = 0.0f;
+        int teamCount = 0, opponentCount = 0;                       // accumulate over players (not reset, KDG:273-276)
+        for (int s = 0; s < g.P; s++) {
+            for (int o = 0; o < g.P; o++) {
+                if (s == o) teamScore += (float)g.k[o].time;
+                else if (g.team[s] == g.team[o]) { teamScore += (float)g.k[o].time * tsm; teamCount += 1; }
+                else { opponentScore += (float)g.k[o].time; opponentCount += 1; }
+            }
+            const float score = opponentScore * (((float)teamCount * tsm + 1.0f) / ((float)opponentCount * 1.0f)) - teamScore;
+            raw[s] = score;
+            const bool nn = __builtin_isnan(score);                 // Math.Max / Math.Min propagate NaN
+            maxScore = (__builtin_isnan(maxScore) || nn) ? __builtin_nanf("") : (maxScore > score ? maxScore : score);
+            minScore = (__builtin_isnan(minScore) || nn) ? __builtin_nanf("") : (minScore < score ? minScore : score);
+        }
+        for (int s = 0; s < g.P; s++) {
+            const int si = (raw[s] >= -2147483648.0f && raw[s] < 2147483648.0f) ? (int)raw[s] : (-2147483647 - 1);
+            scores[s] = ((float)si - minScore) * 1.0f / (maxScore - minScore);
+        }
+        return true;
+    }
+    scores[0] = (float)(C.P->max_steps - g.k[0].time / C.P->max_steps);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the tree (KartMCTS.cs)
+
+__device__ inline float mc_uct(const MNode* nd, int c)
+{   // UCTWeight :162-165 (integer division inside the log)
+    const MNode& n = nd[c];
+    return (n.totalValue / (float)n.numEpisodes) + sqrtf(1.0f) * hk_logf((float)(nd[n.parent].numEpisodes / n.numEpisodes));
+}
+__device__ inline int mc_ucs(MctsCtx& C, const MNode* nd, int node)
+{   // upperConfidenceStrategy :167-193; children in insertion order
+    const int index = mc_rand_next(C, nd[node].n_children);
+    int c = nd[node].first_child;
+    for (int q = 0; q < index; q++) c = nd[c].next_sibling;
+    int best = c;
+    float best_uct = mc_uct(nd, best);
+    for (c = nd[node].first_child; c >= 0; c = nd[c].next_sibling) {
+        const float u = mc_uct(nd, c);
+        if (u > best_uct) { best_uct = u; best = c; }
+    }
+    return best;
+}
+
+__global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M, int set)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= M.qcnt[set * 8]) return;
+    const unsigned ent = (unsigned)M.queue[(size_t)set * 2 * P.E * P.A + q];
+    const int pair = (int)(ent & 0xFFFFFFu);
+    if (((unsigned)M.req[pair].gen & 0xFFu) != (ent >> 24)) return;          // superseded by a later request of the same ego
+    const int slot = atomicAdd(&M.qcnt[set * 8 - 1], 1);                     // arena slot (counter [6] of the set)
+    if (slot >= M.slots) return;
+    const int env = pair / P.A, ego = pair % P.A;
+    const TabView T = tab_view(P, P.tab);
+    const MctsReq& R = M.req[pair];
+    hk_mcts_state* mst = &M.st[pair];
+    MNode* nd = M.nodes + (size_t)slot * M.pool_cap;
+
+    MctsCtx C;
+    C.P = &P; C.T = &T;
+    C.bucket = P.vbucket[ego]; C.precision = P.time_precision[ego];
+    C.vmax = (int)P.max_speed;
+    C.nact = 0;
+    for (int i = 6; i < C.vmax; i += C.bucket) C.nact += 4;
+    if (C.nact > MC_MAXA) C.nact = MC_MAXA;
+    C.key0 = P.mcts_seed; C.key1 = (uint32_t)(P.env_id_base + env) * (uint32_t)P.A + (uint32_t)ego;
+    C.c1 = (uint32_t)R.episode_steps; C.c2 = (uint32_t)R.epoch; C.draw = 0;
+
+    // planWithMCTS HKA:172-263: the discrete game of the karts within sectionWindow sections of the ego
+    DGame root;
+    int agent_of[MC_MAXP];
+    root.P = 0;
+    int initialSection = R.k[ego].section, furthest = ego;
+    for (int i = 0; i < P.A; i++) {
+        int d = R.k[i].section - R.k[ego].section; d = d < 0 ? -d : d;
+        if (d < P.section_window[ego]) {
+            agent_of[root.P++] = i;
+            if (R.k[i].section > initialSection) initialSection = R.k[i].section;
+            if (initialSection == R.k[i].section) furthest = i;
+        }
+    }
+    for (int p = 0; p < MC_MAXP; p++) {
+        DKart& k = root.k[p];
+        k.section = 0; k.time = 0; k.minv = 0; k.maxv = 0; k.lane = 1; k.tire = 0; k.lchg = 0; root.team[p] = 0;
+        if (p >= root.P) continue;
+        const MctsKartSnap& s = R.k[agent_of[p]];
+        root.team[p] = P.team_of[agent_of[p]];
+        k.minv = 0;                                                  // HKA:211-219: the bucket loop breaks at i = 0
+        k.maxv = C.bucket < C.vmax ? C.bucket : C.vmax;
+        k.section = initialSection;
+        if (s.section != initialSection)                             // HKA:221-224
+            k.time = (int)((float)(s.sec_time[s.section & 3] - R.k[furthest].sec_time[s.section & 3]) * P.dt * (float)C.precision);
+        k.lane = s.lane; k.tire = s.tire_age; k.lchg = s.lane_changes;
+    }
+    root.last = initialSection;
+    root.fin = initialSection + P.depth[ego];
+
+    int n_nodes = 1;
+    nd[0].parent = -1; nd[0].first_child = -1; nd[0].last_child = -1; nd[0].next_sibling = -1;
+    nd[0].numEpisodes = 0; nd[0].totalValue = 0.0f; nd[0].action = 0; nd[0].n_children = 0; nd[0].pad = 0; nd[0].pad2 = 0;
+    nd[0].upnext = (unsigned char)mc_up_next(root);
+
+    float scores[2 * MC_MAXP];
+    MoveEval mv;
+    for (int it = 0; it < R.iterations; it++) {
+        // findLeaf :195-202 on a running copy of the root state
+        DGame g = root;
+        int node = 0;
+        int np = nd[0].upnext;
+        mc_eval_moves(C, g, np, mv);
+        while (nd[node].n_children > 0 && nd[node].n_children == mv.n) {
+            node = mc_ucs(C, nd, node);
+            mc_make_move(C, g, np, nd[node].action);
+            np = nd[node].upnext;
+            mc_eval_moves(C, g, np, mv);
+        }
+        // simulate :242-283 (mv / np describe the position of `node`)
+        bool out_of_nodes = false;
+        while (true) {
+            if (mc_is_over(C, g, np, mv.n, scores)) break;
+            const int ol = T.sec[g.last % P.L].optimal_lane;
+            const int sign = ol == 1 ? 1 : (ol == 4 ? -1 : 0);
+            // OrderBy(time added).ThenByDescending(max_velocity).ThenBy(|lane change|).ThenBy(sign * lane): stable
+            unsigned char ord[MC_MAXA];
+            for (int i = 0; i < mv.n; i++) ord[i] = (unsigned char)i;
+            auto less = [&](int x, int y) {
+                int mx, Mx, lx, my, My, ly;
+                mc_action(C, mv.idx[x], mx, Mx, lx); mc_action(C, mv.idx[y], my, My, ly);
+                if (mv.dt[x] != mv.dt[y]) return mv.dt[x] < mv.dt[y];
+                if (Mx != My) return Mx > My;
+                const int cl = g.k[np].lane;
+                const int dx = lx > cl ? lx - cl : cl - lx, dy = ly > cl ? ly - cl : cl - ly;
+                if (dx != dy) return dx < dy;
+                if (sign * lx != sign * ly) return sign * lx < sign * ly;
+                return false;
+            };
+            for (int i = 1; i < mv.n; i++) {
+                const int t = ord[i];
+                int j = i - 1;
+                while (j >= 0 && less(t, ord[j])) { ord[j + 1] = ord[j]; j--; }
+                ord[j + 1] = (unsigned char)t;
+            }
+            int index;
+            if (mv.n > 2) index = (int)__builtin_rintf(f_abs(mc_gauss_bounded(C, 0.0f, (float)mv.n / 6.0f, -(float)mv.n + 1.0f, (float)mv.n - 1.0f)));
+            else index = mc_rand_next(C, mv.n);
+            const int move = mv.idx[ord[index]];
+            int c = -1;
+            for (int ch = nd[node].first_child; ch >= 0; ch = nd[ch].next_sibling)
+                if (nd[ch].action == move) { c = ch; break; }
+            mc_make_move(C, g, np, move);
+            const int np2 = mc_up_next(g);
+            if (c < 0) {
+                if (n_nodes >= M.pool_cap) { out_of_nodes = true; break; }
+                c = n_nodes++;
+                MNode& nn = nd[c];
+                nn.parent = node; nn.first_child = -1; nn.last_child = -1; nn.next_sibling = -1;
+                nn.numEpisodes = 0; nn.totalValue = 0.0f; nn.action = (unsigned char)move; nn.upnext = (unsigned char)np2;
+                nn.n_children = 0; nn.pad = 0; nn.pad2 = 0;
+                if (nd[node].last_child >= 0) nd[nd[node].last_child].next_sibling = c; else nd[node].first_child = c;
+                nd[node].last_child = c;
+                nd[node].n_children += 1;
+            }
+            node = c;
+            np = np2;
+            mc_eval_moves(C, g, np, mv);
+        }
+        if (out_of_nodes) break;
+        // backpropagate :285-293
+        for (int b = node; b >= 0; b = nd[b].parent) {
+            nd[b].totalValue += scores[nd[b].upnext];
+            nd[b].numEpisodes += 1;
+        }
+    }
+
+    // getBestStatesSequence :108-123
+    hk_mcts_plan plan;
+    __builtin_memset(&plan, 0, sizeof(plan));
+    plan.n_players = root.P;
+    for (int p = 0; p < root.P; p++) plan.player_agent[p] = (uint8_t)agent_of[p];
+    {
+        DGame g = root;
+        int node = 0;
+        while (nd[node].n_children > 0) {
+            const int np = nd[node].upnext;
+            node = mc_ucs(C, nd, node);
+            mc_make_move(C, g, np, nd[node].action);
+            bool all_at = true;
+            for (int p = 0; p < g.P; p++) all_at = all_at && (g.k[p].section == g.last);
+            if (all_at && plan.n_states < HK_MCTS_MAX_DEPTH) {
+                const int s = plan.n_states++;
+                plan.section[s] = g.last;
+                for (int p = 0; p < g.P; p++) { plan.lane[s][p] = (uint8_t)g.k[p].lane; plan.vel[s][p] = (uint8_t)g.k[p].maxv; }
+            }
+        }
+    }
+    mst->pend = plan;
+}
+
+}  // namespace hk

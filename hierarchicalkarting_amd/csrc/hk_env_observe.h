@@ -6,10 +6,10 @@
 
 namespace hk {
 
-__device__ inline float local_speed(const EnvParams& P, const hk_agent_state* a)
+// (fx, fz) = the kart's forward (sin yaw, cos yaw): evaluated once per kart by the caller, not per use
+__device__ inline float local_speed(const EnvParams& P, const hk_agent_state* a, float fx, float fz)
 {   // AK:325-342
     if (!(a->flags & HK_F_CAN_MOVE)) return 0.0f;
-    float fx = hk_sinf(a->yaw), fz = hk_cosf(a->yaw);
     float dot = fx * a->vx + fz * a->vz;
     if (f_abs(dot) > 0.1f) {
         float speed = mag3(a->vx, 0.0f, a->vz);
@@ -18,9 +18,8 @@ __device__ inline float local_speed(const EnvParams& P, const hk_agent_state* a)
     return 0.0f;
 }
 
-__device__ inline void inv_transform_point(const hk_agent_state* a, float wx, float wy, float wz, float ky, float out[3])
+__device__ inline void inv_transform_point(const hk_agent_state* a, float fx, float fz, float wx, float wy, float wz, float ky, float out[3])
 {   // Transform.InverseTransformPoint of a yaw-only transform
-    float fx = hk_sinf(a->yaw), fz = hk_cosf(a->yaw);
     float rx = wx - a->px, rz = wz - a->pz;
     out[0] = rx * fz + rz * (-fx);
     out[1] = wy - ky;
@@ -39,8 +38,12 @@ __global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_
     const hk_agent_state* ags = agents + (size_t)env * A;
     const hk_agent_state* a = &ags[i];
     float* o = obs + (size_t)gid * dim;
+    // forward vectors of every kart of the env, once
+    float kfx[HK_MAX_AGENTS], kfz[HK_MAX_AGENTS];
+    for (int j = 0; j < A; j++) { kfx[j] = hk_sinf(ags[j].yaw); kfz[j] = hk_cosf(ags[j].yaw); }
+    const float fx = kfx[i], fz = kfz[i];
     int p = 0;
-    o[p++] = local_speed(P, a);
+    o[p++] = local_speed(P, a, fx, fz);
     o[p++] = (a->flags & HK_F_ACCEL) ? 1.0f : 0.0f;
     o[p++] = (float)a->lane;
     o[p++] = a->lane_changes * 1.0f / P.max_lane_changes;
@@ -51,8 +54,9 @@ __global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_
     for (int pass = 0; pass < 2; pass++) {
         const int cnt = pass == 0 ? P.n_team[i] : P.n_other[i];
         for (int j = 0; j < cnt; j++) {
-            const hk_agent_state* b = &ags[pass == 0 ? P.team[i][j] : P.other[i][j]];
-            o[p++] = local_speed(P, b);
+            const int bj = pass == 0 ? P.team[i][j] : P.other[i][j];
+            const hk_agent_state* b = &ags[bj];
+            o[p++] = local_speed(P, b, kfx[bj], kfz[bj]);
             o[p++] = (b->flags & HK_F_ACCEL) ? 1.0f : 0.0f;
             o[p++] = (float)b->lane;
             o[p++] = b->lane_changes * 1.0f / P.max_lane_changes;
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_
             o[p++] = b->section_index * 1.0f / goal;
             o[p++] = mag3(b->px - a->px, 0.0f, b->pz - a->pz);
             float lp[3];
-            inv_transform_point(a, b->px, P.kart_y, b->pz, P.kart_y, lp);
+            inv_transform_point(a, fx, fz, b->px, P.kart_y, b->pz, P.kart_y, lp);
             o[p++] = lp[0]; o[p++] = lp[1]; o[p++] = lp[2];
         }
     }
@@ -73,25 +77,18 @@ __global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_
         if (pl != 0) {
             float mx, mz;
             lane_marker(T, next, pl, mx, mz);
-            inv_transform_point(a, mx, T.sec[next].marker_y, mz, P.kart_y, lp);
+            inv_transform_point(a, fx, fz, mx, T.sec[next].marker_y, mz, P.kart_y, lp);
             o[p++] = lp[0]; o[p++] = lp[1]; o[p++] = lp[2];
             o[p++] = a->plan_vel[next] / P.max_speed;
         } else {
-            inv_transform_point(a, T.sec[next].trig_x, T.sec[next].marker_y, T.sec[next].trig_z, P.kart_y, lp);
+            inv_transform_point(a, fx, fz, T.sec[next].trig_x, T.sec[next].marker_y, T.sec[next].trig_z, P.kart_y, lp);
             o[p++] = lp[0]; o[p++] = lp[1]; o[p++] = lp[2];
             o[p++] = 1.0f;
         }
         o[p++] = is_straight(P, T, next) ? 1.0f : 0.0f;
     }
-    const float fx = hk_sinf(a->yaw), fz = hk_cosf(a->yaw);
     const float ox = a->px + SENSOR_LZ * fx, oz = a->pz + SENSOR_LZ * fz;
-    // the other karts' forward vectors, once (not per sensor)
-    float bfx[HK_MAX_AGENTS], bfz[HK_MAX_AGENTS];
     const bool see = (a->flags & HK_F_ENABLED) != 0;
-    for (int j = 0; j < A; j++) {
-        bfx[j] = 0.0f; bfz[j] = 0.0f;
-        if (see && j != i && (ags[j].flags & HK_F_ENABLED)) { bfx[j] = hk_sinf(ags[j].yaw); bfz[j] = hk_cosf(ags[j].yaw); }
-    }
     for (int si = 0; si < HK_NUM_SENSORS; si++) {
         float dx, dz;
         sensor_dir(P, si, fx, fz, dx, dz);
@@ -118,7 +115,7 @@ __global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_
         if (see) {
             for (int j = 0; j < A; j++) {
                 if (j == i || !(ags[j].flags & HK_F_ENABLED)) continue;
-                float t = ray_stadium(ox, oz, dx, dz, ags[j].px, ags[j].pz, bfx[j], bfz[j], P.ray_agent_r);
+                float t = ray_stadium(ox, oz, dx, dz, ags[j].px, ags[j].pz, kfx[j], kfz[j], P.ray_agent_r);
                 if (t >= 0.0f && t <= maxd && (ha < 0.0f || t < ha)) ha = t;
             }
         }

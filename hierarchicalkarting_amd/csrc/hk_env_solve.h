@@ -234,7 +234,7 @@ __device__ inline void lq1_solve(const EnvParams& P, const GamePlayer& gp, Hot& 
 template <bool SINGLE>
 __device__ __forceinline__ void assemble_player(const EnvParams& P, const TabView& T, const int env, const int ego, const int i, const int N,
                                                 const int nearbyAgents, const int* pl, const KartS* kq, const bool fixed,
-                                                const float dy, GamePlayer* gp, hk_lq_debug* dbg_out)
+                                                const float dy, GamePlayer* gp, hk_lq_debug* dbg_out, const hk_mcts_state* bel)
 {
     const int A = P.A, L = P.L;
     const KartS& mek = kq[ego];
@@ -265,7 +265,18 @@ __device__ __forceinline__ void assemble_player(const EnvParams& P, const TabVie
                 double pv = mek.pv2 + (fixed ? 0 : P.vbucket[ego] * 2);
                 nextVel = (double)P.max_speed < pv ? (double)P.max_speed : pv;
             }
-        }   // else: the ego's belief about k's plan is only ever filled by the MCTS planner -> Trigger / max speed
+        } else if (bel) {                                                             // :767-771, :797-801: the EGO's beliefs
+            if (bel->belief_lane[ki][idx] != 0) {
+                laneSel = bel->belief_lane[ki][idx];
+                double pv = (float)bel->belief_vel[ki][idx] + (fixed ? 0 : P.vbucket[ego] * 2);
+                vel = (double)P.max_speed < pv ? (double)P.max_speed : pv;
+            }
+            if (bel->belief_lane[ki][idx2] != 0) {
+                nextSel = bel->belief_lane[ki][idx2];
+                double pv = (float)bel->belief_vel[ki][idx2] + (fixed ? 0 : P.vbucket[ego] * 2);
+                nextVel = (double)P.max_speed < pv ? (double)P.max_speed : pv;
+            }
+        }   // no belief (only the MCTS planner fills them) -> Trigger / max speed
         float lx, lz, nx, nz, cx, cz;
         lane_marker(T, idx, laneSel, lx, lz);
         lane_marker(T, idx2, nextSel, nx, nz);
@@ -374,8 +385,13 @@ __device__ __forceinline__ void assemble_player(const EnvParams& P, const TabVie
                     ov = (double)P.max_speed < pv ? (double)P.max_speed : pv;
                 } else ov = P.max_speed;
             } else {
-                lane_marker(T, io, 0, olx, olz);
-                ov = isteam ? o.msfs : P.max_speed;
+                const int bl = bel ? bel->belief_lane[oi][io] : 0;                    // :1054 / :1150
+                lane_marker(T, io, bl, olx, olz);
+                if (isteam) ov = o.msfs;
+                else if (bl != 0) {
+                    double pv = (float)bel->belief_vel[oi][io] + (fixed ? 0 : P.vbucket[ego] * 2);
+                    ov = (double)P.max_speed < pv ? (double)P.max_speed : pv;
+                } else ov = P.max_speed;
             }
             gp->opt[M][0] = olx; gp->opt[M][1] = olz; gp->opt[M][2] = ov;
             double mx = initial[2] > 1 ? initial[2] : 1;
@@ -423,7 +439,7 @@ __device__ __forceinline__ void wave_lds_sync()
 __device__ inline bool phase_assemble(const EnvParams& P, const TabView& T, KartS* ks, const int env, const int ego,
                                       const bool act, const hk_env_state& es, Hot& h, const float hfx, const float hfz, hk_agent_state* agents,
                                       GameDesc* games,
-                                      int* queue_cnt, int* queue, hk_lq_debug* dbg_out, int* status)
+                                      int* queue_cnt, int* queue, hk_lq_debug* dbg_out, int* status, const hk_mcts_state* mcts_all)
 {
     const int A = P.A, L = P.L;
     const bool me = act && ego < A;
@@ -530,16 +546,17 @@ __device__ inline bool phase_assemble(const EnvParams& P, const TabView& T, Kart
         nearbyAgents = nearbyAgents > 1 ? nearbyAgents : 1;
     }
     const bool fixed = P.high_mode[ego] == HK_HIGH_FIXED;
+    const hk_mcts_state* bel = mcts_all ? &mcts_all[(size_t)env * A + ego] : nullptr;
     const float dy = T.sec[0].marker_y - P.kart_y;                                    // Q13
     if (N == 1) {
         // single-player game: assemble into registers and run the whole Riccati recursion right here
         GamePlayer loc;
-        assemble_player<true>(P, T, env, ego, 0, N, nearbyAgents, pl, kq, fixed, dy, &loc, dbg_out);
+        assemble_player<true>(P, T, env, ego, 0, N, nearbyAgents, pl, kq, fixed, dy, &loc, dbg_out, bel);
         if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = 1;
         lq1_solve(P, loc, h, (dbg_out && (P.debug & 1)) ? &dbg_out[(size_t)env * A + ego] : nullptr, status);
         return false;
     }
-    for (int i = 0; i < N; i++) assemble_player<false>(P, T, env, ego, i, N, nearbyAgents, pl, kq, fixed, dy, &G->p[i], dbg_out);
+    for (int i = 0; i < N; i++) assemble_player<false>(P, T, env, ego, i, N, nearbyAgents, pl, kq, fixed, dy, &G->p[i], dbg_out, bel);
     G->N = N;
     if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = N;
     // bin the multi-player game by N

@@ -7,6 +7,7 @@
 // are supersets of what can be reached, so results equal a brute force scan over every wall (what the CPU oracle does).
 #pragma once
 #include "hk_env_device.h"
+#include "hk_env_mcts.h"
 
 namespace hk {
 
@@ -74,7 +75,7 @@ __device__ inline void snapshot_result(const Hot& h, float cum_reward, hk_episod
 
 // explicit hk_reset
 __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
-                                                        const int* env_ids, int n, int experiment_num)
+                                                        const int* env_ids, int n, int experiment_num, MctsDev M, int set)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = gid >> 2, i = gid & 3;
@@ -82,7 +83,15 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_st
     const int env = env_ids ? env_ids[slot] : slot;
     const int ex = experiment_num >= 0 ? experiment_num : (P.env_id_base + env) % P.nperm;
     const TabView T = tab_view(P, P.tab);
-    reset_agent(P, T, env, i, ex, &agents[(size_t)env * P.A + i]);
+    hk_agent_state* ar = &agents[(size_t)env * P.A + i];
+    reset_agent(P, T, env, i, ex, ar);
+    if (M.st) {
+        mcts_reset_state(&M.st[(size_t)env * P.A + i]);
+        uint32_t req = 0;
+        for (int e = 0; e < P.A; e++) if (P.high_mode[e] == HK_HIGH_MCTS) req |= 1u << e;
+        mcts_post_request(P, M, set, env, i, req, 0, envs[env].episodes_done, P.mcts_iter0, P.mcts_lat0,
+                          ar->section_index, ar->lane, ar->lane_changes, ar->final_steer);
+    }
     if (i == 0) {
         hk_env_state* es = &envs[env];
         es->experiment_num = ex;
@@ -99,7 +108,8 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_st
 // env is parked (auto_reset off and the episode is over): nothing else happens on this tick.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ inline bool phase_begin(const EnvParams& P, const int env, const int i, const bool env_ok, hk_env_state& es,
-                                   Hot& h, float& hfx, float& hfz, hk_agent_state* agents, hk_episode_result* results)
+                                   Hot& h, float& hfx, float& hfz, hk_agent_state* agents, hk_episode_result* results,
+                                   const MctsDev& M, const int set)
 {
     const bool me = env_ok && i < P.A;
     hk_agent_state* a = me ? &agents[(size_t)env * P.A + i] : nullptr;
@@ -153,6 +163,14 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
         es.episode_steps = 0;
         es.inactive_mask = 0;
         es.initial_started = 1;
+        if (M.st) {
+            // prepareForReuse + initialPlan (HKA:84-96, 428-452): planner state cleared, first plan requested (T = 1.5 s)
+            if (me) mcts_reset_state(&M.st[(size_t)env * P.A + i]);
+            uint32_t req = 0;
+            for (int e = 0; e < P.A; e++) if (P.high_mode[e] == HK_HIGH_MCTS) req |= 1u << e;
+            mcts_post_request(P, M, set, env, i, req, 0, es.episodes_done, P.mcts_iter0, P.mcts_lat0,
+                              h.section_index, h.lane, h.lane_changes, h.final_steer);
+        }
     }
     // own pose / flags (after a possible reset)
     float px = 0, pz = 0, fx = 0, fz = 1;
@@ -226,7 +244,7 @@ __device__ inline int calculate_lane(const EnvParams& P, const SecDev& s, float 
 // phase C of a tick (after every ego's controls are known)
 __device__ inline void phase_move(const EnvParams& P, const TabView& T, const int env, const int i, const bool env_ok,
                                   hk_env_state& es, Hot& h, float& hfx, float& hfz, hk_agent_state* agents, const float* act_steer,
-                                  const int* act_branch)
+                                  const int* act_branch, hk_mcts_state* mcts_all)
 {
     const bool me = env_ok && i < P.A;
     const int episode_steps = es.episode_steps;
@@ -455,6 +473,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                     else if (cur_lane != lane) lc += dl;
                     h.lane_changes = lc;
                     h.section_index = index; h.lane = lane;
+                    if (mcts_all) mcts_all[(size_t)env * P.A + i].sec_time[index & 3] = episode_steps;   // sectionTimes HKA:651
                     if (index == P.laps * L + 1) {                         // ReachGoalSection REC:469-474
                         h.time_steps = episode_steps;
                         fl = deactivate_fields(P, h, fl);

@@ -81,6 +81,11 @@ class RacingEnv:
         self._ck(self.L.hk_get_episode_results(self.h, out.ctypes.data_as(C.POINTER(_lib.EpisodeResult))))
         return out
 
+    def mcts_state(self):
+        out = np.zeros((self.E, self.A), np.dtype(_lib.MctsState))
+        self._ck(self.L.hk_get_mcts_state(self.h, out.ctypes.data_as(C.POINTER(_lib.MctsState))))
+        return out
+
     def observations(self):
         out = np.zeros((self.E, self.A, self.obs_dim), np.float32)
         self._ck(self.L.hk_get_observations(self.h, out.ctypes.data_as(C.POINTER(C.c_float))))

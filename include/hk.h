@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define HK_ABI_VERSION 1
+#define HK_ABI_VERSION 2
 #define HK_MAX_AGENTS 8      /* ABI capacity; the round-1 kernels accept num_agents <= 4 (largest reference scene) */
 #define HK_MAX_SECTIONS 64   /* Oval 24, Complex 41 */
 #define HK_NUM_SENSORS 9     /* MLAgent_Sensors.prefab */
@@ -107,7 +107,47 @@ typedef struct hk_config {
     int32_t num_walls;
     const hk_section* sections;
     const hk_wall_seg* walls;
+    /* MCTS high-level planner (HighMode == HK_HIGH_MCTS; KartMCTS.cs, KartDiscreteGame.cs, HKA:172-284,330-402).
+     * gameParams (HKA:38-52), scene values {timePrecision 100, sectionWindow 2, treeSearchDepth 8, velocityBucketSize 2}.
+     * The reference searches on a background thread under a WALL-CLOCK budget (T = 1.5 s at reset, 0.9 s every 100
+     * ticks) with System.Random / MathNet draws; here the budget is an iteration count, the plan becomes visible a fixed
+     * number of ticks after it was requested, and the draws are Philox-4x32 keyed by mcts_seed ("parity unpinned"). */
+    int32_t time_precision[HK_MAX_AGENTS];
+    int32_t section_window[HK_MAX_AGENTS];
+    int32_t mcts_iterations;          /* search iterations of a 100-tick replan (stands for T = 0.9 s) */
+    int32_t mcts_initial_iterations;  /* of the plan made at reset (T = 1.5 s) */
+    int32_t mcts_latency_ticks;       /* ticks until a replan's result is used (0.9 s = 45 ticks) */
+    int32_t mcts_initial_latency_ticks;/* same for the plan made at reset (1.5 s = 75 ticks = the start hold) */
+    uint32_t mcts_seed;
+    int32_t reserved_cfg[3];
 } hk_config;
+
+#define HK_MCTS_MAX_DEPTH 8      /* gameParams.treeSearchDepth <= 8 */
+#define HK_MCTS_MAX_ACTIONS 20   /* 5 velocity buckets x 4 lanes (KartDiscreteGame.cs:333-347) */
+
+/* Planner state of one agent (kept beside hk_agent_state; HighMode MCTS agents only).  `best` is what the reference
+ * holds in bestStates (HKA:70,252): for each future section the game reached by every player, each player's lane and
+ * max_velocity; `pend` is a finished search that becomes `best` at episode step ready_step. */
+typedef struct hk_mcts_plan {
+    int32_t n_states;                                  /* 0..HK_MCTS_MAX_DEPTH */
+    int32_t n_players;
+    int32_t section[HK_MCTS_MAX_DEPTH];                /* lastCompletedSection of the state */
+    uint8_t player_agent[HK_MAX_AGENTS];               /* Agents[] index of each player */
+    uint8_t lane[HK_MCTS_MAX_DEPTH][HK_MAX_AGENTS];
+    uint8_t vel[HK_MCTS_MAX_DEPTH][HK_MAX_AGENTS];     /* max_velocity */
+} hk_mcts_plan;
+
+typedef struct hk_mcts_state {
+    int32_t sec_time[4];                               /* KartAgent.sectionTimes (KA:124), ring over section & 3 */
+    int32_t ready_step;                                /* episode step at which `pend` replaces `best`; -1: nothing pending */
+    int32_t searches;                                  /* searches started since hk_create (debug / RNG stream id) */
+    hk_mcts_plan best, pend;
+    /* opponentUpcomingLanes / opponentUpcomingVelocities (HKA:77-78): this agent's belief about every other agent's
+     * plan, keyed by section % L; 0 = no entry */
+    uint8_t belief_lane[HK_MAX_AGENTS][HK_MAX_SECTIONS];
+    uint8_t belief_vel[HK_MAX_AGENTS][HK_MAX_SECTIONS];
+} hk_mcts_state;
+
 
 /* Per-agent persistent state: the fields of KartAgent (KA:102-128), ArcadeKart (AK:190-205) and the Rigidbody that
  * survive a tick.  This IS the device record (one per [env][agent]); hk_get/set_agent_state copy it verbatim, which
@@ -213,6 +253,8 @@ int hk_get_env_state(hk_handle h, hk_env_state* out /*[E]*/);
 int hk_set_env_state(hk_handle h, const hk_env_state* in /*[E]*/);
 int hk_get_episode_results(hk_handle h, hk_episode_result* out /*[E][A]*/);
 int hk_get_lq_debug(hk_handle h, int env, int ego, hk_lq_debug* out);
+/* planner state of every agent, [E][A] (zeros for agents that are not HighMode MCTS) */
+int hk_get_mcts_state(hk_handle h, hk_mcts_state* out /*[E][A]*/);
 
 /* KartLQR.solveFeedbackLQR (AI/LQR/KartLQR.cs:17) batched, 1:1 incl. quirks Q1 (block-transposed LHS) and Q2.
  * A[b][N][4][4], B[b][N][4][2], Q[b][N][n][n], q[b][N][n], R[b][N][2][2], x0[b][n], n = 4N; u0_out[b][2].

@@ -289,6 +289,24 @@ static void reset_env(hko_env* e, int env)
         /* Activate KA:421-435 */
         a->flags = HK_F_ACTIVE | HK_F_ENABLED;               /* m_CanMove stays false until StartRaceAfterDelay */
     }
+    if (e->mcts) {
+        /* prepareForReuse HKA:428-452 (beliefs, bestStates cleared; sectionTimes[m_SectionIndex] = 0 KA:212), then
+         * initialPlan -> planWithMCTS(T: 1.5) HKA:84-96 once every agent is placed (deviation, see hk_oracle_mcts.c) */
+        for (int i = 0; i < e->A; i++) {
+            hk_mcts_state* m = &e->mcts[(size_t)env * e->A + i];
+            const int searches = m->searches;
+            memset(m, 0, sizeof(*m));
+            m->searches = searches;
+            m->ready_step = -1;
+        }
+        for (int i = 0; i < e->A; i++) {
+            if (e->cfg.high_mode[i] != HK_HIGH_MCTS) continue;
+            hk_mcts_state* m = &e->mcts[(size_t)env * e->A + i];
+            hko_mcts_search(e, env, i, e->cfg.mcts_initial_iterations, &m->pend);
+            m->searches += 1;
+            m->ready_step = e->cfg.mcts_initial_latency_ticks;
+        }
+    }
 }
 
 static void snapshot_results(hko_env* e, int env)
@@ -391,10 +409,15 @@ static void solve_lqr(hko_env* e, int env, int ego)
         /* :750-777 target lane / velocity: own plan, or the ego's BELIEF about k's plan (opponentUpcomingLanes,
          * only ever filled by the MCTS planner, HKA:395-400) -> empty for Fixed agents */
         pt2 lane; double vel;
+        const hk_mcts_state* bel = e->mcts ? &e->mcts[(size_t)env * A + ego] : NULL;   /* the EGO's beliefs (HKA:77-78) */
         if (ki == ego && me->plan_lane[idx] != 0) {
             lane = lane_marker(e, idx, me->plan_lane[idx]);
             double pv = me->plan_vel[idx] + (fixed ? 0 : cfg->velocity_bucket_size[ego] * 2);
             vel = (double)e->max_speed < pv ? (double)e->max_speed : pv;   /* Math.Min :757 */
+        } else if (ki != ego && bel && bel->belief_lane[ki][idx] != 0) {   /* :767-771 */
+            lane = lane_marker(e, idx, bel->belief_lane[ki][idx]);
+            double pv = (float)bel->belief_vel[ki][idx] + (fixed ? 0 : cfg->velocity_bucket_size[ego] * 2);
+            vel = (double)e->max_speed < pv ? (double)e->max_speed : pv;
         } else {
             lane = lane_marker(e, idx, 0); vel = e->max_speed;             /* :761-762 / :774-775 */
         }
@@ -404,6 +427,10 @@ static void solve_lqr(hko_env* e, int env, int ego)
         if (ki == ego && me->plan_lane[idx2] != 0) {
             nextLane = lane_marker(e, idx2, me->plan_lane[idx2]);
             double pv = me->plan_vel[idx2] + (fixed ? 0 : cfg->velocity_bucket_size[ego] * 2);
+            nextVel = (double)e->max_speed < pv ? (double)e->max_speed : pv;
+        } else if (ki != ego && bel && bel->belief_lane[ki][idx2] != 0) {  /* :797-801 */
+            nextLane = lane_marker(e, idx2, bel->belief_lane[ki][idx2]);
+            double pv = (float)bel->belief_vel[ki][idx2] + (fixed ? 0 : cfg->velocity_bucket_size[ego] * 2);
             nextVel = (double)e->max_speed < pv ? (double)e->max_speed : pv;
         } else {
             nextLane = lane_marker(e, idx2, 0); nextVel = e->max_speed;
@@ -537,8 +564,13 @@ static void solve_lqr(hko_env* e, int env, int ego)
                     ov = (double)e->max_speed < pv ? (double)e->max_speed : pv;         /* :1044 */
                 } else ov = e->max_speed;                                               /* :1049 */
             } else {
-                ol = lane_marker(e, io, 0);                                             /* believed plans empty */
-                ov = oteam[j] ? max_speed_for_state(e, o) : e->max_speed;               /* :1158 / :1062 */
+                const int bl = bel ? bel->belief_lane[oi][io] : 0;                      /* :1054 / :1150 */
+                ol = lane_marker(e, io, bl);
+                if (oteam[j]) ov = max_speed_for_state(e, o);                           /* :1153,1158 */
+                else if (bl != 0) {
+                    double pv = (float)bel->belief_vel[oi][io] + (fixed ? 0 : cfg->velocity_bucket_size[ego] * 2);
+                    ov = (double)e->max_speed < pv ? (double)e->max_speed : pv;         /* :1057 */
+                } else ov = e->max_speed;                                               /* :1062 */
             }
             opp_t[M * 4 + XI] = ol.x; opp_t[M * 4 + ZI] = ol.z; opp_t[M * 4 + VI] = ov; opp_t[M * 4 + HI] = 0.0;
             /* opponent-target weights :1071-1094 / :1167-1189 */
@@ -711,6 +743,7 @@ static void on_trigger_enter(hko_env* e, int env, int ai, int t)
         if (is_straight(e, sec) != is_straight(e, index)) a->lane_changes = 0;          /* :641 */
         else if (a->lane != lane) a->lane_changes += dl;                                /* :645 */
         a->section_index = index; a->lane = lane;                                       /* :649-650 */
+        if (e->mcts) e->mcts[(size_t)env * e->A + ai].sec_time[index & 3] = es->episode_steps;   /* :651 sectionTimes */
         const int goal = e->cfg.laps * L + 1;                                           /* REC:165 */
         if (a->section_index == goal) {                                                 /* :652 -> REC.ResolveEvent :469-474 */
             a->time_steps = es->episode_steps;
@@ -831,8 +864,20 @@ static void step_env(hko_env* e, int env)
             if (br > 1) a->flags |= HK_F_ACCEL; else a->flags &= ~HK_F_ACCEL;
             if (br < 1) a->flags |= HK_F_BRAKE; else a->flags &= ~HK_F_BRAKE;
         }
-        if (es->episode_steps % 100 == 0 && es->episode_steps < cfg->max_episode_steps && es->episode_steps > 0 && !inactive)
+        if (es->episode_steps % 100 == 0 && es->episode_steps < cfg->max_episode_steps && es->episode_steps > 0 && !inactive) {
             if (cfg->high_mode[i] == HK_HIGH_FIXED) plan_fixed(e, i, a);                /* :331-355 */
+            else {                                                                      /* :335-350 planWithMCTS() */
+                hk_mcts_state* m = &e->mcts[(size_t)env * A + i];
+                hko_mcts_search(e, env, i, cfg->mcts_iterations, &m->pend);
+                m->searches += 1;
+                m->ready_step = es->episode_steps + cfg->mcts_latency_ticks;
+            }
+        }
+        if (cfg->high_mode[i] == HK_HIGH_MCTS) {                                        /* :366-402 */
+            hk_mcts_state* m = &e->mcts[(size_t)env * A + i];
+            if (m->ready_step >= 0 && es->episode_steps >= m->ready_step) { m->best = m->pend; m->ready_step = -1; }
+            hko_mcts_consume(e, env, i);
+        }
     }
     /* (c) ArcadeKart.FixedUpdate */
     for (int i = 0; i < A; i++) {
@@ -1009,6 +1054,8 @@ hko_env* hko_create(const hk_config* cfg)
     e->dbg = (hk_lq_debug*)calloc(na, sizeof(hk_lq_debug));
     e->act_steer = (float*)calloc(na, sizeof(float));
     e->act_branch = (int32_t*)calloc(na, sizeof(int32_t));
+    for (int i = 0; i < e->A; i++)
+        if (cfg->high_mode[i] == HK_HIGH_MCTS && !e->mcts) e->mcts = (hk_mcts_state*)calloc(na, sizeof(hk_mcts_state));
     for (size_t i = 0; i < na; i++) { e->res[i].episode = -1; e->act_branch[i] = 1; }
     const hk_kart_stats* s = &cfg->stats;
     e->max_speed = f_max(s->TopSpeed, s->ReverseSpeed);                                  /* AK:210 */
@@ -1040,6 +1087,7 @@ void hko_destroy(hko_env* e)
     if (!e) return;
     free(e->sec); free(e->sp); free(e->walls); free(e->ag); free(e->es); free(e->res); free(e->dbg);
     hko_policy_free(e);
+    free(e->mcts);
     free(e->act_steer); free(e->act_branch); free(e->perms); free(e);
 }
 
@@ -1091,6 +1139,12 @@ int hko_get_agent_state(hko_env* e, hk_agent_state* out) { memcpy(out, e->ag, si
 int hko_set_agent_state(hko_env* e, const hk_agent_state* in) { memcpy(e->ag, in, sizeof(hk_agent_state) * e->E * e->A); return 0; }
 int hko_get_env_state(hko_env* e, hk_env_state* out) { memcpy(out, e->es, sizeof(hk_env_state) * e->E); return 0; }
 int hko_set_env_state(hko_env* e, const hk_env_state* in) { memcpy(e->es, in, sizeof(hk_env_state) * e->E); return 0; }
+int hko_get_mcts_state(hko_env* e, hk_mcts_state* out)
+{
+    if (e->mcts) memcpy(out, e->mcts, sizeof(hk_mcts_state) * e->E * e->A);
+    else memset(out, 0, sizeof(hk_mcts_state) * e->E * e->A);
+    return 0;
+}
 int hko_get_episode_results(hko_env* e, hk_episode_result* out) { memcpy(out, e->res, sizeof(hk_episode_result) * e->E * e->A); return 0; }
 int hko_debug_last_game(hko_env* e, int env, int ego, hk_lq_debug* out)
 {

@@ -32,6 +32,8 @@ struct hko_env {
     int* perms;            /* [A!][A] lexicographic (REC:137-145,166) */
     float ray_agent_r;     /* stadium radius of a kart capsule sliced at the sensor height */
     float sens_c[HK_NUM_SENSORS], sens_s[HK_NUM_SENSORS];   /* cos / sin of the sensors' local yaw */
+    /* MCTS planner (hk_oracle_mcts.c): [E][A], NULL when no agent is HighMode MCTS */
+    hk_mcts_state* mcts;
     /* RL policies (hk_oracle_policy.c) */
     int n_policies;
     struct hko_policy* policy[HK_MAX_POLICIES];
@@ -54,6 +56,10 @@ static inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 }
 static inline float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
+
+/* hk_oracle_mcts.c */
+void hko_mcts_search(hko_env* e, int env, int ego, int iterations, hk_mcts_plan* plan);
+void hko_mcts_consume(hko_env* e, int env, int i);
 
 /* hk_oracle_policy.c */
 void hko_policy_decide(hko_env* e);           /* observe -> stack -> infer -> latch actions, if this tick is a decision tick */

@@ -105,6 +105,8 @@ def _env_api():
         L.hko_debug_last_game.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(HL.LqDebug)]
         L.hko_raycast_track.restype = C.c_float
         L.hko_raycast_track.argtypes = [C.c_void_p] + [C.c_float] * 5
+        L.hko_get_mcts_state.restype = C.c_int
+        L.hko_get_mcts_state.argtypes = [C.c_void_p, C.POINTER(HL.MctsState)]
         fp = C.POINTER(C.c_float)
         L.hko_policy_attach.restype = C.c_int
         L.hko_policy_attach.argtypes = [C.c_void_p, C.POINTER(HL.PolicyDesc), C.POINTER(C.c_int32), C.c_int, C.c_int]
@@ -182,6 +184,11 @@ class OracleEnv:
     def set_actions(self, steer, branch):
         s = np.ascontiguousarray(steer, np.float32); b = np.ascontiguousarray(branch, np.int32)
         self.L.hko_set_actions(self.h, s.ctypes.data_as(C.POINTER(C.c_float)), b.ctypes.data_as(C.POINTER(C.c_int32)))
+
+    def mcts_state(self):
+        out = np.zeros((self.E, self.A), np.dtype(HL.MctsState))
+        self.L.hko_get_mcts_state(self.h, out.ctypes.data_as(C.POINTER(HL.MctsState)))
+        return out
 
     def get_actions(self):
         s = np.zeros((self.E, self.A), np.float32); b = np.zeros((self.E, self.A), np.int32)

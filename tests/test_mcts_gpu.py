@@ -1,0 +1,76 @@
+"""MCTS planner on device (mcts_search_kernel + the request / consume hooks of the fused tick kernel, through the C ABI)
+vs the CPU oracle: planner state (pending / visible plans, beliefs, section times) and every agent field bit-identical,
+tick by tick, including time-out resets that re-plan."""
+import numpy as np
+import pytest
+import oracle_lib as O
+from hierarchicalkarting_amd import _lib
+
+pytestmark = pytest.mark.gpu
+MC, FX = _lib.HK_HIGH_MCTS, _lib.HK_HIGH_FIXED
+
+
+def _pair(E, A, high, **kw):
+    import hierarchicalkarting_amd as hk
+    kw.setdefault("tree_search_depth", [8 if h == MC else 5 for h in high])
+    b = hk.make_config(E, A, high_mode=high, **kw)
+    g = hk.RacingEnv(b)
+    o = O.OracleEnv(b)
+    g.reset(); o.reset()
+    return g, o
+
+
+def _cmp(g, o, t, full=True):
+    gm, om = g.mcts_state(), o.mcts_state()
+
+    def walk(x, y, path):
+        if x.dtype.names:
+            for n in x.dtype.names:
+                walk(x[n], y[n], path + "." + n)
+        else:
+            assert np.array_equal(x, y), (t, path, np.argwhere(x != y)[:4].tolist())
+    walk(gm, om, "mcts")
+    if full:
+        gs, os_ = g.agent_state(), o.agent_state()
+        for name in gs.dtype.names:
+            assert np.array_equal(gs[name], os_[name]), (t, name)
+        ge, oe = g.env_state(), o.env_state()
+        for name in ("episode_steps", "inactive_mask", "experiment_num", "episodes_done", "status", "initial_started"):
+            assert np.array_equal(ge[name], oe[name]), (t, name)
+
+
+def test_first_plan_matches():
+    g, o = _pair(16, 2, [MC, FX], jitter_seed=3, mcts_iterations=48)
+    _cmp(g, o, 0)
+    assert (g.mcts_state()["pend"]["n_states"][:, 0] == 8).all()
+
+
+def test_two_agent_mcts_vs_fixed_tick_by_tick():
+    g, o = _pair(6, 2, [MC, FX], jitter_seed=5, mcts_iterations=32)
+    for t in range(1, 331):
+        g.step(1); o.step(1)
+        _cmp(g, o, t, full=(t % 10 == 0 or 70 < t < 80 or 140 < t < 150))
+
+
+def test_four_agents_all_mcts_odd_steps_and_timeout_resets():
+    g, o = _pair(12, 4, [MC, MC, MC, MC], jitter_seed=7, mcts_iterations=16, max_episode_steps=260)
+    t = 0
+    for n in (3, 97, 1, 45, 60, 54, 7, 100, 133, 29, 71):
+        g.step(n); o.step(n); t += n
+        _cmp(g, o, t)
+    assert (g.env_state()["episodes_done"] >= 2).all()
+
+
+def test_mixed_team_complex_track():
+    g, o = _pair(8, 4, [MC, FX, MC, FX], track="complex", jitter_seed=2, mcts_iterations=20)
+    t = 0
+    for n in (100, 50, 150, 200):
+        g.step(n); o.step(n); t += n
+        _cmp(g, o, t)
+
+
+def test_create_rejects_bad_planner_budgets():
+    import hierarchicalkarting_amd as hk
+    for kw in (dict(mcts_latency_ticks=4), dict(mcts_latency_ticks=120), dict(mcts_iterations=0), dict(tree_search_depth=[9, 5])):
+        with pytest.raises(hk.HkError):
+            hk.RacingEnv(hk.make_config(2, 2, high_mode=[MC, FX], **{**dict(tree_search_depth=[8, 5]), **kw}))
