@@ -364,8 +364,12 @@ inline int env_rounds_for(const hk_config& cfg, int n_ticks)
 inline int env_launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
 {
     const int threads = cfg.num_envs * 4;
-    hipLaunchKernelGGL(env_run_kernel, dim3((threads + 255) / 256), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs, d.results,
-                       d.games, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status, d.tab_lds ? 1 : 0, d.mcts);
+    if (d.mcts.st)
+        hipLaunchKernelGGL(env_run_kernel<true>, dim3((threads + 255) / 256), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs, d.results,
+                           d.games, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status, d.tab_lds ? 1 : 0, d.mcts);
+    else
+        hipLaunchKernelGGL(env_run_kernel<false>, dim3((threads + 255) / 256), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs, d.results,
+                           d.games, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status, d.tab_lds ? 1 : 0, d.mcts);
     return launch_check(err, "env_run_kernel");
 }
 

@@ -38,11 +38,15 @@ __global__ __launch_bounds__(256) void env_check_kernel(const hk_env_state* envs
     if (env < E && (envs[env].reserved[0] != 0 || envs[env].reserved[1] != 0)) atomicOr(status, 4);
 }
 
+// HAS_MCTS = false is the headline path: the planner hooks (request / consume / beliefs) compile away entirely
+template <bool HAS_MCTS>
 __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
                                                       hk_episode_result* results, GameDesc* games, int* queue_cnt_all,
                                                       int* queue_all, int set, const float* act_steer, const int* act_branch,
-                                                      hk_lq_debug* dbg_out, int* status, int use_lds, MctsDev M)
+                                                      hk_lq_debug* dbg_out, int* status, int use_lds, MctsDev Marg)
 {
+    MctsDev M{};
+    if (HAS_MCTS) M = Marg;
     __shared__ KartS ks[256];
     extern __shared__ __align__(16) unsigned char smem[];
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;

@@ -116,8 +116,8 @@ def test_invalid_configs_are_refused():
     import hierarchicalkarting_amd as hk
     from hierarchicalkarting_amd import _lib
     with pytest.raises(_lib.HkError) as e:
-        hk.RacingEnv(hk.make_config(2, 4, high_mode=_lib.HK_HIGH_MCTS))
-    assert e.value.code == _lib.HK_ERR_UNSUPPORTED
+        hk.RacingEnv(hk.make_config(2, 4, high_mode=_lib.HK_HIGH_MCTS, tree_search_depth=12))   # gameParams.treeSearchDepth <= 8
+    assert e.value.code == _lib.HK_ERR_INVALID
     with pytest.raises(_lib.HkError) as e:
         hk.RacingEnv(hk.make_config(2, 4, env_mode=_lib.HK_MODE_TRAINING))
     assert e.value.code == _lib.HK_ERR_UNSUPPORTED
