@@ -103,6 +103,53 @@ def bench_rl(a, rank, local_rank, world, dist, torch, hk):
         dist.destroy_process_group()
 
 
+def bench_mcts(a, rank, local_rank, world, dist, torch, hk):
+    """BASELINE.json configs[2]: 4-agent Complex track, every agent MCTS high level + LQNG low level, 16 384 envs per GPU.
+    The planner's wall-clock budget of the reference is an iteration budget here (--mcts-iterations per 100-tick replan)."""
+    from hierarchicalkarting_amd import _lib
+    E = a.envs_per_gpu if a.envs_per_gpu != 65536 else 16384
+    A = 4
+    env = hk.RacingEnv(hk.make_config(E, A, track="complex", high_mode=[_lib.HK_HIGH_MCTS] * A, tree_search_depth=8,
+                                      mcts_iterations=a.mcts_iterations, jitter_seed=0x5EED0000, env_id_base=rank * E, device_id=local_rank))
+    env.reset()
+    env.step(a.warmup)
+    env.synchronize()
+
+    def barrier():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        env.synchronize()
+
+    env.prof_enable(True)
+    env.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    env.step(a.steps)
+    env.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = env.prof_read()
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        m = env.mcts_state()
+        out = {"metric": "env-steps/sec (4-agent Complex, MCTS-LQNG)", "value": E * world * a.steps / dt, "unit": "env-steps/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "4-agent Complex track (41 sections), MCTS high level (%d iterations per replan, depth 8, replan every 100 ticks) "
+                                      "+ LQNG low level, %d envs per GPU" % (a.mcts_iterations, E), "envs_per_gpu": E, "agents": A,
+                          "searches_per_agent_mean": float(m["searches"].mean())},
+               "kernel_total_ms": {k: v[0] for k, v in prof.items()},
+               "note": "the planner kernel (mcts_search_kernel, one lane per search) is not bracketed by hk_prof: its share = wall time - the stages above"}
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,8 +159,10 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--agents", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=("lqng", "rl"), default="lqng",
-                    help="lqng: BASELINE.json configs[1] (the headline); rl: 2v2 Oval with the RL low-level actor on device (configs[3] shape)")
+    ap.add_argument("--mcts-iterations", type=int, default=64)
+    ap.add_argument("--workload", choices=("lqng", "rl", "mcts"), default="lqng",
+                    help="lqng: BASELINE.json configs[1] (the headline); rl: 2v2 Oval with the RL low-level actor on device (configs[3] shape); "
+                         "mcts: 4-agent Complex track, MCTS-LQNG, 16 384 envs (configs[2])")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -139,6 +188,8 @@ def main():
 
     if a.workload == "rl":
         return bench_rl(a, rank, local_rank, world, dist, torch, hk)
+    if a.workload == "mcts":
+        return bench_mcts(a, rank, local_rank, world, dist, torch, hk)
     E = a.envs_per_gpu
     seed = 0x5EED0000
     env = hk.RacingEnv(hk.make_config(E, a.agents, jitter_seed=seed, env_id_base=rank * E, device_id=local_rank))

@@ -297,6 +297,9 @@ static int step_ticks(hk_handle h, int n_ticks)
         if (rc) { g_last_error = h->err; return rc; }
         h->prof.end(1, e, h->stream);
     }
+    // planner searches requested in the last rounds run before hk_step returns (the next call may be far away in ticks)
+    rc = hk::env_flush_mcts(h->dev, h->stream, h->err);
+    if (rc) { g_last_error = h->err; return rc; }
     rc = hk::env_launch_check(h->dev, h->cfg, h->stream, h->err);
     if (rc) { g_last_error = h->err; return rc; }
     return HK_OK;

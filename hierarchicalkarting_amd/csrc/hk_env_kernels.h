@@ -37,9 +37,13 @@ struct EnvDevice {
     int tab_lds = 0;               // dynamic LDS bytes the env kernels are launched with (0: read tables from global)
     // MCTS planner (hk_env_mcts.h): all null / 0 when no agent is HighMode MCTS
     MctsDev mcts{};
+    int mset = 0;                  // planner queue set the tick kernel currently fills
+    int mcts_rounds = 0;           // rounds of the tick kernel since the last search launch
     SecGeo* sec_geo = nullptr;
     EnvParams P{};
 };
+
+constexpr int MCTS_MIN_LATENCY = 40;   // (MCTS_FLUSH_ROUNDS + 1) * RUN_CAP: see env_flush_mcts
 
 namespace detail {
 
@@ -78,7 +82,7 @@ int upload(T** dst, const std::vector<T>& v, std::string& err)
 inline void env_destroy(EnvDevice& d)
 {
     void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.status, d.games, d.queue_cnt, d.queue, d.env_ids, d.tab, d.perms,
-                    d.mcts.st, d.mcts.req, d.mcts.queue, d.mcts.nodes, d.sec_geo};
+                    d.mcts.st, d.mcts.req, d.mcts.qcnt, d.mcts.queue, d.mcts.nodes, d.mcts.dt_tab, d.mcts.load_tab, d.mcts.rad_tab, d.sec_geo};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = EnvDevice{};
 }
@@ -102,9 +106,9 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
                 cfg.time_precision[i] < 1 || cfg.section_window[i] < 1) { err = "hk_create: bad MCTS gameParams (depth 1..8, bucket, precision, window >= 1)"; return HK_ERR_INVALID; }
             // a search requested on tick t runs between two launches of the tick kernel (<= RUN_CAP ticks each) and must be
             // finished before tick t + latency; it must also have been consumed before the next request (every 100 ticks)
-            if (cfg.mcts_iterations < 1 || cfg.mcts_initial_iterations < 1 || cfg.mcts_latency_ticks <= RUN_CAP || cfg.mcts_latency_ticks >= 100 ||
-                cfg.mcts_initial_latency_ticks <= RUN_CAP || cfg.mcts_initial_latency_ticks >= 100) {
-                err = "hk_create: MCTS budget / latency out of range (iterations >= 1, RUN_CAP < latency ticks < 100)"; return HK_ERR_INVALID;
+            if (cfg.mcts_iterations < 1 || cfg.mcts_initial_iterations < 1 || cfg.mcts_latency_ticks <= MCTS_MIN_LATENCY || cfg.mcts_latency_ticks >= 100 ||
+                cfg.mcts_initial_latency_ticks <= MCTS_MIN_LATENCY || cfg.mcts_initial_latency_ticks >= 100) {
+                err = "hk_create: MCTS budget / latency out of range (iterations >= 1, 40 < latency ticks < 100)"; return HK_ERR_INVALID;
             }
         }
         if (cfg.low_mode[i] != HK_LOW_LQR && cfg.low_mode[i] != HK_LOW_RL) { err = "hk_create: LowMode MPC is dead code in the reference"; return HK_ERR_UNSUPPORTED; }
@@ -270,7 +274,25 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         HK_ALLOC(d.mcts.req, na * sizeof(MctsReq));
         HK_ALLOC(d.mcts.queue, 2 * 2 * na * sizeof(int));
         HK_ALLOC(d.mcts.nodes, (size_t)d.mcts.slots * d.mcts.pool_cap * sizeof(MNode));
-        d.mcts.qcnt = d.queue_cnt + 7;
+        HK_ALLOC(d.mcts.qcnt, 4 * sizeof(int));
+        // move tables: one set for the whole handle, so every MCTS agent must share bucket size and time precision
+        int ego0 = -1;
+        for (int i = 0; i < A; i++) {
+            if (cfg.high_mode[i] != HK_HIGH_MCTS) continue;
+            if (ego0 < 0) ego0 = i;
+            else if (cfg.velocity_bucket_size[i] != cfg.velocity_bucket_size[ego0] || cfg.time_precision[i] != cfg.time_precision[ego0]) {
+                err = "hk_create: MCTS agents with different velocityBucketSize / timePrecision are not built yet"; return HK_ERR_UNSUPPORTED;
+            }
+        }
+        int nv = 0;
+        for (int v = 6; v < (int)P.max_speed && nv < 5; v += cfg.velocity_bucket_size[ego0]) nv++;
+        d.mcts.nv = nv;
+        const int ntab = L * 4 * (nv + 1) * HK_MCTS_MAX_ACTIONS;
+        HK_ALLOC(d.mcts.dt_tab, (size_t)ntab * sizeof(int));
+        HK_ALLOC(d.mcts.load_tab, (size_t)L * 4 * HK_MCTS_MAX_ACTIONS * sizeof(float));
+        HK_ALLOC(d.mcts.rad_tab, (size_t)L * 4 * 4 * sizeof(float));
+        hipLaunchKernelGGL(mcts_table_kernel, dim3((ntab + 255) / 256), dim3(256), 0, stream, P, d.mcts, ego0);
+        if ((e = hipGetLastError()) != hipSuccess) { err = std::string("mcts_table_kernel: ") + hipGetErrorString(e); return HK_ERR_HIP; }
     }
 #undef HK_ALLOC
     // REC.Start :148-168: every agent starts inactive; results carry episode = -1; RL branch defaults to "coast"
@@ -299,12 +321,23 @@ inline int launch_check(std::string& err, const char* what)
     return HK_OK;
 }
 
-// the planner searches queued in set `set` (a no-op kernel when the queue is empty)
-inline int env_launch_mcts(EnvDevice& d, int set, hipStream_t stream, std::string& err)
+// Run the planner searches queued so far and hand the tick kernel the other (cleared) queue set.  A search requested on
+// tick t must be finished before tick t + latency (> RUN_CAP, checked in env_create); the tick kernel advances an env by at
+// most RUN_CAP ticks per round, so flushing every MCTS_FLUSH_ROUNDS rounds with (MCTS_FLUSH_ROUNDS + 1) * RUN_CAP < latency
+// is early enough — and batching the requests of several rounds into one launch matters, because a launch takes as long
+// as its slowest search however few searches it holds.
+constexpr int MCTS_FLUSH_ROUNDS = 4;
+static_assert((MCTS_FLUSH_ROUNDS + 1) * RUN_CAP <= MCTS_MIN_LATENCY, "a queued search must finish before its plan is due");
+inline int env_flush_mcts(EnvDevice& d, hipStream_t stream, std::string& err)
 {
     if (!d.mcts.st) return HK_OK;
-    hipLaunchKernelGGL(mcts_search_kernel, dim3((2 * d.mcts.slots + 63) / 64), dim3(64), 0, stream, d.P, d.mcts, set);
-    return launch_check(err, "mcts_search_kernel");
+    hipLaunchKernelGGL(mcts_search_kernel, dim3((2 * d.mcts.slots + 63) / 64), dim3(64), 0, stream, d.P, d.mcts, d.mset);
+    int rc = launch_check(err, "mcts_search_kernel");
+    if (rc) return rc;
+    d.mset ^= 1;
+    d.mcts_rounds = 0;
+    if (hipMemsetAsync(d.mcts.qcnt + d.mset * 2, 0, 2 * sizeof(int), stream) != hipSuccess) { err = "mcts queue memset"; return HK_ERR_HIP; }
+    return HK_OK;
 }
 
 inline int env_reset(EnvDevice& d, const hk_config& cfg, const int32_t* env_ids, int n, int experiment_num, hipStream_t stream,
@@ -327,14 +360,11 @@ inline int env_reset(EnvDevice& d, const hk_config& cfg, const int32_t* env_ids,
         dids = d.env_ids;
     }
     const int threads = cnt * 4;
-    // first plans of MCTS agents go to the queue set the NEXT tick-kernel launch clears (its own set is filled by that launch)
-    const int mset = (d.round & 1) ^ 1;
-    if (d.mcts.st && hipMemsetAsync(d.mcts.qcnt + mset * 8 - 1, 0, 2 * sizeof(int), stream) != hipSuccess) { err = "hk_reset: memset"; return HK_ERR_HIP; }
     hipLaunchKernelGGL(env_reset_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.envs, dids, cnt, experiment_num,
-                       d.mcts, mset);
+                       d.mcts, d.mset);
     int rc = launch_check(err, "env_reset_kernel");
     if (rc) return rc;
-    if ((rc = env_launch_mcts(d, mset, stream, err))) return rc;
+    if ((rc = env_flush_mcts(d, stream, err))) return rc;          // the first plans (T = 1.5 s in the reference)
     if (hipStreamSynchronize(stream) != hipSuccess) { err = "hk_reset: sync failed"; return HK_ERR_HIP; }
     return HK_OK;
 }
@@ -366,10 +396,10 @@ inline int env_launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream
     const int threads = cfg.num_envs * 4;
     if (d.mcts.st)
         hipLaunchKernelGGL(env_run_kernel<true>, dim3((threads + 255) / 256), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs, d.results,
-                           d.games, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status, d.tab_lds ? 1 : 0, d.mcts);
+                           d.games, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status, d.tab_lds ? 1 : 0, d.mcts, d.mset);
     else
         hipLaunchKernelGGL(env_run_kernel<false>, dim3((threads + 255) / 256), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs, d.results,
-                           d.games, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status, d.tab_lds ? 1 : 0, d.mcts);
+                           d.games, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status, d.tab_lds ? 1 : 0, d.mcts, d.mset);
     return launch_check(err, "env_run_kernel");
 }
 
@@ -378,7 +408,7 @@ inline int env_launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream
 {
     const int ngames = cfg.num_envs * cfg.num_agents;
     const int set = d.round & 1;
-    { int rcm = env_launch_mcts(d, set, stream, err); if (rcm) return rcm; }      // planner searches requested in this round
+    if (d.mcts.st && ++d.mcts_rounds >= MCTS_FLUSH_ROUNDS) { int rcm = env_flush_mcts(d, stream, err); if (rcm) return rcm; }
     const int* qc = d.queue_cnt + set * 8;
     const int* qu = d.queue + (size_t)set * 3 * ngames;
     int rc = HK_OK;

@@ -12,8 +12,9 @@
 //     agent's plan and its beliefs about the other karts (HKA:366-402).
 // One lane per search in this first version.  Data layout differs from the reference (and from the CPU oracle, which
 // follows the C#): ONE running game state per search instead of a state per tree node, nodes are 32-byte records in a
-// first-child / next-sibling arena, and the legal-move scan of a position is done once and shared by isOver, nextMoves
-// and the rollout ordering (the reference recomputes it three times).  The draws (Philox) and every float expression
+// first-child / next-sibling arena, the legal-move scan of a position is done once and shared by isOver, nextMoves and
+// the rollout ordering (the reference recomputes it three times), and what a move costs (time, tire load) comes from
+// tables filled once at hk_create by the very functions that restate applyAction / computeTOC.  The draws (Philox) and every float expression
 // are the same, so the plans agree with the oracle's bit for bit.
 #pragma once
 #include "hk_env_device.h"
@@ -40,9 +41,17 @@ static_assert(sizeof(MNode) == 32, "MNode layout");
 struct MctsDev {
     hk_mcts_state* st;      // [E][A]; nullptr: no agent plans with MCTS
     MctsReq* req;           // [E][A]
-    int* qcnt;              // &queue_cnt[7]; set s counts at [s * 8] (double buffered over rounds with the LQ game queues)
+    int* qcnt;              // [2 sets][2]: {queued searches, arena slots handed out}; the host flips the set when it launches
+                            // the search kernel (every few rounds of the tick kernel, see env_launch_lqn) and clears the new one
     int* queue;             // [2][2*E*A]: (env * A + agent) | generation << 24
     MNode* nodes;           // [slots][pool_cap]
+    // move tables, filled once by mcts_table_kernel with the same device functions the search would call (so they are
+    // bit-identical to evaluating applyAction on the spot): what a move costs depends only on the section (mod L), the
+    // kart's lane and velocity bucket and the action — not on the tree
+    int* dt_tab;            // [L][4 lanes][nv + 1 buckets][20 actions]: time added (x timePrecision); < 0 = infeasible
+    float* load_tab;        // [L][4][20]: tireLoad of the move
+    float* rad_tab;         // [L][4][4]: radiusOfLane(section, from, to)
+    int nv;                 // velocity buckets of the action list (<= 5)
     int pool_cap;
     int slots;              // searches the arena can hold at once (E * number of MCTS agents)
 };
@@ -82,7 +91,7 @@ __device__ inline void mcts_post_request(const EnvParams& P, const MctsDev& M, i
         r->episode_steps = episode_steps; r->epoch = epoch; r->iterations = iterations; r->gen += 1;
         mine->searches += 1;
         mine->ready_step = ready_step;
-        const int slot = atomicAdd(&M.qcnt[set * 8], 1);
+        const int slot = atomicAdd(&M.qcnt[set * 2], 1);
         // an ego can post twice in one launch (a replan tick, then the episode ends and the reset plans again): the queue set
         // holds 2 entries per agent and the entry carries the request generation, so the search kernel skips the stale one
         M.queue[(size_t)set * 2 * P.E * P.A + slot] = (env * P.A + i) | ((r->gen & 0xFF) << 24);
@@ -150,6 +159,7 @@ struct MctsCtx {
     const TabView* T;
     int bucket, precision, vmax, nact;
     uint32_t key0, key1, c1, c2, draw;
+    const int* dt_tab; const float* load_tab; const float* rad_tab; int nv;
 };
 
 __device__ inline void mc_draw(MctsCtx& C, uint32_t r[4]) { philox4x32(C.draw++, C.c1, C.c2, 0x4D435453u, C.key0, C.key1, r); }
@@ -297,33 +307,47 @@ __device__ inline int mc_up_next(const DGame& g)
     return -1;
 }
 
-// nextMoves KDG:318-411 for the player who is up next (np), with the time each legal move adds
+__device__ inline int mc_vb(const MctsCtx& C, int minv) { return minv == 0 ? 0 : 1 + (minv - 6) / C.bucket; }
+
+// nextMoves KDG:318-411 for the player who is up next (np), with the time each legal move adds (from the move tables)
 __device__ inline void mc_eval_moves(const MctsCtx& C, const DGame& g, int np, MoveEval& mv)
 {
     const DKart& cur = g.k[np];
+    const int L = C.P->L, sm = cur.section % L;
     const bool str = mc_straight(C, cur.section);
+    const float wear = (float)cur.tire / 10000.0f;
+    float vlim[4];                                                   // lateral-g speed limit per target lane
+    for (int l = 0; l < 4; l++) vlim[l] = mc_max_speed(C, C.rad_tab[(sm * 4 + (cur.lane - 1)) * 4 + l], wear);
+    const int* dtp = C.dt_tab + (size_t)((sm * 4 + (cur.lane - 1)) * (C.nv + 1) + mc_vb(C, cur.minv)) * MC_MAXA;
     mv.n = 0;
     for (int a = 0; a < C.nact; a++) {
-        int minv, maxv, lane;
-        mc_action(C, a, minv, maxv, lane);
+        const int lane = (a & 3) + 1, minv = 6 + (a >> 2) * C.bucket;
         const int dl = lane > cur.lane ? lane - cur.lane : cur.lane - lane;
         if (str && cur.lchg + dl > C.P->max_lane_changes) continue;
-        const float radius = mc_radius(C, cur.section, cur.lane, lane);
-        if (mc_max_speed(C, radius, (float)cur.tire / 10000.0f) < (float)minv) continue;
-        DKart nk; int dt;
-        if (!mc_apply(C, cur, minv, maxv, lane, nk, dt)) continue;
+        if (vlim[lane - 1] < (float)minv) continue;
+        const int dt = dtp[a];
+        if (dt < 0) continue;
         mv.idx[mv.n] = (unsigned char)a; mv.dt[mv.n] = dt; mv.n++;
     }
 }
 
-// makeMove KDG:416-443 on the running state
+// makeMove KDG:416-443 on the running state (applyAction through the move tables)
 __device__ inline void mc_make_move(const MctsCtx& C, DGame& g, int np, int a)
 {
-    int minv, maxv, lane, dt;
+    DKart& k = g.k[np];
+    const int L = C.P->L, sm = k.section % L;
+    int minv, maxv, lane;
     mc_action(C, a, minv, maxv, lane);
-    DKart nk;
-    mc_apply(C, g.k[np], minv, maxv, lane, nk, dt);
-    g.k[np] = nk;
+    const int dl = lane > k.lane ? lane - k.lane : k.lane - lane;
+    int lchg;
+    if (mc_straight(C, k.section) != mc_straight(C, k.section + 1)) lchg = 0;
+    else if (lane != k.lane) lchg = k.lchg + dl;
+    else lchg = k.lchg;
+    const int dt = C.dt_tab[(size_t)((sm * 4 + (k.lane - 1)) * (C.nv + 1) + mc_vb(C, k.minv)) * MC_MAXA + a];
+    const float load = C.load_tab[(sm * 4 + (k.lane - 1)) * MC_MAXA + a];
+    k.tire = (int)(((float)k.tire / 10000.0f + load * C.P->st.TireWearFactor) * 10000.0f);
+    k.time += dt;
+    k.section += 1; k.minv = minv; k.maxv = maxv; k.lane = lane; k.lchg = lchg;
     bool allAhead = true;
     for (int i = 0; i < g.P; i++) allAhead = allAhead && (g.k[i].section > g.last);
     if (allAhead) g.last += 1;
@@ -369,6 +393,46 @@ __device__ inline bool mc_is_over(const MctsCtx& C, const DGame& g, int np, int 
     return true;
 }
 
+__device__ inline void mc_ctx_init(MctsCtx& C, const EnvParams& P, const TabView& T, const MctsDev& M, int ego)
+{
+    C.P = &P; C.T = &T;
+    C.bucket = P.vbucket[ego]; C.precision = P.time_precision[ego];
+    C.vmax = (int)P.max_speed;
+    C.nact = 0;
+    for (int i = 6; i < C.vmax; i += C.bucket) C.nact += 4;
+    if (C.nact > MC_MAXA) C.nact = MC_MAXA;
+    C.dt_tab = M.dt_tab; C.load_tab = M.load_tab; C.rad_tab = M.rad_tab; C.nv = M.nv;
+    C.key0 = 0; C.key1 = 0; C.c1 = 0; C.c2 = 0; C.draw = 0;
+}
+
+// fills the move tables (hk_create): one thread per (section, lane, velocity bucket, action)
+__global__ __launch_bounds__(256) void mcts_table_kernel(EnvParams P, MctsDev M, int ego)
+{
+    const TabView T = tab_view(P, P.tab);
+    MctsCtx C;
+    mc_ctx_init(C, P, T, M, ego);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nb = M.nv + 1;
+    if (t >= P.L * 4 * nb * MC_MAXA) return;
+    const int a = t % MC_MAXA, vb = (t / MC_MAXA) % nb, l0 = (t / (MC_MAXA * nb)) % 4, sec = t / (MC_MAXA * nb * 4);
+    int dt = -1;
+    float load = 0.0f;
+    if (a < C.nact) {
+        DKart cur;
+        cur.section = sec; cur.time = 0; cur.lane = l0 + 1; cur.tire = 0; cur.lchg = 0;
+        cur.minv = vb == 0 ? 0 : 6 + (vb - 1) * C.bucket;
+        cur.maxv = vb == 0 ? (C.bucket < C.vmax ? C.bucket : C.vmax) : ((cur.minv + C.bucket) < C.vmax ? (cur.minv + C.bucket) : C.vmax);
+        int minv, maxv, lane;
+        mc_action(C, a, minv, maxv, lane);
+        DKart nk;
+        if (!mc_apply(C, cur, minv, maxv, lane, nk, dt)) dt = dt < 0 ? dt : -1;
+        load = mc_tire_load(C, sec, (float)maxv, l0 + 1, lane);
+    }
+    M.dt_tab[t] = dt;
+    if (vb == 0) M.load_tab[(sec * 4 + l0) * MC_MAXA + a] = load;
+    if (vb == 0 && a < 4) M.rad_tab[(sec * 4 + l0) * 4 + a] = mc_radius(C, sec, l0 + 1, a + 1);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // the tree (KartMCTS.cs)
 
@@ -394,11 +458,11 @@ __device__ inline int mc_ucs(MctsCtx& C, const MNode* nd, int node)
 __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M, int set)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= M.qcnt[set * 8]) return;
+    if (q >= M.qcnt[set * 2]) return;
     const unsigned ent = (unsigned)M.queue[(size_t)set * 2 * P.E * P.A + q];
     const int pair = (int)(ent & 0xFFFFFFu);
     if (((unsigned)M.req[pair].gen & 0xFFu) != (ent >> 24)) return;          // superseded by a later request of the same ego
-    const int slot = atomicAdd(&M.qcnt[set * 8 - 1], 1);                     // arena slot (counter [6] of the set)
+    const int slot = atomicAdd(&M.qcnt[set * 2 + 1], 1);                     // arena slot
     if (slot >= M.slots) return;
     const int env = pair / P.A, ego = pair % P.A;
     const TabView T = tab_view(P, P.tab);
@@ -407,12 +471,7 @@ __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M,
     MNode* nd = M.nodes + (size_t)slot * M.pool_cap;
 
     MctsCtx C;
-    C.P = &P; C.T = &T;
-    C.bucket = P.vbucket[ego]; C.precision = P.time_precision[ego];
-    C.vmax = (int)P.max_speed;
-    C.nact = 0;
-    for (int i = 6; i < C.vmax; i += C.bucket) C.nact += 4;
-    if (C.nact > MC_MAXA) C.nact = MC_MAXA;
+    mc_ctx_init(C, P, T, M, ego);
     C.key0 = P.mcts_seed; C.key1 = (uint32_t)(P.env_id_base + env) * (uint32_t)P.A + (uint32_t)ego;
     C.c1 = (uint32_t)R.episode_steps; C.c2 = (uint32_t)R.epoch; C.draw = 0;
 
@@ -470,24 +529,26 @@ __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M,
             if (mc_is_over(C, g, np, mv.n, scores)) break;
             const int ol = T.sec[g.last % P.L].optimal_lane;
             const int sign = ol == 1 ? 1 : (ol == 4 ? -1 : 0);
-            // OrderBy(time added).ThenByDescending(max_velocity).ThenBy(|lane change|).ThenBy(sign * lane): stable
+            // OrderBy(time added).ThenByDescending(max_velocity).ThenBy(|lane change|).ThenBy(sign * lane), stable: the four
+            // keys packed into one integer (time added >= 0; max_velocity <= 255; |lane change| <= 3; sign * lane in -4..4)
             unsigned char ord[MC_MAXA];
-            for (int i = 0; i < mv.n; i++) ord[i] = (unsigned char)i;
-            auto less = [&](int x, int y) {
-                int mx, Mx, lx, my, My, ly;
-                mc_action(C, mv.idx[x], mx, Mx, lx); mc_action(C, mv.idx[y], my, My, ly);
-                if (mv.dt[x] != mv.dt[y]) return mv.dt[x] < mv.dt[y];
-                if (Mx != My) return Mx > My;
+            unsigned long long key[MC_MAXA];
+            {
                 const int cl = g.k[np].lane;
-                const int dx = lx > cl ? lx - cl : cl - lx, dy = ly > cl ? ly - cl : cl - ly;
-                if (dx != dy) return dx < dy;
-                if (sign * lx != sign * ly) return sign * lx < sign * ly;
-                return false;
-            };
+                for (int i = 0; i < mv.n; i++) {
+                    int mn, mx, ln;
+                    mc_action(C, mv.idx[i], mn, mx, ln);
+                    const int dl = ln > cl ? ln - cl : cl - ln;
+                    key[i] = ((unsigned long long)(unsigned)mv.dt[i] << 24) | ((unsigned long long)(255 - mx) << 16) |
+                             ((unsigned long long)dl << 8) | (unsigned long long)(sign * ln + 8);
+                    ord[i] = (unsigned char)i;
+                }
+            }
             for (int i = 1; i < mv.n; i++) {
                 const int t = ord[i];
+                const unsigned long long kt = key[t];
                 int j = i - 1;
-                while (j >= 0 && less(t, ord[j])) { ord[j + 1] = ord[j]; j--; }
+                while (j >= 0 && kt < key[ord[j]]) { ord[j + 1] = ord[j]; j--; }
                 ord[j + 1] = (unsigned char)t;
             }
             int index;

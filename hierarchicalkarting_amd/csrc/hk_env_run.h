@@ -43,7 +43,7 @@ template <bool HAS_MCTS>
 __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
                                                       hk_episode_result* results, GameDesc* games, int* queue_cnt_all,
                                                       int* queue_all, int set, const float* act_steer, const int* act_branch,
-                                                      hk_lq_debug* dbg_out, int* status, int use_lds, MctsDev Marg)
+                                                      hk_lq_debug* dbg_out, int* status, int use_lds, MctsDev Marg, int mset)
 {
     MctsDev M{};
     if (HAS_MCTS) M = Marg;
@@ -76,13 +76,13 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
     while (env_ok && (phase != 0 || (left > 0 && budget > 0))) {
         dirty = true;
         if (phase == 0) {
-            const bool parked = phase_begin(P, env, i, env_ok, es, h, hfx, hfz, agents, results, M, set);
+            const bool parked = phase_begin(P, env, i, env_ok, es, h, hfx, hfz, agents, results, M, mset);
             bool queued = false;
             if (!parked) {
                 const bool act = (es.episode_steps % cadence) == 0 &&                                  // HKA:317 (Q9)
                                  !(!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u));
                 queued = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st);
-                if (M.st) phase_plan(P, M, set, env, i, es, h.flags, h.section_index, h.lane, h.lane_changes, h.final_steer, arec);
+                if (M.st) phase_plan(P, M, mset, env, i, es, h.flags, h.section_index, h.lane, h.lane_changes, h.final_steer, arec);
             } else {
                 left -= 1; budget -= 1;         // a parked env lets the tick pass
                 continue;
