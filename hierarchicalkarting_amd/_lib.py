@@ -44,6 +44,15 @@ class WallSeg(C.Structure):
 _I8 = C.c_int32 * HK_MAX_AGENTS
 
 
+class RewardParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "WallHitPenalty", "OpponentHitPenalty", "HitByOpponentPenalty", "PassCheckpointLaneReward", "PassCheckpointVelocityReward",
+        "PassCheckpointBase", "PassCheckpointTimeMultiplier", "TeamPassCheckpointBase", "TeamPassCheckpointTimeMultiplier",
+        "BeingBehindOpponentCheckpointPenalty", "BeingBehindTeammateCheckpointPenalty", "TeamScoreRewardMultiplier",
+        "ReversePenalty", "SwervingPenalty", "ReachGoalCheckpointRewardMultplier", "ReachGoalCheckpointRewardBase",
+        "TowardsCheckpointReward", "SpeedReward", "SlowMovingPenalty", "AccelerationReward", "NotAtGoalPenalty")]
+
+
 class Config(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32), ("num_envs", C.c_int32), ("num_agents", C.c_int32), ("device_id", C.c_int32),
@@ -61,7 +70,7 @@ class Config(C.Structure):
         ("sections", C.POINTER(Section)), ("walls", C.POINTER(WallSeg)),
         ("time_precision", _I8), ("section_window", _I8), ("mcts_iterations", C.c_int32),
         ("mcts_initial_iterations", C.c_int32), ("mcts_latency_ticks", C.c_int32), ("mcts_initial_latency_ticks", C.c_int32),
-        ("mcts_seed", C.c_uint32), ("reserved_cfg", C.c_int32 * 3),
+        ("mcts_seed", C.c_uint32), ("rewards", C.c_int32), ("training_agent", _I8), ("rw", RewardParams),
     ]
 
 
@@ -94,6 +103,7 @@ class AgentState(C.Structure):
         ("tele_completed_laps", C.c_int32), ("tele_lap_end_step", C.c_int32), ("tele_last_lap", C.c_float),
         ("tele_best_lap", C.c_float), ("tele_total_time", C.c_float),
         ("plan_lane", C.c_uint8 * HK_MAX_SECTIONS), ("plan_vel", C.c_float * HK_MAX_SECTIONS),
+        ("step_reward", C.c_float), ("group_reward", C.c_float),
     ]
 
 
@@ -107,7 +117,7 @@ class EpisodeResult(C.Structure):
                 ("forward_collisions", C.c_int32), ("avg_lane_diff", C.c_float), ("avg_vel_diff", C.c_float),
                 ("reward", C.c_float), ("episode", C.c_int32), ("last_lap", C.c_float), ("best_lap", C.c_float),
                 ("total_time", C.c_float), ("laps_completed", C.c_int32), ("lap_end_step", C.c_int32), ("speed", C.c_float),
-                ("active", C.c_int32), ("reserved", C.c_int32)]
+                ("active", C.c_int32), ("group_reward", C.c_float)]
 
 
 class LqDebug(C.Structure):
@@ -144,6 +154,7 @@ SYMBOLS = {
     "hk_get_env_state": (C.c_int, [_H, C.POINTER(EnvState)]),
     "hk_set_env_state": (C.c_int, [_H, C.POINTER(EnvState)]),
     "hk_get_episode_results": (C.c_int, [_H, C.POINTER(EpisodeResult)]),
+    "hk_get_rewards": (C.c_int, [_H, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "hk_get_lq_debug": (C.c_int, [_H, C.c_int, C.c_int, C.POINTER(LqDebug)]),
     "hk_get_mcts_state": (C.c_int, [_H, C.POINTER(MctsState)]),
     "hk_lq_solve_batch": (C.c_int, [_H, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp]),

@@ -45,11 +45,22 @@ class BuiltConfig:
         self.cfg, self.sections, self.walls, self.track = cfg, sections, walls, track
 
 
+# RacingEnvController.cs:65-108 field initialisers
+REWARD_DEFAULTS = dict(
+    WallHitPenalty=-0.05, OpponentHitPenalty=-2.0, HitByOpponentPenalty=-2.0, PassCheckpointLaneReward=4.0,
+    PassCheckpointVelocityReward=4.0, PassCheckpointBase=20.0, PassCheckpointTimeMultiplier=5.0, TeamPassCheckpointBase=20.0,
+    TeamPassCheckpointTimeMultiplier=5.0, BeingBehindOpponentCheckpointPenalty=-0.06, BeingBehindTeammateCheckpointPenalty=-0.02,
+    TeamScoreRewardMultiplier=0.75, ReversePenalty=-0.5, SwervingPenalty=-0.5, ReachGoalCheckpointRewardMultplier=5.0,
+    ReachGoalCheckpointRewardBase=3.0, TowardsCheckpointReward=0.008, SpeedReward=0.07, SlowMovingPenalty=-3.0,
+    AccelerationReward=0.002, NotAtGoalPenalty=-0.001)
+
+
 def make_config(num_envs, num_agents=4, track="oval", high_mode=_lib.HK_HIGH_FIXED, low_mode=_lib.HK_LOW_LQR,
                 tree_search_depth=5, jitter_seed=0, jitter_pos=0.5, jitter_yaw=0.05, auto_reset=1, env_id_base=0,
                 device_id=0, wiring=None, env_mode=_lib.HK_MODE_EXPERIMENT, max_episode_steps=None, laps=None,
                 stats=None, time_precision=100, section_window=2, mcts_iterations=128, mcts_initial_iterations=None,
-                mcts_latency_ticks=45, mcts_initial_latency_ticks=75, mcts_seed=0x4D435453):
+                mcts_latency_ticks=45, mcts_initial_latency_ticks=75, mcts_seed=0x4D435453, rewards=0, training_agents=None,
+                reward_params=None, disable_on_end=None):
     tr = load_track(track) if isinstance(track, str) else track
     secs = tr["sections"]
     L = len(secs)
@@ -104,7 +115,7 @@ def make_config(num_envs, num_agents=4, track="oval", high_mode=_lib.HK_HIGH_FIX
     cfg.max_episode_steps = int(max_episode_steps if max_episode_steps is not None else rules["maxEpisodeSteps"])
     cfg.max_lane_changes = int(rules["MaxLaneChanges"])
     cfg.section_horizon = int(rules["sectionHorizon"])
-    cfg.disable_on_end = int(rules["disableOnEnd"])
+    cfg.disable_on_end = int(rules["disableOnEnd"] if disable_on_end is None else disable_on_end)
     cfg.env_mode = env_mode
     cfg.start_hold_ticks = 75
     cfg.auto_reset = auto_reset
@@ -120,6 +131,15 @@ def make_config(num_envs, num_agents=4, track="oval", high_mode=_lib.HK_HIGH_FIX
     cfg.mcts_initial_iterations = int(mcts_initial_iterations if mcts_initial_iterations is not None else (mcts_iterations * 5 + 2) // 3)
     cfg.mcts_latency_ticks, cfg.mcts_initial_latency_ticks = int(mcts_latency_ticks), int(mcts_initial_latency_ticks)
     cfg.mcts_seed = mcts_seed
+    # reward shaping (REC:65-108 defaults; scenes may override)
+    cfg.rewards = int(rewards)
+    for i in range(num_agents):
+        cfg.training_agent[i] = int(training_agents[i]) if training_agents is not None else 0
+    rw = dict(REWARD_DEFAULTS)
+    if reward_params:
+        rw.update(reward_params)
+    for k, v in rw.items():
+        setattr(cfg.rw, k, v)
     cfg.jitter_seed = jitter_seed
     cfg.jitter_pos, cfg.jitter_yaw = jitter_pos, jitter_yaw
     cfg.env_id_base = env_id_base

@@ -55,6 +55,9 @@ struct EnvParams {
     int team_of[ENV_MAXA], time_precision[ENV_MAXA], section_window[ENV_MAXA];
     int mcts_iter, mcts_iter0, mcts_lat, mcts_lat0, any_mcts;
     uint32_t mcts_seed;
+    // reward shaping (hk_env_reward.h)
+    int rewards, n_teams, team_size[ENV_MAXA], training_agent[ENV_MAXA];
+    hk_reward_params rw;
 };
 constexpr float GRID_CELL = 2.0f;       // cell size (m)
 constexpr float GRID_REACH = 2.2f;      // list radius: 2 m side rays / 1 m half-spacing of the long-ray samples / 1.11 m

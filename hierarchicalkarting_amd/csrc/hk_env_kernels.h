@@ -37,6 +37,7 @@ struct EnvDevice {
     int tab_lds = 0;               // dynamic LDS bytes the env kernels are launched with (0: read tables from global)
     // MCTS planner (hk_env_mcts.h): all null / 0 when no agent is HighMode MCTS
     MctsDev mcts{};
+    RwDev rw{};                    // reward shaping tables (null when hk_config.rewards == 0)
     int mset = 0;                  // planner queue set the tick kernel currently fills
     int mcts_rounds = 0;           // rounds of the tick kernel since the last search launch
     SecGeo* sec_geo = nullptr;
@@ -82,7 +83,7 @@ int upload(T** dst, const std::vector<T>& v, std::string& err)
 inline void env_destroy(EnvDevice& d)
 {
     void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.status, d.games, d.queue_cnt, d.queue, d.env_ids, d.tab, d.perms,
-                    d.mcts.st, d.mcts.req, d.mcts.qcnt, d.mcts.queue, d.mcts.nodes, d.mcts.dt_tab, d.mcts.load_tab, d.mcts.rad_tab, d.sec_geo};
+                    d.rw.sec_time, d.rw.sec_cnt, d.mcts.st, d.mcts.req, d.mcts.qcnt, d.mcts.queue, d.mcts.nodes, d.mcts.dt_tab, d.mcts.load_tab, d.mcts.rad_tab, d.sec_geo};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = EnvDevice{};
 }
@@ -135,6 +136,13 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     for (int i = 0; i < HK_NUM_SENSORS; i++) {
         const float dl = cfg.sensor_yaw_deg[i] * DEG2RAD_F;
         P.sens_c[i] = hk_cosf(dl); P.sens_s[i] = hk_sinf(dl); P.ray_dist[i] = cfg.ray_distance[i];
+    }
+    P.rewards = cfg.rewards; P.rw = cfg.rw;
+    for (int i = 0; i < A; i++) {
+        if (cfg.team_of[i] < 0 || cfg.team_of[i] >= A) { err = "hk_create: team_of out of range"; return HK_ERR_INVALID; }
+        P.training_agent[i] = cfg.training_agent[i];
+        P.team_size[cfg.team_of[i]] += 1;
+        if (cfg.team_of[i] + 1 > P.n_teams) P.n_teams = cfg.team_of[i] + 1;
     }
     P.mcts_iter = cfg.mcts_iterations; P.mcts_iter0 = cfg.mcts_initial_iterations; P.mcts_lat = cfg.mcts_latency_ticks;
     P.mcts_lat0 = cfg.mcts_initial_latency_ticks; P.mcts_seed = cfg.mcts_seed;
@@ -260,6 +268,13 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     HK_ALLOC(d.games, na * sizeof(GameDesc));
     HK_ALLOC(d.queue_cnt, 2 * 8 * sizeof(int));
     HK_ALLOC(d.queue, 2 * 3 * na * sizeof(int));
+    if (cfg.rewards) {
+        d.rw.S = cfg.laps * L + 2;
+        const size_t n = na * (size_t)d.rw.S;
+        HK_ALLOC(d.rw.sec_time, n * sizeof(int));
+        HK_ALLOC(d.rw.sec_cnt, n * sizeof(int));
+        if ((e = hipMemsetAsync(d.rw.sec_time, 0xFF, n * sizeof(int), stream)) != hipSuccess) { err = "hipMemset"; return HK_ERR_HIP; }
+    }
     if (P.any_mcts) {
         if (na >= (1u << 24)) { err = "hk_create: MCTS planner queues address at most 2^24 agents per device"; return HK_ERR_UNSUPPORTED; }
         std::vector<SecGeo> geo(L);
@@ -361,7 +376,7 @@ inline int env_reset(EnvDevice& d, const hk_config& cfg, const int32_t* env_ids,
     }
     const int threads = cnt * 4;
     hipLaunchKernelGGL(env_reset_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.envs, dids, cnt, experiment_num,
-                       d.mcts, d.mset);
+                       d.mcts, d.mset, d.rw);
     int rc = launch_check(err, "env_reset_kernel");
     if (rc) return rc;
     if ((rc = env_flush_mcts(d, stream, err))) return rc;          // the first plans (T = 1.5 s in the reference)
@@ -382,24 +397,29 @@ inline int env_launch_check(EnvDevice& d, const hk_config& cfg, hipStream_t stre
     return launch_check(err, "env_check_kernel");
 }
 
-// number of {run, lqn} rounds that always suffice for n ticks (see hk_env_run.h)
+// Number of {run, lqn} rounds issued for n ticks (see hk_env_run.h).  A round retires at least one solve cadence of every
+// unfinished env (resume the pending tick, run to the next solve tick) — except around an episode reset: the tick that
+// resets has episode_steps = 0, which is a solve tick whatever the phase of the old episode was, so the round that contains
+// a reset can retire fewer ticks.  An episode lasts at least the start hold (75 ticks), hence the n / 32 + 2 extra rounds;
+// rounds that find nothing to do cost a few microseconds, and env_check_kernel still guards the result.
 inline int env_rounds_for(const hk_config& cfg, int n_ticks)
 {
     const int cadence = cfg.num_agents > 2 ? 4 : 1;
     static_assert(RUN_CAP > 4, "RUN_CAP must exceed the solve cadence");
-    return (n_ticks + cadence - 1) / cadence + 1;
+    return (n_ticks + cadence - 1) / cadence + 1 + n_ticks / 32 + 2;
 }
 
 // one round, part 1: the fused tick kernel (fills queue set round & 1)
 inline int env_launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
 {
     const int threads = cfg.num_envs * 4;
-    if (d.mcts.st)
-        hipLaunchKernelGGL(env_run_kernel<true>, dim3((threads + 255) / 256), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs, d.results,
-                           d.games, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status, d.tab_lds ? 1 : 0, d.mcts, d.mset);
-    else
-        hipLaunchKernelGGL(env_run_kernel<false>, dim3((threads + 255) / 256), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs, d.results,
-                           d.games, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status, d.tab_lds ? 1 : 0, d.mcts, d.mset);
+#define HK_RUN(MC, RWF)                                                                                                       \
+    hipLaunchKernelGGL((env_run_kernel<MC, RWF>), dim3((threads + 255) / 256), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs,   \
+                       d.results, d.games, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status,     \
+                       d.tab_lds ? 1 : 0, d.mcts, d.mset, d.rw)
+    if (d.mcts.st) { if (d.rw.sec_time) HK_RUN(true, true); else HK_RUN(true, false); }
+    else { if (d.rw.sec_time) HK_RUN(false, true); else HK_RUN(false, false); }
+#undef HK_RUN
     return launch_check(err, "env_run_kernel");
 }
 

@@ -15,6 +15,11 @@ __device__ __forceinline__ float quad_get(float v, int q) { return __shfl(v, (th
 __device__ __forceinline__ uint32_t quad_get(uint32_t v, int q) { return (uint32_t)__shfl((int)v, (threadIdx.x & ~3) | q, 64); }
 __device__ __forceinline__ int quad_get(int v, int q) { return __shfl(v, (threadIdx.x & ~3) | q, 64); }
 
+}  // namespace hk
+#include "hk_env_reward.h"
+namespace hk {
+
+
 // REC.ResetGame :499-719 for one agent (Experiment / Race grid); see oracle reset_env for the line map
 __device__ inline void reset_agent(const EnvParams& P, const TabView& T, int env, int i, int experiment_num, hk_agent_state* a)
 {
@@ -56,7 +61,7 @@ __device__ inline void reset_agent(const EnvParams& P, const TabView& T, int env
     a->flags = HK_F_ACTIVE | HK_F_ENABLED;
 }
 
-__device__ inline void snapshot_result(const Hot& h, float cum_reward, hk_episode_result* r, int episode)
+__device__ inline void snapshot_result(const Hot& h, float cum_reward, float group_reward, hk_episode_result* r, int episode)
 {
     r->time_steps = h.time_steps;
     r->section_index = h.section_index;
@@ -70,12 +75,12 @@ __device__ inline void snapshot_result(const Hot& h, float cum_reward, hk_episod
     r->laps_completed = h.tele_completed_laps; r->lap_end_step = h.tele_lap_end_step;
     r->speed = mag3(h.vx, 0.0f, h.vz);
     r->active = (h.flags & HK_F_ACTIVE) ? 1 : 0;
-    r->reserved = 0;
+    r->group_reward = group_reward;
 }
 
 // explicit hk_reset
 __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
-                                                        const int* env_ids, int n, int experiment_num, MctsDev M, int set)
+                                                        const int* env_ids, int n, int experiment_num, MctsDev M, int set, RwDev RD)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = gid >> 2, i = gid & 3;
@@ -85,6 +90,10 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_st
     const TabView T = tab_view(P, P.tab);
     hk_agent_state* ar = &agents[(size_t)env * P.A + i];
     reset_agent(P, T, env, i, ex, ar);
+    if (RD.sec_time) {
+        const int nn = P.A * RD.S;
+        for (int q = i; q < nn; q += P.A) { RD.sec_time[(size_t)env * nn + q] = -1; RD.sec_cnt[(size_t)env * nn + q] = 0; }
+    }
     if (M.st) {
         mcts_reset_state(&M.st[(size_t)env * P.A + i]);
         uint32_t req = 0;
@@ -107,20 +116,26 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_st
 // rays (:135-167).  `es` is the quad's register copy of the env words (identical in the 4 lanes).  Returns true when the
 // env is parked (auto_reset off and the episode is over): nothing else happens on this tick.
 // ---------------------------------------------------------------------------------------------------------------
+template <bool RW>
 __device__ inline bool phase_begin(const EnvParams& P, const int env, const int i, const bool env_ok, hk_env_state& es,
                                    Hot& h, float& hfx, float& hfz, hk_agent_state* agents, hk_episode_result* results,
-                                   const MctsDev& M, const int set)
+                                   const MctsDev& M, const int set, const RwDev& RD, RwAcc& rwv, const int* act_branch)
 {
     const bool me = env_ok && i < P.A;
     hk_agent_state* a = me ? &agents[(size_t)env * P.A + i] : nullptr;
     const uint32_t all_mask = (1u << P.A) - 1u;
     bool skip = !env_ok;       // envs that stay parked (auto_reset off and finished)
     bool finish = false, timeout = false;
+    if (RW && me && !(!P.auto_reset && (es.inactive_mask & all_mask) == all_mask)) {
+        // Academy step: OnActionReceived rewards on the state the previous tick left
+        const TabView Tg = tab_view(P, P.tab);
+        rw_academy(P, Tg, env, i, h, hfx, hfz, a, act_branch, rwv);
+    }
     if (env_ok) {
         if ((es.inactive_mask & all_mask) == all_mask) {
             if (!P.auto_reset) {
                 if (!(es.status & 4u)) {
-                    if (me) snapshot_result(h, a->cum_reward, &results[(size_t)env * P.A + i], es.episodes_done);
+                    if (me) snapshot_result(h, RW ? rwv.cum : a->cum_reward, RW ? rwv.group : a->group_reward, &results[(size_t)env * P.A + i], es.episodes_done);
                     es.episodes_done += 1; es.status |= 4u;
                 }
                 skip = true;
@@ -132,7 +147,7 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
                     if (me) {
                         uint32_t fl = h.flags;
                         if (fl & HK_F_ACTIVE) h.flags = deactivate_fields(P, h, fl);
-                        snapshot_result(h, a->cum_reward, &results[(size_t)env * P.A + i], es.episodes_done);
+                        snapshot_result(h, RW ? rwv.cum : a->cum_reward, RW ? rwv.group : a->group_reward, &results[(size_t)env * P.A + i], es.episodes_done);
                     }
                     es.inactive_mask = all_mask;
                     es.episodes_done += 1; es.status |= 2u | 4u;
@@ -147,10 +162,21 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
             if (fl & HK_F_ACTIVE) h.flags = deactivate_fields(P, h, fl);
         }
         if (es.initial_started || timeout) {
-            if (me) snapshot_result(h, a->cum_reward, &results[(size_t)env * P.A + i], es.episodes_done);
+            if (me) snapshot_result(h, RW ? rwv.cum : a->cum_reward, RW ? rwv.group : a->group_reward, &results[(size_t)env * P.A + i], es.episodes_done);
             es.episodes_done += 1;
             es.status = (es.status & ~2u) | (timeout ? 2u : 0u);
             es.experiment_num += 1;
+        }
+        if (RW) {
+            // AddGoalTimingRewards (REC:267 / :306) before ResetGame; then ResetGame clears the section tables (:508-512)
+            rw_goal_timing(P, i, me ? h.time_steps : 0, me && (h.flags & HK_F_ENABLED), rwv);
+            if (me) results[(size_t)env * P.A + i].group_reward = rwv.group;
+            if (env_ok) {
+                const int n = P.A * RD.S;
+                for (int q = i; q < n; q += 4) { RD.sec_time[(size_t)env * n + q] = -1; RD.sec_cnt[(size_t)env * n + q] = 0; }
+            }
+            __threadfence();
+            rwv.cum = 0.0f; rwv.step = 0.0f; rwv.group = 0.0f;      // the record is rewritten below (EndGroupEpisode)
         }
         if (me) {
             // REC.ResetGame rewrites the whole record (plans included): through memory, then back into registers
@@ -214,6 +240,7 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
             }
         }
         h.flags = fl;
+        if (RW && (fl & HK_F_ENABLED)) rw_not_at_goal(P, h, rwv);     // KA:165
     }
     return skip;
 }
@@ -242,9 +269,10 @@ __device__ inline int calculate_lane(const EnvParams& P, const SecDev& s, float 
 }
 
 // phase C of a tick (after every ego's controls are known)
+template <bool RW>
 __device__ inline void phase_move(const EnvParams& P, const TabView& T, const int env, const int i, const bool env_ok,
                                   hk_env_state& es, Hot& h, float& hfx, float& hfz, hk_agent_state* agents, const float* act_steer,
-                                  const int* act_branch, hk_mcts_state* mcts_all)
+                                  const int* act_branch, hk_mcts_state* mcts_all, const RwDev& RD, RwAcc& rwv)
 {
     const bool me = env_ok && i < P.A;
     const int episode_steps = es.episode_steps;
@@ -421,6 +449,8 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
     if (live) bad = !f_finite(px) || !f_finite(pz) || !f_finite(vx) || !f_finite(vz) || !f_finite(yaw) || !f_finite(wy);
     // ---- trigger dispatch (HKA.OnTriggerEnter :611-675) on the post-contact pose
     uint32_t newly_inactive = 0;
+    RwEvent ev[RW_MAX_EVENTS];
+    int nev = 0;
     if (enabled) {
         h.px = px; h.pz = pz; h.yaw = yaw; h.vx = vx; h.vz = vz; h.wy = wy;
         float ax, az, bx, bz;
@@ -456,7 +486,9 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                 if (index != -1 && ((index > sec) || (index % L == 0 && sec % L == L - 1))) {
                     const int key = index % L;
                     const int pl = a->plan_lane[key];
+                    float lane_div = 1.0f, vel_div = 1.0f;                 // HKA:618-619
                     if (pl != 0) {
+                        if (RW) rw_dividers(P, T, i, key, lane, pl, a->plan_vel[key], px, pz, vx, vz, lane_div, vel_div);
                         float lmx, lmz;
                         lane_marker(T, key, pl, lmx, lmz);
                         float dist = mag3(px - lmx, P.kart_y - T.sec[key].marker_y, pz - lmz);
@@ -468,7 +500,12 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                     const int cur_lane = h.lane;
                     int dl = cur_lane - lane; if (dl < 0) dl = -dl;
                     int lc = h.lane_changes;
-                    if (lc + dl > P.max_lane_changes && is_straight(P, T, sec)) h.illegal_lane_changes += 1;
+                    const bool swerve = lc + dl > P.max_lane_changes && is_straight(P, T, sec);
+                    if (swerve) h.illegal_lane_changes += 1;
+                    if (RW && nev < RW_MAX_EVENTS) {
+                        ev[nev].kind = 1; ev[nev].section = index; ev[nev].swerve = swerve ? 1 : 0;
+                        ev[nev].lane_div = lane_div; ev[nev].vel_div = vel_div; nev++;
+                    }
                     if (is_straight(P, T, sec) != is_straight(P, T, index)) lc = 0;
                     else if (cur_lane != lane) lc += dl;
                     h.lane_changes = lc;
@@ -481,6 +518,10 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                         newly_inactive |= 1u << i;
                     }
                 } else if (index != -1 && ((index < sec) || (sec % L == 0 && index % L == L - 1))) {
+                    if (RW && nev < RW_MAX_EVENTS) {
+                        ev[nev].kind = 2; ev[nev].section = sec - index + 1; ev[nev].swerve = 0;
+                        ev[nev].lane_div = 1.0f; ev[nev].vel_div = 1.0f; nev++;
+                    }
                     h.section_index = index;
                 } else if (index == -1) {                                  // DroveReverseLimit REC:475-479
                     h.time_steps = P.max_steps * 6;
@@ -492,6 +533,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
         }
     }
     hfx = cfx; hfz = cfz;
+    if (RW && !parked) rw_replay_events(P, RD, env, i, episode_steps, ev, nev, enabled, live && (fl & HK_F_ENABLED), rwv);
     if (live) {
         h.flags = fl;
         // TelemetryViewer.Update :49-88 (once per tick)

@@ -81,6 +81,13 @@ class RacingEnv:
         self._ck(self.L.hk_get_episode_results(self.h, out.ctypes.data_as(C.POINTER(_lib.EpisodeResult))))
         return out
 
+    def rewards(self):
+        """Agent.SendInfo: (m_Reward, m_GroupReward) collected since the last call, [E, A] each; both reset to 0"""
+        r = np.zeros((self.E, self.A), np.float32)
+        g = np.zeros((self.E, self.A), np.float32)
+        self._ck(self.L.hk_get_rewards(self.h, r.ctypes.data_as(C.POINTER(C.c_float)), g.ctypes.data_as(C.POINTER(C.c_float))))
+        return r, g
+
     def mcts_state(self):
         out = np.zeros((self.E, self.A), np.dtype(_lib.MctsState))
         self._ck(self.L.hk_get_mcts_state(self.h, out.ctypes.data_as(C.POINTER(_lib.MctsState))))

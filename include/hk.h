@@ -70,6 +70,15 @@ typedef struct hk_section {
 
 typedef struct hk_wall_seg { float x0, z0, x1, z1; } hk_wall_seg; /* road-side wall face, world metres */
 
+/* RacingEnvController reward fields (REC:65-108, defaults as in the source) */
+typedef struct hk_reward_params {
+    float WallHitPenalty, OpponentHitPenalty, HitByOpponentPenalty, PassCheckpointLaneReward, PassCheckpointVelocityReward;
+    float PassCheckpointBase, PassCheckpointTimeMultiplier, TeamPassCheckpointBase, TeamPassCheckpointTimeMultiplier;
+    float BeingBehindOpponentCheckpointPenalty, BeingBehindTeammateCheckpointPenalty, TeamScoreRewardMultiplier;
+    float ReversePenalty, SwervingPenalty, ReachGoalCheckpointRewardMultplier, ReachGoalCheckpointRewardBase;
+    float TowardsCheckpointReward, SpeedReward, SlowMovingPenalty, AccelerationReward, NotAtGoalPenalty;
+} hk_reward_params;
+
 typedef struct hk_config {
     int32_t abi_version;         /* HK_ABI_VERSION */
     int32_t num_envs;            /* E: independent RacingEnvControllers on this device */
@@ -119,7 +128,10 @@ typedef struct hk_config {
     int32_t mcts_latency_ticks;       /* ticks until a replan's result is used (0.9 s = 45 ticks) */
     int32_t mcts_initial_latency_ticks;/* same for the plan made at reset (1.5 s = 75 ticks = the start hold) */
     uint32_t mcts_seed;
-    int32_t reserved_cfg[3];
+    /* reward shaping: 0 = off (hk_agent_state reward fields stay 0) */
+    int32_t rewards;
+    int32_t training_agent[HK_MAX_AGENTS];   /* KartAgent.Mode == AgentMode.Training (KA:34-38): only these enter AddGoalTimingRewards (REC:217) */
+    hk_reward_params rw;
 } hk_config;
 
 #define HK_MCTS_MAX_DEPTH 8      /* gameParams.treeSearchDepth <= 8 */
@@ -161,7 +173,7 @@ typedef struct hk_agent_state {
     float steering;               /* KartAgent.m_Steering (KA:106) */
     float avg_lane_diff;          /* KA:116 */
     float avg_vel_diff;           /* KA:115 */
-    float cum_reward;             /* ML-Agents cumulative reward ("next" row; 0 in round 1) */
+    float cum_reward;             /* Agent.GetCumulativeReward(): sum of AddReward since the episode began (0 unless cfg.rewards) */
     float contact_nx, contact_nz; /* m_LastCollisionNormal (AK:201), x/z */
     int32_t section_index;        /* m_SectionIndex KA:107 */
     int32_t lane;                 /* m_Lane KA:108 */
@@ -182,6 +194,10 @@ typedef struct hk_agent_state {
     float tele_total_time;        /* lastOverallTimes (s) */
     uint8_t plan_lane[HK_MAX_SECTIONS]; /* m_UpcomingLanes keyed by section % L (KA:117); 0 = no entry */
     float plan_vel[HK_MAX_SECTIONS];    /* m_UpcomingVelocities (KA:118) */
+    /* ML-Agents per-decision accumulators: what Agent.AddReward / AddGroupReward collected since hk_get_rewards last
+     * read them (Agent.SendInfo resets m_Reward / m_GroupReward the same way) */
+    float step_reward;
+    float group_reward;
 } hk_agent_state;
 
 typedef struct hk_env_state {
@@ -209,7 +225,8 @@ typedef struct hk_episode_result {
     int32_t lap_end_step;          /* lastEpisodeSteps (enters the reference's winner rule, TelemetryViewer.cs:80) */
     float speed;                   /* Rigidbody.velocity.magnitude when the block was written */
     int32_t active;                /* is_active when the block was written */
-    int32_t reserved;
+    float group_reward;            /* m_GroupReward when the episode ended, AddGoalTimingRewards (REC:174-237) included: the record is
+                                      rewritten by ResetGame in the same tick, so this is where a trainer finds the terminal group reward */
 } hk_episode_result;
 
 /* debug tap: the LQ game one ego assembled on its last solve tick (HKA:699-1201), ego-local player order */
@@ -252,6 +269,8 @@ int hk_set_agent_state(hk_handle h, const hk_agent_state* in /*[E][A]*/);
 int hk_get_env_state(hk_handle h, hk_env_state* out /*[E]*/);
 int hk_set_env_state(hk_handle h, const hk_env_state* in /*[E]*/);
 int hk_get_episode_results(hk_handle h, hk_episode_result* out /*[E][A]*/);
+/* Agent.SendInfo: reward[E][A] = m_Reward, group_reward[E][A] = m_GroupReward collected since the last call; both reset to 0 */
+int hk_get_rewards(hk_handle h, float* reward, float* group_reward);
 int hk_get_lq_debug(hk_handle h, int env, int ego, hk_lq_debug* out);
 /* planner state of every agent, [E][A] (zeros for agents that are not HighMode MCTS) */
 int hk_get_mcts_state(hk_handle h, hk_mcts_state* out /*[E][A]*/);

@@ -63,6 +63,7 @@ int hko_set_env_state(hko_env*, const hk_env_state* in);
 int hko_get_observations(hko_env*, float* obs);
 int hko_get_episode_results(hko_env*, hk_episode_result* out);
 int hko_get_mcts_state(hko_env*, hk_mcts_state* out /*[E][A]*/);
+int hko_get_rewards(hko_env*, float* reward, float* group_reward);   /* read and reset, as hk_get_rewards */
 /* RL policy (hk_oracle_policy.c): same contracts as hk_policy_attach / hk_policy_forward / hk_get_actions */
 int hko_policy_attach(hko_env*, const hk_policy_desc* desc, const int32_t* agent_slots, int n_slots, int decision_period);
 int hko_policy_forward(hko_env*, int policy, int rows, const float* obs, float* mu, float* logits);

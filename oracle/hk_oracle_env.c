@@ -253,6 +253,7 @@ static void reset_env(hko_env* e, int env)
     static const int expSectionChoices[4] = {0, 0, 1, 1};    /* :527 */
     es->episode_steps = 0;                                   /* :505 */
     es->inactive_mask = 0;                                   /* :506 */
+    if (e->sec_min_time) hko_rw_reset_env(e, env);           /* :508-512 */
     const int* ord = &e->perms[(size_t)(((es->experiment_num % e->nperm) + e->nperm) % e->nperm) * e->A];  /* :528 */
     const uint32_t env_gid = (uint32_t)(e->cfg.env_id_base + env);
     for (int j = 0; j < e->A; j++) {
@@ -327,7 +328,7 @@ static void snapshot_results(hko_env* e, int env)
         r->laps_completed = a->tele_completed_laps; r->lap_end_step = a->tele_lap_end_step;
         r->speed = mag3(a->vx, 0.0f, a->vz);
         r->active = (a->flags & HK_F_ACTIVE) ? 1 : 0;
-        r->reserved = 0;
+        r->group_reward = a->group_reward;
     }
 }
 
@@ -724,9 +725,12 @@ static void on_trigger_enter(hko_env* e, int env, int ai, int t)
         if (idx % L == t) { index = idx; lane = calculate_lane(e, &e->sec[idx % L], a->px, a->pz); break; }
     }
     const int sec = a->section_index;
+    const int rw = e->cfg.rewards;
+    float lane_div = 1.0f, vel_div = 1.0f;                                              /* :618-619 */
     if (index != -1 && ((index > sec) || (index % L == 0 && sec % L == L - 1))) {       /* :621 */
         const int key = index % L;
         if (a->plan_lane[key] != 0) {                                                   /* :623 */
+            if (rw) hko_rw_dividers(e, ai, a, index, lane, &lane_div, &vel_div);        /* :625-626 */
             /* UpdateLaneDifferenceCalculation KA:226-230 */
             pt2 lm = lane_marker(e, key, a->plan_lane[key]);
             float dist = mag3(a->px - lm.x, e->cfg.kart_y - e->sec[key].marker_y, a->pz - lm.z);
@@ -739,7 +743,10 @@ static void on_trigger_enter(hko_env* e, int env, int ai, int t)
             a->plan_lane[key] = 0; a->plan_vel[key] = 0.0f;                             /* :629-630 */
         }
         int dl = a->lane - lane; if (dl < 0) dl = -dl;
-        if (a->lane_changes + dl > e->cfg.max_lane_changes && is_straight(e, sec)) a->illegal_lane_changes += 1;   /* :636-640 */
+        if (a->lane_changes + dl > e->cfg.max_lane_changes && is_straight(e, sec)) {    /* :636-640 */
+            if (rw) hko_rw_swerve(e, a);
+            a->illegal_lane_changes += 1;
+        }
         if (is_straight(e, sec) != is_straight(e, index)) a->lane_changes = 0;          /* :641 */
         else if (a->lane != lane) a->lane_changes += dl;                                /* :645 */
         a->section_index = index; a->lane = lane;                                       /* :649-650 */
@@ -747,10 +754,12 @@ static void on_trigger_enter(hko_env* e, int env, int ai, int t)
         const int goal = e->cfg.laps * L + 1;                                           /* REC:165 */
         if (a->section_index == goal) {                                                 /* :652 -> REC.ResolveEvent :469-474 */
             a->time_steps = es->episode_steps;
+            if (rw) hko_rw_section(e, env, ai, lane_div, vel_div);                      /* REC:471 */
             deactivate(e, a);
             es->inactive_mask |= 1u << ai;
-        }
+        } else if (rw) hko_rw_section(e, env, ai, lane_div, vel_div);                   /* REC:467 */
     } else if (index != -1 && ((index < sec) || (sec % L == 0 && index % L == L - 1))) {/* :663 */
+        if (rw) hko_rw_reverse(e, a, sec, index);                                       /* :666 */
         a->section_index = index;                                                       /* :667 */
     } else if (index == -1) {                                                           /* :671 DroveReverseLimit REC:475-479 */
         a->time_steps = e->cfg.max_episode_steps * 6;
@@ -790,6 +799,10 @@ static void finish_episode(hko_env* e, int env, int timeout)
         es->status = (es->status & ~2u) | (timeout ? 2u : 0u);
         es->experiment_num += 1;                                                        /* REC:268-269 / :308 */
     }
+    if (e->cfg.rewards) {                                                               /* REC:267 / :306, before ResetGame */
+        hko_rw_goal_timing(e, env);
+        for (int i = 0; i < e->A; i++) e->res[(size_t)env * e->A + i].group_reward = ags[i].group_reward;
+    }
     reset_env(e, env);                                                                  /* REC:270 / :309 */
     es->initial_started = 1;                                                            /* REC:277 */
 }
@@ -801,6 +814,8 @@ static void step_env(hko_env* e, int env)
     hk_agent_state* ags = &e->ag[(size_t)env * e->A];
     const int A = e->A, L = e->L;
     const uint32_t all_mask = (1u << A) - 1u;
+    /* Academy step: KartAgent.OnActionReceived rewards on the state the previous tick left (a parked env has no agents) */
+    if (cfg->rewards && !(!cfg->auto_reset && (es->inactive_mask & all_mask) == all_mask)) hko_rw_academy(e, env);
     /* (a) REC.FixedUpdate :239-311 */
     if ((es->inactive_mask & all_mask) == all_mask) {
         if (!cfg->auto_reset) {
@@ -848,6 +863,7 @@ static void step_env(hko_env* e, int env)
         } else {
             a->flags &= ~HK_F_FORWARD_COLLISION;
         }
+        if (cfg->rewards) hko_rw_not_at_goal(e, a);                                     /* :165 */
     }
     /* HKA.FixedUpdate :313-362. SolveLQR only writes the ego's own controls, and reads poses/plans that no agent
      * script modifies before (c), so the A solves of a tick are order independent (Q9). */
@@ -1054,6 +1070,12 @@ hko_env* hko_create(const hk_config* cfg)
     e->dbg = (hk_lq_debug*)calloc(na, sizeof(hk_lq_debug));
     e->act_steer = (float*)calloc(na, sizeof(float));
     e->act_branch = (int32_t*)calloc(na, sizeof(int32_t));
+    if (cfg->rewards) {
+        const size_t n = na * (size_t)hko_rw_table_len(e);
+        e->sec_min_time = (int32_t*)malloc(n * sizeof(int32_t));
+        e->sec_count = (uint8_t*)malloc(n);
+        memset(e->sec_min_time, 0xFF, n * sizeof(int32_t)); memset(e->sec_count, 0, n);
+    }
     for (int i = 0; i < e->A; i++)
         if (cfg->high_mode[i] == HK_HIGH_MCTS && !e->mcts) e->mcts = (hk_mcts_state*)calloc(na, sizeof(hk_mcts_state));
     for (size_t i = 0; i < na; i++) { e->res[i].episode = -1; e->act_branch[i] = 1; }
@@ -1088,6 +1110,7 @@ void hko_destroy(hko_env* e)
     free(e->sec); free(e->sp); free(e->walls); free(e->ag); free(e->es); free(e->res); free(e->dbg);
     hko_policy_free(e);
     free(e->mcts);
+    free(e->sec_min_time); free(e->sec_count);
     free(e->act_steer); free(e->act_branch); free(e->perms); free(e);
 }
 

@@ -34,6 +34,9 @@ struct hko_env {
     float sens_c[HK_NUM_SENSORS], sens_s[HK_NUM_SENSORS];   /* cos / sin of the sensors' local yaw */
     /* MCTS planner (hk_oracle_mcts.c): [E][A], NULL when no agent is HighMode MCTS */
     hk_mcts_state* mcts;
+    /* reward shaping (hk_oracle_reward.c): minSectionTimes / agentsPastSection, [E][A teams][laps * L + 2]; NULL when off */
+    int32_t* sec_min_time;
+    uint8_t* sec_count;
     /* RL policies (hk_oracle_policy.c) */
     int n_policies;
     struct hko_policy* policy[HK_MAX_POLICIES];
@@ -60,6 +63,17 @@ static inline float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.
 /* hk_oracle_mcts.c */
 void hko_mcts_search(hko_env* e, int env, int ego, int iterations, hk_mcts_plan* plan);
 void hko_mcts_consume(hko_env* e, int env, int i);
+
+/* hk_oracle_reward.c */
+int hko_rw_table_len(const hko_env* e);
+void hko_rw_reset_env(hko_env* e, int env);
+void hko_rw_academy(hko_env* e, int env);
+void hko_rw_not_at_goal(hko_env* e, hk_agent_state* a);
+void hko_rw_dividers(hko_env* e, int agent, const hk_agent_state* a, int index, int lane, float* lane_div, float* vel_div);
+void hko_rw_swerve(hko_env* e, hk_agent_state* a);
+void hko_rw_reverse(hko_env* e, hk_agent_state* a, int old_section, int index);
+void hko_rw_section(hko_env* e, int env, int ai, float lane_div, float vel_div);
+void hko_rw_goal_timing(hko_env* e, int env);
 
 /* hk_oracle_policy.c */
 void hko_policy_decide(hko_env* e);           /* observe -> stack -> infer -> latch actions, if this tick is a decision tick */

@@ -107,6 +107,8 @@ def _env_api():
         L.hko_raycast_track.argtypes = [C.c_void_p] + [C.c_float] * 5
         L.hko_get_mcts_state.restype = C.c_int
         L.hko_get_mcts_state.argtypes = [C.c_void_p, C.POINTER(HL.MctsState)]
+        L.hko_get_rewards.restype = C.c_int
+        L.hko_get_rewards.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         fp = C.POINTER(C.c_float)
         L.hko_policy_attach.restype = C.c_int
         L.hko_policy_attach.argtypes = [C.c_void_p, C.POINTER(HL.PolicyDesc), C.POINTER(C.c_int32), C.c_int, C.c_int]
@@ -184,6 +186,11 @@ class OracleEnv:
     def set_actions(self, steer, branch):
         s = np.ascontiguousarray(steer, np.float32); b = np.ascontiguousarray(branch, np.int32)
         self.L.hko_set_actions(self.h, s.ctypes.data_as(C.POINTER(C.c_float)), b.ctypes.data_as(C.POINTER(C.c_int32)))
+
+    def rewards(self):
+        r = np.zeros((self.E, self.A), np.float32); g = np.zeros((self.E, self.A), np.float32)
+        self.L.hko_get_rewards(self.h, r.ctypes.data_as(C.POINTER(C.c_float)), g.ctypes.data_as(C.POINTER(C.c_float)))
+        return r, g
 
     def mcts_state(self):
         out = np.zeros((self.E, self.A), np.dtype(HL.MctsState))

@@ -1,0 +1,99 @@
+"""Reward shaping, CPU oracle: the terms of KA:165 / :440-470, REC:359-433 and REC:174-237 checked against
+hand evaluation of the reference formulas on recorded states."""
+import numpy as np
+import oracle_lib as O
+from hierarchicalkarting_amd.config import make_config, REWARD_DEFAULTS as RW
+
+f32 = np.float32
+
+
+def test_rewards_off_by_default():
+    o = O.OracleEnv(make_config(2, 2, jitter_seed=1)); o.reset(); o.step(300)
+    a = o.agent_state()
+    assert (a["cum_reward"] == 0).all() and (a["step_reward"] == 0).all() and (a["group_reward"] == 0).all()
+
+
+def test_per_tick_terms_during_the_start_hold():
+    """karts stand still for 75 ticks: direction and speed terms are 0, the LQ planner already asks for throttle
+    (AccelerationReward) and every tick costs NotAtGoalPenalty"""
+    o = O.OracleEnv(make_config(2, 2, rewards=1, jitter_seed=1)); o.reset()
+    o.step(1)
+    r, g = o.rewards()
+    # tick 1: Academy step sees flags of the reset (no accel yet) -> only NotAtGoalPenalty
+    assert np.allclose(r, RW["NotAtGoalPenalty"], atol=1e-7) and (g == 0).all()
+    o.step(10)
+    r, g = o.rewards()
+    acc = (o.agent_state()["flags"] & 1) != 0
+    assert acc.all()
+    assert np.allclose(r, 10 * (RW["NotAtGoalPenalty"] + RW["AccelerationReward"]), atol=1e-6)
+    assert np.allclose(o.agent_state()["cum_reward"], 11 * RW["NotAtGoalPenalty"] + 10 * RW["AccelerationReward"], atol=1e-6)
+
+
+def test_first_section_pass_reward_and_group_reward():
+    b = make_config(1, 2, rewards=1, jitter_seed=0, jitter_pos=0.0, jitter_yaw=0.0)
+    o = O.OracleEnv(b); o.reset()
+    prev = o.agent_state()["section_index"].copy()
+    o.rewards()
+    for t in range(400):
+        o.step(1)
+        a = o.agent_state()
+        r, g = o.rewards()
+        ch = a["section_index"] != prev
+        if ch.any():
+            i = int(np.argmax(ch[0]))
+            steps = int(o.env_state()["episode_steps"][0])
+            # first kart of the race through a section: first of its team, no opponent there yet -> total = 1 -> full reward
+            big = RW["PassCheckpointBase"] + RW["PassCheckpointTimeMultiplier"] * (6000 - steps) / 6000.0
+            # plus the lane / velocity rewards (Fixed plans: velocity divider 1), minus per-tick terms (small)
+            assert big + 4.0 / 1.3 ** 12 + 4.0 - 0.1 < r[0, i] < big + 8.0 + 0.2, (r, big)
+            gexp = RW["TeamPassCheckpointBase"] + RW["TeamPassCheckpointTimeMultiplier"] * (6000 - steps) / 6000.0
+            assert abs(g[0, i] - gexp) < 1e-4 and g[0, 1 - i] == 0           # 1v1: the group is the kart alone
+            break
+        prev = a["section_index"].copy()
+    else:
+        raise AssertionError("no section passed")
+
+
+def test_being_behind_penalty_and_rank_multipliers():
+    b = make_config(1, 2, rewards=1, jitter_seed=0, jitter_pos=0.0, jitter_yaw=0.0)
+    o = O.OracleEnv(b); o.reset(); o.rewards()
+    seen = {}
+    prev = o.agent_state()["section_index"].copy()
+    for t in range(700):
+        o.step(1)
+        a = o.agent_state(); r, g = o.rewards()
+        steps = int(o.env_state()["episode_steps"][0])
+        for i in range(2):
+            s = int(a["section_index"][0, i])
+            if s != prev[0, i]:
+                if s in seen:                                   # the other team was here first: rank 2 -> x0.75, minus the penalty
+                    first = seen[s]
+                    pen = RW["BeingBehindOpponentCheckpointPenalty"] * (steps - first) * 1 / 1.0
+                    base = 0.75 * RW["PassCheckpointBase"] + 0.75 * RW["PassCheckpointTimeMultiplier"] * (6000 - steps) / 6000.0
+                    assert base + pen + 4.0 / 1.3 ** 12 + 4.0 - 0.1 < r[0, i] < base + pen + 8.0 + 0.2, (s, r[0, i], base, pen)
+                    return
+                seen[s] = steps
+        prev = a["section_index"].copy()
+    raise AssertionError("never second through a section")
+
+
+def test_goal_timing_group_reward_only_for_training_agents():
+    """REC:174-237: the goal-timing reward goes to the groups of Mode == Training agents, and only to group members whose
+    GameObject is still enabled (disableOnEnd = 1 in the scenes unregisters finished karts, so there it reaches nobody)"""
+    def run(training, doe):
+        o = O.OracleEnv(make_config(2, 2, rewards=1, jitter_seed=3, laps=1, max_episode_steps=3000, training_agents=training,
+                                    disable_on_end=doe))
+        o.reset()
+        for _ in range(16):
+            o.step(100)
+        res = o.episode_results()
+        assert (res["episode"] >= 0).all()
+        return res["group_reward"].astype(np.float64)          # terminal m_GroupReward (the record itself is reset in that tick)
+    base = run([0, 0], 0)
+    assert np.allclose(run([1, 1], 1), run([0, 0], 1))              # disabled karts receive nothing
+    both = run([1, 1], 0)
+    extra = both - base
+    # s = Base + Mult * (gt + 1) / 2 with gt in (-1, 1): between 3 and 8 per finished episode, winner more than loser
+    assert ((extra > 2.9) & (extra < 16.1)).all(), extra
+    only0 = run([1, 0], 0) - base
+    assert (only0[:, 0] > 2.9).all() and np.allclose(only0[:, 1], 0.0, atol=1e-4)
