@@ -346,7 +346,7 @@ static_assert((MCTS_FLUSH_ROUNDS + 1) * RUN_CAP <= MCTS_MIN_LATENCY, "a queued s
 inline int env_flush_mcts(EnvDevice& d, hipStream_t stream, std::string& err)
 {
     if (!d.mcts.st) return HK_OK;
-    hipLaunchKernelGGL(mcts_search_kernel, dim3((2 * d.mcts.slots + 63) / 64), dim3(64), 0, stream, d.P, d.mcts, d.mset);
+    hipLaunchKernelGGL(mcts_search_kernel, dim3((2 * d.mcts.slots + MC_SPW - 1) / MC_SPW), dim3(64), 0, stream, d.P, d.mcts, d.mset);
     int rc = launch_check(err, "mcts_search_kernel");
     if (rc) return rc;
     d.mset ^= 1;

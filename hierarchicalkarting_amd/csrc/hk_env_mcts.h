@@ -23,6 +23,10 @@ namespace hk {
 
 constexpr int MC_MAXP = 4;                    // players of a discrete game (<= agents of an env)
 constexpr int MC_MAXA = HK_MCTS_MAX_ACTIONS;  // 20
+#ifndef HK_MC_SPW
+#define HK_MC_SPW 64
+#endif
+constexpr int MC_SPW = HK_MC_SPW;             // searches per wave (see mcts_search_kernel)
 
 struct MctsKartSnap { int section, lane, lane_changes, tire_age; int sec_time[4]; };
 struct MctsReq {
@@ -149,10 +153,13 @@ struct DGame {
     int team[MC_MAXP];
     int last, fin;              // lastCompletedSection, finalSection
 };
-struct MoveEval {               // the legal moves of the player who is up next, in canonical (velocity-major) order
+// The legal moves of the player who is up next: a bit per canonical action (velocity-major) and the time each adds.
+// Every loop over dt[] is fully unrolled, so the array lives in registers (no scratch: a scratch round trip costs
+// hundreds of cycles at the one-wave-per-SIMD occupancy this kernel runs at, and there were hundreds per position).
+struct MoveEval {
     int n;
-    unsigned char idx[MC_MAXA];
-    int dt[MC_MAXA];            // time the move adds to that player's timeAtSection
+    uint32_t legal;
+    int dt[MC_MAXA];
 };
 struct MctsCtx {
     const EnvParams* P;
@@ -287,24 +294,48 @@ __device__ inline int mc_cmp(const DKart& a, const DKart& b)
     }
     return 1;
 }
+
+// g.k[] is only ever indexed with compile-time constants (unrolled loops / these selectors), so the game state stays in
+// registers
+__device__ __forceinline__ DKart mc_get(const DGame& g, int p)
+{
+    DKart r = g.k[0];
+    if (p == 1) r = g.k[1];
+    if (p == 2) r = g.k[2];
+    if (p == 3) r = g.k[3];
+    return r;
+}
+__device__ __forceinline__ void mc_set(DGame& g, int p, const DKart& v)
+{
+    if (p == 0) g.k[0] = v;
+    if (p == 1) g.k[1] = v;
+    if (p == 2) g.k[2] = v;
+    if (p == 3) g.k[3] = v;
+}
+__device__ __forceinline__ int mc_team(const DGame& g, int p)
+{
+    int r = g.team[0];
+    if (p == 1) r = g.team[1];
+    if (p == 2) r = g.team[2];
+    if (p == 3) r = g.team[3];
+    return r;
+}
+
+// upNext KDG:183-238: the first kart, in the order List.Sort leaves them, that has not completed section last + 1.
+// Every kart of a game state sits at section `last` or `last + 1`, so those still to move sort before the others and the
+// answer is their minimum under the comparison; .NET's small-partition sorts (2: one compare-swap, 3: (0,1)(0,2)(1,2),
+// 4..16: insertion sort) all leave the lowest-indexed of several equal minima in front, which is the tie rule used here
+// (the CPU oracle runs the sorts themselves).
 __device__ inline int mc_up_next(const DGame& g)
-{   // KDG:183-238.  List.Sort on <= 16 elements: 2 -> one compare-swap, 3 -> (0,1) (0,2) (1,2), else insertion sort
-    int o[MC_MAXP];
-    for (int i = 0; i < MC_MAXP; i++) o[i] = i;
-    auto sig = [&](int i, int j) { if (mc_cmp(g.k[o[i]], g.k[o[j]]) > 0) { const int t = o[i]; o[i] = o[j]; o[j] = t; } };
-    if (g.P == 2) sig(0, 1);
-    else if (g.P == 3) { sig(0, 1); sig(0, 2); sig(1, 2); }
-    else if (g.P > 3) {
-        for (int i = 0; i < g.P - 1; i++) {
-            const int t = o[i + 1];
-            int j = i;
-            while (j >= 0 && mc_cmp(g.k[t], g.k[o[j]]) < 0) { o[j + 1] = o[j]; j--; }
-            o[j + 1] = t;
-        }
+{
+    int best = -1;
+    DKart bk = g.k[0];
+#pragma unroll
+    for (int p = 0; p < MC_MAXP; p++) {
+        if (p >= g.P || g.k[p].section == g.last + 1) continue;
+        if (best < 0 || mc_cmp(g.k[p], bk) < 0) { best = p; bk = g.k[p]; }
     }
-    for (int i = 0; i < g.P; i++)
-        if (g.k[o[i]].section != g.last + 1) return o[i];
-    return -1;
+    return best;
 }
 
 __device__ inline int mc_vb(const MctsCtx& C, int minv) { return minv == 0 ? 0 : 1 + (minv - 6) / C.bucket; }
@@ -312,29 +343,31 @@ __device__ inline int mc_vb(const MctsCtx& C, int minv) { return minv == 0 ? 0 :
 // nextMoves KDG:318-411 for the player who is up next (np), with the time each legal move adds (from the move tables)
 __device__ inline void mc_eval_moves(const MctsCtx& C, const DGame& g, int np, MoveEval& mv)
 {
-    const DKart& cur = g.k[np];
+    const DKart cur = mc_get(g, np);
     const int L = C.P->L, sm = cur.section % L;
     const bool str = mc_straight(C, cur.section);
     const float wear = (float)cur.tire / 10000.0f;
-    float vlim[4];                                                   // lateral-g speed limit per target lane
-    for (int l = 0; l < 4; l++) vlim[l] = mc_max_speed(C, C.rad_tab[(sm * 4 + (cur.lane - 1)) * 4 + l], wear);
+    const float* rp = C.rad_tab + (sm * 4 + (cur.lane - 1)) * 4;
+    const float v0 = mc_max_speed(C, rp[0], wear), v1 = mc_max_speed(C, rp[1], wear);      // lateral-g speed limit per target lane
+    const float v2 = mc_max_speed(C, rp[2], wear), v3 = mc_max_speed(C, rp[3], wear);
     const int* dtp = C.dt_tab + (size_t)((sm * 4 + (cur.lane - 1)) * (C.nv + 1) + mc_vb(C, cur.minv)) * MC_MAXA;
-    mv.n = 0;
-    for (int a = 0; a < C.nact; a++) {
+    mv.n = 0; mv.legal = 0;
+#pragma unroll
+    for (int a = 0; a < MC_MAXA; a++) {
         const int lane = (a & 3) + 1, minv = 6 + (a >> 2) * C.bucket;
         const int dl = lane > cur.lane ? lane - cur.lane : cur.lane - lane;
-        if (str && cur.lchg + dl > C.P->max_lane_changes) continue;
-        if (vlim[lane - 1] < (float)minv) continue;
-        const int dt = dtp[a];
-        if (dt < 0) continue;
-        mv.idx[mv.n] = (unsigned char)a; mv.dt[mv.n] = dt; mv.n++;
+        const float vl = (a & 3) == 0 ? v0 : ((a & 3) == 1 ? v1 : ((a & 3) == 2 ? v2 : v3));
+        const int dt = a < C.nact ? dtp[a] : -1;
+        const bool ok = a < C.nact && !(str && cur.lchg + dl > C.P->max_lane_changes) && !(vl < (float)minv) && dt >= 0;
+        mv.dt[a] = dt;
+        if (ok) { mv.legal |= 1u << a; mv.n++; }
     }
 }
 
 // makeMove KDG:416-443 on the running state (applyAction through the move tables)
 __device__ inline void mc_make_move(const MctsCtx& C, DGame& g, int np, int a)
 {
-    DKart& k = g.k[np];
+    DKart k = mc_get(g, np);
     const int L = C.P->L, sm = k.section % L;
     int minv, maxv, lane;
     mc_action(C, a, minv, maxv, lane);
@@ -348,19 +381,62 @@ __device__ inline void mc_make_move(const MctsCtx& C, DGame& g, int np, int a)
     k.tire = (int)(((float)k.tire / 10000.0f + load * C.P->st.TireWearFactor) * 10000.0f);
     k.time += dt;
     k.section += 1; k.minv = minv; k.maxv = maxv; k.lane = lane; k.lchg = lchg;
+    mc_set(g, np, k);
     bool allAhead = true;
-    for (int i = 0; i < g.P; i++) allAhead = allAhead && (g.k[i].section > g.last);
+#pragma unroll
+    for (int i = 0; i < MC_MAXP; i++) if (i < g.P) allAhead = allAhead && (g.k[i].section > g.last);
     if (allAhead) g.last += 1;
 }
 
+// The move the rollout picks (KM:255-270): the index-th of the legal moves ordered by
+// OrderBy(time added).ThenByDescending(max_velocity).ThenBy(|lane change|).ThenBy(sign * lane), a stable sort.  The four keys
+// pack into one integer; the index-th element is the one with exactly `index` legal moves before it (ties by canonical
+// order) — all in registers.
+__device__ inline int mc_pick_move(const MctsCtx& C, const MoveEval& mv, int cur_lane, int sign, int index)
+{
+    uint32_t key[MC_MAXA];
+#pragma unroll
+    for (int a = 0; a < MC_MAXA; a++) {
+        const int lane = (a & 3) + 1, minv = 6 + (a >> 2) * C.bucket;
+        const int maxv = (minv + C.bucket) < C.vmax ? (minv + C.bucket) : C.vmax;
+        const int dl = lane > cur_lane ? lane - cur_lane : cur_lane - lane;
+        key[a] = ((uint32_t)mv.dt[a] << 12) | ((uint32_t)(C.vmax - maxv) << 6) | ((uint32_t)dl << 4) | (uint32_t)(sign * lane + 4);
+    }
+    // selection by repeated minimum: the draw is |gaussian| with sd n / 6, so `index` is almost always 0..3
+    uint32_t left = mv.legal;
+    int move = 0;
+    for (int r = 0; r <= index; r++) {
+        uint32_t best = 0xFFFFFFFFu;
+        move = 0;
+#pragma unroll
+        for (int a = 0; a < MC_MAXA; a++) {
+            const bool take = ((left >> a) & 1u) && key[a] < best;          // strict <: the lowest action wins ties (stable order)
+            best = take ? key[a] : best;
+            move = take ? a : move;
+        }
+        left &= ~(1u << move);
+    }
+    return move;
+}
+
 // isOver KDG:246-313 given the legal-move count of the position.  scores: the reference's List<float> (can exceed P)
-__device__ inline bool mc_is_over(const MctsCtx& C, const DGame& g, int np, int n_legal, float* scores)
+__device__ inline bool mc_is_over(const MctsCtx& C, const DGame& g, int np, int n_legal, float (&scores)[2 * MC_MAXP])
 {
     if (n_legal == 0) {
+        // for each player: [0.0 if it is the stuck player or a team mate of it], then 0.5 (the reference has no `else`)
+        const int tnp = mc_team(g, np);
         int n = 0;
-        for (int i = 0; i < g.P; i++) {
-            if (i == np || g.team[i] == g.team[np]) scores[n++] = 0.0f;
-            scores[n++] = 0.5f;                                     // the reference has no `else` here
+#pragma unroll
+        for (int q = 0; q < 2 * MC_MAXP; q++) scores[q] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MC_MAXP; i++) {
+            if (i >= g.P) continue;
+            const bool zero_first = (i == np) || (g.team[i] == tnp);
+            // entries n (0.0, only when zero_first) and then 0.5
+            const int pos = n + (zero_first ? 1 : 0);
+#pragma unroll
+            for (int q = 0; q < 2 * MC_MAXP; q++) if (q == pos) scores[q] = 0.5f;
+            n = pos + 1;
         }
         return true;
     }
@@ -371,8 +447,13 @@ __device__ inline bool mc_is_over(const MctsCtx& C, const DGame& g, int np, int 
         float raw[MC_MAXP];
         float teamScore = 0.0f, opponentScore = 0.0f;
         int teamCount = 0, opponentCount = 0;                       // accumulate over players (not reset, KDG:273-276)
-        for (int s = 0; s < g.P; s++) {
-            for (int o = 0; o < g.P; o++) {
+#pragma unroll
+        for (int s = 0; s < MC_MAXP; s++) {
+            raw[s] = 0.0f;
+            if (s >= g.P) continue;
+#pragma unroll
+            for (int o = 0; o < MC_MAXP; o++) {
+                if (o >= g.P) continue;
                 if (s == o) teamScore += (float)g.k[o].time;
                 else if (g.team[s] == g.team[o]) { teamScore += (float)g.k[o].time * tsm; teamCount += 1; }
                 else { opponentScore += (float)g.k[o].time; opponentCount += 1; }
@@ -383,7 +464,9 @@ __device__ inline bool mc_is_over(const MctsCtx& C, const DGame& g, int np, int 
             maxScore = (__builtin_isnan(maxScore) || nn) ? __builtin_nanf("") : (maxScore > score ? maxScore : score);
             minScore = (__builtin_isnan(minScore) || nn) ? __builtin_nanf("") : (minScore < score ? minScore : score);
         }
-        for (int s = 0; s < g.P; s++) {
+#pragma unroll
+        for (int s = 0; s < MC_MAXP; s++) {
+            if (s >= g.P) continue;
             const int si = (raw[s] >= -2147483648.0f && raw[s] < 2147483648.0f) ? (int)raw[s] : (-2147483647 - 1);
             scores[s] = ((float)si - minScore) * 1.0f / (maxScore - minScore);
         }
@@ -391,6 +474,14 @@ __device__ inline bool mc_is_over(const MctsCtx& C, const DGame& g, int np, int 
     }
     scores[0] = (float)(C.P->max_steps - g.k[0].time / C.P->max_steps);
     return true;
+}
+
+__device__ __forceinline__ float mc_score_at(const float (&scores)[2 * MC_MAXP], int q)
+{
+    float r = scores[0];
+#pragma unroll
+    for (int j = 1; j < 2 * MC_MAXP; j++) if (q == j) r = scores[j];
+    return r;
 }
 
 __device__ inline void mc_ctx_init(MctsCtx& C, const EnvParams& P, const TabView& T, const MctsDev& M, int ego)
@@ -457,7 +548,11 @@ __device__ inline int mc_ucs(MctsCtx& C, const MNode* nd, int node)
 
 __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M, int set)
 {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    // MC_SPW searches per wave.  Measured (16 384 envs x 4 agents = 1 024 full waves, one per SIMD): 64 -> 11.2 M env-steps/s,
+    // 32 -> 11.0 M, 21 -> 10.3 M, 16 -> 9.7 M: a launch lasts as long as one search however the searches are spread, so
+    // thinner waves buy nothing
+    if ((int)threadIdx.x >= MC_SPW) return;
+    const int q = blockIdx.x * MC_SPW + threadIdx.x;
     if (q >= M.qcnt[set * 2]) return;
     const unsigned ent = (unsigned)M.queue[(size_t)set * 2 * P.E * P.A + q];
     const int pair = (int)(ent & 0xFFFFFFu);
@@ -477,23 +572,25 @@ __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M,
 
     // planWithMCTS HKA:172-263: the discrete game of the karts within sectionWindow sections of the ego
     DGame root;
-    int agent_of[MC_MAXP];
+    uint32_t agent_of = 0;                                           // player p is agent (agent_of >> 8p) & 255
     root.P = 0;
     int initialSection = R.k[ego].section, furthest = ego;
     for (int i = 0; i < P.A; i++) {
         int d = R.k[i].section - R.k[ego].section; d = d < 0 ? -d : d;
         if (d < P.section_window[ego]) {
-            agent_of[root.P++] = i;
+            agent_of |= (uint32_t)i << (8 * root.P); root.P++;
             if (R.k[i].section > initialSection) initialSection = R.k[i].section;
             if (initialSection == R.k[i].section) furthest = i;
         }
     }
+#pragma unroll
     for (int p = 0; p < MC_MAXP; p++) {
         DKart& k = root.k[p];
         k.section = 0; k.time = 0; k.minv = 0; k.maxv = 0; k.lane = 1; k.tire = 0; k.lchg = 0; root.team[p] = 0;
         if (p >= root.P) continue;
-        const MctsKartSnap& s = R.k[agent_of[p]];
-        root.team[p] = P.team_of[agent_of[p]];
+        const int ap = (int)((agent_of >> (8 * p)) & 255u);
+        const MctsKartSnap& s = R.k[ap];
+        root.team[p] = P.team_of[ap];
         k.minv = 0;                                                  // HKA:211-219: the bucket loop breaks at i = 0
         k.maxv = C.bucket < C.vmax ? C.bucket : C.vmax;
         k.section = initialSection;
@@ -529,32 +626,10 @@ __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M,
             if (mc_is_over(C, g, np, mv.n, scores)) break;
             const int ol = T.sec[g.last % P.L].optimal_lane;
             const int sign = ol == 1 ? 1 : (ol == 4 ? -1 : 0);
-            // OrderBy(time added).ThenByDescending(max_velocity).ThenBy(|lane change|).ThenBy(sign * lane), stable: the four
-            // keys packed into one integer (time added >= 0; max_velocity <= 255; |lane change| <= 3; sign * lane in -4..4)
-            unsigned char ord[MC_MAXA];
-            unsigned long long key[MC_MAXA];
-            {
-                const int cl = g.k[np].lane;
-                for (int i = 0; i < mv.n; i++) {
-                    int mn, mx, ln;
-                    mc_action(C, mv.idx[i], mn, mx, ln);
-                    const int dl = ln > cl ? ln - cl : cl - ln;
-                    key[i] = ((unsigned long long)(unsigned)mv.dt[i] << 24) | ((unsigned long long)(255 - mx) << 16) |
-                             ((unsigned long long)dl << 8) | (unsigned long long)(sign * ln + 8);
-                    ord[i] = (unsigned char)i;
-                }
-            }
-            for (int i = 1; i < mv.n; i++) {
-                const int t = ord[i];
-                const unsigned long long kt = key[t];
-                int j = i - 1;
-                while (j >= 0 && kt < key[ord[j]]) { ord[j + 1] = ord[j]; j--; }
-                ord[j + 1] = (unsigned char)t;
-            }
             int index;
             if (mv.n > 2) index = (int)__builtin_rintf(f_abs(mc_gauss_bounded(C, 0.0f, (float)mv.n / 6.0f, -(float)mv.n + 1.0f, (float)mv.n - 1.0f)));
             else index = mc_rand_next(C, mv.n);
-            const int move = mv.idx[ord[index]];
+            const int move = mc_pick_move(C, mv, mc_get(g, np).lane, sign, index);
             int c = -1;
             for (int ch = nd[node].first_child; ch >= 0; ch = nd[ch].next_sibling)
                 if (nd[ch].action == move) { c = ch; break; }
@@ -578,7 +653,7 @@ __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M,
         if (out_of_nodes) break;
         // backpropagate :285-293
         for (int b = node; b >= 0; b = nd[b].parent) {
-            nd[b].totalValue += scores[nd[b].upnext];
+            nd[b].totalValue += mc_score_at(scores, nd[b].upnext);
             nd[b].numEpisodes += 1;
         }
     }
@@ -587,7 +662,7 @@ __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M,
     hk_mcts_plan plan;
     __builtin_memset(&plan, 0, sizeof(plan));
     plan.n_players = root.P;
-    for (int p = 0; p < root.P; p++) plan.player_agent[p] = (uint8_t)agent_of[p];
+    for (int p = 0; p < root.P; p++) plan.player_agent[p] = (uint8_t)((agent_of >> (8 * p)) & 255u);
     {
         DGame g = root;
         int node = 0;
@@ -596,11 +671,13 @@ __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M,
             node = mc_ucs(C, nd, node);
             mc_make_move(C, g, np, nd[node].action);
             bool all_at = true;
-            for (int p = 0; p < g.P; p++) all_at = all_at && (g.k[p].section == g.last);
+#pragma unroll
+            for (int p = 0; p < MC_MAXP; p++) if (p < g.P) all_at = all_at && (g.k[p].section == g.last);
             if (all_at && plan.n_states < HK_MCTS_MAX_DEPTH) {
                 const int s = plan.n_states++;
                 plan.section[s] = g.last;
-                for (int p = 0; p < g.P; p++) { plan.lane[s][p] = (uint8_t)g.k[p].lane; plan.vel[s][p] = (uint8_t)g.k[p].maxv; }
+#pragma unroll
+                for (int p = 0; p < MC_MAXP; p++) if (p < g.P) { plan.lane[s][p] = (uint8_t)g.k[p].lane; plan.vel[s][p] = (uint8_t)g.k[p].maxv; }
             }
         }
     }
