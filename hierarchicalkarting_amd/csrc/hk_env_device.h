@@ -57,6 +57,7 @@ struct EnvParams {
     uint32_t mcts_seed;
     // reward shaping (hk_env_reward.h)
     int rewards, n_teams, team_size[ENV_MAXA], training_agent[ENV_MAXA];
+    float wall_val[HK_NUM_SENSORS], agent_val[HK_NUM_SENSORS];   // Sensor.WallHitValidationDistance / AgentHitValidationDistance
     hk_reward_params rw;
 };
 constexpr float GRID_CELL = 2.0f;       // cell size (m)

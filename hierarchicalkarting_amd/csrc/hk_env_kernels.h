@@ -83,7 +83,7 @@ int upload(T** dst, const std::vector<T>& v, std::string& err)
 inline void env_destroy(EnvDevice& d)
 {
     void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.status, d.games, d.queue_cnt, d.queue, d.env_ids, d.tab, d.perms,
-                    d.rw.sec_time, d.rw.sec_cnt, d.mcts.st, d.mcts.req, d.mcts.qcnt, d.mcts.queue, d.mcts.nodes, d.mcts.dt_tab, d.mcts.load_tab, d.mcts.rad_tab, d.sec_geo};
+                    d.rw.sec_time, d.rw.sec_cnt, d.rw.hit_code, d.mcts.st, d.mcts.req, d.mcts.qcnt, d.mcts.queue, d.mcts.nodes, d.mcts.dt_tab, d.mcts.load_tab, d.mcts.rad_tab, d.sec_geo};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = EnvDevice{};
 }
@@ -138,6 +138,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         P.sens_c[i] = hk_cosf(dl); P.sens_s[i] = hk_sinf(dl); P.ray_dist[i] = cfg.ray_distance[i];
     }
     P.rewards = cfg.rewards; P.rw = cfg.rw;
+    for (int i = 0; i < HK_NUM_SENSORS; i++) { P.wall_val[i] = cfg.wall_hit_validation[i]; P.agent_val[i] = cfg.agent_hit_validation[i]; }
     for (int i = 0; i < A; i++) {
         if (cfg.team_of[i] < 0 || cfg.team_of[i] >= A) { err = "hk_create: team_of out of range"; return HK_ERR_INVALID; }
         P.training_agent[i] = cfg.training_agent[i];
@@ -273,6 +274,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         const size_t n = na * (size_t)d.rw.S;
         HK_ALLOC(d.rw.sec_time, n * sizeof(int));
         HK_ALLOC(d.rw.sec_cnt, n * sizeof(int));
+        HK_ALLOC(d.rw.hit_code, na * HK_NUM_SENSORS);
         if ((e = hipMemsetAsync(d.rw.sec_time, 0xFF, n * sizeof(int), stream)) != hipSuccess) { err = "hipMemset"; return HK_ERR_HIP; }
     }
     if (P.any_mcts) {
@@ -452,8 +454,12 @@ inline int env_launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream
 inline int env_launch_observe(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
 {
     const int threads = cfg.num_envs * cfg.num_agents;
-    hipLaunchKernelGGL(env_observe_kernel, dim3((threads + 127) / 128), dim3(128), 0, stream, d.P, d.agents, d.obs);
-    return launch_check(err, "env_observe_kernel");
+    hipLaunchKernelGGL(env_observe_kernel, dim3((threads + 127) / 128), dim3(128), 0, stream, d.P, d.agents, d.obs, d.rw.hit_code);
+    int rc = launch_check(err, "env_observe_kernel");
+    if (rc || !d.rw.hit_code) return rc;
+    // CollectObservations raised HitWall / HitOpponent events (HKA:580-598): replayed per env in agent / sensor order
+    hipLaunchKernelGGL(reward_hits_kernel, dim3((cfg.num_envs + 127) / 128), dim3(128), 0, stream, d.P, d.agents, d.rw.hit_code);
+    return launch_check(err, "reward_hits_kernel");
 }
 
 }  // namespace hk

@@ -26,7 +26,7 @@ __device__ inline void inv_transform_point(const hk_agent_state* a, float fx, fl
     out[2] = rx * fx + rz * fz;
 }
 
-__global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_agent_state* agents, float* obs)
+__global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_agent_state* agents, float* obs, unsigned char* hit_code)
 {
     const TabView T = tab_view(P, P.tab);
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -112,16 +112,19 @@ __global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_
             if (ht >= 0.0f && ht <= sd + 1.0f) break;
         }
         float ha = -1.0f;
+        int who = -1;
         if (see) {
             for (int j = 0; j < A; j++) {
                 if (j == i || !(ags[j].flags & HK_F_ENABLED)) continue;
                 float t = ray_stadium(ox, oz, dx, dz, ags[j].px, ags[j].pz, kfx[j], kfz[j], P.ray_agent_r);
-                if (t >= 0.0f && t <= maxd && (ha < 0.0f || t < ha)) ha = t;
+                if (t >= 0.0f && t <= maxd && (ha < 0.0f || t < ha)) { ha = t; who = j; }
             }
         }
-        if (ht >= 0.0f && (ha < 0.0f || ht < ha)) o[p++] = ht;
-        else if (ha >= 0.0f) o[p++] = ha;
+        int code = 0;                                                    // HitWall / HitOpponent events (HKA:580-598)
+        if (ht >= 0.0f && (ha < 0.0f || ht < ha)) { o[p++] = ht; if (ht < P.wall_val[si]) code = 1; }
+        else if (ha >= 0.0f) { o[p++] = ha; if (ha < P.agent_val[si]) code = 2 + who; }
         else o[p++] = maxd;
+        if (hit_code) hit_code[(size_t)gid * HK_NUM_SENSORS + si] = (unsigned char)code;
     }
 }
 

@@ -9,7 +9,8 @@
 // KA.FixedUpdate (NotAtGoalPenalty) -> triggers.  Trigger rewards touch state shared by the env's agents
 // (minSectionTimes / agentsPastSection, group rewards): they are recorded per lane during the trigger loop and replayed
 // agent by agent afterwards (rw_replay_events), which is the order the engine restatement dispatches the triggers in.
-// Not built: the HitWall / HitOpponent penalties raised from CollectObservations (HKA:580-598).
+// CollectObservations raises HitWall / HitOpponent from its ray distances (HKA:580-598): env_observe_kernel records a code
+// per sensor, reward_hits_kernel replays them per env in agent / sensor order (REC.ResolveEvent :444-462).
 #pragma once
 #include "hk_env_device.h"
 
@@ -21,6 +22,8 @@ struct RwDev {
     int* sec_time;      // [E][A teams][S]  minSectionTimes (episode step; -1 = key absent)
     int* sec_cnt;       // [E][A teams][S]  agentsPastSection
     int S;              // laps * L + 2
+    unsigned char* hit_code;   // [E][A][sensors]: what the last CollectObservations saw closer than the validation distance
+                               // (0 nothing, 1 wall, 2 + j agent j); replayed by reward_hits_kernel
 };
 
 struct RwEvent {        // one OnTriggerEnter outcome of this lane's kart, replayed in rw_replay_events
@@ -198,6 +201,28 @@ __device__ inline void rw_goal_timing(const EnvParams& P, const int i, const int
         mine += P.rw.ReachGoalCheckpointRewardBase + P.rw.ReachGoalCheckpointRewardMultplier * ((gt - minReward) * 1.0f / (maxReward - minReward));
     }
     if (enabled) r.group += mine / (float)P.team_size[P.team_of[i]];
+}
+
+// REC.ResolveEvent :438-462 for the HitWall / HitOpponent events of the last observation pass; one thread per env
+__global__ __launch_bounds__(128) void reward_hits_kernel(EnvParams P, hk_agent_state* agents, const unsigned char* hit_code)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= P.E) return;
+    hk_agent_state* ags = agents + (size_t)env * P.A;
+    for (int i = 0; i < P.A; i++) {
+        if (!(ags[i].flags & HK_F_ACTIVE)) continue;                                     // :441
+        for (int si = 0; si < HK_NUM_SENSORS; si++) {
+            const int code = hit_code[((size_t)env * P.A + i) * HK_NUM_SENSORS + si];
+            if (code == 0) continue;
+            if (code == 1) { const float x = 1.0f * P.rw.WallHitPenalty; ags[i].step_reward += x; ags[i].cum_reward += x; continue; }
+            const int v = code - 2;
+            { const float x = 1.0f * P.rw.OpponentHitPenalty; ags[i].step_reward += x; ags[i].cum_reward += x; }
+            if (P.team_of[i] == P.team_of[v]) {
+                { const float x = 1.5f * P.rw.OpponentHitPenalty; ags[i].step_reward += x; ags[i].cum_reward += x; }
+                { const float x = 1.15f * P.rw.HitByOpponentPenalty; ags[v].step_reward += x; ags[v].cum_reward += x; }
+            } else { const float x = 1.0f * P.rw.HitByOpponentPenalty; ags[v].step_reward += x; ags[v].cum_reward += x; }
+        }
+    }
 }
 
 // hk_get_rewards: Agent.SendInfo reads and zeroes m_Reward / m_GroupReward

@@ -1206,7 +1206,7 @@ void hko_observe_env(hko_env* e, int env, float* obs)
     const int dim = hko_obs_dim(e);
     const int goal = cfg->laps * L + 1;
     {
-        const hk_agent_state* ags = &e->ag[(size_t)env * A];
+        hk_agent_state* ags = &e->ag[(size_t)env * A];
         for (int i = 0; i < A; i++) {
             const hk_agent_state* a = &ags[i];
             float* o = obs + (size_t)i * dim;
@@ -1256,10 +1256,15 @@ void hko_observe_env(hko_env* e, int env, float* obs)
                 float ox, oz, dx, dz;
                 sensor_ray(e, a, si, &ox, &oz, &dx, &dz);
                 float ht = hko_raycast_track(e, ox, oz, dx, dz, cfg->ray_distance[si]);
-                float ha = (a->flags & HK_F_ENABLED) ? raycast_agents(e, ags, i, ox, oz, dx, dz, cfg->ray_distance[si], NULL) : -1.0f;
-                if (ht >= 0.0f && (ha < 0.0f || ht < ha)) o[p++] = ht;                  /* :580-588 */
-                else if (ha >= 0.0f) o[p++] = ha;                                       /* :589-598 */
-                else o[p++] = cfg->ray_distance[si];                                    /* :601 */
+                int who = -1;
+                float ha = (a->flags & HK_F_ENABLED) ? raycast_agents(e, ags, i, ox, oz, dx, dz, cfg->ray_distance[si], &who) : -1.0f;
+                if (ht >= 0.0f && (ha < 0.0f || ht < ha)) {                             /* :580-588 */
+                    if (cfg->rewards && ht < cfg->wall_hit_validation[si]) hko_rw_hit(e, env, i, -1);
+                    o[p++] = ht;
+                } else if (ha >= 0.0f) {                                                /* :589-598 */
+                    if (cfg->rewards && ha < cfg->agent_hit_validation[si]) hko_rw_hit(e, env, i, who);
+                    o[p++] = ha;
+                } else o[p++] = cfg->ray_distance[si];                                  /* :601 */
             }
         }
     }

@@ -74,6 +74,7 @@ void hko_rw_swerve(hko_env* e, hk_agent_state* a);
 void hko_rw_reverse(hko_env* e, hk_agent_state* a, int old_section, int index);
 void hko_rw_section(hko_env* e, int env, int ai, float lane_div, float vel_div);
 void hko_rw_goal_timing(hko_env* e, int env);
+void hko_rw_hit(hko_env* e, int env, int agent, int victim);
 
 /* hk_oracle_policy.c */
 void hko_policy_decide(hko_env* e);           /* observe -> stack -> infer -> latch actions, if this tick is a decision tick */

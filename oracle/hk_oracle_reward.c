@@ -8,7 +8,8 @@
  * package source is not in the reference checkout, so that boundary is "parity unpinned".
  * Order inside a tick: Academy step (OnActionReceived rewards, state as the previous tick left it) -> REC.FixedUpdate
  * (AddGoalTimingRewards before ResetGame) -> KA.FixedUpdate (NotAtGoalPenalty) -> physics triggers (section rewards).
- * NOT restated here: the HitWall / HitOpponent penalties raised from CollectObservations (HKA:580-598) — see DESIGN.md.
+ * CollectObservations raises HitWall / HitOpponent from its ray distances (HKA:580-598 -> REC.ResolveEvent :444-462): applied
+ * whenever observations are collected (a decision tick of an attached policy, or hko_get_observations).
  */
 #include <stdlib.h>
 #include <string.h>
@@ -201,6 +202,21 @@ void hko_rw_goal_timing(hko_env* e, int env)
             rw->ReachGoalCheckpointRewardMultplier * ((gt[i] - minReward) * 1.0f / (maxReward - minReward));   /* :220 */
     }
     for (int t = 0; t < T; t++) add_group_reward(e, env, t, groupRewards[t] / (float)team_size(e, t));          /* :233 */
+}
+
+/* REC.ResolveEvent :438-462 for Event.HitWall (victim < 0) / Event.HitOpponent raised by `agent` from CollectObservations */
+void hko_rw_hit(hko_env* e, int env, int agent, int victim)
+{
+    const hk_reward_params* rw = &e->cfg.rw;
+    hk_agent_state* ags = &e->ag[(size_t)env * e->A];
+    hk_agent_state* a = &ags[agent];
+    if (!(a->flags & HK_F_ACTIVE)) return;                                               /* :441 */
+    if (victim < 0) { add_reward(a, 1.0f * rw->WallHitPenalty); return; }               /* ApplyHitWallPenalty KA:380 */
+    add_reward(a, 1.0f * rw->OpponentHitPenalty);                                        /* :448 */
+    if (e->cfg.team_of[agent] == e->cfg.team_of[victim]) {                               /* :452-456 crashing into a team mate */
+        add_reward(a, 1.5f * rw->OpponentHitPenalty);
+        add_reward(&ags[victim], 1.15f * rw->HitByOpponentPenalty);
+    } else add_reward(&ags[victim], 1.0f * rw->HitByOpponentPenalty);                    /* :460 */
 }
 
 int hko_get_rewards(hko_env* e, float* reward, float* group_reward)

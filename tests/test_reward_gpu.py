@@ -82,3 +82,30 @@ def test_rl_and_mcts_agents_with_rewards():
     for n in (80, 45, 100, 75):
         g.step(n); o.step(n); t += n
         _cmp(g, o, t)
+
+
+def test_hit_penalties_from_observations():
+    """HKA:580-598: karts parked against a wall and behind each other; hk_get_observations raises the events"""
+    g, o = _pair(3, 4, jitter_seed=0, jitter_pos=0.0, jitter_yaw=0.0)
+    for e in (g, o):
+        e.step(80); e.rewards()
+        st = e.agent_state()
+        for k in range(3):
+            st["px"][k] = [19.6 - 0.05 * k, 15.0, 15.0, 15.9]; st["pz"][k] = [2.0, 30.0, 31.3, 30.6]
+            st["yaw"][k] = [np.pi / 2, 0.0, 0.0, 3.3]
+        st["vx"][:] = 0; st["vz"][:] = 0
+        e.set_agent_state(st)
+    assert np.array_equal(g.observations(), o.observations())
+    _cmp(g, o, 80)
+    gr, gg = g.rewards(); orr, og = o.rewards()
+    assert np.array_equal(gr.view(np.uint32), orr.view(np.uint32)) and (gr < -0.04).any()
+    # and through the decision loop of an attached policy
+    import hierarchicalkarting_amd as hk
+    from hierarchicalkarting_amd.policy import Policy
+    b = hk.make_config(16, 2, rewards=1, jitter_seed=3, low_mode=[_lib.HK_LOW_RL, _lib.HK_LOW_RL])
+    g = hk.RacingEnv(b); o = O.OracleEnv(b); g.reset(); o.reset()
+    pol = Policy.random(g.obs_dim * 4, 64, 2, seed=8)
+    g.attach_policy(pol, [0, 1], 2); o.attach_policy(pol, [0, 1], 2)
+    for t in (150, 151, 200, 97):
+        g.step(t); o.step(t)
+        _cmp(g, o, t)

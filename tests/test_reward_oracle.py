@@ -97,3 +97,30 @@ def test_goal_timing_group_reward_only_for_training_agents():
     assert ((extra > 2.9) & (extra < 16.1)).all(), extra
     only0 = run([1, 0], 0) - base
     assert (only0[:, 0] > 2.9).all() and np.allclose(only0[:, 1], 0.0, atol=1e-4)
+
+
+def test_hit_penalties_raised_by_collect_observations():
+    """HKA:580-598 -> REC.ResolveEvent :444-462: a ray shorter than the sensor's validation distance costs WallHitPenalty; a kart
+    closer than AgentHitValidationDistance costs the observer OpponentHitPenalty (x2.5 in total for a team mate) and the
+    observed kart HitByOpponentPenalty (x1.15 for a team mate)"""
+    from hierarchicalkarting_amd import _lib
+    o = O.OracleEnv(make_config(1, 4, rewards=1, jitter_seed=0, jitter_pos=0.0, jitter_yaw=0.0)); o.reset()
+    o.step(80); o.rewards()
+    st = o.agent_state()
+    # kart 0 nose-to-wall on the first straight (walls at x = 11.28 / 20.48), heading +x; kart 1 (team mate) right behind
+    # kart 2 (opponent), nobody else near
+    st["px"][0] = [19.6, 15.0, 15.0, 40.0]; st["pz"][0] = [2.0, 30.0, 31.3, 40.0]
+    st["yaw"][0] = [np.pi / 2, 0.0, 0.0, 0.0]
+    st["vx"][0] = 0; st["vz"][0] = 0
+    o.set_agent_state(st)
+    obs = o.observations()
+    r, g = o.rewards()
+    # kart 0: sensor 0 (straight ahead) sees the wall at 20.48 - 19.6 - 0.1 = 0.78 < 0.8 -> one WallHitPenalty (other sensors: longer rays)
+    n_wall = int(((obs[0, 0, -9:] < np.array([0.8, 0.9, 1.0, 0.8, 0.6, 0.9, 1.0, 0.8, 0.6])).sum()))
+    assert n_wall >= 1 and abs(r[0, 0] - n_wall * RW["WallHitPenalty"]) < 1e-6
+    # kart 1 sees kart 2 (opponent: teams are {0,1} vs {2,3}) 1.3 m ahead -> inside 1.5 m on the forward sensor(s)
+    n12 = int((obs[0, 1, -9:] < 1.5).sum())
+    assert n12 >= 1
+    assert abs(r[0, 1] - n12 * RW["OpponentHitPenalty"]) < 1e-5
+    assert abs(r[0, 2] - n12 * RW["HitByOpponentPenalty"]) < 1e-5 or r[0, 2] < n12 * RW["HitByOpponentPenalty"]   # kart 2 may see kart 1 behind it too
+    assert r[0, 3] == 0 and (g == 0).all()
