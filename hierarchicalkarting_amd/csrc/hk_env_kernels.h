@@ -453,8 +453,8 @@ inline int env_launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream
 
 inline int env_launch_observe(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
 {
-    const int threads = cfg.num_envs * cfg.num_agents;
-    hipLaunchKernelGGL(env_observe_kernel, dim3((threads + 127) / 128), dim3(128), 0, stream, d.P, d.agents, d.obs, d.rw.hit_code);
+    const long long threads = (long long)cfg.num_envs * cfg.num_agents * OBS_LANES;
+    hipLaunchKernelGGL(env_observe_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d.P, d.agents, d.obs, d.rw.hit_code);
     int rc = launch_check(err, "env_observe_kernel");
     if (rc || !d.rw.hit_code) return rc;
     // CollectObservations raised HitWall / HitOpponent events (HKA:580-598): replayed per env in agent / sensor order

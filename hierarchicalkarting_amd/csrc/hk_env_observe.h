@@ -26,11 +26,19 @@ __device__ inline void inv_transform_point(const hk_agent_state* a, float fx, fl
     out[2] = rx * fx + rz * fz;
 }
 
-__global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_agent_state* agents, float* obs, unsigned char* hit_code)
+// 16 lanes per agent: lanes 0-8 cast one sensor ray each (Physics.Raycast vs TrackMask and vs AgentMask), lanes 9-13 write the
+// upcoming sections (strided when sectionHorizon > 5), lane 14 the agent's own block, lane 15 the blocks of the other karts.
+// Lane l of the group first evaluates the forward vector of kart l % A (one fp64 sin/cos pair per lane instead of A per
+// agent) and the group shares them by shuffles.
+constexpr int OBS_LANES = 16;
+__global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_agent_state* agents, float* obs, unsigned char* hit_code)
 {
     const TabView T = tab_view(P, P.tab);
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= P.E * P.A) return;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid0 = tid / OBS_LANES, l = tid % OBS_LANES;
+    const int n_agents = P.E * P.A;
+    const bool valid = gid0 < n_agents;
+    const int gid = valid ? gid0 : n_agents - 1;       // idle groups shadow the last agent (shuffles stay convergent), writes off
     const int env = gid / P.A, i = gid % P.A;
     const int A = P.A, L = P.L, H = P.H;
     const int dim = HK_NUM_SENSORS + H * 5 + 8 + 12 * (A - 1);
@@ -38,58 +46,78 @@ __global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_
     const hk_agent_state* ags = agents + (size_t)env * A;
     const hk_agent_state* a = &ags[i];
     float* o = obs + (size_t)gid * dim;
-    // forward vectors of every kart of the env, once
-    float kfx[HK_MAX_AGENTS], kfz[HK_MAX_AGENTS];
-    for (int j = 0; j < A; j++) { kfx[j] = hk_sinf(ags[j].yaw); kfz[j] = hk_cosf(ags[j].yaw); }
-    const float fx = kfx[i], fz = kfz[i];
-    int p = 0;
-    o[p++] = local_speed(P, a, fx, fz);
-    o[p++] = (a->flags & HK_F_ACCEL) ? 1.0f : 0.0f;
-    o[p++] = (float)a->lane;
-    o[p++] = a->lane_changes * 1.0f / P.max_lane_changes;
-    o[p++] = (a->flags & HK_F_ACTIVE) ? 1.0f : 0.0f;
-    o[p++] = a->section_index * 1.0f / goal;
-    o[p++] = is_straight(P, T, a->section_index) ? 1.0f : 0.0f;
-    o[p++] = tire_wear(P, a->final_steer);
-    for (int pass = 0; pass < 2; pass++) {
-        const int cnt = pass == 0 ? P.n_team[i] : P.n_other[i];
-        for (int j = 0; j < cnt; j++) {
-            const int bj = pass == 0 ? P.team[i][j] : P.other[i][j];
-            const hk_agent_state* b = &ags[bj];
-            o[p++] = local_speed(P, b, kfx[bj], kfz[bj]);
-            o[p++] = (b->flags & HK_F_ACCEL) ? 1.0f : 0.0f;
-            o[p++] = (float)b->lane;
-            o[p++] = b->lane_changes * 1.0f / P.max_lane_changes;
-            o[p++] = (b->flags & HK_F_ACTIVE) ? 1.0f : 0.0f;
-            o[p++] = is_straight(P, T, b->section_index) ? 1.0f : 0.0f;
-            o[p++] = tire_wear(P, b->final_steer);
-            o[p++] = b->section_index * 1.0f / goal;
-            o[p++] = mag3(b->px - a->px, 0.0f, b->pz - a->pz);
+    // forward vectors of the env's karts: lane l evaluates kart l % A, the group shares them
+    float kfx[ENV_MAXA], kfz[ENV_MAXA];
+    {
+        const float yl = ags[l % A].yaw;
+        const float sx = hk_sinf(yl), cz = hk_cosf(yl);
+        const int base = (threadIdx.x & 63) & ~(OBS_LANES - 1);
+#pragma unroll
+        for (int j = 0; j < ENV_MAXA; j++) {
+            kfx[j] = __shfl(sx, base + (j < A ? j : 0), 64);
+            kfz[j] = __shfl(cz, base + (j < A ? j : 0), 64);
+        }
+    }
+    float fx = kfx[0], fz = kfz[0];
+#pragma unroll
+    for (int j = 1; j < ENV_MAXA; j++) if (i == j) { fx = kfx[j]; fz = kfz[j]; }
+    if (!valid) return;
+    if (l == 14) {                                                           // own block HKA:489-496
+        o[0] = local_speed(P, a, fx, fz);
+        o[1] = (a->flags & HK_F_ACCEL) ? 1.0f : 0.0f;
+        o[2] = (float)a->lane;
+        o[3] = a->lane_changes * 1.0f / P.max_lane_changes;
+        o[4] = (a->flags & HK_F_ACTIVE) ? 1.0f : 0.0f;
+        o[5] = a->section_index * 1.0f / goal;
+        o[6] = is_straight(P, T, a->section_index) ? 1.0f : 0.0f;
+        o[7] = tire_wear(P, a->final_steer);
+    } else if (l == 15) {                                                    // team mates, then opponents HKA:500-527
+        int p = 8;
+        for (int pass = 0; pass < 2; pass++) {
+            const int cnt = pass == 0 ? P.n_team[i] : P.n_other[i];
+            for (int j = 0; j < cnt; j++) {
+                const int bj = pass == 0 ? P.team[i][j] : P.other[i][j];
+                const hk_agent_state* b = &ags[bj];
+                float bfx = kfx[0], bfz = kfz[0];
+#pragma unroll
+                for (int q = 1; q < ENV_MAXA; q++) if (bj == q) { bfx = kfx[q]; bfz = kfz[q]; }
+                o[p++] = local_speed(P, b, bfx, bfz);
+                o[p++] = (b->flags & HK_F_ACCEL) ? 1.0f : 0.0f;
+                o[p++] = (float)b->lane;
+                o[p++] = b->lane_changes * 1.0f / P.max_lane_changes;
+                o[p++] = (b->flags & HK_F_ACTIVE) ? 1.0f : 0.0f;
+                o[p++] = is_straight(P, T, b->section_index) ? 1.0f : 0.0f;
+                o[p++] = tire_wear(P, b->final_steer);
+                o[p++] = b->section_index * 1.0f / goal;
+                o[p++] = mag3(b->px - a->px, 0.0f, b->pz - a->pz);
+                float lp[3];
+                inv_transform_point(a, fx, fz, b->px, P.kart_y, b->pz, P.kart_y, lp);
+                o[p++] = lp[0]; o[p++] = lp[1]; o[p++] = lp[2];
+            }
+        }
+    } else if (l >= 9) {                                                     // upcoming sections HKA:530-552
+        for (int q = l - 9; q < H; q += 5) {
+            const int next = (a->section_index + 1 + q) % L;
+            float* os = o + 8 + 12 * (A - 1) + 5 * q;
             float lp[3];
-            inv_transform_point(a, fx, fz, b->px, P.kart_y, b->pz, P.kart_y, lp);
-            o[p++] = lp[0]; o[p++] = lp[1]; o[p++] = lp[2];
+            const int pl = a->plan_lane[next];
+            if (pl != 0) {
+                float mx, mz;
+                lane_marker(T, next, pl, mx, mz);
+                inv_transform_point(a, fx, fz, mx, T.sec[next].marker_y, mz, P.kart_y, lp);
+                os[0] = lp[0]; os[1] = lp[1]; os[2] = lp[2];
+                os[3] = a->plan_vel[next] / P.max_speed;
+            } else {
+                inv_transform_point(a, fx, fz, T.sec[next].trig_x, T.sec[next].marker_y, T.sec[next].trig_z, P.kart_y, lp);
+                os[0] = lp[0]; os[1] = lp[1]; os[2] = lp[2];
+                os[3] = 1.0f;
+            }
+            os[4] = is_straight(P, T, next) ? 1.0f : 0.0f;
         }
-    }
-    for (int s = a->section_index + 1; s < a->section_index + 1 + H; s++) {
-        const int next = s % L;
-        float lp[3];
-        const int pl = a->plan_lane[next];
-        if (pl != 0) {
-            float mx, mz;
-            lane_marker(T, next, pl, mx, mz);
-            inv_transform_point(a, fx, fz, mx, T.sec[next].marker_y, mz, P.kart_y, lp);
-            o[p++] = lp[0]; o[p++] = lp[1]; o[p++] = lp[2];
-            o[p++] = a->plan_vel[next] / P.max_speed;
-        } else {
-            inv_transform_point(a, fx, fz, T.sec[next].trig_x, T.sec[next].marker_y, T.sec[next].trig_z, P.kart_y, lp);
-            o[p++] = lp[0]; o[p++] = lp[1]; o[p++] = lp[2];
-            o[p++] = 1.0f;
-        }
-        o[p++] = is_straight(P, T, next) ? 1.0f : 0.0f;
-    }
-    const float ox = a->px + SENSOR_LZ * fx, oz = a->pz + SENSOR_LZ * fz;
-    const bool see = (a->flags & HK_F_ENABLED) != 0;
-    for (int si = 0; si < HK_NUM_SENSORS; si++) {
+    } else {                                                                 // sensor l HKA:553-603
+        const int si = l;
+        const float ox = a->px + SENSOR_LZ * fx, oz = a->pz + SENSOR_LZ * fz;
+        const bool see = (a->flags & HK_F_ENABLED) != 0;
         float dx, dz;
         sensor_dir(P, si, fx, fz, dx, dz);
         const float maxd = P.ray_dist[si];
@@ -114,16 +142,19 @@ __global__ __launch_bounds__(128) void env_observe_kernel(EnvParams P, const hk_
         float ha = -1.0f;
         int who = -1;
         if (see) {
-            for (int j = 0; j < A; j++) {
-                if (j == i || !(ags[j].flags & HK_F_ENABLED)) continue;
+#pragma unroll
+            for (int j = 0; j < ENV_MAXA; j++) {
+                if (j >= A || j == i || !(ags[j].flags & HK_F_ENABLED)) continue;
                 float t = ray_stadium(ox, oz, dx, dz, ags[j].px, ags[j].pz, kfx[j], kfz[j], P.ray_agent_r);
                 if (t >= 0.0f && t <= maxd && (ha < 0.0f || t < ha)) { ha = t; who = j; }
             }
         }
-        int code = 0;                                                    // HitWall / HitOpponent events (HKA:580-598)
-        if (ht >= 0.0f && (ha < 0.0f || ht < ha)) { o[p++] = ht; if (ht < P.wall_val[si]) code = 1; }
-        else if (ha >= 0.0f) { o[p++] = ha; if (ha < P.agent_val[si]) code = 2 + who; }
-        else o[p++] = maxd;
+        int code = 0;                                                        // HitWall / HitOpponent events (HKA:580-598)
+        float val;
+        if (ht >= 0.0f && (ha < 0.0f || ht < ha)) { val = ht; if (ht < P.wall_val[si]) code = 1; }
+        else if (ha >= 0.0f) { val = ha; if (ha < P.agent_val[si]) code = 2 + who; }
+        else val = maxd;
+        o[8 + 12 * (A - 1) + 5 * H + si] = val;
         if (hit_code) hit_code[(size_t)gid * HK_NUM_SENSORS + si] = (unsigned char)code;
     }
 }
