@@ -435,17 +435,12 @@ inline int env_launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream
     const int* qu = d.queue + (size_t)set * 3 * ngames;
     int rc = HK_OK;
     if (cfg.num_agents >= 2) {
-        const int blocks = std::min((ngames + 3) / 4, 8192);
-        hipLaunchKernelGGL(lqn_kernel<2>, dim3(blocks), dim3(64), 0, stream, d.P, d.agents, d.games, qc, qu, d.lq_debug, d.status);
-        if ((rc = launch_check(err, "lqn_kernel<2>"))) return rc;
-        if (cfg.num_agents >= 3) {
-            hipLaunchKernelGGL(lqn_kernel<3>, dim3(blocks), dim3(64), 0, stream, d.P, d.agents, d.games, qc, qu, d.lq_debug, d.status);
-            if ((rc = launch_check(err, "lqn_kernel<3>"))) return rc;
-        }
-        if (cfg.num_agents >= 4) {
-            hipLaunchKernelGGL(lqn_kernel<4>, dim3(blocks), dim3(64), 0, stream, d.P, d.agents, d.games, qc, qu, d.lq_debug, d.status);
-            if ((rc = launch_check(err, "lqn_kernel<4>"))) return rc;
-        }
+        // 1 024 workgroups per game size (one wave per SIMD at this kernel's 256 VGPRs) walking their queue grid-stride: dispatching
+        // 3 x 8 192 workgroups that exit at once cost 25 us per round in steady state
+        const int nb = std::min((ngames + 3) / 4, 1024);
+        const int sizes = cfg.num_agents - 1;                 // player counts 2 .. A
+        hipLaunchKernelGGL(lqn_all_kernel, dim3(nb * sizes), dim3(64), 0, stream, d.P, d.agents, d.games, qc, qu, d.lq_debug, d.status, nb);
+        if ((rc = launch_check(err, "lqn_all_kernel"))) return rc;
     }
     d.round += 1;
     return HK_OK;

@@ -6,7 +6,7 @@
 //                              (HKA:726-1198).  Writes one compact GameDesc per ego and bins the game by player count.
 //   K_B2 lq1_kernel            one THREAD per single-player game (n = 4, m = 2): the whole Riccati recursion in
 //                              registers.  Once the field has spread out (> 8 m apart) ~99 % of all games are of this kind.
-//        lqn_kernel<N>         multi-player games (N = 2..4) from the per-N queues, 4 games per wave, 16-lane group per
+//        lqn_all_kernel        multi-player games (N = 2..4) from the per-N queues, 4 games per wave, 16-lane group per
 //                              game, through hk_lq_core.h.
 //   both decode u0 -> (Accelerate, Brake, Steering) (HKA:1206-1224).
 //
@@ -581,19 +581,19 @@ struct QCompact {
 };
 
 template <int NP>
-__global__ __launch_bounds__(64) void lqn_kernel(EnvParams P, hk_agent_state* agents, const GameDesc* games, const int* queue_cnt,
-                                                 const int* queue, hk_lq_debug* dbg_out, int* status)
+__device__ __forceinline__ void lqn_body(const int block, const int nblocks, const EnvParams& P, hk_agent_state* agents, const GameDesc* games,
+                                         const int* queue_cnt, const int* queue, hk_lq_debug* dbg_out, int* status, unsigned char* smem)
 {
     constexpr int n = LqDims<NP>::n, GPW = LqDims<NP>::GPW, SLOTS = LqDims<NP>::SLOTS;
-    __shared__ LqGameLds<NP> lds[SLOTS];
-    __shared__ CostRows<NP> rows[SLOTS];
+    LqGameLds<NP>* lds = reinterpret_cast<LqGameLds<NP>*>(smem);                                     // [SLOTS]
+    CostRows<NP>* rows = reinterpret_cast<CostRows<NP>*>(smem + sizeof(LqGameLds<NP>) * SLOTS);     // [SLOTS]
     const int lane = threadIdx.x & 63;
     const int gs = lane / n, r = lane % n;
     const int count = queue_cnt[NP];
     const int* qbase = queue + (size_t)(NP - 2) * P.E * P.A;
     LqGameLds<NP>& LG = lds[gs];
     CostRows<NP>& CR = rows[gs];
-    for (int base = blockIdx.x * GPW; base < count; base += gridDim.x * GPW) {
+    for (int base = block * GPW; base < count; base += nblocks * GPW) {
         const int slot = base + gs;
         const bool live = gs < GPW && slot < count;
         const int game = qbase[live ? slot : count - 1];      // idle slots recompute the last game and discard it
@@ -670,6 +670,24 @@ __global__ __launch_bounds__(64) void lqn_kernel(EnvParams P, hk_agent_state* ag
             me->flags = fl; me->steering = st;
         }
     }
+}
+
+// One launch for the queued games of every size: blocks [0, nb) take the 2-player queue, [nb, 2 nb) the 3-player one,
+// [2 nb, 3 nb) the 4-player one.  (Three separate launches cost ~12 us each even when — as in steady state, where 99.95 % of
+// the games are single-player and solved inside the tick kernel — their queues are empty: 10 % of the headline's wall time.)
+__global__ __launch_bounds__(64) void lqn_all_kernel(EnvParams P, hk_agent_state* agents, const GameDesc* games, const int* queue_cnt,
+                                                     const int* queue, hk_lq_debug* dbg_out, int* status, int nb)
+{
+    // one LDS block, sized for the largest game size and reused by whichever size this workgroup solves
+    constexpr size_t B2 = (sizeof(LqGameLds<2>) + sizeof(CostRows<2>)) * LqDims<2>::SLOTS;
+    constexpr size_t B3 = (sizeof(LqGameLds<3>) + sizeof(CostRows<3>)) * LqDims<3>::SLOTS;
+    constexpr size_t B4 = (sizeof(LqGameLds<4>) + sizeof(CostRows<4>)) * LqDims<4>::SLOTS;
+    constexpr size_t BMAX = B2 > B3 ? (B2 > B4 ? B2 : B4) : (B3 > B4 ? B3 : B4);
+    __shared__ __align__(16) unsigned char smem[BMAX];
+    const int which = blockIdx.x / nb, b = blockIdx.x - which * nb;
+    if (which == 0) lqn_body<2>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
+    else if (which == 1) lqn_body<3>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
+    else lqn_body<4>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
 }
 
 }  // namespace hk
