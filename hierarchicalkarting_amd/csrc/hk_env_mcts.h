@@ -147,12 +147,33 @@ __device__ inline void phase_plan(const EnvParams& P, const MctsDev& M, int set,
 // the discrete game (KartDiscreteGame.cs), one running state per search
 
 struct DKart { int section, time, minv, maxv, lane, tire, lchg; };
+// The karts are NAMED members, not an array: every access is either mc_k<I>(g) with a compile-time I or a field-wise value
+// select (mc_get / mc_set).  With an array the compiler keeps the state in scratch and turns the selects into address
+// selects; a scratch round trip costs hundreds of cycles at this kernel's occupancy and there were hundreds per position.
 struct DGame {
     int P;
-    DKart k[MC_MAXP];
-    int team[MC_MAXP];
+    DKart k0, k1, k2, k3;
+    int t0, t1, t2, t3;         // team of each player
     int last, fin;              // lastCompletedSection, finalSection
 };
+static_assert(MC_MAXP == 4, "DGame names its four karts");
+template <int I> __device__ __forceinline__ DKart& mc_k(DGame& g)
+{
+    if constexpr (I == 0) return g.k0; else if constexpr (I == 1) return g.k1; else if constexpr (I == 2) return g.k2; else return g.k3;
+}
+template <int I> __device__ __forceinline__ const DKart& mc_k(const DGame& g)
+{
+    if constexpr (I == 0) return g.k0; else if constexpr (I == 1) return g.k1; else if constexpr (I == 2) return g.k2; else return g.k3;
+}
+template <int I> __device__ __forceinline__ int& mc_t(DGame& g)
+{
+    if constexpr (I == 0) return g.t0; else if constexpr (I == 1) return g.t1; else if constexpr (I == 2) return g.t2; else return g.t3;
+}
+template <int I> __device__ __forceinline__ int mc_t(const DGame& g)
+{
+    if constexpr (I == 0) return g.t0; else if constexpr (I == 1) return g.t1; else if constexpr (I == 2) return g.t2; else return g.t3;
+}
+#define MC_EACH(X) X(0) X(1) X(2) X(3)
 // The legal moves of the player who is up next: a bit per canonical action (velocity-major) and the time each adds.
 // Every loop over dt[] is fully unrolled, so the array lives in registers (no scratch: a scratch round trip costs
 // hundreds of cycles at the one-wave-per-SIMD occupancy this kernel runs at, and there were hundreds per position).
@@ -169,20 +190,20 @@ struct MctsCtx {
     const int* dt_tab; const float* load_tab; const float* rad_tab; int nv;
 };
 
-__device__ inline void mc_draw(MctsCtx& C, uint32_t r[4]) { philox4x32(C.draw++, C.c1, C.c2, 0x4D435453u, C.key0, C.key1, r); }
-__device__ inline int mc_rand_next(MctsCtx& C, int n)
+__device__ __forceinline__ void mc_draw(MctsCtx& C, uint32_t r[4]) { philox4x32(C.draw++, C.c1, C.c2, 0x4D435453u, C.key0, C.key1, r); }
+__device__ __forceinline__ int mc_rand_next(MctsCtx& C, int n)
 {
     uint32_t r[4]; mc_draw(C, r);
     return (int)(((unsigned long long)r[0] * (unsigned long long)n) >> 32);
 }
-__device__ inline float mc_normal(MctsCtx& C)
+__device__ __forceinline__ float mc_normal(MctsCtx& C)
 {
     uint32_t r[4]; mc_draw(C, r);
     const float u1 = (float)((r[0] >> 8) + 1u) * (1.0f / 16777216.0f);
     const float u2 = u01(r[1]);
     return sqrtf(-2.0f * hk_logf(u1)) * hk_cosf((2.0f * HK_PI_F) * u2);
 }
-__device__ inline float mc_gauss_bounded(MctsCtx& C, float mean, float sd, float lo, float hi)
+__device__ __forceinline__ float mc_gauss_bounded(MctsCtx& C, float mean, float sd, float lo, float hi)
 {   // KartMCTS.NextGaussian(mean, sd, min, max) :225-240
     float x; int attempts = 0;
     do { x = mean + mc_normal(C) * sd; attempts += 1; } while ((x < lo || x > hi) && attempts < 10);
@@ -190,7 +211,7 @@ __device__ inline float mc_gauss_bounded(MctsCtx& C, float mean, float sd, float
     return x;
 }
 
-__device__ inline void mc_action(const MctsCtx& C, int a, int& minv, int& maxv, int& lane)
+__device__ __forceinline__ void mc_action(const MctsCtx& C, int a, int& minv, int& maxv, int& lane)
 {   // KDG:325-338: for (i = 6; i < maxSpeed; i += bucket) for (lane = 1..4)
     const int vi = a >> 2;
     minv = 6 + vi * C.bucket;
@@ -228,7 +249,7 @@ __device__ inline float mc_tire_load(const MctsCtx& C, int section, float veloci
     const float gs = (velocity * velocity) / mc_radius(C, section, l0, l1);
     return gs * mc_distance(C, section, l0, l1) * 0.01f;
 }
-__device__ inline float mc_max_speed(const MctsCtx& C, float radius, float wear)
+__device__ __forceinline__ float mc_max_speed(const MctsCtx& C, float radius, float wear)
 {   // ArcadeKart.getMaxSpeedForRadiusAndWear :536-547
     const hk_kart_stats& st = C.P->st;
     if (radius == 0.0f) return st.TopSpeed;
@@ -237,7 +258,7 @@ __device__ inline float mc_max_speed(const MctsCtx& C, float radius, float wear)
     if (__builtin_isinf(v) || __builtin_isnan(v)) v = st.TopSpeed;
     return v < 0.0001f ? 0.0001f : (v > st.TopSpeed ? st.TopSpeed : v);
 }
-__device__ inline bool mc_straight(const MctsCtx& C, int section) { return C.T->sec[section % C.P->L].inside_radius == 0.0f; }
+__device__ __forceinline__ bool mc_straight(const MctsCtx& C, int section) { return C.T->sec[section % C.P->L].inside_radius == 0.0f; }
 __device__ inline float mc_avgv(int minv, int maxv) { return (1.0f * (float)(minv + maxv)) / 2.0f; }
 
 __device__ inline float mc_toc(const MctsCtx& C, float distance, float radius, float wear, float initV, float finalV)
@@ -281,7 +302,7 @@ __device__ inline bool mc_apply(const MctsCtx& C, const DKart& k, int minv, int 
     return dt >= 0;
 }
 
-__device__ inline int mc_cmp(const DKart& a, const DKart& b)
+__device__ __forceinline__ int mc_cmp(const DKart& a, const DKart& b)
 {   // the Comparison of upNext KDG:186-223
     if (a.section < b.section) return -1;
     if (a.section > b.section) return 1;
@@ -295,30 +316,30 @@ __device__ inline int mc_cmp(const DKart& a, const DKart& b)
     return 1;
 }
 
-// g.k[] is only ever indexed with compile-time constants (unrolled loops / these selectors), so the game state stays in
-// registers
+// Selection by bit masks, not by ?: — a conditional between two member reads becomes a select of ADDRESSES followed by one
+// load (in C++ `c ? lvalue : lvalue` is an lvalue, and LLVM forms the same thing from selects of loads), which pins the
+// whole game state in scratch.  All fields are ints, so and / or with all-ones masks is exact.
 __device__ __forceinline__ DKart mc_get(const DGame& g, int p)
 {
-    DKart r = g.k[0];
-    if (p == 1) r = g.k[1];
-    if (p == 2) r = g.k[2];
-    if (p == 3) r = g.k[3];
+    const int m1 = -(int)(p == 1), m2 = -(int)(p == 2), m3 = -(int)(p == 3), m0 = ~(m1 | m2 | m3);
+    DKart r;
+#define MC_SEL(f) r.f = (g.k0.f & m0) | (g.k1.f & m1) | (g.k2.f & m2) | (g.k3.f & m3);
+    MC_SEL(section) MC_SEL(time) MC_SEL(minv) MC_SEL(maxv) MC_SEL(lane) MC_SEL(tire) MC_SEL(lchg)
+#undef MC_SEL
     return r;
 }
 __device__ __forceinline__ void mc_set(DGame& g, int p, const DKart& v)
 {
-    if (p == 0) g.k[0] = v;
-    if (p == 1) g.k[1] = v;
-    if (p == 2) g.k[2] = v;
-    if (p == 3) g.k[3] = v;
+#define MC_PUT(I, f) mc_k<I>(g).f = (mc_k<I>(g).f & ~(-(int)(p == I))) | (v.f & -(int)(p == I));
+#define MC_PUTK(I) MC_PUT(I, section) MC_PUT(I, time) MC_PUT(I, minv) MC_PUT(I, maxv) MC_PUT(I, lane) MC_PUT(I, tire) MC_PUT(I, lchg)
+    MC_EACH(MC_PUTK)
+#undef MC_PUTK
+#undef MC_PUT
 }
 __device__ __forceinline__ int mc_team(const DGame& g, int p)
 {
-    int r = g.team[0];
-    if (p == 1) r = g.team[1];
-    if (p == 2) r = g.team[2];
-    if (p == 3) r = g.team[3];
-    return r;
+    const int m1 = -(int)(p == 1), m2 = -(int)(p == 2), m3 = -(int)(p == 3), m0 = ~(m1 | m2 | m3);
+    return (g.t0 & m0) | (g.t1 & m1) | (g.t2 & m2) | (g.t3 & m3);
 }
 
 // upNext KDG:183-238: the first kart, in the order List.Sort leaves them, that has not completed section last + 1.
@@ -326,22 +347,23 @@ __device__ __forceinline__ int mc_team(const DGame& g, int p)
 // answer is their minimum under the comparison; .NET's small-partition sorts (2: one compare-swap, 3: (0,1)(0,2)(1,2),
 // 4..16: insertion sort) all leave the lowest-indexed of several equal minima in front, which is the tie rule used here
 // (the CPU oracle runs the sorts themselves).
-__device__ inline int mc_up_next(const DGame& g)
+__device__ __forceinline__ int mc_up_next(const DGame& g)
 {
     int best = -1;
-    DKart bk = g.k[0];
-#pragma unroll
-    for (int p = 0; p < MC_MAXP; p++) {
-        if (p >= g.P || g.k[p].section == g.last + 1) continue;
-        if (best < 0 || mc_cmp(g.k[p], bk) < 0) { best = p; bk = g.k[p]; }
+    DKart bk = g.k0;
+#define MC_STEP(I)                                                                           \
+    if (I < g.P && mc_k<I>(g).section != g.last + 1) {                                       \
+        if (best < 0 || mc_cmp(mc_k<I>(g), bk) < 0) { best = I; bk = mc_k<I>(g); }           \
     }
+    MC_EACH(MC_STEP)
+#undef MC_STEP
     return best;
 }
 
-__device__ inline int mc_vb(const MctsCtx& C, int minv) { return minv == 0 ? 0 : 1 + (minv - 6) / C.bucket; }
+__device__ __forceinline__ int mc_vb(const MctsCtx& C, int minv) { return minv == 0 ? 0 : 1 + (minv - 6) / C.bucket; }
 
 // nextMoves KDG:318-411 for the player who is up next (np), with the time each legal move adds (from the move tables)
-__device__ inline void mc_eval_moves(const MctsCtx& C, const DGame& g, int np, MoveEval& mv)
+__device__ __forceinline__ void mc_eval_moves(const MctsCtx& C, const DGame& g, int np, MoveEval& mv)
 {
     const DKart cur = mc_get(g, np);
     const int L = C.P->L, sm = cur.section % L;
@@ -365,7 +387,7 @@ __device__ inline void mc_eval_moves(const MctsCtx& C, const DGame& g, int np, M
 }
 
 // makeMove KDG:416-443 on the running state (applyAction through the move tables)
-__device__ inline void mc_make_move(const MctsCtx& C, DGame& g, int np, int a)
+__device__ __forceinline__ void mc_make_move(const MctsCtx& C, DGame& g, int np, int a)
 {
     DKart k = mc_get(g, np);
     const int L = C.P->L, sm = k.section % L;
@@ -383,8 +405,9 @@ __device__ inline void mc_make_move(const MctsCtx& C, DGame& g, int np, int a)
     k.section += 1; k.minv = minv; k.maxv = maxv; k.lane = lane; k.lchg = lchg;
     mc_set(g, np, k);
     bool allAhead = true;
-#pragma unroll
-    for (int i = 0; i < MC_MAXP; i++) if (i < g.P) allAhead = allAhead && (g.k[i].section > g.last);
+#define MC_AHEAD(I) if (I < g.P) allAhead = allAhead && (mc_k<I>(g).section > g.last);
+    MC_EACH(MC_AHEAD)
+#undef MC_AHEAD
     if (allAhead) g.last += 1;
 }
 
@@ -392,7 +415,7 @@ __device__ inline void mc_make_move(const MctsCtx& C, DGame& g, int np, int a)
 // OrderBy(time added).ThenByDescending(max_velocity).ThenBy(|lane change|).ThenBy(sign * lane), a stable sort.  The four keys
 // pack into one integer; the index-th element is the one with exactly `index` legal moves before it (ties by canonical
 // order) — all in registers.
-__device__ inline int mc_pick_move(const MctsCtx& C, const MoveEval& mv, int cur_lane, int sign, int index)
+__device__ __forceinline__ int mc_pick_move(const MctsCtx& C, const MoveEval& mv, int cur_lane, int sign, int index)
 {
     uint32_t key[MC_MAXA];
 #pragma unroll
@@ -420,7 +443,7 @@ __device__ inline int mc_pick_move(const MctsCtx& C, const MoveEval& mv, int cur
 }
 
 // isOver KDG:246-313 given the legal-move count of the position.  scores: the reference's List<float> (can exceed P)
-__device__ inline bool mc_is_over(const MctsCtx& C, const DGame& g, int np, int n_legal, float (&scores)[2 * MC_MAXP])
+__device__ __forceinline__ bool mc_is_over(const MctsCtx& C, const DGame& g, int np, int n_legal, float (&scores)[2 * MC_MAXP])
 {
     if (n_legal == 0) {
         // for each player: [0.0 if it is the stuck player or a team mate of it], then 0.5 (the reference has no `else`)
@@ -428,51 +451,52 @@ __device__ inline bool mc_is_over(const MctsCtx& C, const DGame& g, int np, int 
         int n = 0;
 #pragma unroll
         for (int q = 0; q < 2 * MC_MAXP; q++) scores[q] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < MC_MAXP; i++) {
-            if (i >= g.P) continue;
-            const bool zero_first = (i == np) || (g.team[i] == tnp);
-            // entries n (0.0, only when zero_first) and then 0.5
-            const int pos = n + (zero_first ? 1 : 0);
-#pragma unroll
-            for (int q = 0; q < 2 * MC_MAXP; q++) if (q == pos) scores[q] = 0.5f;
-            n = pos + 1;
+#define MC_NOMOVE(I)                                                                         \
+        if (I < g.P) {                                                                       \
+            const bool zero_first = (I == np) || (mc_t<I>(g) == tnp);                        \
+            const int pos = n + (zero_first ? 1 : 0);   /* entry n = 0.0 (only when zero_first), then 0.5 */ \
+            _Pragma("unroll") for (int q = 0; q < 2 * MC_MAXP; q++) if (q == pos) scores[q] = 0.5f;          \
+            n = pos + 1;                                                                     \
         }
+        MC_EACH(MC_NOMOVE)
+#undef MC_NOMOVE
         return true;
     }
     if (g.last != g.fin) return false;
     if (g.P > 1) {
         const float tsm = 0.75f;                                    // RacingEnvController.TeamScoreRewardMultiplier
         float maxScore = (float)C.precision * -1000.0f, minScore = (float)C.precision * 1000.0f;
-        float raw[MC_MAXP];
         float teamScore = 0.0f, opponentScore = 0.0f;
         int teamCount = 0, opponentCount = 0;                       // accumulate over players (not reset, KDG:273-276)
-#pragma unroll
-        for (int s = 0; s < MC_MAXP; s++) {
-            raw[s] = 0.0f;
-            if (s >= g.P) continue;
-#pragma unroll
-            for (int o = 0; o < MC_MAXP; o++) {
-                if (o >= g.P) continue;
-                if (s == o) teamScore += (float)g.k[o].time;
-                else if (g.team[s] == g.team[o]) { teamScore += (float)g.k[o].time * tsm; teamCount += 1; }
-                else { opponentScore += (float)g.k[o].time; opponentCount += 1; }
-            }
-            const float score = opponentScore * (((float)teamCount * tsm + 1.0f) / ((float)opponentCount * 1.0f)) - teamScore;
-            raw[s] = score;
-            const bool nn = __builtin_isnan(score);                 // Math.Max / Math.Min propagate NaN
-            maxScore = (__builtin_isnan(maxScore) || nn) ? __builtin_nanf("") : (maxScore > score ? maxScore : score);
-            minScore = (__builtin_isnan(minScore) || nn) ? __builtin_nanf("") : (minScore < score ? minScore : score);
+        float raw0 = 0.0f, raw1 = 0.0f, raw2 = 0.0f, raw3 = 0.0f;
+#define MC_PAIR(S, O)                                                                        \
+        if (O < g.P) {                                                                       \
+            if (S == O) teamScore += (float)mc_k<O>(g).time;                                 \
+            else if (mc_t<S>(g) == mc_t<O>(g)) { teamScore += (float)mc_k<O>(g).time * tsm; teamCount += 1; } \
+            else { opponentScore += (float)mc_k<O>(g).time; opponentCount += 1; }            \
         }
-#pragma unroll
-        for (int s = 0; s < MC_MAXP; s++) {
-            if (s >= g.P) continue;
-            const int si = (raw[s] >= -2147483648.0f && raw[s] < 2147483648.0f) ? (int)raw[s] : (-2147483647 - 1);
-            scores[s] = ((float)si - minScore) * 1.0f / (maxScore - minScore);
+#define MC_SCORE(S)                                                                          \
+        if (S < g.P) {                                                                       \
+            MC_PAIR(S, 0) MC_PAIR(S, 1) MC_PAIR(S, 2) MC_PAIR(S, 3)                          \
+            const float score = opponentScore * (((float)teamCount * tsm + 1.0f) / ((float)opponentCount * 1.0f)) - teamScore; \
+            raw##S = score;                                                                  \
+            const bool nn = __builtin_isnan(score);   /* Math.Max / Math.Min propagate NaN */ \
+            maxScore = (__builtin_isnan(maxScore) || nn) ? __builtin_nanf("") : (maxScore > score ? maxScore : score); \
+            minScore = (__builtin_isnan(minScore) || nn) ? __builtin_nanf("") : (minScore < score ? minScore : score); \
         }
+        MC_EACH(MC_SCORE)
+#undef MC_SCORE
+#undef MC_PAIR
+#define MC_NORM(S)                                                                           \
+        if (S < g.P) {                                                                       \
+            const int si = (raw##S >= -2147483648.0f && raw##S < 2147483648.0f) ? (int)raw##S : (-2147483647 - 1); \
+            scores[S] = ((float)si - minScore) * 1.0f / (maxScore - minScore);               \
+        }
+        MC_EACH(MC_NORM)
+#undef MC_NORM
         return true;
     }
-    scores[0] = (float)(C.P->max_steps - g.k[0].time / C.P->max_steps);
+    scores[0] = (float)(C.P->max_steps - g.k0.time / C.P->max_steps);
     return true;
 }
 
@@ -527,12 +551,12 @@ __global__ __launch_bounds__(256) void mcts_table_kernel(EnvParams P, MctsDev M,
 // ---------------------------------------------------------------------------------------------------------------------
 // the tree (KartMCTS.cs)
 
-__device__ inline float mc_uct(const MNode* nd, int c)
+__device__ __forceinline__ float mc_uct(const MNode* nd, int c)
 {   // UCTWeight :162-165 (integer division inside the log)
     const MNode& n = nd[c];
     return (n.totalValue / (float)n.numEpisodes) + sqrtf(1.0f) * hk_logf((float)(nd[n.parent].numEpisodes / n.numEpisodes));
 }
-__device__ inline int mc_ucs(MctsCtx& C, const MNode* nd, int node)
+__device__ __forceinline__ int mc_ucs(MctsCtx& C, const MNode* nd, int node)
 {   // upperConfidenceStrategy :167-193; children in insertion order
     const int index = mc_rand_next(C, nd[node].n_children);
     int c = nd[node].first_child;
@@ -583,21 +607,24 @@ __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M,
             if (initialSection == R.k[i].section) furthest = i;
         }
     }
-#pragma unroll
-    for (int p = 0; p < MC_MAXP; p++) {
-        DKart& k = root.k[p];
-        k.section = 0; k.time = 0; k.minv = 0; k.maxv = 0; k.lane = 1; k.tire = 0; k.lchg = 0; root.team[p] = 0;
-        if (p >= root.P) continue;
-        const int ap = (int)((agent_of >> (8 * p)) & 255u);
-        const MctsKartSnap& s = R.k[ap];
-        root.team[p] = P.team_of[ap];
-        k.minv = 0;                                                  // HKA:211-219: the bucket loop breaks at i = 0
-        k.maxv = C.bucket < C.vmax ? C.bucket : C.vmax;
-        k.section = initialSection;
-        if (s.section != initialSection)                             // HKA:221-224
-            k.time = (int)((float)(s.sec_time[s.section & 3] - R.k[furthest].sec_time[s.section & 3]) * P.dt * (float)C.precision);
-        k.lane = s.lane; k.tire = s.tire_age; k.lchg = s.lane_changes;
+#define MC_ROOT(I)                                                                           \
+    {                                                                                        \
+        DKart& k = mc_k<I>(root);                                                            \
+        k.section = 0; k.time = 0; k.minv = 0; k.maxv = 0; k.lane = 1; k.tire = 0; k.lchg = 0; mc_t<I>(root) = 0; \
+        if (I < root.P) {                                                                    \
+            const int ap = (int)((agent_of >> (8 * I)) & 255u);                              \
+            const MctsKartSnap& s = R.k[ap];                                                 \
+            mc_t<I>(root) = P.team_of[ap];                                                   \
+            k.minv = 0;                                /* HKA:211-219: the bucket loop breaks at i = 0 */ \
+            k.maxv = C.bucket < C.vmax ? C.bucket : C.vmax;                                  \
+            k.section = initialSection;                                                      \
+            if (s.section != initialSection)           /* HKA:221-224 */                      \
+                k.time = (int)((float)(s.sec_time[s.section & 3] - R.k[furthest].sec_time[s.section & 3]) * P.dt * (float)C.precision); \
+            k.lane = s.lane; k.tire = s.tire_age; k.lchg = s.lane_changes;                   \
+        }                                                                                    \
     }
+    MC_EACH(MC_ROOT)
+#undef MC_ROOT
     root.last = initialSection;
     root.fin = initialSection + P.depth[ego];
 
@@ -671,13 +698,15 @@ __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M,
             node = mc_ucs(C, nd, node);
             mc_make_move(C, g, np, nd[node].action);
             bool all_at = true;
-#pragma unroll
-            for (int p = 0; p < MC_MAXP; p++) if (p < g.P) all_at = all_at && (g.k[p].section == g.last);
+#define MC_AT(I) if (I < g.P) all_at = all_at && (mc_k<I>(g).section == g.last);
+            MC_EACH(MC_AT)
+#undef MC_AT
             if (all_at && plan.n_states < HK_MCTS_MAX_DEPTH) {
                 const int s = plan.n_states++;
                 plan.section[s] = g.last;
-#pragma unroll
-                for (int p = 0; p < MC_MAXP; p++) if (p < g.P) { plan.lane[s][p] = (uint8_t)g.k[p].lane; plan.vel[s][p] = (uint8_t)g.k[p].maxv; }
+#define MC_OUT(I) if (I < g.P) { plan.lane[s][I] = (uint8_t)mc_k<I>(g).lane; plan.vel[s][I] = (uint8_t)mc_k<I>(g).maxv; }
+                MC_EACH(MC_OUT)
+#undef MC_OUT
             }
         }
     }
