@@ -11,7 +11,7 @@
 
 namespace hk {
 
-constexpr int ENV_MAXA = 4;             // agents per env handled by the round-1 kernels
+constexpr int ENV_MAXA = 4;             // agents per env (a quad of lanes); the largest reference scene has 4
 constexpr float DEG2RAD_F = 0.0174532924f;
 constexpr float TWO_PI_F = 2.0f * HK_PI_F;
 constexpr float CAP_R = 0.45f;          // kart capsule (BaseKartClassic.prefab): radius, core segment in kart-local z

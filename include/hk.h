@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 #define HK_ABI_VERSION 2
-#define HK_MAX_AGENTS 8      /* ABI capacity; the round-1 kernels accept num_agents <= 4 (largest reference scene) */
+#define HK_MAX_AGENTS 8      /* ABI capacity; the kernels accept num_agents <= 4 (the largest reference scene) */
 #define HK_MAX_SECTIONS 64   /* Oval 24, Complex 41 */
 #define HK_NUM_SENSORS 9     /* MLAgent_Sensors.prefab */
 
@@ -29,7 +29,7 @@ typedef enum hk_status {
     HK_ERR_INVALID = -1,      /* bad argument / config */
     HK_ERR_NO_DEVICE = -2,    /* no HIP device: the product path has no CPU fallback */
     HK_ERR_HIP = -3,          /* HIP runtime error (see hk_last_error) */
-    HK_ERR_UNSUPPORTED = -4,  /* valid in the reference, not built yet (e.g. num_agents > 4, MCTS, RL policy) */
+    HK_ERR_UNSUPPORTED = -4,  /* valid in the reference, not built yet (num_agents > 4, Training-mode randomised resets, LQ games of > 4 players) */
     HK_ERR_SINGULAR = -5      /* LQ: zero pivot in the m x m solve */
 } hk_status;
 
@@ -277,7 +277,7 @@ int hk_get_mcts_state(hk_handle h, hk_mcts_state* out /*[E][A]*/);
 
 /* KartLQR.solveFeedbackLQR (AI/LQR/KartLQR.cs:17) batched, 1:1 incl. quirks Q1 (block-transposed LHS) and Q2.
  * A[b][N][4][4], B[b][N][4][2], Q[b][N][n][n], q[b][N][n], R[b][N][2][2], x0[b][n], n = 4N; u0_out[b][2].
- * Host pointers; h may be NULL (a temporary context on device 0 is used). N <= 4 in round 1. */
+ * Host pointers; h may be NULL (a temporary context on device 0 is used). N <= 4. */
 int hk_lq_solve_batch(hk_handle h, int batch, int N, const double* A, const double* B, const double* Q, const double* q,
                       const double* R, const double* x0, int horizon, double* u0_out);
 
