@@ -71,6 +71,7 @@ class Config(C.Structure):
         ("time_precision", _I8), ("section_window", _I8), ("mcts_iterations", C.c_int32),
         ("mcts_initial_iterations", C.c_int32), ("mcts_latency_ticks", C.c_int32), ("mcts_initial_latency_ticks", C.c_int32),
         ("mcts_seed", C.c_uint32), ("rewards", C.c_int32), ("training_agent", _I8), ("rw", RewardParams),
+        ("train_seed", C.c_uint32), ("reserved_cfg", C.c_int32),
     ]
 
 

@@ -60,7 +60,7 @@ def make_config(num_envs, num_agents=4, track="oval", high_mode=_lib.HK_HIGH_FIX
                 device_id=0, wiring=None, env_mode=_lib.HK_MODE_EXPERIMENT, max_episode_steps=None, laps=None,
                 stats=None, time_precision=100, section_window=2, mcts_iterations=128, mcts_initial_iterations=None,
                 mcts_latency_ticks=45, mcts_initial_latency_ticks=75, mcts_seed=0x4D435453, rewards=0, training_agents=None,
-                reward_params=None, disable_on_end=None):
+                reward_params=None, disable_on_end=None, train_seed=0x54524149):
     tr = load_track(track) if isinstance(track, str) else track
     secs = tr["sections"]
     L = len(secs)
@@ -117,7 +117,9 @@ def make_config(num_envs, num_agents=4, track="oval", high_mode=_lib.HK_HIGH_FIX
     cfg.section_horizon = int(rules["sectionHorizon"])
     cfg.disable_on_end = int(rules["disableOnEnd"] if disable_on_end is None else disable_on_end)
     cfg.env_mode = env_mode
-    cfg.start_hold_ticks = 75
+    # StartRaceAfterDelay waits 1.5 s except in Training mode (REC:723-724)
+    cfg.start_hold_ticks = 0 if env_mode == _lib.HK_MODE_TRAINING else 75
+    cfg.train_seed = train_seed
     cfg.auto_reset = auto_reset
     cfg.dt = 0.02
     cfg.kart_y = 0.28

@@ -59,6 +59,9 @@ struct EnvParams {
     int rewards, n_teams, team_size[ENV_MAXA], training_agent[ENV_MAXA];
     float wall_val[HK_NUM_SENSORS], agent_val[HK_NUM_SENSORS];   // Sensor.WallHitValidationDistance / AgentHitValidationDistance
     hk_reward_params rw;
+    // Training mode (hk_env_training.h)
+    int training_reset;
+    uint32_t train_seed;
 };
 constexpr float GRID_CELL = 2.0f;       // cell size (m)
 constexpr float GRID_REACH = 2.2f;      // list radius: 2 m side rays / 1 m half-spacing of the long-ray samples / 1.11 m

@@ -96,7 +96,6 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         err = "hk_create: bad num_envs / num_agents / track table"; return HK_ERR_INVALID;
     }
     if (A > ENV_MAXA) { err = "hk_create: num_agents > 4 not built yet (largest reference scene has 4)"; return HK_ERR_UNSUPPORTED; }
-    if (cfg.env_mode == HK_MODE_TRAINING) { err = "hk_create: Training-mode randomised resets not built yet"; return HK_ERR_UNSUPPORTED; }
     for (int i = 0; i < A; i++) {
         if (cfg.n_team[i] < 0 || cfg.n_other[i] < 0 || cfg.n_team[i] + cfg.n_other[i] != A - 1) {
             err = "hk_create: teamAgents + otherAgents of every agent must list every other agent exactly once"; return HK_ERR_INVALID;
@@ -137,6 +136,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         const float dl = cfg.sensor_yaw_deg[i] * DEG2RAD_F;
         P.sens_c[i] = hk_cosf(dl); P.sens_s[i] = hk_sinf(dl); P.ray_dist[i] = cfg.ray_distance[i];
     }
+    P.training_reset = cfg.env_mode == HK_MODE_TRAINING ? 1 : 0; P.train_seed = cfg.train_seed;
     P.rewards = cfg.rewards; P.rw = cfg.rw;
     for (int i = 0; i < HK_NUM_SENSORS; i++) { P.wall_val[i] = cfg.wall_hit_validation[i]; P.agent_val[i] = cfg.agent_hit_validation[i]; }
     for (int i = 0; i < A; i++) {
@@ -415,12 +415,15 @@ inline int env_rounds_for(const hk_config& cfg, int n_ticks)
 inline int env_launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
 {
     const int threads = cfg.num_envs * 4;
-#define HK_RUN(MC, RWF)                                                                                                       \
-    hipLaunchKernelGGL((env_run_kernel<MC, RWF>), dim3((threads + 255) / 256), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs,   \
+#define HK_RUN(MC, RWF, TRN)                                                                                                  \
+    hipLaunchKernelGGL((env_run_kernel<MC, RWF, TRN>), dim3((threads + 255) / 256), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs,   \
                        d.results, d.games, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status,     \
                        d.tab_lds ? 1 : 0, d.mcts, d.mset, d.rw)
-    if (d.mcts.st) { if (d.rw.sec_time) HK_RUN(true, true); else HK_RUN(true, false); }
-    else { if (d.rw.sec_time) HK_RUN(false, true); else HK_RUN(false, false); }
+    bool train = d.P.training_reset != 0;
+    for (int i = 0; i < cfg.num_agents; i++) train = train || d.P.training_agent[i] != 0;
+    if (train) HK_RUN(true, true, true);
+    else if (d.mcts.st) { if (d.rw.sec_time) HK_RUN(true, true, false); else HK_RUN(true, false, false); }
+    else { if (d.rw.sec_time) HK_RUN(false, true, false); else HK_RUN(false, false, false); }
 #undef HK_RUN
     return launch_check(err, "env_run_kernel");
 }

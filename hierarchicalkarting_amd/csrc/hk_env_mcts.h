@@ -134,7 +134,7 @@ __device__ inline void phase_plan(const EnvParams& P, const MctsDev& M, int set,
     const bool enabled = me && (flags & HK_F_ENABLED);
     const bool inactive = (es.inactive_mask >> i) & 1u;
     uint32_t req = 0;
-    if (enabled && P.high_mode[i] == HK_HIGH_MCTS && es.episode_steps % 100 == 0 && es.episode_steps < P.max_steps &&
+    if (enabled && P.high_mode[i] == HK_HIGH_MCTS && !P.training_agent[i] && es.episode_steps % 100 == 0 && es.episode_steps < P.max_steps &&
         es.episode_steps > 0 && !inactive)
         req = 1u << i;
     req |= __shfl_xor(req, 1, 64); req |= __shfl_xor(req, 2, 64);

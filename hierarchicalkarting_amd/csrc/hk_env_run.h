@@ -38,8 +38,10 @@ __global__ __launch_bounds__(256) void env_check_kernel(const hk_env_state* envs
     if (env < E && (envs[env].reserved[0] != 0 || envs[env].reserved[1] != 0)) atomicOr(status, 4);
 }
 
-// HAS_MCTS = false is the headline path: the planner hooks (request / consume / beliefs) compile away entirely
-template <bool HAS_MCTS, bool HAS_RW>
+// <false, false, false> is the headline path: the planner hooks (request / consume / beliefs), reward shaping and the
+// Training-mode code compile away entirely.  Instantiated: every (HAS_MCTS, HAS_RW) pair without Training code, and
+// <true, true, true> for any handle that uses Training mode (its planner / reward parts are also guarded at run time).
+template <bool HAS_MCTS, bool HAS_RW, bool HAS_TRAIN>
 __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
                                                       hk_episode_result* results, GameDesc* games, int* queue_cnt_all,
                                                       int* queue_all, int set, const float* act_steer, const int* act_branch,
@@ -74,11 +76,11 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
     if (arec) h = load_hot(arec); else { Hot z = {}; h = z; }
     float hfx = hk_sinf(h.yaw), hfz = hk_cosf(h.yaw);    // the kart's forward, carried across ticks (changes only when yaw does)
     RwAcc rwv = {0.0f, 0.0f, 0.0f};
-    if (HAS_RW && arec) { rwv.cum = arec->cum_reward; rwv.step = arec->step_reward; rwv.group = arec->group_reward; }
+    if (HAS_RW && P.rewards && arec) { rwv.cum = arec->cum_reward; rwv.step = arec->step_reward; rwv.group = arec->group_reward; }
     while (env_ok && (phase != 0 || (left > 0 && budget > 0))) {
         dirty = true;
         if (phase == 0) {
-            const bool parked = phase_begin<HAS_RW>(P, env, i, env_ok, es, h, hfx, hfz, agents, results, M, mset, RD, rwv, act_branch);
+            const bool parked = phase_begin<HAS_RW, HAS_TRAIN>(P, env, i, env_ok, es, h, hfx, hfz, agents, results, M, mset, RD, rwv, act_branch);
             bool queued = false;
             if (!parked) {
                 const bool act = (es.episode_steps % cadence) == 0 &&                                  // HKA:317 (Q9)
@@ -94,13 +96,13 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
             q |= __shfl_xor(q, 1, 64); q |= __shfl_xor(q, 2, 64);
             if (q) { phase = 1; break; }
         }
-        phase_move<HAS_RW>(P, T, env, i, env_ok, es, h, hfx, hfz, agents, act_steer, act_branch, M.st, RD, rwv);
+        phase_move<HAS_RW, HAS_TRAIN>(P, T, env, i, env_ok, es, h, hfx, hfz, agents, act_steer, act_branch, M.st, RD, rwv);
         phase = 0;
         left -= 1; budget -= 1;
     }
     if (arec && dirty) {
         store_hot(arec, h);
-        if (HAS_RW) { arec->cum_reward = rwv.cum; arec->step_reward = rwv.step; arec->group_reward = rwv.group; }
+        if (HAS_RW && P.rewards) { arec->cum_reward = rwv.cum; arec->step_reward = rwv.step; arec->group_reward = rwv.group; }
     }
     if (env_ok && dirty && i == 0) {
         es.reserved[0] = left;

@@ -8,6 +8,7 @@
 #pragma once
 #include "hk_env_device.h"
 #include "hk_env_mcts.h"
+#include "hk_env_training.h"
 
 namespace hk {
 
@@ -21,7 +22,8 @@ namespace hk {
 
 
 // REC.ResetGame :499-719 for one agent (Experiment / Race grid); see oracle reset_env for the line map
-__device__ inline void reset_agent(const EnvParams& P, const TabView& T, int env, int i, int experiment_num, hk_agent_state* a)
+template <bool TRAIN>
+__device__ inline void reset_agent(const EnvParams& P, const TabView& T, int env, int i, int experiment_num, int episodes_done, hk_agent_state* a)
 {
     const int expLane[4] = {2, 3, 2, 3};
     const int expSection[4] = {0, 0, 1, 1};
@@ -36,16 +38,22 @@ __device__ inline void reset_agent(const EnvParams& P, const TabView& T, int env
     __builtin_memset(a, 0, sizeof(hk_agent_state));     // (not a uint32_t* loop: that would violate type-based aliasing)
     a->tele_completed_laps = t_laps; a->tele_lap_end_step = t_step;
     a->tele_last_lap = t_last; a->tele_best_lap = t_best; a->tele_total_time = t_total;
-    const int sec = expSection[j & 3];
-    const int lane = expLane[j & 3];
+    int sec = expSection[j & 3];
+    int lane = expLane[j & 3];
+    float spawn = 3.0f, acc0 = P.init_acc;
+    if (TRAIN && P.training_reset) {                         // Training mode: random scatter (REC:520-668)
+        float twp = 0.25f;
+        training_layout(P, T, env, experiment_num, episodes_done, ord, i, sec, lane, twp, spawn);
+        acc0 = -P.st.TireWearRate * hk_logf(1 - ((P.st.MaxSteer - P.st.MinSteer) * twp / P.st.MaxSteer));
+    }
     a->section_index = sec;
     a->init_checkpoint_index = sec;
-    a->acc_ang_v = P.init_acc;
+    a->acc_ang_v = acc0;
     a->lane = lane;
     const SecDev& s = T.sec[sec % P.L];
     float yaw = s.yaw_rad;
-    float px = s.lane_x[lane - 1] + s.fx * 3.0f;
-    float pz = s.lane_z[lane - 1] + s.fz * 3.0f;
+    float px = s.lane_x[lane - 1] + s.fx * spawn;
+    float pz = s.lane_z[lane - 1] + s.fz * spawn;
     if (P.jitter_seed != 0u) {
         uint32_t r[4];
         philox4x32((uint32_t)experiment_num, (uint32_t)i, 0u, 0u, P.jitter_seed + (uint32_t)(P.env_id_base + env), 0u, r);
@@ -57,7 +65,8 @@ __device__ inline void reset_agent(const EnvParams& P, const TabView& T, int env
     }
     a->px = px; a->pz = pz; a->yaw = yaw;
     a->final_steer = kart_steer(P, a->acc_ang_v);
-    if (P.high_mode[i] == HK_HIGH_FIXED) plan_fixed(P, T, i, a->section_index, a);
+    if (TRAIN && P.training_agent[i]) plan_randomly(P, T, env, i, a->section_index, 0, episodes_done, a);     // Mode == Training (HKA:101-103)
+    else if (P.high_mode[i] == HK_HIGH_FIXED) plan_fixed(P, T, i, a->section_index, a);
     a->flags = HK_F_ACTIVE | HK_F_ENABLED;
 }
 
@@ -89,7 +98,7 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_st
     const int ex = experiment_num >= 0 ? experiment_num : (P.env_id_base + env) % P.nperm;
     const TabView T = tab_view(P, P.tab);
     hk_agent_state* ar = &agents[(size_t)env * P.A + i];
-    reset_agent(P, T, env, i, ex, ar);
+    reset_agent<true>(P, T, env, i, ex, envs[env].episodes_done, ar);
     if (RD.sec_time) {
         const int nn = P.A * RD.S;
         for (int q = i; q < nn; q += P.A) { RD.sec_time[(size_t)env * nn + q] = -1; RD.sec_cnt[(size_t)env * nn + q] = 0; }
@@ -97,7 +106,7 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_st
     if (M.st) {
         mcts_reset_state(&M.st[(size_t)env * P.A + i]);
         uint32_t req = 0;
-        for (int e = 0; e < P.A; e++) if (P.high_mode[e] == HK_HIGH_MCTS) req |= 1u << e;
+        for (int e = 0; e < P.A; e++) if (P.high_mode[e] == HK_HIGH_MCTS && !P.training_agent[e]) req |= 1u << e;
         mcts_post_request(P, M, set, env, i, req, 0, envs[env].episodes_done, P.mcts_iter0, P.mcts_lat0,
                           ar->section_index, ar->lane, ar->lane_changes, ar->final_steer);
     }
@@ -116,11 +125,12 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_st
 // rays (:135-167).  `es` is the quad's register copy of the env words (identical in the 4 lanes).  Returns true when the
 // env is parked (auto_reset off and the episode is over): nothing else happens on this tick.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool RW>
+template <bool RWT, bool TRAIN>
 __device__ inline bool phase_begin(const EnvParams& P, const int env, const int i, const bool env_ok, hk_env_state& es,
                                    Hot& h, float& hfx, float& hfz, hk_agent_state* agents, hk_episode_result* results,
                                    const MctsDev& M, const int set, const RwDev& RD, RwAcc& rwv, const int* act_branch)
 {
+    const bool RW = RWT && P.rewards != 0;     // the <true, true, true> instantiation also serves handles without rewards
     const bool me = env_ok && i < P.A;
     hk_agent_state* a = me ? &agents[(size_t)env * P.A + i] : nullptr;
     const uint32_t all_mask = (1u << P.A) - 1u;
@@ -182,7 +192,7 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
             // REC.ResetGame rewrites the whole record (plans included): through memory, then back into registers
             store_hot(a, h);
             const TabView T = tab_view(P, P.tab);
-            reset_agent(P, T, env, i, es.experiment_num, a);
+            reset_agent<TRAIN>(P, T, env, i, es.experiment_num, es.episodes_done, a);
             h = load_hot(a);
             hfx = hk_sinf(h.yaw); hfz = hk_cosf(h.yaw);
         }
@@ -193,7 +203,7 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
             // prepareForReuse + initialPlan (HKA:84-96, 428-452): planner state cleared, first plan requested (T = 1.5 s)
             if (me) mcts_reset_state(&M.st[(size_t)env * P.A + i]);
             uint32_t req = 0;
-            for (int e = 0; e < P.A; e++) if (P.high_mode[e] == HK_HIGH_MCTS) req |= 1u << e;
+            for (int e = 0; e < P.A; e++) if (P.high_mode[e] == HK_HIGH_MCTS && !P.training_agent[e]) req |= 1u << e;
             mcts_post_request(P, M, set, env, i, req, 0, es.episodes_done, P.mcts_iter0, P.mcts_lat0,
                               h.section_index, h.lane, h.lane_changes, h.final_steer);
         }
@@ -269,11 +279,12 @@ __device__ inline int calculate_lane(const EnvParams& P, const SecDev& s, float 
 }
 
 // phase C of a tick (after every ego's controls are known)
-template <bool RW>
+template <bool RWT, bool TRAIN>
 __device__ inline void phase_move(const EnvParams& P, const TabView& T, const int env, const int i, const bool env_ok,
                                   hk_env_state& es, Hot& h, float& hfx, float& hfz, hk_agent_state* agents, const float* act_steer,
                                   const int* act_branch, hk_mcts_state* mcts_all, const RwDev& RD, RwAcc& rwv)
 {
+    const bool RW = RWT && P.rewards != 0;
     const bool me = env_ok && i < P.A;
     const int episode_steps = es.episode_steps;
     const uint32_t inactive_mask = es.inactive_mask, status = es.status;
@@ -296,8 +307,10 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             if (br > 1) fl |= HK_F_ACCEL; else fl &= ~HK_F_ACCEL;
             if (br < 1) fl |= HK_F_BRAKE; else fl &= ~HK_F_BRAKE;
         }
-        if (episode_steps % 100 == 0 && episode_steps < P.max_steps && episode_steps > 0 && !inactive_before)
-            if (P.high_mode[i] == HK_HIGH_FIXED) plan_fixed(P, T, i, h.section_index, a);
+        if (episode_steps % 100 == 0 && episode_steps < P.max_steps && episode_steps > 0 && !inactive_before) {
+            if (TRAIN && P.training_agent[i]) plan_randomly(P, T, env, i, h.section_index, episode_steps, es.episodes_done, a);   // HKA:357-360
+            else if (P.high_mode[i] == HK_HIGH_FIXED) plan_fixed(P, T, i, h.section_index, a);
+        }
         // ---- ArcadeKart.FixedUpdate
         bool accelerate = false, brake = false; float turnInput = 0.0f;
         if (fl & HK_F_ACTIVE) { accelerate = (fl & HK_F_ACCEL) != 0; brake = (fl & HK_F_BRAKE) != 0; turnInput = h.steering; }

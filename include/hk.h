@@ -132,6 +132,11 @@ typedef struct hk_config {
     int32_t rewards;
     int32_t training_agent[HK_MAX_AGENTS];   /* KartAgent.Mode == AgentMode.Training (KA:34-38): only these enter AddGoalTimingRewards (REC:217) */
     hk_reward_params rw;
+    /* env_mode == HK_MODE_TRAINING: ResetGame scatters the karts at random (REC:520-668); training_agent[i]: the agent plans
+     * with planRandomly (HKA:109-143) instead of planFixed / MCTS.  UnityEngine.Random / System.Random draws become
+     * Philox-4x32 keyed by train_seed, the global env id and the episode ("parity unpinned"). */
+    uint32_t train_seed;
+    int32_t reserved_cfg;
 } hk_config;
 
 #define HK_MCTS_MAX_DEPTH 8      /* gameParams.treeSearchDepth <= 8 */

@@ -233,6 +233,98 @@ static void plan_fixed(const hko_env* e, int agent, hk_agent_state* a)
     }
 }
 
+/* draws of the Training-mode code (stand-ins for UnityEngine.Random / System.Random / MathNet Normal, see hk.h) */
+typedef struct { uint32_t k0, k1, c1, c2, c3, n; } tr_rng;
+static uint32_t tr_u32(tr_rng* g) { uint32_t r[4]; philox4x32(g->n++, g->c1, g->c2, g->c3, g->k0, g->k1, r); return r[0]; }
+static int tr_range_i(tr_rng* g, int lo, int hi)        /* Random.Range(int, int): [lo, hi) */
+{
+    if (hi <= lo) return lo;
+    return lo + (int)(((uint64_t)tr_u32(g) * (uint64_t)(hi - lo)) >> 32);
+}
+static float tr_range_f(tr_rng* g, float lo, float hi) { return lo + u01(tr_u32(g)) * (hi - lo); }   /* Random.Range(float, float) */
+static float tr_normal(tr_rng* g)
+{
+    uint32_t r[4]; philox4x32(g->n++, g->c1, g->c2, g->c3, g->k0, g->k1, r);
+    float u1 = (float)((r[0] >> 8) + 1u) * (1.0f / 16777216.0f), u2 = u01(r[1]);
+    return sqrtf(-2.0f * hk_logf(u1)) * hk_cosf((2.0f * HK_PI_F) * u2);
+}
+static float tr_gauss_bounded(tr_rng* g, float mean, float sd, float lo, float hi)
+{   /* KartMCTS.NextGaussian(mean, sd, min, max) KM:225-240 */
+    float x; int attempts = 0;
+    do { x = mean + tr_normal(g) * sd; attempts += 1; } while ((x < lo || x > hi) && attempts < 10);
+    if (attempts == 10 && (x < lo || x > hi)) return mean;
+    return x;
+}
+
+/* HKA.planRandomly :109-143 */
+static void plan_randomly(const hko_env* e, int env, int agent, hk_agent_state* a)
+{
+    const hk_env_state* es = &e->es[env];
+    tr_rng g = {e->cfg.train_seed ^ 0x504C414Eu, (uint32_t)(e->cfg.env_id_base + env) * (uint32_t)e->A + (uint32_t)agent,
+                (uint32_t)es->episode_steps, (uint32_t)es->episodes_done, 0u, 0u};
+    int depth = e->cfg.tree_search_depth[agent];
+    int hi = a->section_index + depth; if (hi > 1000) hi = 1000;
+    for (int i = a->section_index + 1; i < hi + 1; i++) {
+        int key = i % e->L;
+        if (a->plan_lane[key] != 0) continue;
+        int index = (int)__builtin_rintf(f_abs(tr_gauss_bounded(&g, 0.0f, 1.0f, -(float)4 + 1.0f, (float)4 - 1.0f)));
+        int ol = e->sec[(i - 1) % e->L].optimal_lane;
+        int sign = ol == 1 ? 1 : (ol == 4 ? -1 : 0);                 /* getOptimalLaneSign DPT:221-231 */
+        int lane = sign < 0 ? 4 - index : 1 + index;                 /* Enumerable.Range(1, 4).OrderBy(l => sign * l)[index] */
+        a->plan_lane[key] = (uint8_t)lane;
+        if (e->cfg.high_mode[agent] == HK_HIGH_FIXED) a->plan_vel[key] = e->max_speed;
+        else a->plan_vel[key] = e->max_speed - f_abs(tr_gauss_bounded(&g, 0.0f, 1.5f, -8.0f, 8.0f));
+    }
+}
+
+/* REC.ResetGame :520-668, Training mode: where every kart starts.  out: section, lane, genTWP, distFromSpawn per agent */
+static void training_layout(hko_env* e, int env, const int* ord, int* sec, int* lane, float* twp, float* dist)
+{
+    const hk_env_state* es = &e->es[env];
+    tr_rng g = {e->cfg.train_seed, (uint32_t)(e->cfg.env_id_base + env), (uint32_t)es->episodes_done, (uint32_t)es->experiment_num, 0x54524E47u, 0u};
+    const int A = e->A, L = e->L, goal = e->cfg.laps * L + 1;
+    const int headToHead = tr_range_i(&g, 0, 9) >= 3;                                   /* :523 */
+    int used_sec[HK_MAX_AGENTS], used_lane[HK_MAX_AGENTS], n_added = 0, initialSection = -1;
+    for (int j = 0; j < A; j++) {
+        const int i = ord[j];
+        int s_i, l_i;
+        if (!headToHead) {                                                              /* :533-580 */
+            while (1) {
+                s_i = tr_range_i(&g, 0, goal);
+                l_i = tr_range_i(&g, 1, 5);
+                int clash = 0;
+                for (int q = 0; q < n_added; q++) clash |= (used_sec[q] == s_i % L && used_lane[q] == l_i);
+                if (!clash) break;
+            }
+            twp[i] = tr_range_f(&g, 0.0f, 1.0f);
+        } else if (n_added == 0) {                                                      /* :585-629 */
+            s_i = tr_range_i(&g, 0, goal);
+            initialSection = s_i;
+            twp[i] = tr_range_f(&g, 0.0f, 1.0f);
+            l_i = tr_range_i(&g, 1, 5);
+        } else {                                                                        /* :631-684 */
+            const int lo = initialSection - 1 > 0 ? initialSection - 1 : 0, hi = initialSection + 2 < goal ? initialSection + 2 : goal;
+            while (1) {
+                s_i = tr_range_i(&g, lo, hi);
+                l_i = tr_range_i(&g, 1, 5);
+                int clash = 0;
+                for (int q = 0; q < n_added; q++) clash |= (used_sec[q] == s_i % L && used_lane[q] == l_i);
+                if (!clash) break;
+            }
+            twp[i] = tr_range_f(&g, 0.0f, 1.0f);
+        }
+        float d = tr_range_f(&g, 1.0f, 4.0f);
+        if (tr_range_f(&g, 0.0f, 1.0f) < 0.3f) {                                        /* start close behind a wall */
+            const hk_section* s = &e->sec[s_i % L];
+            const sec_pre* sp = &e->sp[s_i % L];
+            float hit = hko_raycast_track(e, s->lane_x[l_i - 1], s->lane_z[l_i - 1], sp->fx, sp->fz, 10.0f);
+            if (hit >= 0.0f) d = hit - 1.0f;
+        }
+        sec[i] = s_i; lane[i] = l_i; dist[i] = d;
+        used_sec[n_added] = s_i % L; used_lane[n_added] = l_i; n_added++;
+    }
+}
+
 /* KA.SetZeroInputs :480-486, KA.Deactivate :405-416 */
 static void deactivate(const hko_env* e, hk_agent_state* a)
 {
@@ -256,6 +348,10 @@ static void reset_env(hko_env* e, int env)
     if (e->sec_min_time) hko_rw_reset_env(e, env);           /* :508-512 */
     const int* ord = &e->perms[(size_t)(((es->experiment_num % e->nperm) + e->nperm) % e->nperm) * e->A];  /* :528 */
     const uint32_t env_gid = (uint32_t)(e->cfg.env_id_base + env);
+    const int training = e->cfg.env_mode == HK_MODE_TRAINING;
+    int t_sec[HK_MAX_AGENTS], t_lane[HK_MAX_AGENTS];
+    float t_twp[HK_MAX_AGENTS], t_dist[HK_MAX_AGENTS];
+    if (training) training_layout(e, env, ord, t_sec, t_lane, t_twp, t_dist);
     for (int j = 0; j < e->A; j++) {
         int i = ord[j];
         hk_agent_state* a = &ags[i];
@@ -265,15 +361,20 @@ static void reset_env(hko_env* e, int env)
         /* the TelemetryViewer is not reset with the game: its arrays survive (it notices the lower lap count itself) */
         a->tele_completed_laps = t_laps; a->tele_lap_end_step = t_step;
         a->tele_last_lap = t_last; a->tele_best_lap = t_best; a->tele_total_time = t_total;
-        a->section_index = expSectionChoices[j & 3];         /* :583 / :634 */
+        a->section_index = training ? t_sec[i] : expSectionChoices[j & 3];   /* :583 / :634 */
         a->init_checkpoint_index = a->section_index;         /* :586 */
         a->acc_ang_v = e->init_acc_ang_v;                    /* :588 */
-        a->lane = expLaneChoices[j & 3];                     /* :593 */
+        if (training) {
+            const hk_kart_stats* st = &e->cfg.stats;
+            a->acc_ang_v = -st->TireWearRate * hk_logf(1 - ((st->MaxSteer - st->MinSteer) * t_twp[i] / st->MaxSteer));
+        }
+        a->lane = training ? t_lane[i] : expLaneChoices[j & 3];              /* :593 */
+        const float spawn = training ? t_dist[i] : 3.0f;
         const hk_section* s = &e->sec[a->section_index % e->L];
         const sec_pre* sp = &e->sp[a->section_index % e->L];
         float yaw = sp->yaw_rad;                             /* :602 rotation = lane marker rotation */
-        float px = s->lane_x[a->lane - 1] + sp->fx * 3.0f;   /* :614 position + forward * distFromSpawn (3.0) */
-        float pz = s->lane_z[a->lane - 1] + sp->fz * 3.0f;
+        float px = s->lane_x[a->lane - 1] + sp->fx * spawn;  /* :614 position + forward * distFromSpawn (3.0 outside Training) */
+        float pz = s->lane_z[a->lane - 1] + sp->fz * spawn;
         if (e->cfg.jitter_seed != 0u) {                      /* synthetic, NOT in the reference */
             uint32_t r[4];
             philox4x32((uint32_t)es->experiment_num, (uint32_t)i, 0u, 0u, e->cfg.jitter_seed + env_gid, 0u, r);
@@ -286,7 +387,8 @@ static void reset_env(hko_env* e, int env)
         a->px = px; a->pz = pz; a->yaw = yaw;
         /* prepareForReuse KA:209-221 (UpdateStats, counters, plans cleared) + initialPlan HKA:84-104 */
         a->final_steer = kart_steer(e, a->acc_ang_v);
-        if (e->cfg.high_mode[i] == HK_HIGH_FIXED) plan_fixed(e, i, a);
+        if (e->cfg.training_agent[i]) plan_randomly(e, env, i, a);                      /* Mode == Training: HKA:101-103 */
+        else if (e->cfg.high_mode[i] == HK_HIGH_FIXED) plan_fixed(e, i, a);
         /* Activate KA:421-435 */
         a->flags = HK_F_ACTIVE | HK_F_ENABLED;               /* m_CanMove stays false until StartRaceAfterDelay */
     }
@@ -301,7 +403,7 @@ static void reset_env(hko_env* e, int env)
             m->ready_step = -1;
         }
         for (int i = 0; i < e->A; i++) {
-            if (e->cfg.high_mode[i] != HK_HIGH_MCTS) continue;
+            if (e->cfg.high_mode[i] != HK_HIGH_MCTS || e->cfg.training_agent[i]) continue;
             hk_mcts_state* m = &e->mcts[(size_t)env * e->A + i];
             hko_mcts_search(e, env, i, e->cfg.mcts_initial_iterations, &m->pend);
             m->searches += 1;
@@ -881,7 +983,8 @@ static void step_env(hko_env* e, int env)
             if (br < 1) a->flags |= HK_F_BRAKE; else a->flags &= ~HK_F_BRAKE;
         }
         if (es->episode_steps % 100 == 0 && es->episode_steps < cfg->max_episode_steps && es->episode_steps > 0 && !inactive) {
-            if (cfg->high_mode[i] == HK_HIGH_FIXED) plan_fixed(e, i, a);                /* :331-355 */
+            if (cfg->training_agent[i]) plan_randomly(e, env, i, a);                    /* :357-360 Mode == Training */
+            else if (cfg->high_mode[i] == HK_HIGH_FIXED) plan_fixed(e, i, a);           /* :331-355 */
             else {                                                                      /* :335-350 planWithMCTS() */
                 hk_mcts_state* m = &e->mcts[(size_t)env * A + i];
                 hko_mcts_search(e, env, i, cfg->mcts_iterations, &m->pend);
@@ -1117,7 +1220,6 @@ void hko_destroy(hko_env* e)
 int hko_reset(hko_env* e, const int32_t* env_ids, int n, int experiment_num)
 {
     if (!e) return HK_ERR_INVALID;
-    if (e->cfg.env_mode == HK_MODE_TRAINING) return HK_ERR_UNSUPPORTED;
     int cnt = env_ids ? n : e->E;
     for (int q = 0; q < cnt; q++) {
         int env = env_ids ? env_ids[q] : q;

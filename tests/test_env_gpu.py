@@ -126,7 +126,7 @@ def test_invalid_configs_are_refused():
         hk.RacingEnv(hk.make_config(2, 4, high_mode=_lib.HK_HIGH_MCTS, tree_search_depth=12))   # gameParams.treeSearchDepth <= 8
     assert e.value.code == _lib.HK_ERR_INVALID
     with pytest.raises(_lib.HkError) as e:
-        hk.RacingEnv(hk.make_config(2, 4, env_mode=_lib.HK_MODE_TRAINING))
+        hk.RacingEnv(hk.make_config(2, 4, low_mode=_lib.HK_LOW_MPC))          # dead code in the reference
     assert e.value.code == _lib.HK_ERR_UNSUPPORTED
     with pytest.raises(_lib.HkError) as e:
         hk.RacingEnv(hk.make_config(2, 4, wiring=([0, 0, 1, 1], [[1], [0], [3], []], [[2, 3], [2, 3], [0, 1], [0, 1]])))

@@ -79,24 +79,20 @@ def test_being_behind_penalty_and_rank_multipliers():
 
 def test_goal_timing_group_reward_only_for_training_agents():
     """REC:174-237: the goal-timing reward goes to the groups of Mode == Training agents, and only to group members whose
-    GameObject is still enabled (disableOnEnd = 1 in the scenes unregisters finished karts, so there it reaches nobody)"""
+    GameObject is still enabled (disableOnEnd = 1 in the scenes unregisters finished karts, so there it reaches nobody).
+    A 60-tick time-out inside the start hold: nobody moves, nobody finishes -> every m_timeSteps becomes 5 * max, gt = 0,
+    s = Base + Mult * (0 + 1) / 2 = 5.5 for each Training agent, and no other group reward exists."""
     def run(training, doe):
-        o = O.OracleEnv(make_config(2, 2, rewards=1, jitter_seed=3, laps=1, max_episode_steps=3000, training_agents=training,
-                                    disable_on_end=doe))
+        o = O.OracleEnv(make_config(3, 2, rewards=1, jitter_seed=3, max_episode_steps=60, training_agents=training, disable_on_end=doe))
         o.reset()
-        for _ in range(16):
-            o.step(100)
+        o.step(61)
         res = o.episode_results()
-        assert (res["episode"] >= 0).all()
-        return res["group_reward"].astype(np.float64)          # terminal m_GroupReward (the record itself is reset in that tick)
-    base = run([0, 0], 0)
-    assert np.allclose(run([1, 1], 1), run([0, 0], 1))              # disabled karts receive nothing
-    both = run([1, 1], 0)
-    extra = both - base
-    # s = Base + Mult * (gt + 1) / 2 with gt in (-1, 1): between 3 and 8 per finished episode, winner more than loser
-    assert ((extra > 2.9) & (extra < 16.1)).all(), extra
-    only0 = run([1, 0], 0) - base
-    assert (only0[:, 0] > 2.9).all() and np.allclose(only0[:, 1], 0.0, atol=1e-4)
+        assert (res["episode"] == 0).all()
+        return res["group_reward"]
+    assert np.allclose(run([1, 0], 0), [[5.5, 0.0]] * 3, atol=1e-6)
+    assert np.allclose(run([1, 1], 0), [[5.5, 5.5]] * 3, atol=1e-6)
+    assert np.allclose(run([1, 1], 1), 0.0)                          # disabled karts are not registered: nobody receives it
+    assert np.allclose(run([0, 0], 0), 0.0)
 
 
 def test_hit_penalties_raised_by_collect_observations():
