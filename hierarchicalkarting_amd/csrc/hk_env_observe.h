@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_
     float kfx[ENV_MAXA], kfz[ENV_MAXA];
     {
         const float yl = ags[l % A].yaw;
-        const float sx = hk_sinf(yl), cz = hk_cosf(yl);
+        float sx, cz;
+        hk_sincosf(yl, &sx, &cz);
         const int base = (threadIdx.x & 63) & ~(OBS_LANES - 1);
 #pragma unroll
         for (int j = 0; j < ENV_MAXA; j++) {

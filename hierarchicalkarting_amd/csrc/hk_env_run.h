@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
     hk_agent_state* arec = (env_ok && i < P.A) ? &agents[(size_t)env * P.A + i] : nullptr;
     Hot h;
     if (arec) h = load_hot(arec); else { Hot z = {}; h = z; }
-    float hfx = hk_sinf(h.yaw), hfz = hk_cosf(h.yaw);    // the kart's forward, carried across ticks (changes only when yaw does)
+    float hfx, hfz;                                      // the kart's forward, carried across ticks (changes only when yaw does)
+    hk_sincosf(h.yaw, &hfx, &hfz);
     RwAcc rwv = {0.0f, 0.0f, 0.0f};
     if (HAS_RW && P.rewards && arec) { rwv.cum = arec->cum_reward; rwv.step = arec->step_reward; rwv.group = arec->group_reward; }
     while (env_ok && (phase != 0 || (left > 0 && budget > 0))) {

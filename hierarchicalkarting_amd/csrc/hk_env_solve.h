@@ -45,7 +45,9 @@ struct KartS {                 // per-kart staging (LDS), filled by the kart's o
 
 __device__ __forceinline__ double angle_difference(double a1, double a2)
 {   // HKA:1341-1344
-    return hk_atan2(hk_sin(a2 - a1), hk_cos(a2 - a1));
+    double sd, cd;
+    hk_sincos(a2 - a1, &sd, &cd);
+    return hk_atan2(sd, cd);
 }
 
 // HKA:1206-1224
@@ -245,10 +247,12 @@ __device__ __forceinline__ void assemble_player(const EnvParams& P, const TabVie
         initial[0] = kk.px; initial[1] = kk.pz; initial[2] = speed; initial[3] = kk.heading;
         {   // LinearizedBicycle (KartLQRDynamics.cs:40-62), dt = Time.fixedDeltaTime widened to double (HKA:707)
             const double dt = (double)P.dt;
-            gp->a4[0] = hk_cos(initial[3]) * dt;
-            gp->a4[1] = hk_sin(initial[3]) * dt;
-            gp->a4[2] = -hk_sin(initial[3]) * dt * initial[2];
-            gp->a4[3] = hk_cos(initial[3]) * dt * initial[2];
+            double sh, ch;
+            hk_sincos(initial[3], &sh, &ch);
+            gp->a4[0] = ch * dt;
+            gp->a4[1] = sh * dt;
+            gp->a4[2] = -sh * dt * initial[2];
+            gp->a4[3] = ch * dt * initial[2];
         }
         const int s = kk.sec + 1;                                                     // :746
         const int idx = s % L, idx2 = (s + 1) % L;

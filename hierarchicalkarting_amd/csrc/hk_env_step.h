@@ -194,7 +194,7 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
             const TabView T = tab_view(P, P.tab);
             reset_agent<TRAIN>(P, T, env, i, es.experiment_num, es.episodes_done, a);
             h = load_hot(a);
-            hfx = hk_sinf(h.yaw); hfz = hk_cosf(h.yaw);
+            hk_sincosf(h.yaw, &hfx, &hfz);
         }
         es.episode_steps = 0;
         es.inactive_mask = 0;
@@ -260,7 +260,8 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void rot_y(float ang_rad, float& x, float& z)
 {
-    float c = hk_cosf(ang_rad), s = hk_sinf(ang_rad);
+    float c, s;
+    hk_sincosf(ang_rad, &s, &c);
     float nx = x * c + z * s;
     float nz = z * c - x * s;
     x = nx; z = nz;
@@ -379,7 +380,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             if (yaw >= TWO_PI_F) yaw -= TWO_PI_F;
             px = px + vx * dt;
             pz = pz + vz * dt;
-            cfx = hk_sinf(yaw); cfz = hk_cosf(yaw);
+            hk_sincosf(yaw, &cfx, &cfz);
         }
     }
     // ---- kart-kart contacts (Jacobi over one snapshot)

@@ -98,6 +98,21 @@ HK_HD double hk_cos(double x)
     }
 }
 
+/* sin and cos of the same argument: one range reduction, both kernels evaluated once (branch-free), results selected by
+ * quadrant.  Bit-identical to (hk_sin(x), hk_cos(x)) by construction — same reduction, same kernels (tests/test_detmath.py).
+ * The HIP kernels call this where they need the pair (a wave's lanes sit in different quadrants, so the switch of hk_sin /
+ * hk_cos made every lane evaluate both kernels anyway — twice when the pair was needed). */
+HK_HD void hk_sincos(double x, double* s, double* c)
+{
+    double r;
+    const int q = hk__rem_pio2(x, &r);
+    const double ks = hk__ksin(r), kc = hk__kcos(r);
+    const double a = (q & 1) ? kc : ks;          /* |sin| source */
+    const double b = (q & 1) ? ks : kc;          /* |cos| source */
+    *s = (q & 2) ? -a : a;                       /* q: 0 ks, 1 kc, 2 -ks, 3 -kc */
+    *c = ((q + 1) & 2) ? -b : b;                 /* q: 0 kc, 1 -ks, 2 -kc, 3 ks */
+}
+
 /* atan(t) for t in [0,1] */
 HK_HD double hk__atan01(double t)
 {
@@ -205,6 +220,7 @@ HK_HD double hk_log(double x)
 /* Mathf.* = libm in double, result rounded to float (Q8) */
 HK_HD float hk_sinf(float x) { return (float)hk_sin((double)x); }
 HK_HD float hk_cosf(float x) { return (float)hk_cos((double)x); }
+HK_HD void hk_sincosf(float x, float* s, float* c) { double ds, dc; hk_sincos((double)x, &ds, &dc); *s = (float)ds; *c = (float)dc; }
 HK_HD float hk_atan2f(float y, float x) { return (float)hk_atan2((double)y, (double)x); }
 HK_HD float hk_expf(float x) { return (float)hk_exp((double)x); }
 HK_HD float hk_logf(float x) { return (float)hk_log((double)x); }

@@ -47,7 +47,8 @@ double hko_cos(double x);
 double hko_atan2(double y, double x);
 double hko_exp(double x);
 double hko_log(double x);
-float hko_expf_fast(float x);   /* the actor's Swish exp (fp32) */
+float hko_expf_fast(float x);
+void hko_sincos(double x, double* s, double* c);   /* the kernels' fused pair: must equal (hko_sin, hko_cos) bit for bit */   /* the actor's Swish exp (fp32) */
 
 /* ---- whole-environment oracle (components a4-a11) ---- */
 typedef struct hko_env hko_env;

@@ -95,3 +95,21 @@ def test_expf_fast_within_2ulp_and_saturates():
     assert (np.abs(got.astype(np.float64) - ref) / ulp).max() <= 2.0
     assert L.hko_expf_fast(1000.0) == L.hko_expf_fast(88.0) and L.hko_expf_fast(-1000.0) == L.hko_expf_fast(-87.0)
     assert L.hko_expf_fast(0.0) == 1.0
+
+
+def test_sincos_pair_is_bit_identical_to_sin_and_cos():
+    """the HIP kernels use hk_sincos where they need both values; the oracle calls hk_sin / hk_cos: they must agree exactly"""
+    import ctypes as C
+    L = lib()
+    L.hko_sincos.restype = None
+    L.hko_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    r = np.random.default_rng(11)
+    xs = np.concatenate([r.uniform(-7, 7, 20000), r.uniform(-1e4, 1e4, 5000), r.uniform(-1e-3, 1e-3, 2000),
+                         [0.0, -0.0, np.pi / 2, np.pi, 3 * np.pi / 2, 2 * np.pi, 0.78539816339744828]])
+    xs = np.concatenate([xs, xs.astype(np.float32).astype(np.float64)])
+    s, c = C.c_double(), C.c_double()
+    for x in xs:
+        L.hko_sincos(float(x), C.byref(s), C.byref(c))
+        assert s.value == L.hko_sin(float(x)) and c.value == L.hko_cos(float(x)), x
+        assert (s.value == 0.0) == (L.hko_sin(float(x)) == 0.0)          # also the sign of zero
+        assert np.signbit(s.value) == np.signbit(L.hko_sin(float(x))) and np.signbit(c.value) == np.signbit(L.hko_cos(float(x)))
