@@ -12,6 +12,7 @@ HK_NUM_SENSORS = 9
 HK_ABI_VERSION = 2
 HK_PROF_STAGES = 5
 PROF_STAGE_NAMES = ("env_run_kernel", "lqn_kernel<2,3,4>", "lq_batch_kernel", "policy_mlp_kernel", "observe+stack")
+HK_COMM_ID_BYTES = 128
 HK_MAX_POLICIES = 4
 HK_POLICY_MAX_LAYERS = 4
 HK_POLICY_MAX_IN = 1280
@@ -168,6 +169,10 @@ SYMBOLS = {
     "hk_policy_attach": (C.c_int, [_H, C.POINTER(PolicyDesc), C.POINTER(C.c_int32), C.c_int, C.c_int]),
     "hk_policy_forward": (C.c_int, [_H, C.c_int, C.c_int, _fp, _fp, _fp]),
     "hk_get_actions": (C.c_int, [_H, _fp, C.POINTER(C.c_int32)]),
+    "hk_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "hk_comm_init": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
+    "hk_gather_results": (C.c_int, [_H, C.POINTER(EpisodeResult)]),
+    "hk_comm_destroy": (C.c_int, [_H]),
     "hk_prof_enable": (C.c_int, [_H, C.c_int]),
     "hk_prof_reset": (C.c_int, [_H]),
     "hk_prof_read": (C.c_int, [_H, _dp, C.POINTER(C.c_int64)]),

@@ -12,6 +12,7 @@
 #include "hk_lq_kernels.h"
 #include "hk_env_kernels.h"
 #include "hk_policy.h"
+#include <dlfcn.h>
 
 namespace {
 
@@ -83,6 +84,11 @@ struct hk_context {
     long long academy_step = 0;    // ticks stepped since hk_create (Academy.StepCount)
     void* pol_scratch = nullptr;   // hk_policy_forward staging
     size_t pol_scratch_bytes = 0;
+    // RCCL communicator for hk_gather_results (librccl.so loaded lazily)
+    void* comm = nullptr;
+    int comm_world = 0, comm_rank = 0;
+    void* gather_buf = nullptr;
+    size_t gather_bytes = 0;
 };
 
 namespace {
@@ -121,6 +127,34 @@ int ensure_ctx_basics(hk_context* h)
 
 hk_context* g_default_ctx = nullptr;   // used by hk_lq_solve_batch(NULL, ...)
 
+// The five RCCL entry points hk_gather_results needs, resolved from librccl.so at first use (signatures as in rccl.h;
+// ncclUniqueId is a 128-byte struct passed by value, ncclChar = 0, ncclSuccess = 0).
+struct RcclId { char internal[HK_COMM_ID_BYTES]; };
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(RcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool load(std::string& err)
+    {
+        if (lib) return true;
+        lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) { err = std::string("hk_comm: cannot load librccl.so: ") + dlerror(); return false; }
+        GetUniqueId = (int (*)(RcclId*))dlsym(lib, "ncclGetUniqueId");
+        CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(lib, "ncclCommInitRank");
+        AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(lib, "ncclAllGather");
+        CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+        GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy) { err = "hk_comm: librccl.so lacks an expected symbol"; lib = nullptr; return false; }
+        return true;
+    }
+    std::string why(int rc) const { return GetErrorString ? std::string(GetErrorString(rc)) : std::to_string(rc); }
+};
+RcclApi g_rccl;
+
 }  // namespace
 
 extern "C" {
@@ -158,6 +192,8 @@ void hk_destroy(hk_handle h)
     hk::env_destroy(h->dev);
     if (h->d_status) (void)hipFree(h->d_status);
     if (h->lq_scratch) (void)hipFree(h->lq_scratch);
+    if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
+    if (h->gather_buf) (void)hipFree(h->gather_buf);
     if (h->pol_scratch) (void)hipFree(h->pol_scratch);
     for (int p = 0; p < HK_MAX_POLICIES; p++) hk::policy_free(h->policy[p]);
     h->prof.fold();
@@ -503,6 +539,62 @@ int hk_get_episode_results(hk_handle h, hk_episode_result* out)
     const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
     HK_HIP(h, hipMemcpyAsync(out, h->dev.results, cnt * sizeof(hk_episode_result), hipMemcpyDeviceToHost, h->stream));
     HK_HIP(h, hipStreamSynchronize(h->stream));
+    return HK_OK;
+}
+
+int hk_comm_unique_id(void* id_out)
+{
+    if (!id_out) return fail(nullptr, HK_ERR_INVALID, "hk_comm_unique_id: NULL pointer");
+    std::string err;
+    if (!g_rccl.load(err)) return fail(nullptr, HK_ERR_UNSUPPORTED, err);
+    RcclId id;
+    const int rc = g_rccl.GetUniqueId(&id);
+    if (rc != 0) return fail(nullptr, HK_ERR_HIP, "ncclGetUniqueId: " + g_rccl.why(rc));
+    std::memcpy(id_out, id.internal, HK_COMM_ID_BYTES);
+    return HK_OK;
+}
+
+int hk_comm_init(hk_handle h, int world_size, int rank, const void* id)
+{
+    HK_NEED_ENV(h);
+    if (!id || world_size < 1 || rank < 0 || rank >= world_size) return fail(h, HK_ERR_INVALID, "hk_comm_init: bad world_size / rank / id");
+    if (h->comm) return fail(h, HK_ERR_INVALID, "hk_comm_init: this handle already has a communicator");
+    if (!g_rccl.load(h->err)) { g_last_error = h->err; return HK_ERR_UNSUPPORTED; }
+    RcclId rid;
+    std::memcpy(rid.internal, id, HK_COMM_ID_BYTES);
+    const int rc = g_rccl.CommInitRank(&h->comm, world_size, rid, rank);
+    if (rc != 0) { h->comm = nullptr; return fail(h, HK_ERR_HIP, "ncclCommInitRank: " + g_rccl.why(rc)); }
+    h->comm_world = world_size; h->comm_rank = rank;
+    return HK_OK;
+}
+
+int hk_gather_results(hk_handle h, hk_episode_result* all)
+{
+    HK_NEED_ENV(h);
+    if (!all) return fail(h, HK_ERR_INVALID, "hk_gather_results: NULL pointer");
+    if (!h->comm) return fail(h, HK_ERR_INVALID, "hk_gather_results: call hk_comm_init first");
+    { int rc = check_device_status(h); if (rc) return rc; }
+    const size_t local = (size_t)h->cfg.num_envs * h->cfg.num_agents * sizeof(hk_episode_result);
+    const size_t total = local * (size_t)h->comm_world;
+    if (total > h->gather_bytes) {
+        if (h->gather_buf) HK_HIP(h, hipFree(h->gather_buf));
+        h->gather_buf = nullptr; h->gather_bytes = 0;
+        HK_HIP(h, hipMalloc(&h->gather_buf, total));
+        h->gather_bytes = total;
+    }
+    // bytes on the wire (ncclChar): the records are plain data, identical layout on every rank
+    const int rc = g_rccl.AllGather(h->dev.results, h->gather_buf, local, /*ncclChar*/ 0, h->comm, h->stream);
+    if (rc != 0) return fail(h, HK_ERR_HIP, "ncclAllGather: " + g_rccl.why(rc));
+    HK_HIP(h, hipMemcpyAsync(all, h->gather_buf, total, hipMemcpyDeviceToHost, h->stream));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    return HK_OK;
+}
+
+int hk_comm_destroy(hk_handle h)
+{
+    if (!h) return fail(nullptr, HK_ERR_INVALID, "NULL handle");
+    if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
+    h->comm = nullptr; h->comm_world = 0;
     return HK_OK;
 }
 

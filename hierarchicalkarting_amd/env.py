@@ -150,5 +150,24 @@ class RacingEnv:
         self._ck(self.L.hk_prof_read(self.h, ms, n))
         return {name: (ms[i], n[i]) for i, name in enumerate(_lib.PROF_STAGE_NAMES)}
 
+    # ---- the path's one exchange step, natively over RCCL (hk_comm_* / hk_gather_results)
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_char * _lib.HK_COMM_ID_BYTES)()
+        _lib.check(_lib.load().hk_comm_unique_id(buf), None)
+        return bytes(buf.raw)
+
+    def comm_init(self, world_size, rank, comm_id):
+        assert len(comm_id) == _lib.HK_COMM_ID_BYTES
+        buf = (C.c_char * _lib.HK_COMM_ID_BYTES).from_buffer_copy(comm_id)
+        self._ck(self.L.hk_comm_init(self.h, int(world_size), int(rank), buf))
+        self._comm_world = int(world_size)
+
+    def gather_results(self):
+        """-> hk_episode_result[world * E][A] on every rank (one RCCL all-gather)"""
+        out = np.zeros((self._comm_world * self.E, self.A), RESULT_DT)
+        self._ck(self.L.hk_gather_results(self.h, out.ctypes.data_as(C.POINTER(_lib.EpisodeResult))))
+        return out
+
     def device_results_ptr(self):
         return self.L.hk_device_results_ptr(self.h)

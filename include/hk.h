@@ -342,6 +342,20 @@ int hk_policy_forward(hk_handle h, int policy, int rows, const float* obs /*[row
 /* The actions currently latched for every agent (what the policies / hk_set_actions wrote): steer[E][A], branch[E][A] */
 int hk_get_actions(hk_handle h, float* steer, int32_t* branch);
 
+/* ---- multi-GPU: the path's ONE exchange step ---------------------------------------------------------------
+ * Race instances are independent (one RacingEnvController owns its own Agents[] / Sections[], REC:46-52): every rank steps its
+ * own contiguous env-id range (hk_config.env_id_base) and nothing crosses GPUs on the data path.  What a host wants at the end
+ * of an episode batch — the reference writes it to ExperimentLogs/ (REC:249-265) — is every race's result: one all-gather of
+ * hk_episode_result[E][A] over RCCL (xGMI inside a node).  librccl.so is loaded on the first hk_comm_* call, so single-GPU users
+ * do not need it.  Bootstrap as with NCCL: rank 0 obtains an id, the host passes it to every rank by whatever channel it has
+ * (MPI, a file, torch.distributed's store, ...), every rank calls hk_comm_init.  One communicator per handle. */
+#define HK_COMM_ID_BYTES 128
+int hk_comm_unique_id(void* id_out /*[HK_COMM_ID_BYTES]*/);
+int hk_comm_init(hk_handle h, int world_size, int rank, const void* id /*[HK_COMM_ID_BYTES]*/);
+/* all[world_size * E][A] (host pointer), rank r's envs at rows [r * E, (r + 1) * E); every rank must hold the same E and A */
+int hk_gather_results(hk_handle h, hk_episode_result* all);
+int hk_comm_destroy(hk_handle h);
+
 /* timing taps for bench.py's roofline object: accumulated HIP-event time (ms) and launch count per kernel stage since
  * the last hk_prof_reset.  Stages: [0] env_run_kernel (the fused tick kernel), [1] the lqn_kernel<2,3,4> launches of a
  * round (one bracket), [2] lq_batch_kernel, [3] policy_mlp_kernel,
