@@ -164,6 +164,13 @@ SYMBOLS = {
                                            C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "hk_device_results_ptr": (C.c_void_p, [_H]),
     "hk_device_agents_ptr": (C.c_void_p, [_H]),
+    "hk_observe": (C.c_int, [_H]),
+    "hk_rewards_device": (C.c_int, [_H]),
+    "hk_device_obs_ptr": (C.c_void_p, [_H]),
+    "hk_device_reward_ptr": (C.c_void_p, [_H]),
+    "hk_device_group_reward_ptr": (C.c_void_p, [_H]),
+    "hk_device_act_steer_ptr": (C.c_void_p, [_H]),
+    "hk_device_act_branch_ptr": (C.c_void_p, [_H]),
     "hk_stream": (C.c_void_p, [_H]),
     "hk_synchronize": (C.c_int, [_H]),
     "hk_policy_attach": (C.c_int, [_H, C.POINTER(PolicyDesc), C.POINTER(C.c_int32), C.c_int, C.c_int]),

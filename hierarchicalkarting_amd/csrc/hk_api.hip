@@ -604,14 +604,7 @@ int hk_get_rewards(hk_handle h, float* reward, float* group_reward)
     if (!reward || !group_reward) return fail(h, HK_ERR_INVALID, "NULL pointer");
     { int rc = check_device_status(h); if (rc) return rc; }
     const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
-    const size_t bytes = 2 * cnt * sizeof(float);
-    if (bytes > h->pol_scratch_bytes) {
-        if (h->pol_scratch) HK_HIP(h, hipFree(h->pol_scratch));
-        h->pol_scratch = nullptr; h->pol_scratch_bytes = 0;
-        HK_HIP(h, hipMalloc(&h->pol_scratch, bytes));
-        h->pol_scratch_bytes = bytes;
-    }
-    float* d_r = (float*)h->pol_scratch;
+    float* d_r = h->dev.reward_out;
     hipLaunchKernelGGL(hk::rewards_read_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->dev.agents, (int)cnt, d_r, d_r + cnt);
     HK_HIP(h, hipGetLastError());
     HK_HIP(h, hipMemcpyAsync(reward, d_r, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -646,6 +639,32 @@ int hk_get_lq_debug(hk_handle h, int env, int ego, hk_lq_debug* out)
 
 void* hk_device_results_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.results : nullptr; }
 void* hk_device_agents_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.agents : nullptr; }
+void* hk_device_obs_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.obs : nullptr; }
+void* hk_device_act_steer_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.act_steer : nullptr; }
+void* hk_device_act_branch_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.act_branch : nullptr; }
+void* hk_device_reward_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.reward_out : nullptr; }
+void* hk_device_group_reward_ptr(hk_handle h)
+{
+    return (h && h->env_ready && h->dev.reward_out) ? (void*)(h->dev.reward_out + (size_t)h->cfg.num_envs * h->cfg.num_agents) : nullptr;
+}
+
+int hk_observe(hk_handle h)
+{
+    HK_NEED_ENV(h);
+    int rc = hk::env_launch_observe(h->dev, h->cfg, h->stream, h->err);
+    if (rc) g_last_error = h->err;
+    return rc;
+}
+
+int hk_rewards_device(hk_handle h)
+{
+    HK_NEED_ENV(h);
+    const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
+    hipLaunchKernelGGL(hk::rewards_read_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->dev.agents, (int)cnt,
+                       h->dev.reward_out, h->dev.reward_out + cnt);
+    HK_HIP(h, hipGetLastError());
+    return HK_OK;
+}
 
 int hk_prof_enable(hk_handle h, int on)
 {

@@ -24,6 +24,7 @@ struct EnvDevice {
     float* obs = nullptr;
     float* act_steer = nullptr;
     int32_t* act_branch = nullptr;
+    float* reward_out = nullptr;   // [2][E][A]: m_Reward, m_GroupReward as read by hk_get_rewards / hk_rewards_device
     int* status = nullptr;
     GameDesc* games = nullptr;     // [E][A] compact LQ games written by K_B1
     int* queue_cnt = nullptr;      // [2 sets][8] number of queued multi-player games per player count
@@ -82,7 +83,7 @@ int upload(T** dst, const std::vector<T>& v, std::string& err)
 
 inline void env_destroy(EnvDevice& d)
 {
-    void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.status, d.games, d.queue_cnt, d.queue, d.env_ids, d.tab, d.perms,
+    void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.reward_out, d.status, d.games, d.queue_cnt, d.queue, d.env_ids, d.tab, d.perms,
                     d.rw.sec_time, d.rw.sec_cnt, d.rw.hit_code, d.mcts.st, d.mcts.req, d.mcts.qcnt, d.mcts.queue, d.mcts.nodes, d.mcts.dt_tab, d.mcts.load_tab, d.mcts.rad_tab, d.sec_geo};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = EnvDevice{};
@@ -265,6 +266,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     HK_ALLOC(d.obs, na * obs_dim * sizeof(float));
     HK_ALLOC(d.act_steer, na * sizeof(float));
     HK_ALLOC(d.act_branch, na * sizeof(int32_t));
+    HK_ALLOC(d.reward_out, 2 * na * sizeof(float));
     HK_ALLOC(d.status, 4 * sizeof(int));
     HK_ALLOC(d.games, na * sizeof(GameDesc));
     HK_ALLOC(d.queue_cnt, 2 * 8 * sizeof(int));

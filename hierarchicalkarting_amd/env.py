@@ -169,5 +169,34 @@ class RacingEnv:
         self._ck(self.L.hk_gather_results(self.h, out.ctypes.data_as(C.POINTER(_lib.EpisodeResult))))
         return out
 
+    # ---- device-resident RL loop: zero-copy torch views of the library's buffers (PyTorch as plumbing, not as compute)
+    def torch_views(self):
+        """-> dict of torch CUDA tensors ALIASING libhk's device buffers: obs [E, A, obs_dim] f32, reward / group_reward [E, A] f32,
+        act_steer [E, A] f32, act_branch [E, A] i32.  Fill them with observe() / rewards_device(), write actions in place,
+        then step().  The handle's stream is not torch's current stream: call synchronize() (or use the stream pointer from
+        hk_stream) before reading on another stream.  Import torch and touch the GPU (torch.cuda.init())
+        BEFORE the first RacingEnv of the process: torch ships its own libamdhip64, and whichever HIP runtime is loaded first
+        serves both libraries (the other order leaves torch without a device)."""
+        import torch
+
+        class _Ext:
+            def __init__(self, ptr, shape, typestr):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr), False), "version": 3, "strides": None}
+
+        dev = "cuda:%d" % self.built.cfg.device_id
+        mk = lambda ptr, shape, ts: torch.as_tensor(_Ext(ptr, shape, ts), device=dev)
+        E, A = self.E, self.A
+        return {"obs": mk(self.L.hk_device_obs_ptr(self.h), (E, A, self.obs_dim), "<f4"),
+                "reward": mk(self.L.hk_device_reward_ptr(self.h), (E, A), "<f4"),
+                "group_reward": mk(self.L.hk_device_group_reward_ptr(self.h), (E, A), "<f4"),
+                "act_steer": mk(self.L.hk_device_act_steer_ptr(self.h), (E, A), "<f4"),
+                "act_branch": mk(self.L.hk_device_act_branch_ptr(self.h), (E, A), "<i4")}
+
+    def observe(self):
+        self._ck(self.L.hk_observe(self.h))
+
+    def rewards_device(self):
+        self._ck(self.L.hk_rewards_device(self.h))
+
     def device_results_ptr(self):
         return self.L.hk_device_results_ptr(self.h)

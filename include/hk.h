@@ -291,6 +291,18 @@ int hk_lq_solve_batch_device(hk_handle h, int batch, int N, const double* dA, co
                              const double* dq, const double* dR, const double* dx0, int horizon, double* du0, void* stream);
 void* hk_device_results_ptr(hk_handle h);  /* hk_episode_result[E][A] on device: the payload of the RCCL all-gather */
 void* hk_device_agents_ptr(hk_handle h);   /* hk_agent_state[E][A] on device */
+/* Device-resident RL loop (an external trainer that keeps its tensors on the GPU): hk_observe runs CollectObservations into
+ * the library's device buffer (asynchronous, on the handle's stream; raises the HitWall / HitOpponent reward events like
+ * hk_get_observations); hk_rewards_device moves m_Reward / m_GroupReward into the two device buffers and zeroes the
+ * accumulators (Agent.SendInfo); the trainer writes its actions straight into the action buffers before hk_step.
+ * All four buffers are [E][A] (obs: [E][A][hk_obs_dim]); synchronise with hk_stream / hk_synchronize. */
+int hk_observe(hk_handle h);
+int hk_rewards_device(hk_handle h);
+void* hk_device_obs_ptr(hk_handle h);           /* float[E][A][hk_obs_dim] */
+void* hk_device_reward_ptr(hk_handle h);        /* float[E][A], valid after hk_rewards_device */
+void* hk_device_group_reward_ptr(hk_handle h);  /* float[E][A], valid after hk_rewards_device */
+void* hk_device_act_steer_ptr(hk_handle h);     /* float[E][A]: continuous action 0 */
+void* hk_device_act_branch_ptr(hk_handle h);    /* int32[E][A]: discrete action 0 */
 void* hk_stream(hk_handle h);              /* hipStream_t the handle launches on */
 int hk_synchronize(hk_handle h);
 
