@@ -219,7 +219,7 @@ int hk_lq_solve_batch_device(hk_handle h, int batch, int N, const double* dA, co
 {
     if (!h) return fail(nullptr, HK_ERR_INVALID, "hk_lq_solve_batch_device: handle required");
     if (batch < 0 || N < 1 || horizon < 0) return fail(h, HK_ERR_INVALID, "hk_lq_solve_batch: bad batch/N/horizon");
-    if (N > hk::LQ_MAXP) return fail(h, HK_ERR_UNSUPPORTED, "hk_lq_solve_batch: N > 4 players not built yet");
+    if (N > hk::LQ_BATCH_MAXP) return fail(h, HK_ERR_UNSUPPORTED, "hk_lq_solve_batch: N > 8 players not built");
     if (batch == 0) return HK_OK;
     HK_HIP(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
@@ -231,7 +231,7 @@ int hk_lq_solve_batch_device(hk_handle h, int batch, int N, const double* dA, co
         hipLaunchKernelGGL(hk::lq_batch_kernel<NP>, dim3((batch + gpw - 1) / gpw), dim3(64), 0, st, batch, dA, dB, dQ, dq, dR, \
                            dx0, horizon, du0, h->d_status);                                                              \
     } break;
-        HK_LQ_CASE(1) HK_LQ_CASE(2) HK_LQ_CASE(3) HK_LQ_CASE(4)
+        HK_LQ_CASE(1) HK_LQ_CASE(2) HK_LQ_CASE(3) HK_LQ_CASE(4) HK_LQ_CASE(5) HK_LQ_CASE(6) HK_LQ_CASE(7) HK_LQ_CASE(8)
 #undef HK_LQ_CASE
     }
     HK_HIP(h, hipGetLastError());
@@ -250,7 +250,7 @@ int hk_lq_solve_batch(hk_handle h, int batch, int N, const double* A, const doub
         h = g_default_ctx;
     }
     if (batch < 0 || N < 1) return fail(h, HK_ERR_INVALID, "hk_lq_solve_batch: bad batch/N");
-    if (N > hk::LQ_MAXP) return fail(h, HK_ERR_UNSUPPORTED, "hk_lq_solve_batch: N > 4 players not built yet");
+    if (N > hk::LQ_BATCH_MAXP) return fail(h, HK_ERR_UNSUPPORTED, "hk_lq_solve_batch: N > 8 players not built");
     if (batch == 0) return HK_OK;
     if (!A || !B || !Q || !q || !R || !x0 || !u0_out) return fail(h, HK_ERR_INVALID, "hk_lq_solve_batch: NULL pointer");
     HK_HIP(h, hipSetDevice(h->device));

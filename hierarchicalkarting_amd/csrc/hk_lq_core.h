@@ -19,7 +19,9 @@
 
 namespace hk {
 
-constexpr int LQ_MAXP = 4;          // largest player count built
+constexpr int LQ_MAXP = 4;          // largest player count of the env path (agents per env)
+constexpr int LQ_BATCH_MAXP = 8;    // largest player count of hk_lq_solve_batch (the core is generic in NP; beyond 4 players the
+                                    // per-lane value-matrix rows no longer fit the register file and spill: functional, not tuned)
 
 __device__ __forceinline__ double fma64(double a, double b, double c) { return __builtin_fma(a, b, c); }
 

@@ -29,7 +29,7 @@ typedef enum hk_status {
     HK_ERR_INVALID = -1,      /* bad argument / config */
     HK_ERR_NO_DEVICE = -2,    /* no HIP device: the product path has no CPU fallback */
     HK_ERR_HIP = -3,          /* HIP runtime error (see hk_last_error) */
-    HK_ERR_UNSUPPORTED = -4,  /* valid in the reference, not built yet (num_agents > 4, Training-mode randomised resets, LQ games of > 4 players) */
+    HK_ERR_UNSUPPORTED = -4,  /* valid in the reference, not built yet (num_agents > 4, LQ games of > 8 players) */
     HK_ERR_SINGULAR = -5      /* LQ: zero pivot in the m x m solve */
 } hk_status;
 
@@ -282,7 +282,8 @@ int hk_get_mcts_state(hk_handle h, hk_mcts_state* out /*[E][A]*/);
 
 /* KartLQR.solveFeedbackLQR (AI/LQR/KartLQR.cs:17) batched, 1:1 incl. quirks Q1 (block-transposed LHS) and Q2.
  * A[b][N][4][4], B[b][N][4][2], Q[b][N][n][n], q[b][N][n], R[b][N][2][2], x0[b][n], n = 4N; u0_out[b][2].
- * Host pointers; h may be NULL (a temporary context on device 0 is used). N <= 4. */
+ * Host pointers; h may be NULL (a temporary context on device 0 is used). N <= 8
+ * (the env path uses N <= 4 = agents per env; 5..8 run the same generic core, untuned). */
 int hk_lq_solve_batch(hk_handle h, int batch, int N, const double* A, const double* B, const double* Q, const double* q,
                       const double* R, const double* x0, int horizon, double* u0_out);
 

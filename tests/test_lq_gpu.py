@@ -14,7 +14,7 @@ def _stack(cases):
     return [np.array([c[k] for c in cases]) for k in ("A", "B", "Q", "q", "R", "x0")]
 
 
-@pytest.mark.parametrize("N", [1, 2, 3, 4])
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 8])
 def test_golden(N):
     import hierarchicalkarting_amd as hk
     with open(os.path.join(GOLD, "lq_N%d.json" % N)) as f:
@@ -28,11 +28,11 @@ def test_golden(N):
         assert np.array_equal(u[i], uo), (u[i], uo)          # bit-exact vs the oracle
 
 
-@pytest.mark.parametrize("N", [1, 2, 3, 4])
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_random_batch_bit_exact(N):
     import hierarchicalkarting_amd as hk
     rng = np.random.default_rng(50 + N)
-    games = [LQ.random_game(rng, N) for _ in range(203)]          # ragged vs the 4-games-per-wave packing
+    games = [LQ.random_game(rng, N) for _ in range(203 if N <= 4 else 37)]   # ragged vs the games-per-wave packing
     A = np.array([g[0] for g in games]); B = np.array([g[1] for g in games]); Q = np.array([g[2] for g in games])
     q = np.array([g[3] for g in games]); R = np.array([g[4] for g in games]); x0 = np.array([g[5] for g in games])
     u = hk.solve_feedback_lqr_batch(A, B, Q, q, R, x0, 3)
@@ -74,8 +74,8 @@ def test_horizon_and_edge_cases():
     # unsupported / invalid
     from hierarchicalkarting_amd import _lib
     with pytest.raises(_lib.HkError) as e:
-        hk.solve_feedback_lqr_batch(np.zeros((1, 5, 4, 4)), np.zeros((1, 5, 4, 2)), np.zeros((1, 5, 20, 20)),
-                                    np.zeros((1, 5, 20)), np.zeros((1, 5, 2, 2)), np.zeros((1, 20)))
+        hk.solve_feedback_lqr_batch(np.zeros((1, 9, 4, 4)), np.zeros((1, 9, 4, 2)), np.zeros((1, 9, 36, 36)),
+                                    np.zeros((1, 9, 36)), np.zeros((1, 9, 2, 2)), np.zeros((1, 36)))      # > 8 players
     assert e.value.code == _lib.HK_ERR_UNSUPPORTED
     # singular LHS (all-zero costs and R) reports instead of returning garbage
     with pytest.raises(_lib.HkError) as e:
