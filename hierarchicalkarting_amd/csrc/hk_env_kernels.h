@@ -26,7 +26,7 @@ struct EnvDevice {
     int32_t* act_branch = nullptr;
     float* reward_out = nullptr;   // [2][E][A]: m_Reward, m_GroupReward as read by hk_get_rewards / hk_rewards_device
     int* status = nullptr;
-    GameDesc* games = nullptr;     // [E][A] compact LQ games written by K_B1
+    double* games = nullptr;       // queued multi-player games, structure-of-arrays (GameSoA, hk_env_solve.h)
     int* queue_cnt = nullptr;      // [2 sets][8] number of queued multi-player games per player count
     int* queue = nullptr;          // [2 sets][3][E*A] game ids with N = 2, 3, 4
     int round = 0;                 // launches so far: round & 1 selects the queue set (double buffered over rounds)
@@ -268,7 +268,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     HK_ALLOC(d.act_branch, na * sizeof(int32_t));
     HK_ALLOC(d.reward_out, 2 * na * sizeof(float));
     HK_ALLOC(d.status, 4 * sizeof(int));
-    HK_ALLOC(d.games, na * sizeof(GameDesc));
+    HK_ALLOC(d.games, na * (size_t)LQ_MAXP * GP_FIELDS * sizeof(double));
     HK_ALLOC(d.queue_cnt, 2 * 8 * sizeof(int));
     HK_ALLOC(d.queue, 2 * 3 * na * sizeof(int));
     if (cfg.rewards) {
@@ -419,7 +419,7 @@ inline int env_launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream
     const int threads = cfg.num_envs * 4;
 #define HK_RUN(MC, RWF, TRN)                                                                                                  \
     hipLaunchKernelGGL((env_run_kernel<MC, RWF, TRN>), dim3((threads + 255) / 256), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs,   \
-                       d.results, d.games, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status,     \
+                       d.results, GameSoA{d.games, (size_t)cfg.num_envs * cfg.num_agents}, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status,     \
                        d.tab_lds ? 1 : 0, d.mcts, d.mset, d.rw)
     bool train = d.P.training_reset != 0;
     for (int i = 0; i < cfg.num_agents; i++) train = train || d.P.training_agent[i] != 0;
@@ -444,7 +444,7 @@ inline int env_launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream
         // 3 x 8 192 workgroups that exit at once cost 25 us per round in steady state
         const int nb = std::min((ngames + 3) / 4, 1024);
         const int sizes = cfg.num_agents - 1;                 // player counts 2 .. A
-        hipLaunchKernelGGL(lqn_all_kernel, dim3(nb * sizes), dim3(64), 0, stream, d.P, d.agents, d.games, qc, qu, d.lq_debug, d.status, nb);
+        hipLaunchKernelGGL(lqn_all_kernel, dim3(nb * sizes), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status, nb);
         if ((rc = launch_check(err, "lqn_all_kernel"))) return rc;
     }
     d.round += 1;

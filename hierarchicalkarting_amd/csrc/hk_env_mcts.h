@@ -90,12 +90,13 @@ __device__ inline void mcts_post_request(const EnvParams& P, const MctsDev& M, i
     for (int q = 0; q < 4; q++) s.sec_time[q] = mine->sec_time[q];
     for (int e = 0; e < P.A; e++)
         if (req_mask & (1u << e)) M.req[(size_t)env * P.A + e].k[i] = s;
-    if (req_mask & (1u << i)) {
+    const bool requesting = (req_mask & (1u << i)) != 0;
+    const int slot = wave_agg_inc(&M.qcnt[set * 2], requesting);          // one atomic per wave, not per ego
+    if (requesting) {
         MctsReq* r = &M.req[(size_t)env * P.A + i];
         r->episode_steps = episode_steps; r->epoch = epoch; r->iterations = iterations; r->gen += 1;
         mine->searches += 1;
         mine->ready_step = ready_step;
-        const int slot = atomicAdd(&M.qcnt[set * 2], 1);
         // an ego can post twice in one launch (a replan tick, then the episode ends and the reset plans again): the queue set
         // holds 2 entries per agent and the entry carries the request generation, so the search kernel skips the stale one
         M.queue[(size_t)set * 2 * P.E * P.A + slot] = (env * P.A + i) | ((r->gen & 0xFF) << 24);
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M,
     const unsigned ent = (unsigned)M.queue[(size_t)set * 2 * P.E * P.A + q];
     const int pair = (int)(ent & 0xFFFFFFu);
     if (((unsigned)M.req[pair].gen & 0xFFu) != (ent >> 24)) return;          // superseded by a later request of the same ego
-    const int slot = atomicAdd(&M.qcnt[set * 2 + 1], 1);                     // arena slot
+    const int slot = wave_agg_inc(&M.qcnt[set * 2 + 1], true);               // arena slot (one atomic per wave)
     if (slot >= M.slots) return;
     const int env = pair / P.A, ego = pair % P.A;
     const TabView T = tab_view(P, P.tab);

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void env_check_kernel(const hk_env_state* envs
 // <true, true, true> for any handle that uses Training mode (its planner / reward parts are also guarded at run time).
 template <bool HAS_MCTS, bool HAS_RW, bool HAS_TRAIN>
 __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
-                                                      hk_episode_result* results, GameDesc* games, int* queue_cnt_all,
+                                                      hk_episode_result* results, GameSoA games, int* queue_cnt_all,
                                                       int* queue_all, int set, const float* act_steer, const int* act_branch,
                                                       hk_lq_debug* dbg_out, int* status, int use_lds, MctsDev Marg, int mset, RwDev RD)
 {
@@ -82,18 +82,24 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
         dirty = true;
         if (phase == 0) {
             const bool parked = phase_begin<HAS_RW, HAS_TRAIN>(P, env, i, env_ok, es, h, hfx, hfz, agents, results, M, mset, RD, rwv, act_branch);
-            bool queued = false;
+            int qn = 0;              // player count of the multi-player game this ego assembled on this tick (0: none)
             if (!parked) {
                 const bool act = (es.episode_steps % cadence) == 0 &&                                  // HKA:317 (Q9)
                                  !(!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u));
-                queued = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st);
+                qn = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st);
+                // bin the queued games by player count, one atomic per wave and count
+#pragma unroll
+                for (int n = 2; n <= LQ_MAXP; n++) {
+                    const int pos = wave_agg_inc(&queue_cnt[n], qn == n);
+                    if (qn == n) queue[(size_t)(n - 2) * P.E * P.A + pos] = env * P.A + i;
+                }
                 if (M.st) phase_plan(P, M, mset, env, i, es, h.flags, h.section_index, h.lane, h.lane_changes, h.final_steer, arec);
             } else {
                 left -= 1; budget -= 1;         // a parked env lets the tick pass
                 continue;
             }
             // does any ego of this env wait for a multi-player solve?
-            int q = queued ? 1 : 0;
+            int q = qn ? 1 : 0;
             q |= __shfl_xor(q, 1, 64); q |= __shfl_xor(q, 2, 64);
             if (q) { phase = 1; break; }
         }

@@ -28,10 +28,17 @@ struct GamePlayer {            // one player's share of a game, ego-local order 
     double opt[3][3];          // opponent target (x, z, v); heading entry is never set -> 0  HKA:1065-1067
     int M, agent, branch, pad_;
 };
-struct GameDesc {
-    int N;                     // 0: this ego does not solve on this tick
-    int pad_;
-    GamePlayer p[LQ_MAXP];
+// Queued multi-player games live in ONE array of doubles, structure-of-arrays over the games: field f of player i of game g
+// (g = env * A + ego) sits at d[(i * GP_FIELDS + f) * ng + g].  The egos of a wave are consecutive games, so every store of
+// the assembly and every load of the solver is one contiguous run per wave instruction (the array-of-structs this replaces
+// cost 64 scattered sectors per instruction: the 2-agent configuration, where every tick queues a 2-player game per ego,
+// spent most of its time there).
+constexpr int GP_X0 = 0, GP_A4 = 4, GP_TW = 8, GP_TGT = 12, GP_RC = 16, GP_AW = 17, GP_OPW = 20, GP_OPT = 29, GP_M = 38, GP_FIELDS = 40;
+struct GameSoA {
+    double* d;
+    size_t ng;
+    __device__ __forceinline__ double get(int game, int i, int f) const { return d[((size_t)(i * GP_FIELDS + f)) * ng + game]; }
+    __device__ __forceinline__ void put(int game, int i, int f, double v) const { d[((size_t)(i * GP_FIELDS + f)) * ng + game] = v; }
 };
 
 struct KartS {                 // per-kart staging (LDS), filled by the kart's own lane
@@ -236,8 +243,12 @@ __device__ inline void lq1_solve(const EnvParams& P, const GamePlayer& gp, Hot& 
 template <bool SINGLE>
 __device__ __forceinline__ void assemble_player(const EnvParams& P, const TabView& T, const int env, const int ego, const int i, const int N,
                                                 const int nearbyAgents, const int* pl, const KartS* kq, const bool fixed,
-                                                const float dy, GamePlayer* gp, hk_lq_debug* dbg_out, const hk_mcts_state* bel)
+                                                const float dy, GamePlayer* gp, hk_lq_debug* dbg_out, const hk_mcts_state* bel,
+                                                const GameSoA& games, const int game)
 {
+    // Single-player games stay in the register struct `gp` (the others loop below never runs for them).  Multi-player games
+    // go straight to the structure-of-arrays buffer: staging them in a local struct would put it in scratch (the per-other
+    // fields are indexed by a run-time M), and 80 scratch round trips per player dominated the 2-agent configuration.
     const int A = P.A, L = P.L;
     const KartS& mek = kq[ego];
         const int ki = pl[i];
@@ -249,10 +260,9 @@ __device__ __forceinline__ void assemble_player(const EnvParams& P, const TabVie
             const double dt = (double)P.dt;
             double sh, ch;
             hk_sincos(initial[3], &sh, &ch);
-            gp->a4[0] = ch * dt;
-            gp->a4[1] = sh * dt;
-            gp->a4[2] = -sh * dt * initial[2];
-            gp->a4[3] = ch * dt * initial[2];
+            const double a40 = ch * dt, a41 = sh * dt, a42 = -sh * dt * initial[2], a43 = ch * dt * initial[2];
+            if (SINGLE) { gp->a4[0] = a40; gp->a4[1] = a41; gp->a4[2] = a42; gp->a4[3] = a43; }
+            else { games.put(game, i, GP_A4 + 0, a40); games.put(game, i, GP_A4 + 1, a41); games.put(game, i, GP_A4 + 2, a42); games.put(game, i, GP_A4 + 3, a43); }
         }
         const int s = kk.sec + 1;                                                     // :746
         const int idx = s % L, idx2 = (s + 1) % L;
@@ -378,7 +388,7 @@ __device__ __forceinline__ void assemble_player(const EnvParams& P, const TabVie
                 w = 1.0f / (pw * mult);
                 if (!isteam) nearbyOpponents += 1;
             }
-            gp->aw[M] = w;
+            if (SINGLE) gp->aw[M] = w; else games.put(game, i, GP_AW + M, w);
             const int io = (o.sec + 1) % L;
             float olx, olz; double ov;
             if (oi == ego) {
@@ -397,7 +407,8 @@ __device__ __forceinline__ void assemble_player(const EnvParams& P, const TabVie
                     ov = (double)P.max_speed < pv ? (double)P.max_speed : pv;
                 } else ov = P.max_speed;
             }
-            gp->opt[M][0] = olx; gp->opt[M][1] = olz; gp->opt[M][2] = ov;
+            if (SINGLE) { gp->opt[M][0] = olx; gp->opt[M][1] = olz; gp->opt[M][2] = ov; }
+            else { games.put(game, i, GP_OPT + 3 * M + 0, olx); games.put(game, i, GP_OPT + 3 * M + 1, olz); games.put(game, i, GP_OPT + 3 * M + 2, ov); }
             double mx = initial[2] > 1 ? initial[2] : 1;
             double w0, w1, w2;
             if (!isteam) {
@@ -409,15 +420,23 @@ __device__ __forceinline__ void assemble_player(const EnvParams& P, const TabVie
                 else if (N > 2) { w0 = -(fixed ? 0 : 3e-5) / (mx * nearbyAgents); w1 = -(fixed ? 0 : 3e-5) / (mx * nearbyAgents); w2 = 0 / nearbyAgents; }
                 else { w0 = -(fixed ? 1e-4 : 2e-4) / mx; w1 = -(fixed ? 1e-4 : 2e-4) / mx; w2 = 0; }
             }
-            gp->opw[M][0] = w0; gp->opw[M][1] = w1; gp->opw[M][2] = w2;
+            if (SINGLE) { gp->opw[M][0] = w0; gp->opw[M][1] = w1; gp->opw[M][2] = w2; }
+            else { games.put(game, i, GP_OPW + 3 * M + 0, w0); games.put(game, i, GP_OPW + 3 * M + 1, w1); games.put(game, i, GP_OPW + 3 * M + 2, w2); }
             M++;
         }
         double controlcost = 0.115;                                                   // :1192-1196
         if (N > 2) controlcost = fixed ? 0.135 : 0.25;
-        gp->rc = 1.0 * controlcost;                                                   // getRMatrix: SparseIdentity * w
-        gp->M = M; gp->agent = ki; gp->branch = branch;
+        if (SINGLE) {
+            gp->rc = 1.0 * controlcost;                                               // getRMatrix: SparseIdentity * w
+            gp->M = M; gp->agent = ki; gp->branch = branch;
 #pragma unroll
-        for (int c = 0; c < 4; c++) { gp->x0[c] = initial[c]; gp->tw[c] = tw[c]; gp->tgt[c] = target[c]; }
+            for (int c = 0; c < 4; c++) { gp->x0[c] = initial[c]; gp->tw[c] = tw[c]; gp->tgt[c] = target[c]; }
+        } else {
+            games.put(game, i, GP_RC, 1.0 * controlcost);
+            games.put(game, i, GP_M, (double)M);
+#pragma unroll
+            for (int c = 0; c < 4; c++) { games.put(game, i, GP_X0 + c, initial[c]); games.put(game, i, GP_TW + c, tw[c]); games.put(game, i, GP_TGT + c, target[c]); }
+        }
         if (dbg_out && (P.debug & 1)) {
             hk_lq_debug* d = &dbg_out[(size_t)env * A + ego];
             d->player_agent[i] = ki; d->branch[i] = branch; d->control_w[i] = controlcost;
@@ -437,12 +456,12 @@ __device__ __forceinline__ void wave_lds_sync()
 
 // ---------------------------------------------------------------------------------------------------------------
 // phase B1 of a tick: the ego's sensor rays, game assembly; a single-player game is solved on the spot, a multi-player
-// game is written to games[] and queued by player count.  Returns true when the ego's game was queued.
+// game is written to games[] (the caller queues it by player count).  Returns the player count of a game to queue, else 0.
 // `act`: this env solves on this tick (cadence, not parked); it is quad-uniform.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ inline bool phase_assemble(const EnvParams& P, const TabView& T, KartS* ks, const int env, const int ego,
+__device__ inline int phase_assemble(const EnvParams& P, const TabView& T, KartS* ks, const int env, const int ego,
                                       const bool act, const hk_env_state& es, Hot& h, const float hfx, const float hfz, hk_agent_state* agents,
-                                      GameDesc* games,
+                                      const GameSoA games,
                                       int* queue_cnt, int* queue, hk_lq_debug* dbg_out, int* status, const hk_mcts_state* mcts_all)
 {
     const int A = P.A, L = P.L;
@@ -526,11 +545,10 @@ __device__ inline bool phase_assemble(const EnvParams& P, const TabView& T, Kart
     }
     ks[threadIdx.x] = k;
     wave_lds_sync();
-    if (!me) return false;
+    if (!me) return 0;
     const KartS* kq = &ks[threadIdx.x & ~3];          // the env's four karts
-    GameDesc* G = &games[(size_t)env * A + ego];
     const bool solving = (k.flags & HK_F_ENABLED) && P.low_mode[ego] == HK_LOW_LQR && !((es.inactive_mask >> ego) & 1u);
-    if (!solving) return false;
+    if (!solving) return 0;
     // ---- players (HKA:702-725)
     int pl[ENV_MAXA] = {0, 0, 0, 0};
     int N = 0, nearbyAgents = -1;
@@ -555,18 +573,14 @@ __device__ inline bool phase_assemble(const EnvParams& P, const TabView& T, Kart
     if (N == 1) {
         // single-player game: assemble into registers and run the whole Riccati recursion right here
         GamePlayer loc;
-        assemble_player<true>(P, T, env, ego, 0, N, nearbyAgents, pl, kq, fixed, dy, &loc, dbg_out, bel);
+        assemble_player<true>(P, T, env, ego, 0, N, nearbyAgents, pl, kq, fixed, dy, &loc, dbg_out, bel, games, 0);
         if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = 1;
         lq1_solve(P, loc, h, (dbg_out && (P.debug & 1)) ? &dbg_out[(size_t)env * A + ego] : nullptr, status);
-        return false;
+        return 0;
     }
-    for (int i = 0; i < N; i++) assemble_player<false>(P, T, env, ego, i, N, nearbyAgents, pl, kq, fixed, dy, &G->p[i], dbg_out, bel);
-    G->N = N;
+    for (int i = 0; i < N; i++) assemble_player<false>(P, T, env, ego, i, N, nearbyAgents, pl, kq, fixed, dy, nullptr, dbg_out, bel, games, env * A + ego);
     if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = N;
-    // bin the multi-player game by N
-    const int pos = atomicAdd(&queue_cnt[N], 1);
-    queue[(size_t)(N - 2) * P.E * A + pos] = env * A + ego;
-    return true;
+    return N;                // the caller bins the game by N (wave-aggregated slot allocation needs every queued lane together)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -585,7 +599,7 @@ struct QCompact {
 };
 
 template <int NP>
-__device__ __forceinline__ void lqn_body(const int block, const int nblocks, const EnvParams& P, hk_agent_state* agents, const GameDesc* games,
+__device__ __forceinline__ void lqn_body(const int block, const int nblocks, const EnvParams& P, hk_agent_state* agents, const GameSoA games,
                                          const int* queue_cnt, const int* queue, hk_lq_debug* dbg_out, int* status, unsigned char* smem)
 {
     constexpr int n = LqDims<NP>::n, GPW = LqDims<NP>::GPW, SLOTS = LqDims<NP>::SLOTS;
@@ -601,7 +615,6 @@ __device__ __forceinline__ void lqn_body(const int block, const int nblocks, con
         const int slot = base + gs;
         const bool live = gs < GPW && slot < count;
         const int game = qbase[live ? slot : count - 1];      // idle slots recompute the last game and discard it
-        const GameDesc* G = &games[game];
         __syncthreads();
         // game inputs -> LDS
 #pragma unroll
@@ -610,16 +623,16 @@ __device__ __forceinline__ void lqn_body(const int block, const int nblocks, con
                 const int rr = e >> 2, cc = e & 3;
                 double av = 0.0;
                 if (rr == cc) av = 1.0;
-                else if (rr == 0 && cc == 2) av = G->p[i].a4[0];
-                else if (rr == 1 && cc == 2) av = G->p[i].a4[1];
-                else if (rr == 0 && cc == 3) av = G->p[i].a4[2];
-                else if (rr == 1 && cc == 3) av = G->p[i].a4[3];
+                else if (rr == 0 && cc == 2) av = games.get(game, i, GP_A4 + 0);
+                else if (rr == 1 && cc == 2) av = games.get(game, i, GP_A4 + 1);
+                else if (rr == 0 && cc == 3) av = games.get(game, i, GP_A4 + 2);
+                else if (rr == 1 && cc == 3) av = games.get(game, i, GP_A4 + 3);
                 LG.Ab[i][e] = av;
             }
             for (int e = r; e < 8; e += n) LG.Bb[i][e] = (e == 4 || e == 7) ? (double)P.dt : 0.0;      // B[v][0] = B[h][1] = dt
-            if (r < 4) LG.Rb[i][r] = (r == 0 || r == 3) ? G->p[i].rc : 0.0;
+            if (r < 4) LG.Rb[i][r] = (r == 0 || r == 3) ? games.get(game, i, GP_RC) : 0.0;
         }
-        LG.x0[r] = G->p[r >> 2].x0[r & 3];
+        LG.x0[r] = games.get(game, r >> 2, GP_X0 + (r & 3));
         // compact reach-avoid cost rows (KartLQRCosts.cs:57-127): lane r = row r
         {
             const int b = r >> 2, sidx = r & 3;
@@ -629,31 +642,35 @@ __device__ __forceinline__ void lqn_body(const int block, const int nblocks, con
 #pragma unroll
                 for (int q = 0; q < NP; q++) qc[q] = 0.0;
                 double qv = 0.0;
-                const GamePlayer& gp = G->p[i];
-                const int M = gp.M;
+                const int M = (int)games.get(game, i, GP_M);
+                auto AW = [&](int j) { return games.get(game, i, GP_AW + j); };
+                auto TW = [&](int c) { return games.get(game, i, GP_TW + c); };
+                auto TGT = [&](int c) { return games.get(game, i, GP_TGT + c); };
+                auto OPW = [&](int j, int c) { return games.get(game, i, GP_OPW + 3 * j + c); };
+                auto OPT = [&](int j, int c) { return games.get(game, i, GP_OPT + 3 * j + c); };
                 if (b == 0) {
                     double d = 0.0;
                     if (sidx < 2) {
                         double total = 0.0;                                    // :67-79
-                        for (int j = 0; j < M; j++) total -= gp.aw[j];
+                        for (int j = 0; j < M; j++) total -= AW(j);
                         d = total;
                     }
-                    d += gp.tw[sidx];                                          // :81-84
+                    d += TW(sidx);                                          // :81-84
                     qc[0] = d;
                     if (sidx < 2) {
 #pragma unroll
-                        for (int q = 1; q < NP; q++) if (M > q - 1) qc[q] = gp.aw[q - 1];
+                        for (int q = 1; q < NP; q++) if (M > q - 1) qc[q] = AW(q - 1);
                     }
-                    double t = -gp.tgt[sidx];                                  // getQVec :109-113
-                    qv = t * gp.tw[sidx];
+                    double t = -TGT(sidx);                                  // getQVec :109-113
+                    qv = t * TW(sidx);
                 } else {
                     const int j = b - 1;
-                    if (sidx < 2) qc[0] = gp.aw[j];                            // :74
+                    if (sidx < 2) qc[0] = AW(j);                            // :74
                     double dg = 0.0;
-                    if (sidx < 3) dg = -gp.opw[j][sidx];                       // :91 assignment (Q4)
+                    if (sidx < 3) dg = -OPW(j, sidx);                       // :91 assignment (Q4)
 #pragma unroll
                     for (int q = 1; q < NP; q++) if (b == q) qc[q] = dg;
-                    if (sidx < 3) { qv = gp.opt[j][sidx]; qv = qv * -gp.opw[j][sidx]; }   // :117,:121 (heading entry 0)
+                    if (sidx < 3) { qv = OPT(j, sidx); qv = qv * -OPW(j, sidx); }   // :117,:121 (heading entry 0)
                 }
 #pragma unroll
                 for (int q = 0; q < NP; q++) CR.QC[i][q][r] = qc[q];
@@ -679,7 +696,7 @@ __device__ __forceinline__ void lqn_body(const int block, const int nblocks, con
 // One launch for the queued games of every size: blocks [0, nb) take the 2-player queue, [nb, 2 nb) the 3-player one,
 // [2 nb, 3 nb) the 4-player one.  (Three separate launches cost ~12 us each even when — as in steady state, where 99.95 % of
 // the games are single-player and solved inside the tick kernel — their queues are empty: 10 % of the headline's wall time.)
-__global__ __launch_bounds__(64) void lqn_all_kernel(EnvParams P, hk_agent_state* agents, const GameDesc* games, const int* queue_cnt,
+__global__ __launch_bounds__(64) void lqn_all_kernel(EnvParams P, hk_agent_state* agents, const GameSoA games, const int* queue_cnt,
                                                      const int* queue, hk_lq_debug* dbg_out, int* status, int nb)
 {
     // one LDS block, sized for the largest game size and reused by whichever size this workgroup solves
