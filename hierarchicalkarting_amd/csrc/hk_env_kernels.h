@@ -439,7 +439,12 @@ inline int env_launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream
     const int* qc = d.queue_cnt + set * 8;
     const int* qu = d.queue + (size_t)set * 3 * ngames;
     int rc = HK_OK;
-    if (cfg.num_agents >= 2) {
+    if (cfg.num_agents == 2) {
+        // 1v1: only 2-player games exist, one per ego per tick
+        const int nb = std::min((ngames + 7) / 8, 4096);
+        hipLaunchKernelGGL(lqn_single_kernel<2>, dim3(nb), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status);
+        if ((rc = launch_check(err, "lqn_single_kernel<2>"))) return rc;
+    } else if (cfg.num_agents > 2) {
         // 1 024 workgroups per game size (one wave per SIMD at this kernel's 256 VGPRs) walking their queue grid-stride: dispatching
         // 3 x 8 192 workgroups that exit at once cost 25 us per round in steady state
         const int nb = std::min((ngames + 3) / 4, 1024);

@@ -711,4 +711,16 @@ __global__ __launch_bounds__(64) void lqn_all_kernel(EnvParams P, hk_agent_state
     else lqn_body<4>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
 }
 
+// The same solver for ONE game size, with that size's own register allocation (2-player games need 166 VGPRs, the merged kernel
+// is compiled for the 4-player body's 256): used when every game of the handle has the same size — 1v1 races (A = 2), where
+// every ego queues a 2-player game on every tick and this kernel is most of the work.
+template <int NP>
+__global__ __launch_bounds__(64) void lqn_single_kernel(EnvParams P, hk_agent_state* agents, const GameSoA games, const int* queue_cnt,
+                                                        const int* queue, hk_lq_debug* dbg_out, int* status)
+{
+    constexpr size_t BYTES = (sizeof(LqGameLds<NP>) + sizeof(CostRows<NP>)) * LqDims<NP>::SLOTS;
+    __shared__ __align__(16) unsigned char smem[BYTES];
+    lqn_body<NP>(blockIdx.x, gridDim.x, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
+}
+
 }  // namespace hk
