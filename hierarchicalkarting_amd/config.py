@@ -34,6 +34,11 @@ def default_wiring(num_agents):
         return [0, 1], [[], []], [[1], [0]]
     if num_agents == 4:
         return [1, 1, 0, 0], [[1], [0], [3], [2]], [[2, 3], [2, 3], [0, 1], [0, 1]]
+    if num_agents == 8:
+        # synthetic 4v4 (BASELINE configs[4]; the reference has no 8-agent scene): the duos pattern with four karts a side
+        a, b = [0, 1, 2, 3], [4, 5, 6, 7]
+        return ([1] * 4 + [0] * 4, [[j for j in (a if i < 4 else b) if j != i] for i in range(8)],
+                [list(b if i < 4 else a) for i in range(8)])
     team_of = list(range(num_agents))
     return team_of, [[] for _ in range(num_agents)], [[j for j in range(num_agents) if j != i] for i in range(num_agents)]
 

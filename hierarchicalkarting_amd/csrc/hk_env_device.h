@@ -11,7 +11,10 @@
 
 namespace hk {
 
-constexpr int ENV_MAXA = 4;             // agents per env (a quad of lanes); the largest reference scene has 4
+constexpr int ENV_MAXA = HK_MAX_AGENTS; // capacity of the per-agent parameter arrays; the kernels are compiled per lane-group width GA (hk_env_ga.h)
+constexpr int RUN_CAP = 8;      // ticks per env per launch (> cadence).  Measured at E = 65 536, 4-agent Oval: 8 -> 533 M env-steps/s,
+                                // 6 -> 456 M, 5 -> 408 M (misaligned with the 4-tick cadence), 16 -> 503 M, 32 -> 450 M, 128 -> 264 M: a quad that
+                                // queues a game idles its lanes until the launch ends, so long launches waste lanes
 constexpr float DEG2RAD_F = 0.0174532924f;
 constexpr float TWO_PI_F = 2.0f * HK_PI_F;
 constexpr float CAP_R = 0.45f;          // kart capsule (BaseKartClassic.prefab): radius, core segment in kart-local z
@@ -63,6 +66,41 @@ struct EnvParams {
     int training_reset;
     uint32_t train_seed;
 };
+// ---- device buffers of the MCTS planner (hk_env_mcts.h) and of the reward shaping (hk_env_reward.h): the same for every GA
+struct MctsKartSnap { int section, lane, lane_changes, tire_age; int sec_time[4]; };
+struct MNode {
+    int parent, first_child, last_child, next_sibling;
+    int numEpisodes;
+    float totalValue;
+    unsigned char action, upnext, n_children, pad;
+    int pad2;
+};
+static_assert(sizeof(MNode) == 32, "MNode layout");
+struct MctsDev {
+    hk_mcts_state* st;      // [E][A]; nullptr: no agent plans with MCTS
+    void* req;              // [E][A] MctsReq (its size depends on GA: one kart snapshot per lane of the group)
+    int* qcnt;              // [2 sets][2]: {queued searches, arena slots handed out}; the host flips the set when it launches
+                            // the search kernel (every few rounds of the tick kernel, see env_launch_lqn) and clears the new one
+    int* queue;             // [2][2*E*A]: (env * A + agent) | generation << 24
+    MNode* nodes;           // [slots][pool_cap]
+    // move tables, filled once by mcts_table_kernel with the same device functions the search would call (so they are
+    // bit-identical to evaluating applyAction on the spot): what a move costs depends only on the section (mod L), the
+    // kart's lane and velocity bucket and the action — not on the tree
+    int* dt_tab;            // [L][4 lanes][nv + 1 buckets][20 actions]: time added (x timePrecision); < 0 = infeasible
+    float* load_tab;        // [L][4][20]: tireLoad of the move
+    float* rad_tab;         // [L][4][4]: radiusOfLane(section, from, to)
+    int nv;                 // velocity buckets of the action list (<= 5)
+    int pool_cap;
+    int slots;              // searches the arena can hold at once (E * number of MCTS agents)
+};
+struct RwDev {
+    int* sec_time;      // [E][A teams][S]  minSectionTimes (episode step; -1 = key absent)
+    int* sec_cnt;       // [E][A teams][S]  agentsPastSection
+    int S;              // laps * L + 2
+    unsigned char* hit_code;   // [E][A][sensors]: what the last CollectObservations saw closer than the validation distance
+                               // (0 nothing, 1 wall, 2 + j agent j); replayed by reward_hits_kernel
+};
+
 constexpr float GRID_CELL = 2.0f;       // cell size (m)
 constexpr float GRID_REACH = 2.2f;      // list radius: 2 m side rays / 1 m half-spacing of the long-ray samples / 1.11 m
                                         // contact reach, plus slack for float rounding of the cell index

@@ -9,10 +9,7 @@
 #include <vector>
 #include "../../include/hk.h"
 #include "hk_env_device.h"
-#include "hk_env_step.h"
-#include "hk_env_solve.h"
-#include "hk_env_run.h"
-#include "hk_env_observe.h"
+#include "hk_lq_core.h"
 
 namespace hk {
 
@@ -27,8 +24,8 @@ struct EnvDevice {
     float* reward_out = nullptr;   // [2][E][A]: m_Reward, m_GroupReward as read by hk_get_rewards / hk_rewards_device
     int* status = nullptr;
     double* games = nullptr;       // queued multi-player games, structure-of-arrays (GameSoA, hk_env_solve.h)
-    int* queue_cnt = nullptr;      // [2 sets][8] number of queued multi-player games per player count
-    int* queue = nullptr;          // [2 sets][3][E*A] game ids with N = 2, 3, 4
+    int* queue_cnt = nullptr;      // [2 sets][16] number of queued multi-player games per player count
+    int* queue = nullptr;          // [2 sets][GA - 1][E*A] game ids with N = 2 .. GA
     int round = 0;                 // launches so far: round & 1 selects the queue set (double buffered over rounds)
     int* env_ids = nullptr;
     int env_ids_cap = 0;
@@ -45,7 +42,36 @@ struct EnvDevice {
     EnvParams P{};
 };
 
-constexpr int MCTS_MIN_LATENCY = 40;   // (MCTS_FLUSH_ROUNDS + 1) * RUN_CAP: see env_flush_mcts
+constexpr int MCTS_MIN_LATENCY = 40;   // (MCTS_FLUSH_ROUNDS + 1) * RUN_CAP: see flush_mcts (hk_env_launch.h)
+constexpr int MCTS_FLUSH_ROUNDS = 4;
+static_assert((MCTS_FLUSH_ROUNDS + 1) * RUN_CAP <= MCTS_MIN_LATENCY, "a queued search must finish before its plan is due");
+
+inline int launch_check(std::string& err, const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err = std::string(what) + ": " + hipGetErrorString(e); return HK_ERR_HIP; }
+    return HK_OK;
+}
+
+}  // namespace hk
+
+// the env kernels, compiled once per lane-group width (see hk_env_ga.h)
+#define HK_GA 4
+#define HK_GA_NS g4
+#include "hk_env_ga.h"
+#undef HK_GA
+#undef HK_GA_NS
+#define HK_GA 8
+#define HK_GA_NS g8
+#include "hk_env_ga.h"
+#undef HK_GA
+#undef HK_GA_NS
+
+namespace hk {
+
+using g4::rewards_read_kernel;      // does not depend on the group width
+// forward to the kernels of the handle's lane-group width
+#define HK_GA_CALL(d, call) ((d).P.A > 4 ? g8::call : g4::call)
 
 namespace detail {
 
@@ -96,7 +122,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     if (E < 1 || A < 1 || L < 1 || L > HK_MAX_SECTIONS || cfg.num_walls < 0 || !cfg.sections || (cfg.num_walls > 0 && !cfg.walls)) {
         err = "hk_create: bad num_envs / num_agents / track table"; return HK_ERR_INVALID;
     }
-    if (A > ENV_MAXA) { err = "hk_create: num_agents > 4 not built yet (largest reference scene has 4)"; return HK_ERR_UNSUPPORTED; }
+    if (A > ENV_MAXA) { err = "hk_create: num_agents > 8"; return HK_ERR_UNSUPPORTED; }
     for (int i = 0; i < A; i++) {
         if (cfg.n_team[i] < 0 || cfg.n_other[i] < 0 || cfg.n_team[i] + cfg.n_other[i] != A - 1) {
             err = "hk_create: teamAgents + otherAgents of every agent must list every other agent exactly once"; return HK_ERR_INVALID;
@@ -268,9 +294,9 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     HK_ALLOC(d.act_branch, na * sizeof(int32_t));
     HK_ALLOC(d.reward_out, 2 * na * sizeof(float));
     HK_ALLOC(d.status, 4 * sizeof(int));
-    HK_ALLOC(d.games, na * (size_t)LQ_MAXP * GP_FIELDS * sizeof(double));
-    HK_ALLOC(d.queue_cnt, 2 * 8 * sizeof(int));
-    HK_ALLOC(d.queue, 2 * 3 * na * sizeof(int));
+    HK_ALLOC(d.games, na * HK_GA_CALL(d, game_doubles_per_ego()) * sizeof(double));
+    HK_ALLOC(d.queue_cnt, 2 * 16 * sizeof(int));
+    HK_ALLOC(d.queue, 2 * HK_GA_CALL(d, queue_ints_per_set(na)) * sizeof(int));
     if (cfg.rewards) {
         d.rw.S = cfg.laps * L + 2;
         const size_t n = na * (size_t)d.rw.S;
@@ -290,7 +316,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         d.mcts.pool_cap = 1 + std::max(cfg.mcts_iterations, cfg.mcts_initial_iterations) * (max_depth * A + 1);
         d.mcts.slots = E * P.any_mcts;
         HK_ALLOC(d.mcts.st, na * sizeof(hk_mcts_state));
-        HK_ALLOC(d.mcts.req, na * sizeof(MctsReq));
+        HK_ALLOC(d.mcts.req, na * HK_GA_CALL(d, mcts_req_bytes()));
         HK_ALLOC(d.mcts.queue, 2 * 2 * na * sizeof(int));
         HK_ALLOC(d.mcts.nodes, (size_t)d.mcts.slots * d.mcts.pool_cap * sizeof(MNode));
         HK_ALLOC(d.mcts.qcnt, 4 * sizeof(int));
@@ -310,8 +336,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         HK_ALLOC(d.mcts.dt_tab, (size_t)ntab * sizeof(int));
         HK_ALLOC(d.mcts.load_tab, (size_t)L * 4 * HK_MCTS_MAX_ACTIONS * sizeof(float));
         HK_ALLOC(d.mcts.rad_tab, (size_t)L * 4 * 4 * sizeof(float));
-        hipLaunchKernelGGL(mcts_table_kernel, dim3((ntab + 255) / 256), dim3(256), 0, stream, P, d.mcts, ego0);
-        if ((e = hipGetLastError()) != hipSuccess) { err = std::string("mcts_table_kernel: ") + hipGetErrorString(e); return HK_ERR_HIP; }
+        if ((rc = HK_GA_CALL(d, launch_mcts_table(d, ego0, ntab, stream, err)))) return rc;
     }
 #undef HK_ALLOC
     // REC.Start :148-168: every agent starts inactive; results carry episode = -1; RL branch defaults to "coast"
@@ -333,31 +358,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     return HK_OK;
 }
 
-inline int launch_check(std::string& err, const char* what)
-{
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { err = std::string(what) + ": " + hipGetErrorString(e); return HK_ERR_HIP; }
-    return HK_OK;
-}
-
-// Run the planner searches queued so far and hand the tick kernel the other (cleared) queue set.  A search requested on
-// tick t must be finished before tick t + latency (> RUN_CAP, checked in env_create); the tick kernel advances an env by at
-// most RUN_CAP ticks per round, so flushing every MCTS_FLUSH_ROUNDS rounds with (MCTS_FLUSH_ROUNDS + 1) * RUN_CAP < latency
-// is early enough — and batching the requests of several rounds into one launch matters, because a launch takes as long
-// as its slowest search however few searches it holds.
-constexpr int MCTS_FLUSH_ROUNDS = 4;
-static_assert((MCTS_FLUSH_ROUNDS + 1) * RUN_CAP <= MCTS_MIN_LATENCY, "a queued search must finish before its plan is due");
-inline int env_flush_mcts(EnvDevice& d, hipStream_t stream, std::string& err)
-{
-    if (!d.mcts.st) return HK_OK;
-    hipLaunchKernelGGL(mcts_search_kernel, dim3((2 * d.mcts.slots + MC_SPW - 1) / MC_SPW), dim3(64), 0, stream, d.P, d.mcts, d.mset);
-    int rc = launch_check(err, "mcts_search_kernel");
-    if (rc) return rc;
-    d.mset ^= 1;
-    d.mcts_rounds = 0;
-    if (hipMemsetAsync(d.mcts.qcnt + d.mset * 2, 0, 2 * sizeof(int), stream) != hipSuccess) { err = "mcts queue memset"; return HK_ERR_HIP; }
-    return HK_OK;
-}
+inline int env_flush_mcts(EnvDevice& d, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, flush_mcts(d, stream, err)); }
 
 inline int env_reset(EnvDevice& d, const hk_config& cfg, const int32_t* env_ids, int n, int experiment_num, hipStream_t stream,
                      std::string& err)
@@ -378,12 +379,8 @@ inline int env_reset(EnvDevice& d, const hk_config& cfg, const int32_t* env_ids,
         if (hipMemcpyAsync(d.env_ids, env_ids, sizeof(int) * n, hipMemcpyHostToDevice, stream) != hipSuccess) { err = "hipMemcpy env ids"; return HK_ERR_HIP; }
         dids = d.env_ids;
     }
-    const int threads = cnt * 4;
-    hipLaunchKernelGGL(env_reset_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.envs, dids, cnt, experiment_num,
-                       d.mcts, d.mset, d.rw);
-    int rc = launch_check(err, "env_reset_kernel");
+    int rc = HK_GA_CALL(d, launch_reset(d, dids, cnt, experiment_num, stream, err));
     if (rc) return rc;
-    if ((rc = env_flush_mcts(d, stream, err))) return rc;          // the first plans (T = 1.5 s in the reference)
     if (hipStreamSynchronize(stream) != hipSuccess) { err = "hk_reset: sync failed"; return HK_ERR_HIP; }
     return HK_OK;
 }
@@ -391,14 +388,14 @@ inline int env_reset(EnvDevice& d, const hk_config& cfg, const int32_t* env_ids,
 // arm hk_step(n): every env gets n ticks to run
 inline int env_launch_arm(EnvDevice& d, const hk_config& cfg, int n_ticks, hipStream_t stream, std::string& err)
 {
-    hipLaunchKernelGGL(env_arm_kernel, dim3((cfg.num_envs + 255) / 256), dim3(256), 0, stream, d.envs, cfg.num_envs, n_ticks);
-    return launch_check(err, "env_arm_kernel");
+    hipLaunchKernelGGL(g4::env_arm_kernel, dim3((cfg.num_envs + 255) / 256), dim3(256), 0, stream, d.envs, cfg.num_envs, n_ticks);
+    return launch_check(err, "g4::env_arm_kernel");
 }
 
 inline int env_launch_check(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
 {
-    hipLaunchKernelGGL(env_check_kernel, dim3((cfg.num_envs + 255) / 256), dim3(256), 0, stream, d.envs, cfg.num_envs, d.status);
-    return launch_check(err, "env_check_kernel");
+    hipLaunchKernelGGL(g4::env_check_kernel, dim3((cfg.num_envs + 255) / 256), dim3(256), 0, stream, d.envs, cfg.num_envs, d.status);
+    return launch_check(err, "g4::env_check_kernel");
 }
 
 // Number of {run, lqn} rounds issued for n ticks (see hk_env_run.h).  A round retires at least one solve cadence of every
@@ -413,58 +410,8 @@ inline int env_rounds_for(const hk_config& cfg, int n_ticks)
     return (n_ticks + cadence - 1) / cadence + 1 + n_ticks / 32 + 2;
 }
 
-// one round, part 1: the fused tick kernel (fills queue set round & 1)
-inline int env_launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
-{
-    const int threads = cfg.num_envs * 4;
-#define HK_RUN(MC, RWF, TRN)                                                                                                  \
-    hipLaunchKernelGGL((env_run_kernel<MC, RWF, TRN>), dim3((threads + 255) / 256), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs,   \
-                       d.results, GameSoA{d.games, (size_t)cfg.num_envs * cfg.num_agents}, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status,     \
-                       d.tab_lds ? 1 : 0, d.mcts, d.mset, d.rw)
-    bool train = d.P.training_reset != 0;
-    for (int i = 0; i < cfg.num_agents; i++) train = train || d.P.training_agent[i] != 0;
-    if (train) HK_RUN(true, true, true);
-    else if (d.mcts.st) { if (d.rw.sec_time) HK_RUN(true, true, false); else HK_RUN(true, false, false); }
-    else { if (d.rw.sec_time) HK_RUN(false, true, false); else HK_RUN(false, false, false); }
-#undef HK_RUN
-    return launch_check(err, "env_run_kernel");
-}
-
-// one round, part 2: the Riccati solves of the queued multi-player games, binned by player count
-inline int env_launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
-{
-    const int ngames = cfg.num_envs * cfg.num_agents;
-    const int set = d.round & 1;
-    if (d.mcts.st && ++d.mcts_rounds >= MCTS_FLUSH_ROUNDS) { int rcm = env_flush_mcts(d, stream, err); if (rcm) return rcm; }
-    const int* qc = d.queue_cnt + set * 8;
-    const int* qu = d.queue + (size_t)set * 3 * ngames;
-    int rc = HK_OK;
-    if (cfg.num_agents == 2) {
-        // 1v1: only 2-player games exist, one per ego per tick
-        const int nb = std::min((ngames + 7) / 8, 4096);
-        hipLaunchKernelGGL(lqn_single_kernel<2>, dim3(nb), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status);
-        if ((rc = launch_check(err, "lqn_single_kernel<2>"))) return rc;
-    } else if (cfg.num_agents > 2) {
-        // 1 024 workgroups per game size (one wave per SIMD at this kernel's 256 VGPRs) walking their queue grid-stride: dispatching
-        // 3 x 8 192 workgroups that exit at once cost 25 us per round in steady state
-        const int nb = std::min((ngames + 3) / 4, 1024);
-        const int sizes = cfg.num_agents - 1;                 // player counts 2 .. A
-        hipLaunchKernelGGL(lqn_all_kernel, dim3(nb * sizes), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status, nb);
-        if ((rc = launch_check(err, "lqn_all_kernel"))) return rc;
-    }
-    d.round += 1;
-    return HK_OK;
-}
-
-inline int env_launch_observe(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
-{
-    const long long threads = (long long)cfg.num_envs * cfg.num_agents * OBS_LANES;
-    hipLaunchKernelGGL(env_observe_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d.P, d.agents, d.obs, d.rw.hit_code);
-    int rc = launch_check(err, "env_observe_kernel");
-    if (rc || !d.rw.hit_code) return rc;
-    // CollectObservations raised HitWall / HitOpponent events (HKA:580-598): replayed per env in agent / sensor order
-    hipLaunchKernelGGL(reward_hits_kernel, dim3((cfg.num_envs + 127) / 128), dim3(128), 0, stream, d.P, d.agents, d.rw.hit_code);
-    return launch_check(err, "reward_hits_kernel");
-}
+inline int env_launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_run(d, cfg, stream, err)); }
+inline int env_launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_lqn(d, cfg, stream, err)); }
+inline int env_launch_observe(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_observe(d, cfg, stream, err)); }
 
 }  // namespace hk

@@ -1,0 +1,106 @@
+// hk_env_launch.h — host-side launches of the env kernels of ONE lane-group width (namespace hk::HK_GA_NS); hk_env_kernels.h
+// picks the width from hk_config.num_agents and forwards here.
+// (included once per lane-group width by hk_env_ga.h: no include guard)
+
+namespace hk { namespace HK_GA_NS {
+
+inline size_t mcts_req_bytes() { return sizeof(MctsReq); }
+inline size_t game_doubles_per_ego() { return (size_t)GA * GP_FIELDS; }      // GameSoA: GA players x GP_FIELDS doubles
+inline size_t queue_ints_per_set(size_t na) { return (size_t)(GA - 1) * na; }   // one queue per player count 2 .. GA
+
+inline int launch_mcts_table(EnvDevice& d, int ego0, int ntab, hipStream_t stream, std::string& err)
+{
+    hipLaunchKernelGGL(mcts_table_kernel, dim3((ntab + 255) / 256), dim3(256), 0, stream, d.P, d.mcts, ego0);
+    return launch_check(err, "mcts_table_kernel");
+}
+
+// Run the planner searches queued so far and hand the tick kernel the other (cleared) queue set.  A search requested on
+// tick t must be finished before tick t + latency (> RUN_CAP, checked in env_create); the tick kernel advances an env by at
+// most RUN_CAP ticks per round, so flushing every MCTS_FLUSH_ROUNDS rounds with (MCTS_FLUSH_ROUNDS + 1) * RUN_CAP < latency
+// is early enough — and batching the requests of several rounds into one launch matters, because a launch takes as long
+// as its slowest search however few searches it holds.
+inline int flush_mcts(EnvDevice& d, hipStream_t stream, std::string& err)
+{
+    if (!d.mcts.st) return HK_OK;
+    hipLaunchKernelGGL(mcts_search_kernel, dim3((2 * d.mcts.slots + MC_SPW - 1) / MC_SPW), dim3(64), 0, stream, d.P, d.mcts, d.mset);
+    int rc = launch_check(err, "mcts_search_kernel");
+    if (rc) return rc;
+    d.mset ^= 1;
+    d.mcts_rounds = 0;
+    if (hipMemsetAsync(d.mcts.qcnt + d.mset * 2, 0, 2 * sizeof(int), stream) != hipSuccess) { err = "mcts queue memset"; return HK_ERR_HIP; }
+    return HK_OK;
+}
+
+inline int launch_reset(EnvDevice& d, const int* dids, int cnt, int experiment_num, hipStream_t stream, std::string& err)
+{
+    const int threads = cnt * GA;
+    hipLaunchKernelGGL(env_reset_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.envs, dids, cnt, experiment_num,
+                       d.mcts, d.mset, d.rw);
+    int rc = launch_check(err, "env_reset_kernel");
+    if (rc) return rc;
+    return flush_mcts(d, stream, err);          // the first plans (T = 1.5 s in the reference)
+}
+
+// one round, part 1: the fused tick kernel (fills queue set round & 1)
+inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
+    const long long threads = (long long)cfg.num_envs * GA;
+#define HK_RUN(MC, RWF, TRN)                                                                                                  \
+    hipLaunchKernelGGL((env_run_kernel<MC, RWF, TRN>), dim3((unsigned)((threads + 255) / 256)), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs,   \
+                       d.results, GameSoA{d.games, (size_t)cfg.num_envs * cfg.num_agents}, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status,     \
+                       d.tab_lds ? 1 : 0, d.mcts, d.mset, d.rw)
+    bool train = d.P.training_reset != 0;
+    for (int i = 0; i < cfg.num_agents; i++) train = train || d.P.training_agent[i] != 0;
+    if (train) HK_RUN(true, true, true);
+    else if (d.mcts.st) { if (d.rw.sec_time) HK_RUN(true, true, false); else HK_RUN(true, false, false); }
+    else { if (d.rw.sec_time) HK_RUN(false, true, false); else HK_RUN(false, false, false); }
+#undef HK_RUN
+    return launch_check(err, "env_run_kernel");
+}
+
+// one round, part 2: the Riccati solves of the queued multi-player games, binned by player count
+inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
+    const int ngames = cfg.num_envs * cfg.num_agents;
+    const int set = d.round & 1;
+    if (d.mcts.st && ++d.mcts_rounds >= MCTS_FLUSH_ROUNDS) { int rcm = flush_mcts(d, stream, err); if (rcm) return rcm; }
+    const int* qc = d.queue_cnt + set * 16;
+    const int* qu = d.queue + (size_t)set * queue_ints_per_set((size_t)ngames);
+    int rc = HK_OK;
+    if (cfg.num_agents == 2) {
+        // 1v1: only 2-player games exist, one per ego per tick
+        const int nb = std::min((ngames + 7) / 8, 4096);
+        hipLaunchKernelGGL(lqn_single_kernel<2>, dim3(nb), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status);
+        if ((rc = launch_check(err, "lqn_single_kernel<2>"))) return rc;
+    } else if (cfg.num_agents > 2) {
+        // 1 024 workgroups per game size (one wave per SIMD at this kernel's 256 VGPRs) walking their queue grid-stride: dispatching
+        // 3 x 8 192 workgroups that exit at once cost 25 us per round in steady state
+        const int nb = std::min((ngames + 3) / 4, 1024);
+        const int sizes = std::min(cfg.num_agents, 4) - 1;     // player counts 2 .. min(A, 4)
+        hipLaunchKernelGGL(lqn_all_kernel, dim3(nb * sizes), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status, nb);
+        if ((rc = launch_check(err, "lqn_all_kernel"))) return rc;
+#if HK_GA > 4
+        if (cfg.num_agents > 4) {
+            const int nbb = std::min((ngames + 1) / 2, 512);
+            hipLaunchKernelGGL(lqn_big_kernel, dim3(nbb * (cfg.num_agents - 4)), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu,
+                               d.lq_debug, d.status, nbb);
+            if ((rc = launch_check(err, "lqn_big_kernel"))) return rc;
+        }
+#endif
+    }
+    d.round += 1;
+    return HK_OK;
+}
+
+inline int launch_observe(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
+    const long long threads = (long long)cfg.num_envs * cfg.num_agents * OBS_LANES;
+    hipLaunchKernelGGL(env_observe_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d.P, d.agents, d.obs, d.rw.hit_code);
+    int rc = launch_check(err, "env_observe_kernel");
+    if (rc || !d.rw.hit_code) return rc;
+    // CollectObservations raised HitWall / HitOpponent events (HKA:580-598): replayed per env in agent / sensor order
+    hipLaunchKernelGGL(reward_hits_kernel, dim3((cfg.num_envs + 127) / 128), dim3(128), 0, stream, d.P, d.agents, d.rw.hit_code);
+    return launch_check(err, "reward_hits_kernel");
+}
+
+} }  // namespace hk::HK_GA_NS

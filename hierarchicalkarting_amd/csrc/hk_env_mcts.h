@@ -16,50 +16,23 @@
 // the rollout ordering (the reference recomputes it three times), and what a move costs (time, tire load) comes from
 // tables filled once at hk_create by the very functions that restate applyAction / computeTOC.  The draws (Philox) and every float expression
 // are the same, so the plans agree with the oracle's bit for bit.
-#pragma once
+// (included once per lane-group width by hk_env_ga.h: no include guard, namespace hk::HK_GA_NS)
 #include "hk_env_device.h"
 
-namespace hk {
+namespace hk { namespace HK_GA_NS {
 
-constexpr int MC_MAXP = 4;                    // players of a discrete game (<= agents of an env)
+constexpr int MC_MAXP = GA;                   // players of a discrete game (<= agents of an env)
 constexpr int MC_MAXA = HK_MCTS_MAX_ACTIONS;  // 20
 #ifndef HK_MC_SPW
 #define HK_MC_SPW 64
 #endif
 constexpr int MC_SPW = HK_MC_SPW;             // searches per wave (see mcts_search_kernel)
 
-struct MctsKartSnap { int section, lane, lane_changes, tire_age; int sec_time[4]; };
 struct MctsReq {
     int episode_steps, epoch, iterations, gen;      // gen: bumped by every request of this ego (stale queue entries are skipped)
     MctsKartSnap k[MC_MAXP];
 };
-struct MNode {
-    int parent, first_child, last_child, next_sibling;
-    int numEpisodes;
-    float totalValue;
-    unsigned char action, upnext, n_children, pad;
-    int pad2;
-};
-static_assert(sizeof(MNode) == 32, "MNode layout");
-
-struct MctsDev {
-    hk_mcts_state* st;      // [E][A]; nullptr: no agent plans with MCTS
-    MctsReq* req;           // [E][A]
-    int* qcnt;              // [2 sets][2]: {queued searches, arena slots handed out}; the host flips the set when it launches
-                            // the search kernel (every few rounds of the tick kernel, see env_launch_lqn) and clears the new one
-    int* queue;             // [2][2*E*A]: (env * A + agent) | generation << 24
-    MNode* nodes;           // [slots][pool_cap]
-    // move tables, filled once by mcts_table_kernel with the same device functions the search would call (so they are
-    // bit-identical to evaluating applyAction on the spot): what a move costs depends only on the section (mod L), the
-    // kart's lane and velocity bucket and the action — not on the tree
-    int* dt_tab;            // [L][4 lanes][nv + 1 buckets][20 actions]: time added (x timePrecision); < 0 = infeasible
-    float* load_tab;        // [L][4][20]: tireLoad of the move
-    float* rad_tab;         // [L][4][4]: radiusOfLane(section, from, to)
-    int nv;                 // velocity buckets of the action list (<= 5)
-    int pool_cap;
-    int slots;              // searches the arena can hold at once (E * number of MCTS agents)
-};
-
+__device__ __forceinline__ MctsReq* mc_reqs(const MctsDev& M) { return static_cast<MctsReq*>(M.req); }
 // ---------------------------------------------------------------------------------------------------------------------
 // pieces used by the tick kernel
 
@@ -77,7 +50,7 @@ __device__ inline int mcts_tire_age(const EnvParams& P, float final_steer)
     return (int)((P.st.MaxSteer - final_steer) / (P.st.MaxSteer - P.st.MinSteer) * 10000.0f);
 }
 
-// Every lane of the quad calls this with the same req_mask (bit e: ego e plans on this tick).  Lane i contributes its
+// Every lane of the env's group calls this with the same req_mask (bit e: ego e plans on this tick).  Lane i contributes its
 // own kart's snapshot to every requesting ego's record; a requesting ego also writes the header and queues itself.
 __device__ inline void mcts_post_request(const EnvParams& P, const MctsDev& M, int set, int env, int i, uint32_t req_mask,
                                          int episode_steps, int epoch, int iterations, int ready_step,
@@ -89,11 +62,11 @@ __device__ inline void mcts_post_request(const EnvParams& P, const MctsDev& M, i
     s.section = section; s.lane = lane; s.lane_changes = lane_changes; s.tire_age = mcts_tire_age(P, final_steer);
     for (int q = 0; q < 4; q++) s.sec_time[q] = mine->sec_time[q];
     for (int e = 0; e < P.A; e++)
-        if (req_mask & (1u << e)) M.req[(size_t)env * P.A + e].k[i] = s;
+        if (req_mask & (1u << e)) mc_reqs(M)[(size_t)env * P.A + e].k[i] = s;
     const bool requesting = (req_mask & (1u << i)) != 0;
     const int slot = wave_agg_inc(&M.qcnt[set * 2], requesting);          // one atomic per wave, not per ego
     if (requesting) {
-        MctsReq* r = &M.req[(size_t)env * P.A + i];
+        MctsReq* r = &mc_reqs(M)[(size_t)env * P.A + i];
         r->episode_steps = episode_steps; r->epoch = epoch; r->iterations = iterations; r->gen += 1;
         mine->searches += 1;
         mine->ready_step = ready_step;
@@ -138,7 +111,7 @@ __device__ inline void phase_plan(const EnvParams& P, const MctsDev& M, int set,
     if (enabled && P.high_mode[i] == HK_HIGH_MCTS && !P.training_agent[i] && es.episode_steps % 100 == 0 && es.episode_steps < P.max_steps &&
         es.episode_steps > 0 && !inactive)
         req = 1u << i;
-    req |= __shfl_xor(req, 1, 64); req |= __shfl_xor(req, 2, 64);
+    req = (uint32_t)group_or((int)req);
     if (req) mcts_post_request(P, M, set, env, i, req, es.episode_steps, es.episodes_done, P.mcts_iter, es.episode_steps + P.mcts_lat,
                                section, lane, lane_changes, final_steer);
     if (enabled && P.high_mode[i] == HK_HIGH_MCTS) mcts_consume(P, &M.st[(size_t)env * P.A + i], arec, i, es.episode_steps, section);
@@ -151,30 +124,48 @@ struct DKart { int section, time, minv, maxv, lane, tire, lchg; };
 // The karts are NAMED members, not an array: every access is either mc_k<I>(g) with a compile-time I or a field-wise value
 // select (mc_get / mc_set).  With an array the compiler keeps the state in scratch and turns the selects into address
 // selects; a scratch round trip costs hundreds of cycles at this kernel's occupancy and there were hundreds per position.
+#if HK_GA > 4
+#define MC_EACH(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define MC_EACH2(X, S) X(S, 0) X(S, 1) X(S, 2) X(S, 3) X(S, 4) X(S, 5) X(S, 6) X(S, 7)
+#else
+#define MC_EACH(X) X(0) X(1) X(2) X(3)
+#define MC_EACH2(X, S) X(S, 0) X(S, 1) X(S, 2) X(S, 3)
+#endif
 struct DGame {
     int P;
-    DKart k0, k1, k2, k3;
-    int t0, t1, t2, t3;         // team of each player
+#define MC_MEMBER(I) DKart k##I; int t##I;        /* kart and team of player I */
+    MC_EACH(MC_MEMBER)
+#undef MC_MEMBER
     int last, fin;              // lastCompletedSection, finalSection
 };
-static_assert(MC_MAXP == 4, "DGame names its four karts");
 template <int I> __device__ __forceinline__ DKart& mc_k(DGame& g)
 {
-    if constexpr (I == 0) return g.k0; else if constexpr (I == 1) return g.k1; else if constexpr (I == 2) return g.k2; else return g.k3;
+#define MC_REF(J) if constexpr (I == J) return g.k##J;
+    MC_EACH(MC_REF)
+#undef MC_REF
+    __builtin_unreachable();
 }
 template <int I> __device__ __forceinline__ const DKart& mc_k(const DGame& g)
 {
-    if constexpr (I == 0) return g.k0; else if constexpr (I == 1) return g.k1; else if constexpr (I == 2) return g.k2; else return g.k3;
+#define MC_REF(J) if constexpr (I == J) return g.k##J;
+    MC_EACH(MC_REF)
+#undef MC_REF
+    __builtin_unreachable();
 }
 template <int I> __device__ __forceinline__ int& mc_t(DGame& g)
 {
-    if constexpr (I == 0) return g.t0; else if constexpr (I == 1) return g.t1; else if constexpr (I == 2) return g.t2; else return g.t3;
+#define MC_REF(J) if constexpr (I == J) return g.t##J;
+    MC_EACH(MC_REF)
+#undef MC_REF
+    __builtin_unreachable();
 }
 template <int I> __device__ __forceinline__ int mc_t(const DGame& g)
 {
-    if constexpr (I == 0) return g.t0; else if constexpr (I == 1) return g.t1; else if constexpr (I == 2) return g.t2; else return g.t3;
+#define MC_REF(J) if constexpr (I == J) return g.t##J;
+    MC_EACH(MC_REF)
+#undef MC_REF
+    __builtin_unreachable();
 }
-#define MC_EACH(X) X(0) X(1) X(2) X(3)
 // The legal moves of the player who is up next: a bit per canonical action (velocity-major) and the time each adds.
 // Every loop over dt[] is fully unrolled, so the array lives in registers (no scratch: a scratch round trip costs
 // hundreds of cycles at the one-wave-per-SIMD occupancy this kernel runs at, and there were hundreds per position).
@@ -322,11 +313,23 @@ __device__ __forceinline__ int mc_cmp(const DKart& a, const DKart& b)
 // whole game state in scratch.  All fields are ints, so and / or with all-ones masks is exact.
 __device__ __forceinline__ DKart mc_get(const DGame& g, int p)
 {
-    const int m1 = -(int)(p == 1), m2 = -(int)(p == 2), m3 = -(int)(p == 3), m0 = ~(m1 | m2 | m3);
+    // player 0 also answers for any p outside 1 .. MC_MAXP - 1
+    int rest = 0;
+#define MC_REST(I) if (I > 0) rest |= -(int)(p == I);
+    MC_EACH(MC_REST)
+#undef MC_REST
+    const int m0 = ~rest;
     DKart r;
-#define MC_SEL(f) r.f = (g.k0.f & m0) | (g.k1.f & m1) | (g.k2.f & m2) | (g.k3.f & m3);
-    MC_SEL(section) MC_SEL(time) MC_SEL(minv) MC_SEL(maxv) MC_SEL(lane) MC_SEL(tire) MC_SEL(lchg)
-#undef MC_SEL
+    r.section = g.k0.section & m0; r.time = g.k0.time & m0; r.minv = g.k0.minv & m0; r.maxv = g.k0.maxv & m0;
+    r.lane = g.k0.lane & m0; r.tire = g.k0.tire & m0; r.lchg = g.k0.lchg & m0;
+#define MC_SELK(I)                                                                           \
+    if (I > 0) {                                                                             \
+        const int m = -(int)(p == I);                                                        \
+        r.section |= mc_k<I>(g).section & m; r.time |= mc_k<I>(g).time & m; r.minv |= mc_k<I>(g).minv & m; r.maxv |= mc_k<I>(g).maxv & m; \
+        r.lane |= mc_k<I>(g).lane & m; r.tire |= mc_k<I>(g).tire & m; r.lchg |= mc_k<I>(g).lchg & m; \
+    }
+    MC_EACH(MC_SELK)
+#undef MC_SELK
     return r;
 }
 __device__ __forceinline__ void mc_set(DGame& g, int p, const DKart& v)
@@ -339,8 +342,11 @@ __device__ __forceinline__ void mc_set(DGame& g, int p, const DKart& v)
 }
 __device__ __forceinline__ int mc_team(const DGame& g, int p)
 {
-    const int m1 = -(int)(p == 1), m2 = -(int)(p == 2), m3 = -(int)(p == 3), m0 = ~(m1 | m2 | m3);
-    return (g.t0 & m0) | (g.t1 & m1) | (g.t2 & m2) | (g.t3 & m3);
+    int rest = 0, r = 0;
+#define MC_TSEL(I) if (I > 0) { const int m = -(int)(p == I); rest |= m; r |= mc_t<I>(g) & m; }
+    MC_EACH(MC_TSEL)
+#undef MC_TSEL
+    return r | (g.t0 & ~rest);
 }
 
 // upNext KDG:183-238: the first kart, in the order List.Sort leaves them, that has not completed section last + 1.
@@ -469,7 +475,9 @@ __device__ __forceinline__ bool mc_is_over(const MctsCtx& C, const DGame& g, int
         float maxScore = (float)C.precision * -1000.0f, minScore = (float)C.precision * 1000.0f;
         float teamScore = 0.0f, opponentScore = 0.0f;
         int teamCount = 0, opponentCount = 0;                       // accumulate over players (not reset, KDG:273-276)
-        float raw0 = 0.0f, raw1 = 0.0f, raw2 = 0.0f, raw3 = 0.0f;
+#define MC_RAW(I) float raw##I = 0.0f;
+        MC_EACH(MC_RAW)
+#undef MC_RAW
 #define MC_PAIR(S, O)                                                                        \
         if (O < g.P) {                                                                       \
             if (S == O) teamScore += (float)mc_k<O>(g).time;                                 \
@@ -478,7 +486,7 @@ __device__ __forceinline__ bool mc_is_over(const MctsCtx& C, const DGame& g, int
         }
 #define MC_SCORE(S)                                                                          \
         if (S < g.P) {                                                                       \
-            MC_PAIR(S, 0) MC_PAIR(S, 1) MC_PAIR(S, 2) MC_PAIR(S, 3)                          \
+            MC_EACH2(MC_PAIR, S)                                                             \
             const float score = opponentScore * (((float)teamCount * tsm + 1.0f) / ((float)opponentCount * 1.0f)) - teamScore; \
             raw##S = score;                                                                  \
             const bool nn = __builtin_isnan(score);   /* Math.Max / Math.Min propagate NaN */ \
@@ -581,12 +589,12 @@ __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M,
     if (q >= M.qcnt[set * 2]) return;
     const unsigned ent = (unsigned)M.queue[(size_t)set * 2 * P.E * P.A + q];
     const int pair = (int)(ent & 0xFFFFFFu);
-    if (((unsigned)M.req[pair].gen & 0xFFu) != (ent >> 24)) return;          // superseded by a later request of the same ego
+    if (((unsigned)mc_reqs(M)[pair].gen & 0xFFu) != (ent >> 24)) return;          // superseded by a later request of the same ego
     const int slot = wave_agg_inc(&M.qcnt[set * 2 + 1], true);               // arena slot (one atomic per wave)
     if (slot >= M.slots) return;
     const int env = pair / P.A, ego = pair % P.A;
     const TabView T = tab_view(P, P.tab);
-    const MctsReq& R = M.req[pair];
+    const MctsReq& R = mc_reqs(M)[pair];
     hk_mcts_state* mst = &M.st[pair];
     MNode* nd = M.nodes + (size_t)slot * M.pool_cap;
 
@@ -597,13 +605,13 @@ __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M,
 
     // planWithMCTS HKA:172-263: the discrete game of the karts within sectionWindow sections of the ego
     DGame root;
-    uint32_t agent_of = 0;                                           // player p is agent (agent_of >> 8p) & 255
+    uint32_t agent_of = 0;                                           // player p is agent (agent_of >> 4p) & 15
     root.P = 0;
     int initialSection = R.k[ego].section, furthest = ego;
     for (int i = 0; i < P.A; i++) {
         int d = R.k[i].section - R.k[ego].section; d = d < 0 ? -d : d;
         if (d < P.section_window[ego]) {
-            agent_of |= (uint32_t)i << (8 * root.P); root.P++;
+            agent_of |= (uint32_t)i << (4 * root.P); root.P++;
             if (R.k[i].section > initialSection) initialSection = R.k[i].section;
             if (initialSection == R.k[i].section) furthest = i;
         }
@@ -613,7 +621,7 @@ __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M,
         DKart& k = mc_k<I>(root);                                                            \
         k.section = 0; k.time = 0; k.minv = 0; k.maxv = 0; k.lane = 1; k.tire = 0; k.lchg = 0; mc_t<I>(root) = 0; \
         if (I < root.P) {                                                                    \
-            const int ap = (int)((agent_of >> (8 * I)) & 255u);                              \
+            const int ap = (int)((agent_of >> (4 * I)) & 15u);                              \
             const MctsKartSnap& s = R.k[ap];                                                 \
             mc_t<I>(root) = P.team_of[ap];                                                   \
             k.minv = 0;                                /* HKA:211-219: the bucket loop breaks at i = 0 */ \
@@ -690,7 +698,7 @@ __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M,
     hk_mcts_plan plan;
     __builtin_memset(&plan, 0, sizeof(plan));
     plan.n_players = root.P;
-    for (int p = 0; p < root.P; p++) plan.player_agent[p] = (uint8_t)((agent_of >> (8 * p)) & 255u);
+    for (int p = 0; p < root.P; p++) plan.player_agent[p] = (uint8_t)((agent_of >> (4 * p)) & 15u);
     {
         DGame g = root;
         int node = 0;
@@ -714,4 +722,7 @@ __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M,
     mst->pend = plan;
 }
 
-}  // namespace hk
+#undef MC_EACH
+#undef MC_EACH2
+
+} }  // namespace hk::HK_GA_NS

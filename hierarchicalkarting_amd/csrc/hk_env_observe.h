@@ -1,10 +1,10 @@
 // hk_env_observe.h — HierarchicalKartAgent.CollectObservations (HKA:485-604): one thread per (env, agent).
 // Layout = the order the reference calls sensor.AddObservation: 8 own, 12 per teammate, 12 per opponent,
 // 5 per upcoming section (sectionHorizon), 9 ray distances (up to 20 m long: walked through the wall grid).
-#pragma once
+// (included once per lane-group width by hk_env_ga.h: no include guard, namespace hk::HK_GA_NS)
 #include "hk_env_device.h"
 
-namespace hk {
+namespace hk { namespace HK_GA_NS {
 
 // (fx, fz) = the kart's forward (sin yaw, cos yaw): evaluated once per kart by the caller, not per use
 __device__ inline float local_speed(const EnvParams& P, const hk_agent_state* a, float fx, float fz)
@@ -47,21 +47,21 @@ __global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_
     const hk_agent_state* a = &ags[i];
     float* o = obs + (size_t)gid * dim;
     // forward vectors of the env's karts: lane l evaluates kart l % A, the group shares them
-    float kfx[ENV_MAXA], kfz[ENV_MAXA];
+    float kfx[GA], kfz[GA];
     {
         const float yl = ags[l % A].yaw;
         float sx, cz;
         hk_sincosf(yl, &sx, &cz);
         const int base = (threadIdx.x & 63) & ~(OBS_LANES - 1);
 #pragma unroll
-        for (int j = 0; j < ENV_MAXA; j++) {
+        for (int j = 0; j < GA; j++) {
             kfx[j] = __shfl(sx, base + (j < A ? j : 0), 64);
             kfz[j] = __shfl(cz, base + (j < A ? j : 0), 64);
         }
     }
     float fx = kfx[0], fz = kfz[0];
 #pragma unroll
-    for (int j = 1; j < ENV_MAXA; j++) if (i == j) { fx = kfx[j]; fz = kfz[j]; }
+    for (int j = 1; j < GA; j++) if (i == j) { fx = kfx[j]; fz = kfz[j]; }
     if (!valid) return;
     if (l == 14) {                                                           // own block HKA:489-496
         o[0] = local_speed(P, a, fx, fz);
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_
                 const hk_agent_state* b = &ags[bj];
                 float bfx = kfx[0], bfz = kfz[0];
 #pragma unroll
-                for (int q = 1; q < ENV_MAXA; q++) if (bj == q) { bfx = kfx[q]; bfz = kfz[q]; }
+                for (int q = 1; q < GA; q++) if (bj == q) { bfx = kfx[q]; bfz = kfz[q]; }
                 o[p++] = local_speed(P, b, bfx, bfz);
                 o[p++] = (b->flags & HK_F_ACCEL) ? 1.0f : 0.0f;
                 o[p++] = (float)b->lane;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_
         int who = -1;
         if (see) {
 #pragma unroll
-            for (int j = 0; j < ENV_MAXA; j++) {
+            for (int j = 0; j < GA; j++) {
                 if (j >= A || j == i || !(ags[j].flags & HK_F_ENABLED)) continue;
                 float t = ray_stadium(ox, oz, dx, dz, ags[j].px, ags[j].pz, kfx[j], kfz[j], P.ray_agent_r);
                 if (t >= 0.0f && t <= maxd && (ha < 0.0f || t < ha)) { ha = t; who = j; }
@@ -160,4 +160,4 @@ __global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_
     }
 }
 
-}  // namespace hk
+} }  // namespace hk::HK_GA_NS

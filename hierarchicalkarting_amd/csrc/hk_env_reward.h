@@ -11,20 +11,12 @@
 // agent by agent afterwards (rw_replay_events), which is the order the engine restatement dispatches the triggers in.
 // CollectObservations raises HitWall / HitOpponent from its ray distances (HKA:580-598): env_observe_kernel records a code
 // per sensor, reward_hits_kernel replays them per env in agent / sensor order (REC.ResolveEvent :444-462).
-#pragma once
+// (included once per lane-group width by hk_env_ga.h: no include guard, namespace hk::HK_GA_NS)
 #include "hk_env_device.h"
 
-namespace hk {
+namespace hk { namespace HK_GA_NS {
 
 struct RwAcc { float cum, step, group; };
-
-struct RwDev {
-    int* sec_time;      // [E][A teams][S]  minSectionTimes (episode step; -1 = key absent)
-    int* sec_cnt;       // [E][A teams][S]  agentsPastSection
-    int S;              // laps * L + 2
-    unsigned char* hit_code;   // [E][A][sensors]: what the last CollectObservations saw closer than the validation distance
-                               // (0 nothing, 1 wall, 2 + j agent j); replayed by reward_hits_kernel
-};
 
 struct RwEvent {        // one OnTriggerEnter outcome of this lane's kart, replayed in rw_replay_events
     int kind;           // 1: reached a section (forward), 2: drove back through one
@@ -151,9 +143,7 @@ __device__ inline float rw_section(const EnvParams& P, const RwDev& R, const int
 __device__ inline void rw_replay_events(const EnvParams& P, const RwDev& R, const int env, const int i, const int steps,
                                         const RwEvent* ev, const int nev, const bool en_before, const bool en_after, RwAcc& r)
 {
-    int any = nev;
-    any |= __shfl_xor(any, 1, 64); any |= __shfl_xor(any, 2, 64);
-    if (!any) return;
+    if (!group_or(nev)) return;
     for (int j = 0; j < P.A; j++) {
         float gadd[RW_MAX_EVENTS] = {0.0f, 0.0f};
         int gn = 0;
@@ -181,8 +171,8 @@ __device__ inline void rw_replay_events(const EnvParams& P, const RwDev& R, cons
 __device__ inline void rw_goal_timing(const EnvParams& P, const int i, const int time_steps, const bool enabled, RwAcc& r)
 {
     const int A = P.A, maxs = P.max_steps;
-    int ts[ENV_MAXA];
-    for (int j = 0; j < ENV_MAXA; j++) { const int t = quad_get(time_steps, j); ts[j] = t == 0 ? 5 * maxs : t; }
+    int ts[GA];
+    for (int j = 0; j < GA; j++) { const int t = quad_get(time_steps, j); ts[j] = t == 0 ? 5 * maxs : t; }
     if (i >= A) return;
     if (A == 1) {
         if (time_steps != 0) rw_add(r, P.rw.ReachGoalCheckpointRewardMultplier * (1.0f - (float)time_steps * 1.0f / (float)maxs) + P.rw.ReachGoalCheckpointRewardBase);
@@ -234,4 +224,4 @@ __global__ __launch_bounds__(256) void rewards_read_kernel(hk_agent_state* agent
     agents[t].step_reward = 0.0f; agents[t].group_reward = 0.0f;
 }
 
-}  // namespace hk
+} }  // namespace hk::HK_GA_NS

@@ -1,7 +1,7 @@
 // hk_env_run.h — the fused tick kernel.
 //
-// env_run_kernel advances every race instance by up to RUN_CAP Unity FixedUpdate ticks in ONE launch: a quad of lanes
-// (lane = agent) loops  phase A (episode controller + kart-vs-kart rays)  ->  phase B1 (wall rays, game assembly,
+// env_run_kernel advances every race instance by up to RUN_CAP Unity FixedUpdate ticks in ONE launch: a group of GA lanes
+// (a quad for up to 4 agents; lane = agent) loops  phase A (episode controller + kart-vs-kart rays)  ->  phase B1 (wall rays, game assembly,
 // single-player Riccati solve)  ->  phase C (ArcadeKart model, engine restatement, triggers)  with the env words and
 // the per-tick agent fields (Hot) in registers; only the plan arrays are touched in memory.  The only thing a quad cannot do alone is a multi-player LQ game
 // (2-4 players, 8-16 cooperating lanes): it writes the game, queues it by player count, stores its progress and
@@ -15,16 +15,10 @@
 // rounds that find nothing to do cost a few microseconds.  (RUN_CAP must exceed the cadence: a resumed env finishes its
 // pending tick and must be able to reach its next solve tick within the same launch.)  env_check_kernel flags any env
 // that still has ticks left after the last round (a bug guard: hk_get_* then fail instead of returning stale state).
-#pragma once
+// (included once per lane-group width by hk_env_ga.h: no include guard, namespace hk::HK_GA_NS)
 #include "hk_env_device.h"
-#include "hk_env_step.h"
-#include "hk_env_solve.h"
 
-namespace hk {
-
-constexpr int RUN_CAP = 8;      // ticks per env per launch (> cadence).  Measured at E = 65 536, 4-agent Oval: 8 -> 533 M env-steps/s,
-                                // 6 -> 456 M, 5 -> 408 M (misaligned with the 4-tick cadence), 16 -> 503 M, 32 -> 450 M, 128 -> 264 M: a quad that
-                                // queues a game idles its lanes until the launch ends, so long launches waste lanes
+namespace hk { namespace HK_GA_NS {
 
 __global__ __launch_bounds__(256) void env_arm_kernel(hk_env_state* envs, int E, int n_ticks)
 {
@@ -52,13 +46,13 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
     __shared__ KartS ks[256];
     extern __shared__ __align__(16) unsigned char smem[];
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int env = gid >> 2, i = gid & 3;
+    const int env = gid / GA, i = gid % GA;
     const bool env_ok = env < P.E;
     // the game queues are double buffered over rounds: this launch fills `set`, and clears the other one, which the
     // previous round's lqn kernels have finished reading
-    int* queue_cnt = queue_cnt_all + set * 8;
-    int* queue = queue_all + (size_t)set * 3 * P.E * P.A;
-    if (gid < 8) queue_cnt_all[(set ^ 1) * 8 + gid] = 0;
+    int* queue_cnt = queue_cnt_all + set * 16;
+    int* queue = queue_all + (size_t)set * (GA - 1) * P.E * P.A;
+    if (gid < 16) queue_cnt_all[(set ^ 1) * 16 + gid] = 0;
     hk_env_state es;
     if (env_ok) es = envs[env];
     else { es.episode_steps = 0; es.inactive_mask = 0; es.experiment_num = 0; es.episodes_done = 0; es.status = 0; es.initial_started = 0; es.reserved[0] = 0; es.reserved[1] = 0; }
@@ -89,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
                 qn = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st);
                 // bin the queued games by player count, one atomic per wave and count
 #pragma unroll
-                for (int n = 2; n <= LQ_MAXP; n++) {
+                for (int n = 2; n <= GA; n++) {
                     const int pos = wave_agg_inc(&queue_cnt[n], qn == n);
                     if (qn == n) queue[(size_t)(n - 2) * P.E * P.A + pos] = env * P.A + i;
                 }
@@ -99,9 +93,7 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
                 continue;
             }
             // does any ego of this env wait for a multi-player solve?
-            int q = qn ? 1 : 0;
-            q |= __shfl_xor(q, 1, 64); q |= __shfl_xor(q, 2, 64);
-            if (q) { phase = 1; break; }
+            if (group_or(qn ? 1 : 0)) { phase = 1; break; }
         }
         phase_move<HAS_RW, HAS_TRAIN>(P, T, env, i, env_ok, es, h, hfx, hfz, agents, act_steer, act_branch, M.st, RD, rwv);
         phase = 0;
@@ -118,4 +110,4 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
     }
 }
 
-}  // namespace hk
+} }  // namespace hk::HK_GA_NS

@@ -11,11 +11,11 @@
 //   both decode u0 -> (Accelerate, Brake, Steering) (HKA:1206-1224).
 //
 // Results are bit-identical to the CPU oracle's dense restatement: see the arithmetic contract in hk_lq_core.h.
-#pragma once
+// (included once per lane-group width by hk_env_ga.h: no include guard, namespace hk::HK_GA_NS)
 #include "hk_env_device.h"
 #include "hk_lq_core.h"
 
-namespace hk {
+namespace hk { namespace HK_GA_NS {
 
 struct GamePlayer {            // one player's share of a game, ego-local order (Q3)
     double x0[4];              // initial (x, z, v, heading)                                  HKA:730-736
@@ -23,9 +23,9 @@ struct GamePlayer {            // one player's share of a game, ego-local order 
     double tw[4];              // target weights                                              HKA:930-964
     double tgt[4];             // target state                                                HKA:808-926
     double rc;                 // control weight                                              HKA:1192-1196
-    double aw[3];              // avoid weight per other player (x and z share it)            HKA:1019,1114
-    double opw[3][3];          // opponent-target weights (x, z, v)                           HKA:1073-1093,1168-1188
-    double opt[3][3];          // opponent target (x, z, v); heading entry is never set -> 0  HKA:1065-1067
+    double aw[GA - 1];         // avoid weight per other player (x and z share it)            HKA:1019,1114
+    double opw[GA - 1][3];     // opponent-target weights (x, z, v)                           HKA:1073-1093,1168-1188
+    double opt[GA - 1][3];     // opponent target (x, z, v); heading entry is never set -> 0  HKA:1065-1067
     int M, agent, branch, pad_;
 };
 // Queued multi-player games live in ONE array of doubles, structure-of-arrays over the games: field f of player i of game g
@@ -33,7 +33,9 @@ struct GamePlayer {            // one player's share of a game, ego-local order 
 // the assembly and every load of the solver is one contiguous run per wave instruction (the array-of-structs this replaces
 // cost 64 scattered sectors per instruction: the 2-agent configuration, where every tick queues a 2-player game per ego,
 // spent most of its time there).
-constexpr int GP_X0 = 0, GP_A4 = 4, GP_TW = 8, GP_TGT = 12, GP_RC = 16, GP_AW = 17, GP_OPW = 20, GP_OPT = 29, GP_M = 38, GP_FIELDS = 40;
+constexpr int GP_NO = GA - 1;     // other players of a game, at most
+constexpr int GP_X0 = 0, GP_A4 = 4, GP_TW = 8, GP_TGT = 12, GP_RC = 16, GP_AW = 17, GP_OPW = GP_AW + GP_NO, GP_OPT = GP_OPW + 3 * GP_NO,
+              GP_M = GP_OPT + 3 * GP_NO, GP_FIELDS = (GP_M + 2) & ~1;      // GA = 4: 20, 29, 38, 40
 struct GameSoA {
     double* d;
     size_t ng;
@@ -546,14 +548,14 @@ __device__ inline int phase_assemble(const EnvParams& P, const TabView& T, KartS
     ks[threadIdx.x] = k;
     wave_lds_sync();
     if (!me) return 0;
-    const KartS* kq = &ks[threadIdx.x & ~3];          // the env's four karts
+    const KartS* kq = &ks[threadIdx.x & ~(GA - 1)];   // the env's karts
     const bool solving = (k.flags & HK_F_ENABLED) && P.low_mode[ego] == HK_LOW_LQR && !((es.inactive_mask >> ego) & 1u);
     if (!solving) return 0;
     // ---- players (HKA:702-725)
-    int pl[ENV_MAXA] = {0, 0, 0, 0};
+    int pl[GA] = {};
     int N = 0, nearbyAgents = -1;
     {
-        int all[ENV_MAXA], nall = 0;
+        int all[GA], nall = 0;
         all[nall++] = ego;
         for (int j = 0; j < P.n_team[ego]; j++) all[nall++] = P.team[ego][j];
         for (int j = 0; j < P.n_other[ego]; j++) all[nall++] = P.other[ego][j];
@@ -723,4 +725,26 @@ __global__ __launch_bounds__(64) void lqn_single_kernel(EnvParams P, hk_agent_st
     lqn_body<NP>(blockIdx.x, gridDim.x, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
 }
 
-}  // namespace hk
+#if HK_GA > 4
+// Games with 5..8 players (only the synthetic 8-agent configuration has them): blocks [0, nb) take the 5-player queue, ... [3 nb, 4 nb)
+// the 8-player one.  The generic core is the same; beyond 4 players a lane's value-matrix rows (NP x 4 NP doubles) exceed the
+// register file and spill — functional, not tuned (such games are rare: more than 4 karts within 8 m of each other).
+__global__ __launch_bounds__(64) void lqn_big_kernel(EnvParams P, hk_agent_state* agents, const GameSoA games, const int* queue_cnt,
+                                                     const int* queue, hk_lq_debug* dbg_out, int* status, int nb)
+{
+    constexpr size_t B5 = (sizeof(LqGameLds<5>) + sizeof(CostRows<5>)) * LqDims<5>::SLOTS;
+    constexpr size_t B6 = (sizeof(LqGameLds<6>) + sizeof(CostRows<6>)) * LqDims<6>::SLOTS;
+    constexpr size_t B7 = (sizeof(LqGameLds<7>) + sizeof(CostRows<7>)) * LqDims<7>::SLOTS;
+    constexpr size_t B8 = (sizeof(LqGameLds<8>) + sizeof(CostRows<8>)) * LqDims<8>::SLOTS;
+    constexpr size_t BA = B5 > B6 ? B5 : B6, BB = B7 > B8 ? B7 : B8, BMAX = BA > BB ? BA : BB;
+    static_assert(BMAX <= 160 * 1024, "one workgroup's games must fit the CU's LDS");
+    __shared__ __align__(16) unsigned char smem[BMAX];
+    const int which = blockIdx.x / nb, b = blockIdx.x - which * nb;
+    if (which == 0) lqn_body<5>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
+    else if (which == 1) lqn_body<6>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
+    else if (which == 2) lqn_body<7>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
+    else lqn_body<8>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
+}
+#endif
+
+} }  // namespace hk::HK_GA_NS

@@ -1,32 +1,20 @@
 // hk_env_step.h — the non-LQ part of a tick: episode controller, sensing, ArcadeKart model, engine restatement.
 //
-// Thread mapping: 4 consecutive lanes (a "quad") own one race instance, lane q = agent q; a 256-thread block holds
-// 64 envs.  Kart-to-kart data moves with quad-wide shuffles; per-env words (episode_steps, inactive set) are
-// recomputed identically by the 4 lanes and written by lane 0.  Wall queries read the uniform wall grid that
+// Thread mapping: GA consecutive lanes (a "quad" for GA = 4: up to 4 agents per env; 8 lanes for the synthetic 8-agent
+// configuration) own one race instance, lane q = agent q; a 256-thread block holds 256 / GA envs.  Kart-to-kart data moves
+// with group-wide shuffles; per-env words (episode_steps, inactive set) are recomputed identically by the lanes of the group
+// and written by lane 0.  Wall queries read the uniform wall grid that
 // hk_create builds (per 2 m cell: every segment within 2.2 m), staged in LDS with the other track tables; the lists
 // are supersets of what can be reached, so results equal a brute force scan over every wall (what the CPU oracle does).
-#pragma once
+// (included once per lane-group width by hk_env_ga.h: no include guard, namespace hk::HK_GA_NS)
 #include "hk_env_device.h"
-#include "hk_env_mcts.h"
-#include "hk_env_training.h"
 
-namespace hk {
-
-__device__ __forceinline__ float quad_get(float v, int q) { return __shfl(v, (threadIdx.x & ~3) | q, 64); }
-__device__ __forceinline__ uint32_t quad_get(uint32_t v, int q) { return (uint32_t)__shfl((int)v, (threadIdx.x & ~3) | q, 64); }
-__device__ __forceinline__ int quad_get(int v, int q) { return __shfl(v, (threadIdx.x & ~3) | q, 64); }
-
-}  // namespace hk
-#include "hk_env_reward.h"
-namespace hk {
-
+namespace hk { namespace HK_GA_NS {
 
 // REC.ResetGame :499-719 for one agent (Experiment / Race grid); see oracle reset_env for the line map
 template <bool TRAIN>
 __device__ inline void reset_agent(const EnvParams& P, const TabView& T, int env, int i, int experiment_num, int episodes_done, hk_agent_state* a)
 {
-    const int expLane[4] = {2, 3, 2, 3};
-    const int expSection[4] = {0, 0, 1, 1};
     const int pi = ((experiment_num % P.nperm) + P.nperm) % P.nperm;
     const int* ord = P.perms + (size_t)pi * P.A;
     int j = 0;
@@ -38,8 +26,9 @@ __device__ inline void reset_agent(const EnvParams& P, const TabView& T, int env
     __builtin_memset(a, 0, sizeof(hk_agent_state));     // (not a uint32_t* loop: that would violate type-based aliasing)
     a->tele_completed_laps = t_laps; a->tele_lap_end_step = t_step;
     a->tele_last_lap = t_last; a->tele_best_lap = t_best; a->tele_total_time = t_total;
-    int sec = expSection[j & 3];
-    int lane = expLane[j & 3];
+    // expSectionChoices {0, 0, 1, 1} / expLaneChoices {2, 3, 2, 3} (REC:526-527), continued row by row for more than 4 agents
+    int sec = j >> 1;
+    int lane = 2 + (j & 1);
     float spawn = 3.0f, acc0 = P.init_acc;
     if (TRAIN && P.training_reset) {                         // Training mode: random scatter (REC:520-668)
         float twp = 0.25f;
@@ -92,7 +81,7 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_st
                                                         const int* env_ids, int n, int experiment_num, MctsDev M, int set, RwDev RD)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int slot = gid >> 2, i = gid & 3;
+    const int slot = gid / GA, i = gid % GA;
     if (slot >= n || i >= P.A) return;
     const int env = env_ids ? env_ids[slot] : slot;
     const int ex = experiment_num >= 0 ? experiment_num : (P.env_id_base + env) % P.nperm;
@@ -183,7 +172,7 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
             if (me) results[(size_t)env * P.A + i].group_reward = rwv.group;
             if (env_ok) {
                 const int n = P.A * RD.S;
-                for (int q = i; q < n; q += 4) { RD.sec_time[(size_t)env * n + q] = -1; RD.sec_cnt[(size_t)env * n + q] = 0; }
+                for (int q = i; q < n; q += GA) { RD.sec_time[(size_t)env * n + q] = -1; RD.sec_cnt[(size_t)env * n + q] = 0; }
             }
             __threadfence();
             rwv.cum = 0.0f; rwv.step = 0.0f; rwv.group = 0.0f;      // the record is rewritten below (EndGroupEpisode)
@@ -223,7 +212,7 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
         float ddx[3], ddz[3];
 #pragma unroll
         for (int q = 0; q < 3; q++) sensor_dir(P, csens[q], fx, fz, ddx[q], ddz[q]);
-        for (int j = 0; j < ENV_MAXA; j++) {
+        for (int j = 0; j < GA; j++) {
             const float jpx = quad_get(px, j), jpz = quad_get(pz, j), jfx = quad_get(fx, j), jfz = quad_get(fz, j);
             const uint32_t jfl = quad_get(fl, j);
             if (j >= P.A || j == i || !(jfl & HK_F_ENABLED)) continue;
@@ -389,7 +378,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
         kart_core(cfx, cfz, px, pz, ax, az, bx, bz);
         float cpx = 0, cpz = 0, cvx = 0, cvz = 0;
         bool touched = false;
-        for (int j = 0; j < ENV_MAXA; j++) {
+        for (int j = 0; j < GA; j++) {
             const float jpx = quad_get(px, j), jpz = quad_get(pz, j), jfx = quad_get(cfx, j), jfz = quad_get(cfz, j);
             const float jvx = quad_get(vx, j), jvz = quad_get(vz, j);
             const uint32_t jfl = quad_get(fl, j);
@@ -568,10 +557,10 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
     }
     // per-env words: OR over the quad
     uint32_t ni = newly_inactive, bd = bad ? 1u : 0u;
-    ni |= (uint32_t)__shfl_xor((int)ni, 1, 64); ni |= (uint32_t)__shfl_xor((int)ni, 2, 64);
-    bd |= (uint32_t)__shfl_xor((int)bd, 1, 64); bd |= (uint32_t)__shfl_xor((int)bd, 2, 64);
-    es.inactive_mask = inactive_mask | ni;      // identical in the 4 lanes (quad-reduced)
+    ni = (uint32_t)group_or((int)ni);
+    bd = (uint32_t)group_or((int)bd);
+    es.inactive_mask = inactive_mask | ni;      // identical in the lanes of the group
     if (bd) es.status = status | 1u;
 }
 
-}  // namespace hk
+} }  // namespace hk::HK_GA_NS

@@ -6,10 +6,10 @@
 // env's layout (the placement of one kart depends on the karts placed before it) and keeps its own row.  This code is compiled
 // only into the env_run_kernel<true, true, true> instantiation: inlined into the headline kernel it cost 9 % (register pressure in
 // a path that never runs there), and as noinline calls even more (call ABI spills).
-#pragma once
+// (included once per lane-group width by hk_env_ga.h: no include guard, namespace hk::HK_GA_NS)
 #include "hk_env_device.h"
 
-namespace hk {
+namespace hk { namespace HK_GA_NS {
 
 struct TrRng { uint32_t k0, k1, c1, c2, c3, n; };
 __device__ inline uint32_t tr_u32(TrRng& g) { uint32_t r[4]; philox4x32(g.n++, g.c1, g.c2, g.c3, g.k0, g.k1, r); return r[0]; }
@@ -60,7 +60,7 @@ __device__ inline void training_layout(const EnvParams& P, const TabView& T, int
     TrRng g = {P.train_seed, (uint32_t)(P.env_id_base + env), (uint32_t)episodes_done, (uint32_t)experiment_num, 0x54524E47u, 0u};
     const int A = P.A, L = P.L, goal = P.laps * L + 1;
     const bool headToHead = tr_range_i(g, 0, 9) >= 3;
-    int used_sec[ENV_MAXA], used_lane[ENV_MAXA], n_added = 0, initialSection = -1;
+    int used_sec[GA], used_lane[GA], n_added = 0, initialSection = -1;
     for (int j = 0; j < A; j++) {
         const int i = ord[j];
         int s_i, l_i;
@@ -105,4 +105,4 @@ __device__ inline void training_layout(const EnvParams& P, const TabView& T, int
     }
 }
 
-}  // namespace hk
+} }  // namespace hk::HK_GA_NS

@@ -341,8 +341,9 @@ static void reset_env(hko_env* e, int env)
 {
     hk_env_state* es = &e->es[env];
     hk_agent_state* ags = &e->ag[(size_t)env * e->A];
-    static const int expLaneChoices[4] = {2, 3, 2, 3};       /* :526 */
-    static const int expSectionChoices[4] = {0, 0, 1, 1};    /* :527 */
+    /* expLaneChoices {2, 3, 2, 3} / expSectionChoices {0, 0, 1, 1} (:526-527) cover the 4 agents of the largest reference scene
+       (a fifth agent would index past them).  For the synthetic 8-agent configuration the same pattern continues row by row:
+       grid slot j starts in section j / 2, lane 2 + j % 2 — identical to the reference's tables for j < 4. */
     es->episode_steps = 0;                                   /* :505 */
     es->inactive_mask = 0;                                   /* :506 */
     if (e->sec_min_time) hko_rw_reset_env(e, env);           /* :508-512 */
@@ -361,14 +362,14 @@ static void reset_env(hko_env* e, int env)
         /* the TelemetryViewer is not reset with the game: its arrays survive (it notices the lower lap count itself) */
         a->tele_completed_laps = t_laps; a->tele_lap_end_step = t_step;
         a->tele_last_lap = t_last; a->tele_best_lap = t_best; a->tele_total_time = t_total;
-        a->section_index = training ? t_sec[i] : expSectionChoices[j & 3];   /* :583 / :634 */
+        a->section_index = training ? t_sec[i] : (j >> 1);   /* :583 / :634 */
         a->init_checkpoint_index = a->section_index;         /* :586 */
         a->acc_ang_v = e->init_acc_ang_v;                    /* :588 */
         if (training) {
             const hk_kart_stats* st = &e->cfg.stats;
             a->acc_ang_v = -st->TireWearRate * hk_logf(1 - ((st->MaxSteer - st->MinSteer) * t_twp[i] / st->MaxSteer));
         }
-        a->lane = training ? t_lane[i] : expLaneChoices[j & 3];              /* :593 */
+        a->lane = training ? t_lane[i] : 2 + (j & 1);              /* :593 */
         const float spawn = training ? t_dist[i] : 3.0f;
         const hk_section* s = &e->sec[a->section_index % e->L];
         const sec_pre* sp = &e->sp[a->section_index % e->L];
