@@ -108,15 +108,22 @@ def bench_mcts(a, rank, local_rank, world, dist, torch, hk):
     The planner's wall-clock budget of the reference is an iteration budget here (--mcts-iterations per 100-tick replan)."""
     from hierarchicalkarting_amd import _lib
     rl = a.workload == "mctsrl"
-    E = a.envs_per_gpu if a.envs_per_gpu != 65536 else (32768 if rl else 16384)
-    A = 4
+    a8 = a.workload == "a8"
+    E = a.envs_per_gpu if a.envs_per_gpu != 65536 else (131072 if a8 else (32768 if rl else 16384))
+    A = 8 if a8 else 4
+    low = [_lib.HK_LOW_RL if rl else _lib.HK_LOW_LQR] * A
+    if a8:      # configs[4]: "mixed MCTS-RL vs MCTS-LQNG" = team 1 (agents 0-3) MCTS + RL actor, team 0 (agents 4-7) MCTS + LQNG
+        low = [_lib.HK_LOW_RL] * 4 + [_lib.HK_LOW_LQR] * 4
     env = hk.RacingEnv(hk.make_config(E, A, track="oval" if rl else "complex", high_mode=[_lib.HK_HIGH_MCTS] * A, tree_search_depth=8,
-                                      low_mode=[_lib.HK_LOW_RL if rl else _lib.HK_LOW_LQR] * A,
+                                      low_mode=low,
                                       mcts_iterations=a.mcts_iterations, jitter_seed=0x5EED0000, env_id_base=rank * E, device_id=local_rank))
     if rl:      # configs[3]: one 312 -> 256 x 3 actor per team (random-init weights of the reference architecture), DecisionPeriod 2
         from hierarchicalkarting_amd.policy import Policy
         env.attach_policy(Policy.random(env.obs_dim * 4, 256, 3, seed=101), [0, 1], 2)
         env.attach_policy(Policy.random(env.obs_dim * 4, 256, 3, seed=202), [2, 3], 2)
+    if a8:      # one 504 -> 256 x 3 actor for the RL team
+        from hierarchicalkarting_amd.policy import Policy
+        env.attach_policy(Policy.random(env.obs_dim * 4, 256, 3, seed=303), [0, 1, 2, 3], 2)
     env.reset()
     env.step(a.warmup)
     env.synchronize()
@@ -142,13 +149,16 @@ def bench_mcts(a, rank, local_rank, world, dist, torch, hk):
         dt = float(t.item())
     if rank == 0:
         m = env.mcts_state()
-        out = {"metric": "env-steps/sec (2v2 OvalDuos, MCTS-RL)" if rl else "env-steps/sec (4-agent Complex, MCTS-LQNG)",
+        out = {"metric": "env-steps/sec (8-agent Complex, mixed MCTS-RL vs MCTS-LQNG)" if a8 else
+                         ("env-steps/sec (2v2 OvalDuos, MCTS-RL)" if rl else "env-steps/sec (4-agent Complex, MCTS-LQNG)"),
                "value": E * world * a.steps / dt, "unit": "env-steps/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": ("2v2 Oval, " if rl else "4-agent Complex track (41 sections), ") +
+               "config": {"workload": ("8-agent (4v4, synthetic: the reference has no 8-agent scene) Complex track, " if a8 else
+                                       ("2v2 Oval, " if rl else "4-agent Complex track (41 sections), ")) +
                                       "MCTS high level (%d iterations per replan, depth 8, replan every 100 ticks) + %s low level, %d envs per GPU"
-                                      % (a.mcts_iterations, "RL actor on device (312 -> 256 x 3 per team, DecisionPeriod 2)" if rl else "LQNG", E),
+                                      % (a.mcts_iterations, "RL actor on device (504 -> 256 x 3, DecisionPeriod 2) for one team, LQNG for the other" if a8 else
+                                         ("RL actor on device (312 -> 256 x 3 per team, DecisionPeriod 2)" if rl else "LQNG"), E),
                           "envs_per_gpu": E, "agents": A,
                           "searches_per_agent_mean": float(m["searches"].mean())},
                "kernel_total_ms": {k: v[0] for k, v in prof.items()},
@@ -169,10 +179,11 @@ def main():
     ap.add_argument("--agents", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mcts-iterations", type=int, default=64)
-    ap.add_argument("--workload", choices=("lqng", "rl", "mcts", "mctsrl"), default="lqng",
+    ap.add_argument("--workload", choices=("lqng", "rl", "mcts", "mctsrl", "a8"), default="lqng",
                     help="lqng: BASELINE.json configs[1] (the headline); rl: 2v2 Oval with the RL low-level actor on device (configs[3] shape); "
                          "mcts: 4-agent Complex track, MCTS-LQNG, 16 384 envs (configs[2]); "
-                         "mctsrl: 2v2 OvalDuos, MCTS high level + RL low level on device, 32 768 envs per GPU (configs[3])")
+                         "mctsrl: 2v2 OvalDuos, MCTS high level + RL low level on device, 32 768 envs per GPU (configs[3]); "
+                         "a8: 8-agent Complex, mixed MCTS-RL vs MCTS-LQNG, 131 072 envs per GPU (configs[4])")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -198,7 +209,7 @@ def main():
 
     if a.workload == "rl":
         return bench_rl(a, rank, local_rank, world, dist, torch, hk)
-    if a.workload in ("mcts", "mctsrl"):
+    if a.workload in ("mcts", "mctsrl", "a8"):
         return bench_mcts(a, rank, local_rank, world, dist, torch, hk)
     E = a.envs_per_gpu
     seed = 0x5EED0000

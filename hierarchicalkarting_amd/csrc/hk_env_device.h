@@ -79,7 +79,7 @@ static_assert(sizeof(MNode) == 32, "MNode layout");
 struct MctsDev {
     hk_mcts_state* st;      // [E][A]; nullptr: no agent plans with MCTS
     void* req;              // [E][A] MctsReq (its size depends on GA: one kart snapshot per lane of the group)
-    int* qcnt;              // [2 sets][2]: {queued searches, arena slots handed out}; the host flips the set when it launches
+    int* qcnt;              // [2 sets][2]: {queued searches, unused}; the host flips the set when it launches
                             // the search kernel (every few rounds of the tick kernel, see env_launch_lqn) and clears the new one
     int* queue;             // [2][2*E*A]: (env * A + agent) | generation << 24
     MNode* nodes;           // [slots][pool_cap]
@@ -91,7 +91,7 @@ struct MctsDev {
     float* rad_tab;         // [L][4][4]: radiusOfLane(section, from, to)
     int nv;                 // velocity buckets of the action list (<= 5)
     int pool_cap;
-    int slots;              // searches the arena can hold at once (E * number of MCTS agents)
+    int slots;              // trees the arena holds = lanes of the search kernel's grid (<= MCTS_ARENA_WAVES waves)
 };
 struct RwDev {
     int* sec_time;      // [E][A teams][S]  minSectionTimes (episode step; -1 = key absent)

@@ -44,6 +44,7 @@ struct EnvDevice {
 
 constexpr int MCTS_MIN_LATENCY = 40;   // (MCTS_FLUSH_ROUNDS + 1) * RUN_CAP: see flush_mcts (hk_env_launch.h)
 constexpr int MCTS_FLUSH_ROUNDS = 4;
+constexpr int MCTS_ARENA_WAVES = 2048;
 static_assert((MCTS_FLUSH_ROUNDS + 1) * RUN_CAP <= MCTS_MIN_LATENCY, "a queued search must finish before its plan is due");
 
 inline int launch_check(std::string& err, const char* what)
@@ -314,7 +315,12 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         int max_depth = 1;
         for (int i = 0; i < A; i++) if (cfg.high_mode[i] == HK_HIGH_MCTS) max_depth = std::max(max_depth, cfg.tree_search_depth[i]);
         d.mcts.pool_cap = 1 + std::max(cfg.mcts_iterations, cfg.mcts_initial_iterations) * (max_depth * A + 1);
-        d.mcts.slots = E * P.any_mcts;
+        {   // the search kernel is a fixed grid walking the queue: the arena holds one tree per resident lane, at most
+            // MCTS_ARENA_WAVES waves (2 per SIMD of the 256 CUs), however many envs there are
+            const int spw = HK_GA_CALL(d, mcts_searches_per_wave());
+            const long long want = (((long long)E * P.any_mcts + spw - 1) / spw) * spw;
+            d.mcts.slots = (int)std::min<long long>(want, (long long)MCTS_ARENA_WAVES * spw);
+        }
         HK_ALLOC(d.mcts.st, na * sizeof(hk_mcts_state));
         HK_ALLOC(d.mcts.req, na * HK_GA_CALL(d, mcts_req_bytes()));
         HK_ALLOC(d.mcts.queue, 2 * 2 * na * sizeof(int));

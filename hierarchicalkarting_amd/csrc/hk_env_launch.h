@@ -5,6 +5,7 @@
 namespace hk { namespace HK_GA_NS {
 
 inline size_t mcts_req_bytes() { return sizeof(MctsReq); }
+inline int mcts_searches_per_wave() { return MC_SPW; }
 inline size_t game_doubles_per_ego() { return (size_t)GA * GP_FIELDS; }      // GameSoA: GA players x GP_FIELDS doubles
 inline size_t queue_ints_per_set(size_t na) { return (size_t)(GA - 1) * na; }   // one queue per player count 2 .. GA
 
@@ -22,7 +23,7 @@ inline int launch_mcts_table(EnvDevice& d, int ego0, int ntab, hipStream_t strea
 inline int flush_mcts(EnvDevice& d, hipStream_t stream, std::string& err)
 {
     if (!d.mcts.st) return HK_OK;
-    hipLaunchKernelGGL(mcts_search_kernel, dim3((2 * d.mcts.slots + MC_SPW - 1) / MC_SPW), dim3(64), 0, stream, d.P, d.mcts, d.mset);
+    hipLaunchKernelGGL(mcts_search_kernel, dim3((d.mcts.slots + MC_SPW - 1) / MC_SPW), dim3(64), 0, stream, d.P, d.mcts, d.mset);
     int rc = launch_check(err, "mcts_search_kernel");
     if (rc) return rc;
     d.mset ^= 1;

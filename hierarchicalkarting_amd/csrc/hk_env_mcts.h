@@ -579,24 +579,15 @@ __device__ __forceinline__ int mc_ucs(MctsCtx& C, const MNode* nd, int node)
     return best;
 }
 
-__global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M, int set)
+// one queued search (queue entry q of `set`), its tree in the arena slice `nd`
+__device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDev& M, const TabView& T, const int set, const int q, MNode* nd)
 {
-    // MC_SPW searches per wave.  Measured (16 384 envs x 4 agents = 1 024 full waves, one per SIMD): 64 -> 11.2 M env-steps/s,
-    // 32 -> 11.0 M, 21 -> 10.3 M, 16 -> 9.7 M: a launch lasts as long as one search however the searches are spread, so
-    // thinner waves buy nothing
-    if ((int)threadIdx.x >= MC_SPW) return;
-    const int q = blockIdx.x * MC_SPW + threadIdx.x;
-    if (q >= M.qcnt[set * 2]) return;
     const unsigned ent = (unsigned)M.queue[(size_t)set * 2 * P.E * P.A + q];
     const int pair = (int)(ent & 0xFFFFFFu);
     if (((unsigned)mc_reqs(M)[pair].gen & 0xFFu) != (ent >> 24)) return;          // superseded by a later request of the same ego
-    const int slot = wave_agg_inc(&M.qcnt[set * 2 + 1], true);               // arena slot (one atomic per wave)
-    if (slot >= M.slots) return;
     const int env = pair / P.A, ego = pair % P.A;
-    const TabView T = tab_view(P, P.tab);
     const MctsReq& R = mc_reqs(M)[pair];
     hk_mcts_state* mst = &M.st[pair];
-    MNode* nd = M.nodes + (size_t)slot * M.pool_cap;
 
     MctsCtx C;
     mc_ctx_init(C, P, T, M, ego);
@@ -720,6 +711,22 @@ __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M,
         }
     }
     mst->pend = plan;
+}
+
+// The search kernel: a fixed grid of waves (the arena holds one tree per resident lane, M.slots = gridDim.x * MC_SPW) walks the
+// queue with a grid stride, so the arena does not grow with the number of envs and every wave ends when the queue is exhausted.
+__global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M, int set)
+{
+    // MC_SPW searches per wave.  Measured (16 384 envs x 4 agents = 1 024 full waves, one per SIMD): 64 -> 11.2 M env-steps/s,
+    // 32 -> 11.0 M, 21 -> 10.3 M, 16 -> 9.7 M: a launch lasts as long as one search however the searches are spread, so
+    // thinner waves buy nothing
+    if ((int)threadIdx.x >= MC_SPW) return;
+    const int count = M.qcnt[set * 2];
+    const int lane0 = blockIdx.x * MC_SPW + threadIdx.x;
+    if (lane0 >= M.slots) return;
+    const TabView T = tab_view(P, P.tab);
+    MNode* nd = M.nodes + (size_t)lane0 * M.pool_cap;
+    for (int q = lane0; q < count; q += gridDim.x * MC_SPW) mcts_search_one(P, M, T, set, q, nd);
 }
 
 #undef MC_EACH
