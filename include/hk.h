@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 #define HK_ABI_VERSION 2
-#define HK_MAX_AGENTS 8      /* ABI capacity; the kernels accept num_agents <= 4 (the largest reference scene) */
+#define HK_MAX_AGENTS 8      /* the largest reference scene has 4; 5..8 agents per env is the synthetic extension of BASELINE configs[4] (start grid continued row by row) */
 #define HK_MAX_SECTIONS 64   /* Oval 24, Complex 41 */
 #define HK_NUM_SENSORS 9     /* MLAgent_Sensors.prefab */
 

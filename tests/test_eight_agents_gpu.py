@@ -114,3 +114,18 @@ def test_training_mode_8_agents():
     for n in (50, 150, 300, 300, 400):
         g.step(n); o.step(n); t += n
         _cmp(g, o, t)
+
+
+def test_eight_agent_trajectory_hash_matches_the_committed_pin():
+    """the kernels alone against the committed oracle pin (no oracle run on the GPU box)"""
+    import hashlib, json, os
+    import hierarchicalkarting_amd as hk
+    from test_env_gpu import _pinned_bytes
+    g = hk.RacingEnv(hk.make_config(2, 8, jitter_seed=0, laps=1))
+    g.reset(experiment_num=0)
+    hashes = []
+    for _ in range(4):
+        g.step(512)
+        hashes.append(hashlib.sha256(_pinned_bytes(g.agent_state())).hexdigest())
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oval_8agent_2048_hash.json")))["sha256"]
+    assert hashes == want

@@ -210,3 +210,31 @@ def test_trajectory_hash_pin():
                        "config": "make_config(1, 2, jitter_seed=0), reset(experiment_num=0)", "every": 512, "sha256": hashes}, f, indent=1)
     want = json.load(open(path))["sha256"]
     assert hashes == want
+
+
+def test_eight_agent_oracle_pin_and_sanity():
+    """The synthetic 8-agent configuration on the oracle: the start grid continues the reference's {section j/2, lane 2 + j%2}
+    pattern (identical to REC:526-527 for the first four slots), all eight finish a 1-lap Oval race, and the trajectory is
+    pinned by hash (tests/golden/oval_8agent_2048_hash.json; the GPU test compares the same hashes)."""
+    b = make_config(2, 8, jitter_seed=0, laps=1)
+    o = O.OracleEnv(b)
+    o.reset(experiment_num=0)
+    st = o.agent_state()
+    assert list(st["section_index"][0]) == [0, 0, 1, 1, 2, 2, 3, 3] and list(st["lane"][0]) == [2, 3] * 4
+    b4 = make_config(1, 4, jitter_seed=0)
+    o4 = O.OracleEnv(b4); o4.reset(experiment_num=0)
+    s4 = o4.agent_state()
+    for name in ("px", "pz", "yaw", "section_index", "lane"):
+        assert np.array_equal(s4[name][0], st[name][0][:4]), name          # first four grid slots = the reference's
+    hashes = []
+    for _ in range(4):
+        o.step(512)
+        hashes.append(hashlib.sha256(_pinned_bytes(o.agent_state())).hexdigest())
+    res = o.episode_results()
+    assert (res["episode"] >= 0).all() and (res["time_steps"] > 800).all() and (res["time_steps"] < 2048).all(), res["time_steps"]
+    path = os.path.join(GOLD, "oval_8agent_2048_hash.json")
+    if os.environ.get("HK_REGEN_GOLDEN") == "1":
+        with open(path, "w") as f:
+            json.dump({"generator": "tests/test_oracle_env.py::test_eight_agent_oracle_pin_and_sanity (HK_REGEN_GOLDEN=1), CPU oracle",
+                       "config": "make_config(2, 8, jitter_seed=0, laps=1), reset(experiment_num=0)", "every": 512, "sha256": hashes}, f, indent=1)
+    assert hashes == json.load(open(path))["sha256"]
