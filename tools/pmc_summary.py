@@ -13,6 +13,7 @@ def fold(path, counter, last=None):
             if r.get("Counter_Name") != counter:
                 continue
             name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("hk::", "")
+            name = re.sub(r"^g[48]::", "", name)                               # lane-group namespace (hk_env_ga.h)
             name = re.sub(r"^env_run_kernel<.*>$", "env_run_kernel", name)     # the headline instantiation <false, false>
             per[name].append(float(r["Counter_Value"]))
     return {k: (sum(v[-last:]) / len(v[-last:]) if last else sum(v) / len(v), len(v)) for k, v in per.items()}
