@@ -186,27 +186,29 @@ __device__ __forceinline__ int grid_cell(const EnvParams& P, float x, float z)
 }
 
 // ------------------------------------------------------------------ analytic Physics.Raycast pieces
-#define HK_RAY_SEG_BODY                                      \
-    float ex = w.x1 - w.x0, ez = w.z1 - w.z0;                \
-    float den = dx * ez - dz * ex;                           \
-    if (den == 0.0f) return -1.0f;                           \
-    float wx = w.x0 - ox, wz = w.z0 - oz;                    \
-    float t = (wx * ez - wz * ex) / den;                     \
-    float s = (wx * dz - wz * dx) / den;                     \
-    if (t >= 0.0f && s >= 0.0f && s <= 1.0f) return t;       \
-    return -1.0f;
+// ray (o, unit d) vs one wall segment.  With e = p1 - p0, w = p0 - o:  den = d x e,  s = (w x d) / den (position along the
+// segment),  t = (w x e) / den (distance along the ray).  The crossing test 0 <= s <= 1, t >= 0 is made on the cross products
+// themselves (signs and |s numerator| <= |den|): no rounded quotient is compared, and only an actual hit pays for a division.
+#define HK_RAY_SEG_CROSS                                     \
+    const float ex = w.x1 - w.x0, ez = w.z1 - w.z0;          \
+    den = dx * ez - dz * ex;                                 \
+    const float wx = w.x0 - ox, wz = w.z0 - oz;              \
+    tn = wx * ez - wz * ex;                                  \
+    const float sn = wx * dz - wz * dx;                      \
+    return den > 0.0f ? (sn >= 0.0f && sn <= den && tn >= 0.0f) : (den < 0.0f && sn <= 0.0f && sn >= den && tn <= 0.0f);
 // host twin (hk_create precomputes the static lane->lane "cut" rays with the same arithmetic)
-inline float ray_seg_host(float ox, float oz, float dx, float dz, const hk_wall_seg& w) { HK_RAY_SEG_BODY }
+inline bool ray_seg_hits_host(float ox, float oz, float dx, float dz, const hk_wall_seg& w, float& tn, float& den) { HK_RAY_SEG_CROSS }
+inline float ray_seg_host(float ox, float oz, float dx, float dz, const hk_wall_seg& w)
+{
+    float tn, den;
+    return ray_seg_hits_host(ox, oz, dx, dz, w, tn, den) ? tn / den : -1.0f;
+}
+// does the ray cross the segment?  tn / den is then the distance
+__device__ __forceinline__ bool ray_seg_hits(float ox, float oz, float dx, float dz, const hk_wall_seg& w, float& tn, float& den) { HK_RAY_SEG_CROSS }
 __device__ __forceinline__ float ray_seg(float ox, float oz, float dx, float dz, const hk_wall_seg& w)
 {
-    float ex = w.x1 - w.x0, ez = w.z1 - w.z0;
-    float den = dx * ez - dz * ex;
-    if (den == 0.0f) return -1.0f;
-    float wx = w.x0 - ox, wz = w.z0 - oz;
-    float t = (wx * ez - wz * ex) / den;
-    float s = (wx * dz - wz * dx) / den;
-    if (t >= 0.0f && s >= 0.0f && s <= 1.0f) return t;
-    return -1.0f;
+    float tn, den;
+    return ray_seg_hits(ox, oz, dx, dz, w, tn, den) ? tn / den : -1.0f;
 }
 
 // ray vs another kart's capsule sliced at the ray height (stadium); origin inside -> no hit (Q10)

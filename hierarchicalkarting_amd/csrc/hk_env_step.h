@@ -421,23 +421,49 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             const int w0 = T.grid_off[cell], w1 = T.grid_off[cell + 1];
             float bestpen = 0.0f, bnx = 0.0f, bnz = 0.0f;
             bool found = false;
-            for (int q = w0; q < w1; q++) {
-                const hk_wall_seg ws = T.walls[T.grid_idx[q]];
-                float c1x, c1z, c2x, c2z;
-                float d2 = seg_seg_closest(ax, az, bx, bz, ws.x0, ws.z0, ws.x1, ws.z1, c1x, c1z, c2x, c2z);
-                if (d2 < CAP_R * CAP_R) {
-                    float d = sqrtf(d2);
-                    float pen = CAP_R - d;
-                    float nx, nz;
-                    if (d > 1e-6f) { nx = (c1x - c2x) / d; nz = (c1z - c2z) / d; }
-                    else {
-                        float ex = ws.x1 - ws.x0, ez = ws.z1 - ws.z0;
-                        float el = sqrtf(ex * ex + ez * ez);
-                        nx = -ez / el; nz = ex / el;
-                        if ((px - ws.x0) * nx + (pz - ws.z0) * nz < 0.0f) { nx = -nx; nz = -nz; }
+            // Two passes over the cell's list, 32 walls at a time: a cheap bounding-box test marks the walls that can be within
+            // CAP_R of the core at all (a bit per wall), then only those get the closest-point computation, in ascending list
+            // order.  The lanes of a wave sit in different cells: with the full test on every listed wall the wave paid the
+            // longest list (a curve's ~7 one-metre segments) times the full test on every tick, although almost no kart
+            // touches a wall.  The box test is conservative (1 cm margin >> float rounding), so the result is unchanged.
+            const float kx0 = f_min(ax, bx) - (CAP_R + 0.01f), kx1 = f_max(ax, bx) + (CAP_R + 0.01f);
+            const float kz0 = f_min(az, bz) - (CAP_R + 0.01f), kz1 = f_max(az, bz) + (CAP_R + 0.01f);
+            for (int base = w0; base < w1; base += 32) {
+                const int nq = (w1 - base) < 32 ? (w1 - base) : 32;
+                uint32_t cand = 0;
+                for (int q = 0; q < nq; q += 4) {
+                    // four independent index -> wall load chains in flight (the LDS round trips, not the arithmetic, are what
+                    // this pass costs); slots past the end re-read the last wall and are masked out
+                    hk_wall_seg ws[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) ws[j] = T.walls[T.grid_idx[base + ((q + j) < nq ? (q + j) : (nq - 1))]];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const bool apart = f_max(ws[j].x0, ws[j].x1) < kx0 || f_min(ws[j].x0, ws[j].x1) > kx1 ||
+                                           f_max(ws[j].z0, ws[j].z1) < kz0 || f_min(ws[j].z0, ws[j].z1) > kz1;
+                        cand |= ((apart || (q + j) >= nq) ? 0u : 1u) << (q + j);
                     }
-                    // grid_idx is ascending per cell, so "first strictly deeper" == the oracle's lowest-index tie break
-                    if (!found || pen > bestpen) { found = true; bestpen = pen; bnx = nx; bnz = nz; }
+                }
+                while (cand) {
+                    const int q = __ffs((int)cand) - 1;
+                    cand &= cand - 1u;
+                    const hk_wall_seg ws = T.walls[T.grid_idx[base + q]];
+                    float c1x, c1z, c2x, c2z;
+                    float d2 = seg_seg_closest(ax, az, bx, bz, ws.x0, ws.z0, ws.x1, ws.z1, c1x, c1z, c2x, c2z);
+                    if (d2 < CAP_R * CAP_R) {
+                        float d = sqrtf(d2);
+                        float pen = CAP_R - d;
+                        float nx, nz;
+                        if (d > 1e-6f) { nx = (c1x - c2x) / d; nz = (c1z - c2z) / d; }
+                        else {
+                            float ex = ws.x1 - ws.x0, ez = ws.z1 - ws.z0;
+                            float el = sqrtf(ex * ex + ez * ez);
+                            nx = -ez / el; nz = ex / el;
+                            if ((px - ws.x0) * nx + (pz - ws.z0) * nz < 0.0f) { nx = -nx; nz = -nz; }
+                        }
+                        // grid_idx is ascending per cell, so "first strictly deeper" == the oracle's lowest-index tie break
+                        if (!found || pen > bestpen) { found = true; bestpen = pen; bnx = nx; bnz = nz; }
+                    }
                 }
             }
             if (!found) break;

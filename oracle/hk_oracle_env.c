@@ -78,17 +78,21 @@ static float max_speed_for_state(const hko_env* e, const hk_agent_state* a)
 }
 
 /* ------------------------------------------------------------------ analytic Physics.Raycast */
-/* ray (o, unit d) vs one wall segment: returns t >= 0 (distance) or -1 */
+/* ray (o, unit d) vs one wall segment: returns t >= 0 (distance) or -1.  With e = p1 - p0, w = p0 - o:
+ *   den = d x e,  s = (w x d) / den (position along the segment),  t = (w x e) / den (distance along the ray).
+ * The crossing test 0 <= s <= 1, t >= 0 is made on the cross products themselves (signs and |s-numerator| <= |den|), so no
+ * rounded quotient is compared; only the distance of an actual hit is divided.  (This is our own restatement of
+ * Physics.Raycast against a wall slice — DESIGN.md section 4 — and the kernels use exactly the same expressions.) */
 static inline float ray_seg(float ox, float oz, float dx, float dz, const hk_wall_seg* w)
 {
     float ex = w->x1 - w->x0, ez = w->z1 - w->z0;
     float den = dx * ez - dz * ex;
-    if (den == 0.0f) return -1.0f;
     float wx = w->x0 - ox, wz = w->z0 - oz;
-    float t = (wx * ez - wz * ex) / den;
-    float s = (wx * dz - wz * dx) / den;
-    if (t >= 0.0f && s >= 0.0f && s <= 1.0f) return t;
-    return -1.0f;
+    float tn = wx * ez - wz * ex;
+    float sn = wx * dz - wz * dx;
+    int hit = den > 0.0f ? (sn >= 0.0f && sn <= den && tn >= 0.0f) : (den < 0.0f && sn <= 0.0f && sn >= den && tn <= 0.0f);
+    if (!hit) return -1.0f;
+    return tn / den;
 }
 
 /* Physics.Raycast(origin, dir, maxDistance, TrackMask, Ignore triggers): nearest wall hit within maxdist, else -1 */
