@@ -48,10 +48,13 @@ struct EnvParams {
     int debug;
     // the read-only track tables live in ONE packed buffer (16-B aligned segments); kernels copy it to LDS
     const unsigned char* tab;   // packed tables in global memory
-    int tab_bytes, o_walls, o_goff, o_gidx, o_cut;
+    int tab_bytes, o_walls, o_goff, o_gidx, o_cut, o_tmask;
     // uniform grid over the walls' bounding box: cell (ix, iz) lists every wall segment within GRID_REACH of the cell
     float grid_x0, grid_z0, grid_inv;   // origin and 1 / cell size
     int grid_nx, grid_nz;
+    // coarse grid over the same box: per TRIG_CELL x TRIG_CELL cell a 64-bit mask of the section Triggers a kart in that cell can overlap
+    float tgrid_x0, tgrid_z0, tgrid_inv;      // its box contains every Trigger centre
+    int tgrid_nx, tgrid_nz;
     const int* perms;      // [A!][A]
     // MCTS planner (hk_env_mcts.h)
     const SecGeo* sec_geo; // [L]
@@ -101,6 +104,8 @@ struct RwDev {
                                // (0 nothing, 1 wall, 2 + j agent j); replayed by reward_hits_kernel
 };
 
+constexpr float TRIG_CELL = 8.0f;       // coarse cell of the Trigger candidate masks
+constexpr float TRIG_REACH = 6.6f;      // a kart overlaps a Trigger only within 6.5 m of its centre (box half diagonal 5.03 + capsule reach 1.11)
 constexpr float GRID_CELL = 2.0f;       // cell size (m)
 constexpr float GRID_REACH = 2.2f;      // list radius: 2 m side rays / 1 m half-spacing of the long-ray samples / 1.11 m
                                         // contact reach, plus slack for float rounding of the cell index
@@ -112,6 +117,7 @@ struct TabView {
     const unsigned short* grid_off;   // [nx*nz + 1] candidate wall segments per grid cell (ascending wall index)
     const unsigned short* grid_idx;
     const unsigned char* cut;     // [L][5][5]: does the ray lane marker -> next lane marker hit a wall (HKA:832)
+    const uint2* tmask;           // [tgrid_nx * tgrid_nz] Trigger candidates per coarse cell (bit t = section t)
 };
 __host__ __device__ inline TabView tab_view(const EnvParams& P, const unsigned char* base)
 {
@@ -121,6 +127,7 @@ __host__ __device__ inline TabView tab_view(const EnvParams& P, const unsigned c
     T.grid_off = reinterpret_cast<const unsigned short*>(base + P.o_goff);
     T.grid_idx = reinterpret_cast<const unsigned short*>(base + P.o_gidx);
     T.cut = base + P.o_cut;
+    T.tmask = reinterpret_cast<const uint2*>(base + P.o_tmask);
     return T;
 }
 // copy the packed tables into dynamic LDS (all threads of the block), or fall back to global memory when the launch
@@ -183,6 +190,17 @@ __device__ __forceinline__ int grid_cell(const EnvParams& P, float x, float z)
     ix = ix < 0 ? 0 : (ix >= P.grid_nx ? P.grid_nx - 1 : ix);
     iz = iz < 0 ? 0 : (iz >= P.grid_nz ? P.grid_nz - 1 : iz);
     return iz * P.grid_nx + ix;
+}
+
+// Triggers a kart at (x, z) can overlap: every Trigger within TRIG_REACH of the kart's coarse cell (a superset of those within
+// 6.5 m of the kart; a position outside the grid's box clamps to the border cell, and since every Trigger centre lies inside
+// the box the clamped point is nearer to each of them than the kart is)
+__device__ __forceinline__ uint2 trig_candidates(const EnvParams& P, const TabView& T, float x, float z)
+{
+    int ix = (int)((x - P.tgrid_x0) * P.tgrid_inv), iz = (int)((z - P.tgrid_z0) * P.tgrid_inv);
+    ix = ix < 0 ? 0 : (ix >= P.tgrid_nx ? P.tgrid_nx - 1 : ix);
+    iz = iz < 0 ? 0 : (iz >= P.tgrid_nz ? P.tgrid_nz - 1 : iz);
+    return T.tmask[iz * P.tgrid_nx + ix];
 }
 
 // ------------------------------------------------------------------ analytic Physics.Raycast pieces

@@ -270,6 +270,31 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         P.o_goff = seg(goff.data(), goff.size() * sizeof(unsigned short));
         P.o_gidx = seg(gidx.data(), gidx.size() * sizeof(unsigned short));
         P.o_cut = seg(cut.data(), cut.size());
+        {   // Trigger candidate masks over a coarse grid whose box holds the wall grid and every Trigger centre
+            double bx0 = P.grid_x0, bz0 = P.grid_z0, bx1 = P.grid_x0 + P.grid_nx * (double)GRID_CELL, bz1 = P.grid_z0 + P.grid_nz * (double)GRID_CELL;
+            for (int t = 0; t < L; t++) {
+                bx0 = std::min(bx0, (double)sections[t].trig_x - 1.0); bx1 = std::max(bx1, (double)sections[t].trig_x + 1.0);
+                bz0 = std::min(bz0, (double)sections[t].trig_z - 1.0); bz1 = std::max(bz1, (double)sections[t].trig_z + 1.0);
+            }
+            P.tgrid_x0 = (float)std::floor(bx0); P.tgrid_z0 = (float)std::floor(bz0);
+            P.tgrid_inv = 1.0f / TRIG_CELL;
+            P.tgrid_nx = (int)std::ceil((bx1 - P.tgrid_x0) / TRIG_CELL) + 1;
+            P.tgrid_nz = (int)std::ceil((bz1 - P.tgrid_z0) / TRIG_CELL) + 1;
+            if ((long long)P.tgrid_nx * P.tgrid_nz > 65536) { err = "hk_create: track too large for the Trigger grid"; return HK_ERR_UNSUPPORTED; }
+            std::vector<uint32_t> tm((size_t)P.tgrid_nx * P.tgrid_nz * 2, 0u);
+            for (int iz = 0; iz < P.tgrid_nz; iz++)
+                for (int ix = 0; ix < P.tgrid_nx; ix++) {
+                    // 0.25 m slack on the cell rectangle for the float rounding of the cell index
+                    const double cx0 = P.tgrid_x0 + ix * (double)TRIG_CELL - 0.25, cz0 = P.tgrid_z0 + iz * (double)TRIG_CELL - 0.25;
+                    const double cx1 = cx0 + TRIG_CELL + 0.5, cz1 = cz0 + TRIG_CELL + 0.5;
+                    for (int t = 0; t < L; t++) {
+                        const double tx = sections[t].trig_x, tz = sections[t].trig_z;
+                        const double ddx = tx < cx0 ? cx0 - tx : (tx > cx1 ? tx - cx1 : 0.0), ddz = tz < cz0 ? cz0 - tz : (tz > cz1 ? tz - cz1 : 0.0);
+                        if (ddx * ddx + ddz * ddz <= (double)TRIG_REACH * TRIG_REACH) tm[((size_t)iz * P.tgrid_nx + ix) * 2 + (t >> 5)] |= 1u << (t & 31);
+                    }
+                }
+            P.o_tmask = seg(tm.data(), tm.size() * sizeof(uint32_t));
+        }
         pk.resize((pk.size() + 15) & ~size_t(15));
         P.tab_bytes = (int)pk.size();
         int rc0;

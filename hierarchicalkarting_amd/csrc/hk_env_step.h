@@ -485,25 +485,36 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
         float ax, az, bx, bz;
         kart_core(cfx, cfz, px, pz, ax, az, bx, bz);
         uint32_t lo = 0, hi = 0;
-        for (int t = 0; t < P.L; t++) {
-            const SecDev& s = T.sec[t];
-            // exact cull: box half diagonal 5.03 + capsule reach 1.11 < 6.5
-            if ((px - s.trig_x) * (px - s.trig_x) + (pz - s.trig_z) * (pz - s.trig_z) > 6.5f * 6.5f) continue;
-            float rax = ax - s.trig_x, raz = az - s.trig_z, rbx = bx - s.trig_x, rbz = bz - s.trig_z;
-            float lax = rax * s.fz - raz * s.fx, laz = rax * s.fx + raz * s.fz;
-            float lbx = rbx * s.fz - rbz * s.fx, lbz = rbx * s.fx + rbz * s.fz;
-            float zlo = f_min(laz, lbz) - CAP_R, zhi = f_max(laz, lbz) + CAP_R;
-            float xlo = f_min(lax, lbx) - CAP_R, xhi = f_max(lax, lbx) + CAP_R;
-            if (zlo <= TRIG_HZ && zhi >= -TRIG_HZ && xlo <= TRIG_HX && xhi >= -TRIG_HX) {
-                if (t < 32) lo |= 1u << t; else hi |= 1u << (t - 32);
+        // only the Triggers listed for the kart's coarse cell can be within reach (the others fail the distance cull below
+        // by construction): a couple of trips instead of one per section, each a dependent LDS round trip
+        const uint2 tc = trig_candidates(P, T, px, pz);
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            uint32_t bits = half ? tc.y : tc.x;
+            while (bits) {
+                const int t = (__ffs((int)bits) - 1) + 32 * half;
+                bits &= bits - 1u;
+                const SecDev& s = T.sec[t];
+                // exact cull: box half diagonal 5.03 + capsule reach 1.11 < 6.5
+                if ((px - s.trig_x) * (px - s.trig_x) + (pz - s.trig_z) * (pz - s.trig_z) > 6.5f * 6.5f) continue;
+                float rax = ax - s.trig_x, raz = az - s.trig_z, rbx = bx - s.trig_x, rbz = bz - s.trig_z;
+                float lax = rax * s.fz - raz * s.fx, laz = rax * s.fx + raz * s.fz;
+                float lbx = rbx * s.fz - rbz * s.fx, lbz = rbx * s.fx + rbz * s.fz;
+                float zlo = f_min(laz, lbz) - CAP_R, zhi = f_max(laz, lbz) + CAP_R;
+                float xlo = f_min(lax, lbx) - CAP_R, xhi = f_max(lax, lbx) + CAP_R;
+                if (zlo <= TRIG_HZ && zhi >= -TRIG_HZ && xlo <= TRIG_HX && xhi >= -TRIG_HX) {
+                    if (t < 32) lo |= 1u << t; else hi |= 1u << (t - 32);
+                }
             }
         }
         const uint32_t nlo = lo & ~h.trig_lo, nhi = hi & ~h.trig_hi;
         h.trig_lo = lo; h.trig_hi = hi;
         if (nlo | nhi) {
-            for (int t = 0; t < P.L; t++) {
-                const bool ent = t < 32 ? ((nlo >> t) & 1u) : ((nhi >> (t - 32)) & 1u);
-                if (!ent || !(fl & HK_F_ACTIVE)) continue;
+            uint32_t elo = nlo, ehi = nhi;
+            while (elo | ehi) {                                        // newly entered Triggers in section order
+                int t;
+                if (elo) { t = __ffs((int)elo) - 1; elo &= elo - 1u; } else { t = (__ffs((int)ehi) - 1) + 32; ehi &= ehi - 1u; }
+                if (!(fl & HK_F_ACTIVE)) continue;
                 const int L = P.L, H = P.H;
                 const int sec = h.section_index, init = h.init_checkpoint_index;
                 int index = -1, lane = -1;
