@@ -9,6 +9,7 @@
 #if !defined(HK_GA) || !defined(HK_GA_NS)
 #error "hk_env_ga.h needs HK_GA and HK_GA_NS"
 #endif
+#include <utility>
 #include "hk_env_device.h"
 #include "hk_lq_core.h"
 
@@ -21,6 +22,19 @@ static_assert(GA == 4 || GA == 8, "lane groups of 4 or 8");
 __device__ __forceinline__ float quad_get(float v, int q) { return __shfl(v, (threadIdx.x & ~(GA - 1)) | q, 64); }
 __device__ __forceinline__ uint32_t quad_get(uint32_t v, int q) { return (uint32_t)__shfl((int)v, (threadIdx.x & ~(GA - 1)) | q, 64); }
 __device__ __forceinline__ int quad_get(int v, int q) { return __shfl(v, (threadIdx.x & ~(GA - 1)) | q, 64); }
+// The same with a compile-time lane: for a quad this is one DPP move (quad_perm [J, J, J, J]) instead of a ds_bpermute round
+// trip through the LDS crossbar — the per-tick kart-vs-kart loops broadcast a dozen values per kart.  Every lane of the group
+// must be active (the callers are group-uniform); an 8-lane group has no single-instruction broadcast and keeps the shuffle.
+template <int J> __device__ __forceinline__ int group_get(int v)
+{
+    if constexpr (GA == 4) return __builtin_amdgcn_update_dpp(0, v, J * 0x55, 0xF, 0xF, true);
+    else return __shfl(v, (threadIdx.x & ~(GA - 1)) | J, 64);
+}
+template <int J> __device__ __forceinline__ uint32_t group_get(uint32_t v) { return (uint32_t)group_get<J>((int)v); }
+template <int J> __device__ __forceinline__ float group_get(float v) { return __builtin_bit_cast(float, group_get<J>(__builtin_bit_cast(int, v))); }
+// f(std::integral_constant<int, j>) for j = 0 .. GA - 1, unrolled
+template <class F, int... Js> __device__ __forceinline__ void for_lanes_impl(F&& f, std::integer_sequence<int, Js...>) { (f(std::integral_constant<int, Js>{}), ...); }
+template <class F> __device__ __forceinline__ void for_each_lane(F&& f) { for_lanes_impl(f, std::make_integer_sequence<int, GA>{}); }
 // OR over the lanes of the group (every lane gets the result)
 __device__ __forceinline__ int group_or(int v)
 {

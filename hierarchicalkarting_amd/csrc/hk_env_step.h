@@ -212,19 +212,20 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
         float ddx[3], ddz[3];
 #pragma unroll
         for (int q = 0; q < 3; q++) sensor_dir(P, csens[q], fx, fz, ddx[q], ddz[q]);
-        for (int j = 0; j < GA; j++) {
-            const float jpx = quad_get(px, j), jpz = quad_get(pz, j), jfx = quad_get(fx, j), jfz = quad_get(fz, j);
-            const uint32_t jfl = quad_get(fl, j);
-            if (j >= P.A || j == i || !(jfl & HK_F_ENABLED)) continue;
+        for_each_lane([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const float jpx = group_get<j>(px), jpz = group_get<j>(pz), jfx = group_get<j>(fx), jfz = group_get<j>(fz);
+            const uint32_t jfl = group_get<j>(fl);
+            if (j >= P.A || j == i || !(jfl & HK_F_ENABLED)) return;
             // exact cull: a 0.9 m ray from 0.1 m ahead of this kart cannot reach a capsule whose origin is > 2.2 m away
             // (0.1 + 0.9 + core half length 0.657 + slice radius 0.4425 = 2.10)
-            if ((jpx - px) * (jpx - px) + (jpz - pz) * (jpz - pz) > 2.2f * 2.2f) continue;
+            if ((jpx - px) * (jpx - px) + (jpz - pz) * (jpz - pz) > 2.2f * 2.2f) return;
 #pragma unroll
             for (int q = 0; q < 3; q++) {
                 float t = ray_stadium(ox, oz, ddx[q], ddz[q], jpx, jpz, jfx, jfz, P.ray_agent_r);
                 if (t >= 0.0f && t <= clen[q]) hitAgent = true;
             }
-        }
+        });
     }
     if (me && !skip) {
         if (fl & HK_F_ENABLED) {
@@ -378,13 +379,14 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
         kart_core(cfx, cfz, px, pz, ax, az, bx, bz);
         float cpx = 0, cpz = 0, cvx = 0, cvz = 0;
         bool touched = false;
-        for (int j = 0; j < GA; j++) {
-            const float jpx = quad_get(px, j), jpz = quad_get(pz, j), jfx = quad_get(cfx, j), jfz = quad_get(cfz, j);
-            const float jvx = quad_get(vx, j), jvz = quad_get(vz, j);
-            const uint32_t jfl = quad_get(fl, j);
-            if (j >= P.A || j == i || !enabled || !(jfl & HK_F_ENABLED)) continue;
+        for_each_lane([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const float jpx = group_get<j>(px), jpz = group_get<j>(pz), jfx = group_get<j>(cfx), jfz = group_get<j>(cfz);
+            const float jvx = group_get<j>(vx), jvz = group_get<j>(vz);
+            const uint32_t jfl = group_get<j>(fl);
+            if (j >= P.A || j == i || !enabled || !(jfl & HK_F_ENABLED)) return;
             // exact cull: two capsules (reach 0.657 + 0.45 from their origins) cannot touch when the origins are > 2.3 m apart
-            if ((jpx - px) * (jpx - px) + (jpz - pz) * (jpz - pz) > 2.3f * 2.3f) continue;
+            if ((jpx - px) * (jpx - px) + (jpz - pz) * (jpz - pz) > 2.3f * 2.3f) return;
             float cx, cz, dx, dz, c1x, c1z, c2x, c2z;
             kart_core(jfx, jfz, jpx, jpz, cx, cz, dx, dz);
             float d2 = seg_seg_closest(ax, az, bx, bz, cx, cz, dx, dz, c1x, c1z, c2x, c2z);
@@ -405,7 +407,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                 if (vrel < 0.0f) { cvx -= nx * (vrel * share); cvz -= nz * (vrel * share); }
                 touched = true;
             }
-        }
+        });
         if (live) {
             if (touched && (fl & HK_F_CAN_MOVE)) { px += cpx; pz += cpz; vx += cvx; vz += cvz; }
             if (touched) fl |= HK_F_HAS_COLLISION; else fl &= ~HK_F_HAS_COLLISION;
