@@ -300,64 +300,59 @@ __device__ __forceinline__ void assemble_player(const EnvParams& P, const TabVie
         double target[4];
         target[0] = lx; target[1] = lz;
         target[2] = (speed <= 5.0f) ? 0.0f : vel;                                     // :810-817
-        double fth;
+        // The 7-branch heading heuristic (:819-926; table in SURVEY 8 a4).  The lanes of a wave sit in different branches, and a
+        // wave executes every branch any of its lanes takes: written branch by branch (as the C# is) it paid for up to five
+        // atan2 and nine AngleDifference evaluations (all fp64) per player.  Here the branch is decided first with cheap tests,
+        // then each transcendental is evaluated ONCE on branch-selected arguments: atan2(L - p), atan2(C - p), one more atan2
+        // (B4: N - p, B5: N - L), one inner AngleDifference (B2, B5) and the final one.  Every lane computes exactly the values
+        // its own branch computed before (same functions, same arguments, same operation order), so nothing changes numerically.
+        const float h1raw = hk_atan2f(lz - kk.pz, lx - kk.px);                        // :821 targetHeading, :827 heading1
+        float h1w = h1raw;
+        if (h1w < 0) h1w += TWO_PI_F;
+        const float h5raw = hk_atan2f(cz - kk.pz, cx - kk.px);                        // heading5 (:831), B6's heading (:909)
+        float h5w = h5raw;
+        if (h5w < 0) h5w += TWO_PI_F;
         int branch;
-        float targetHeading = hk_atan2f(lz - kk.pz, lx - kk.px);                      // :821
-        if (targetHeading < 0) targetHeading += TWO_PI_F;
         if (mag3(lx - kk.px, dy, lz - kk.pz) <= (kk.straight ? 10.5f : 7.5f)) {       // :823
-            float h1 = hk_atan2f(lz - kk.pz, lx - kk.px);
-            float h5 = hk_atan2f(cz - kk.pz, cx - kk.px);
             const bool cutTrack = T.cut[(idx * 5 + laneSel) * 5 + nextSel] != 0;      // :832 (static geometry)
             const bool hit0 = kk.ray[0] <= speed * 0.5f;                              // :834
             const bool side = (kk.ray[1] <= 2.0f) || (kk.ray[2] <= 1.5f) || (kk.ray[3] <= 1.5f) || (kk.ray[4] <= 2.0f);
             const float dC = kk.dC;
-            if (cutTrack && dC > 4.0f) {                                              // B1 :846
-                branch = 1;
-                if (h5 < 0) h5 += TWO_PI_F;
-                fth = h5;
-                if (fth < 0) fth += TWO_PI_F;
-                fth = initial[3] - angle_difference(initial[3], fth);
-            } else if ((side && (f_sign(h1) == f_sign(h5))) || hit0) {                // B2 :857 (Q12)
-                branch = 2;
-                if (h5 < 0) h5 += TWO_PI_F;
-                fth = h5 - angle_difference(h1, h5) * 0.7f;
-                if (fth < 0) fth += TWO_PI_F;
-                fth = initial[3] - angle_difference(initial[3], fth);
-            } else if (side && (f_sign(h1) != f_sign(h5))) {                          // B3 :867
-                branch = 3;
-                if (h5 < 0) h5 += TWO_PI_F;
-                fth = h5;
-                if (fth < 0) fth += TWO_PI_F;
-                fth = initial[3] - angle_difference(initial[3], fth);
-            } else if (dC <= 4.0f) {                                                  // B4 :876
-                branch = 4;
-                float h6 = hk_atan2f(nz - kk.pz, nx - kk.px);
-                target[0] = nx; target[1] = nz;
-                if (speed > 5.0f) target[2] = nextVel;
-                if (h6 < 0) h6 += TWO_PI_F;
-                fth = h6;
-                if (fth < 0) fth += TWO_PI_F;
-                fth = initial[3] - angle_difference(initial[3], fth);
-            } else {                                                                  // B5 :891
-                branch = 5;
-                float h2 = hk_atan2f(nz - lz, nx - lx);
-                if (h1 < 0) h1 += TWO_PI_F;
-                if (h2 < 0) h2 += TWO_PI_F;
-                fth = h1 - angle_difference(h2, h1) * 0.4f;
-                if (fth < 0) fth += TWO_PI_F;
-                fth = initial[3] - angle_difference(initial[3], fth);
-            }
+            if (cutTrack && dC > 4.0f) branch = 1;                                    // :846
+            else if ((side && (f_sign(h1raw) == f_sign(h5raw))) || hit0) branch = 2;  // :857 (Q12: signs of the un-wrapped values)
+            else if (side && (f_sign(h1raw) != f_sign(h5raw))) branch = 3;            // :867
+            else if (dC <= 4.0f) branch = 4;                                          // :876
+            else branch = 5;                                                          // :891
         } else {
-            const bool hit = kk.ray[0] <= (kk.straight ? 8.0f : 5.0f);                // :906
-            if (hit) {                                                                // B6
-                branch = 6;
-                float h1 = hk_atan2f(cz - kk.pz, cx - kk.px);
-                if (h1 < 0) h1 += TWO_PI_F;
-                fth = initial[3] - angle_difference(initial[3], h1) * 0.85f;
-            } else {                                                                  // B7
-                branch = 7;
-                fth = initial[3] - angle_difference(initial[3], targetHeading);
-            }
+            branch = (kk.ray[0] <= (kk.straight ? 8.0f : 5.0f)) ? 6 : 7;              // :906
+        }
+        float h3w = 0.0f;                                                             // B4: heading6 = atan2(N - p) :878;  B5: heading2 = atan2(N - L) :893
+        if (branch == 4 || branch == 5) {
+            const float ay = branch == 4 ? nz - kk.pz : nz - lz;
+            const float ax = branch == 4 ? nx - kk.px : nx - lx;
+            h3w = hk_atan2f(ay, ax);
+            if (h3w < 0) h3w += TWO_PI_F;
+        }
+        double inner = 0.0;                                                           // B2: AD(heading1, heading5) :860;  B5: AD(heading2, heading1) :898
+        if (branch == 2 || branch == 5) {
+            const double pa = branch == 2 ? (double)h1raw : (double)h3w;
+            const double qa = branch == 2 ? (double)h5w : (double)h1w;
+            inner = angle_difference(pa, qa);
+        }
+        double fth;
+        if (branch == 2) fth = h5w - inner * 0.7f;
+        else if (branch == 5) fth = h1w - inner * 0.4f;
+        else if (branch == 4) fth = h3w;
+        else if (branch == 7) fth = h1w;
+        else fth = h5w;                                                               // B1, B3, B6
+        if (branch == 4) {
+            target[0] = nx; target[1] = nz;
+            if (speed > 5.0f) target[2] = nextVel;
+        }
+        if (fth < 0) fth += TWO_PI_F;                                                 // (B6 / B7 values are already in [0, 2 pi))
+        {
+            const double ad = angle_difference(initial[3], fth);
+            fth = initial[3] - (branch == 6 ? ad * 0.85f : ad);                       // :852,862,872,887,900,921 / :918
         }
         target[3] = fth;                                                              // :926
         double tw[4];                                                                 // :930-964
