@@ -144,14 +144,14 @@ HK_HD double hk_atan2(double y, double x)
     const double PI_HI = 3.1415926535897931, PI_LO = 1.2246467991473532e-16;
     const double PIO2_HI = 1.5707963267948966, PIO2_LO = 6.123233995736766e-17;
     double ax = hk_fabs(x), ay = hk_fabs(y);
-    double r;
-    if (ax == 0.0 && ay == 0.0) {
-        r = 0.0;
-    } else if (ay <= ax) {
-        r = hk__atan01(ay / ax);
-    } else {
-        r = (PIO2_HI - hk__atan01(ax / ay)) + PIO2_LO;
-    }
+    /* one evaluation of atan01 on min / max (on a GPU the lanes of a wave sit on both sides of the diagonal: written as two
+       branches, both were executed, divisions included); atan2(0, 0): 0 / 1 -> atan01(0) = 0 */
+    const int lower = ay <= ax;                       /* below the diagonal: atan(ay / ax), else pi/2 - atan(ax / ay) */
+    const double num = lower ? ay : ax;
+    double dnm = lower ? ax : ay;
+    if (dnm == 0.0) dnm = 1.0;
+    const double a = hk__atan01(num / dnm);
+    double r = lower ? a : (PIO2_HI - a) + PIO2_LO;
     if (x < 0.0) r = (PI_HI - r) + PI_LO;
     return y < 0.0 ? -r : r;
 }
