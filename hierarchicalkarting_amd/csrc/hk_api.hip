@@ -320,7 +320,21 @@ int hk_set_actions(hk_handle h, const float* steer, const int32_t* branch)
 // n_ticks of every env: arm, rounds of {fused tick kernel, queued multi-player solves}, check
 static int step_ticks(hk_handle h, int n_ticks)
 {
-    int rc = hk::env_launch_arm(h->dev, h->cfg, n_ticks, h->stream, h->err);
+    int rc;
+    // Planner searches: a launch of the search kernel lasts as long as one search however few it holds, so requests are
+    // batched.  A long call launches them every MCTS_FLUSH_ROUNDS rounds and once more before it returns; short calls (a
+    // Unity host stepping tick by tick, or the chunks between two RL decisions) share ONE launch until MCTS_DEFER_TICKS
+    // ticks have been armed since the last one — early enough, because a plan is due > MCTS_MIN_LATENCY ticks after its
+    // request.  (hk_get_mcts_state launches what is pending before it reads.)
+    const bool planner = h->dev.mcts.st != nullptr;
+    const bool short_call = planner && n_ticks <= hk::MCTS_DEFER_TICKS;
+    if (planner && h->dev.mcts_ticks > 0 && (!short_call || h->dev.mcts_ticks + n_ticks > hk::MCTS_DEFER_TICKS)) {
+        rc = hk::env_flush_mcts(h->dev, h->stream, h->err);
+        if (rc) { g_last_error = h->err; return rc; }
+    }
+    if (short_call) h->dev.mcts_ticks += n_ticks;
+    h->dev.mcts_defer = short_call;
+    rc = hk::env_launch_arm(h->dev, h->cfg, n_ticks, h->stream, h->err);
     if (rc) { g_last_error = h->err; return rc; }
     const int rounds = hk::env_rounds_for(h->cfg, n_ticks);
     for (int r = 0; r < rounds; r++) {
@@ -334,9 +348,11 @@ static int step_ticks(hk_handle h, int n_ticks)
         if (rc) { g_last_error = h->err; return rc; }
         h->prof.end(1, e, h->stream);
     }
-    // planner searches requested in the last rounds run before hk_step returns (the next call may be far away in ticks)
-    rc = hk::env_flush_mcts(h->dev, h->stream, h->err);
-    if (rc) { g_last_error = h->err; return rc; }
+    if (planner && !short_call) {
+        // searches requested in the last rounds of a long call run before it returns
+        rc = hk::env_flush_mcts(h->dev, h->stream, h->err);
+        if (rc) { g_last_error = h->err; return rc; }
+    }
     rc = hk::env_launch_check(h->dev, h->cfg, h->stream, h->err);
     if (rc) { g_last_error = h->err; return rc; }
     return HK_OK;
@@ -620,6 +636,10 @@ int hk_get_mcts_state(hk_handle h, hk_mcts_state* out)
     { int rc = check_device_status(h); if (rc) return rc; }
     const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
     if (!h->dev.mcts.st) { std::memset(out, 0, cnt * sizeof(hk_mcts_state)); return HK_OK; }
+    if (h->dev.mcts_ticks > 0) {          // searches deferred by short hk_step calls: `pend` must be there when the host looks
+        int rc = hk::env_flush_mcts(h->dev, h->stream, h->err);
+        if (rc) { g_last_error = h->err; return rc; }
+    }
     HK_HIP(h, hipMemcpyAsync(out, h->dev.mcts.st, cnt * sizeof(hk_mcts_state), hipMemcpyDeviceToHost, h->stream));
     HK_HIP(h, hipStreamSynchronize(h->stream));
     return HK_OK;

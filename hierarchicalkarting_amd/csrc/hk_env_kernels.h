@@ -38,6 +38,8 @@ struct EnvDevice {
     RwDev rw{};                    // reward shaping tables (null when hk_config.rewards == 0)
     int mset = 0;                  // planner queue set the tick kernel currently fills
     int mcts_rounds = 0;           // rounds of the tick kernel since the last search launch
+    int mcts_ticks = 0;            // ticks armed by short hk_step calls since the last search launch (see step_ticks)
+    bool mcts_defer = false;       // the current hk_step call is short: its rounds do not launch searches themselves
     SecGeo* sec_geo = nullptr;
     EnvParams P{};
 };
@@ -45,6 +47,8 @@ struct EnvDevice {
 constexpr int MCTS_MIN_LATENCY = 40;   // (MCTS_FLUSH_ROUNDS + 1) * RUN_CAP: see flush_mcts (hk_env_launch.h)
 constexpr int MCTS_FLUSH_ROUNDS = 4;
 constexpr int MCTS_ARENA_WAVES = 2048;
+constexpr int MCTS_DEFER_TICKS = 32;   // short hk_step calls share one search launch until this many ticks have been armed
+static_assert(MCTS_DEFER_TICKS < MCTS_MIN_LATENCY, "a deferred search must still finish before its plan is due");
 static_assert((MCTS_FLUSH_ROUNDS + 1) * RUN_CAP <= MCTS_MIN_LATENCY, "a queued search must finish before its plan is due");
 
 inline int launch_check(std::string& err, const char* what)

@@ -28,6 +28,7 @@ inline int flush_mcts(EnvDevice& d, hipStream_t stream, std::string& err)
     if (rc) return rc;
     d.mset ^= 1;
     d.mcts_rounds = 0;
+    d.mcts_ticks = 0;
     if (hipMemsetAsync(d.mcts.qcnt + d.mset * 2, 0, 2 * sizeof(int), stream) != hipSuccess) { err = "mcts queue memset"; return HK_ERR_HIP; }
     return HK_OK;
 }
@@ -64,7 +65,7 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
 {
     const int ngames = cfg.num_envs * cfg.num_agents;
     const int set = d.round & 1;
-    if (d.mcts.st && ++d.mcts_rounds >= MCTS_FLUSH_ROUNDS) { int rcm = flush_mcts(d, stream, err); if (rcm) return rcm; }
+    if (d.mcts.st && !d.mcts_defer && ++d.mcts_rounds >= MCTS_FLUSH_ROUNDS) { int rcm = flush_mcts(d, stream, err); if (rcm) return rcm; }
     const int* qc = d.queue_cnt + set * 16;
     const int* qu = d.queue + (size_t)set * queue_ints_per_set((size_t)ngames);
     int rc = HK_OK;

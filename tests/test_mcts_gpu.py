@@ -74,3 +74,25 @@ def test_create_rejects_bad_planner_budgets():
     for kw in (dict(mcts_latency_ticks=4), dict(mcts_latency_ticks=120), dict(mcts_iterations=0), dict(tree_search_depth=[9, 5])):
         with pytest.raises(hk.HkError):
             hk.RacingEnv(hk.make_config(2, 2, high_mode=[MC, FX], **{**dict(tree_search_depth=[8, 5]), **kw}))
+
+
+def test_tick_by_tick_stepping_defers_but_never_misses_a_plan():
+    """A host that steps one tick per call (Unity's FixedUpdate) or in small uneven chunks: the searches are batched over up to
+    32 armed ticks, yet every plan is there when it is due — records, plans and beliefs equal the oracle's all the way."""
+    import hierarchicalkarting_amd as hk
+    b = hk.make_config(6, 4, track="complex", jitter_seed=21, high_mode=_lib.HK_HIGH_MCTS, tree_search_depth=4, mcts_iterations=10,
+                       mcts_latency_ticks=41, mcts_initial_latency_ticks=41)
+    g = hk.RacingEnv(b); o = O.OracleEnv(b)
+    g.reset(); o.reset()
+    t = 0
+    chunks = [1] * 130 + [3, 7, 31, 2, 32, 33, 1, 1, 30, 5, 64, 1] + [1] * 60
+    for k, n in enumerate(chunks):
+        g.step(n); o.step(n); t += n
+        if k % 9 == 0 or n > 1:
+            gs, os_ = g.agent_state(), o.agent_state()
+            for name in gs.dtype.names:
+                assert np.array_equal(gs[name], os_[name]), (t, name)
+    gm, om = g.mcts_state(), o.mcts_state()
+    for name in gm.dtype.names:
+        assert np.array_equal(gm[name], om[name]), (t, name)
+    assert gm["searches"].min() >= 4
