@@ -41,12 +41,18 @@ struct EnvDevice {
     int mcts_ticks = 0;            // ticks armed by short hk_step calls since the last search launch (see step_ticks)
     bool mcts_defer = false;       // the current hk_step call is short: its rounds do not launch searches themselves
     SecGeo* sec_geo = nullptr;
+    // lane-group -> env assignment of the tick kernel, regrouped by solve phase every REGROUP_ROUNDS rounds (hk_env_run.h)
+    int* perm = nullptr;           // [E]
+    int* perm_counts = nullptr;    // [8]
+    bool perm_valid = false;
+    int rounds_since_regroup = 0;
     EnvParams P{};
 };
 
 constexpr int MCTS_MIN_LATENCY = 40;   // (MCTS_FLUSH_ROUNDS + 1) * RUN_CAP: see flush_mcts (hk_env_launch.h)
 constexpr int MCTS_FLUSH_ROUNDS = 4;
 constexpr int MCTS_ARENA_WAVES = 2048;
+constexpr int REGROUP_ROUNDS = 48;     // the tick kernel's lane groups are re-assigned by solve phase every so many rounds (~200 ticks)
 constexpr int MCTS_DEFER_TICKS = 32;   // short hk_step calls share one search launch until this many ticks have been armed
 static_assert(MCTS_DEFER_TICKS < MCTS_MIN_LATENCY, "a deferred search must still finish before its plan is due");
 static_assert((MCTS_FLUSH_ROUNDS + 1) * RUN_CAP <= MCTS_MIN_LATENCY, "a queued search must finish before its plan is due");
@@ -115,7 +121,7 @@ int upload(T** dst, const std::vector<T>& v, std::string& err)
 inline void env_destroy(EnvDevice& d)
 {
     void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.reward_out, d.status, d.games, d.queue_cnt, d.queue, d.env_ids, d.tab, d.perms,
-                    d.rw.sec_time, d.rw.sec_cnt, d.rw.hit_code, d.mcts.st, d.mcts.req, d.mcts.qcnt, d.mcts.queue, d.mcts.nodes, d.mcts.dt_tab, d.mcts.load_tab, d.mcts.rad_tab, d.sec_geo};
+                    d.rw.sec_time, d.rw.sec_cnt, d.rw.hit_code, d.mcts.st, d.mcts.req, d.mcts.qcnt, d.mcts.queue, d.mcts.nodes, d.mcts.dt_tab, d.mcts.load_tab, d.mcts.rad_tab, d.sec_geo, d.perm, d.perm_counts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = EnvDevice{};
 }
@@ -326,6 +332,8 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     HK_ALLOC(d.status, 4 * sizeof(int));
     HK_ALLOC(d.games, na * HK_GA_CALL(d, game_doubles_per_ego()) * sizeof(double));
     HK_ALLOC(d.queue_cnt, 2 * 16 * sizeof(int));
+    HK_ALLOC(d.perm, (size_t)E * sizeof(int));
+    HK_ALLOC(d.perm_counts, 8 * sizeof(int));
     HK_ALLOC(d.queue, 2 * HK_GA_CALL(d, queue_ints_per_set(na)) * sizeof(int));
     if (cfg.rewards) {
         d.rw.S = cfg.laps * L + 2;
@@ -445,7 +453,15 @@ inline int env_rounds_for(const hk_config& cfg, int n_ticks)
     return (n_ticks + cadence - 1) / cadence + 1 + n_ticks / 32 + 2;
 }
 
-inline int env_launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_run(d, cfg, stream, err)); }
+inline int env_launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
+    if (++d.rounds_since_regroup >= REGROUP_ROUNDS) {
+        d.rounds_since_regroup = 0;
+        int rc = HK_GA_CALL(d, launch_regroup(d, cfg, stream, err));
+        if (rc) return rc;
+    }
+    return HK_GA_CALL(d, launch_run(d, cfg, stream, err));
+}
 inline int env_launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_lqn(d, cfg, stream, err)); }
 inline int env_launch_observe(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_observe(d, cfg, stream, err)); }
 

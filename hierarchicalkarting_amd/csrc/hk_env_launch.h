@@ -43,6 +43,18 @@ inline int launch_reset(EnvDevice& d, const int* dids, int cnt, int experiment_n
     return flush_mcts(d, stream, err);          // the first plans (T = 1.5 s in the reference)
 }
 
+// re-assign the lane groups by solve phase (see env_regroup_count_kernel); only meaningful with the 4-tick cadence
+inline int launch_regroup(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
+    if (cfg.num_agents <= 2 || !d.perm) return HK_OK;
+    const int E = cfg.num_envs;
+    if (hipMemsetAsync(d.perm_counts, 0, 8 * sizeof(int), stream) != hipSuccess) { err = "regroup memset"; return HK_ERR_HIP; }
+    hipLaunchKernelGGL(env_regroup_count_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, d.envs, E, d.perm_counts);
+    hipLaunchKernelGGL(env_regroup_scatter_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, d.envs, E, d.perm_counts, d.perm);
+    d.perm_valid = true;
+    return launch_check(err, "env_regroup kernels");
+}
+
 // one round, part 1: the fused tick kernel (fills queue set round & 1)
 inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
 {
@@ -50,7 +62,7 @@ inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
 #define HK_RUN(MC, RWF, TRN)                                                                                                  \
     hipLaunchKernelGGL((env_run_kernel<MC, RWF, TRN>), dim3((unsigned)((threads + 255) / 256)), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs,   \
                        d.results, GameSoA{d.games, (size_t)cfg.num_envs * cfg.num_agents}, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status,     \
-                       d.tab_lds ? 1 : 0, d.mcts, d.mset, d.rw)
+                       d.tab_lds ? 1 : 0, d.mcts, d.mset, d.rw, d.perm_valid ? d.perm : nullptr)
     bool train = d.P.training_reset != 0;
     for (int i = 0; i < cfg.num_agents; i++) train = train || d.P.training_agent[i] != 0;
     if (train) HK_RUN(true, true, true);

@@ -32,6 +32,31 @@ __global__ __launch_bounds__(256) void env_check_kernel(const hk_env_state* envs
     if (env < E && (envs[env].reserved[0] != 0 || envs[env].reserved[1] != 0)) atomicOr(status, 4);
 }
 
+// Regrouping by solve phase.  SolveLQR runs on ticks with episodeSteps % 4 == 0 (A > 2, Q9): during the first episode every env
+// of a wave is in the same phase, but auto-resets happen at different ticks, and from then on a wave would run the (expensive)
+// solve path for some of its lanes on EVERY tick.  Every few hundred ticks the lane groups are therefore re-assigned so that the
+// envs of a wave share their phase: perm[slot] = env, grouped by key = (episode_steps + ticks still to run) & 3, which does not
+// change while the call runs.  Envs are independent, so which lanes run an env changes nothing but the speed.
+__global__ __launch_bounds__(256) void env_regroup_count_kernel(const hk_env_state* envs, int E, int* counts /*[8]: 4 counts, 4 cursors*/)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int key = env < E ? ((envs[env].episode_steps + envs[env].reserved[0]) & 3) : -1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) (void)wave_agg_inc(&counts[k], key == k);
+}
+__global__ __launch_bounds__(256) void env_regroup_scatter_kernel(const hk_env_state* envs, int E, int* counts, int* perm)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int key = env < E ? ((envs[env].episode_steps + envs[env].reserved[0]) & 3) : -1;
+    const int c0 = counts[0], c1 = counts[1], c2 = counts[2];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int pos = wave_agg_inc(&counts[4 + k], key == k);
+        const int base = k == 0 ? 0 : (k == 1 ? c0 : (k == 2 ? c0 + c1 : c0 + c1 + c2));
+        if (key == k) perm[base + pos] = env;
+    }
+}
+
 // <false, false, false> is the headline path: the planner hooks (request / consume / beliefs), reward shaping and the
 // Training-mode code compile away entirely.  Instantiated: every (HAS_MCTS, HAS_RW) pair without Training code, and
 // <true, true, true> for any handle that uses Training mode (its planner / reward parts are also guarded at run time).
@@ -39,15 +64,16 @@ template <bool HAS_MCTS, bool HAS_RW, bool HAS_TRAIN>
 __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
                                                       hk_episode_result* results, GameSoA games, int* queue_cnt_all,
                                                       int* queue_all, int set, const float* act_steer, const int* act_branch,
-                                                      hk_lq_debug* dbg_out, int* status, int use_lds, MctsDev Marg, int mset, RwDev RD)
+                                                      hk_lq_debug* dbg_out, int* status, int use_lds, MctsDev Marg, int mset, RwDev RD, const int* perm)
 {
     MctsDev M{};
     if (HAS_MCTS) M = Marg;
     __shared__ KartS ks[256];
     extern __shared__ __align__(16) unsigned char smem[];
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int env = gid / GA, i = gid % GA;
-    const bool env_ok = env < P.E;
+    const int slot = gid / GA, i = gid % GA;
+    const bool env_ok = slot < P.E;
+    const int env = (perm && env_ok) ? perm[slot] : slot;     // lane groups are re-assigned by solve phase (env_regroup_*)
     // the game queues are double buffered over rounds: this launch fills `set`, and clears the other one, which the
     // previous round's lqn kernels have finished reading
     int* queue_cnt = queue_cnt_all + set * 16;
