@@ -362,7 +362,10 @@ static int step_ticks(hk_handle h, int n_ticks)
 static int policy_decide(hk_handle h)
 {
     hipEvent_t eo = h->prof.begin(h->stream);
-    int rc = hk::env_launch_observe(h->dev, h->cfg, h->stream, h->err);
+    uint32_t need = 0;                      // only the agents some attached actor drives are observed here
+    for (int p = 0; p < h->n_policies; p++)
+        for (int j = 0; j < h->policy[p].q.n_slots; j++) need |= 1u << h->policy[p].q.slots[j];
+    int rc = hk::env_launch_observe(h->dev, h->cfg, need, h->stream, h->err);
     if (rc) { g_last_error = h->err; return rc; }
     const unsigned long long decision = (unsigned long long)(h->academy_step / h->decision_period);
     const int E = h->cfg.num_envs, A = h->cfg.num_agents;
@@ -490,7 +493,7 @@ int hk_get_observations(hk_handle h, float* obs)
 {
     HK_NEED_ENV(h);
     if (!obs) return fail(h, HK_ERR_INVALID, "hk_get_observations: NULL pointer");
-    int rc = hk::env_launch_observe(h->dev, h->cfg, h->stream, h->err);
+    int rc = hk::env_launch_observe(h->dev, h->cfg, 0xFFFFFFFFu, h->stream, h->err);
     if (rc) { g_last_error = h->err; return rc; }
     const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents * hk_obs_dim(h);
     HK_HIP(h, hipMemcpyAsync(obs, h->dev.obs, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -671,7 +674,7 @@ void* hk_device_group_reward_ptr(hk_handle h)
 int hk_observe(hk_handle h)
 {
     HK_NEED_ENV(h);
-    int rc = hk::env_launch_observe(h->dev, h->cfg, h->stream, h->err);
+    int rc = hk::env_launch_observe(h->dev, h->cfg, 0xFFFFFFFFu, h->stream, h->err);
     if (rc) g_last_error = h->err;
     return rc;
 }

@@ -463,6 +463,7 @@ inline int env_launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream
     return HK_GA_CALL(d, launch_run(d, cfg, stream, err));
 }
 inline int env_launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_lqn(d, cfg, stream, err)); }
-inline int env_launch_observe(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_observe(d, cfg, stream, err)); }
+// agent_mask: the agent slots whose observations are needed (all of them for the host's hk_get_observations / hk_observe)
+inline int env_launch_observe(EnvDevice& d, const hk_config& cfg, uint32_t agent_mask, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_observe(d, cfg, agent_mask, stream, err)); }
 
 }  // namespace hk

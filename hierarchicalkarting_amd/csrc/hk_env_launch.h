@@ -106,10 +106,11 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
     return HK_OK;
 }
 
-inline int launch_observe(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+inline int launch_observe(EnvDevice& d, const hk_config& cfg, uint32_t agent_mask, hipStream_t stream, std::string& err)
 {
     const long long threads = (long long)cfg.num_envs * cfg.num_agents * OBS_LANES;
-    hipLaunchKernelGGL(env_observe_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d.P, d.agents, d.obs, d.rw.hit_code);
+    hipLaunchKernelGGL(env_observe_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d.P, d.agents, d.obs, d.rw.hit_code,
+                       d.rw.hit_code ? 0xFFFFFFFFu : agent_mask);      // the reward replay needs every agent's hit codes
     int rc = launch_check(err, "env_observe_kernel");
     if (rc || !d.rw.hit_code) return rc;
     // CollectObservations raised HitWall / HitOpponent events (HKA:580-598): replayed per env in agent / sensor order

@@ -31,7 +31,8 @@ __device__ inline void inv_transform_point(const hk_agent_state* a, float fx, fl
 // Lane l of the group first evaluates the forward vector of kart l % A (one fp64 sin/cos pair per lane instead of A per
 // agent) and the group shares them by shuffles.
 constexpr int OBS_LANES = 16;
-__global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_agent_state* agents, float* obs, unsigned char* hit_code)
+__global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_agent_state* agents, float* obs, unsigned char* hit_code,
+                                                          uint32_t agent_mask /* bit i: agent slot i is observed */)
 {
     const TabView T = tab_view(P, P.tab);
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_
     float fx = kfx[0], fz = kfz[0];
 #pragma unroll
     for (int j = 1; j < GA; j++) if (i == j) { fx = kfx[j]; fz = kfz[j]; }
-    if (!valid) return;
+    if (!valid || !((agent_mask >> i) & 1u)) return;
     if (l == 14) {                                                           // own block HKA:489-496
         o[0] = local_speed(P, a, fx, fz);
         o[1] = (a->flags & HK_F_ACCEL) ? 1.0f : 0.0f;
