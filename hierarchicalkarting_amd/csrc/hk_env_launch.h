@@ -109,8 +109,8 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
 inline int launch_observe(EnvDevice& d, const hk_config& cfg, uint32_t agent_mask, hipStream_t stream, std::string& err)
 {
     const long long threads = (long long)cfg.num_envs * cfg.num_agents * OBS_LANES;
-    hipLaunchKernelGGL(env_observe_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d.P, d.agents, d.obs, d.rw.hit_code,
-                       d.rw.hit_code ? 0xFFFFFFFFu : agent_mask);      // the reward replay needs every agent's hit codes
+    hipLaunchKernelGGL(env_observe_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), d.tab_lds, stream, d.P, d.agents, d.obs, d.rw.hit_code,
+                       d.rw.hit_code ? 0xFFFFFFFFu : agent_mask, d.tab_lds ? 1 : 0);      // the reward replay needs every agent's hit codes
     int rc = launch_check(err, "env_observe_kernel");
     if (rc || !d.rw.hit_code) return rc;
     // CollectObservations raised HitWall / HitOpponent events (HKA:580-598): replayed per env in agent / sensor order
