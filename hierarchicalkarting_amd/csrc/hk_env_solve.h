@@ -1,13 +1,12 @@
-// hk_env_solve.h — HierarchicalKartAgent.SolveLQR (HKA:699-1236) on gfx950, split in two stages so that each runs
-// at full lane utilisation:
+// hk_env_solve.h — HierarchicalKartAgent.SolveLQR (HKA:699-1236) on gfx950, inside the fused tick kernel (hk_env_run.h):
 //
-//   K_B1 env_assemble_kernel   quad per env, lane = ego.  Sensor rays of the ego's own kart, then the ego's game:
-//                              players within 8 m, per player initial/target/weights and the 7-branch heading heuristic
-//                              (HKA:726-1198).  Writes one compact GameDesc per ego and bins the game by player count.
-//   K_B2 lq1_kernel            one THREAD per single-player game (n = 4, m = 2): the whole Riccati recursion in
-//                              registers.  Once the field has spread out (> 8 m apart) ~99 % of all games are of this kind.
-//        lqn_all_kernel        multi-player games (N = 2..4) from the per-N queues, 4 games per wave, 16-lane group per
-//                              game, through hk_lq_core.h.
+//   phase_assemble      lane = ego.  Sensor rays of the ego's own kart through the LDS wall grid, the players within 8 m, per
+//                       player initial / target / weights and the 7-branch heading heuristic (HKA:726-1198).
+//   lq1_solve           a single-player game (n = 4, m = 2; ~99.9 % of the games once the field has spread out) is solved by
+//                       the assembling lane itself: the whole Riccati recursion in registers.
+//   lqn_body<N>         multi-player games (N = 2 .. GA) are written to a structure-of-arrays buffer (GameSoA), queued by
+//                       player count and solved between two launches of the tick kernel by lqn_all_kernel / lqn_single_kernel /
+//                       lqn_big_kernel: 64 / (4 N) games per wave through hk_lq_core.h.
 //   both decode u0 -> (Accelerate, Brake, Steering) (HKA:1206-1224).
 //
 // Results are bit-identical to the CPU oracle's dense restatement: see the arithmetic contract in hk_lq_core.h.
