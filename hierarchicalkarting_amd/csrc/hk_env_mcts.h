@@ -560,27 +560,31 @@ __global__ __launch_bounds__(256) void mcts_table_kernel(EnvParams P, MctsDev M,
 // ---------------------------------------------------------------------------------------------------------------------
 // the tree (KartMCTS.cs)
 
-__device__ __forceinline__ float mc_uct(const MNode* nd, int c)
-{   // UCTWeight :162-165 (integer division inside the log)
-    const MNode& n = nd[c];
-    return (n.totalValue / (float)n.numEpisodes) + sqrtf(1.0f) * hk_logf((float)(nd[n.parent].numEpisodes / n.numEpisodes));
-}
-__device__ __forceinline__ int mc_ucs(MctsCtx& C, const MNode* nd, int node)
-{   // upperConfidenceStrategy :167-193; children in insertion order
-    const int index = mc_rand_next(C, nd[node].n_children);
-    int c = nd[node].first_child;
-    for (int q = 0; q < index; q++) c = nd[c].next_sibling;
-    int best = c;
-    float best_uct = mc_uct(nd, best);
-    for (c = nd[node].first_child; c >= 0; c = nd[c].next_sibling) {
-        const float u = mc_uct(nd, c);
-        if (u > best_uct) { best_uct = u; best = c; }
+// upperConfidenceStrategy :167-193 (children in insertion order) with UCTWeight :162-165 (integer division inside the log).
+// The reference starts from the child at a random index and lets any child with a strictly larger weight replace it, walking
+// the list from the front: the result is the FIRST child holding the maximum if that maximum exceeds the random child's
+// weight, else the random child — computed here in ONE walk over the sibling list (each hop is a dependent global load).
+__device__ __forceinline__ int mc_ucs(MctsCtx& C, const MNode* nd, int first_child, int n_children, int parent_episodes)
+{
+    const int index = mc_rand_next(C, n_children);
+    int best_first = -1, idx_child = first_child;
+    float best = -__builtin_inff(), u_idx = 0.0f;
+    int c = first_child;
+    for (int q = 0; c >= 0; q++) {
+        const MNode n = nd[c];
+        const float u = (n.totalValue / (float)n.numEpisodes) + sqrtf(1.0f) * hk_logf((float)(parent_episodes / n.numEpisodes));
+        if (q == index) { idx_child = c; u_idx = u; }
+        if (u > best) { best = u; best_first = c; }
+        c = n.next_sibling;
     }
-    return best;
+    return (best > u_idx) ? best_first : idx_child;
 }
 
+constexpr int MC_MAXPATH = HK_MCTS_MAX_DEPTH * MC_MAXP + 2;     // nodes on one root-to-leaf path (a move per player and depth level)
+
 // one queued search (queue entry q of `set`), its tree in the arena slice `nd`
-__device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDev& M, const TabView& T, const int set, const int q, MNode* nd)
+__device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDev& M, const TabView& T, const int set, const int q, MNode* nd,
+                                                int* path /* LDS, [MC_MAXPATH][64], this lane's column */, unsigned char* pup)
 {
     const unsigned ent = (unsigned)M.queue[(size_t)set * 2 * P.E * P.A + q];
     const int pair = (int)(ent & 0xFFFFFFu);
@@ -633,22 +637,32 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
     nd[0].numEpisodes = 0; nd[0].totalValue = 0.0f; nd[0].action = 0; nd[0].n_children = 0; nd[0].pad = 0; nd[0].pad2 = 0;
     nd[0].upnext = (unsigned char)mc_up_next(root);
 
+    // The tree lives in global memory and a search is one lane: every dependent load is a round trip nothing hides.  So the
+    // node the search stands on is kept in registers (`cur`), the path is remembered in LDS instead of being re-walked through
+    // the parent links, and nodes created in this iteration are only ever stored: once a rollout leaves the existing tree
+    // every deeper node is new, so the rest of the rollout and most of the back-propagation load nothing at all.
     float scores[2 * MC_MAXP];
     MoveEval mv;
     for (int it = 0; it < R.iterations; it++) {
         // findLeaf :195-202 on a running copy of the root state
         DGame g = root;
-        int node = 0;
-        int np = nd[0].upnext;
+        int node = 0, depth = 0;
+        MNode cur = nd[0];
+        path[0] = 0; pup[0] = cur.upnext;
+        int np = cur.upnext;
         mc_eval_moves(C, g, np, mv);
-        while (nd[node].n_children > 0 && nd[node].n_children == mv.n) {
-            node = mc_ucs(C, nd, node);
-            mc_make_move(C, g, np, nd[node].action);
-            np = nd[node].upnext;
+        while (cur.n_children > 0 && cur.n_children == mv.n) {
+            node = mc_ucs(C, nd, cur.first_child, cur.n_children, cur.numEpisodes);
+            cur = nd[node];
+            mc_make_move(C, g, np, cur.action);
+            np = cur.upnext;
+            depth++;
+            path[depth * 64] = node; pup[depth * 64] = cur.upnext;
             mc_eval_moves(C, g, np, mv);
         }
         // simulate :242-283 (mv / np describe the position of `node`)
         bool out_of_nodes = false;
+        int first_new = MC_MAXPATH;                    // depth of the first node created in this iteration
         while (true) {
             if (mc_is_over(C, g, np, mv.n, scores)) break;
             const int ol = T.sec[g.last % P.L].optimal_lane;
@@ -658,30 +672,43 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
             else index = mc_rand_next(C, mv.n);
             const int move = mc_pick_move(C, mv, mc_get(g, np).lane, sign, index);
             int c = -1;
-            for (int ch = nd[node].first_child; ch >= 0; ch = nd[ch].next_sibling)
-                if (nd[ch].action == move) { c = ch; break; }
+            MNode nxt;
+            if (cur.n_children > 0) {
+                for (int ch = cur.first_child; ch >= 0;) {
+                    const MNode n = nd[ch];
+                    if (n.action == move) { c = ch; nxt = n; break; }
+                    ch = n.next_sibling;
+                }
+            }
             mc_make_move(C, g, np, move);
             const int np2 = mc_up_next(g);
             if (c < 0) {
-                if (n_nodes >= M.pool_cap) { out_of_nodes = true; break; }
+                if (n_nodes >= M.pool_cap || depth + 1 >= MC_MAXPATH) { out_of_nodes = true; break; }
                 c = n_nodes++;
-                MNode& nn = nd[c];
-                nn.parent = node; nn.first_child = -1; nn.last_child = -1; nn.next_sibling = -1;
-                nn.numEpisodes = 0; nn.totalValue = 0.0f; nn.action = (unsigned char)move; nn.upnext = (unsigned char)np2;
-                nn.n_children = 0; nn.pad = 0; nn.pad2 = 0;
-                if (nd[node].last_child >= 0) nd[nd[node].last_child].next_sibling = c; else nd[node].first_child = c;
-                nd[node].last_child = c;
-                nd[node].n_children += 1;
+                nxt.parent = node; nxt.first_child = -1; nxt.last_child = -1; nxt.next_sibling = -1;
+                nxt.numEpisodes = 0; nxt.totalValue = 0.0f; nxt.action = (unsigned char)move; nxt.upnext = (unsigned char)np2;
+                nxt.n_children = 0; nxt.pad = 0; nxt.pad2 = 0;
+                nd[c] = nxt;
+                if (cur.last_child >= 0) nd[cur.last_child].next_sibling = c; else cur.first_child = c;
+                cur.last_child = c;
+                cur.n_children += 1;
+                nd[node] = cur;                        // (numEpisodes / totalValue of `cur` are still those of the tree)
+                if (first_new == MC_MAXPATH) first_new = depth + 1;
             }
             node = c;
+            cur = nxt;
             np = np2;
+            depth++;
+            path[depth * 64] = node; pup[depth * 64] = (unsigned char)np2;
             mc_eval_moves(C, g, np, mv);
         }
         if (out_of_nodes) break;
-        // backpropagate :285-293
-        for (int b = node; b >= 0; b = nd[b].parent) {
-            nd[b].totalValue += mc_score_at(scores, nd[b].upnext);
-            nd[b].numEpisodes += 1;
+        // backpropagate :285-293 along the remembered path, leaf to root; a node created in this iteration holds 0 / 0.0f
+        for (int d = depth; d >= 0; d--) {
+            const int b = path[d * 64];
+            const float sc = mc_score_at(scores, pup[d * 64]);
+            if (d >= first_new) { nd[b].totalValue = 0.0f + sc; nd[b].numEpisodes = 1; }
+            else { nd[b].totalValue += sc; nd[b].numEpisodes += 1; }
         }
     }
 
@@ -694,8 +721,9 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
         DGame g = root;
         int node = 0;
         while (nd[node].n_children > 0) {
-            const int np = nd[node].upnext;
-            node = mc_ucs(C, nd, node);
+            const MNode rec = nd[node];
+            const int np = rec.upnext;
+            node = mc_ucs(C, nd, rec.first_child, rec.n_children, rec.numEpisodes);
             mc_make_move(C, g, np, nd[node].action);
             bool all_at = true;
 #define MC_AT(I) if (I < g.P) all_at = all_at && (mc_k<I>(g).section == g.last);
@@ -726,7 +754,9 @@ __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M,
     if (lane0 >= M.slots) return;
     const TabView T = tab_view(P, P.tab);
     MNode* nd = M.nodes + (size_t)lane0 * M.pool_cap;
-    for (int q = lane0; q < count; q += gridDim.x * MC_SPW) mcts_search_one(P, M, T, set, q, nd);
+    __shared__ int path[MC_MAXPATH * 64];
+    __shared__ unsigned char pup[MC_MAXPATH * 64];
+    for (int q = lane0; q < count; q += gridDim.x * MC_SPW) mcts_search_one(P, M, T, set, q, nd, path + threadIdx.x, pup + threadIdx.x);
 }
 
 #undef MC_EACH
