@@ -16,7 +16,7 @@ def gather_episode_results(env_or_array, dist=None):
     """-> structured array [E_total][A] on every rank.  `env_or_array`: a RacingEnv (device results) or a local
     numpy RESULT_DT array (used by the CPU gloo tests)."""
     local = env_or_array if isinstance(env_or_array, np.ndarray) else env_or_array.episode_results()
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return local
     import torch
     world = dist.get_world_size()
