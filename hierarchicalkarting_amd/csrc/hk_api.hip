@@ -528,6 +528,7 @@ int hk_set_agent_state(hk_handle h, const hk_agent_state* in)
     if (!in) return fail(h, HK_ERR_INVALID, "NULL pointer");
     const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
     HK_HIP(h, hipMemcpyAsync(h->dev.agents, in, cnt * sizeof(hk_agent_state), hipMemcpyHostToDevice, h->stream));
+    { int rc = hk::env_mcts_invalidate(h->dev, h->cfg, h->stream, h->err); if (rc) { g_last_error = h->err; return rc; } }   // plans were rewritten
     HK_HIP(h, hipStreamSynchronize(h->stream));
     return HK_OK;
 }

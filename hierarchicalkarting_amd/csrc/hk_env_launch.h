@@ -15,6 +15,14 @@ inline int launch_mcts_table(EnvDevice& d, int ego0, int ntab, hipStream_t strea
     return launch_check(err, "mcts_table_kernel");
 }
 
+inline int launch_mcts_invalidate(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
+    if (!d.mcts.st) return HK_OK;
+    const int n = cfg.num_envs * cfg.num_agents;
+    hipLaunchKernelGGL(mcts_invalidate_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d.mcts, n);
+    return launch_check(err, "mcts_invalidate_copy_kernel");
+}
+
 // Run the planner searches queued so far and hand the tick kernel the other (cleared) queue set.  A search requested on
 // tick t must be finished before tick t + latency (> RUN_CAP, checked in env_create); the tick kernel advances an env by at
 // most RUN_CAP ticks per round, so flushing every MCTS_FLUSH_ROUNDS rounds with (MCTS_FLUSH_ROUNDS + 1) * RUN_CAP < latency

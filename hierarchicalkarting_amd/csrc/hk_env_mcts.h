@@ -30,6 +30,7 @@ constexpr int MC_SPW = HK_MC_SPW;             // searches per wave (see mcts_sea
 
 struct MctsReq {
     int episode_steps, epoch, iterations, gen;      // gen: bumped by every request of this ego (stale queue entries are skipped)
+    int last_sec, pad0, pad1, pad2;                 // last_sec: m_SectionIndex at the last copy of bestStates (mcts_consume)
     MctsKartSnap k[MC_MAXP];
 };
 __device__ __forceinline__ MctsReq* mc_reqs(const MctsDev& M) { return static_cast<MctsReq*>(M.req); }
@@ -44,6 +45,7 @@ __device__ inline void mcts_reset_state(hk_mcts_state* m)
     m->searches = searches;
     m->ready_step = -1;
 }
+
 
 __device__ inline int mcts_tire_age(const EnvParams& P, float final_steer)
 {   // HKA:236
@@ -77,9 +79,17 @@ __device__ inline void mcts_post_request(const EnvParams& P, const MctsDev& M, i
 }
 
 // HKA.FixedUpdate :366-402, every tick: promote a finished search, then copy bestStates into the own plan and beliefs
-__device__ inline void mcts_consume(const EnvParams& P, hk_mcts_state* m, hk_agent_state* a, int i, int episode_steps, int section_index)
+// The reference repeats the copy on every tick; it is idempotent while bestStates and m_SectionIndex stand still (the set of
+// own-plan entries it writes only shrinks as the section index grows, nothing else writes beliefs, and a passed checkpoint
+// clears an entry outside that set), so here it runs when a search is promoted or the section index changed — two loads per
+// tick instead of re-reading the plan and re-storing ~100 B of plan / belief entries per agent and tick.
+__device__ inline void mcts_consume(const EnvParams& P, hk_mcts_state* m, hk_agent_state* a, int i, int episode_steps, int section_index,
+                                    MctsReq* r)
 {
-    if (m->ready_step >= 0 && episode_steps >= m->ready_step) { m->best = m->pend; m->ready_step = -1; }
+    bool promoted = false;
+    if (m->ready_step >= 0 && episode_steps >= m->ready_step) { m->best = m->pend; m->ready_step = -1; promoted = true; }
+    if (!promoted && r->last_sec == section_index) return;
+    r->last_sec = section_index;
     const hk_mcts_plan& b = m->best;
     const int L = P.L;
     for (int q = 0; q < b.n_states; q++) {
@@ -114,7 +124,7 @@ __device__ inline void phase_plan(const EnvParams& P, const MctsDev& M, int set,
     req = (uint32_t)group_or((int)req);
     if (req) mcts_post_request(P, M, set, env, i, req, es.episode_steps, es.episodes_done, P.mcts_iter, es.episode_steps + P.mcts_lat,
                                section, lane, lane_changes, final_steer);
-    if (enabled && P.high_mode[i] == HK_HIGH_MCTS) mcts_consume(P, &M.st[(size_t)env * P.A + i], arec, i, es.episode_steps, section);
+    if (enabled && P.high_mode[i] == HK_HIGH_MCTS) mcts_consume(P, &M.st[(size_t)env * P.A + i], arec, i, es.episode_steps, section, &mc_reqs(M)[(size_t)env * P.A + i]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -527,6 +537,13 @@ __device__ inline void mc_ctx_init(MctsCtx& C, const EnvParams& P, const TabView
     if (C.nact > MC_MAXA) C.nact = MC_MAXA;
     C.dt_tab = M.dt_tab; C.load_tab = M.load_tab; C.rad_tab = M.rad_tab; C.nv = M.nv;
     C.key0 = 0; C.key1 = 0; C.c1 = 0; C.c2 = 0; C.draw = 0;
+}
+
+// the host rewrote agent records (hk_set_agent_state): the next tick copies bestStates again whatever the section index is
+__global__ __launch_bounds__(256) void mcts_invalidate_copy_kernel(MctsDev M, int n)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) mc_reqs(M)[t].last_sec = -1;
 }
 
 // fills the move tables (hk_create): one thread per (section, lane, velocity bucket, action)

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_st
     }
     if (M.st) {
         mcts_reset_state(&M.st[(size_t)env * P.A + i]);
+        mc_reqs(M)[(size_t)env * P.A + i].last_sec = -1;
         uint32_t req = 0;
         for (int e = 0; e < P.A; e++) if (P.high_mode[e] == HK_HIGH_MCTS && !P.training_agent[e]) req |= 1u << e;
         mcts_post_request(P, M, set, env, i, req, 0, envs[env].episodes_done, P.mcts_iter0, P.mcts_lat0,
@@ -190,7 +191,7 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
         es.initial_started = 1;
         if (M.st) {
             // prepareForReuse + initialPlan (HKA:84-96, 428-452): planner state cleared, first plan requested (T = 1.5 s)
-            if (me) mcts_reset_state(&M.st[(size_t)env * P.A + i]);
+            if (me) { mcts_reset_state(&M.st[(size_t)env * P.A + i]); mc_reqs(M)[(size_t)env * P.A + i].last_sec = -1; }
             uint32_t req = 0;
             for (int e = 0; e < P.A; e++) if (P.high_mode[e] == HK_HIGH_MCTS && !P.training_agent[e]) req |= 1u << e;
             mcts_post_request(P, M, set, env, i, req, 0, es.episodes_done, P.mcts_iter0, P.mcts_lat0,
