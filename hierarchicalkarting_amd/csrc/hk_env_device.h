@@ -86,6 +86,7 @@ struct MctsDev {
                             // the search kernel (every few rounds of the tick kernel, see env_launch_lqn) and clears the new one
     int* queue;             // [2][2*E*A]: (env * A + agent) | generation << 24
     MNode* nodes;           // [slots][pool_cap]
+    int* roots;             // [words of the root position][slots]: each search's root game state (hk_env_mcts.h)
     // move tables, filled once by mcts_table_kernel with the same device functions the search would call (so they are
     // bit-identical to evaluating applyAction on the spot): what a move costs depends only on the section (mod L), the
     // kart's lane and velocity bucket and the action — not on the tree

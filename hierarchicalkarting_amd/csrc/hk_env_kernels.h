@@ -121,7 +121,7 @@ int upload(T** dst, const std::vector<T>& v, std::string& err)
 inline void env_destroy(EnvDevice& d)
 {
     void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.reward_out, d.status, d.games, d.queue_cnt, d.queue, d.env_ids, d.tab, d.perms,
-                    d.rw.sec_time, d.rw.sec_cnt, d.rw.hit_code, d.mcts.st, d.mcts.req, d.mcts.qcnt, d.mcts.queue, d.mcts.nodes, d.mcts.dt_tab, d.mcts.load_tab, d.mcts.rad_tab, d.sec_geo, d.perm, d.perm_counts};
+                    d.rw.sec_time, d.rw.sec_cnt, d.rw.hit_code, d.mcts.st, d.mcts.req, d.mcts.qcnt, d.mcts.queue, d.mcts.nodes, d.mcts.dt_tab, d.mcts.load_tab, d.mcts.rad_tab, d.mcts.roots, d.sec_geo, d.perm, d.perm_counts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = EnvDevice{};
 }
@@ -361,7 +361,9 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         HK_ALLOC(d.mcts.st, na * sizeof(hk_mcts_state));
         HK_ALLOC(d.mcts.req, na * HK_GA_CALL(d, mcts_req_bytes()));
         HK_ALLOC(d.mcts.queue, 2 * 2 * na * sizeof(int));
+        if (d.mcts.pool_cap > 65535) { err = "hk_create: MCTS iteration budget too large (the tree pool is limited to 65 535 nodes per search)"; return HK_ERR_UNSUPPORTED; }
         HK_ALLOC(d.mcts.nodes, (size_t)d.mcts.slots * d.mcts.pool_cap * sizeof(MNode));
+        HK_ALLOC(d.mcts.roots, (size_t)d.mcts.slots * HK_GA_CALL(d, mcts_root_words()) * sizeof(int));
         HK_ALLOC(d.mcts.qcnt, 4 * sizeof(int));
         // move tables: one set for the whole handle, so every MCTS agent must share bucket size and time precision
         int ego0 = -1;

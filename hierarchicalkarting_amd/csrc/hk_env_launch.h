@@ -6,6 +6,7 @@ namespace hk { namespace HK_GA_NS {
 
 inline size_t mcts_req_bytes() { return sizeof(MctsReq); }
 inline int mcts_searches_per_wave() { return MC_SPW; }
+inline int mcts_root_words() { return MC_ROOT_WORDS; }
 inline size_t game_doubles_per_ego() { return (size_t)GA * GP_FIELDS; }      // GameSoA: GA players x GP_FIELDS doubles
 inline size_t queue_ints_per_set(size_t na) { return (size_t)(GA - 1) * na; }   // one queue per player count 2 .. GA
 
@@ -117,8 +118,11 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
 inline int launch_observe(EnvDevice& d, const hk_config& cfg, uint32_t agent_mask, hipStream_t stream, std::string& err)
 {
     const long long threads = (long long)cfg.num_envs * cfg.num_agents * OBS_LANES;
-    hipLaunchKernelGGL(env_observe_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), d.tab_lds, stream, d.P, d.agents, d.obs, d.rw.hit_code,
-                       d.rw.hit_code ? 0xFFFFFFFFu : agent_mask, d.tab_lds ? 1 : 0);      // the reward replay needs every agent's hit codes
+    // a block is only 16 agents: copying the tables into LDS pays for the Oval's 20 KB (+3 % on the RL workload), not for the
+    // Complex track's 40 KB (the 8-agent workload lost 10 %), which keeps reading them through L1 / L2
+    const int lds = (d.tab_lds && d.tab_lds <= 24 * 1024) ? d.tab_lds : 0;
+    hipLaunchKernelGGL(env_observe_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, stream, d.P, d.agents, d.obs, d.rw.hit_code,
+                       d.rw.hit_code ? 0xFFFFFFFFu : agent_mask, lds ? 1 : 0);      // the reward replay needs every agent's hit codes
     int rc = launch_check(err, "env_observe_kernel");
     if (rc || !d.rw.hit_code) return rc;
     // CollectObservations raised HitWall / HitOpponent events (HKA:580-598): replayed per env in agent / sensor order

@@ -598,10 +598,31 @@ __device__ __forceinline__ int mc_ucs(MctsCtx& C, const MNode* nd, int first_chi
 }
 
 constexpr int MC_MAXPATH = HK_MCTS_MAX_DEPTH * MC_MAXP + 2;     // nodes on one root-to-leaf path (a move per player and depth level)
+constexpr int MC_ROOT_WORDS = (int)(sizeof(DGame) / sizeof(int));
+static_assert(sizeof(DGame) % sizeof(int) == 0, "DGame is all ints");
+// The root position is needed once per iteration (and for the final read-out) but would sit in ~35 (8 karts: ~70) registers for
+// the whole search: it waits in global memory instead, word-major over the arena's lanes (M.roots[word][lane]: coalesced).
+__device__ __forceinline__ void mc_root_store(int* rootl, const int stride, const DGame& g)
+{
+    int w[MC_ROOT_WORDS];
+    __builtin_memcpy(w, &g, sizeof(DGame));
+#pragma unroll
+    for (int f = 0; f < MC_ROOT_WORDS; f++) rootl[(size_t)f * stride] = w[f];
+}
+__device__ __forceinline__ DGame mc_root_load(const int* rootl, const int stride)
+{
+    int w[MC_ROOT_WORDS];
+#pragma unroll
+    for (int f = 0; f < MC_ROOT_WORDS; f++) w[f] = rootl[(size_t)f * stride];
+    DGame g;
+    __builtin_memcpy(&g, w, sizeof(DGame));
+    return g;
+}
 
 // one queued search (queue entry q of `set`), its tree in the arena slice `nd`
 __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDev& M, const TabView& T, const int set, const int q, MNode* nd,
-                                                int* path /* LDS, [MC_MAXPATH][64], this lane's column */, unsigned char* pup)
+                                                unsigned short* path /* LDS, [MC_MAXPATH][64], this lane's column */, unsigned char* pup,
+                                                int* rootl /* M.roots + this lane: the root position, stride M.slots */)
 {
     const unsigned ent = (unsigned)M.queue[(size_t)set * 2 * P.E * P.A + q];
     const int pair = (int)(ent & 0xFFFFFFu);
@@ -649,6 +670,8 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
     root.last = initialSection;
     root.fin = initialSection + P.depth[ego];
 
+    const int rootP = root.P;
+    mc_root_store(rootl, M.slots, root);
     int n_nodes = 1;
     nd[0].parent = -1; nd[0].first_child = -1; nd[0].last_child = -1; nd[0].next_sibling = -1;
     nd[0].numEpisodes = 0; nd[0].totalValue = 0.0f; nd[0].action = 0; nd[0].n_children = 0; nd[0].pad = 0; nd[0].pad2 = 0;
@@ -662,7 +685,7 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
     MoveEval mv;
     for (int it = 0; it < R.iterations; it++) {
         // findLeaf :195-202 on a running copy of the root state
-        DGame g = root;
+        DGame g = mc_root_load(rootl, M.slots);
         int node = 0, depth = 0;
         MNode cur = nd[0];
         path[0] = 0; pup[0] = cur.upnext;
@@ -674,7 +697,7 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
             mc_make_move(C, g, np, cur.action);
             np = cur.upnext;
             depth++;
-            path[depth * 64] = node; pup[depth * 64] = cur.upnext;
+            path[depth * 64] = (unsigned short)node; pup[depth * 64] = cur.upnext;
             mc_eval_moves(C, g, np, mv);
         }
         // simulate :242-283 (mv / np describe the position of `node`)
@@ -716,7 +739,7 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
             cur = nxt;
             np = np2;
             depth++;
-            path[depth * 64] = node; pup[depth * 64] = (unsigned char)np2;
+            path[depth * 64] = (unsigned short)node; pup[depth * 64] = (unsigned char)np2;
             mc_eval_moves(C, g, np, mv);
         }
         if (out_of_nodes) break;
@@ -732,10 +755,10 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
     // getBestStatesSequence :108-123
     hk_mcts_plan plan;
     __builtin_memset(&plan, 0, sizeof(plan));
-    plan.n_players = root.P;
-    for (int p = 0; p < root.P; p++) plan.player_agent[p] = (uint8_t)((agent_of >> (4 * p)) & 15u);
+    plan.n_players = rootP;
+    for (int p = 0; p < rootP; p++) plan.player_agent[p] = (uint8_t)((agent_of >> (4 * p)) & 15u);
     {
-        DGame g = root;
+        DGame g = mc_root_load(rootl, M.slots);
         int node = 0;
         while (nd[node].n_children > 0) {
             const MNode rec = nd[node];
@@ -760,7 +783,12 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
 
 // The search kernel: a fixed grid of waves (the arena holds one tree per resident lane, M.slots = gridDim.x * MC_SPW) walks the
 // queue with a grid stride, so the arena does not grow with the number of envs and every wave ends when the queue is exhausted.
-__global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M, int set)
+#if HK_GA > 4
+#define HK_MC_BOUNDS __launch_bounds__(64, 2)      /* 8 karts: hold the kernel to 256 registers so that two waves fit a SIMD */
+#else
+#define HK_MC_BOUNDS __launch_bounds__(64)
+#endif
+__global__ HK_MC_BOUNDS void mcts_search_kernel(EnvParams P, MctsDev M, int set)
 {
     // MC_SPW searches per wave.  Measured (16 384 envs x 4 agents = 1 024 full waves, one per SIMD): 64 -> 11.2 M env-steps/s,
     // 32 -> 11.0 M, 21 -> 10.3 M, 16 -> 9.7 M: a launch lasts as long as one search however the searches are spread, so
@@ -771,12 +799,13 @@ __global__ __launch_bounds__(64) void mcts_search_kernel(EnvParams P, MctsDev M,
     if (lane0 >= M.slots) return;
     const TabView T = tab_view(P, P.tab);
     MNode* nd = M.nodes + (size_t)lane0 * M.pool_cap;
-    __shared__ int path[MC_MAXPATH * 64];
+    __shared__ unsigned short path[MC_MAXPATH * 64];        // node indices fit 16 bits: hk_create refuses pools beyond 65 535 nodes
     __shared__ unsigned char pup[MC_MAXPATH * 64];
-    for (int q = lane0; q < count; q += gridDim.x * MC_SPW) mcts_search_one(P, M, T, set, q, nd, path + threadIdx.x, pup + threadIdx.x);
+    for (int q = lane0; q < count; q += gridDim.x * MC_SPW) mcts_search_one(P, M, T, set, q, nd, path + threadIdx.x, pup + threadIdx.x, M.roots + lane0);
 }
 
 #undef MC_EACH
 #undef MC_EACH2
+#undef HK_MC_BOUNDS
 
 } }  // namespace hk::HK_GA_NS
