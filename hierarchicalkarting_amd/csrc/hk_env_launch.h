@@ -105,9 +105,14 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
 #if HK_GA > 4
         if (cfg.num_agents > 4) {
             const int nbb = std::min((ngames + 1) / 2, 512);
-            hipLaunchKernelGGL(lqn_big_kernel, dim3(nbb * (cfg.num_agents - 4)), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu,
+            hipLaunchKernelGGL(lqn_big_kernel<5>, dim3(nbb * (cfg.num_agents > 5 ? 2 : 1)), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu,
                                d.lq_debug, d.status, nbb);
-            if ((rc = launch_check(err, "lqn_big_kernel"))) return rc;
+            if ((rc = launch_check(err, "lqn_big_kernel<5>"))) return rc;
+            if (cfg.num_agents > 6) {
+                hipLaunchKernelGGL(lqn_big_kernel<7>, dim3(nbb * (cfg.num_agents > 7 ? 2 : 1)), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu,
+                                   d.lq_debug, d.status, nbb);
+                if ((rc = launch_check(err, "lqn_big_kernel<7>"))) return rc;
+            }
         }
 #endif
     }

@@ -720,24 +720,24 @@ __global__ __launch_bounds__(64) void lqn_single_kernel(EnvParams P, hk_agent_st
 }
 
 #if HK_GA > 4
-// Games with 5..8 players (only the synthetic 8-agent configuration has them): blocks [0, nb) take the 5-player queue, ... [3 nb, 4 nb)
-// the 8-player one.  The generic core is the same; beyond 4 players a lane's value-matrix rows (NP x 4 NP doubles) exceed the
-// register file and spill — functional, not tuned (such games are rare: more than 4 karts within 8 m of each other).
+// Games with 5..8 players (only the synthetic 8-agent configuration has them).  The generic core is the same; beyond 4 players a
+// lane's value-matrix rows (NP x 4 NP doubles) exceed the register file and spill — the more players the more — so the sizes
+// are compiled in two kernels ({5, 6} and {7, 8}: a kernel's register / scratch budget is that of its largest size; the common
+// 5- and 6-player games would otherwise run with the 8-player allocation).  Blocks [0, nb) take the lower size, [nb, 2 nb) the
+// higher one.  Functional, not tuned: such games need more than 4 karts within 8 m of each other.
+template <int NA>
 __global__ __launch_bounds__(64) void lqn_big_kernel(EnvParams P, hk_agent_state* agents, const GameSoA games, const int* queue_cnt,
                                                      const int* queue, hk_lq_debug* dbg_out, int* status, int nb)
 {
-    constexpr size_t B5 = (sizeof(LqGameLds<5>) + sizeof(CostRows<5>)) * LqDims<5>::SLOTS;
-    constexpr size_t B6 = (sizeof(LqGameLds<6>) + sizeof(CostRows<6>)) * LqDims<6>::SLOTS;
-    constexpr size_t B7 = (sizeof(LqGameLds<7>) + sizeof(CostRows<7>)) * LqDims<7>::SLOTS;
-    constexpr size_t B8 = (sizeof(LqGameLds<8>) + sizeof(CostRows<8>)) * LqDims<8>::SLOTS;
-    constexpr size_t BA = B5 > B6 ? B5 : B6, BB = B7 > B8 ? B7 : B8, BMAX = BA > BB ? BA : BB;
+    constexpr int NB = NA + 1;
+    constexpr size_t BA = (sizeof(LqGameLds<NA>) + sizeof(CostRows<NA>)) * LqDims<NA>::SLOTS;
+    constexpr size_t BB = (sizeof(LqGameLds<NB>) + sizeof(CostRows<NB>)) * LqDims<NB>::SLOTS;
+    constexpr size_t BMAX = BA > BB ? BA : BB;
     static_assert(BMAX <= 160 * 1024, "one workgroup's games must fit the CU's LDS");
     __shared__ __align__(16) unsigned char smem[BMAX];
     const int which = blockIdx.x / nb, b = blockIdx.x - which * nb;
-    if (which == 0) lqn_body<5>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
-    else if (which == 1) lqn_body<6>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
-    else if (which == 2) lqn_body<7>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
-    else lqn_body<8>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
+    if (which == 0) lqn_body<NA>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
+    else lqn_body<NB>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
 }
 #endif
 
