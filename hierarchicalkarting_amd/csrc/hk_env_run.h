@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
     if (arec) h = load_hot(arec); else { Hot z = {}; h = z; }
     float hfx, hfz;                                      // the kart's forward, carried across ticks (changes only when yaw does)
     hk_sincosf(h.yaw, &hfx, &hfz);
+    const LaneCfg LC = lane_cfg(P, i);                   // this lane's agent: modes and player list, read once
     RwAcc rwv = {0.0f, 0.0f, 0.0f};
     if (HAS_RW && P.rewards && arec) { rwv.cum = arec->cum_reward; rwv.step = arec->step_reward; rwv.group = arec->group_reward; }
     while (env_ok && (phase != 0 || (left > 0 && budget > 0))) {
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
             if (!parked) {
                 const bool act = (es.episode_steps % cadence) == 0 &&                                  // HKA:317 (Q9)
                                  !(!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u));
-                qn = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st);
+                qn = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
                 // bin the queued games by player count, one atomic per wave and count
 #pragma unroll
                 for (int n = 2; n <= GA; n++) {
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
             // does any ego of this env wait for a multi-player solve?
             if (group_or(qn ? 1 : 0)) { phase = 1; break; }
         }
-        phase_move<HAS_RW, HAS_TRAIN>(P, T, env, i, env_ok, es, h, hfx, hfz, agents, act_steer, act_branch, M.st, RD, rwv);
+        phase_move<HAS_RW, HAS_TRAIN>(P, T, env, i, env_ok, es, h, hfx, hfz, agents, act_steer, act_branch, M.st, RD, rwv, LC.low_mode, LC.high_mode);
         phase = 0;
         left -= 1; budget -= 1;
     }

@@ -42,6 +42,21 @@ struct GameSoA {
     __device__ __forceinline__ void put(int game, int i, int f, double v) const { d[((size_t)(i * GP_FIELDS + f)) * ng + game] = v; }
 };
 
+// What the parameter block says about THIS lane's agent, read once per launch: indexing the by-value kernel argument with the
+// lane's agent index makes every use a vector load from the kernarg segment (and small local arrays filled with run-time
+// counts live in scratch), inside the tick loop.  order: the agent's player list [this, teamAgents..., otherAgents...]
+// (HKA:702), 4 bits per entry.
+struct LaneCfg { int low_mode, high_mode, vbucket, nall; uint32_t order; };
+__device__ __forceinline__ LaneCfg lane_cfg(const EnvParams& P, const int i)
+{
+    LaneCfg c;
+    c.low_mode = P.low_mode[i]; c.high_mode = P.high_mode[i]; c.vbucket = P.vbucket[i];
+    c.order = (uint32_t)i; c.nall = 1;
+    for (int j = 0; j < P.n_team[i]; j++) { c.order |= (uint32_t)P.team[i][j] << (4 * c.nall); c.nall++; }
+    for (int j = 0; j < P.n_other[i]; j++) { c.order |= (uint32_t)P.other[i][j] << (4 * c.nall); c.nall++; }
+    return c;
+}
+
 struct KartS {                 // per-kart staging (LDS), filled by the kart's own lane
     float px, pz, yaw, fx, fz, speed, heading, msfs, dC;
     float ray[5];              // nearest wall distance along sensors 0, 2, 4, 8, 6 (3e38 = none)
@@ -243,7 +258,7 @@ __device__ inline void lq1_solve(const EnvParams& P, const GamePlayer& gp, Hot& 
 // global descriptor otherwise
 template <bool SINGLE>
 __device__ __forceinline__ void assemble_player(const EnvParams& P, const TabView& T, const int env, const int ego, const int i, const int N,
-                                                const int nearbyAgents, const int* pl, const KartS* kq, const bool fixed,
+                                                const int nearbyAgents, const uint32_t plm /* players, 4 bits each */, const KartS* kq, const bool fixed, const int vbucket,
                                                 const float dy, GamePlayer* gp, hk_lq_debug* dbg_out, const hk_mcts_state* bel,
                                                 const GameSoA& games, const int game)
 {
@@ -252,7 +267,7 @@ __device__ __forceinline__ void assemble_player(const EnvParams& P, const TabVie
     // fields are indexed by a run-time M), and 80 scratch round trips per player dominated the 2-agent configuration.
     const int A = P.A, L = P.L;
     const KartS& mek = kq[ego];
-        const int ki = pl[i];
+        const int ki = (int)((plm >> (4 * i)) & 15u);
         const KartS& kk = kq[ki];
         const float speed = kk.speed;
         double initial[4];
@@ -272,23 +287,23 @@ __device__ __forceinline__ void assemble_player(const EnvParams& P, const TabVie
         if (ki == ego) {                                                              // :752-764, :782-794
             if (mek.pl1 != 0) {
                 laneSel = mek.pl1;
-                double pv = mek.pv1 + (fixed ? 0 : P.vbucket[ego] * 2);
+                double pv = mek.pv1 + (fixed ? 0 : vbucket * 2);
                 vel = (double)P.max_speed < pv ? (double)P.max_speed : pv;
             }
             if (mek.pl2 != 0) {
                 nextSel = mek.pl2;
-                double pv = mek.pv2 + (fixed ? 0 : P.vbucket[ego] * 2);
+                double pv = mek.pv2 + (fixed ? 0 : vbucket * 2);
                 nextVel = (double)P.max_speed < pv ? (double)P.max_speed : pv;
             }
         } else if (bel) {                                                             // :767-771, :797-801: the EGO's beliefs
             if (bel->belief_lane[ki][idx] != 0) {
                 laneSel = bel->belief_lane[ki][idx];
-                double pv = (float)bel->belief_vel[ki][idx] + (fixed ? 0 : P.vbucket[ego] * 2);
+                double pv = (float)bel->belief_vel[ki][idx] + (fixed ? 0 : vbucket * 2);
                 vel = (double)P.max_speed < pv ? (double)P.max_speed : pv;
             }
             if (bel->belief_lane[ki][idx2] != 0) {
                 nextSel = bel->belief_lane[ki][idx2];
-                double pv = (float)bel->belief_vel[ki][idx2] + (fixed ? 0 : P.vbucket[ego] * 2);
+                double pv = (float)bel->belief_vel[ki][idx2] + (fixed ? 0 : vbucket * 2);
                 nextVel = (double)P.max_speed < pv ? (double)P.max_speed : pv;
             }
         }   // no belief (only the MCTS planner fills them) -> Trigger / max speed
@@ -372,7 +387,7 @@ __device__ __forceinline__ void assemble_player(const EnvParams& P, const TabVie
             const bool isteam = j >= no;
             const int oi = isteam ? P.team[ki][j - no] : P.other[ki][j];
             bool member = false;
-            for (int q = 0; q < N; q++) if (pl[q] == oi) member = true;
+            for (int q = 0; q < N; q++) if ((int)((plm >> (4 * q)) & 15u) == oi) member = true;
             if (!member) continue;
             const KartS& o = kq[oi];
             const float dist = mag3(o.px - kk.px, 0.0f, o.pz - kk.pz);
@@ -391,7 +406,7 @@ __device__ __forceinline__ void assemble_player(const EnvParams& P, const TabVie
                 lane_marker(T, io, mek.pl1, olx, olz);
                 if (isteam) ov = mek.msfs;
                 else if (mek.pl1 != 0) {
-                    double pv = mek.pv1 + (fixed ? 0 : P.vbucket[ego] * 2);
+                    double pv = mek.pv1 + (fixed ? 0 : vbucket * 2);
                     ov = (double)P.max_speed < pv ? (double)P.max_speed : pv;
                 } else ov = P.max_speed;
             } else {
@@ -399,7 +414,7 @@ __device__ __forceinline__ void assemble_player(const EnvParams& P, const TabVie
                 lane_marker(T, io, bl, olx, olz);
                 if (isteam) ov = o.msfs;
                 else if (bl != 0) {
-                    double pv = (float)bel->belief_vel[oi][io] + (fixed ? 0 : P.vbucket[ego] * 2);
+                    double pv = (float)bel->belief_vel[oi][io] + (fixed ? 0 : vbucket * 2);
                     ov = (double)P.max_speed < pv ? (double)P.max_speed : pv;
                 } else ov = P.max_speed;
             }
@@ -458,7 +473,8 @@ __device__ __forceinline__ void wave_lds_sync()
 __device__ inline int phase_assemble(const EnvParams& P, const TabView& T, KartS* ks, const int env, const int ego,
                                       const bool act, const hk_env_state& es, Hot& h, const float hfx, const float hfz, hk_agent_state* agents,
                                       const GameSoA games,
-                                      int* queue_cnt, int* queue, hk_lq_debug* dbg_out, int* status, const hk_mcts_state* mcts_all)
+                                      int* queue_cnt, int* queue, hk_lq_debug* dbg_out, int* status, const hk_mcts_state* mcts_all,
+                                      const LaneCfg& LC)
 {
     const int A = P.A, L = P.L;
     const bool me = act && ego < A;
@@ -543,38 +559,34 @@ __device__ inline int phase_assemble(const EnvParams& P, const TabView& T, KartS
     wave_lds_sync();
     if (!me) return 0;
     const KartS* kq = &ks[threadIdx.x & ~(GA - 1)];   // the env's karts
-    const bool solving = (k.flags & HK_F_ENABLED) && P.low_mode[ego] == HK_LOW_LQR && !((es.inactive_mask >> ego) & 1u);
+    const bool solving = (k.flags & HK_F_ENABLED) && LC.low_mode == HK_LOW_LQR && !((es.inactive_mask >> ego) & 1u);
     if (!solving) return 0;
     // ---- players (HKA:702-725)
-    int pl[GA] = {};
+    uint32_t plm = 0;
     int N = 0, nearbyAgents = -1;
-    {
-        int all[GA], nall = 0;
-        all[nall++] = ego;
-        for (int j = 0; j < P.n_team[ego]; j++) all[nall++] = P.team[ego][j];
-        for (int j = 0; j < P.n_other[ego]; j++) all[nall++] = P.other[ego][j];
+    for (int q = 0; q < LC.nall; q++) {
+        const uint32_t who = (LC.order >> (4 * q)) & 15u;
+        bool in = true;
         if (A > 2) {
-            for (int q = 0; q < nall; q++) {
-                const KartS& o = kq[all[q]];
-                if (mag3(o.px - k.px, 0.0f, o.pz - k.pz) < 8) { nearbyAgents += 1; pl[N++] = all[q]; }
-            }
-        } else {
-            for (int q = 0; q < nall; q++) pl[N++] = all[q];
+            const KartS& o = kq[who];
+            in = mag3(o.px - k.px, 0.0f, o.pz - k.pz) < 8;
+            if (in) nearbyAgents += 1;
         }
-        nearbyAgents = nearbyAgents > 1 ? nearbyAgents : 1;
+        if (in) { plm |= who << (4 * N); N++; }
     }
-    const bool fixed = P.high_mode[ego] == HK_HIGH_FIXED;
+    nearbyAgents = nearbyAgents > 1 ? nearbyAgents : 1;
+    const bool fixed = LC.high_mode == HK_HIGH_FIXED;
     const hk_mcts_state* bel = mcts_all ? &mcts_all[(size_t)env * A + ego] : nullptr;
     const float dy = T.sec[0].marker_y - P.kart_y;                                    // Q13
     if (N == 1) {
         // single-player game: assemble into registers and run the whole Riccati recursion right here
         GamePlayer loc;
-        assemble_player<true>(P, T, env, ego, 0, N, nearbyAgents, pl, kq, fixed, dy, &loc, dbg_out, bel, games, 0);
+        assemble_player<true>(P, T, env, ego, 0, N, nearbyAgents, plm, kq, fixed, LC.vbucket, dy, &loc, dbg_out, bel, games, 0);
         if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = 1;
         lq1_solve(P, loc, h, (dbg_out && (P.debug & 1)) ? &dbg_out[(size_t)env * A + ego] : nullptr, status);
         return 0;
     }
-    for (int i = 0; i < N; i++) assemble_player<false>(P, T, env, ego, i, N, nearbyAgents, pl, kq, fixed, dy, nullptr, dbg_out, bel, games, env * A + ego);
+    for (int i = 0; i < N; i++) assemble_player<false>(P, T, env, ego, i, N, nearbyAgents, plm, kq, fixed, LC.vbucket, dy, nullptr, dbg_out, bel, games, env * A + ego);
     if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = N;
     return N;                // the caller bins the game by N (wave-aggregated slot allocation needs every queued lane together)
 }

@@ -274,7 +274,8 @@ __device__ inline int calculate_lane(const EnvParams& P, const SecDev& s, float 
 template <bool RWT, bool TRAIN>
 __device__ inline void phase_move(const EnvParams& P, const TabView& T, const int env, const int i, const bool env_ok,
                                   hk_env_state& es, Hot& h, float& hfx, float& hfz, hk_agent_state* agents, const float* act_steer,
-                                  const int* act_branch, hk_mcts_state* mcts_all, const RwDev& RD, RwAcc& rwv)
+                                  const int* act_branch, hk_mcts_state* mcts_all, const RwDev& RD, RwAcc& rwv, const int my_low_mode,
+                                  const int my_high_mode)
 {
     const bool RW = RWT && P.rewards != 0;
     const bool me = env_ok && i < P.A;
@@ -293,7 +294,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
     const bool inactive_before = (inactive_mask >> i) & 1u;
     if (enabled) {
         // KA.OnActionReceived / InterpretDiscreteActions (HKA:1371-1379) for RL agents
-        if (P.low_mode[i] == HK_LOW_RL && (fl & HK_F_ACTIVE)) {
+        if (my_low_mode == HK_LOW_RL && (fl & HK_F_ACTIVE)) {
             h.steering = act_steer[(size_t)env * P.A + i];
             int br = act_branch[(size_t)env * P.A + i];
             if (br > 1) fl |= HK_F_ACCEL; else fl &= ~HK_F_ACCEL;
@@ -301,7 +302,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
         }
         if (episode_steps % 100 == 0 && episode_steps < P.max_steps && episode_steps > 0 && !inactive_before) {
             if (TRAIN && P.training_agent[i]) plan_randomly(P, T, env, i, h.section_index, episode_steps, es.episodes_done, a);   // HKA:357-360
-            else if (P.high_mode[i] == HK_HIGH_FIXED) plan_fixed(P, T, i, h.section_index, a);
+            else if (my_high_mode == HK_HIGH_FIXED) plan_fixed(P, T, i, h.section_index, a);
         }
         // ---- ArcadeKart.FixedUpdate
         bool accelerate = false, brake = false; float turnInput = 0.0f;
