@@ -690,7 +690,7 @@ __device__ __forceinline__ void lqn_body(const int block, const int nblocks, con
         qp.C = &CR;
         double u0[2];
         int singular = 0;
-        lq_solve_game<NP>(r, LG, qp, 3, u0, singular);                          // HKA:1201 horizon literal 3 (Q6)
+        lq_solve_game<NP, QCompact<NP>, true>(r, LG, qp, 3, u0, singular);      // HKA:1201 horizon literal 3 (Q6)
         if (live && r == 0) {
             if (singular) atomicOr(status, 1);
             hk_agent_state* me = &agents[game];

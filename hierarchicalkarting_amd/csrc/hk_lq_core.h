@@ -52,7 +52,11 @@ struct __attribute__((aligned(16))) LqGameLds {
 
 // Q provider concept: double Q(int i, int r, int c); double q(int i, int r);   (player i's cost, ego-local order)
 // All 64 lanes of the wave must call this (it contains block barriers); r in [0, n) for real lanes.
-template <int NP, class QP>
+// BICYCLE: the game is one of SolveLQR's (block-diagonal A, B_k with zero position rows — the linearised bicycle of
+// KartLQRDynamics.cs:40-62).  Then the position rows (x, z) of F = A - sum B_k P_k are exactly +0.0 outside their own player's
+// block, whatever P is, and the chain W = Z_i F may leave those terms out (fma(z, +0.0, s) = s exactly): 37 % of the chain at
+// N = 4.  The generic hk_lq_solve_batch (arbitrary A, B) keeps every term.
+template <int NP, class QP, bool BICYCLE = false>
 __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const int horizon, double u0[2], int& singular)
 {
     constexpr int n = LqDims<NP>::n, m = LqDims<NP>::m;
@@ -261,10 +265,12 @@ __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             // W = Z_i F (row r): four independent fma chains per pass (columns c..c+3)
-            for (int c = 0; c < n; c += 4) {
+            for (int c = 0; c < n; c += 4) {                // columns c .. c + 3 = the states of player c / 4
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
                 for (int k = 0; k < n; k++) {
+                    // (BICYCLE) rows k = 4 j, 4 j + 1 of F are zero in these columns unless j is the columns' player
+                    if (BICYCLE && (k & 3) < 2 && (k >> 2) != (c >> 2)) continue;
                     const double2 f = *reinterpret_cast<const double2*>(&L.F[k][c]);
                     const double2 g = *reinterpret_cast<const double2*>(&L.F[k][c + 2]);
                     s0 = fma64(Z[i][k], f.x, s0);
