@@ -42,6 +42,21 @@ sa, sb = a.agent_state(), b.agent_state()
 for name in sa.dtype.names:
     assert np.array_equal(sa[name], sb[name]), name
 assert np.array_equal(tot_a, tot_b) and (tot_a != 0).all()
+# hk_lq_solve_batch_device: the LQ solve on tensors that already live on the GPU (no host staging), same bits as the host entry point
+import ctypes as C
+from oracle import lq_numpy as LQ
+rng = np.random.default_rng(3)
+games = [LQ.random_game(rng, 3) for _ in range(300)]
+args = [np.ascontiguousarray(np.array([g[k] for g in games]), np.float64) for k in range(6)]
+u_host = hk.solve_feedback_lqr_batch(*args, 3)
+dev = [torch.from_numpy(x).cuda() for x in args]
+u_dev = torch.zeros((300, 2), dtype=torch.float64, device="cuda")
+torch.cuda.synchronize()
+dp = lambda t: C.cast(t.data_ptr(), C.POINTER(C.c_double))
+rc = a.L.hk_lq_solve_batch_device(a.h, 300, 3, dp(dev[0]), dp(dev[1]), dp(dev[2]), dp(dev[3]), dp(dev[4]), dp(dev[5]), 3, dp(u_dev), None)
+assert rc == 0, rc
+a.synchronize()
+assert np.array_equal(u_dev.cpu().numpy().view(np.uint64), u_host.view(np.uint64))
 print("DEVICE_LOOP_OK")
 """
 
