@@ -163,6 +163,10 @@ class RacingEnv:
         self._ck(self.L.hk_comm_init(self.h, int(world_size), int(rank), buf))
         self._comm_world = int(world_size)
 
+    def comm_destroy(self):
+        self._ck(self.L.hk_comm_destroy(self.h))
+        self._comm_world = 0
+
     def gather_results(self):
         """-> hk_episode_result[world * E][A] on every rank (one RCCL all-gather)"""
         out = np.zeros((self._comm_world * self.E, self.A), RESULT_DT)

@@ -19,3 +19,8 @@ def test_gather_results_single_rank():
     assert allr.shape == (9, 2) and allr.tobytes() == loc.tobytes() and (allr["episode"] >= 0).all()
     with pytest.raises(hk.HkError):
         g.comm_init(1, 0, cid)                       # one communicator per handle
+    g.comm_destroy()
+    with pytest.raises(hk.HkError):
+        g.gather_results()                           # no communicator any more
+    g.comm_init(1, 0, hk.RacingEnv.comm_unique_id()) # a new one can be made
+    assert g.gather_results().tobytes() == loc.tobytes()
