@@ -252,7 +252,7 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
 __device__ __forceinline__ void rot_y(float ang_rad, float& x, float& z)
 {
     float c, s;
-    hk_sincosf(ang_rad, &s, &c);
+    hk_sincosf_near0(ang_rad, &s, &c);        // a few degrees per tick: the reduction-free path of the same function
     float nx = x * c + z * s;
     float nz = z * c - x * s;
     x = nx; z = nz;

@@ -113,6 +113,15 @@ HK_HD void hk_sincos(double x, double* s, double* c)
     *c = ((q + 1) & 2) ? -b : b;                 /* q: 0 kc, 1 -ks, 2 -kc, 3 ks */
 }
 
+/* The same pair for an argument that is almost always near zero (the per-tick AngleAxis rotations: a few degrees): for
+ * |x| < 0.78 < pi/4 the reduction picks k = 0 and leaves r = x exactly, so the two kernels can be evaluated on x directly —
+ * bit-identical to hk_sincos, without the reduction and the quadrant selects; any other argument takes the general path. */
+HK_HD void hk_sincos_near0(double x, double* s, double* c)
+{
+    if (hk_fabs(x) < 0.78) { *s = hk__ksin(x); *c = hk__kcos(x); return; }
+    hk_sincos(x, s, c);
+}
+
 /* atan(t) for t in [0,1] */
 HK_HD double hk__atan01(double t)
 {
@@ -221,6 +230,7 @@ HK_HD double hk_log(double x)
 HK_HD float hk_sinf(float x) { return (float)hk_sin((double)x); }
 HK_HD float hk_cosf(float x) { return (float)hk_cos((double)x); }
 HK_HD void hk_sincosf(float x, float* s, float* c) { double ds, dc; hk_sincos((double)x, &ds, &dc); *s = (float)ds; *c = (float)dc; }
+HK_HD void hk_sincosf_near0(float x, float* s, float* c) { double ds, dc; hk_sincos_near0((double)x, &ds, &dc); *s = (float)ds; *c = (float)dc; }
 HK_HD float hk_atan2f(float y, float x) { return (float)hk_atan2((double)y, (double)x); }
 HK_HD float hk_expf(float x) { return (float)hk_exp((double)x); }
 HK_HD float hk_logf(float x) { return (float)hk_log((double)x); }

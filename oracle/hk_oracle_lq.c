@@ -15,6 +15,7 @@ double hko_exp(double x) { return hk_exp(x); }
 double hko_log(double x) { return hk_log(x); }
 float hko_expf_fast(float x) { return hk_expf_fast(x); }
 void hko_sincos(double x, double* s, double* c) { hk_sincos(x, s, c); }
+void hko_sincos_near0(double x, double* s, double* c) { hk_sincos_near0(x, s, c); }
 
 /* KartMPC index constants (AI/MPC/KartMPC.cs:15-18) */
 enum { XI = 0, ZI = 1, VI = 2, HI = 3 };

@@ -107,9 +107,15 @@ def test_sincos_pair_is_bit_identical_to_sin_and_cos():
     xs = np.concatenate([r.uniform(-7, 7, 20000), r.uniform(-1e4, 1e4, 5000), r.uniform(-1e-3, 1e-3, 2000),
                          [0.0, -0.0, np.pi / 2, np.pi, 3 * np.pi / 2, 2 * np.pi, 0.78539816339744828]])
     xs = np.concatenate([xs, xs.astype(np.float32).astype(np.float64)])
+    L.hko_sincos_near0.restype = None
+    L.hko_sincos_near0.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    xs = np.concatenate([xs, r.uniform(-0.79, 0.79, 20000), [0.78, -0.78, np.nextafter(0.78, 0), np.nextafter(0.78, 1), 0.7853981633974483]])
     s, c = C.c_double(), C.c_double()
+    s0, c0 = C.c_double(), C.c_double()
     for x in xs:
         L.hko_sincos(float(x), C.byref(s), C.byref(c))
         assert s.value == L.hko_sin(float(x)) and c.value == L.hko_cos(float(x)), x
+        L.hko_sincos_near0(float(x), C.byref(s0), C.byref(c0))            # the reduction-free path for small angles: same bits
+        assert s0.value == s.value and c0.value == c.value and np.signbit(s0.value) == np.signbit(s.value), x
         assert (s.value == 0.0) == (L.hko_sin(float(x)) == 0.0)          # also the sign of zero
         assert np.signbit(s.value) == np.signbit(L.hko_sin(float(x))) and np.signbit(c.value) == np.signbit(L.hko_cos(float(x)))
