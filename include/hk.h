@@ -270,14 +270,16 @@ int hk_obs_dim(hk_handle h);
 int hk_get_observations(hk_handle h, float* obs);
 
 int hk_get_agent_state(hk_handle h, hk_agent_state* out /*[E][A]*/);
-int hk_set_agent_state(hk_handle h, const hk_agent_state* in /*[E][A]*/);
+int hk_set_agent_state(hk_handle h, const hk_agent_state* in /*[E][A]*/);   /* (MCTS agents: bestStates are copied into the new records on the next tick) */
 int hk_get_env_state(hk_handle h, hk_env_state* out /*[E]*/);
 int hk_set_env_state(hk_handle h, const hk_env_state* in /*[E]*/);
 int hk_get_episode_results(hk_handle h, hk_episode_result* out /*[E][A]*/);
 /* Agent.SendInfo: reward[E][A] = m_Reward, group_reward[E][A] = m_GroupReward collected since the last call; both reset to 0 */
 int hk_get_rewards(hk_handle h, float* reward, float* group_reward);
 int hk_get_lq_debug(hk_handle h, int env, int ego, hk_lq_debug* out);
-/* planner state of every agent, [E][A] (zeros for agents that are not HighMode MCTS) */
+/* planner state of every agent, [E][A] (zeros for agents that are not HighMode MCTS).  Searches are batched over hk_step calls
+ * (at most 32 armed ticks, well inside the 41+ ticks a plan has until it is due): this call runs whatever is still queued first,
+ * so `pend` always holds the result of the last request. */
 int hk_get_mcts_state(hk_handle h, hk_mcts_state* out /*[E][A]*/);
 
 /* KartLQR.solveFeedbackLQR (AI/LQR/KartLQR.cs:17) batched, 1:1 incl. quirks Q1 (block-transposed LHS) and Q2.
