@@ -74,6 +74,11 @@ def test_create_rejects_bad_planner_budgets():
     for kw in (dict(mcts_latency_ticks=4), dict(mcts_latency_ticks=120), dict(mcts_iterations=0), dict(tree_search_depth=[9, 5])):
         with pytest.raises(hk.HkError):
             hk.RacingEnv(hk.make_config(2, 2, high_mode=[MC, FX], **{**dict(tree_search_depth=[8, 5]), **kw}))
+    # a tree pool beyond 65 535 nodes per search (1 + iterations x (depth x agents + 1)) is refused, not truncated
+    with pytest.raises(hk.HkError) as e:
+        hk.RacingEnv(hk.make_config(2, 2, high_mode=[MC, FX], tree_search_depth=[8, 5], mcts_iterations=4000))
+    assert e.value.code == _lib.HK_ERR_UNSUPPORTED
+    hk.RacingEnv(hk.make_config(2, 2, high_mode=[MC, FX], tree_search_depth=[8, 5], mcts_iterations=2000)).close()   # 1 + 3334 x 17 nodes fits
 
 
 def test_tick_by_tick_stepping_defers_but_never_misses_a_plan():
