@@ -27,7 +27,8 @@ __device__ inline void inv_transform_point(const hk_agent_state* a, float fx, fl
 }
 
 // 16 lanes per agent: lanes 0-8 cast one sensor ray each (Physics.Raycast vs TrackMask and vs AgentMask), lanes 9-13 write the
-// upcoming sections (strided when sectionHorizon > 5), lane 14 the agent's own block, lane 15 the blocks of the other karts.
+// upcoming sections (strided when sectionHorizon > 5), lane 14 the agent's own block; the blocks of the other karts are written by
+// lanes 0 .. A - 2 (one kart each) before they turn to their ray or section.
 // Lane l of the group first evaluates the forward vector of kart l % A (one fp64 sin/cos pair per lane instead of A per
 // agent) and the group shares them by shuffles.
 constexpr int OBS_LANES = 16;
@@ -75,30 +76,32 @@ __global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_
         o[5] = a->section_index * 1.0f / goal;
         o[6] = is_straight(P, T, a->section_index) ? 1.0f : 0.0f;
         o[7] = tire_wear(P, a->final_steer);
-    } else if (l == 15) {                                                    // team mates, then opponents HKA:500-527
-        int p = 8;
-        for (int pass = 0; pass < 2; pass++) {
-            const int cnt = pass == 0 ? P.n_team[i] : P.n_other[i];
-            for (int j = 0; j < cnt; j++) {
-                const int bj = pass == 0 ? P.team[i][j] : P.other[i][j];
-                const hk_agent_state* b = &ags[bj];
-                float bfx = kfx[0], bfz = kfz[0];
+    }
+    // team mates, then opponents HKA:500-527: block q of the list is written by lane q of the group (one kart each, side by side,
+    // instead of one lane walking all of them while the other fifteen wait)
+    if (l < P.n_team[i] + P.n_other[i]) {
+        const int nt = P.n_team[i];
+        const int bj = l < nt ? P.team[i][l] : P.other[i][l - nt];
+        int p = 8 + 12 * l;
+        const hk_agent_state* b = &ags[bj];
+        float bfx = kfx[0], bfz = kfz[0];
 #pragma unroll
-                for (int q = 1; q < GA; q++) if (bj == q) { bfx = kfx[q]; bfz = kfz[q]; }
-                o[p++] = local_speed(P, b, bfx, bfz);
-                o[p++] = (b->flags & HK_F_ACCEL) ? 1.0f : 0.0f;
-                o[p++] = (float)b->lane;
-                o[p++] = b->lane_changes * 1.0f / P.max_lane_changes;
-                o[p++] = (b->flags & HK_F_ACTIVE) ? 1.0f : 0.0f;
-                o[p++] = is_straight(P, T, b->section_index) ? 1.0f : 0.0f;
-                o[p++] = tire_wear(P, b->final_steer);
-                o[p++] = b->section_index * 1.0f / goal;
-                o[p++] = mag3(b->px - a->px, 0.0f, b->pz - a->pz);
-                float lp[3];
-                inv_transform_point(a, fx, fz, b->px, P.kart_y, b->pz, P.kart_y, lp);
-                o[p++] = lp[0]; o[p++] = lp[1]; o[p++] = lp[2];
-            }
-        }
+        for (int q = 1; q < GA; q++) if (bj == q) { bfx = kfx[q]; bfz = kfz[q]; }
+        o[p++] = local_speed(P, b, bfx, bfz);
+        o[p++] = (b->flags & HK_F_ACCEL) ? 1.0f : 0.0f;
+        o[p++] = (float)b->lane;
+        o[p++] = b->lane_changes * 1.0f / P.max_lane_changes;
+        o[p++] = (b->flags & HK_F_ACTIVE) ? 1.0f : 0.0f;
+        o[p++] = is_straight(P, T, b->section_index) ? 1.0f : 0.0f;
+        o[p++] = tire_wear(P, b->final_steer);
+        o[p++] = b->section_index * 1.0f / goal;
+        o[p++] = mag3(b->px - a->px, 0.0f, b->pz - a->pz);
+        float lp[3];
+        inv_transform_point(a, fx, fz, b->px, P.kart_y, b->pz, P.kart_y, lp);
+        o[p++] = lp[0]; o[p++] = lp[1]; o[p++] = lp[2];
+    }
+    if (l == 14 || l == 15) {
+        // (lane 14 wrote the own block above)
     } else if (l >= 9) {                                                     // upcoming sections HKA:530-552
         for (int q = l - 9; q < H; q += 5) {
             const int next = (a->section_index + 1 + q) % L;
