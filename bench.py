@@ -2,14 +2,25 @@
 """bench.py — env-steps/s of the 4-agent Oval Fixed-LQNG race, 65 536 parallel envs per GPU (BASELINE.json configs[1]).
 
   python bench.py --gpus N --steps K --warmup W
-A "step" is one Unity FixedUpdate tick of EVERY env on the rank (K_A begin + K_B SolveLQR + K_C vehicle/engine kernels),
-state resident in HBM.  For N > 1 the driver launches one rank per GPU with torch.distributed.run; envs shard
-contiguously over ranks (no data-path collective), and the episode results are all-gathered over RCCL after the timed
-region (the path's only exchange step).  Rank 0 prints ONE JSON line.
+
+A "step" is one Unity FixedUpdate tick of EVERY env on the rank (hk_step: rounds of the fused tick kernel + the queued
+multi-player LQ solves), state resident in HBM.  Protocol of the default workload (the metric is the
+STEADY STATE of the race, ticks 512..3584):
+    reset -> PRE-ROLL to tick 512 (untimed set-up, --preroll) -> W warm-up ticks (untimed) -> EXACTLY K timed ticks,
+bracketed by barrier + synchronize on both sides, max over ranks.  `config.ticks` states the tick range that was timed.
+After the timed region the same process also measures, as labelled secondary fields, the full BASELINE protocol
+(ticks 512..3584 of a fresh race) and the race start (ticks 0..512: everyone within 8 m, 4-player games).
+
+--gpus N with N > 1: when WORLD_SIZE is not set, THIS process starts N ranks (python -m torch.distributed.run, one per GPU)
+as a child BEFORE anything touches the GPU, relays the child's JSON line and exits with its code; it fails cleanly when the
+box has fewer than N GPUs.  Under torch.distributed.run (WORLD_SIZE set) it is one rank: envs shard contiguously over ranks
+(no data-path collective), the episode results are all-gathered over RCCL after the timed region (the path's only exchange
+step), rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -20,31 +31,167 @@ ALGO_BYTES_PER_ENV_STEP = 1056.0       # state in + state out at 
 ALGO_FLOP_PER_ENV_STEP = 330e3         # dense-equivalent fp64 flop (4 ego solves x 322 kflop / 4-tick cadence + physics)
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VECTOR_PEAK_TFLOPS = 78.6         # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
+FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32-input MFMA = the fp32 vector rate
+STEADY_TICK = 512                      # steady state = ticks 512 .. 3584
 
 
-def cpu_baseline(num_agents, warmup, seed):
-    """The CPU oracle (a line-by-line port of the reference C#, NOT the reference itself: no dotnet/Unity on the box)
-    timed on the host cores with OpenMP over envs, on a bounded sample of the same workload."""
+def lq_flop(N, sweeps=4):
+    """dense flop of one KartLQR.solveFeedbackLQR call with N players (SURVEY §8 a1 formula; horizon 3 = 4 sweeps)"""
+    n, m = 4 * N, 2 * N
+    return sweeps * (N * (4 * n ** 3 + 12 * n ** 2) + 2.0 / 3 * m ** 3 + 2 * m * m * (n + 1) + 2 * m * n)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# launcher: --gpus N > 1 without WORLD_SIZE -> N ranks as a child process group (nothing here touches the GPU)
+# ----------------------------------------------------------------------------------------------------------------------
+def launch_ranks(a, argv):
+    selftest = a.selftest_launcher
+    if not selftest:
+        import torch                                   # device_count() does not initialise the GPU on this image
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            print("bench.py: --gpus %d needs %d GPUs, this box has %d" % (a.gpus, a.gpus, have), file=sys.stderr)
+            return 2
+    port = int(os.environ.get("MASTER_PORT", 29500 + (os.getpid() % 2000)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if p.returncode != 0 or line is None:
+        print("bench.py: the %d-rank child failed (exit code %d)" % (a.gpus, p.returncode), file=sys.stderr)
+        return p.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
+class Dist:
+    """the rank's view of the job: barrier, max-over-ranks of a time, the result gather (RCCL on GPUs, gloo in the CPU selftest)"""
+
+    def __init__(self, backend):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        self.backend = backend
+        import torch
+        self.torch = torch
+        if self.world > 1 or os.environ.get("HK_BENCH_FORCE_DIST") == "1":      # (the flag: exercise the RCCL path with one rank on a 1-GPU box)
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            self.dist = dist
+        self.dev = "cuda" if backend == "nccl" else "cpu"
+
+    def barrier(self, env=None):
+        if self.dist:
+            self.dist.barrier()
+        if self.backend == "nccl":
+            self.torch.cuda.synchronize()
+        if env is not None:
+            env.synchronize()
+
+    def max_time(self, dt):
+        if not self.dist:
+            return dt
+        t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.dist:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed_ticks(D, env, ticks):
+    """EXACTLY `ticks` ticks of every env on every rank, barrier + synchronize on both sides, max over ranks -> seconds"""
+    D.barrier(env)
+    t0 = time.perf_counter()
+    env.step(ticks)
+    env.synchronize()
+    D.barrier(env)
+    return D.max_time(time.perf_counter() - t0)
+
+
+def selftest_launcher(a):
+    """CPU check of the N-rank plumbing (tests/test_bench_launcher.py): rendezvous, shard ranges that do not divide,
+    barrier, max-over-ranks, the padded all-gather, one JSON line from rank 0.  No libhk compute, no GPU."""
+    import numpy as np
+    D = Dist("gloo")
+    if D.world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, D.world))
+    from hierarchicalkarting_amd.parallel import shard_range, gather_episode_results
+    from hierarchicalkarting_amd.env import RESULT_DT
+    total = a.envs_per_gpu * D.world + 1                     # +1: the last rank's shard is shorter than the others
+    lo, hi = shard_range(total, D.rank, D.world)
+    local = np.zeros((hi - lo, 2), RESULT_DT)
+    local["time_steps"] = np.arange(lo, hi, dtype=np.int32)[:, None] * 2 + np.arange(2, dtype=np.int32)[None, :]
+    D.barrier()
+    dt = D.max_time(0.001 * (D.rank + 1))
+    allres = gather_episode_results(local, D.dist)
+    ok = allres.shape == (total, 2) and bool((allres["time_steps"] == np.arange(total, dtype=np.int32)[:, None] * 2 + np.arange(2)[None, :]).all())
+    if D.rank == 0:
+        print(json.dumps({"metric": "launcher selftest", "n_gpus": D.world, "gathered_envs": int(allres.shape[0]),
+                          "gather_ok": ok, "max_time": dt, "selftest": True}), flush=True)
+    D.close()
+    return 0 if ok else 1
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle, timed beside the GPU path on rank 0 at N = 1)
+# ----------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(num_agents, seed, start_tick):
+    """the CPU oracle (a line-by-line C port of the reference C#, NOT the reference itself: no
+    dotnet / Unity on either box) at E = 4 096 on the same inputs, from the same tick the GPU window starts at; timed on
+    all host cores (OpenMP over envs, >= 16 envs per thread) and on ONE thread.  Bounded: ~10 s each."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     import hierarchicalkarting_amd as hk
-    E, ticks = 512, 200
-    b = hk.make_config(E, num_agents, jitter_seed=seed)
-    o = O.OracleEnv(b)
+    E = 4096
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    threads = max(1, min(cores, E // 16))
+    O.set_threads(threads)
+    o = O.OracleEnv(hk.make_config(E, num_agents, jitter_seed=seed))
     o.reset()
-    o.step(warmup)
-    t0 = time.perf_counter()
-    o.step(ticks)
-    dt = time.perf_counter() - t0
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return {"value": E * ticks / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "CPU oracle (C port of the reference C#), %d envs x %d ticks after %d warmup ticks, OpenMP over envs" % (E, ticks, warmup)}
+    o.step(start_tick)                                       # untimed: the same pre-roll as the GPU run
+
+    def sample(budget_s, chunk, max_ticks):
+        done, t0 = 0, time.perf_counter()
+        while done < max_ticks and (time.perf_counter() - t0) < budget_s:
+            o.step(chunk)
+            done += chunk
+        return done, time.perf_counter() - t0
+    ticks_all, dt_all = sample(10.0, 16, 2048)
+    O.set_threads(1)
+    ticks_one, dt_one = sample(10.0, 2, 256)
+    O.set_threads(threads)
+    return {"value": E * ticks_all / dt_all, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": "CPU oracle (C port of the reference C#; the reference itself cannot run here), E = %d envs, ticks %d..%d "
+                      "of the same workload, OpenMP over envs on %d threads (%d host cores visible)"
+                      % (E, start_tick, start_tick + ticks_all, threads, cores),
+            "single_thread": {"value": E * ticks_one / dt_one, "unit": "env-steps/s", "cores": 1,
+                              "sample": "same envs, the next %d ticks on 1 thread" % ticks_one}}
 
 
-FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32-input MFMA = the fp32 vector rate
-
-
-def bench_rl(a, rank, local_rank, world, dist, torch, hk):
+# ----------------------------------------------------------------------------------------------------------------------
+# workloads
+# ----------------------------------------------------------------------------------------------------------------------
+def bench_rl(a, D, hk):
     """2v2 Oval, every agent LowMode RL (HighMode Fixed): per 2-tick decision the actor of the reference's
     HierarchicalAgent-Team-*scaledown* models (312 -> 256 x 3 Swish -> {mu, 3 logits}; random-init weights of that
     architecture) runs on device for all E x 4 agents.  One JSON line, roofline of policy_mlp_kernel against the f32 MFMA."""
@@ -52,43 +199,25 @@ def bench_rl(a, rank, local_rank, world, dist, torch, hk):
     from hierarchicalkarting_amd.policy import Policy
     E = a.envs_per_gpu
     A = 4
-    env = hk.RacingEnv(hk.make_config(E, A, low_mode=[_lib.HK_LOW_RL] * A, jitter_seed=0x5EED0000, env_id_base=rank * E, device_id=local_rank))
+    env = hk.RacingEnv(hk.make_config(E, A, low_mode=[_lib.HK_LOW_RL] * A, jitter_seed=0x5EED0000, env_id_base=D.rank * E, device_id=D.local_rank))
     in_dim = env.obs_dim * 4
-    p1 = Policy.random(in_dim, 256, 3, seed=101)
-    p2 = Policy.random(in_dim, 256, 3, seed=202)
-    env.attach_policy(p1, [0, 1], 2)
-    env.attach_policy(p2, [2, 3], 2)
+    env.attach_policy(Policy.random(in_dim, 256, 3, seed=101), [0, 1], 2)
+    env.attach_policy(Policy.random(in_dim, 256, 3, seed=202), [2, 3], 2)
     env.reset()
     env.step(a.warmup)
     env.synchronize()
-
-    def barrier():
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        env.synchronize()
-
     env.prof_enable(True)
     env.prof_reset()
-    barrier()
-    t0 = time.perf_counter()
-    env.step(a.steps)
-    env.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = timed_ticks(D, env, a.steps)
     prof = env.prof_read()
-    if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if rank == 0:
+    if D.rank == 0:
         avg = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in prof.items()}
         rows = E * 2                                   # rows per launch (one launch per team policy)
         flop_row = 2.0 * (in_dim * 256 + 2 * 256 * 256 + 4 * 256)
         ms = avg["policy_mlp_kernel"]
         ach = rows * flop_row / 1e12 / (ms * 1e-3) if ms > 0 else 0.0
-        out = {"metric": "env-steps/sec (2v2 Oval, RL low-level on device)", "value": E * world * a.steps / dt, "unit": "env-steps/s",
-               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+        out = {"metric": "env-steps/sec (2v2 Oval, RL low-level on device)", "value": E * D.world * a.steps / dt, "unit": "env-steps/s",
+               "n_gpus": D.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "2v2 Oval, 4 agents LowMode RL / HighMode Fixed, %d envs per GPU, DecisionPeriod 2, one actor per team "
                                       "(%d -> 256 x 3 Swish -> mu + 3 logits, random-init weights of the reference architecture)" % (E, in_dim),
@@ -98,12 +227,10 @@ def bench_rl(a, rank, local_rank, world, dist, torch, hk):
                             "flop_per_launch": rows * flop_row, "kernel_avg_ms": avg,
                             "kernel_total_ms": {k: v[0] for k, v in prof.items()}}}
         print(json.dumps(out), flush=True)
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    D.close()
 
 
-def bench_mcts(a, rank, local_rank, world, dist, torch, hk):
+def bench_mcts(a, D, hk):
     """BASELINE.json configs[2]: 4-agent Complex track, every agent MCTS high level + LQNG low level, 16 384 envs per GPU.
     The planner's wall-clock budget of the reference is an iteration budget here (--mcts-iterations per 100-tick replan)."""
     from hierarchicalkarting_amd import _lib
@@ -116,7 +243,7 @@ def bench_mcts(a, rank, local_rank, world, dist, torch, hk):
         low = [_lib.HK_LOW_RL] * 4 + [_lib.HK_LOW_LQR] * 4
     env = hk.RacingEnv(hk.make_config(E, A, track="oval" if rl else "complex", high_mode=[_lib.HK_HIGH_MCTS] * A, tree_search_depth=8,
                                       low_mode=low,
-                                      mcts_iterations=a.mcts_iterations, jitter_seed=0x5EED0000, env_id_base=rank * E, device_id=local_rank))
+                                      mcts_iterations=a.mcts_iterations, jitter_seed=0x5EED0000, env_id_base=D.rank * E, device_id=D.local_rank))
     if rl:      # configs[3]: one 312 -> 256 x 3 actor per team (random-init weights of the reference architecture), DecisionPeriod 2
         from hierarchicalkarting_amd.policy import Policy
         env.attach_policy(Policy.random(env.obs_dim * 4, 256, 3, seed=101), [0, 1], 2)
@@ -127,32 +254,16 @@ def bench_mcts(a, rank, local_rank, world, dist, torch, hk):
     env.reset()
     env.step(a.warmup)
     env.synchronize()
-
-    def barrier():
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        env.synchronize()
-
     env.prof_enable(True)
     env.prof_reset()
-    barrier()
-    t0 = time.perf_counter()
-    env.step(a.steps)
-    env.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = timed_ticks(D, env, a.steps)
     prof = env.prof_read()
-    if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if rank == 0:
+    if D.rank == 0:
         m = env.mcts_state()
         out = {"metric": "env-steps/sec (8-agent Complex, mixed MCTS-RL vs MCTS-LQNG)" if a8 else
                          ("env-steps/sec (2v2 OvalDuos, MCTS-RL)" if rl else "env-steps/sec (4-agent Complex, MCTS-LQNG)"),
-               "value": E * world * a.steps / dt, "unit": "env-steps/s",
-               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+               "value": E * D.world * a.steps / dt, "unit": "env-steps/s",
+               "n_gpus": D.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": ("8-agent (4v4, synthetic: the reference has no 8-agent scene) Complex track, " if a8 else
                                        ("2v2 Oval, " if rl else "4-agent Complex track (41 sections), ")) +
@@ -162,150 +273,264 @@ def bench_mcts(a, rank, local_rank, world, dist, torch, hk):
                           "envs_per_gpu": E, "agents": A,
                           "searches_per_agent_mean": float(m["searches"].mean())},
                "kernel_total_ms": {k: v[0] for k, v in prof.items()},
-               "note": "the planner kernel (mcts_search_kernel, one lane per search) is not bracketed by hk_prof: its share = wall time - the stages above"}
+               "note": "the planner kernel (mcts_search_kernel) is not bracketed by hk_prof: its share = wall time - the stages above"}
         print(json.dumps(out), flush=True)
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    D.close()
+
+
+def bench_lqbatch(a, D, hk):
+    """K1 alone (SURVEY §7 minimum slice): hk_lq_solve_batch_device on 262 144 random N-player games resident in HBM, N = 2 and 4;
+    solves/s, algorithmic GB/s and the fraction of the fp64 vector peak (dense flop formula of SURVEY §8 a1)."""
+    import ctypes as C
+    import numpy as np
+    from hierarchicalkarting_amd import _lib
+    torch = D.torch
+
+    def random_game(rng, N):
+        """inputs with the structure SolveLQR hands to solveFeedbackLQR (HKA:726-1198): linearised bicycles about random kart
+        states, reach-avoid costs with weights in the ranges the heuristics generate.  (A, B, Q, q, R, x0)"""
+        n = 4 * N
+        near = max(N - 1, 1)
+        dt = 0.02
+        As, Bs, Qs, qs, Rs, x0 = [], [], [], [], [], []
+        for k in range(N):
+            x, z, v, th = rng.uniform(-50, 25), rng.uniform(-50, 65), rng.uniform(0, 15), rng.uniform(0, 2 * np.pi)
+            x0 += [x, z, v, th]
+            Ak = np.eye(4)
+            Ak[0, 2], Ak[1, 2], Ak[0, 3], Ak[1, 3] = np.cos(th) * dt, np.sin(th) * dt, -np.sin(th) * dt * v, np.cos(th) * dt * v
+            Bk = np.zeros((4, 2)); Bk[2, 0] = dt; Bk[3, 1] = dt
+            tw = np.array([near * 0.93 / max(1, v), near * 0.93 / max(1, v), near * 5e-4, 2.5 * near])
+            tgt = np.array([x + rng.uniform(-10, 10), z + rng.uniform(-10, 10), 15.0, th + rng.uniform(-0.6, 0.6)])
+            Q = np.zeros((n, n)); q = np.zeros(n)
+            for j in range(1, N):                              # avoid terms on (x, z) pairs, then the opponent-target diagonal
+                w = 1.0 / (rng.uniform(1.0, 8.0) ** 1.5 * 1.3 / near)
+                for s_ in range(2):
+                    Q[s_, s_] -= w; Q[s_, 4 * j + s_] = w; Q[4 * j + s_, s_] = w
+                ow = np.array([0.1 / (max(1, v) * near), 0.1 / (max(1, v) * near), 0.08 / near])
+                ot = np.array([rng.uniform(-50, 25), rng.uniform(-50, 65), 15.0])
+                for s_ in range(3):
+                    Q[4 * j + s_, 4 * j + s_] = -ow[s_]; q[4 * j + s_] = -ow[s_] * ot[s_]
+            for s_ in range(4):
+                Q[s_, s_] += tw[s_]; q[s_] = -tgt[s_] * tw[s_]
+            As.append(Ak); Bs.append(Bk); Qs.append(Q); qs.append(q); Rs.append(np.eye(2) * (0.135 if N > 2 else 0.115))
+        return As, Bs, Qs, qs, Rs, np.array(x0)
+
+    L = _lib.load()
+    h = C.c_void_p()
+    _lib.check(L.hk_create(None, C.byref(h)), None)
+    batch = a.lq_batch
+    rows = {}
+    for N in (2, 4):
+        rng = np.random.default_rng(1000 + N)
+        base = [random_game(rng, N) for _ in range(256)]
+        arrs = [np.array([g[k] for g in base]) for k in range(6)]
+        dev = []
+        for x in arrs:                                     # tile the 256 distinct games to the batch, on device
+            t = torch.from_numpy(np.ascontiguousarray(x, np.float64)).cuda()
+            reps = [batch // 256] + [1] * (t.dim() - 1)
+            dev.append(t.repeat(*reps).contiguous())
+        u0 = torch.zeros(batch, 2, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+
+        def run():
+            _lib.check(L.hk_lq_solve_batch_device(h, batch, N, ptr(dev[0]), ptr(dev[1]), ptr(dev[2]), ptr(dev[3]), ptr(dev[4]), ptr(dev[5]), 3, ptr(u0), None), h)
+        for _ in range(a.warmup if a.warmup < 50 else 5):
+            run()
+        _lib.check(L.hk_synchronize(h), h)
+        _lib.check(L.hk_prof_enable(h, 1), h)
+        _lib.check(L.hk_prof_reset(h), h)
+        iters = a.steps if a.steps < 500 else 20
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            run()
+        _lib.check(L.hk_synchronize(h), h)
+        dt = time.perf_counter() - t0
+        ms = (C.c_double * _lib.HK_PROF_STAGES)()
+        n = (C.c_int64 * _lib.HK_PROF_STAGES)()
+        _lib.check(L.hk_prof_read(h, ms, n), h)
+        k_ms = ms[2] / max(n[2], 1)
+        nn = 4 * N
+        bytes_game = 8.0 * (N * 16 + N * 8 + N * nn * nn + N * nn + N * 4 + nn + 2)
+        tf = batch * lq_flop(N) / 1e12 / (k_ms * 1e-3)
+        rows["N%d" % N] = {"solves_per_s_wall": batch * iters / dt, "solves_per_s_kernel": batch / (k_ms * 1e-3), "kernel_ms": k_ms,
+                           "dense_flop_per_solve": lq_flop(N), "achieved_tflops": tf, "frac_fp64_vector_peak": tf / FP64_VECTOR_PEAK_TFLOPS,
+                           "algorithmic_bytes_per_solve": bytes_game, "achieved_gbs": batch * bytes_game / 1e9 / (k_ms * 1e-3),
+                           "frac_hbm_peak": batch * bytes_game / 1e9 / (k_ms * 1e-3) / HBM_PEAK_GBS}
+    r4 = rows["N4"]
+    out = {"metric": "LQ Nash solves/sec (hk_lq_solve_batch, N = 4 players, batch 262 144)", "value": r4["solves_per_s_wall"], "unit": "solves/s",
+           "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": r4["kernel_ms"], "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "KartLQR.solveFeedbackLQR batched: %d random games per launch (256 distinct, tiled), horizon 3, dense Q / q / R inputs" % batch},
+           "roofline": {"bound": "fp64_valu", "kernel": "lq_batch_kernel<4>", "achieved": r4["achieved_tflops"], "peak": FP64_VECTOR_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": r4["frac_fp64_vector_peak"], "traffic": None},
+           "per_N": rows}
+    print(json.dumps(out), flush=True)
+    L.hk_destroy(h)
+    D.close()
+
+
+def bench_lqng(a, D, hk):
+    """the headline: BASELINE.json configs[1]"""
+    import numpy as np
+    from hierarchicalkarting_amd.parallel import gather_episode_results
+    E, A = a.envs_per_gpu, a.agents
+    seed = 0x5EED0000
+    env = hk.RacingEnv(hk.make_config(E, A, jitter_seed=seed, env_id_base=D.rank * E, device_id=D.local_rank))
+    env.reset()
+    if a.preroll > 0:
+        env.step(a.preroll)                              # untimed set-up: to the start of the steady state
+    if a.warmup > 0:
+        env.step(a.warmup)
+    env.synchronize()
+    env.prof_enable(True)
+    env.prof_reset()
+    dt = timed_ticks(D, env, a.steps)
+    prof = env.prof_read()
+    games = env.prof_games()
+    env.prof_enable(False)
+    st = env.agent_state() if D.rank == 0 else None
+    # the path's one exchange step: all-gather of the episode results (RCCL over xGMI), off the timed region
+    results = gather_episode_results(env, D.dist)
+    value = E * D.world * a.steps / dt
+    t_first = a.preroll + a.warmup
+
+    # secondary, labelled: the full BASELINE protocol window and the race start, each on a fresh race
+    secondary = {}
+    if not a.no_secondary:
+        env.reset()
+        dt_rs = timed_ticks(D, env, STEADY_TICK)
+        prof_rs = None
+        env.prof_enable(True); env.prof_reset()
+        dt_full = timed_ticks(D, env, 3072)
+        prof_full = env.prof_read()
+        games_full = env.prof_games()
+        env.prof_enable(False)
+        secondary = {
+            "baseline_protocol_ticks_512_3584": {"value": E * D.world * 3072 / dt_full, "unit": "env-steps/s", "seconds": dt_full,
+                                                 "kernel_total_ms": {k: v[0] for k, v in prof_full.items() if v[1]},
+                                                 "launches": {k: v[1] for k, v in prof_full.items() if v[1]},
+                                                 "multi_player_games": {str(k): v for k, v in games_full.items() if v}},
+            "race_start_ticks_0_512": {"value": E * D.world * STEADY_TICK / dt_rs, "unit": "env-steps/s", "seconds": dt_rs,
+                                       "note": "start hold + everyone within 8 m: every ego solves a 4-player game"}}
+
+    if D.rank == 0:
+        avg = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in prof.items()}           # ms per launch, HIP events on the handle's stream
+        tot = {k: v[0] for k, v in prof.items()}
+        dom = max(tot, key=lambda k: tot[k])                                         # the stage with the largest total in THIS run
+        dom_ms, dom_n = avg[dom], max(prof[dom][1], 1)
+        # players per game over the live egos at the end of the timed region
+        live = (st["flags"] & 4) != 0
+        dx = st["px"][:, :, None] - st["px"][:, None, :]
+        dz = st["pz"][:, :, None] - st["pz"][:, None, :]
+        near = (np.sqrt(dx * dx + dz * dz) < 8.0).sum(axis=2)                        # players within 8 m incl. self (HKA:714)
+        hist = np.bincount(near[live].ravel(), minlength=A + 1)[1:]
+        hist = (hist / max(hist.sum(), 1)).round(4).tolist()
+        exec_flop = sum(h * lq_flop(i + 1) for i, h in enumerate(hist)) * A / (4 if A > 2 else 1) + 2000.0 * A
+        tick_ms = dt / a.steps * 1e3
+        if dom == "env_run_kernel":
+            # one launch of the fused kernel advances the envs by a variable number of ticks (<= RUN_CAP): units per launch =
+            # env-steps of the timed region / launches of the timed region; algorithmic bytes = 1 056 B x that
+            algo = ALGO_BYTES_PER_ENV_STEP * (A / 4.0) * E * a.steps / dom_n
+            achieved = algo / 1e9 / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
+            roof = {"bound": "hbm", "kernel": "env_run_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": algo,
+                    "traffic_note": "HBM bytes are not measurable in-process; the --pmc passes of this command are under profiles/ (r02_pmc_summary.json)"}
+        else:
+            # the multi-player solver dominates (race start / close racing): price it against the fp64 vector peak with the
+            # dense flop count of the games it actually solved in this run (hk_prof_games)
+            flop = sum(n * lq_flop(N) for N, n in games.items()) / dom_n
+            achieved = flop / 1e12 / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
+            roof = {"bound": "fp64_valu", "kernel": "lqn_all_kernel (lqn_body<2,3,4>)", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "dense_flop_per_launch": flop}
+        roof.update({"avg_launch_ms": dom_ms, "launches": prof[dom][1], "chosen_as": "largest total_ms among the stages of this run",
+                     "kernel_total_ms": tot, "kernel_avg_ms": avg, "multi_player_games_solved": {str(k): v for k, v in games.items() if v},
+                     "whole_job_hbm": {"achieved": ALGO_BYTES_PER_ENV_STEP * (A / 4.0) * E / 1e9 / (tick_ms * 1e-3),
+                                       "frac": ALGO_BYTES_PER_ENV_STEP * (A / 4.0) * E / 1e9 / (tick_ms * 1e-3) / HBM_PEAK_GBS,
+                                       "note": "algorithmic bytes of the timed region / its wall time (all kernels + launch gaps)"},
+                     "fp64_valu": {"dense_equivalent_flop_per_env_step_N4": ALGO_FLOP_PER_ENV_STEP,
+                                   "executed_flop_per_env_step_at_measured_N": exec_flop,
+                                   "achieved_tflops_dense_equivalent": ALGO_FLOP_PER_ENV_STEP * value / D.world / 1e12,
+                                   "achieved_tflops_at_measured_N": exec_flop * value / D.world / 1e12,
+                                   "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                                   "frac_at_measured_N": exec_flop * value / D.world / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                                   "note": "SURVEY §8d priced the path at N = 4 players per game; once the field spreads (> 8 m) ~99 % of the games are single-player"}})
+        out = {
+            "metric": "env-steps/sec (4-agent Oval, batch=65k)" if (A == 4 and E == 65536) else "env-steps/sec",
+            "value": value, "unit": "env-steps/s", "n_gpus": D.world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": tick_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d-agent Oval, Fixed-LQNG vs Fixed-LQNG (2v2), %d parallel envs per GPU, seeded start jitter, auto-reset"
+                                   % (A, E), "envs_per_gpu": E, "agents": A, "sharding": "envs split contiguously over ranks",
+                       "ticks": "race ticks %d..%d timed (untimed before: pre-roll 0..%d to the steady state of BASELINE.md §3, then %d warm-up ticks)"
+                                % (t_first, t_first + a.steps, a.preroll, a.warmup),
+                       "timed_tick_range": [t_first, t_first + a.steps],
+                       "players_per_game_hist_N1..": hist,
+                       "finished_episodes_seen": int((results["episode"] >= 0).any(axis=1).sum())},
+            "roofline": roof,
+        }
+        out.update(secondary)
+        if not a.no_cpu_baseline and D.world == 1:          # reported on rank 0 at N = 1 only
+            out["cpu_baseline"] = cpu_baseline(A, seed, a.preroll)
+        print(json.dumps(out), flush=True)
+    D.close()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # 4 096 ticks per env, steady state = ticks 512-3 584 -> warm-up 512, timed 3 072
+    # BASELINE.md §3: 4 096 ticks per env, steady state = ticks 512-3 584 -> pre-roll 512 (set-up), timed 3 072
     ap.add_argument("--steps", type=int, default=3072)
-    ap.add_argument("--warmup", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--preroll", type=int, default=None, help="untimed set-up ticks before the warm-up (default: 512 for the lqng workload = "
+                                                                "the start of BASELINE.md's steady-state window, 0 otherwise)")
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--agents", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the labelled secondary measurements (protocol window, race start)")
     ap.add_argument("--mcts-iterations", type=int, default=64)
-    ap.add_argument("--workload", choices=("lqng", "rl", "mcts", "mctsrl", "a8"), default="lqng",
+    ap.add_argument("--lq-batch", type=int, default=262144)
+    ap.add_argument("--selftest-launcher", action="store_true", help="CPU check of the N-rank plumbing (gloo; no GPU, no libhk compute)")
+    ap.add_argument("--workload", choices=("lqng", "rl", "mcts", "mctsrl", "a8", "lqbatch"), default="lqng",
                     help="lqng: BASELINE.json configs[1] (the headline); rl: 2v2 Oval with the RL low-level actor on device (configs[3] shape); "
                          "mcts: 4-agent Complex track, MCTS-LQNG, 16 384 envs (configs[2]); "
                          "mctsrl: 2v2 OvalDuos, MCTS high level + RL low level on device, 32 768 envs per GPU (configs[3]); "
-                         "a8: 8-agent Complex, mixed MCTS-RL vs MCTS-LQNG, 131 072 envs per GPU (configs[4])")
+                         "a8: 8-agent Complex, mixed MCTS-RL vs MCTS-LQNG, 131 072 envs per GPU (configs[4]); "
+                         "lqbatch: hk_lq_solve_batch alone, 262 144 games, N = 2 and 4")
     a = ap.parse_args()
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if a.preroll is None:
+        a.preroll = STEADY_TICK if a.workload == "lqng" else 0
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # the parent of the ranks: must never touch HIP (a process that has initialised the GPU must not spawn-by-exec)
+        raise SystemExit(launch_ranks(a, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU)" % (a.gpus, world))
+    if a.selftest_launcher:
+        raise SystemExit(selftest_launcher(a))
+
     import torch
-    dist = None
-    if world > 1 or os.environ.get("HK_BENCH_FORCE_DIST") == "1":      # (the flag: exercise the RCCL path with one rank on a 1-GPU box)
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if torch.cuda.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: libhk has no CPU fallback")
+    D = Dist("nccl")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libhk has no CPU fallback")
-
     import __graft_entry__ as ge
-    if rank == 0:
+    if D.rank == 0:
         ge.build()
-    if dist:
-        dist.barrier()
+    if D.dist:
+        D.dist.barrier()
     import hierarchicalkarting_amd as hk
-    from hierarchicalkarting_amd.parallel import gather_episode_results
-
     if a.workload == "rl":
-        return bench_rl(a, rank, local_rank, world, dist, torch, hk)
+        return bench_rl(a, D, hk)
     if a.workload in ("mcts", "mctsrl", "a8"):
-        return bench_mcts(a, rank, local_rank, world, dist, torch, hk)
-    E = a.envs_per_gpu
-    seed = 0x5EED0000
-    env = hk.RacingEnv(hk.make_config(E, a.agents, jitter_seed=seed, env_id_base=rank * E, device_id=local_rank))
-    env.reset()
-    env.step(a.warmup)
-    env.synchronize()
-
-    def barrier():
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        env.synchronize()
-
-    env.prof_enable(True)
-    env.prof_reset()
-    barrier()
-    t0 = time.perf_counter()
-    env.step(a.steps)
-    env.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = env.prof_read()
-    env.prof_enable(False)
-    if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    # the path's one exchange step: all-gather of the episode results (RCCL over xGMI), off the timed region
-    results = gather_episode_results(env, dist)
-    total_envs = E * world
-    value = total_envs * a.steps / dt
-
-    if rank == 0:
-        avg = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in prof.items()}           # ms per launch, HIP events
-        dom = "env_run_kernel"                                                       # the fused tick kernel
-        dom_ms = avg[dom]
-        # one launch of the fused kernel advances the envs by a variable number of ticks (<= RUN_CAP = 32): the units
-        # one launch processes = env-steps of the timed region / launches of the timed region
-        algo_bytes = ALGO_BYTES_PER_ENV_STEP * E * a.steps / max(prof[dom][1], 1)
-        achieved = algo_bytes / 1e9 / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc) and E == 65536 and a.agents == 4:
-            try:
-                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # what the solves really were: players per game over the live egos at the end of the timed region
-        st = env.agent_state()
-        import numpy as np
-        live = (st["flags"] & 4) != 0
-        dx = st["px"][:, :, None] - st["px"][:, None, :]
-        dz = st["pz"][:, :, None] - st["pz"][:, None, :]
-        near = (np.sqrt(dx * dx + dz * dz) < 8.0).sum(axis=2)                        # players within 8 m incl. self (HKA:714)
-        hist = np.bincount(near[live].ravel(), minlength=a.agents + 1)[1:]
-        hist = (hist / max(hist.sum(), 1)).round(4).tolist()
-
-        def lq_flop(N):                                                              # SURVEY §8 a1 dense flop formula
-            n, m = 4 * N, 2 * N
-            return 4 * (N * (4 * n ** 3 + 12 * n ** 2) + 2.0 / 3 * m ** 3 + 2 * m * m * (n + 1) + 2 * m * n)
-        exec_flop = sum(h * lq_flop(i + 1) for i, h in enumerate(hist)) * a.agents / (4 if a.agents > 2 else 1) + 2000.0 * a.agents
-        tick_ms = dt / a.steps * 1e3
-        out = {
-            "metric": "env-steps/sec (4-agent Oval, batch=65k)" if (a.agents == 4 and E == 65536) else "env-steps/sec",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": tick_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d-agent Oval, Fixed-LQNG vs Fixed-LQNG (2v2), %d parallel envs per GPU, seeded start jitter, auto-reset"
-                                   % (a.agents, E), "envs_per_gpu": E, "agents": a.agents, "sharding": "envs split contiguously over ranks",
-                       "ticks": "warm-up %d then %d timed (BASELINE.md: steady state = ticks 512-3584)" % (a.warmup, a.steps),
-                       "players_per_game_hist_N1..": hist,
-                       "finished_episodes_seen": int((results["episode"] >= 0).any(axis=1).sum())},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": dom_ms, "launches": prof[dom][1],
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "whole_job": {"achieved": ALGO_BYTES_PER_ENV_STEP * E / 1e9 / (tick_ms * 1e-3),
-                                       "frac": ALGO_BYTES_PER_ENV_STEP * E / 1e9 / (tick_ms * 1e-3) / HBM_PEAK_GBS,
-                                       "note": "algorithmic bytes of the timed region / its wall time (all kernels + launch gaps)"},
-                         "env_run_kernel_total_ms": prof[dom][0],
-                         "kernel_avg_ms": avg,
-                         "fp64_valu": {"dense_equivalent_flop_per_env_step_N4": ALGO_FLOP_PER_ENV_STEP,
-                                       "executed_flop_per_env_step_at_measured_N": exec_flop,
-                                       "achieved_tflops_dense_equivalent": ALGO_FLOP_PER_ENV_STEP * value / world / 1e12,
-                                       "achieved_tflops_at_measured_N": exec_flop * value / world / 1e12,
-                                       "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                                       "frac_at_measured_N": exec_flop * value / world / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                                       "note": "SURVEY §8d priced the path at N = 4 players per game; once the field spreads (> 8 m) ~99 % of the games are single-player"}},
-        }
-        if not a.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(a.agents, a.warmup, seed)
-        print(json.dumps(out), flush=True)
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        return bench_mcts(a, D, hk)
+    if a.workload == "lqbatch":
+        return bench_lqbatch(a, D, hk)
+    return bench_lqng(a, D, hk)
 
 
 if __name__ == "__main__":

@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("HK_LIB_PATH") or os.path.join(_HERE, "libhk.so")   # 
 HK_MAX_AGENTS = 8
 HK_MAX_SECTIONS = 64
 HK_NUM_SENSORS = 9
-HK_ABI_VERSION = 2
+HK_ABI_VERSION = 3
 HK_PROF_STAGES = 5
 PROF_STAGE_NAMES = ("env_run_kernel", "lqn_kernel<2,3,4>", "lq_batch_kernel", "policy_mlp_kernel", "observe+stack")
 HK_COMM_ID_BYTES = 128
@@ -72,7 +72,7 @@ class Config(C.Structure):
         ("time_precision", _I8), ("section_window", _I8), ("mcts_iterations", C.c_int32),
         ("mcts_initial_iterations", C.c_int32), ("mcts_latency_ticks", C.c_int32), ("mcts_initial_latency_ticks", C.c_int32),
         ("mcts_seed", C.c_uint32), ("rewards", C.c_int32), ("training_agent", _I8), ("rw", RewardParams),
-        ("train_seed", C.c_uint32), ("reserved_cfg", C.c_int32),
+        ("train_seed", C.c_uint32), ("debug_taps", C.c_int32),
     ]
 
 
@@ -183,6 +183,8 @@ SYMBOLS = {
     "hk_prof_enable": (C.c_int, [_H, C.c_int]),
     "hk_prof_reset": (C.c_int, [_H]),
     "hk_prof_read": (C.c_int, [_H, _dp, C.POINTER(C.c_int64)]),
+    "hk_prof_games": (C.c_int, [_H, C.POINTER(C.c_int64)]),
+    "hk_gather_count": (C.c_int, [_H, C.POINTER(C.c_int64)]),
 }
 
 _lib = None

@@ -9,10 +9,16 @@
 #include <utility>
 #include <new>
 #include "../../include/hk.h"
-#include "hk_lq_kernels.h"
+#include "hk_lq_core.h"
 #include "hk_env_kernels.h"
 #include "hk_policy.h"
 #include <dlfcn.h>
+
+namespace hk {
+// hk_lq_batch.hip
+int lq_batch_launch(int batch, int N, const double* dA, const double* dB, const double* dQ, const double* dq, const double* dR,
+                    const double* dx0, int horizon, double* du0, int* d_status, hipStream_t st);
+}
 
 namespace {
 
@@ -89,6 +95,8 @@ struct hk_context {
     int comm_world = 0, comm_rank = 0;
     void* gather_buf = nullptr;
     size_t gather_bytes = 0;
+    void* gather_cnt = nullptr;    // per-rank byte counts of the gather (ranks may hold different env counts)
+    size_t gather_cnt_bytes = 0;
 };
 
 namespace {
@@ -194,6 +202,7 @@ void hk_destroy(hk_handle h)
     if (h->lq_scratch) (void)hipFree(h->lq_scratch);
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     if (h->gather_buf) (void)hipFree(h->gather_buf);
+    if (h->gather_cnt) (void)hipFree(h->gather_cnt);
     if (h->pol_scratch) (void)hipFree(h->pol_scratch);
     for (int p = 0; p < HK_MAX_POLICIES; p++) hk::policy_free(h->policy[p]);
     h->prof.fold();
@@ -224,16 +233,8 @@ int hk_lq_solve_batch_device(hk_handle h, int batch, int N, const double* dA, co
     HK_HIP(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     hipEvent_t pe0 = h->prof.begin(st);
-    switch (N) {
-#define HK_LQ_CASE(NP)                                                                                                   \
-    case NP: {                                                                                                           \
-        const int gpw = hk::LqDims<NP>::GPW;                                                                             \
-        hipLaunchKernelGGL(hk::lq_batch_kernel<NP>, dim3((batch + gpw - 1) / gpw), dim3(64), 0, st, batch, dA, dB, dQ, dq, dR, \
-                           dx0, horizon, du0, h->d_status);                                                              \
-    } break;
-        HK_LQ_CASE(1) HK_LQ_CASE(2) HK_LQ_CASE(3) HK_LQ_CASE(4) HK_LQ_CASE(5) HK_LQ_CASE(6) HK_LQ_CASE(7) HK_LQ_CASE(8)
-#undef HK_LQ_CASE
-    }
+    if (hk::lq_batch_launch(batch, N, dA, dB, dQ, dq, dR, dx0, horizon, du0, h->d_status, st) == HK_ERR_UNSUPPORTED)
+        return fail(h, HK_ERR_UNSUPPORTED, "hk_lq_solve_batch: N > 8 players not built");
     HK_HIP(h, hipGetLastError());
     h->prof.end(2, pe0, st);
     return HK_OK;
@@ -434,6 +435,8 @@ int hk_policy_attach(hk_handle h, const hk_policy_desc* desc, const int32_t* age
                 if (h->policy[p].q.slots[q] == a) return fail(h, HK_ERR_INVALID, "hk_policy_attach: agent slot already has a policy");
         for (int q = 0; q < j; q++) if (agent_slots[q] == a) return fail(h, HK_ERR_INVALID, "hk_policy_attach: duplicate agent slot");
     }
+    if (h->n_policies > 0 && decision_period != h->decision_period)
+        return fail(h, HK_ERR_INVALID, "hk_policy_attach: decision_period differs from the policies already attached (DecisionRequester is per handle)");
     const int idx = h->n_policies;
     rc = hk::policy_upload(h->policy[idx], desc, idx, hk_obs_dim(h), agent_slots, n_slots, h->cfg.num_envs, h->stream, h->err);
     if (rc) { hk::policy_free(h->policy[idx]); g_last_error = h->err; return rc; }
@@ -594,19 +597,81 @@ int hk_gather_results(hk_handle h, hk_episode_result* all)
     if (!all) return fail(h, HK_ERR_INVALID, "hk_gather_results: NULL pointer");
     if (!h->comm) return fail(h, HK_ERR_INVALID, "hk_gather_results: call hk_comm_init first");
     { int rc = check_device_status(h); if (rc) return rc; }
+    const int W = h->comm_world;
     const size_t local = (size_t)h->cfg.num_envs * h->cfg.num_agents * sizeof(hk_episode_result);
-    const size_t total = local * (size_t)h->comm_world;
+    // Ranks may hold different env counts (a contiguous split of a total that the world size does not divide): exchange the
+    // byte counts first (8 bytes per rank), pad every contribution to the largest, gather, and trim on the way to the host.
+    const size_t cnt_bytes = (size_t)W * sizeof(unsigned long long);
+    if (cnt_bytes + sizeof(unsigned long long) > h->gather_cnt_bytes) {
+        if (h->gather_cnt) HK_HIP(h, hipFree(h->gather_cnt));
+        h->gather_cnt = nullptr; h->gather_cnt_bytes = 0;
+        HK_HIP(h, hipMalloc(&h->gather_cnt, cnt_bytes + sizeof(unsigned long long)));
+        h->gather_cnt_bytes = cnt_bytes + sizeof(unsigned long long);
+    }
+    unsigned long long* d_cnt = (unsigned long long*)h->gather_cnt;          // [W] gathered, [W] = this rank's word
+    const unsigned long long mine = (unsigned long long)local;
+    HK_HIP(h, hipMemcpyAsync(d_cnt + W, &mine, sizeof(mine), hipMemcpyHostToDevice, h->stream));
+    int rc = g_rccl.AllGather(d_cnt + W, d_cnt, sizeof(unsigned long long), /*ncclChar*/ 0, h->comm, h->stream);
+    if (rc != 0) return fail(h, HK_ERR_HIP, "ncclAllGather (sizes): " + g_rccl.why(rc));
+    std::vector<unsigned long long> cnt((size_t)W);
+    HK_HIP(h, hipMemcpyAsync(cnt.data(), d_cnt, cnt_bytes, hipMemcpyDeviceToHost, h->stream));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    size_t per = 0;
+    for (int r = 0; r < W; r++) {
+        if (cnt[r] % ((size_t)h->cfg.num_agents * sizeof(hk_episode_result)) != 0)
+            return fail(h, HK_ERR_INVALID, "hk_gather_results: a rank holds a different num_agents");
+        per = cnt[r] > per ? (size_t)cnt[r] : per;
+    }
+    const size_t total = per * (size_t)W + per;                              // [W] padded slots + this rank's padded send slot
     if (total > h->gather_bytes) {
         if (h->gather_buf) HK_HIP(h, hipFree(h->gather_buf));
         h->gather_buf = nullptr; h->gather_bytes = 0;
         HK_HIP(h, hipMalloc(&h->gather_buf, total));
         h->gather_bytes = total;
     }
+    char* buf = (char*)h->gather_buf;
+    const void* send = h->dev.results;
+    if (local < per) {                                                       // pad this rank's contribution
+        HK_HIP(h, hipMemsetAsync(buf + per * W, 0, per, h->stream));
+        HK_HIP(h, hipMemcpyAsync(buf + per * W, h->dev.results, local, hipMemcpyDeviceToDevice, h->stream));
+        send = buf + per * W;
+    }
     // bytes on the wire (ncclChar): the records are plain data, identical layout on every rank
-    const int rc = g_rccl.AllGather(h->dev.results, h->gather_buf, local, /*ncclChar*/ 0, h->comm, h->stream);
+    rc = g_rccl.AllGather(send, buf, per, /*ncclChar*/ 0, h->comm, h->stream);
     if (rc != 0) return fail(h, HK_ERR_HIP, "ncclAllGather: " + g_rccl.why(rc));
-    HK_HIP(h, hipMemcpyAsync(all, h->gather_buf, total, hipMemcpyDeviceToHost, h->stream));
+    char* out = (char*)all;
+    for (int r = 0; r < W; r++) {                                            // rank r's rows, trimmed to what it holds
+        if (cnt[r]) HK_HIP(h, hipMemcpyAsync(out, buf + per * r, (size_t)cnt[r], hipMemcpyDeviceToHost, h->stream));
+        out += cnt[r];
+    }
     HK_HIP(h, hipStreamSynchronize(h->stream));
+    return HK_OK;
+}
+
+int hk_gather_count(hk_handle h, int64_t* total_envs)
+{
+    HK_NEED_ENV(h);
+    if (!total_envs) return fail(h, HK_ERR_INVALID, "hk_gather_count: NULL pointer");
+    if (!h->comm) return fail(h, HK_ERR_INVALID, "hk_gather_count: call hk_comm_init first");
+    const int W = h->comm_world;
+    const size_t cnt_bytes = (size_t)W * sizeof(unsigned long long);
+    if (cnt_bytes + sizeof(unsigned long long) > h->gather_cnt_bytes) {
+        if (h->gather_cnt) HK_HIP(h, hipFree(h->gather_cnt));
+        h->gather_cnt = nullptr; h->gather_cnt_bytes = 0;
+        HK_HIP(h, hipMalloc(&h->gather_cnt, cnt_bytes + sizeof(unsigned long long)));
+        h->gather_cnt_bytes = cnt_bytes + sizeof(unsigned long long);
+    }
+    unsigned long long* d_cnt = (unsigned long long*)h->gather_cnt;
+    const unsigned long long mine = (unsigned long long)h->cfg.num_envs;
+    HK_HIP(h, hipMemcpyAsync(d_cnt + W, &mine, sizeof(mine), hipMemcpyHostToDevice, h->stream));
+    const int rc = g_rccl.AllGather(d_cnt + W, d_cnt, sizeof(unsigned long long), /*ncclChar*/ 0, h->comm, h->stream);
+    if (rc != 0) return fail(h, HK_ERR_HIP, "ncclAllGather (sizes): " + g_rccl.why(rc));
+    std::vector<unsigned long long> cnt((size_t)W);
+    HK_HIP(h, hipMemcpyAsync(cnt.data(), d_cnt, cnt_bytes, hipMemcpyDeviceToHost, h->stream));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    int64_t t = 0;
+    for (int r = 0; r < W; r++) t += (int64_t)cnt[r];
+    *total_envs = t;
     return HK_OK;
 }
 
@@ -625,8 +690,7 @@ int hk_get_rewards(hk_handle h, float* reward, float* group_reward)
     { int rc = check_device_status(h); if (rc) return rc; }
     const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
     float* d_r = h->dev.reward_out;
-    hipLaunchKernelGGL(hk::rewards_read_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->dev.agents, (int)cnt, d_r, d_r + cnt);
-    HK_HIP(h, hipGetLastError());
+    { int rc = hk::ga_ops(h->dev).launch_rewards_read(h->dev, (int)cnt, d_r, d_r + cnt, h->stream, h->err); if (rc) { g_last_error = h->err; return rc; } }
     HK_HIP(h, hipMemcpyAsync(reward, d_r, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HK_HIP(h, hipMemcpyAsync(group_reward, d_r + cnt, cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HK_HIP(h, hipStreamSynchronize(h->stream));
@@ -684,10 +748,9 @@ int hk_rewards_device(hk_handle h)
 {
     HK_NEED_ENV(h);
     const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
-    hipLaunchKernelGGL(hk::rewards_read_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->dev.agents, (int)cnt,
-                       h->dev.reward_out, h->dev.reward_out + cnt);
-    HK_HIP(h, hipGetLastError());
-    return HK_OK;
+    int rc = hk::ga_ops(h->dev).launch_rewards_read(h->dev, (int)cnt, h->dev.reward_out, h->dev.reward_out + cnt, h->stream, h->err);
+    if (rc) g_last_error = h->err;
+    return rc;
 }
 
 int hk_prof_enable(hk_handle h, int on)
@@ -705,6 +768,21 @@ int hk_prof_reset(hk_handle h)
     HK_HIP(h, hipStreamSynchronize(h->stream));
     h->prof.fold();
     for (int s = 0; s < HK_PROF_STAGES; s++) { h->prof.ms[s] = 0; h->prof.n[s] = 0; }
+    if (h->env_ready && h->dev.game_stats) {
+        HK_HIP(h, hipMemsetAsync(h->dev.game_stats, 0, 16 * sizeof(unsigned long long), h->stream));
+        HK_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    return HK_OK;
+}
+
+int hk_prof_games(hk_handle h, int64_t* games)
+{
+    HK_NEED_ENV(h);
+    if (!games) return fail(h, HK_ERR_INVALID, "hk_prof_games: NULL pointer");
+    unsigned long long g[16];
+    HK_HIP(h, hipMemcpyAsync(g, h->dev.game_stats, sizeof(g), hipMemcpyDeviceToHost, h->stream));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    for (int n = 0; n <= HK_MAX_AGENTS; n++) games[n] = (int64_t)g[n];
     return HK_OK;
 }
 

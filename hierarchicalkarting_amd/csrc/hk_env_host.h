@@ -1,0 +1,99 @@
+// hk_env_host.h — what the host side of the batched kart environment and the per-width kernel translation units share:
+// the device-buffer block (EnvDevice), scheduling constants and the table of launch entry points (GaOps) each width exports.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <cstdlib>
+#include <string>
+#include <vector>
+#include "../../include/hk.h"
+#include "hk_env_device.h"
+#include "hk_lq_core.h"
+
+namespace hk {
+
+struct EnvDevice {
+    hk_agent_state* agents = nullptr;
+    hk_env_state* envs = nullptr;
+    hk_episode_result* results = nullptr;
+    hk_lq_debug* lq_debug = nullptr;
+    float* obs = nullptr;
+    float* act_steer = nullptr;
+    int32_t* act_branch = nullptr;
+    float* reward_out = nullptr;   // [2][E][A]: m_Reward, m_GroupReward as read by hk_get_rewards / hk_rewards_device
+    int* status = nullptr;
+    unsigned long long* game_stats = nullptr;   // [16]: multi-player games solved by the lqn kernels, by player count (hk_prof_games)
+    double* games = nullptr;       // queued multi-player games, structure-of-arrays (GameSoA, hk_env_solve.h)
+    int* queue_cnt = nullptr;      // [2 sets][16] number of queued multi-player games per player count
+    int* queue = nullptr;          // [2 sets][GA - 1][E*A] game ids with N = 2 .. GA
+    int round = 0;                 // launches so far: round & 1 selects the queue set (double buffered over rounds)
+    int* env_ids = nullptr;
+    int env_ids_cap = 0;
+    // tables
+    unsigned char* tab = nullptr;  // packed track tables (EnvParams::tab)
+    int* perms = nullptr;
+    int tab_lds = 0;               // dynamic LDS bytes the env kernels are launched with (0: read tables from global)
+    // MCTS planner (hk_env_mcts.h): all null / 0 when no agent is HighMode MCTS
+    MctsDev mcts{};
+    RwDev rw{};                    // reward shaping tables (null when hk_config.rewards == 0)
+    int mset = 0;                  // planner queue set the tick kernel currently fills
+    int mcts_rounds = 0;           // rounds of the tick kernel since the last search launch
+    int mcts_ticks = 0;            // ticks armed by short hk_step calls since the last search launch (see step_ticks)
+    bool mcts_defer = false;       // the current hk_step call is short: its rounds do not launch searches themselves
+    SecGeo* sec_geo = nullptr;
+    // lane-group -> env assignment of the tick kernel, regrouped by solve phase every REGROUP_ROUNDS rounds (hk_env_run.h)
+    int* perm = nullptr;           // [E]
+    int* perm_counts = nullptr;    // [8]
+    bool perm_valid = false;
+    int rounds_since_regroup = 0;
+    EnvParams P{};
+};
+
+constexpr int MCTS_MIN_LATENCY = 40;   // (MCTS_FLUSH_ROUNDS + 1) * RUN_CAP: see flush_mcts (hk_env_launch.h)
+constexpr int MCTS_FLUSH_ROUNDS = 4;
+constexpr int MCTS_ARENA_WAVES = 2048;
+constexpr int REGROUP_ROUNDS = 48;     // the tick kernel's lane groups are re-assigned by solve phase every so many rounds (~200 ticks)
+constexpr int MCTS_DEFER_TICKS = 32;   // short hk_step calls share one search launch until this many ticks have been armed
+static_assert(MCTS_DEFER_TICKS < MCTS_MIN_LATENCY, "a deferred search must still finish before its plan is due");
+static_assert((MCTS_FLUSH_ROUNDS + 1) * RUN_CAP <= MCTS_MIN_LATENCY, "a queued search must finish before its plan is due");
+
+inline int launch_check(std::string& err, const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err = std::string(what) + ": " + hipGetErrorString(e); return HK_ERR_HIP; }
+    return HK_OK;
+}
+
+}  // namespace hk
+
+
+namespace hk {
+
+// Launch entry points of ONE lane-group width.  The env kernels are compiled per width in their own translation units
+// (hk_ga4.hip: quads, up to 4 agents per env; hk_ga8.hip: 8 lanes, the synthetic 8-agent configuration) so that they build in
+// parallel and a change to one width does not recompile the other; the API translation unit reaches them through this table.
+struct GaOps {
+    size_t (*mcts_req_bytes)();
+    int (*mcts_searches_per_wave)();
+    int (*mcts_root_words)();
+    size_t (*game_doubles_per_ego)();
+    size_t (*queue_ints_per_set)(size_t na);
+    int (*launch_mcts_table)(EnvDevice& d, int ego0, int ntab, hipStream_t stream, std::string& err);
+    int (*launch_mcts_invalidate)(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err);
+    int (*flush_mcts)(EnvDevice& d, hipStream_t stream, std::string& err);
+    int (*launch_reset)(EnvDevice& d, const int* dids, int cnt, int experiment_num, hipStream_t stream, std::string& err);
+    int (*launch_regroup)(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err);
+    int (*launch_run)(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err);
+    int (*launch_lqn)(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err);
+    int (*launch_observe)(EnvDevice& d, const hk_config& cfg, uint32_t agent_mask, hipStream_t stream, std::string& err);
+    int (*launch_arm)(EnvDevice& d, const hk_config& cfg, int n_ticks, hipStream_t stream, std::string& err);
+    int (*launch_done_check)(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err);
+    int (*launch_rewards_read)(EnvDevice& d, int cnt, float* reward, float* group_reward, hipStream_t stream, std::string& err);
+};
+const GaOps& ga_ops_g4();      // hk_ga4.hip
+const GaOps& ga_ops_g8();      // hk_ga8.hip
+inline const GaOps& ga_ops(const EnvDevice& d) { return d.P.A > 4 ? ga_ops_g8() : ga_ops_g4(); }
+
+}  // namespace hk

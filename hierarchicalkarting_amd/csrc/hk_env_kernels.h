@@ -1,88 +1,17 @@
-// hk_env_kernels.h — host side of the batched kart environment: device tables, candidate wall lists, launches.
+// hk_env_kernels.h — host side of the batched kart environment: device tables, candidate wall lists, the round scheduler.
+// (API translation unit only; the kernels live in hk_ga4.hip / hk_ga8.hip behind hk_env_host.h's GaOps table.)
 #pragma once
-#include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
-#include <string>
 #include <vector>
-#include "../../include/hk.h"
-#include "hk_env_device.h"
-#include "hk_lq_core.h"
+#include "hk_env_host.h"
 
 namespace hk {
 
-struct EnvDevice {
-    hk_agent_state* agents = nullptr;
-    hk_env_state* envs = nullptr;
-    hk_episode_result* results = nullptr;
-    hk_lq_debug* lq_debug = nullptr;
-    float* obs = nullptr;
-    float* act_steer = nullptr;
-    int32_t* act_branch = nullptr;
-    float* reward_out = nullptr;   // [2][E][A]: m_Reward, m_GroupReward as read by hk_get_rewards / hk_rewards_device
-    int* status = nullptr;
-    double* games = nullptr;       // queued multi-player games, structure-of-arrays (GameSoA, hk_env_solve.h)
-    int* queue_cnt = nullptr;      // [2 sets][16] number of queued multi-player games per player count
-    int* queue = nullptr;          // [2 sets][GA - 1][E*A] game ids with N = 2 .. GA
-    int round = 0;                 // launches so far: round & 1 selects the queue set (double buffered over rounds)
-    int* env_ids = nullptr;
-    int env_ids_cap = 0;
-    // tables
-    unsigned char* tab = nullptr;  // packed track tables (EnvParams::tab)
-    int* perms = nullptr;
-    int tab_lds = 0;               // dynamic LDS bytes the env kernels are launched with (0: read tables from global)
-    // MCTS planner (hk_env_mcts.h): all null / 0 when no agent is HighMode MCTS
-    MctsDev mcts{};
-    RwDev rw{};                    // reward shaping tables (null when hk_config.rewards == 0)
-    int mset = 0;                  // planner queue set the tick kernel currently fills
-    int mcts_rounds = 0;           // rounds of the tick kernel since the last search launch
-    int mcts_ticks = 0;            // ticks armed by short hk_step calls since the last search launch (see step_ticks)
-    bool mcts_defer = false;       // the current hk_step call is short: its rounds do not launch searches themselves
-    SecGeo* sec_geo = nullptr;
-    // lane-group -> env assignment of the tick kernel, regrouped by solve phase every REGROUP_ROUNDS rounds (hk_env_run.h)
-    int* perm = nullptr;           // [E]
-    int* perm_counts = nullptr;    // [8]
-    bool perm_valid = false;
-    int rounds_since_regroup = 0;
-    EnvParams P{};
-};
-
-constexpr int MCTS_MIN_LATENCY = 40;   // (MCTS_FLUSH_ROUNDS + 1) * RUN_CAP: see flush_mcts (hk_env_launch.h)
-constexpr int MCTS_FLUSH_ROUNDS = 4;
-constexpr int MCTS_ARENA_WAVES = 2048;
-constexpr int REGROUP_ROUNDS = 48;     // the tick kernel's lane groups are re-assigned by solve phase every so many rounds (~200 ticks)
-constexpr int MCTS_DEFER_TICKS = 32;   // short hk_step calls share one search launch until this many ticks have been armed
-static_assert(MCTS_DEFER_TICKS < MCTS_MIN_LATENCY, "a deferred search must still finish before its plan is due");
-static_assert((MCTS_FLUSH_ROUNDS + 1) * RUN_CAP <= MCTS_MIN_LATENCY, "a queued search must finish before its plan is due");
-
-inline int launch_check(std::string& err, const char* what)
-{
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { err = std::string(what) + ": " + hipGetErrorString(e); return HK_ERR_HIP; }
-    return HK_OK;
-}
-
-}  // namespace hk
-
-// the env kernels, compiled once per lane-group width (see hk_env_ga.h)
-#define HK_GA 4
-#define HK_GA_NS g4
-#include "hk_env_ga.h"
-#undef HK_GA
-#undef HK_GA_NS
-#define HK_GA 8
-#define HK_GA_NS g8
-#include "hk_env_ga.h"
-#undef HK_GA
-#undef HK_GA_NS
-
-namespace hk {
-
-using g4::rewards_read_kernel;      // does not depend on the group width
-// forward to the kernels of the handle's lane-group width
-#define HK_GA_CALL(d, call) ((d).P.A > 4 ? g8::call : g4::call)
+// forward to the kernels of the handle's lane-group width (hk_env_host.h: GaOps)
+#define HK_GA_CALL(d, call) (ga_ops(d).call)
 
 namespace detail {
 
@@ -120,7 +49,7 @@ int upload(T** dst, const std::vector<T>& v, std::string& err)
 
 inline void env_destroy(EnvDevice& d)
 {
-    void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.reward_out, d.status, d.games, d.queue_cnt, d.queue, d.env_ids, d.tab, d.perms,
+    void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.reward_out, d.status, d.game_stats, d.games, d.queue_cnt, d.queue, d.env_ids, d.tab, d.perms,
                     d.rw.sec_time, d.rw.sec_cnt, d.rw.hit_code, d.mcts.st, d.mcts.req, d.mcts.qcnt, d.mcts.queue, d.mcts.nodes, d.mcts.dt_tab, d.mcts.load_tab, d.mcts.rad_tab, d.mcts.roots, d.sec_geo, d.perm, d.perm_counts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = EnvDevice{};
@@ -134,9 +63,26 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         err = "hk_create: bad num_envs / num_agents / track table"; return HK_ERR_INVALID;
     }
     if (A > ENV_MAXA) { err = "hk_create: num_agents > 8"; return HK_ERR_UNSUPPORTED; }
+    // The round scheduler (env_rounds_for) and the planner's request queues (two requests per agent between flushes) assume an
+    // episode outlasts the start hold and a 100-tick replan period; every reference scene uses 6 000.
+    if (cfg.max_episode_steps < 100 || cfg.max_episode_steps <= cfg.start_hold_ticks) {
+        err = "hk_create: max_episode_steps must be >= 100 and exceed start_hold_ticks"; return HK_ERR_INVALID;
+    }
+    if (cfg.start_hold_ticks < 0 || cfg.laps < 1 || cfg.section_horizon < 1 || cfg.section_horizon > 16 || !(cfg.dt > 0.0f)) {
+        err = "hk_create: bad start_hold_ticks / laps / section_horizon / dt"; return HK_ERR_INVALID;
+    }
     for (int i = 0; i < A; i++) {
         if (cfg.n_team[i] < 0 || cfg.n_other[i] < 0 || cfg.n_team[i] + cfg.n_other[i] != A - 1) {
             err = "hk_create: teamAgents + otherAgents of every agent must list every other agent exactly once"; return HK_ERR_INVALID;
+        }
+        // every entry in range, not the agent itself, no duplicates (the kernels index kart arrays with them)
+        uint32_t seen = 1u << i;
+        for (int j = 0; j < cfg.n_team[i] + cfg.n_other[i]; j++) {
+            const int o = j < cfg.n_team[i] ? cfg.team_agents[i][j] : cfg.other_agents[i][j - cfg.n_team[i]];
+            if (o < 0 || o >= A || ((seen >> o) & 1u)) {
+                err = "hk_create: teamAgents / otherAgents entries must be distinct agent indices in [0, num_agents) other than the agent itself"; return HK_ERR_INVALID;
+            }
+            seen |= 1u << o;
         }
         if (cfg.high_mode[i] != HK_HIGH_FIXED && cfg.high_mode[i] != HK_HIGH_MCTS) { err = "hk_create: bad high_mode"; return HK_ERR_INVALID; }
         if (cfg.high_mode[i] == HK_HIGH_MCTS) {
@@ -192,7 +138,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         const float dyc = 0.5f - 0.582f;   // sensor height - capsule centre height (kart-local)
         P.ray_agent_r = sqrtf(CAP_R * CAP_R - dyc * dyc);
     }
-    { const char* dbg = std::getenv("HK_LQ_DEBUG"); P.debug = dbg ? std::atoi(dbg) : 0; }   // hk_get_lq_debug taps
+    { const char* dbg = std::getenv("HK_LQ_DEBUG"); P.debug = cfg.debug_taps | (dbg ? std::atoi(dbg) : 0); }   // hk_get_lq_debug taps (hk.h: debug_taps)
     // sections with forward precomputed (same float expressions as everywhere else)
     std::vector<SecDev> sd(L);
     for (int i = 0; i < L; i++) {
@@ -330,6 +276,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     HK_ALLOC(d.act_branch, na * sizeof(int32_t));
     HK_ALLOC(d.reward_out, 2 * na * sizeof(float));
     HK_ALLOC(d.status, 4 * sizeof(int));
+    HK_ALLOC(d.game_stats, 16 * sizeof(unsigned long long));
     HK_ALLOC(d.games, na * HK_GA_CALL(d, game_doubles_per_ego()) * sizeof(double));
     HK_ALLOC(d.queue_cnt, 2 * 16 * sizeof(int));
     HK_ALLOC(d.perm, (size_t)E * sizeof(int));
@@ -434,14 +381,12 @@ inline int env_reset(EnvDevice& d, const hk_config& cfg, const int32_t* env_ids,
 // arm hk_step(n): every env gets n ticks to run
 inline int env_launch_arm(EnvDevice& d, const hk_config& cfg, int n_ticks, hipStream_t stream, std::string& err)
 {
-    hipLaunchKernelGGL(g4::env_arm_kernel, dim3((cfg.num_envs + 255) / 256), dim3(256), 0, stream, d.envs, cfg.num_envs, n_ticks);
-    return launch_check(err, "g4::env_arm_kernel");
+    return HK_GA_CALL(d, launch_arm(d, cfg, n_ticks, stream, err));
 }
 
 inline int env_launch_check(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
 {
-    hipLaunchKernelGGL(g4::env_check_kernel, dim3((cfg.num_envs + 255) / 256), dim3(256), 0, stream, d.envs, cfg.num_envs, d.status);
-    return launch_check(err, "g4::env_check_kernel");
+    return HK_GA_CALL(d, launch_done_check(d, cfg, stream, err));
 }
 
 // Number of {run, lqn} rounds issued for n ticks (see hk_env_run.h).  A round retires at least one solve cadence of every

@@ -46,7 +46,7 @@ inline int launch_reset(EnvDevice& d, const int* dids, int cnt, int experiment_n
 {
     const int threads = cnt * GA;
     hipLaunchKernelGGL(env_reset_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.envs, dids, cnt, experiment_num,
-                       d.mcts, d.mset, d.rw);
+                       d.mcts, d.mset, d.rw, d.status);
     int rc = launch_check(err, "env_reset_kernel");
     if (rc) return rc;
     return flush_mcts(d, stream, err);          // the first plans (T = 1.5 s in the reference)
@@ -93,24 +93,24 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
     if (cfg.num_agents == 2) {
         // 1v1: only 2-player games exist, one per ego per tick
         const int nb = std::min((ngames + 7) / 8, 4096);
-        hipLaunchKernelGGL(lqn_single_kernel<2>, dim3(nb), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status);
+        hipLaunchKernelGGL(lqn_single_kernel<2>, dim3(nb), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status, d.game_stats);
         if ((rc = launch_check(err, "lqn_single_kernel<2>"))) return rc;
     } else if (cfg.num_agents > 2) {
         // 1 024 workgroups per game size (one wave per SIMD at this kernel's 256 VGPRs) walking their queue grid-stride: dispatching
         // 3 x 8 192 workgroups that exit at once cost 25 us per round in steady state
         const int nb = std::min((ngames + 3) / 4, 1024);
         const int sizes = std::min(cfg.num_agents, 4) - 1;     // player counts 2 .. min(A, 4)
-        hipLaunchKernelGGL(lqn_all_kernel, dim3(nb * sizes), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status, nb);
+        hipLaunchKernelGGL(lqn_all_kernel, dim3(nb * sizes), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status, nb, d.game_stats);
         if ((rc = launch_check(err, "lqn_all_kernel"))) return rc;
 #if HK_GA > 4
         if (cfg.num_agents > 4) {
             const int nbb = std::min((ngames + 1) / 2, 512);
             hipLaunchKernelGGL(lqn_big_kernel<5>, dim3(nbb * (cfg.num_agents > 5 ? 2 : 1)), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu,
-                               d.lq_debug, d.status, nbb);
+                               d.lq_debug, d.status, nbb, d.game_stats);
             if ((rc = launch_check(err, "lqn_big_kernel<5>"))) return rc;
             if (cfg.num_agents > 6) {
                 hipLaunchKernelGGL(lqn_big_kernel<7>, dim3(nbb * (cfg.num_agents > 7 ? 2 : 1)), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu,
-                                   d.lq_debug, d.status, nbb);
+                                   d.lq_debug, d.status, nbb, d.game_stats);
                 if ((rc = launch_check(err, "lqn_big_kernel<7>"))) return rc;
             }
         }
@@ -133,6 +133,32 @@ inline int launch_observe(EnvDevice& d, const hk_config& cfg, uint32_t agent_mas
     // CollectObservations raised HitWall / HitOpponent events (HKA:580-598): replayed per env in agent / sensor order
     hipLaunchKernelGGL(reward_hits_kernel, dim3((cfg.num_envs + 127) / 128), dim3(128), 0, stream, d.P, d.agents, d.rw.hit_code);
     return launch_check(err, "reward_hits_kernel");
+}
+
+inline int launch_arm(EnvDevice& d, const hk_config& cfg, int n_ticks, hipStream_t stream, std::string& err)
+{
+    hipLaunchKernelGGL(env_arm_kernel, dim3((cfg.num_envs + 255) / 256), dim3(256), 0, stream, d.envs, cfg.num_envs, n_ticks, d.status);
+    return launch_check(err, "env_arm_kernel");
+}
+
+inline int launch_done_check(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
+    hipLaunchKernelGGL(env_check_kernel, dim3((cfg.num_envs + 255) / 256), dim3(256), 0, stream, d.envs, cfg.num_envs, d.status);
+    return launch_check(err, "env_check_kernel");
+}
+
+inline int launch_rewards_read(EnvDevice& d, int cnt, float* reward, float* group_reward, hipStream_t stream, std::string& err)
+{
+    hipLaunchKernelGGL(rewards_read_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, d.agents, cnt, reward, group_reward);
+    return launch_check(err, "rewards_read_kernel");
+}
+
+inline const GaOps& make_ops()
+{
+    static const GaOps ops = {mcts_req_bytes, mcts_searches_per_wave, mcts_root_words, game_doubles_per_ego, queue_ints_per_set,
+                              launch_mcts_table, launch_mcts_invalidate, flush_mcts, launch_reset, launch_regroup, launch_run, launch_lqn,
+                              launch_observe, launch_arm, launch_done_check, launch_rewards_read};
+    return ops;
 }
 
 } }  // namespace hk::HK_GA_NS

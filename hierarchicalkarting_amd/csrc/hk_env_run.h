@@ -20,10 +20,11 @@
 
 namespace hk { namespace HK_GA_NS {
 
-__global__ __launch_bounds__(256) void env_arm_kernel(hk_env_state* envs, int E, int n_ticks)
+__global__ __launch_bounds__(256) void env_arm_kernel(hk_env_state* envs, int E, int n_ticks, int* status)
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env < E) envs[env].reserved[0] = n_ticks;
+    if (env == 0) atomicAnd(status, ~4);      // a new call: the "did not complete" flag of an earlier one is not permanent
 }
 
 __global__ __launch_bounds__(256) void env_check_kernel(const hk_env_state* envs, int E, int* status)

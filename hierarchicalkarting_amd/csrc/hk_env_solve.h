@@ -608,7 +608,8 @@ struct QCompact {
 
 template <int NP>
 __device__ __forceinline__ void lqn_body(const int block, const int nblocks, const EnvParams& P, hk_agent_state* agents, const GameSoA games,
-                                         const int* queue_cnt, const int* queue, hk_lq_debug* dbg_out, int* status, unsigned char* smem)
+                                         const int* queue_cnt, const int* queue, hk_lq_debug* dbg_out, int* status, unsigned char* smem,
+                                         unsigned long long* gstats)
 {
     constexpr int n = LqDims<NP>::n, GPW = LqDims<NP>::GPW, SLOTS = LqDims<NP>::SLOTS;
     LqGameLds<NP>* lds = reinterpret_cast<LqGameLds<NP>*>(smem);                                     // [SLOTS]
@@ -616,6 +617,7 @@ __device__ __forceinline__ void lqn_body(const int block, const int nblocks, con
     const int lane = threadIdx.x & 63;
     const int gs = lane / n, r = lane % n;
     const int count = queue_cnt[NP];
+    if (block == 0 && threadIdx.x == 0 && count > 0) atomicAdd(&gstats[NP], (unsigned long long)count);   // hk_prof_games
     const int* qbase = queue + (size_t)(NP - 2) * P.E * P.A;
     LqGameLds<NP>& LG = lds[gs];
     CostRows<NP>& CR = rows[gs];
@@ -705,7 +707,7 @@ __device__ __forceinline__ void lqn_body(const int block, const int nblocks, con
 // [2 nb, 3 nb) the 4-player one.  (Three separate launches cost ~12 us each even when — as in steady state, where 99.95 % of
 // the games are single-player and solved inside the tick kernel — their queues are empty: 10 % of the headline's wall time.)
 __global__ __launch_bounds__(64) void lqn_all_kernel(EnvParams P, hk_agent_state* agents, const GameSoA games, const int* queue_cnt,
-                                                     const int* queue, hk_lq_debug* dbg_out, int* status, int nb)
+                                                     const int* queue, hk_lq_debug* dbg_out, int* status, int nb, unsigned long long* gstats)
 {
     // one LDS block, sized for the largest game size and reused by whichever size this workgroup solves
     constexpr size_t B2 = (sizeof(LqGameLds<2>) + sizeof(CostRows<2>)) * LqDims<2>::SLOTS;
@@ -714,9 +716,9 @@ __global__ __launch_bounds__(64) void lqn_all_kernel(EnvParams P, hk_agent_state
     constexpr size_t BMAX = B2 > B3 ? (B2 > B4 ? B2 : B4) : (B3 > B4 ? B3 : B4);
     __shared__ __align__(16) unsigned char smem[BMAX];
     const int which = blockIdx.x / nb, b = blockIdx.x - which * nb;
-    if (which == 0) lqn_body<2>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
-    else if (which == 1) lqn_body<3>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
-    else lqn_body<4>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
+    if (which == 0) lqn_body<2>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
+    else if (which == 1) lqn_body<3>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
+    else lqn_body<4>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
 }
 
 // The same solver for ONE game size, with that size's own register allocation (2-player games need 166 VGPRs, the merged kernel
@@ -724,11 +726,11 @@ __global__ __launch_bounds__(64) void lqn_all_kernel(EnvParams P, hk_agent_state
 // every ego queues a 2-player game on every tick and this kernel is most of the work.
 template <int NP>
 __global__ __launch_bounds__(64) void lqn_single_kernel(EnvParams P, hk_agent_state* agents, const GameSoA games, const int* queue_cnt,
-                                                        const int* queue, hk_lq_debug* dbg_out, int* status)
+                                                        const int* queue, hk_lq_debug* dbg_out, int* status, unsigned long long* gstats)
 {
     constexpr size_t BYTES = (sizeof(LqGameLds<NP>) + sizeof(CostRows<NP>)) * LqDims<NP>::SLOTS;
     __shared__ __align__(16) unsigned char smem[BYTES];
-    lqn_body<NP>(blockIdx.x, gridDim.x, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
+    lqn_body<NP>(blockIdx.x, gridDim.x, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
 }
 
 #if HK_GA > 4
@@ -739,7 +741,7 @@ __global__ __launch_bounds__(64) void lqn_single_kernel(EnvParams P, hk_agent_st
 // higher one.  Functional, not tuned: such games need more than 4 karts within 8 m of each other.
 template <int NA>
 __global__ __launch_bounds__(64) void lqn_big_kernel(EnvParams P, hk_agent_state* agents, const GameSoA games, const int* queue_cnt,
-                                                     const int* queue, hk_lq_debug* dbg_out, int* status, int nb)
+                                                     const int* queue, hk_lq_debug* dbg_out, int* status, int nb, unsigned long long* gstats)
 {
     constexpr int NB = NA + 1;
     constexpr size_t BA = (sizeof(LqGameLds<NA>) + sizeof(CostRows<NA>)) * LqDims<NA>::SLOTS;
@@ -748,8 +750,8 @@ __global__ __launch_bounds__(64) void lqn_big_kernel(EnvParams P, hk_agent_state
     static_assert(BMAX <= 160 * 1024, "one workgroup's games must fit the CU's LDS");
     __shared__ __align__(16) unsigned char smem[BMAX];
     const int which = blockIdx.x / nb, b = blockIdx.x - which * nb;
-    if (which == 0) lqn_body<NA>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
-    else lqn_body<NB>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem);
+    if (which == 0) lqn_body<NA>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
+    else lqn_body<NB>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
 }
 #endif
 

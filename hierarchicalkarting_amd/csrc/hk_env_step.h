@@ -78,9 +78,10 @@ __device__ inline void snapshot_result(const Hot& h, float cum_reward, float gro
 
 // explicit hk_reset
 __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
-                                                        const int* env_ids, int n, int experiment_num, MctsDev M, int set, RwDev RD)
+                                                        const int* env_ids, int n, int experiment_num, MctsDev M, int set, RwDev RD, int* status)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid == 0) atomicAnd(status, ~4);       // (see env_arm_kernel)
     const int slot = gid / GA, i = gid % GA;
     if (slot >= n || i >= P.A) return;
     const int env = env_ids ? env_ids[slot] : slot;
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_st
         es->initial_started = 1;
         es->episode_steps = 0;
         es->inactive_mask = 0;
+        es->reserved[0] = 0; es->reserved[1] = 0;      // an env left mid-tick by a failed hk_step starts clean
     }
 }
 

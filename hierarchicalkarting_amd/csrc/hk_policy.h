@@ -16,6 +16,7 @@
 // exactly the chain the CPU oracle evaluates, so mu / logits agree bit for bit.  The two heads (1 + n_branch outputs)
 // are plain fmaf chains on the vector ALU (N = 4 is not MFMA-shaped).
 #pragma once
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <string>
 #include <vector>
@@ -400,12 +401,21 @@ inline int policy_launch_mlp(const PolicyDevice& pd, int rows, const float* src,
 {
     if (rows <= 0) return HK_OK;
     const size_t lds = policy_lds_bytes(pd.q);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)policy_mlp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)policy_mlp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)policy_mlp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    // the kernels use ~68 KB of dynamic LDS, above the 64 KB default: raise the limit once per DEVICE (the attribute belongs to
+    // the device's code object; a second handle on another device needs it too).  Guarded by a mutex: handles of different
+    // devices may be driven from different host threads.
+    {
+        static std::mutex mu;
+        static unsigned long long done_mask = 0ull;     // bit d: device d has the attribute
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64 || !((done_mask >> dev) & 1ull)) {
+            (void)hipFuncSetAttribute((const void*)policy_mlp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)policy_mlp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)policy_mlp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (dev >= 0 && dev < 64) done_mask |= 1ull << dev;
+        }
     }
     const dim3 grid((rows + PM_TILE - 1) / PM_TILE), block(PM_THREADS);
     if (pd.q.hidden <= 128)

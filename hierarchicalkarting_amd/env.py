@@ -150,6 +150,12 @@ class RacingEnv:
         self._ck(self.L.hk_prof_read(self.h, ms, n))
         return {name: (ms[i], n[i]) for i, name in enumerate(_lib.PROF_STAGE_NAMES)}
 
+    def prof_games(self):
+        """-> {N: multi-player LQ games of N players the solver kernels ran since the last prof_reset} (N = 2 .. 8)"""
+        g = (C.c_int64 * (_lib.HK_MAX_AGENTS + 1))()
+        self._ck(self.L.hk_prof_games(self.h, g))
+        return {n: int(g[n]) for n in range(2, _lib.HK_MAX_AGENTS + 1)}
+
     # ---- the path's one exchange step, natively over RCCL (hk_comm_* / hk_gather_results)
     @staticmethod
     def comm_unique_id():
@@ -168,8 +174,10 @@ class RacingEnv:
         self._comm_world = 0
 
     def gather_results(self):
-        """-> hk_episode_result[world * E][A] on every rank (one RCCL all-gather)"""
-        out = np.zeros((self._comm_world * self.E, self.A), RESULT_DT)
+        """-> hk_episode_result[E_total][A] on every rank, rank order (one RCCL all-gather; ranks may hold different E)"""
+        tot = C.c_int64(0)
+        self._ck(self.L.hk_gather_count(self.h, C.byref(tot)))
+        out = np.zeros((int(tot.value), self.A), RESULT_DT)
         self._ck(self.L.hk_gather_results(self.h, out.ctypes.data_as(C.POINTER(_lib.EpisodeResult))))
         return out
 

@@ -20,11 +20,18 @@ def gather_episode_results(env_or_array, dist=None):
         return local
     import torch
     world = dist.get_world_size()
-    backend = dist.get_backend()
-    raw = torch.from_numpy(np.ascontiguousarray(local).view(np.uint8).reshape(-1).copy())
-    if backend == "nccl":
-        raw = raw.cuda()
-    out = [torch.empty_like(raw) for _ in range(world)]
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    raw = torch.from_numpy(np.ascontiguousarray(local).view(np.uint8).reshape(-1).copy()).to(dev)
+    # ranks may hold different env counts (shard_range of a total the world size does not divide): exchange the byte
+    # counts, pad every contribution to the largest (all_gather needs equal sizes), trim after the gather
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([raw.numel()], dtype=torch.int64, device=dev))
+    sizes = [int(s.item()) for s in sizes]
+    per = max(sizes)
+    if raw.numel() < per:
+        raw = torch.cat([raw, torch.zeros(per - raw.numel(), dtype=torch.uint8, device=dev)])
+    out = [torch.empty(per, dtype=torch.uint8, device=dev) for _ in range(world)]
     dist.all_gather(out, raw)
-    parts = [o.cpu().numpy().view(RESULT_DT).reshape(local.shape) for o in out]
+    A = local.shape[1]
+    parts = [o[:n].cpu().numpy().view(RESULT_DT).reshape(-1, A) for o, n in zip(out, sizes)]
     return np.concatenate(parts, axis=0)

@@ -59,3 +59,61 @@ class ExperimentLog:
         with open(self.path, "a") as f:
             f.write("Experiment %d\n" % experiment_num)
             f.write(telemetry_block(self.names, res_row, self.laps) + "\n")
+
+
+# ---- reading the format back (ours or the reference's own ExperimentLogs/*.txt: the same grammar) -----------------------
+_FIELDS = {"Speed": float, "Reward": float, "Last Lap": float, "Best Lap": float, "Total Time": float, "Overall Time": float,
+           "Illegal Lane Changes": int, "Collisions": int, "Avg Target Lane Difference": float, "Avg Target Vel Difference": float}
+
+
+def read_experiment_log(path):
+    """-> [ {"experiment": k, "winner": str, "agents": {name: {field: value, "laps": (done, total)}}} ] in file order.
+    Grammar (REC:261-264 + TelemetryViewer.cs:90-104): a line "Experiment <k>", then per agent lines "<name> <Field>: <value>"
+    (the name has no spaces), then "Winner: <name or empty>", then a blank line.  Older logs say "Overall Time" for "Total Time"."""
+    out, cur = [], None
+    with open(path) as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if line.startswith("Experiment "):
+                cur = {"experiment": int(line.split()[1]), "winner": "", "agents": {}}
+                out.append(cur)
+                continue
+            if cur is None or not line.strip():
+                continue
+            if line.startswith("Winner:"):
+                cur["winner"] = line[len("Winner:"):].strip()
+                continue
+            name, _, rest = line.partition(" ")
+            field, _, val = rest.rpartition(": ")
+            ag = cur["agents"].setdefault(name, {})
+            if field == "Laps Completed":
+                done, _, tot = val.partition("/")
+                ag["laps"] = (int(done), int(tot))
+            elif field in _FIELDS:
+                ag["Total Time" if field == "Overall Time" else field] = _FIELDS[field](float(val))
+    return out
+
+
+def summarize_log(records):
+    """per agent type (the name up to "("): races, finishes, wins (fastest Total Time among the finishers of a race), DNFs,
+    mean Total Time / Best Lap of the finishers, collisions and illegal lane changes per race"""
+    import statistics
+    acc = {}
+    for rec in records:
+        fin = {n: a for n, a in rec["agents"].items() if a.get("laps", (0, 1))[0] == a.get("laps", (0, 1))[1]}
+        win = min(fin, key=lambda n: fin[n]["Total Time"]) if fin else None
+        for n, a in rec["agents"].items():
+            t = acc.setdefault(n.split("(")[0], {"races": 0, "wins": 0, "dnfs": 0, "total": [], "best": [], "coll": [], "illegal": []})
+            t["races"] += 1
+            t["coll"].append(a.get("Collisions", 0)); t["illegal"].append(a.get("Illegal Lane Changes", 0))
+            if n in fin:
+                t["total"].append(a["Total Time"]); t["best"].append(a["Best Lap"])
+            else:
+                t["dnfs"] += 1
+            if n == win:
+                t["wins"] += 1
+    return {k: {"races": v["races"], "wins": v["wins"], "dnfs": v["dnfs"],
+                "mean_total_time": statistics.fmean(v["total"]) if v["total"] else None,
+                "median_best_lap": statistics.median(v["best"]) if v["best"] else None,
+                "collisions_per_race": statistics.fmean(v["coll"]), "illegal_lane_changes_per_race": statistics.fmean(v["illegal"])}
+            for k, v in acc.items()}

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define HK_ABI_VERSION 2
+#define HK_ABI_VERSION 3
 #define HK_MAX_AGENTS 8      /* the largest reference scene has 4; 5..8 agents per env is the synthetic extension of BASELINE configs[4] (start grid continued row by row) */
 #define HK_MAX_SECTIONS 64   /* Oval 24, Complex 41 */
 #define HK_NUM_SENSORS 9     /* MLAgent_Sensors.prefab */
@@ -136,7 +136,9 @@ typedef struct hk_config {
      * with planRandomly (HKA:109-143) instead of planFixed / MCTS.  UnityEngine.Random / System.Random draws become
      * Philox-4x32 keyed by train_seed, the global env id and the episode ("parity unpinned"). */
     uint32_t train_seed;
-    int32_t reserved_cfg;
+    int32_t debug_taps;          /* bit 0: record the LQ debug taps read by hk_get_lq_debug (costs a few %).  The environment variable
+                                  * HK_LQ_DEBUG=<bits>, read once by hk_create, ORs into this field (tests switch the taps on without
+                                  * rebuilding their configs) */
 } hk_config;
 
 #define HK_MCTS_MAX_DEPTH 8      /* gameParams.treeSearchDepth <= 8 */
@@ -262,7 +264,13 @@ int hk_reset(hk_handle h, const int32_t* env_ids, int n, int experiment_num);
 int hk_set_actions(hk_handle h, const float* steer, const int32_t* branch);
 
 /* n_ticks Unity FixedUpdate ticks: REC.FixedUpdate -> [HKA.FixedUpdate incl. SolveLQR] ->
- * ArcadeKart.FixedUpdate -> engine step (integrate, contacts, triggers). Asynchronous on the handle's stream. */
+ * ArcadeKart.FixedUpdate -> engine step (integrate, contacts, triggers). Asynchronous on the handle's stream.
+ * Error surface: hk_step only reports launch errors.  The library issues a bounded number of kernel rounds per call; a
+ * completion guard (env_check_kernel) runs last, and if any env still had ticks to run the NEXT hk_get_* / hk_gather_results
+ * call fails with HK_ERR_HIP "an env did not complete its ticks" instead of returning stale state.  The flag is cleared by the
+ * next hk_step / hk_reset, which also let the unfinished envs continue.  A zero pivot in an LQ solve is sticky in the same
+ * way (status bit 0) but does not fail the getters: the reference throws nothing there either (MathNet returns inf / NaN),
+ * and hk_env_state.status bit 0 flags the karts whose state went non-finite. */
 int hk_step(hk_handle h, int n_ticks);
 
 /* HierarchicalKartAgent.CollectObservations (HKA:485-604): obs[E][A][hk_obs_dim], order exactly as the reference adds them */
@@ -350,7 +358,8 @@ typedef struct hk_policy_desc {
 } hk_policy_desc;
 
 /* Upload a policy and bind it to the agent slots listed (all must be LowMode == RL; hk_obs_dim * stack must equal
- * in_dim).  Returns the policy index (>= 0) or a negative hk_status.  decision_period is per handle (last call wins). */
+ * in_dim).  Returns the policy index (>= 0) or a negative hk_status.  decision_period (DecisionRequester) is per handle:
+ * a second attach with a different period is refused with HK_ERR_INVALID. */
 int hk_policy_attach(hk_handle h, const hk_policy_desc* desc, const int32_t* agent_slots, int n_slots, int decision_period);
 /* The MLP alone on caller-supplied stacked observations (host pointers): mu[rows], logits[rows][n_branch]. */
 int hk_policy_forward(hk_handle h, int policy, int rows, const float* obs /*[rows][in_dim]*/, float* mu, float* logits);
@@ -367,7 +376,10 @@ int hk_get_actions(hk_handle h, float* steer, int32_t* branch);
 #define HK_COMM_ID_BYTES 128
 int hk_comm_unique_id(void* id_out /*[HK_COMM_ID_BYTES]*/);
 int hk_comm_init(hk_handle h, int world_size, int rank, const void* id /*[HK_COMM_ID_BYTES]*/);
-/* all[world_size * E][A] (host pointer), rank r's envs at rows [r * E, (r + 1) * E); every rank must hold the same E and A */
+/* all[E_total][A] (host pointer), the ranks' rows in rank order.  Ranks may hold different env counts (a contiguous split of a
+ * total the world size does not divide): the byte counts are exchanged first and the contributions padded on the wire.
+ * hk_gather_count returns E_total (the sum of every rank's num_envs) so the caller can size `all`. */
+int hk_gather_count(hk_handle h, int64_t* total_envs);
 int hk_gather_results(hk_handle h, hk_episode_result* all);
 int hk_comm_destroy(hk_handle h);
 
@@ -380,6 +392,9 @@ int hk_comm_destroy(hk_handle h);
 int hk_prof_enable(hk_handle h, int on);
 int hk_prof_reset(hk_handle h);
 int hk_prof_read(hk_handle h, double* ms /*[HK_PROF_STAGES]*/, int64_t* launches /*[HK_PROF_STAGES]*/);
+/* multi-player LQ games (KartLQR.solveFeedbackLQR calls with N >= 2 players) the solver kernels ran since the last hk_prof_reset,
+ * by player count: games[N], N = 2 .. HK_MAX_AGENTS ([0], [1] stay 0: single-player games are solved inside the tick kernel) */
+int hk_prof_games(hk_handle h, int64_t* games /*[HK_MAX_AGENTS + 1]*/);
 
 #ifdef __cplusplus
 }

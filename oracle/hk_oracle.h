@@ -57,6 +57,7 @@ hko_env* hko_create(const hk_config* cfg);
 void hko_destroy(hko_env*);
 int hko_reset(hko_env*, const int32_t* env_ids, int n, int experiment_num);
 int hko_step(hko_env*, int n_ticks);
+int hko_set_threads(int n);   /* OpenMP threads hko_step uses (n <= 0: leave as is); returns the current count */
 int hko_set_actions(hko_env*, const float* steer, const int32_t* branch);
 int hko_get_agent_state(hko_env*, hk_agent_state* out /*[E][A]*/);
 int hko_set_agent_state(hko_env*, const hk_agent_state* in);

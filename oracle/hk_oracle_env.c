@@ -19,6 +19,9 @@
 #include "hk_oracle.h"
 #include "../include/hk_detmath.h"
 #include "hk_oracle_internal.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 enum { XI = 0, ZI = 1, VI = 2, HI = 3 };
 
@@ -1236,6 +1239,18 @@ int hko_reset(hko_env* e, const int32_t* env_ids, int n, int experiment_num)
         hko_policy_invalidate(e, env);
     }
     return 0;
+}
+
+/* host threads hko_step spreads the envs over (bench.py's cpu_baseline times 1 thread and all cores); returns the count in use */
+int hko_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
 }
 
 int hko_step(hko_env* e, int n_ticks)

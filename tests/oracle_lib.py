@@ -93,6 +93,8 @@ def _env_api():
         L.hko_reset.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_int]
         L.hko_step.restype = C.c_int
         L.hko_step.argtypes = [C.c_void_p, C.c_int]
+        L.hko_set_threads.restype = C.c_int
+        L.hko_set_threads.argtypes = [C.c_int]
         L.hko_set_actions.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         for n, t in (("hko_get_agent_state", HL.AgentState), ("hko_set_agent_state", HL.AgentState),
                      ("hko_get_env_state", HL.EnvState), ("hko_set_env_state", HL.EnvState),
@@ -123,6 +125,11 @@ def _env_api():
 AGENT_DT = np.dtype(HL.AgentState)
 ENV_DT = np.dtype(HL.EnvState)
 RESULT_DT = np.dtype(HL.EpisodeResult)
+
+
+def set_threads(n):
+    """OpenMP threads hko_step spreads the envs over (n <= 0: query); -> the count in use"""
+    return _env_api().hko_set_threads(int(n))
 
 
 class OracleEnv:

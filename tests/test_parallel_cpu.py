@@ -8,7 +8,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TOTAL, A, TICKS = 6, 2, 260
+TOTAL, A, TICKS = 7, 2, 260       # 7 envs over 2 ranks: shards of 4 and 3 (the gather pads and trims)
 
 
 def _worker(rank, world, port, q):
