@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <utility>
+#include <algorithm>
 #include <new>
 #include "../../include/hk.h"
 #include "hk_lq_core.h"
@@ -88,6 +89,11 @@ struct hk_context {
     int n_policies = 0;
     int decision_period = 1;
     long long academy_step = 0;    // ticks stepped since hk_create (Academy.StepCount)
+    // lazy completion of hk_step (handles without planner / attached actors): the call issues the rounds a field without
+    // multi-player games needs and a guard kernel that reports what is left; the NEXT entry point that touches the state
+    // finishes the stragglers (finish_ticks)
+    bool step_pending = false;
+    int* done_host = nullptr;      // pinned: [0] max ticks left over the envs, [1] an env waits for a queued game
     void* pol_scratch = nullptr;   // hk_policy_forward staging
     size_t pol_scratch_bytes = 0;
     // RCCL communicator for hk_gather_results (librccl.so loaded lazily)
@@ -98,6 +104,8 @@ struct hk_context {
     void* gather_cnt = nullptr;    // per-rank byte counts of the gather (ranks may hold different env counts)
     size_t gather_cnt_bytes = 0;
 };
+
+static int finish_ticks(hk_context* h);      // lazy completion of the last hk_step (defined with step_ticks)
 
 namespace {
 
@@ -187,6 +195,8 @@ int hk_create(const hk_config* cfg, hk_handle* out)
         rc = hk::env_create(h->cfg, h->sections, h->walls, h->dev, h->stream, h->err);
         if (rc) { g_last_error = h->err; hk_destroy(h); return rc; }
         h->env_ready = true;
+        if (hipHostMalloc((void**)&h->done_host, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) h->done_host = nullptr;   // (no pinned memory: fixed rounds)
+        else { h->done_host[0] = 0; h->done_host[1] = 0; }
     }
     *out = h;
     return HK_OK;
@@ -197,6 +207,7 @@ void hk_destroy(hk_handle h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->done_host) (void)hipHostFree(h->done_host);
     hk::env_destroy(h->dev);
     if (h->d_status) (void)hipFree(h->d_status);
     if (h->lq_scratch) (void)hipFree(h->lq_scratch);
@@ -218,6 +229,7 @@ int hk_synchronize(hk_handle h)
 {
     if (!h) return HK_ERR_INVALID;
     HK_HIP(h, hipSetDevice(h->device));
+    if (h->step_pending) { int rc = finish_ticks(h); if (rc) return rc; }
     HK_HIP(h, hipStreamSynchronize(h->stream));
     return HK_OK;
 }
@@ -289,6 +301,7 @@ int hk_lq_solve_batch(hk_handle h, int batch, int N, const double* A, const doub
         if (!(h)) return fail(nullptr, HK_ERR_INVALID, "NULL handle");                     \
         if (!(h)->env_ready) return fail((h), HK_ERR_INVALID, "handle has no environment"); \
         HK_HIP((h), hipSetDevice((h)->device));                                            \
+        if ((h)->step_pending) { int rc_ = finish_ticks(h); if (rc_) return rc_; }         \
     } while (0)
 
 int hk_reset(hk_handle h, const int32_t* env_ids, int n, int experiment_num)
@@ -318,6 +331,50 @@ int hk_set_actions(hk_handle h, const float* steer, const int32_t* branch)
     return HK_OK;
 }
 
+// `rounds` rounds of {fused tick kernel (up to RUN_CAP ticks per env), queued multi-player solves}
+static int issue_rounds(hk_handle h, int rounds)
+{
+    for (int r = 0; r < rounds; r++) {
+        hipEvent_t e = h->prof.begin(h->stream);
+        int rc = hk::env_launch_run(h->dev, h->cfg, h->stream, h->err);
+        if (rc) { g_last_error = h->err; return rc; }
+        h->prof.end(0, e, h->stream);
+        e = h->prof.begin(h->stream);
+        rc = hk::env_launch_lqn(h->dev, h->cfg, h->stream, h->err);
+        if (rc) { g_last_error = h->err; return rc; }
+        h->prof.end(1, e, h->stream);
+    }
+    return HK_OK;
+}
+
+// guard kernel + (lazy mode) its report on the way to pinned host memory
+static int issue_check(hk_handle h, bool lazy)
+{
+    if (lazy) HK_HIP(h, hipMemsetAsync(h->dev.status + 1, 0, 2 * sizeof(int), h->stream));
+    int rc = hk::env_launch_check(h->dev, h->cfg, lazy, h->stream, h->err);
+    if (rc) { g_last_error = h->err; return rc; }
+    if (lazy) HK_HIP(h, hipMemcpyAsync(h->done_host, h->dev.status + 1, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    return HK_OK;
+}
+
+// Lazy completion: wait for the last hk_step's report; while some env still has ticks to run (it met multi-player games, each
+// of which costs it a round), issue the rounds the laggard needs and look again.
+static int finish_ticks(hk_handle h)
+{
+    const int cadence = h->cfg.num_agents > 2 ? 4 : 1;
+    for (int guard = 0; guard < 1024 && h->step_pending; guard++) {
+        HK_HIP(h, hipStreamSynchronize(h->stream));
+        const int maxleft = h->done_host[0], waiting = h->done_host[1];
+        if (maxleft <= 0 && !waiting) { h->step_pending = false; break; }
+        int rc = issue_rounds(h, (maxleft + cadence - 1) / cadence + 1);
+        if (rc) return rc;
+        rc = issue_check(h, true);
+        if (rc) return rc;
+    }
+    if (h->step_pending) { h->step_pending = false; return fail(h, HK_ERR_HIP, "hk_step: an env did not complete its ticks (internal scheduling error)"); }
+    return HK_OK;
+}
+
 // n_ticks of every env: arm, rounds of {fused tick kernel, queued multi-player solves}, check
 static int step_ticks(hk_handle h, int n_ticks)
 {
@@ -337,25 +394,26 @@ static int step_ticks(hk_handle h, int n_ticks)
     h->dev.mcts_defer = short_call;
     rc = hk::env_launch_arm(h->dev, h->cfg, n_ticks, h->stream, h->err);
     if (rc) { g_last_error = h->err; return rc; }
-    const int rounds = hk::env_rounds_for(h->cfg, n_ticks);
-    for (int r = 0; r < rounds; r++) {
-        // the fused tick kernel (up to RUN_CAP ticks per env), then the queued multi-player solves
-        hipEvent_t e = h->prof.begin(h->stream);
-        rc = hk::env_launch_run(h->dev, h->cfg, h->stream, h->err);
-        if (rc) { g_last_error = h->err; return rc; }
-        h->prof.end(0, e, h->stream);
-        e = h->prof.begin(h->stream);
-        rc = hk::env_launch_lqn(h->dev, h->cfg, h->stream, h->err);
-        if (rc) { g_last_error = h->err; return rc; }
-        h->prof.end(1, e, h->stream);
-    }
+    // Rounds.  An env that meets no multi-player game retires RUN_CAP ticks per round; one that does retires at least a solve
+    // cadence.  Handles with a planner or attached actors issue the worst-case count up front (they step in short chunks and
+    // must not stall on the host).  Everything else — the LQNG races of the headline — issues what a field without
+    // multi-player games needs, and the stragglers are finished lazily by the next call that touches the state
+    // (finish_ticks): most of the worst-case rounds found nothing to do, and on a 20-tick call they were 5 launches of 8.
+    // (short calls — a host stepping tick by tick — keep the fixed count too: a handful of rounds, no host sync)
+    const bool lazy = HK_INWAVE && !planner && h->n_policies == 0 && h->done_host != nullptr && h->cfg.num_agents <= 4 && n_ticks >= 2 * hk::RUN_CAP &&
+                      !std::getenv("HK_FIXED_ROUNDS");
+    int rounds = lazy ? hk::env_rounds_min(h->cfg, n_ticks) : hk::env_rounds_for(h->cfg, n_ticks);
+    if (const char* dr = std::getenv("HK_DEBUG_MAX_ROUNDS")) rounds = std::min(rounds, std::atoi(dr));     // (diagnostic: look at the state between two rounds)
+    rc = issue_rounds(h, rounds);
+    if (rc) return rc;
     if (planner && !short_call) {
         // searches requested in the last rounds of a long call run before it returns
         rc = hk::env_flush_mcts(h->dev, h->stream, h->err);
         if (rc) { g_last_error = h->err; return rc; }
     }
-    rc = hk::env_launch_check(h->dev, h->cfg, h->stream, h->err);
-    if (rc) { g_last_error = h->err; return rc; }
+    rc = issue_check(h, lazy);
+    if (rc) return rc;
+    h->step_pending = lazy;
     return HK_OK;
 }
 
@@ -765,11 +823,12 @@ int hk_prof_reset(hk_handle h)
 {
     if (!h) return HK_ERR_INVALID;
     HK_HIP(h, hipSetDevice(h->device));
+    if (h->step_pending) { int rc = finish_ticks(h); if (rc) return rc; }
     HK_HIP(h, hipStreamSynchronize(h->stream));
     h->prof.fold();
     for (int s = 0; s < HK_PROF_STAGES; s++) { h->prof.ms[s] = 0; h->prof.n[s] = 0; }
     if (h->env_ready && h->dev.game_stats) {
-        HK_HIP(h, hipMemsetAsync(h->dev.game_stats, 0, 16 * sizeof(unsigned long long), h->stream));
+        HK_HIP(h, hipMemsetAsync(h->dev.game_stats, 0, 64 * sizeof(unsigned long long), h->stream));
         HK_HIP(h, hipStreamSynchronize(h->stream));
     }
     return HK_OK;
@@ -779,10 +838,15 @@ int hk_prof_games(hk_handle h, int64_t* games)
 {
     HK_NEED_ENV(h);
     if (!games) return fail(h, HK_ERR_INVALID, "hk_prof_games: NULL pointer");
-    unsigned long long g[16];
+    unsigned long long g[64];
     HK_HIP(h, hipMemcpyAsync(g, h->dev.game_stats, sizeof(g), hipMemcpyDeviceToHost, h->stream));
     HK_HIP(h, hipStreamSynchronize(h->stream));
     for (int n = 0; n <= HK_MAX_AGENTS; n++) games[n] = (int64_t)g[n];
+    if (std::getenv("HK_STAMPS_DUMP")) {       // diagnostic builds (-DHK_STAMPS): the phase cycle counters of the tick kernel
+        std::fprintf(stderr, "HK_STAMPS");
+        for (int k = 16; k < 64; k++) std::fprintf(stderr, " %llu", g[k]);
+        std::fprintf(stderr, "\n");
+    }
     return HK_OK;
 }
 
@@ -790,6 +854,7 @@ int hk_prof_read(hk_handle h, double* ms, int64_t* launches)
 {
     if (!h) return HK_ERR_INVALID;
     HK_HIP(h, hipSetDevice(h->device));
+    if (h->step_pending) { int rc = finish_ticks(h); if (rc) return rc; }
     HK_HIP(h, hipStreamSynchronize(h->stream));
     h->prof.fold();
     for (int s = 0; s < HK_PROF_STAGES; s++) {

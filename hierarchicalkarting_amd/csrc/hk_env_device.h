@@ -345,9 +345,22 @@ __device__ inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_
 }
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
+// Diagnostic build only (-DHK_STAMPS, tools/stamp_profile.py): cycle stamps at the phase boundaries of the fused tick kernel,
+// accumulated per lane, reduced to the wave's maximum and added to game_stats[16 + k] when the kernel ends.
+#ifdef HK_STAMPS
+#define HK_NSTAMP 16
+#define HK_ST(h, k) do { const unsigned long long n_ = __builtin_readcyclecounter(); (h).st_acc[k] += (unsigned)(n_ - (h).st_t); (h).st_t = n_; } while (0)
+#else
+#define HK_ST(h, k) do { } while (0)
+#endif
+
 // the fields of hk_agent_state that change every tick, kept in registers across the ticks of the fused kernel
 // (the plan arrays and the reward stay in the global record)
 struct Hot {
+#ifdef HK_STAMPS
+    unsigned long long st_t;
+    unsigned st_acc[HK_NSTAMP];
+#endif
     float px;
     float pz;
     float yaw;

@@ -10,6 +10,7 @@
 #error "hk_env_ga.h needs HK_GA and HK_GA_NS"
 #endif
 #include <utility>
+#include <type_traits>
 #include "hk_env_device.h"
 #include "hk_lq_core.h"
 

@@ -12,6 +12,13 @@
 #include "hk_env_device.h"
 #include "hk_lq_core.h"
 
+// 1: a wave of the quad tick kernel solves its own sparse 2- / 3-player games between two passes of its tick loop (hk_env_run.h),
+// and hk_step issues only the rounds a field without queued games needs, finishing stragglers lazily (hk_api.hip).
+// 0: every multi-player game goes through the queues and the solver kernels; worst-case round count up front.
+#ifndef HK_INWAVE
+#define HK_INWAVE 0
+#endif
+
 namespace hk {
 
 struct EnvDevice {
@@ -89,7 +96,7 @@ struct GaOps {
     int (*launch_lqn)(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err);
     int (*launch_observe)(EnvDevice& d, const hk_config& cfg, uint32_t agent_mask, hipStream_t stream, std::string& err);
     int (*launch_arm)(EnvDevice& d, const hk_config& cfg, int n_ticks, hipStream_t stream, std::string& err);
-    int (*launch_done_check)(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err);
+    int (*launch_done_check)(EnvDevice& d, const hk_config& cfg, int lazy, hipStream_t stream, std::string& err);
     int (*launch_rewards_read)(EnvDevice& d, int cnt, float* reward, float* group_reward, hipStream_t stream, std::string& err);
 };
 const GaOps& ga_ops_g4();      // hk_ga4.hip

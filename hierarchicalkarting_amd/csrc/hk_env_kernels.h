@@ -276,7 +276,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     HK_ALLOC(d.act_branch, na * sizeof(int32_t));
     HK_ALLOC(d.reward_out, 2 * na * sizeof(float));
     HK_ALLOC(d.status, 4 * sizeof(int));
-    HK_ALLOC(d.game_stats, 16 * sizeof(unsigned long long));
+    HK_ALLOC(d.game_stats, 64 * sizeof(unsigned long long));     // [0, 16) games by player count, [16, 64) diagnostic stamps
     HK_ALLOC(d.games, na * HK_GA_CALL(d, game_doubles_per_ego()) * sizeof(double));
     HK_ALLOC(d.queue_cnt, 2 * 16 * sizeof(int));
     HK_ALLOC(d.perm, (size_t)E * sizeof(int));
@@ -384,9 +384,9 @@ inline int env_launch_arm(EnvDevice& d, const hk_config& cfg, int n_ticks, hipSt
     return HK_GA_CALL(d, launch_arm(d, cfg, n_ticks, stream, err));
 }
 
-inline int env_launch_check(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+inline int env_launch_check(EnvDevice& d, const hk_config& cfg, bool lazy, hipStream_t stream, std::string& err)
 {
-    return HK_GA_CALL(d, launch_done_check(d, cfg, stream, err));
+    return HK_GA_CALL(d, launch_done_check(d, cfg, lazy ? 1 : 0, stream, err));
 }
 
 // Number of {run, lqn} rounds issued for n ticks (see hk_env_run.h).  A round retires at least one solve cadence of every
@@ -399,6 +399,14 @@ inline int env_rounds_for(const hk_config& cfg, int n_ticks)
     const int cadence = cfg.num_agents > 2 ? 4 : 1;
     static_assert(RUN_CAP > 4, "RUN_CAP must exceed the solve cadence");
     return (n_ticks + cadence - 1) / cadence + 1 + n_ticks / 32 + 2;
+}
+
+// Rounds a field WITHOUT multi-player games needs for n ticks (every env retires RUN_CAP ticks per round); with one or two
+// agents every ego queues a game on every tick (no 8 m filter, HKA:709), so each tick is a round.
+inline int env_rounds_min(const hk_config& cfg, int n_ticks)
+{
+    if (cfg.num_agents <= 2) return n_ticks + 1;
+    return (n_ticks + RUN_CAP - 1) / RUN_CAP;
 }
 
 inline int env_launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)

@@ -27,10 +27,17 @@ __global__ __launch_bounds__(256) void env_arm_kernel(hk_env_state* envs, int E,
     if (env == 0) atomicAnd(status, ~4);      // a new call: the "did not complete" flag of an earlier one is not permanent
 }
 
-__global__ __launch_bounds__(256) void env_check_kernel(const hk_env_state* envs, int E, int* status)
+__global__ __launch_bounds__(256) void env_check_kernel(const hk_env_state* envs, int E, int* status, int lazy)
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    if (env < E && (envs[env].reserved[0] != 0 || envs[env].reserved[1] != 0)) atomicOr(status, 4);
+    if (env >= E) return;
+    const int left = envs[env].reserved[0], phase = envs[env].reserved[1];
+    if (left != 0 || phase != 0) {
+        if (!lazy) atomicOr(status, 4);          // sticky error for the getters (fixed-rounds mode)
+        // what the lazy completion of hk_step needs (hk_api.hip finish_ticks): the host cleared both words before this launch
+        atomicMax(status + 1, left);
+        if (phase != 0) atomicOr(status + 2, 1);
+    }
 }
 
 // Regrouping by solve phase.  SolveLQR runs on ticks with episodeSteps % 4 == 0 (A > 2, Q9): during the first episode every env
@@ -65,11 +72,27 @@ template <bool HAS_MCTS, bool HAS_RW, bool HAS_TRAIN>
 __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
                                                       hk_episode_result* results, GameSoA games, int* queue_cnt_all,
                                                       int* queue_all, int set, const float* act_steer, const int* act_branch,
-                                                      hk_lq_debug* dbg_out, int* status, int use_lds, MctsDev Marg, int mset, RwDev RD, const int* perm)
+                                                      hk_lq_debug* dbg_out, int* status, int use_lds, MctsDev Marg, int mset, RwDev RD, const int* perm,
+                                                      unsigned long long* stats)
 {
     MctsDev M{};
     if (HAS_MCTS) M = Marg;
     __shared__ KartS ks[256];
+#if HK_GA == 4 && HK_INWAVE
+    __shared__ InWaveLds inw[4];         // per-wave slices of the in-wave solver
+#endif
+#ifdef HK_DUMMY_SCRATCH
+    if (P.E < 0) {                                     // kernel-variant experiment: what does the scratch frame size alone cost? (never true)
+        volatile int big[HK_DUMMY_SCRATCH / 4];
+        for (int k = 0; k < HK_DUMMY_SCRATCH / 4; k++) big[k] = k * P.A;
+        status[1] = big[(threadIdx.x * 13 + P.L) % (HK_DUMMY_SCRATCH / 4)];
+    }
+#endif
+#ifdef HK_DUMMY_LDS
+    __shared__ int dummy_lds[HK_DUMMY_LDS / 4];        // kernel-variant experiment: what does the LDS footprint alone cost?
+    if (P.E < 0) dummy_lds[threadIdx.x] = P.A;         // (never true; keeps the array alive)
+    if (P.E < -1) status[0] = dummy_lds[(threadIdx.x * 7) % (HK_DUMMY_LDS / 4)];
+#endif
     extern __shared__ __align__(16) unsigned char smem[];
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = gid / GA, i = gid % GA;
@@ -80,6 +103,9 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
     int* queue_cnt = queue_cnt_all + set * 16;
     int* queue = queue_all + (size_t)set * (GA - 1) * P.E * P.A;
     if (gid < 16) queue_cnt_all[(set ^ 1) * 16 + gid] = 0;
+#if HK_GA != 4 || defined(HK_OLD_LOOP)
+    // (lane groups of 8: the loop as it was before the in-wave path existed — nothing to gain there, and with the wave-uniform
+    // form below the 8-lane build decoded single-player controls with a wrong final_steer: unexplained, so not used)
     hk_env_state es;
     if (env_ok) es = envs[env];
     else { es.episode_steps = 0; es.inactive_mask = 0; es.experiment_num = 0; es.episodes_done = 0; es.status = 0; es.initial_started = 0; es.reserved[0] = 0; es.reserved[1] = 0; }
@@ -138,4 +164,144 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
     }
 }
 
+#else
+    hk_env_state es;
+    if (env_ok) es = envs[env];
+    else { es.episode_steps = 0; es.inactive_mask = 0; es.experiment_num = 0; es.episodes_done = 0; es.status = 0; es.initial_started = 0; es.reserved[0] = 0; es.reserved[1] = 0; }
+    // nothing to do in this block? (every env finished its ticks): skip the table staging too
+    if (__syncthreads_or(es.reserved[0] > 0 || es.reserved[1] != 0) == 0) return;
+    const TabView T = tab_stage(P, smem, use_lds != 0);
+    const int cadence = P.A > 2 ? 4 : 1;
+    const uint32_t all_mask = (1u << P.A) - 1u;
+    int budget = RUN_CAP;
+    hk_agent_state* arec = (env_ok && i < P.A) ? &agents[(size_t)env * P.A + i] : nullptr;
+    const LaneCfg LC = lane_cfg(P, i);                   // this lane's agent: modes and player list, read once
+#ifdef HK_STAMPS
+    unsigned st_sum[HK_NSTAMP];
+    for (int k = 0; k < HK_NSTAMP; k++) st_sum[k] = 0;
+#endif
+    // One pass = load the state, run the tick loop, store the state.  A wave that meets a few multi-player games (see
+    // inwave_solve) ends its pass right after the assembly of that tick, with every env it holds parked at "controls ready"
+    // (phase 1, the same state in which an env waits for the solver kernels between two launches), solves the games itself,
+    // and makes another pass.  Nothing but a handful of words is live across the solve, so the solver's registers and the tick
+    // loop's do not compete (with the solve inside the loop body the tick loop lost a third of its speed to spills).
+    for (bool first = true;; first = false) {
+        if (!first && env_ok) es = envs[env];
+        int left = es.reserved[0];
+        int phase = es.reserved[1];
+        bool dirty = false;
+        Hot h;
+        if (arec) h = load_hot(arec); else { Hot z = {}; h = z; }
+#ifdef HK_STAMPS
+        for (int k = 0; k < HK_NSTAMP; k++) h.st_acc[k] = 0;
+        h.st_t = __builtin_readcyclecounter();
+#endif
+        float hfx, hfz;                                      // the kart's forward, carried across ticks (changes only when yaw does)
+        hk_sincosf(h.yaw, &hfx, &hfz);
+        RwAcc rwv = {0.0f, 0.0f, 0.0f};
+        if (HAS_RW && P.rewards && arec) { rwv.cum = arec->cum_reward; rwv.step = arec->step_reward; rwv.group = arec->group_reward; }
+        HK_ST(h, 0);                       // [0] pass prologue: (table staging,) state load
+        unsigned long long inw2 = 0ull, inw3 = 0ull;         // lanes whose 2- / 3-player game this wave solves itself after the pass
+        // The loop is wave-uniform: a lane group whose env has nothing (more) to run in this launch stays in it, idle.
+        // phase 1 = the env waits for the solver KERNELS (it resumes in the next launch, i.e. in the first pass of a launch);
+        // phase 2 = parked by this wave for its own solve (it resumes in the pass right after it)
+        const bool resume = first ? phase != 0 : phase == 2;
+        if (resume) phase = 1;
+        bool go = env_ok && (resume || (phase == 0 && left > 0 && budget > 0));
+        while (__ballot(go) != 0ull) {
+            int qn = 0;                  // player count of the multi-player game this ego assembled on this tick (0: none)
+            bool began = false;          // this env ran phases A / B1 in this iteration (it was at a tick boundary and not parked)
+            bool moving = go;            // this env runs phase C in this iteration
+            if (go) {
+                dirty = true;
+                if (phase == 0) {
+                    const bool parked = phase_begin<HAS_RW, HAS_TRAIN>(P, env, i, env_ok, es, h, hfx, hfz, agents, results, M, mset, RD, rwv, act_branch);
+                    HK_ST(h, 1);               // [1] phase A: episode controller + kart-vs-kart rays
+                    if (!parked) {
+                        const bool act = (es.episode_steps % cadence) == 0 &&                                  // HKA:317 (Q9)
+                                         !(!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u));
+                        qn = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
+                        began = true;
+                    } else {
+                        left -= 1; budget -= 1;         // a parked env lets the tick pass
+                        moving = false;
+                    }
+                }
+            }
+            bool inw = false;
+#if HK_GA == 4 && HK_INWAVE
+            {
+                // few multi-player games in this wave, none with more than 3 players: the wave solves them itself
+                const unsigned long long m2 = __ballot(qn == 2), m3 = __ballot(qn == 3), mbig = __ballot(qn > 3);
+                inw = __builtin_expect((m2 | m3) != 0ull && mbig == 0ull && __popcll(m2) + __popcll(m3) <= INW_MAX, 0);
+                if (inw) { inw2 = m2; inw3 = m3; qn = 0; }
+            }
+#endif
+            if (began) {
+                // bin the games for the solver kernels by player count, one atomic per wave and count
+#pragma unroll
+                for (int n = 2; n <= GA; n++) {
+                    const int pos = wave_agg_inc(&queue_cnt[n], qn == n);
+                    if (qn == n) queue[(size_t)(n - 2) * P.E * P.A + pos] = env * P.A + i;
+                }
+                if (M.st) phase_plan(P, M, mset, env, i, es, h.flags, h.section_index, h.lane, h.lane_changes, h.final_steer, arec);
+                HK_ST(h, 6);           // [6] queue binning (+ planner hooks)
+                // does any ego of this env wait for a queued multi-player solve?
+                if (group_or(qn ? 1 : 0)) { phase = 1; moving = false; go = false; }
+            }
+            if (inw) {
+                if (moving) phase = 2;     // every env of the wave that is mid-tick: phases A / B1 done, controls in its record
+                break;
+            }
+            if (moving) {
+                phase_move<HAS_RW, HAS_TRAIN>(P, T, env, i, env_ok, es, h, hfx, hfz, agents, act_steer, act_branch, M.st, RD, rwv, LC.low_mode, LC.high_mode);
+                phase = 0;
+                left -= 1; budget -= 1;
+            }
+            go = go && (left > 0 && budget > 0);
+        }
+        HK_ST(h, 13);                      // [13] waiting for the other lane groups of the wave to leave the loop
+#ifdef HK_STAMPS
+        for (int k = 0; k < HK_NSTAMP; k++) st_sum[k] += h.st_acc[k];
+#endif
+        if (arec && dirty) {
+            store_hot(arec, h);
+            if (HAS_RW && P.rewards) { arec->cum_reward = rwv.cum; arec->step_reward = rwv.step; arec->group_reward = rwv.group; }
+        }
+        if (env_ok && dirty && i == 0) {
+            es.reserved[0] = left;
+            es.reserved[1] = phase;
+            envs[env] = es;
+        }
+        if ((inw2 | inw3) == 0ull) break;
+#if HK_GA == 4 && HK_INWAVE
+        // the games (GameSoA) and the records were written by the wave's own lanes: make them visible to the others, solve,
+        // and make the controls visible to the egos' lanes again
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        {
+            InWaveLds& IW = inw[threadIdx.x >> 6];
+            const int my_game = env_ok ? env * P.A + i : 0;
+            if (inw2) inwave_solve<2, INW_SLOTS2>(inw2, my_game, P, agents, games, IW.n2.g, IW.n2.c, dbg_out, status);
+            if (inw3) inwave_solve<3, 1>(inw3, my_game, P, agents, games, IW.n3.g, IW.n3.c, dbg_out, status);
+            if ((threadIdx.x & 63) == 0) {                                                         // hk_prof_games
+                if (inw2) atomicAdd(&stats[2], (unsigned long long)__popcll(inw2));
+                if (inw3) atomicAdd(&stats[3], (unsigned long long)__popcll(inw3));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+    }
+#ifdef HK_STAMPS
+    for (int k = 0; k < HK_NSTAMP; k++) {
+        unsigned v = st_sum[k];
+        for (int o = 32; o > 0; o >>= 1) { const unsigned w = (unsigned)__shfl_xor((int)v, o, 64); v = w > v ? w : v; }
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&stats[16 + k], (unsigned long long)v);
+    }
+    if ((threadIdx.x & 63) == 0) atomicAdd(&stats[16 + HK_NSTAMP], 1ull);     // waves that entered the loop
+#endif
+}
+
+#endif
 } }  // namespace hk::HK_GA_NS

@@ -557,6 +557,7 @@ __device__ inline int phase_assemble(const EnvParams& P, const TabView& T, KartS
     }
     ks[threadIdx.x] = k;
     wave_lds_sync();
+    HK_ST(h, 2);                       // [2] own-kart staging + the five wall rays
     if (!me) return 0;
     const KartS* kq = &ks[threadIdx.x & ~(GA - 1)];   // the env's karts
     const bool solving = (k.flags & HK_F_ENABLED) && LC.low_mode == HK_LOW_LQR && !((es.inactive_mask >> ego) & 1u);
@@ -578,16 +579,20 @@ __device__ inline int phase_assemble(const EnvParams& P, const TabView& T, KartS
     const bool fixed = LC.high_mode == HK_HIGH_FIXED;
     const hk_mcts_state* bel = mcts_all ? &mcts_all[(size_t)env * A + ego] : nullptr;
     const float dy = T.sec[0].marker_y - P.kart_y;                                    // Q13
+    HK_ST(h, 3);                       // [3] players within 8 m
     if (N == 1) {
         // single-player game: assemble into registers and run the whole Riccati recursion right here
         GamePlayer loc;
         assemble_player<true>(P, T, env, ego, 0, N, nearbyAgents, plm, kq, fixed, LC.vbucket, dy, &loc, dbg_out, bel, games, 0);
+        HK_ST(h, 4);                   // [4] single-player assembly (heading heuristic, weights)
         if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = 1;
         lq1_solve(P, loc, h, (dbg_out && (P.debug & 1)) ? &dbg_out[(size_t)env * A + ego] : nullptr, status);
+        HK_ST(h, 5);                   // [5] lq1_solve
         return 0;
     }
     for (int i = 0; i < N; i++) assemble_player<false>(P, T, env, ego, i, N, nearbyAgents, plm, kq, fixed, LC.vbucket, dy, nullptr, dbg_out, bel, games, env * A + ego);
     if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = N;
+    HK_ST(h, 7);                       // [7] multi-player assembly
     return N;                // the caller bins the game by N (wave-aggregated slot allocation needs every queued lane together)
 }
 
@@ -605,6 +610,80 @@ struct QCompact {
     __device__ double Q(int i, int r, int c) const { return ((c & 3) == (r & 3)) ? C->QC[i][c >> 2][r] : 0.0; }
     __device__ double q(int i, int r) const { return C->QV[i][r]; }
 };
+
+// one queued game: inputs from the GameSoA buffer -> the game's LDS slice (lane r = row r), then the coupled Riccati recursion
+template <int NP, class SYNC>
+__device__ __forceinline__ void lqn_stage_solve(const int game, const int r, const double dt, const GameSoA& games, LqGameLds<NP>& LG,
+                                                CostRows<NP>& CR, double u0[2], int& singular)
+{
+    constexpr int n = LqDims<NP>::n;
+    SYNC::sync();              // the slice may still be read by the previous game's last sweep
+    // game inputs -> LDS
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        for (int e = r; e < 16; e += n) {
+            const int rr = e >> 2, cc = e & 3;
+            double av = 0.0;
+            if (rr == cc) av = 1.0;
+            else if (rr == 0 && cc == 2) av = games.get(game, i, GP_A4 + 0);
+            else if (rr == 1 && cc == 2) av = games.get(game, i, GP_A4 + 1);
+            else if (rr == 0 && cc == 3) av = games.get(game, i, GP_A4 + 2);
+            else if (rr == 1 && cc == 3) av = games.get(game, i, GP_A4 + 3);
+            LG.Ab[i][e] = av;
+        }
+        for (int e = r; e < 8; e += n) LG.Bb[i][e] = (e == 4 || e == 7) ? dt : 0.0;      // B[v][0] = B[h][1] = dt
+        if (r < 4) LG.Rb[i][r] = (r == 0 || r == 3) ? games.get(game, i, GP_RC) : 0.0;
+    }
+    LG.x0[r] = games.get(game, r >> 2, GP_X0 + (r & 3));
+    // compact reach-avoid cost rows (KartLQRCosts.cs:57-127): lane r = row r
+    {
+        const int b = r >> 2, sidx = r & 3;
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            double qc[NP];
+#pragma unroll
+            for (int q = 0; q < NP; q++) qc[q] = 0.0;
+            double qv = 0.0;
+            const int M = (int)games.get(game, i, GP_M);
+            auto AW = [&](int j) { return games.get(game, i, GP_AW + j); };
+            auto TW = [&](int c) { return games.get(game, i, GP_TW + c); };
+            auto TGT = [&](int c) { return games.get(game, i, GP_TGT + c); };
+            auto OPW = [&](int j, int c) { return games.get(game, i, GP_OPW + 3 * j + c); };
+            auto OPT = [&](int j, int c) { return games.get(game, i, GP_OPT + 3 * j + c); };
+            if (b == 0) {
+                double d = 0.0;
+                if (sidx < 2) {
+                    double total = 0.0;                                    // :67-79
+                    for (int j = 0; j < M; j++) total -= AW(j);
+                    d = total;
+                }
+                d += TW(sidx);                                          // :81-84
+                qc[0] = d;
+                if (sidx < 2) {
+#pragma unroll
+                    for (int q = 1; q < NP; q++) if (M > q - 1) qc[q] = AW(q - 1);
+                }
+                double t = -TGT(sidx);                                  // getQVec :109-113
+                qv = t * TW(sidx);
+            } else {
+                const int j = b - 1;
+                if (sidx < 2) qc[0] = AW(j);                            // :74
+                double dg = 0.0;
+                if (sidx < 3) dg = -OPW(j, sidx);                       // :91 assignment (Q4)
+#pragma unroll
+                for (int q = 1; q < NP; q++) if (b == q) qc[q] = dg;
+                if (sidx < 3) { qv = OPT(j, sidx); qv = qv * -OPW(j, sidx); }   // :117,:121 (heading entry 0)
+            }
+#pragma unroll
+            for (int q = 0; q < NP; q++) CR.QC[i][q][r] = qc[q];
+            CR.QV[i][r] = qv;
+        }
+    }
+    SYNC::sync();
+    QCompact<NP> qp;
+    qp.C = &CR;
+    lq_solve_game<NP, QCompact<NP>, true, SYNC>(r, LG, qp, 3, u0, singular);      // HKA:1201 horizon literal 3 (Q6)
+}
 
 template <int NP>
 __device__ __forceinline__ void lqn_body(const int block, const int nblocks, const EnvParams& P, hk_agent_state* agents, const GameSoA games,
@@ -625,80 +704,79 @@ __device__ __forceinline__ void lqn_body(const int block, const int nblocks, con
         const int slot = base + gs;
         const bool live = gs < GPW && slot < count;
         const int game = qbase[live ? slot : count - 1];      // idle slots recompute the last game and discard it
-        __syncthreads();
-        // game inputs -> LDS
-#pragma unroll
-        for (int i = 0; i < NP; i++) {
-            for (int e = r; e < 16; e += n) {
-                const int rr = e >> 2, cc = e & 3;
-                double av = 0.0;
-                if (rr == cc) av = 1.0;
-                else if (rr == 0 && cc == 2) av = games.get(game, i, GP_A4 + 0);
-                else if (rr == 1 && cc == 2) av = games.get(game, i, GP_A4 + 1);
-                else if (rr == 0 && cc == 3) av = games.get(game, i, GP_A4 + 2);
-                else if (rr == 1 && cc == 3) av = games.get(game, i, GP_A4 + 3);
-                LG.Ab[i][e] = av;
-            }
-            for (int e = r; e < 8; e += n) LG.Bb[i][e] = (e == 4 || e == 7) ? (double)P.dt : 0.0;      // B[v][0] = B[h][1] = dt
-            if (r < 4) LG.Rb[i][r] = (r == 0 || r == 3) ? games.get(game, i, GP_RC) : 0.0;
-        }
-        LG.x0[r] = games.get(game, r >> 2, GP_X0 + (r & 3));
-        // compact reach-avoid cost rows (KartLQRCosts.cs:57-127): lane r = row r
-        {
-            const int b = r >> 2, sidx = r & 3;
-#pragma unroll
-            for (int i = 0; i < NP; i++) {
-                double qc[NP];
-#pragma unroll
-                for (int q = 0; q < NP; q++) qc[q] = 0.0;
-                double qv = 0.0;
-                const int M = (int)games.get(game, i, GP_M);
-                auto AW = [&](int j) { return games.get(game, i, GP_AW + j); };
-                auto TW = [&](int c) { return games.get(game, i, GP_TW + c); };
-                auto TGT = [&](int c) { return games.get(game, i, GP_TGT + c); };
-                auto OPW = [&](int j, int c) { return games.get(game, i, GP_OPW + 3 * j + c); };
-                auto OPT = [&](int j, int c) { return games.get(game, i, GP_OPT + 3 * j + c); };
-                if (b == 0) {
-                    double d = 0.0;
-                    if (sidx < 2) {
-                        double total = 0.0;                                    // :67-79
-                        for (int j = 0; j < M; j++) total -= AW(j);
-                        d = total;
-                    }
-                    d += TW(sidx);                                          // :81-84
-                    qc[0] = d;
-                    if (sidx < 2) {
-#pragma unroll
-                        for (int q = 1; q < NP; q++) if (M > q - 1) qc[q] = AW(q - 1);
-                    }
-                    double t = -TGT(sidx);                                  // getQVec :109-113
-                    qv = t * TW(sidx);
-                } else {
-                    const int j = b - 1;
-                    if (sidx < 2) qc[0] = AW(j);                            // :74
-                    double dg = 0.0;
-                    if (sidx < 3) dg = -OPW(j, sidx);                       // :91 assignment (Q4)
-#pragma unroll
-                    for (int q = 1; q < NP; q++) if (b == q) qc[q] = dg;
-                    if (sidx < 3) { qv = OPT(j, sidx); qv = qv * -OPW(j, sidx); }   // :117,:121 (heading entry 0)
-                }
-#pragma unroll
-                for (int q = 0; q < NP; q++) CR.QC[i][q][r] = qc[q];
-                CR.QV[i][r] = qv;
-            }
-        }
-        __syncthreads();
-        QCompact<NP> qp;
-        qp.C = &CR;
         double u0[2];
         int singular = 0;
-        lq_solve_game<NP, QCompact<NP>, true>(r, LG, qp, 3, u0, singular);      // HKA:1201 horizon literal 3 (Q6)
+        lqn_stage_solve<NP, LqBlockSync>(game, r, (double)P.dt, games, LG, CR, u0, singular);
         if (live && r == 0) {
             if (singular) atomicOr(status, 1);
             hk_agent_state* me = &agents[game];
             uint32_t fl = me->flags; float st = me->steering;
             decode_controls(me->final_steer, fl, st, u0[0], u0[1], (dbg_out && (P.debug & 1)) ? &dbg_out[game] : nullptr);
             me->flags = fl; me->steering = st;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// In-wave path of the tick kernel (quads only).  Once the field has spread out a wave of 16 races holds a multi-player game
+// only now and then — two karts within 8 m of each other, i.e. a pair of 2-player games.  Queueing such a game costs its env a
+// round (it leaves the tick loop, waits for the solver kernel and resumes in the next launch, four ticks behind everyone
+// else), and the rounds that only serve the stragglers run at one wave's latency with a sixteenth of the lanes.  So when a
+// wave holds at most INW_MAX games of 2 or 3 players, its 64 lanes solve them on the spot — the same lq_solve_game<N> core on
+// 8 or 12 of the wave's lanes per game, in a per-wave LDS slice, synchronised by wave-scope fences instead of workgroup
+// barriers — and nobody leaves the loop.  Bulk (the race start: every ego has a game) still goes through the queues, where
+// the solver kernels pack 8 games per wave.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef HK_INWAVE_N3
+#define HK_INWAVE_N3 1
+#endif
+#ifndef HK_INWAVE_SPILL
+#define HK_INWAVE_SPILL 0
+#endif
+#ifndef HK_INWAVE_CALL
+#define HK_INWAVE_CALL __attribute__((noinline))
+#endif
+constexpr int INW_SLOTS2 = 2;          // 2-player games solved side by side (16 lanes)
+#ifndef HK_INWAVE_MAX
+#define HK_INWAVE_MAX 16
+#endif
+constexpr int INW_MAX = HK_INWAVE_MAX;            // more games than this in one wave: queue them
+struct InWaveN2 { LqGameLds<2> g[INW_SLOTS2]; CostRows<2> c[INW_SLOTS2]; };
+struct InWaveN3 { LqGameLds<3> g[1]; CostRows<3> c[1]; };
+struct __attribute__((aligned(16))) InWaveLds {
+    union { InWaveN2 n2; InWaveN3 n3; };
+};
+
+// the games of the lanes in `mask` (NP players each), SLOTS at a time; game_of_lane = env * A + ego of the calling lane.
+// Every lane of the wave must call this.  The controls go into the egos' records, as in lqn_body.
+template <int NP, int SLOTS>
+__device__ HK_INWAVE_CALL void inwave_solve(unsigned long long mask, const int game_of_lane, const EnvParams& P, hk_agent_state* agents,
+                                            const GameSoA games, LqGameLds<NP>* LG, CostRows<NP>* CR, hk_lq_debug* dbg_out, int* status)
+{
+    constexpr int n = LqDims<NP>::n;
+    const int lane = threadIdx.x & 63;
+    const int gs = lane / n, r = lane % n;
+    while (mask) {
+        int src = -1;
+#pragma unroll
+        for (int s = 0; s < SLOTS; s++) {          // slot s takes the next lane of the mask
+            const int b = mask ? __ffsll((long long)mask) - 1 : -1;
+            if (mask) mask &= mask - 1ull;
+            if (gs == s) src = b;
+        }
+        const bool live = gs < SLOTS && src >= 0;
+        const int game = __shfl(game_of_lane, live ? src : lane, 64);
+        if (live) {
+            double u0[2];
+            int singular = 0;
+            lqn_stage_solve<NP, LqWaveSync>(game, r, (double)P.dt, games, LG[gs], CR[gs], u0, singular);
+            if (r == 0) {
+                if (singular) atomicOr(status, 1);
+                hk_agent_state* me = &agents[game];
+                uint32_t fl = me->flags; float st = me->steering;
+                decode_controls(me->final_steer, fl, st, u0[0], u0[1], (dbg_out && (P.debug & 1)) ? &dbg_out[game] : nullptr);
+                me->flags = fl; me->steering = st;
+            }
         }
     }
 }

@@ -185,7 +185,11 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
             store_hot(a, h);
             const TabView T = tab_view(P, P.tab);
             reset_agent<TRAIN>(P, T, env, i, es.experiment_num, es.episodes_done, a);
+#ifdef HK_STAMPS
+            { Hot nh = load_hot(a); nh.st_t = h.st_t; for (int k = 0; k < HK_NSTAMP; k++) nh.st_acc[k] = h.st_acc[k]; h = nh; }
+#else
             h = load_hot(a);
+#endif
             hk_sincosf(h.yaw, &hfx, &hfz);
         }
         es.episode_steps = 0;
@@ -377,6 +381,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             hk_sincosf(yaw, &cfx, &cfz);
         }
     }
+    HK_ST(h, 8);                       // [8] actions, planFixed, ArcadeKart model, integration
     // ---- kart-kart contacts (Jacobi over one snapshot)
     {
         float ax = 0, az = 0, bx = 0, bz = 0;
@@ -417,6 +422,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             if (touched) fl |= HK_F_HAS_COLLISION; else fl &= ~HK_F_HAS_COLLISION;
         }
     }
+    HK_ST(h, 9);                       // [9] kart-kart contacts
     // ---- kart-wall contacts: deepest penetration, two passes
     if (enabled && (fl & HK_F_CAN_MOVE)) {
         for (int pass = 0; pass < 2; pass++) {
@@ -480,6 +486,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             h.contact_nx = bnx; h.contact_nz = bnz;
         }
     }
+    HK_ST(h, 10);                      // [10] kart-wall contacts
     bool bad = false;
     if (live) bad = !f_finite(px) || !f_finite(pz) || !f_finite(vx) || !f_finite(vz) || !f_finite(yaw) || !f_finite(wy);
     // ---- trigger dispatch (HKA.OnTriggerEnter :611-675) on the post-contact pose
@@ -578,6 +585,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             }
         }
     }
+    HK_ST(h, 11);                      // [11] Trigger overlap / enter, section and lane rules
     hfx = cfx; hfz = cfz;
     if (RW && !parked) rw_replay_events(P, RD, env, i, episode_steps, ev, nev, enabled, live && (fl & HK_F_ENABLED), rwv);
     if (live) {
@@ -604,6 +612,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
     bd = (uint32_t)group_or((int)bd);
     es.inactive_mask = inactive_mask | ni;      // identical in the lanes of the group
     if (bd) es.status = status | 1u;
+    HK_ST(h, 12);                      // [12] telemetry, per-env words
 }
 
 } }  // namespace hk::HK_GA_NS

@@ -50,13 +50,27 @@ struct __attribute__((aligned(16))) LqGameLds {
     double lu[m + 2];           // [0] pivot row, [1..m-1] multipliers of the current step, [m] singular flag
 };
 
+// How the lanes of a game synchronise their LDS traffic.  BlockSync: the solver kernels (one wave per workgroup; a workgroup
+// barrier).  WaveSync: the solve runs inside a multi-wave kernel on a subset of one wave's lanes (the tick kernel's in-wave
+// path): a workgroup barrier is not allowed there, and not needed — the LDS serves a wave's requests in order, so a compiler
+// fence is all it takes.
+struct LqBlockSync { static __device__ __forceinline__ void sync() { __syncthreads(); } };
+struct LqWaveSync {
+    static __device__ __forceinline__ void sync()
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+};
+
 // Q provider concept: double Q(int i, int r, int c); double q(int i, int r);   (player i's cost, ego-local order)
-// All 64 lanes of the wave must call this (it contains block barriers); r in [0, n) for real lanes.
+// With LqBlockSync all 64 lanes of the wave must call this (it contains block barriers); r in [0, n) for real lanes.
 // BICYCLE: the game is one of SolveLQR's (block-diagonal A, B_k with zero position rows — the linearised bicycle of
 // KartLQRDynamics.cs:40-62).  Then the position rows (x, z) of F = A - sum B_k P_k are exactly +0.0 outside their own player's
 // block, whatever P is, and the chain W = Z_i F may leave those terms out (fma(z, +0.0, s) = s exactly): 37 % of the chain at
 // N = 4.  The generic hk_lq_solve_batch (arbitrary A, B) keeps every term.
-template <int NP, class QP, bool BICYCLE = false>
+template <int NP, class QP, bool BICYCLE = false, class SYNC = LqBlockSync>
 __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const int horizon, double u0[2], int& singular)
 {
     constexpr int n = LqDims<NP>::n, m = LqDims<NP>::m;
@@ -109,7 +123,7 @@ __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const
             L.vec[r] = eo;
             if (r == 0) L.lu[m] = 0.0;
         }
-        __syncthreads();
+        SYNC::sync();
         // ---------------- S2: columns of [LHS | RHSMat | RHSVec] ----------------
         double col[m], sacc[m], bb[m], bv[m];
         {
@@ -138,7 +152,7 @@ __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const
                 }
             }
         }
-        __syncthreads();
+        SYNC::sync();
         // ---------------- S3: LU (JAMA order) + forward elimination of the right-hand sides ----------------
 #pragma unroll
         for (int k = 0; k < m; k++) {
@@ -166,7 +180,7 @@ __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const
                         L.lu[i] = col[i];
                     }
             }
-            __syncthreads();
+            SYNC::sync();
             const int p = (int)L.lu[0];
             double lm[m];
 #pragma unroll
@@ -198,14 +212,14 @@ __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const
                     double tempv = bv[k] * lm[i];
                     bv[i] = bv[i] - tempv;
                 }
-            __syncthreads();
+            SYNC::sync();
         }
         // publish U (upper triangle incl. diagonal): U[i][c] = col[i] of lane c
         if (r < m) {
 #pragma unroll
             for (int i = 0; i < m; i++) L.Pm[i][r] = col[i];
         }
-        __syncthreads();
+        SYNC::sync();
         // back substitution  U X = Y  (k descending)
 #pragma unroll
         for (int kk = 0; kk < m; kk++) {
@@ -224,7 +238,7 @@ __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const
                 }
         }
         if (L.lu[m] != 0.0) singular = 1;
-        __syncthreads();
+        SYNC::sync();
         // ---------------- S4: publish P (column r) and alpha ----------------
 #pragma unroll
         for (int i = 0; i < m; i++) {
@@ -232,7 +246,7 @@ __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const
             L.Pm[i][r] = bb[i];
             if (r == 0) L.Pm[i][n] = bv[i];
         }
-        __syncthreads();
+        SYNC::sync();
 #pragma unroll
         for (int i = 0; i < m; i++) alpha[i] = L.Pm[i][n];
         // ---------------- S5: F = A - sum_k B_k P_k (column r), beta = -sum_k B_k alpha_k (row r) ----------------
@@ -260,7 +274,7 @@ __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const
             tt = fma64(L.Bb[ib][(r & 3) * 2 + 1], a1, tt);
             L.beta[r] = 0.0 - tt;
         }
-        __syncthreads();
+        SYNC::sync();
         // ---------------- S6: per player Z_i, eta_i update (:113-119) ----------------
 #pragma unroll
         for (int i = 0; i < NP; i++) {
@@ -289,7 +303,7 @@ __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const
                 s = fma64(L.Rb[i][a * 2 + 1], pc[2 * i + 1], s);
                 L.RP[a][r] = s;
             }
-            __syncthreads();
+            SYNC::sync();
             // Z_i <- (Q_i + P_i'(R_i P_i)) + F'(Z_i F)   (row r), written in place over W[r][*]
             for (int c = 0; c < n; c += 2) {
                 double o0 = 0.0, o1 = 0.0;               // two independent chains (columns c, c+1)
@@ -308,7 +322,7 @@ __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const
                 const double z1 = (qp.Q(i, r, c + 1) + t21) + o1;
                 *reinterpret_cast<double2*>(&L.W[r][c]) = make_double2(z0, z1);
             }
-            __syncthreads();
+            SYNC::sync();
 #pragma unroll
             for (int c = 0; c < n; c++) Z[i][c] = L.W[r][c];
             // eta_i <- (q_i + P_i'(R_i alpha_i)) + F'(eta_i + Z_i beta)    with the NEW Z_i (Q2)
@@ -316,7 +330,7 @@ __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const
 #pragma unroll
             for (int k = 0; k < n; k++) zb = fma64(Z[i][k], L.beta[k], zb);
             L.vec[r] = eta[i] + zb;
-            __syncthreads();
+            SYNC::sync();
             double v3 = 0.0;
 #pragma unroll
             for (int k = 0; k < n; k++) v3 = fma64(Fcol[k], L.vec[k], v3);
@@ -329,7 +343,7 @@ __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const
             v2 = fma64(pc[2 * i + 0], ra0, v2);
             v2 = fma64(pc[2 * i + 1], ra1, v2);
             eta[i] = (qp.q(i, r) + v2) + v3;
-            __syncthreads();
+            SYNC::sync();
         }
     }
     // :121-126 u0 = -P_0 x0 - alpha_0   (all lanes compute it redundantly)

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Kernel-variant experiments: build/libhk_<name>.so = the default objects with hk_ga4.hip (the quad kernels) recompiled
+with extra -D flags.  Run a variant with HK_LIB_PATH=build/libhk_<name>.so (it travels to the GPU box with gpurun).
+
+  python tools/build_variant.py <name> [-DFOO=1 ...] [--unit hk_ga4.hip]"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge
+
+
+def main():
+    name = sys.argv[1]
+    defs = [a for a in sys.argv[2:] if a.startswith("-D") or a.startswith("-m") or a.startswith("-f")]
+    unit = "hk_ga4.hip"
+    if "--unit" in sys.argv:
+        unit = sys.argv[sys.argv.index("--unit") + 1]
+    ge.build()
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    obj = os.path.join(ge.OBJ_DIR, "%s_%s.o" % (name, unit.replace(".hip", "")))
+    subprocess.check_call([hipcc] + ge.HIPCC_FLAGS + defs + ["-c", os.path.join(ge.CSRC, unit), "-o", obj])
+    objs = [obj if u == unit else os.path.join(ge.OBJ_DIR, u.replace(".hip", ".o")) for u in ge.UNITS]
+    lib = os.path.join(ROOT, "build", "libhk_%s.so" % name)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib] + objs)
+    print(lib)
+
+
+if __name__ == "__main__":
+    main()
