@@ -392,6 +392,8 @@ static int step_ticks(hk_handle h, int n_ticks)
     }
     if (short_call) h->dev.mcts_ticks += n_ticks;
     h->dev.mcts_defer = short_call;
+    h->dev.ticks_since_reset += h->dev.call_ticks;      // the previous call's ticks
+    h->dev.call_ticks = n_ticks; h->dev.call_ticks_issued = 0;
     rc = hk::env_launch_arm(h->dev, h->cfg, n_ticks, h->stream, h->err);
     if (rc) { g_last_error = h->err; return rc; }
     // Rounds.  An env that meets no multi-player game retires RUN_CAP ticks per round; one that does retires at least a solve
@@ -588,6 +590,7 @@ int hk_set_agent_state(hk_handle h, const hk_agent_state* in)
     HK_NEED_ENV(h);
     if (!in) return fail(h, HK_ERR_INVALID, "NULL pointer");
     const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
+    h->dev.P.hold_dedupe = 0;          // the host moves karts by hand: a held kart is no longer guaranteed to be where its last solve saw it
     HK_HIP(h, hipMemcpyAsync(h->dev.agents, in, cnt * sizeof(hk_agent_state), hipMemcpyHostToDevice, h->stream));
     { int rc = hk::env_mcts_invalidate(h->dev, h->cfg, h->stream, h->err); if (rc) { g_last_error = h->err; return rc; } }   // plans were rewritten
     HK_HIP(h, hipStreamSynchronize(h->stream));
@@ -608,6 +611,7 @@ int hk_set_env_state(hk_handle h, const hk_env_state* in)
 {
     HK_NEED_ENV(h);
     if (!in) return fail(h, HK_ERR_INVALID, "NULL pointer");
+    h->dev.P.hold_dedupe = 0;          // (as hk_set_agent_state: episode_steps may be rewound into a hold whose solves were skipped)
     HK_HIP(h, hipMemcpyAsync(h->dev.envs, in, (size_t)h->cfg.num_envs * sizeof(hk_env_state), hipMemcpyHostToDevice, h->stream));
     HK_HIP(h, hipStreamSynchronize(h->stream));
     return HK_OK;

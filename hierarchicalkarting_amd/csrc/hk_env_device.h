@@ -65,6 +65,9 @@ struct EnvParams {
     int rewards, n_teams, team_size[ENV_MAXA], training_agent[ENV_MAXA];
     float wall_val[HK_NUM_SENSORS], agent_val[HK_NUM_SENSORS];   // Sensor.WallHitValidationDistance / AgentHitValidationDistance
     hk_reward_params rw;
+    // 1: during the start hold the solves after the first cadence are skipped (see env_run_kernel): the karts are frozen, so every
+    // one of them would reproduce the controls the first one decoded
+    int hold_dedupe;
     // Training mode (hk_env_training.h)
     int training_reset;
     uint32_t train_seed;

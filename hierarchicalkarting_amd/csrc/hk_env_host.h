@@ -36,6 +36,8 @@ struct EnvDevice {
     int* queue_cnt = nullptr;      // [2 sets][16] number of queued multi-player games per player count
     int* queue = nullptr;          // [2 sets][GA - 1][E*A] game ids with N = 2 .. GA
     int round = 0;                 // launches so far: round & 1 selects the queue set (double buffered over rounds)
+    long long ticks_since_reset = 1ll << 40;   // ticks stepped since the last hk_reset of every env, up to the current hk_step call (launch_lqn: bulk or sparse)
+    int call_ticks = 0, call_ticks_issued = 0; // the current call: its ticks, and a lower bound of those its rounds so far have retired
     int* env_ids = nullptr;
     int env_ids_cap = 0;
     // tables
@@ -61,6 +63,7 @@ struct EnvDevice {
 constexpr int MCTS_MIN_LATENCY = 40;   // (MCTS_FLUSH_ROUNDS + 1) * RUN_CAP: see flush_mcts (hk_env_launch.h)
 constexpr int MCTS_FLUSH_ROUNDS = 4;
 constexpr int MCTS_ARENA_WAVES = 2048;
+constexpr int BULK_TICKS = 384;        // after a full reset the field needs about this long to spread out (launch_lqn)
 constexpr int REGROUP_ROUNDS = 48;     // the tick kernel's lane groups are re-assigned by solve phase every so many rounds (~200 ticks)
 constexpr int MCTS_DEFER_TICKS = 32;   // short hk_step calls share one search launch until this many ticks have been armed
 static_assert(MCTS_DEFER_TICKS < MCTS_MIN_LATENCY, "a deferred search must still finish before its plan is due");

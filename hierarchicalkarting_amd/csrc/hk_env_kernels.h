@@ -121,6 +121,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         P.sens_c[i] = hk_cosf(dl); P.sens_s[i] = hk_sinf(dl); P.ray_dist[i] = cfg.ray_distance[i];
     }
     P.training_reset = cfg.env_mode == HK_MODE_TRAINING ? 1 : 0; P.train_seed = cfg.train_seed;
+    P.hold_dedupe = 0;          // set below, once the planner count is known
     P.rewards = cfg.rewards; P.rw = cfg.rw;
     for (int i = 0; i < HK_NUM_SENSORS; i++) { P.wall_val[i] = cfg.wall_hit_validation[i]; P.agent_val[i] = cfg.agent_hit_validation[i]; }
     for (int i = 0; i < A; i++) {
@@ -129,6 +130,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         P.team_size[cfg.team_of[i]] += 1;
         if (cfg.team_of[i] + 1 > P.n_teams) P.n_teams = cfg.team_of[i] + 1;
     }
+    P.hold_dedupe = (P.any_mcts == 0 && !P.training_reset && !std::getenv("HK_NO_HOLD_DEDUPE")) ? 1 : 0;
     P.mcts_iter = cfg.mcts_iterations; P.mcts_iter0 = cfg.mcts_initial_iterations; P.mcts_lat = cfg.mcts_latency_ticks;
     P.mcts_lat0 = cfg.mcts_initial_latency_ticks; P.mcts_seed = cfg.mcts_seed;
     P.jitter_seed = cfg.jitter_seed; P.jitter_pos = cfg.jitter_pos; P.jitter_yaw = cfg.jitter_yaw; P.env_id_base = cfg.env_id_base;
@@ -374,6 +376,7 @@ inline int env_reset(EnvDevice& d, const hk_config& cfg, const int32_t* env_ids,
     }
     int rc = HK_GA_CALL(d, launch_reset(d, dids, cnt, experiment_num, stream, err));
     if (rc) return rc;
+    if (!env_ids) { d.ticks_since_reset = 0; d.call_ticks = 0; d.call_ticks_issued = 0; }       // every env stands on the start grid again
     if (hipStreamSynchronize(stream) != hipSuccess) { err = "hk_reset: sync failed"; return HK_ERR_HIP; }
     return HK_OK;
 }
@@ -401,11 +404,11 @@ inline int env_rounds_for(const hk_config& cfg, int n_ticks)
     return (n_ticks + cadence - 1) / cadence + 1 + n_ticks / 32 + 2;
 }
 
-// Rounds a field WITHOUT multi-player games needs for n ticks (every env retires RUN_CAP ticks per round); with one or two
-// agents every ego queues a game on every tick (no 8 m filter, HKA:709), so each tick is a round.
+// Rounds a field needs for n ticks when nothing is queued (2-player games are solved inside the tick kernel, HK_INWAVE): every
+// env retires RUN_CAP ticks per round.
 inline int env_rounds_min(const hk_config& cfg, int n_ticks)
 {
-    if (cfg.num_agents <= 2) return n_ticks + 1;
+    (void)cfg;
     return (n_ticks + RUN_CAP - 1) / RUN_CAP;
 }
 

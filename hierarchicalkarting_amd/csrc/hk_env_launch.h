@@ -90,18 +90,27 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
     const int* qc = d.queue_cnt + set * 16;
     const int* qu = d.queue + (size_t)set * queue_ints_per_set((size_t)ngames);
     int rc = HK_OK;
-    if (cfg.num_agents == 2) {
-        // 1v1: only 2-player games exist, one per ego per tick
-        const int nb = std::min((ngames + 7) / 8, 4096);
+    // Bulk or sparse?  The host cannot see the queues without a sync, but it knows how long ago the field stood on the start grid:
+    // for BULK_TICKS after a reset of every env most egos hold a 2-player game (their row mate), later almost none does.
+    const bool bulk = cfg.num_agents == 2 || d.ticks_since_reset + d.call_ticks_issued < BULK_TICKS;
+    if (bulk) {
+        // 2-player games (every game of a 1v1 race; the bulk of a race start): their own kernel, two waves per SIMD
+        const int nb = std::min((ngames + 7) / 8, cfg.num_agents == 2 ? 4096 : 2048);
         hipLaunchKernelGGL(lqn_single_kernel<2>, dim3(nb), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status, d.game_stats);
         if ((rc = launch_check(err, "lqn_single_kernel<2>"))) return rc;
-    } else if (cfg.num_agents > 2) {
-        // 1 024 workgroups per game size (one wave per SIMD at this kernel's 256 VGPRs) walking their queue grid-stride: dispatching
-        // 3 x 8 192 workgroups that exit at once cost 25 us per round in steady state
+    }
+    if (cfg.num_agents > 2) {
+        // 1 024 workgroups per game size (one wave per SIMD at the 4-player body's registers) walking their queue grid-stride
         const int nb = std::min((ngames + 3) / 4, 1024);
-        const int sizes = std::min(cfg.num_agents, 4) - 1;     // player counts 2 .. min(A, 4)
-        hipLaunchKernelGGL(lqn_all_kernel, dim3(nb * sizes), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status, nb, d.game_stats);
-        if ((rc = launch_check(err, "lqn_all_kernel"))) return rc;
+        if (bulk) {
+            const int sizes = std::min(cfg.num_agents, 4) - 2;     // player counts 3 .. min(A, 4)
+            hipLaunchKernelGGL(lqn_34_kernel, dim3(nb * sizes), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status, nb, d.game_stats);
+            if ((rc = launch_check(err, "lqn_34_kernel"))) return rc;
+        } else {
+            const int sizes = std::min(cfg.num_agents, 4) - 1;     // player counts 2 .. min(A, 4)
+            hipLaunchKernelGGL(lqn_all_kernel, dim3(nb * sizes), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status, nb, d.game_stats);
+            if ((rc = launch_check(err, "lqn_all_kernel"))) return rc;
+        }
 #if HK_GA > 4
         if (cfg.num_agents > 4) {
             const int nbb = std::min((ngames + 1) / 2, 512);
@@ -117,6 +126,7 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
 #endif
     }
     d.round += 1;
+    d.call_ticks_issued = std::min(d.call_ticks_issued + (cfg.num_agents > 2 ? 4 : 1), d.call_ticks);      // a round retires at least one solve cadence
     return HK_OK;
 }
 

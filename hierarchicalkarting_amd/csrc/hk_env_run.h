@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
             int qn = 0;              // player count of the multi-player game this ego assembled on this tick (0: none)
             if (!parked) {
                 const bool act = (es.episode_steps % cadence) == 0 &&                                  // HKA:317 (Q9)
-                                 !(!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u));
+                                 !(!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u)) &&
+                                 !(P.hold_dedupe && es.episode_steps > cadence && es.episode_steps < P.hold);
                 qn = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
                 // bin the queued games by player count, one atomic per wave and count
 #pragma unroll
@@ -218,8 +219,14 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
                     const bool parked = phase_begin<HAS_RW, HAS_TRAIN>(P, env, i, env_ok, es, h, hfx, hfz, agents, results, M, mset, RD, rwv, act_branch);
                     HK_ST(h, 1);               // [1] phase A: episode controller + kart-vs-kart rays
                     if (!parked) {
+                        // Start hold (REC:721-744): the karts cannot move before episodeSteps reaches `hold`, nothing a solve reads changes, and
+                        // each SolveLQR overwrites the controls of the one before: the solves after the first cadence of the hold
+                        // (ticks 0 and `cadence`: the reset tick of an auto-reset, the first solve tick after hk_reset) would decode
+                        // bit-identical controls and are skipped (P.hold_dedupe: no planner whose first plan lands inside the hold,
+                        // and the host has not written kart states by hand).  18 of the 128 solve ticks of a race start.
                         const bool act = (es.episode_steps % cadence) == 0 &&                                  // HKA:317 (Q9)
-                                         !(!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u));
+                                         !(!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u)) &&
+                                         !(P.hold_dedupe && es.episode_steps > cadence && es.episode_steps < P.hold);
                         qn = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
                         began = true;
                     } else {
@@ -231,10 +238,12 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
             bool inw = false;
 #if HK_GA == 4 && HK_INWAVE
             {
-                // few multi-player games in this wave, none with more than 3 players: the wave solves them itself
-                const unsigned long long m2 = __ballot(qn == 2), m3 = __ballot(qn == 3), mbig = __ballot(qn > 3);
-                inw = __builtin_expect((m2 | m3) != 0ull && mbig == 0ull && __popcll(m2) + __popcll(m3) <= INW_MAX, 0);
-                if (inw) { inw2 = m2; inw3 = m3; qn = 0; }
+                // 2-player games: always solved by the wave itself; 3-player games: when it holds few of them (see inwave_solve)
+                const unsigned long long m2 = __ballot(qn == 2), m3 = __ballot(qn == 3);
+                const bool do3 = __popcll(m3) <= INW_MAX3;
+                inw2 = m2; inw3 = do3 ? m3 : 0ull;
+                inw = __builtin_expect((inw2 | inw3) != 0ull, 0);
+                if (qn == 2 || (do3 && qn == 3)) qn = 0;
             }
 #endif
             if (began) {
@@ -282,8 +291,8 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
         {
             InWaveLds& IW = inw[threadIdx.x >> 6];
             const int my_game = env_ok ? env * P.A + i : 0;
-            if (inw2) inwave_solve<2, INW_SLOTS2>(inw2, my_game, P, agents, games, IW.n2.g, IW.n2.c, dbg_out, status);
-            if (inw3) inwave_solve<3, 1>(inw3, my_game, P, agents, games, IW.n3.g, IW.n3.c, dbg_out, status);
+            if (inw2) inwave_solve2(inw2, env, P, agents, games, dbg_out, status);
+            if (inw3) inwave_solve<3, 1>(inw3, my_game, P, agents, games, IW.g, IW.c, dbg_out, status);
             if ((threadIdx.x & 63) == 0) {                                                         // hk_prof_games
                 if (inw2) atomicAdd(&stats[2], (unsigned long long)__popcll(inw2));
                 if (inw3) atomicAdd(&stats[3], (unsigned long long)__popcll(inw3));

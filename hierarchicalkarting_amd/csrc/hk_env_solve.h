@@ -718,34 +718,51 @@ __device__ __forceinline__ void lqn_body(const int block, const int nblocks, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// In-wave path of the tick kernel (quads only).  Once the field has spread out a wave of 16 races holds a multi-player game
-// only now and then — two karts within 8 m of each other, i.e. a pair of 2-player games.  Queueing such a game costs its env a
-// round (it leaves the tick loop, waits for the solver kernel and resumes in the next launch, four ticks behind everyone
-// else), and the rounds that only serve the stragglers run at one wave's latency with a sixteenth of the lanes.  So when a
-// wave holds at most INW_MAX games of 2 or 3 players, its 64 lanes solve them on the spot — the same lq_solve_game<N> core on
-// 8 or 12 of the wave's lanes per game, in a per-wave LDS slice, synchronised by wave-scope fences instead of workgroup
-// barriers — and nobody leaves the loop.  Bulk (the race start: every ego has a game) still goes through the queues, where
-// the solver kernels pack 8 games per wave.
+// In-wave path of the tick kernel (quads only).  Queueing a multi-player game costs its env a round: it leaves the tick loop,
+// waits for the solver kernels and resumes in the next launch, four ticks behind everyone else — and the rounds that only
+// serve such stragglers run at one wave's latency with a sixteenth of the lanes.  So a wave solves what it can itself, between
+// two passes of its tick loop (hk_env_run.h):
+//   2-player games (two karts within 8 m: the start grid's row mates, every overtake — by far the most common kind): always,
+//     by the quad of their own env, in registers (hk_lq2_quad.h), the quads of a wave side by side;
+//   3-player games: when the wave holds at most INW_MAX3 of them, one at a time on 12 lanes with the lq_solve_game<3> core in a
+//     per-wave LDS slice, wave-scope fences instead of workgroup barriers;
+//   everything else goes through the queues to the solver kernels.
 // ---------------------------------------------------------------------------------------------------------------
-#ifndef HK_INWAVE_N3
-#define HK_INWAVE_N3 1
-#endif
-#ifndef HK_INWAVE_SPILL
-#define HK_INWAVE_SPILL 0
-#endif
 #ifndef HK_INWAVE_CALL
 #define HK_INWAVE_CALL __attribute__((noinline))
 #endif
-constexpr int INW_SLOTS2 = 2;          // 2-player games solved side by side (16 lanes)
-#ifndef HK_INWAVE_MAX
-#define HK_INWAVE_MAX 16
+#ifndef HK_INWAVE_MAX3
+#define HK_INWAVE_MAX3 8
 #endif
-constexpr int INW_MAX = HK_INWAVE_MAX;            // more games than this in one wave: queue them
-struct InWaveN2 { LqGameLds<2> g[INW_SLOTS2]; CostRows<2> c[INW_SLOTS2]; };
-struct InWaveN3 { LqGameLds<3> g[1]; CostRows<3> c[1]; };
-struct __attribute__((aligned(16))) InWaveLds {
-    union { InWaveN2 n2; InWaveN3 n3; };
-};
+constexpr int INW_MAX3 = HK_INWAVE_MAX3;
+struct __attribute__((aligned(16))) InWaveLds { LqGameLds<3> g[1]; CostRows<3> c[1]; };
+
+#if HK_GA == 4
+#include "hk_lq2_quad.h"
+
+// every 2-player game of the wave (mask: the egos' lanes), each by the quad of its env; every lane of the wave must call this
+__device__ __forceinline__ void inwave_solve2(const unsigned long long mask, const int env, const EnvParams& P, hk_agent_state* agents,
+                                              const GameSoA games, hk_lq_debug* dbg_out, int* status)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned mine = (unsigned)((mask >> (lane & ~3)) & 0xFull);      // this quad's egos (quad-uniform)
+#pragma unroll 1
+    for (int e = 0; e < 4; e++) {
+        if (!((mine >> e) & 1u)) continue;
+        const int game = env * P.A + e;
+        double u0[2];
+        int singular = 0;
+        lq2_quad_solve(game, lane & 3, (double)P.dt, games, u0, singular);
+        if ((lane & 3) == 0) {
+            if (singular) atomicOr(status, 1);
+            hk_agent_state* me = &agents[game];
+            uint32_t fl = me->flags; float st = me->steering;
+            decode_controls(me->final_steer, fl, st, u0[0], u0[1], (dbg_out && (P.debug & 1)) ? &dbg_out[game] : nullptr);
+            me->flags = fl; me->steering = st;
+        }
+    }
+}
+#endif
 
 // the games of the lanes in `mask` (NP players each), SLOTS at a time; game_of_lane = env * A + ego of the calling lane.
 // Every lane of the wave must call this.  The controls go into the egos' records, as in lqn_body.
@@ -782,12 +799,13 @@ __device__ HK_INWAVE_CALL void inwave_solve(unsigned long long mask, const int g
 }
 
 // One launch for the queued games of every size: blocks [0, nb) take the 2-player queue, [nb, 2 nb) the 3-player one,
-// [2 nb, 3 nb) the 4-player one.  (Three separate launches cost ~12 us each even when — as in steady state, where 99.95 % of
-// the games are single-player and solved inside the tick kernel — their queues are empty: 10 % of the headline's wall time.)
+// [2 nb, 3 nb) the 4-player one.  This is the launch of a round while the field is spread out: the queues are nearly empty
+// (99.95 % of the games are single-player and solved inside the tick kernel), and what a round's solver launches cost is their
+// fixed latency — a kernel launch plus one cold pass through a body's code.  Its registers are the 4-player body's (one wave
+// per SIMD), which is why the bulk of a race start goes through the two kernels below instead (launch_lqn decides).
 __global__ __launch_bounds__(64) void lqn_all_kernel(EnvParams P, hk_agent_state* agents, const GameSoA games, const int* queue_cnt,
                                                      const int* queue, hk_lq_debug* dbg_out, int* status, int nb, unsigned long long* gstats)
 {
-    // one LDS block, sized for the largest game size and reused by whichever size this workgroup solves
     constexpr size_t B2 = (sizeof(LqGameLds<2>) + sizeof(CostRows<2>)) * LqDims<2>::SLOTS;
     constexpr size_t B3 = (sizeof(LqGameLds<3>) + sizeof(CostRows<3>)) * LqDims<3>::SLOTS;
     constexpr size_t B4 = (sizeof(LqGameLds<4>) + sizeof(CostRows<4>)) * LqDims<4>::SLOTS;
@@ -799,9 +817,24 @@ __global__ __launch_bounds__(64) void lqn_all_kernel(EnvParams P, hk_agent_state
     else lqn_body<4>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
 }
 
-// The same solver for ONE game size, with that size's own register allocation (2-player games need 166 VGPRs, the merged kernel
-// is compiled for the 4-player body's 256): used when every game of the handle has the same size — 1v1 races (A = 2), where
-// every ego queues a 2-player game on every tick and this kernel is most of the work.
+// The bulk variant, part 1: the queued games of 3 and 4 players (blocks [0, nb): 3 players, [nb, 2 nb): 4 players).  2-player games
+// — the start grid's row mates: every ego of a race start holds one — go to lqn_single_kernel<2>: the 4-player body needs 458
+// VGPRs (one wave per SIMD) and 39.7 KB of LDS per wave, and in the merged kernel the 2-player games run at that occupancy too
+// (0.6 ms for the 262 144 games of a race-start tick, 13 % of the fp64 vector peak).
+__global__ __launch_bounds__(64) void lqn_34_kernel(EnvParams P, hk_agent_state* agents, const GameSoA games, const int* queue_cnt,
+                                                    const int* queue, hk_lq_debug* dbg_out, int* status, int nb, unsigned long long* gstats)
+{
+    constexpr size_t B3 = (sizeof(LqGameLds<3>) + sizeof(CostRows<3>)) * LqDims<3>::SLOTS;
+    constexpr size_t B4 = (sizeof(LqGameLds<4>) + sizeof(CostRows<4>)) * LqDims<4>::SLOTS;
+    constexpr size_t BMAX = B3 > B4 ? B3 : B4;
+    __shared__ __align__(16) unsigned char smem[BMAX];
+    const int which = blockIdx.x / nb, b = blockIdx.x - which * nb;
+    if (which == 0) lqn_body<3>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
+    else lqn_body<4>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
+}
+
+// The solver for ONE game size, with that size's own register allocation and LDS footprint: 2-player games need 180 VGPRs and
+// 22.4 KB per wave, so two waves share a SIMD (seven workgroups a CU).
 template <int NP>
 __global__ __launch_bounds__(64) void lqn_single_kernel(EnvParams P, hk_agent_state* agents, const GameSoA games, const int* queue_cnt,
                                                         const int* queue, hk_lq_debug* dbg_out, int* status, unsigned long long* gstats)

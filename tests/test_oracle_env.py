@@ -101,11 +101,15 @@ def _race(A, ex):
 
 @pytest.mark.parametrize("A,ex", [(2, 0), (2, 1), (4, 0), (4, 7)])
 def test_race_finishes_inside_the_reference_band(A, ex):
-    """Fixed-LQNG Oval, 4 laps: reference mean 3972 ticks (1v1) / 4127 (2v2), best lap 18.6-19.8 s.  The
-    engine is restated (not PhysX), so the pin is distributional: every kart finishes, in 3.6-4.4 k ticks."""
+    """Fixed-LQNG Oval, 4 laps: reference mean 3972 ticks (1v1) / 4127 (2v2), best lap 18.6-19.8 s.
+    Fixed-vs-Fixed races of the oracle: 3.80-3.95 k ticks, i.e. 1-4 % (1v1) / 4-8 % (2v2) under the reference means, which
+    come from races against an MCTS or RL opponent (no Fixed-vs-Fixed log exists); the like-for-like comparison, with its
+    residuals, is tests/test_reference_logs.py.  The band here is the SURVEY's, widened by that documented residual on the fast
+    side only: nothing may finish faster than 3.75 k or slower than 4.13 k ticks; the best lap must be inside 18.3-19.8 s."""
     res, st = _race(A, ex)
     assert (res["section_index"] == 97).all()                       # goalSection = 4*24 + 1 (REC:165)
-    assert (res["time_steps"] > 3600).all() and (res["time_steps"] < 4400).all(), res["time_steps"]
+    assert (res["time_steps"] > 3750).all() and (res["time_steps"] < 4130).all(), res["time_steps"]
+    assert (res["best_lap"] > 18.3).all() and (res["best_lap"] < 19.8).all(), res["best_lap"]
     assert (res["episode"] == 0).all()
     assert not (st["flags"] & (HL.HK_F_ACTIVE | HL.HK_F_ENABLED | HL.HK_F_CAN_MOVE)).any()
     assert (st["vx"] == 0).all() and (st["vz"] == 0).all()
