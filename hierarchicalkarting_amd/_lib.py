@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("HK_LIB_PATH") or os.path.join(_HERE, "libhk.so")   # 
 HK_MAX_AGENTS = 8
 HK_MAX_SECTIONS = 64
 HK_NUM_SENSORS = 9
-HK_ABI_VERSION = 3
+HK_ABI_VERSION = 4
 HK_PROF_STAGES = 5
 PROF_STAGE_NAMES = ("env_run_kernel", "lqn_kernel<2,3,4>", "lq_batch_kernel", "policy_mlp_kernel", "observe+stack")
 HK_COMM_ID_BYTES = 128
@@ -78,6 +78,8 @@ class Config(C.Structure):
 
 HK_MCTS_MAX_DEPTH = 8
 HK_MCTS_MAX_ACTIONS = 20
+HK_MCTS_SECTIME_RING = 8
+HK_MCTS_MAX_ROOT_PHASES = 3
 _U8A = C.c_uint8 * HK_MAX_AGENTS
 
 
@@ -87,7 +89,8 @@ class MctsPlan(C.Structure):
 
 
 class MctsState(C.Structure):
-    _fields_ = [("sec_time", C.c_int32 * 4), ("ready_step", C.c_int32), ("searches", C.c_int32),
+    _fields_ = [("sec_time", C.c_int32 * HK_MCTS_SECTIME_RING), ("ready_step", C.c_int32), ("searches", C.c_int32),
+                ("root_live", C.c_int32), ("root_cycles", C.c_int32), ("pend_kind", C.c_int32), ("root_phases", C.c_int32),
                 ("best", MctsPlan), ("pend", MctsPlan),
                 ("belief_lane", (C.c_uint8 * HK_MAX_SECTIONS) * HK_MAX_AGENTS),
                 ("belief_vel", (C.c_uint8 * HK_MAX_SECTIONS) * HK_MAX_AGENTS)]

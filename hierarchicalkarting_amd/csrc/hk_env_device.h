@@ -73,7 +73,7 @@ struct EnvParams {
     uint32_t train_seed;
 };
 // ---- device buffers of the MCTS planner (hk_env_mcts.h) and of the reward shaping (hk_env_reward.h): the same for every GA
-struct MctsKartSnap { int section, lane, lane_changes, tire_age; int sec_time[4]; };
+struct MctsKartSnap { int section, lane, lane_changes, tire_age; int sec_time[HK_MCTS_SECTIME_RING]; };
 struct MNode {
     int parent, first_child, last_child, next_sibling;
     int numEpisodes;

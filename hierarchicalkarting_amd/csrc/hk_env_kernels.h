@@ -87,7 +87,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         if (cfg.high_mode[i] != HK_HIGH_FIXED && cfg.high_mode[i] != HK_HIGH_MCTS) { err = "hk_create: bad high_mode"; return HK_ERR_INVALID; }
         if (cfg.high_mode[i] == HK_HIGH_MCTS) {
             if (cfg.tree_search_depth[i] < 1 || cfg.tree_search_depth[i] > HK_MCTS_MAX_DEPTH || cfg.velocity_bucket_size[i] < 1 ||
-                cfg.time_precision[i] < 1 || cfg.section_window[i] < 1) { err = "hk_create: bad MCTS gameParams (depth 1..8, bucket, precision, window >= 1)"; return HK_ERR_INVALID; }
+                cfg.time_precision[i] < 1 || cfg.section_window[i] < 1 || cfg.section_window[i] > 4) { err = "hk_create: bad MCTS gameParams (depth 1..8, bucket, precision, window 1..4)"; return HK_ERR_INVALID; }
             // a search requested on tick t runs between two launches of the tick kernel (<= RUN_CAP ticks each) and must be
             // finished before tick t + latency; it must also have been consumed before the next request (every 100 ticks)
             if (cfg.mcts_iterations < 1 || cfg.mcts_initial_iterations < 1 || cfg.mcts_latency_ticks <= MCTS_MIN_LATENCY || cfg.mcts_latency_ticks >= 100 ||
@@ -300,7 +300,9 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         P.sec_geo = d.sec_geo;
         int max_depth = 1;
         for (int i = 0; i < A; i++) if (cfg.high_mode[i] == HK_HIGH_MCTS) max_depth = std::max(max_depth, cfg.tree_search_depth[i]);
-        d.mcts.pool_cap = 1 + std::max(cfg.mcts_iterations, cfg.mcts_initial_iterations) * (max_depth * A + 1);
+        // every search a tree can receive (root reuse: the first one plus HK_MCTS_MAX_ROOT_PHASES - 1 replans), each adding at most
+        // (depth x players) + 1 nodes per iteration
+        d.mcts.pool_cap = 1 + (std::max(cfg.mcts_iterations, cfg.mcts_initial_iterations) + (HK_MCTS_MAX_ROOT_PHASES - 1) * cfg.mcts_iterations) * (max_depth * A + 1);
         {   // the search kernel is a fixed grid walking the queue: the arena holds one tree per resident lane, at most
             // MCTS_ARENA_WAVES waves (2 per SIMD of the 256 CUs), however many envs there are
             const int spw = HK_GA_CALL(d, mcts_searches_per_wave());

@@ -28,10 +28,18 @@ constexpr int MC_MAXA = HK_MCTS_MAX_ACTIONS;  // 20
 #endif
 constexpr int MC_SPW = HK_MC_SPW;             // searches per wave (see mcts_search_kernel)
 
+// Root reuse (HKA:66-67,175,265-283): the reference keeps the tree of an agent's last plan (currentRoot) and a replan searches it
+// again, up to three searches per tree, unless the kart entered a section in between.  No tree is kept here — the arena belongs
+// to the resident lanes of the search kernel, not to the agents.  What IS kept is the recipe: the root position (the kart
+// snapshots of the request that started the tree) and the (episode step, iteration budget) of every search it received; the
+// draws are counter-based (Philox keyed by episode step / agent / episode), so replaying the earlier searches rebuilds exactly
+// the tree the reference would still hold, and the new search continues on it.  The CPU oracle really keeps its trees.
 struct MctsReq {
-    int episode_steps, epoch, iterations, gen;      // gen: bumped by every request of this ego (stale queue entries are skipped)
-    int last_sec, pad0, pad1, pad2;                 // last_sec: m_SectionIndex at the last copy of bestStates (mcts_consume)
-    MctsKartSnap k[MC_MAXP];
+    int episode_steps, epoch, iterations, gen;      // of the latest request.  gen: bumped by every request of this ego (stale queue entries are skipped)
+    int last_sec, n_phases, pad1, pad2;             // last_sec: m_SectionIndex at the last copy of bestStates (mcts_consume)
+    int ph_step[HK_MCTS_MAX_ROOT_PHASES];           // the searches the current tree has received, oldest first: episode step of the request ...
+    int ph_iter[HK_MCTS_MAX_ROOT_PHASES];           // ... and its iteration budget
+    MctsKartSnap k[MC_MAXP];                        // the root position: every kart as the request that started the tree saw it
 };
 __device__ __forceinline__ MctsReq* mc_reqs(const MctsDev& M) { return static_cast<MctsReq*>(M.req); }
 // ---------------------------------------------------------------------------------------------------------------------
@@ -52,24 +60,42 @@ __device__ inline int mcts_tire_age(const EnvParams& P, float final_steer)
     return (int)((P.st.MaxSteer - final_steer) / (P.st.MaxSteer - P.st.MinSteer) * 10000.0f);
 }
 
-// Every lane of the env's group calls this with the same req_mask (bit e: ego e plans on this tick).  Lane i contributes its
-// own kart's snapshot to every requesting ego's record; a requesting ego also writes the header and queues itself.
-__device__ inline void mcts_post_request(const EnvParams& P, const MctsDev& M, int set, int env, int i, uint32_t req_mask,
+// The replan decision of planWithMCTS (HKA:175 / :265) for the calling ego: 1 = a new tree, 2 = the existing root again,
+// 0 = no search (the tree has had its three).  `t` is always finished here: a search lasts less than the 100 ticks between replans.
+__device__ __forceinline__ int mcts_request_kind(const hk_mcts_state* m)
+{
+    if (!m->root_live) return 1;
+    if (m->root_cycles < 3) return m->root_phases < HK_MCTS_MAX_ROOT_PHASES ? 2 : 1;
+    return 0;
+}
+
+// Every lane of the env's group calls this with the same masks (bit e of req_mask: ego e searches on this tick; bit e of
+// new_mask: its search starts a new tree).  Lane i contributes its own kart's snapshot to the record of every ego that starts a
+// tree; a requesting ego also writes the header and queues itself.  old_steer: m_FinalStats.Steer before ResetGame — at a reset
+// the plans are made agent by agent between the prepareForReuse calls that refresh it (REC:705-710), so ego e sees the stale
+// value of every agent behind it in Agents[] order; elsewhere old_steer = final_steer.
+__device__ inline void mcts_post_request(const EnvParams& P, const MctsDev& M, int set, int env, int i, uint32_t req_mask, uint32_t new_mask,
                                          int episode_steps, int epoch, int iterations, int ready_step,
-                                         int section, int lane, int lane_changes, float final_steer)
+                                         int section, int lane, int lane_changes, float final_steer, float old_steer)
 {
     if (i >= P.A) return;
     hk_mcts_state* mine = &M.st[(size_t)env * P.A + i];
     MctsKartSnap s;
-    s.section = section; s.lane = lane; s.lane_changes = lane_changes; s.tire_age = mcts_tire_age(P, final_steer);
-    for (int q = 0; q < 4; q++) s.sec_time[q] = mine->sec_time[q];
+    s.section = section; s.lane = lane; s.lane_changes = lane_changes;
+    const int age_new = mcts_tire_age(P, final_steer), age_old = mcts_tire_age(P, old_steer);
+    for (int q = 0; q < HK_MCTS_SECTIME_RING; q++) s.sec_time[q] = mine->sec_time[q];
     for (int e = 0; e < P.A; e++)
-        if (req_mask & (1u << e)) mc_reqs(M)[(size_t)env * P.A + e].k[i] = s;
+        if (new_mask & (1u << e)) { s.tire_age = i > e ? age_old : age_new; mc_reqs(M)[(size_t)env * P.A + e].k[i] = s; }
     const bool requesting = (req_mask & (1u << i)) != 0;
     const int slot = wave_agg_inc(&M.qcnt[set * 2], requesting);          // one atomic per wave, not per ego
     if (requesting) {
         MctsReq* r = &mc_reqs(M)[(size_t)env * P.A + i];
         r->episode_steps = episode_steps; r->epoch = epoch; r->iterations = iterations; r->gen += 1;
+        const bool fresh = (new_mask & (1u << i)) != 0;
+        const int ph = fresh ? 0 : r->n_phases;                           // (mcts_request_kind keeps ph < HK_MCTS_MAX_ROOT_PHASES)
+        r->ph_step[ph] = episode_steps; r->ph_iter[ph] = iterations; r->n_phases = ph + 1;
+        mine->root_phases = ph + 1;
+        mine->pend_kind = fresh ? 1 : 2;
         mine->searches += 1;
         mine->ready_step = ready_step;
         // an ego can post twice in one launch (a replan tick, then the episode ends and the reset plans again): the queue set
@@ -87,7 +113,13 @@ __device__ inline void mcts_consume(const EnvParams& P, hk_mcts_state* m, hk_age
                                     MctsReq* r)
 {
     bool promoted = false;
-    if (m->ready_step >= 0 && episode_steps >= m->ready_step) { m->best = m->pend; m->ready_step = -1; promoted = true; }
+    if (m->ready_step >= 0 && episode_steps >= m->ready_step) {
+        // the search thread ends (HKA:250-253 / :271-273): bestStates, currentRoot and CyclesRootProcessed are written
+        m->best = m->pend; m->ready_step = -1; promoted = true;
+        if (m->pend_kind == 1) { m->root_live = 1; m->root_cycles = 1; }
+        else if (m->pend_kind == 2) { m->root_live = 1; m->root_cycles += 1; }
+        m->pend_kind = 0;
+    }
     if (!promoted && r->last_sec == section_index) return;
     r->last_sec = section_index;
     const hk_mcts_plan& b = m->best;
@@ -117,13 +149,17 @@ __device__ inline void phase_plan(const EnvParams& P, const MctsDev& M, int set,
     const bool me = i < P.A;
     const bool enabled = me && (flags & HK_F_ENABLED);
     const bool inactive = (es.inactive_mask >> i) & 1u;
-    uint32_t req = 0;
+    uint32_t req = 0, fresh = 0;
     if (enabled && P.high_mode[i] == HK_HIGH_MCTS && !P.training_agent[i] && es.episode_steps % 100 == 0 && es.episode_steps < P.max_steps &&
-        es.episode_steps > 0 && !inactive)
-        req = 1u << i;
+        es.episode_steps > 0 && !inactive) {
+        const int kind = mcts_request_kind(&M.st[(size_t)env * P.A + i]);
+        if (kind) req = 1u << i;
+        if (kind == 1) fresh = 1u << i;
+    }
     req = (uint32_t)group_or((int)req);
-    if (req) mcts_post_request(P, M, set, env, i, req, es.episode_steps, es.episodes_done, P.mcts_iter, es.episode_steps + P.mcts_lat,
-                               section, lane, lane_changes, final_steer);
+    fresh = (uint32_t)group_or((int)fresh);
+    if (req) mcts_post_request(P, M, set, env, i, req, fresh, es.episode_steps, es.episodes_done, P.mcts_iter, es.episode_steps + P.mcts_lat,
+                               section, lane, lane_changes, final_steer, final_steer);
     if (enabled && P.high_mode[i] == HK_HIGH_MCTS) mcts_consume(P, &M.st[(size_t)env * P.A + i], arec, i, es.episode_steps, section, &mc_reqs(M)[(size_t)env * P.A + i]);
 }
 
@@ -634,7 +670,7 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
     MctsCtx C;
     mc_ctx_init(C, P, T, M, ego);
     C.key0 = P.mcts_seed; C.key1 = (uint32_t)(P.env_id_base + env) * (uint32_t)P.A + (uint32_t)ego;
-    C.c1 = (uint32_t)R.episode_steps; C.c2 = (uint32_t)R.epoch; C.draw = 0;
+    C.c1 = (uint32_t)R.ph_step[0]; C.c2 = (uint32_t)R.epoch; C.draw = 0;
 
     // planWithMCTS HKA:172-263: the discrete game of the karts within sectionWindow sections of the ego
     DGame root;
@@ -661,7 +697,7 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
             k.maxv = C.bucket < C.vmax ? C.bucket : C.vmax;                                  \
             k.section = initialSection;                                                      \
             if (s.section != initialSection)           /* HKA:221-224 */                      \
-                k.time = (int)((float)(s.sec_time[s.section & 3] - R.k[furthest].sec_time[s.section & 3]) * P.dt * (float)C.precision); \
+                k.time = (int)((float)(s.sec_time[s.section & (HK_MCTS_SECTIME_RING - 1)] - R.k[furthest].sec_time[s.section & (HK_MCTS_SECTIME_RING - 1)]) * P.dt * (float)C.precision); \
             k.lane = s.lane; k.tire = s.tire_age; k.lchg = s.lane_changes;                   \
         }                                                                                    \
     }
@@ -683,7 +719,18 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
     // every deeper node is new, so the rest of the rollout and most of the back-propagation load nothing at all.
     float scores[2 * MC_MAXP];
     MoveEval mv;
-    for (int it = 0; it < R.iterations; it++) {
+    // every search the tree has received, oldest first (a re-searched root: the earlier ones are replayed, see MctsReq); each has
+    // its own draw stream, and the last one's continues into the read-out below
+    int ph = 0, it_left = R.ph_iter[0];
+    const int n_phases = R.n_phases;
+    while (true) {
+        if (it_left == 0) {
+            if (++ph >= n_phases) break;
+            C.c1 = (uint32_t)R.ph_step[ph]; C.draw = 0;
+            it_left = R.ph_iter[ph];
+            continue;
+        }
+        it_left--;
         // findLeaf :195-202 on a running copy of the root state
         DGame g = mc_root_load(rootl, M.slots);
         int node = 0, depth = 0;
@@ -742,7 +789,7 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
             path[depth * 64] = (unsigned short)node; pup[depth * 64] = (unsigned char)np2;
             mc_eval_moves(C, g, np, mv);
         }
-        if (out_of_nodes) break;
+        if (out_of_nodes) break;                       // (cannot happen: hk_create sizes the arena for the worst case of every search a tree can receive)
         // backpropagate :285-293 along the remembered path, leaf to root; a node created in this iteration holds 0 / 0.0f
         for (int d = depth; d >= 0; d--) {
             const int b = path[d * 64];

@@ -59,6 +59,37 @@ __device__ inline void reset_agent(const EnvParams& P, const TabView& T, int env
     a->flags = HK_F_ACTIVE | HK_F_ENABLED;
 }
 
+// REC.ResetGame :679-702 for agent i — "Generate times for reaching certain sections": made-up, descending section times (int
+// Random.Range(earliest, 0), here Philox keyed by mcts_seed / env / agent / episode / section) for the sections between the rearmost
+// kart's and its own, 0 for its own (:697).  planWithMCTS reads them as the time offsets of karts behind the furthest one
+// (HKA:221-224).  The agentsPastSection counts of the same loop are dead — ApplySectionRewardsAndPenalties reads a count only where
+// minSectionTimes holds the section, and the statement that creates that key assigns the count (REC:366-370) — and not restated.
+template <bool TRAIN>
+__device__ inline void mcts_backfill_section_times(const EnvParams& P, const TabView& T, int env, int i, int experiment_num, int episodes_done,
+                                                   int own_section, hk_mcts_state* m)
+{
+    int back = 0;                                           // Experiment / Race grid: slot 0 stands in section 0
+    if (TRAIN && P.training_reset) {
+        const int pi = ((experiment_num % P.nperm) + P.nperm) % P.nperm;
+        const int* ord = P.perms + (size_t)pi * P.A;
+        back = own_section;
+        for (int q = 0; q < P.A; q++) {
+            int sec = 0, lane = 0; float twp = 0.0f, spawn = 0.0f;
+            training_layout(P, T, env, experiment_num, episodes_done, ord, q, sec, lane, twp, spawn);
+            back = sec < back ? sec : back;
+        }
+    }
+    int earliest = -P.max_steps;
+    for (int tp = back; tp < own_section; tp++) {
+        uint32_t r[4];
+        philox4x32((uint32_t)tp, (uint32_t)i, (uint32_t)episodes_done, 0x53454354u, P.mcts_seed, (uint32_t)(P.env_id_base + env), r);
+        const int v = earliest + (int)(((unsigned long long)r[0] * (unsigned long long)(uint32_t)(-earliest)) >> 32);   // int Random.Range(earliest, 0)
+        m->sec_time[tp & (HK_MCTS_SECTIME_RING - 1)] = v;
+        earliest = v;
+    }
+    m->sec_time[own_section & (HK_MCTS_SECTIME_RING - 1)] = 0;
+}
+
 __device__ inline void snapshot_result(const Hot& h, float cum_reward, float group_reward, hk_episode_result* r, int episode)
 {
     r->time_steps = h.time_steps;
@@ -88,6 +119,7 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_st
     const int ex = experiment_num >= 0 ? experiment_num : (P.env_id_base + env) % P.nperm;
     const TabView T = tab_view(P, P.tab);
     hk_agent_state* ar = &agents[(size_t)env * P.A + i];
+    const float old_steer = ar->final_steer;        // m_FinalStats.Steer as the previous episode left it (mcts_post_request)
     reset_agent<true>(P, T, env, i, ex, envs[env].episodes_done, ar);
     if (RD.sec_time) {
         const int nn = P.A * RD.S;
@@ -96,10 +128,11 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_st
     if (M.st) {
         mcts_reset_state(&M.st[(size_t)env * P.A + i]);
         mc_reqs(M)[(size_t)env * P.A + i].last_sec = -1;
+        mcts_backfill_section_times<true>(P, T, env, i, ex, envs[env].episodes_done, ar->section_index, &M.st[(size_t)env * P.A + i]);
         uint32_t req = 0;
         for (int e = 0; e < P.A; e++) if (P.high_mode[e] == HK_HIGH_MCTS && !P.training_agent[e]) req |= 1u << e;
-        mcts_post_request(P, M, set, env, i, req, 0, envs[env].episodes_done, P.mcts_iter0, P.mcts_lat0,
-                          ar->section_index, ar->lane, ar->lane_changes, ar->final_steer);
+        mcts_post_request(P, M, set, env, i, req, req, 0, envs[env].episodes_done, P.mcts_iter0, P.mcts_lat0,
+                          ar->section_index, ar->lane, ar->lane_changes, ar->final_steer, old_steer);
     }
     if (i == 0) {
         hk_env_state* es = &envs[env];
@@ -180,6 +213,7 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
             __threadfence();
             rwv.cum = 0.0f; rwv.step = 0.0f; rwv.group = 0.0f;      // the record is rewritten below (EndGroupEpisode)
         }
+        const float old_steer = h.final_steer;      // m_FinalStats.Steer as the episode that just ended left it (mcts_post_request)
         if (me) {
             // REC.ResetGame rewrites the whole record (plans included): through memory, then back into registers
             store_hot(a, h);
@@ -197,11 +231,15 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
         es.initial_started = 1;
         if (M.st) {
             // prepareForReuse + initialPlan (HKA:84-96, 428-452): planner state cleared, first plan requested (T = 1.5 s)
-            if (me) { mcts_reset_state(&M.st[(size_t)env * P.A + i]); mc_reqs(M)[(size_t)env * P.A + i].last_sec = -1; }
+            if (me) {
+                mcts_reset_state(&M.st[(size_t)env * P.A + i]); mc_reqs(M)[(size_t)env * P.A + i].last_sec = -1;
+                const TabView T = tab_view(P, P.tab);
+                mcts_backfill_section_times<TRAIN>(P, T, env, i, es.experiment_num, es.episodes_done, h.section_index, &M.st[(size_t)env * P.A + i]);
+            }
             uint32_t req = 0;
             for (int e = 0; e < P.A; e++) if (P.high_mode[e] == HK_HIGH_MCTS && !P.training_agent[e]) req |= 1u << e;
-            mcts_post_request(P, M, set, env, i, req, 0, es.episodes_done, P.mcts_iter0, P.mcts_lat0,
-                              h.section_index, h.lane, h.lane_changes, h.final_steer);
+            mcts_post_request(P, M, set, env, i, req, req, 0, es.episodes_done, P.mcts_iter0, P.mcts_lat0,
+                              h.section_index, h.lane, h.lane_changes, h.final_steer, old_steer);
         }
     }
     // own pose / flags (after a possible reset)
@@ -563,7 +601,11 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                     else if (cur_lane != lane) lc += dl;
                     h.lane_changes = lc;
                     h.section_index = index; h.lane = lane;
-                    if (mcts_all) mcts_all[(size_t)env * P.A + i].sec_time[index & 3] = episode_steps;   // sectionTimes HKA:651
+                    if (mcts_all) {
+                        hk_mcts_state* mst = &mcts_all[(size_t)env * P.A + i];
+                        mst->sec_time[index & (HK_MCTS_SECTIME_RING - 1)] = episode_steps;   // sectionTimes HKA:651
+                        mst->root_live = 0; mst->root_cycles = 0;                          // currentRoot = null HKA:660-661
+                    }
                     if (index == P.laps * L + 1) {                         // ReachGoalSection REC:469-474
                         h.time_steps = episode_steps;
                         fl = deactivate_fields(P, h, fl);
@@ -576,6 +618,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                         ev[nev].lane_div = 1.0f; ev[nev].vel_div = 1.0f; nev++;
                     }
                     h.section_index = index;
+                    if (mcts_all) { hk_mcts_state* mst = &mcts_all[(size_t)env * P.A + i]; mst->root_live = 0; mst->root_cycles = 0; }   // HKA:668-669
                 } else if (index == -1) {                                  // DroveReverseLimit REC:475-479
                     h.time_steps = P.max_steps * 6;
                     fl = deactivate_fields(P, h, fl);

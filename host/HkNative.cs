@@ -1,4 +1,4 @@
-// HkNative.cs — P/Invoke binding of libhk.so (include/hk.h, HK_ABI_VERSION 3) for the reference's Unity C# host.
+// HkNative.cs — P/Invoke binding of libhk.so (include/hk.h, HK_ABI_VERSION 4) for the reference's Unity C# host.
 //
 // Drop it under Assets/Karting/Scripts/AI/Native/ with libhk.so in Assets/Plugins/x86_64.  Every struct mirrors its C
 // twin field for field (tests/test_csharp_layout.py parses this file and checks field order, types, array lengths and
@@ -11,7 +11,7 @@ namespace KartGame.AI.Native
 {
     public static class HkConst
     {
-        public const int HK_ABI_VERSION = 3;
+        public const int HK_ABI_VERSION = 4;
         public const int HK_MAX_AGENTS = 8;
         public const int HK_MAX_SECTIONS = 64;
         public const int HK_NUM_SENSORS = 9;
@@ -175,9 +175,13 @@ namespace KartGame.AI.Native
     [StructLayout(LayoutKind.Sequential)]
     public unsafe struct HkMctsState
     {
-        public fixed int sec_time[4];
+        public fixed int sec_time[8];
         public int ready_step;
         public int searches;
+        public int root_live;
+        public int root_cycles;
+        public int pend_kind;
+        public int root_phases;
         public HkMctsPlan best;
         public HkMctsPlan pend;
         public fixed byte belief_lane[512];

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define HK_ABI_VERSION 3
+#define HK_ABI_VERSION 4
 #define HK_MAX_AGENTS 8      /* the largest reference scene has 4; 5..8 agents per env is the synthetic extension of BASELINE configs[4] (start grid continued row by row) */
 #define HK_MAX_SECTIONS 64   /* Oval 24, Complex 41 */
 #define HK_NUM_SENSORS 9     /* MLAgent_Sensors.prefab */
@@ -120,7 +120,8 @@ typedef struct hk_config {
      * gameParams (HKA:38-52), scene values {timePrecision 100, sectionWindow 2, treeSearchDepth 8, velocityBucketSize 2}.
      * The reference searches on a background thread under a WALL-CLOCK budget (T = 1.5 s at reset, 0.9 s every 100
      * ticks) with System.Random / MathNet draws; here the budget is an iteration count, the plan becomes visible a fixed
-     * number of ticks after it was requested, and the draws are Philox-4x32 keyed by mcts_seed ("parity unpinned"). */
+     * number of ticks after it was requested, and the draws are Philox-4x32 keyed by mcts_seed ("parity unpinned").  Root reuse
+     * (HKA:265-283) and the sectionTimes back-fill of ResetGame (REC:679-702) are restated; see hk_mcts_state. */
     int32_t time_precision[HK_MAX_AGENTS];
     int32_t section_window[HK_MAX_AGENTS];
     int32_t mcts_iterations;          /* search iterations of a 100-tick replan (stands for T = 0.9 s) */
@@ -143,6 +144,8 @@ typedef struct hk_config {
 
 #define HK_MCTS_MAX_DEPTH 8      /* gameParams.treeSearchDepth <= 8 */
 #define HK_MCTS_MAX_ACTIONS 20   /* 5 velocity buckets x 4 lanes (KartDiscreteGame.cs:333-347) */
+#define HK_MCTS_SECTIME_RING 8   /* sectionTimes entries kept per kart (sectionWindow <= 4) */
+#define HK_MCTS_MAX_ROOT_PHASES 3 /* searches one tree can receive (the reference: CyclesRootProcessed < 3); see hk_mcts_state.root_phases */
 
 /* Planner state of one agent (kept beside hk_agent_state; HighMode MCTS agents only).  `best` is what the reference
  * holds in bestStates (HKA:70,252): for each future section the game reached by every player, each player's lane and
@@ -157,9 +160,16 @@ typedef struct hk_mcts_plan {
 } hk_mcts_plan;
 
 typedef struct hk_mcts_state {
-    int32_t sec_time[4];                               /* KartAgent.sectionTimes (KA:124), ring over section & 3 */
+    int32_t sec_time[HK_MCTS_SECTIME_RING];            /* KartAgent.sectionTimes (KA:124), ring over section & 7: the planner reads the
+                                                        * entries of karts at most 2 * sectionWindow - 2 <= 6 sections apart (HKA:221-224) */
     int32_t ready_step;                                /* episode step at which `pend` replaces `best`; -1: nothing pending */
     int32_t searches;                                  /* searches started since hk_create (debug / RNG stream id) */
+    /* root reuse (HKA:66-67,175,265-283,660-669): a replan re-searches the tree of the previous plan (up to three searches per
+     * tree) unless the kart entered a section, or drove backwards through one, after that plan was finished */
+    int32_t root_live;                                 /* currentRoot != null */
+    int32_t root_cycles;                               /* CyclesRootProcessed */
+    int32_t pend_kind;                                 /* the search in flight: 0 none, 1 a new tree (HKA:175), 2 the existing root again (HKA:265) */
+    int32_t root_phases;                               /* searches the current tree has received (set at the request; <= HK_MCTS_MAX_ROOT_PHASES) */
     hk_mcts_plan best, pend;
     /* opponentUpcomingLanes / opponentUpcomingVelocities (HKA:77-78): this agent's belief about every other agent's
      * plan, keyed by section % L; 0 = no entry */

@@ -360,6 +360,8 @@ static void reset_env(hko_env* e, int env)
     int t_sec[HK_MAX_AGENTS], t_lane[HK_MAX_AGENTS];
     float t_twp[HK_MAX_AGENTS], t_dist[HK_MAX_AGENTS];
     if (training) training_layout(e, env, ord, t_sec, t_lane, t_twp, t_dist);
+    float old_steer[HK_MAX_AGENTS];                          /* m_FinalStats.Steer as the previous episode left it */
+    for (int i = 0; i < e->A; i++) old_steer[i] = ags[i].final_steer;
     for (int j = 0; j < e->A; j++) {
         int i = ord[j];
         hk_agent_state* a = &ags[i];
@@ -401,22 +403,53 @@ static void reset_env(hko_env* e, int env)
         a->flags = HK_F_ACTIVE | HK_F_ENABLED;               /* m_CanMove stays false until StartRaceAfterDelay */
     }
     if (e->mcts) {
-        /* prepareForReuse HKA:428-452 (beliefs, bestStates cleared; sectionTimes[m_SectionIndex] = 0 KA:212), then
-         * initialPlan -> planWithMCTS(T: 1.5) HKA:84-96 once every agent is placed (deviation, see hk_oracle_mcts.c) */
+        /* the sectionTimes back-fill of REC:679-702, then agent by agent prepareForReuse HKA:428-452 (beliefs, bestStates,
+         * currentRoot cleared; the search thread aborted) and initialPlan -> planWithMCTS(T: 1.5) HKA:84-96 (REC:705-710).  The
+         * interleaving is observable in one value: prepareForReuse is what refreshes m_FinalStats.Steer (UpdateStats KA:213), so
+         * agent i's first plan reads the tire age of every agent j > i from the Steer its last tick of the PREVIOUS episode left
+         * (HKA:236) — `old_steer`.  (sectionTimes[own section] = 0, KA:212, was already set by the back-fill.) */
         for (int i = 0; i < e->A; i++) {
             hk_mcts_state* m = &e->mcts[(size_t)env * e->A + i];
             const int searches = m->searches;
             memset(m, 0, sizeof(*m));
             m->searches = searches;
             m->ready_step = -1;
+            hko_mcts_tree_drop(e, env, i);
         }
+        hko_mcts_backfill_section_times(e, env);
         for (int i = 0; i < e->A; i++) {
             if (e->cfg.high_mode[i] != HK_HIGH_MCTS || e->cfg.training_agent[i]) continue;
-            hk_mcts_state* m = &e->mcts[(size_t)env * e->A + i];
-            hko_mcts_search(e, env, i, e->cfg.mcts_initial_iterations, &m->pend);
-            m->searches += 1;
-            m->ready_step = e->cfg.mcts_initial_latency_ticks;
+            float seen[HK_MAX_AGENTS];
+            for (int j = 0; j < e->A; j++) seen[j] = j > i ? old_steer[j] : ags[j].final_steer;
+            hko_mcts_request(e, env, i, e->cfg.mcts_initial_iterations, e->cfg.mcts_initial_latency_ticks, seen);
         }
+    }
+}
+
+/* REC.ResetGame :679-702 — "Generate times for reaching certain sections": every kart gets a made-up history of section times
+ * from the rearmost kart's section up to its own, each drawn below the one before (int Random.Range(earliest, 0)), and 0 for the
+ * section it stands in.  planWithMCTS reads them as the time offsets of karts behind the furthest one (HKA:221-224).
+ * UnityEngine.Random -> Philox keyed by mcts_seed, the global env id, the agent, the episode and the section ("parity unpinned").
+ * The same loop also counts agentsPastSection[team][section]; those counts are dead: ApplySectionRewardsAndPenalties reads
+ * agentsPastSection[t][s] only where minSectionTimes[t] holds s, and the statement that creates that key assigns the count
+ * (REC:366-370), so a back-filled count is always overwritten before it is read.  Not restated. */
+void hko_mcts_backfill_section_times(hko_env* e, int env)
+{
+    const hk_agent_state* ags = &e->ag[(size_t)env * e->A];
+    const uint32_t env_gid = (uint32_t)(e->cfg.env_id_base + env);
+    int back = ags[0].section_index;
+    for (int i = 1; i < e->A; i++) if (ags[i].section_index < back) back = ags[i].section_index;   /* furthestBackSection :546,591 */
+    for (int i = 0; i < e->A; i++) {
+        hk_mcts_state* m = &e->mcts[(size_t)env * e->A + i];
+        int earliest = -e->cfg.max_episode_steps;                                                   /* :687 */
+        for (int tp = back; tp < ags[i].section_index; tp++) {
+            uint32_t r[4];
+            philox4x32((uint32_t)tp, (uint32_t)i, (uint32_t)e->es[env].episodes_done, 0x53454354u, e->cfg.mcts_seed, env_gid, r);
+            const int v = earliest + (int)(((uint64_t)r[0] * (uint64_t)(uint32_t)(-earliest)) >> 32);   /* [earliest, 0) */
+            m->sec_time[tp & (HK_MCTS_SECTIME_RING - 1)] = v;
+            earliest = v;
+        }
+        m->sec_time[ags[i].section_index & (HK_MCTS_SECTIME_RING - 1)] = 0;                          /* :697 */
     }
 }
 
@@ -860,7 +893,11 @@ static void on_trigger_enter(hko_env* e, int env, int ai, int t)
         if (is_straight(e, sec) != is_straight(e, index)) a->lane_changes = 0;          /* :641 */
         else if (a->lane != lane) a->lane_changes += dl;                                /* :645 */
         a->section_index = index; a->lane = lane;                                       /* :649-650 */
-        if (e->mcts) e->mcts[(size_t)env * e->A + ai].sec_time[index & 3] = es->episode_steps;   /* :651 sectionTimes */
+        if (e->mcts) {
+            hk_mcts_state* m = &e->mcts[(size_t)env * e->A + ai];
+            m->sec_time[index & (HK_MCTS_SECTIME_RING - 1)] = es->episode_steps;            /* :651 sectionTimes */
+            m->root_live = 0; m->root_cycles = 0;                                           /* :660-661 currentRoot = null */
+        }
         const int goal = e->cfg.laps * L + 1;                                           /* REC:165 */
         if (a->section_index == goal) {                                                 /* :652 -> REC.ResolveEvent :469-474 */
             a->time_steps = es->episode_steps;
@@ -871,6 +908,7 @@ static void on_trigger_enter(hko_env* e, int env, int ai, int t)
     } else if (index != -1 && ((index < sec) || (sec % L == 0 && index % L == L - 1))) {/* :663 */
         if (rw) hko_rw_reverse(e, a, sec, index);                                       /* :666 */
         a->section_index = index;                                                       /* :667 */
+        if (e->mcts) { hk_mcts_state* m = &e->mcts[(size_t)env * e->A + ai]; m->root_live = 0; m->root_cycles = 0; }   /* :668-669 */
     } else if (index == -1) {                                                           /* :671 DroveReverseLimit REC:475-479 */
         a->time_steps = e->cfg.max_episode_steps * 6;
         deactivate(e, a);
@@ -993,16 +1031,11 @@ static void step_env(hko_env* e, int env)
         if (es->episode_steps % 100 == 0 && es->episode_steps < cfg->max_episode_steps && es->episode_steps > 0 && !inactive) {
             if (cfg->training_agent[i]) plan_randomly(e, env, i, a);                    /* :357-360 Mode == Training */
             else if (cfg->high_mode[i] == HK_HIGH_FIXED) plan_fixed(e, i, a);           /* :331-355 */
-            else {                                                                      /* :335-350 planWithMCTS() */
-                hk_mcts_state* m = &e->mcts[(size_t)env * A + i];
-                hko_mcts_search(e, env, i, cfg->mcts_iterations, &m->pend);
-                m->searches += 1;
-                m->ready_step = es->episode_steps + cfg->mcts_latency_ticks;
-            }
+            else hko_mcts_request(e, env, i, cfg->mcts_iterations, cfg->mcts_latency_ticks, NULL);   /* :335-350 planWithMCTS() */
         }
         if (cfg->high_mode[i] == HK_HIGH_MCTS) {                                        /* :366-402 */
             hk_mcts_state* m = &e->mcts[(size_t)env * A + i];
-            if (m->ready_step >= 0 && es->episode_steps >= m->ready_step) { m->best = m->pend; m->ready_step = -1; }
+            if (m->ready_step >= 0 && es->episode_steps >= m->ready_step) hko_mcts_promote(m);
             hko_mcts_consume(e, env, i);
         }
     }
@@ -1188,7 +1221,10 @@ hko_env* hko_create(const hk_config* cfg)
         memset(e->sec_min_time, 0xFF, n * sizeof(int32_t)); memset(e->sec_count, 0, n);
     }
     for (int i = 0; i < e->A; i++)
-        if (cfg->high_mode[i] == HK_HIGH_MCTS && !e->mcts) e->mcts = (hk_mcts_state*)calloc(na, sizeof(hk_mcts_state));
+        if (cfg->high_mode[i] == HK_HIGH_MCTS && !e->mcts) {
+            e->mcts = (hk_mcts_state*)calloc(na, sizeof(hk_mcts_state));
+            e->trees = (struct hko_tree*)calloc(na, hko_mcts_tree_bytes());
+        }
     for (size_t i = 0; i < na; i++) { e->res[i].episode = -1; e->act_branch[i] = 1; }
     const hk_kart_stats* s = &cfg->stats;
     e->max_speed = f_max(s->TopSpeed, s->ReverseSpeed);                                  /* AK:210 */
@@ -1220,6 +1256,7 @@ void hko_destroy(hko_env* e)
     if (!e) return;
     free(e->sec); free(e->sp); free(e->walls); free(e->ag); free(e->es); free(e->res); free(e->dbg);
     hko_policy_free(e);
+    hko_mcts_trees_free(e);
     free(e->mcts);
     free(e->sec_min_time); free(e->sec_count);
     free(e->act_steer); free(e->act_branch); free(e->perms); free(e);

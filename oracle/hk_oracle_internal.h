@@ -34,6 +34,7 @@ struct hko_env {
     float sens_c[HK_NUM_SENSORS], sens_s[HK_NUM_SENSORS];   /* cos / sin of the sensors' local yaw */
     /* MCTS planner (hk_oracle_mcts.c): [E][A], NULL when no agent is HighMode MCTS */
     hk_mcts_state* mcts;
+    struct hko_tree* trees; /* [E][A] the persisted search trees (currentRoot, HKA:66) */
     /* reward shaping (hk_oracle_reward.c): minSectionTimes / agentsPastSection, [E][A teams][laps * L + 2]; NULL when off */
     int32_t* sec_min_time;
     uint8_t* sec_count;
@@ -61,8 +62,15 @@ static inline float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.
 
 
 /* hk_oracle_mcts.c */
-void hko_mcts_search(hko_env* e, int env, int ego, int iterations, hk_mcts_plan* plan);
+struct hko_tree;
+size_t hko_mcts_tree_bytes(void);
+void hko_mcts_search(hko_env* e, int env, int ego, int iterations, int reuse, const float* steer_seen, hk_mcts_plan* plan);
+void hko_mcts_request(hko_env* e, int env, int ego, int iterations, int latency, const float* steer_seen);
+void hko_mcts_promote(hk_mcts_state* m);
 void hko_mcts_consume(hko_env* e, int env, int i);
+void hko_mcts_tree_drop(hko_env* e, int env, int ego);
+void hko_mcts_trees_free(hko_env* e);
+void hko_mcts_backfill_section_times(hko_env* e, int env);
 
 /* hk_oracle_reward.c */
 int hko_rw_table_len(const hko_env* e);

@@ -22,9 +22,11 @@
  * budget expires and draws from System.Random / MathNet Normal.  Here: a fixed iteration budget, results visible a fixed
  * number of ticks after the request, Philox-4x32 draws.  List<T>.Sort is restated as the .NET introsort small-partition
  * rules (2: one compare-swap, 3: three compare-swaps lo/hi-1, lo/hi, hi-1/hi, 4..16: insertion sort).
- * Deviations (DESIGN.md "MCTS"): the plan at reset is made after ALL agents are placed and sectionTimes restart with the
- * episode (the reference plans inside its reset loop and never clears that dictionary); a replan always starts a new
- * tree (the reference reuses a root up to three times if the agent passed no section in between).
+ * Root reuse (HKA:66-67,175,265-283,660-669) is restated with REAL persistence here: the tree of an agent's last plan stays
+ * allocated (hko_env.trees) and a replan that finds it alive searches it again.  (The HIP side keeps no trees: it rebuilds one by
+ * replaying the searches it received, draw for draw — the two must agree.)  One bound is ours: a tree receives at most
+ * HK_MCTS_MAX_ROOT_PHASES = 3 searches (the reference's count; a finishing background thread that re-installs a root after the main
+ * thread reset CyclesRootProcessed could add more there); beyond that a replan starts a new tree.
  */
 #include <stdlib.h>
 #include <string.h>
@@ -66,9 +68,17 @@ typedef struct {
     /* draws */
     uint32_t key0, key1, c1, c2;
     uint32_t draw;
-    /* node arena */
+    /* node arena of the search in progress (a chunk of the agent's tree) */
     node_t* pool; int pool_n, pool_cap;
 } search_t;
+
+/* currentRoot (HKA:66): the tree of an agent's last plan, kept while root_live.  Every search adds one chunk of nodes. */
+struct hko_tree {
+    node_t* chunk[HK_MCTS_MAX_ROOT_PHASES];
+    int n_chunks;
+    int P;                          /* players of the root game */
+    uint8_t player_agent[MAXP];
+};
 
 /* ---- draws (stand-ins for System.Random / MathNet.Numerics Normal; see header) */
 static void draw4(search_t* S, uint32_t r[4]) { philox4x32(S->draw++, S->c1, S->c2, 0x4D435453u, S->key0, S->key1, r); }
@@ -399,53 +409,85 @@ static void backpropagate(node_t* n, const float* result)
     }
 }
 
-/* planWithMCTS HKA:172-263 + constructSearchTree + getBestStatesSequence; result -> plan */
-void hko_mcts_search(hko_env* e, int env, int ego, int iterations, hk_mcts_plan* plan)
+size_t hko_mcts_tree_bytes(void) { return sizeof(struct hko_tree); }
+static void tree_free(struct hko_tree* t)
+{
+    for (int c = 0; c < t->n_chunks; c++) free(t->chunk[c]);
+    memset(t, 0, sizeof(*t));
+}
+void hko_mcts_trees_free(hko_env* e)
+{
+    if (!e->trees) return;
+    for (size_t i = 0; i < (size_t)e->E * e->A; i++) tree_free(&e->trees[i]);
+    free(e->trees); e->trees = NULL;
+}
+void hko_mcts_tree_drop(hko_env* e, int env, int ego) { if (e->trees) tree_free(&e->trees[(size_t)env * e->A + ego]); }
+
+/* planWithMCTS HKA:172-284 + constructSearchTree KM:50-106 + getBestStatesSequence; result -> plan.
+ * reuse = 0: the game is built from the karts' current state and searched in a new tree (HKA:175-263);
+ * reuse = 1: the agent's existing root is searched again (HKA:265-283).
+ * steer_seen: m_FinalStats.Steer of every kart as this plan sees it (NULL: the karts' current values; the reset passes stale ones). */
+void hko_mcts_search(hko_env* e, int env, int ego, int iterations, int reuse, const float* steer_seen, hk_mcts_plan* plan)
 {
     const hk_config* cfg = &e->cfg;
     const int A = e->A;
     const hk_agent_state* ags = &e->ag[(size_t)env * A];
     const hk_mcts_state* ms = &e->mcts[(size_t)env * A];
+    struct hko_tree* T = &e->trees[(size_t)env * A + ego];
     search_t S; memset(&S, 0, sizeof(S));
     S.e = e; S.ego = ego;
     S.bucket = cfg->velocity_bucket_size[ego]; S.precision = cfg->time_precision[ego];
     S.key0 = cfg->mcts_seed; S.key1 = (uint32_t)(cfg->env_id_base + env) * (uint32_t)A + (uint32_t)ego;
     S.c1 = (uint32_t)e->es[env].episode_steps; S.c2 = (uint32_t)e->es[env].episodes_done;
-    game_t g; memset(&g, 0, sizeof(g));
-    int nearby[MAXP], furthest = ego;
-    int initialSection = ags[ego].section_index;
-    for (int i = 0; i < A; i++) {                                                        /* :180-191 */
-        if (abs(ags[i].section_index - ags[ego].section_index) < cfg->section_window[ego]) {
-            nearby[g.P++] = i;
-            if (ags[i].section_index > initialSection) initialSection = ags[i].section_index;
-            if (initialSection == ags[i].section_index) furthest = i;
-        }
-    }
+    node_t* root;
     memset(plan, 0, sizeof(*plan));
-    plan->n_players = g.P;
-    for (int p = 0; p < g.P; p++) {
-        const int ai = nearby[p];
-        const hk_agent_state* a = &ags[ai];
-        plan->player_agent[p] = (uint8_t)ai;
-        kart_t* k = &g.k[p];
-        k->agent = ai; k->team = cfg->team_of[ai];
-        k->min_velocity = 0;                                                             /* :211-219: the loop breaks at i = 0 */
-        k->max_velocity = S.bucket < (int)e->max_speed ? S.bucket : (int)e->max_speed;
-        k->section = initialSection;
-        k->timeAtSection = 0;
-        if (a->section_index != initialSection)                                          /* :221-224 */
-            k->timeAtSection = (int)((float)(ms[ai].sec_time[a->section_index & 3] - ms[furthest].sec_time[a->section_index & 3]) * cfg->dt * (float)S.precision);
-        k->lane = a->lane;
-        k->tireAge = (int)((cfg->stats.MaxSteer - a->final_steer) / (cfg->stats.MaxSteer - cfg->stats.MinSteer) * 10000.0f);   /* :236 */
-        k->laneChanges = a->lane_changes;
-        k->infeasible = 0;
+    if (!reuse) {
+        tree_free(T);
+        game_t g; memset(&g, 0, sizeof(g));
+        int nearby[MAXP], furthest = ego;
+        int initialSection = ags[ego].section_index;
+        for (int i = 0; i < A; i++) {                                                        /* :180-191 */
+            if (abs(ags[i].section_index - ags[ego].section_index) < cfg->section_window[ego]) {
+                nearby[g.P++] = i;
+                if (ags[i].section_index > initialSection) initialSection = ags[i].section_index;
+                if (initialSection == ags[i].section_index) furthest = i;
+            }
+        }
+        for (int p = 0; p < g.P; p++) {
+            const int ai = nearby[p];
+            const hk_agent_state* a = &ags[ai];
+            T->player_agent[p] = (uint8_t)ai;
+            kart_t* k = &g.k[p];
+            k->agent = ai; k->team = cfg->team_of[ai];
+            k->min_velocity = 0;                                                             /* :211-219: the loop breaks at i = 0 */
+            k->max_velocity = S.bucket < (int)e->max_speed ? S.bucket : (int)e->max_speed;
+            k->section = initialSection;
+            k->timeAtSection = 0;
+            if (a->section_index != initialSection) {                                        /* :221-224 */
+                const int ring = a->section_index & (HK_MCTS_SECTIME_RING - 1);
+                k->timeAtSection = (int)((float)(ms[ai].sec_time[ring] - ms[furthest].sec_time[ring]) * cfg->dt * (float)S.precision);
+            }
+            k->lane = a->lane;
+            k->tireAge = (int)((cfg->stats.MaxSteer - (steer_seen ? steer_seen[ai] : a->final_steer)) / (cfg->stats.MaxSteer - cfg->stats.MinSteer) * 10000.0f);   /* :236 */
+            k->laneChanges = a->lane_changes;
+            k->infeasible = 0;
+        }
+        g.initialSection = initialSection; g.lastCompletedSection = initialSection;
+        g.finalSection = initialSection + cfg->tree_search_depth[ego];
+        T->P = g.P;
+        /* arena: every iteration adds at most (depth x players) nodes */
+        S.pool_cap = 1 + iterations * (cfg->tree_search_depth[ego] * g.P + 1);
+        S.pool = (node_t*)malloc(sizeof(node_t) * (size_t)S.pool_cap);
+        T->chunk[T->n_chunks++] = S.pool;
+        root = new_node(&S, &g, NULL);
+    } else {
+        root = &T->chunk[0][0];                                                              /* constructSearchTree(currentRoot, T: 0.9) KM:79-106 */
+        S.pool_cap = iterations * (cfg->tree_search_depth[ego] * T->P + 1);
+        S.pool = (node_t*)malloc(sizeof(node_t) * (size_t)S.pool_cap);
+        T->chunk[T->n_chunks++] = S.pool;
     }
-    g.initialSection = initialSection; g.lastCompletedSection = initialSection;
-    g.finalSection = initialSection + cfg->tree_search_depth[ego];
-    /* arena: every iteration adds at most (depth x players) nodes */
-    S.pool_cap = 1 + iterations * (cfg->tree_search_depth[ego] * g.P + 1);
-    S.pool = (node_t*)malloc(sizeof(node_t) * (size_t)S.pool_cap);
-    node_t* root = new_node(&S, &g, NULL);
+    plan->n_players = T->P;
+    for (int p = 0; p < T->P; p++) plan->player_agent[p] = T->player_agent[p];
     float scores[2 * MAXP];
     for (int it = 0; it < iterations; it++) {                                            /* KM:50-77 with an iteration budget */
         node_t* leaf = find_leaf(&S, root);
@@ -458,14 +500,39 @@ void hko_mcts_search(hko_env* e, int env, int ego, int iterations, hk_mcts_plan*
     while (n->n_children > 0) {
         n = upper_confidence(&S, n);
         int all_at = 1;
-        for (int p = 0; p < g.P; p++) all_at &= n->state.k[p].section == n->state.lastCompletedSection;
+        for (int p = 0; p < T->P; p++) all_at &= n->state.k[p].section == n->state.lastCompletedSection;
         if (all_at && plan->n_states < HK_MCTS_MAX_DEPTH) {
             int q = plan->n_states++;
             plan->section[q] = n->state.lastCompletedSection;
-            for (int p = 0; p < g.P; p++) { plan->lane[q][p] = (uint8_t)n->state.k[p].lane; plan->vel[q][p] = (uint8_t)n->state.k[p].max_velocity; }
+            for (int p = 0; p < T->P; p++) { plan->lane[q][p] = (uint8_t)n->state.k[p].lane; plan->vel[q][p] = (uint8_t)n->state.k[p].max_velocity; }
         }
     }
-    free(S.pool);
+}
+
+/* The replan of HKA.FixedUpdate :330-350 / initialPlan :84-96 for one agent: decide between a new tree, the old root again, or no
+ * plan at all (CyclesRootProcessed >= 3), run the search and schedule its result.  (`t` is always finished here: a search lasts
+ * less than the 100 ticks between two replans.) */
+void hko_mcts_request(hko_env* e, int env, int ego, int iterations, int latency, const float* steer_seen)
+{
+    hk_mcts_state* m = &e->mcts[(size_t)env * e->A + ego];
+    int kind;
+    if (!m->root_live) kind = 1;                                                             /* HKA:175 */
+    else if (m->root_cycles < 3) kind = m->root_phases < HK_MCTS_MAX_ROOT_PHASES ? 2 : 1;    /* HKA:265 (bound: see the header) */
+    else return;
+    hko_mcts_search(e, env, ego, iterations, kind == 2, steer_seen, &m->pend);
+    m->root_phases = kind == 2 ? m->root_phases + 1 : 1;
+    m->pend_kind = kind;
+    m->searches += 1;
+    m->ready_step = e->es[env].episode_steps + latency;
+}
+
+/* the search thread ends (HKA:250-253 / :271-273): bestStates, currentRoot and CyclesRootProcessed are written */
+void hko_mcts_promote(hk_mcts_state* m)
+{
+    m->best = m->pend; m->ready_step = -1;
+    if (m->pend_kind == 1) { m->root_live = 1; m->root_cycles = 1; }
+    else if (m->pend_kind == 2) { m->root_live = 1; m->root_cycles += 1; }
+    m->pend_kind = 0;
 }
 
 /* HKA.FixedUpdate :366-402: every tick, copy bestStates into the agent's own plan and its beliefs about the others */

@@ -74,11 +74,44 @@ def test_create_rejects_bad_planner_budgets():
     for kw in (dict(mcts_latency_ticks=4), dict(mcts_latency_ticks=120), dict(mcts_iterations=0), dict(tree_search_depth=[9, 5])):
         with pytest.raises(hk.HkError):
             hk.RacingEnv(hk.make_config(2, 2, high_mode=[MC, FX], **{**dict(tree_search_depth=[8, 5]), **kw}))
-    # a tree pool beyond 65 535 nodes per search (1 + iterations x (depth x agents + 1)) is refused, not truncated
+    # a tree pool beyond 65 535 nodes per search (1 + (initial + 2 x replan iterations) x (depth x agents + 1): a root can be
+    # searched three times) is refused, not truncated
     with pytest.raises(hk.HkError) as e:
-        hk.RacingEnv(hk.make_config(2, 2, high_mode=[MC, FX], tree_search_depth=[8, 5], mcts_iterations=4000))
+        hk.RacingEnv(hk.make_config(2, 2, high_mode=[MC, FX], tree_search_depth=[8, 5], mcts_iterations=2000))
     assert e.value.code == _lib.HK_ERR_UNSUPPORTED
-    hk.RacingEnv(hk.make_config(2, 2, high_mode=[MC, FX], tree_search_depth=[8, 5], mcts_iterations=2000)).close()   # 1 + 3334 x 17 nodes fits
+    hk.RacingEnv(hk.make_config(2, 2, high_mode=[MC, FX], tree_search_depth=[8, 5], mcts_iterations=1000)).close()   # 1 + 3667 x 17 nodes fits
+    with pytest.raises(hk.HkError):
+        hk.RacingEnv(hk.make_config(2, 2, high_mode=[MC, FX], tree_search_depth=[8, 5], section_window=5))   # sectionTimes ring: window <= 4
+
+
+def test_root_reuse_matches_the_oracles_persistent_trees():
+    """HKA:265-283: the kernel rebuilds a re-searched tree by replaying the searches it received, the oracle keeps the tree.
+    Kart 0 is pinned to its grid slot (never enters a section): searched at reset, at tick 100 and 200 on the same root, then not
+    at all; the other karts race on and drop their roots at every section they enter."""
+    g, o = _pair(6, 4, [MC, MC, MC, FX], jitter_seed=13, mcts_iterations=20)
+    st = o.agent_state()
+    t = 0
+    for k in range(18):
+        g.step(25); o.step(25); t += 25
+        _cmp(g, o, t)
+        a = o.agent_state()
+        a[:, 0] = st[:, 0]
+        o.set_agent_state(a); g.set_agent_state(a)
+    m = g.mcts_state()
+    assert (m["searches"][:, 0] == 3).all() and (m["root_cycles"][:, 0] == 3).all() and (m["root_phases"][:, 0] == 3).all()
+    assert (m["searches"][:, 1:3] == 5).all()
+    assert (m["root_phases"][:, 1:3].max() >= 1)
+
+
+def test_section_window_three_reads_section_times_two_rows_back():
+    g, o = _pair(8, 4, [MC, MC, MC, MC], jitter_seed=17, mcts_iterations=16, section_window=3, mcts_seed=5)
+    _cmp(g, o, 0)
+    row2 = g.agent_state()["section_index"] == 1
+    assert row2.sum() == 16 and (g.mcts_state()["sec_time"][:, :, 0][row2] < 0).all()     # the second grid row got a made-up time for section 0 (REC:690)
+    t = 0
+    for n in (100, 45, 55, 100):
+        g.step(n); o.step(n); t += n
+        _cmp(g, o, t)
 
 
 def test_tick_by_tick_stepping_defers_but_never_misses_a_plan():
