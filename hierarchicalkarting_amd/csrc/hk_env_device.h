@@ -98,7 +98,10 @@ struct MctsDev {
     float* rad_tab;         // [L][4][4]: radiusOfLane(section, from, to)
     int nv;                 // velocity buckets of the action list (<= 5)
     int pool_cap;
-    int slots;              // trees the arena holds = lanes of the search kernel's grid (<= MCTS_ARENA_WAVES waves)
+    int slots;              // trees the arena holds: one per resident lane of the search kernel (persist = 0) or one per agent (persist = 1)
+    int grid_lanes;         // lanes of the search kernel's grid (<= MCTS_ARENA_WAVES waves)
+    int persist;            // 1: every agent owns an arena slice and its tree survives between searches (root reuse costs nothing
+                            // extra); 0: the arena belongs to the resident lanes and a re-searched root is rebuilt by replay (MctsReq)
 };
 struct RwDev {
     int* sec_time;      // [E][A teams][S]  minSectionTimes (episode step; -1 = key absent)

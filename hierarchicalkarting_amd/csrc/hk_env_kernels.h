@@ -303,11 +303,19 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         // every search a tree can receive (root reuse: the first one plus HK_MCTS_MAX_ROOT_PHASES - 1 replans), each adding at most
         // (depth x players) + 1 nodes per iteration
         d.mcts.pool_cap = 1 + (std::max(cfg.mcts_iterations, cfg.mcts_initial_iterations) + (HK_MCTS_MAX_ROOT_PHASES - 1) * cfg.mcts_iterations) * (max_depth * A + 1);
-        {   // the search kernel is a fixed grid walking the queue: the arena holds one tree per resident lane, at most
-            // MCTS_ARENA_WAVES waves (2 per SIMD of the 256 CUs), however many envs there are
+        {   // the search kernel is a fixed grid walking the queue, at most MCTS_ARENA_WAVES waves (2 per SIMD of the 256 CUs) however
+            // many envs there are.  Where do the trees live?  If one arena slice per AGENT fits the budget (HK_MCTS_PERSIST_GB,
+            // default 64 of the 288 GB), the tree of an agent's last plan simply stays in its slice and a re-searched root (HKA:265)
+            // continues on it; otherwise the arena holds one tree per resident lane and a re-searched root is rebuilt by replaying the
+            // searches it received (hk_env_mcts.h, MctsReq) — same bits, more iterations for the few lanes that reuse a root.
             const int spw = HK_GA_CALL(d, mcts_searches_per_wave());
             const long long want = (((long long)E * P.any_mcts + spw - 1) / spw) * spw;
-            d.mcts.slots = (int)std::min<long long>(want, (long long)MCTS_ARENA_WAVES * spw);
+            d.mcts.grid_lanes = (int)std::min<long long>(want, (long long)MCTS_ARENA_WAVES * spw);
+            double budget_gb = 64.0;
+            if (const char* ev = std::getenv("HK_MCTS_PERSIST_GB")) budget_gb = std::atof(ev);
+            const double per_agent_gb = (double)na * d.mcts.pool_cap * sizeof(MNode) / 1e9;
+            d.mcts.persist = per_agent_gb <= budget_gb ? 1 : 0;
+            d.mcts.slots = d.mcts.persist ? (int)na : d.mcts.grid_lanes;
         }
         HK_ALLOC(d.mcts.st, na * sizeof(hk_mcts_state));
         HK_ALLOC(d.mcts.req, na * HK_GA_CALL(d, mcts_req_bytes()));

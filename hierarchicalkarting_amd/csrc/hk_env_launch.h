@@ -32,7 +32,7 @@ inline int launch_mcts_invalidate(EnvDevice& d, const hk_config& cfg, hipStream_
 inline int flush_mcts(EnvDevice& d, hipStream_t stream, std::string& err)
 {
     if (!d.mcts.st) return HK_OK;
-    hipLaunchKernelGGL(mcts_search_kernel, dim3((d.mcts.slots + MC_SPW - 1) / MC_SPW), dim3(64), 0, stream, d.P, d.mcts, d.mset);
+    hipLaunchKernelGGL(mcts_search_kernel, dim3((d.mcts.grid_lanes + MC_SPW - 1) / MC_SPW), dim3(64), 0, stream, d.P, d.mcts, d.mset);
     int rc = launch_check(err, "mcts_search_kernel");
     if (rc) return rc;
     d.mset ^= 1;

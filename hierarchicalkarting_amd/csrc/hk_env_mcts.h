@@ -36,7 +36,7 @@ constexpr int MC_SPW = HK_MC_SPW;             // searches per wave (see mcts_sea
 // the tree the reference would still hold, and the new search continues on it.  The CPU oracle really keeps its trees.
 struct MctsReq {
     int episode_steps, epoch, iterations, gen;      // of the latest request.  gen: bumped by every request of this ego (stale queue entries are skipped)
-    int last_sec, n_phases, pad1, pad2;             // last_sec: m_SectionIndex at the last copy of bestStates (mcts_consume)
+    int last_sec, n_phases, tree_nodes, pad2;       // last_sec: m_SectionIndex at the last copy of bestStates (mcts_consume); tree_nodes: nodes of the kept tree (M.persist)
     int ph_step[HK_MCTS_MAX_ROOT_PHASES];           // the searches the current tree has received, oldest first: episode step of the request ...
     int ph_iter[HK_MCTS_MAX_ROOT_PHASES];           // ... and its iteration budget
     MctsKartSnap k[MC_MAXP];                        // the root position: every kart as the request that started the tree saw it
@@ -656,15 +656,17 @@ __device__ __forceinline__ DGame mc_root_load(const int* rootl, const int stride
 }
 
 // one queued search (queue entry q of `set`), its tree in the arena slice `nd`
-__device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDev& M, const TabView& T, const int set, const int q, MNode* nd,
-                                                unsigned short* path /* LDS, [MC_MAXPATH][64], this lane's column */, unsigned char* pup,
-                                                int* rootl /* M.roots + this lane: the root position, stride M.slots */)
+__device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDev& M, const TabView& T, const int set, const int q, const int lane0,
+                                                unsigned short* path /* LDS, [MC_MAXPATH][64], this lane's column */, unsigned char* pup)
 {
     const unsigned ent = (unsigned)M.queue[(size_t)set * 2 * P.E * P.A + q];
     const int pair = (int)(ent & 0xFFFFFFu);
     if (((unsigned)mc_reqs(M)[pair].gen & 0xFFu) != (ent >> 24)) return;          // superseded by a later request of the same ego
     const int env = pair / P.A, ego = pair % P.A;
-    const MctsReq& R = mc_reqs(M)[pair];
+    MctsReq& R = mc_reqs(M)[pair];
+    const int slot = M.persist ? pair : lane0;                                    // whose arena slice: the agent's, or the resident lane's
+    MNode* nd = M.nodes + (size_t)slot * M.pool_cap;
+    int* rootl = M.roots + slot;                                                  // the root position, word-major (stride M.slots)
     hk_mcts_state* mst = &M.st[pair];
 
     MctsCtx C;
@@ -707,11 +709,18 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
     root.fin = initialSection + P.depth[ego];
 
     const int rootP = root.P;
-    mc_root_store(rootl, M.slots, root);
+    const int n_phases = R.n_phases;
+    // a re-searched root (n_phases > 1): with per-agent slices the tree is still there and the new search continues on it; without,
+    // the earlier searches are replayed first (each with its own draw stream) — see MctsReq
+    const bool kept = M.persist && n_phases > 1;
     int n_nodes = 1;
-    nd[0].parent = -1; nd[0].first_child = -1; nd[0].last_child = -1; nd[0].next_sibling = -1;
-    nd[0].numEpisodes = 0; nd[0].totalValue = 0.0f; nd[0].action = 0; nd[0].n_children = 0; nd[0].pad = 0; nd[0].pad2 = 0;
-    nd[0].upnext = (unsigned char)mc_up_next(root);
+    if (kept) n_nodes = R.tree_nodes;
+    else {
+        mc_root_store(rootl, M.slots, root);
+        nd[0].parent = -1; nd[0].first_child = -1; nd[0].last_child = -1; nd[0].next_sibling = -1;
+        nd[0].numEpisodes = 0; nd[0].totalValue = 0.0f; nd[0].action = 0; nd[0].n_children = 0; nd[0].pad = 0; nd[0].pad2 = 0;
+        nd[0].upnext = (unsigned char)mc_up_next(root);
+    }
 
     // The tree lives in global memory and a search is one lane: every dependent load is a round trip nothing hides.  So the
     // node the search stands on is kept in registers (`cur`), the path is remembered in LDS instead of being re-walked through
@@ -721,8 +730,8 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
     MoveEval mv;
     // every search the tree has received, oldest first (a re-searched root: the earlier ones are replayed, see MctsReq); each has
     // its own draw stream, and the last one's continues into the read-out below
-    int ph = 0, it_left = R.ph_iter[0];
-    const int n_phases = R.n_phases;
+    int ph = kept ? n_phases - 1 : 0, it_left = R.ph_iter[ph];
+    C.c1 = (uint32_t)R.ph_step[ph];
     while (true) {
         if (it_left == 0) {
             if (++ph >= n_phases) break;
@@ -826,6 +835,7 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
         }
     }
     mst->pend = plan;
+    if (M.persist) R.tree_nodes = n_nodes;
 }
 
 // The search kernel: a fixed grid of waves (the arena holds one tree per resident lane, M.slots = gridDim.x * MC_SPW) walks the
@@ -843,12 +853,11 @@ __global__ HK_MC_BOUNDS void mcts_search_kernel(EnvParams P, MctsDev M, int set)
     if ((int)threadIdx.x >= MC_SPW) return;
     const int count = M.qcnt[set * 2];
     const int lane0 = blockIdx.x * MC_SPW + threadIdx.x;
-    if (lane0 >= M.slots) return;
+    if (lane0 >= M.grid_lanes) return;
     const TabView T = tab_view(P, P.tab);
-    MNode* nd = M.nodes + (size_t)lane0 * M.pool_cap;
     __shared__ unsigned short path[MC_MAXPATH * 64];        // node indices fit 16 bits: hk_create refuses pools beyond 65 535 nodes
     __shared__ unsigned char pup[MC_MAXPATH * 64];
-    for (int q = lane0; q < count; q += gridDim.x * MC_SPW) mcts_search_one(P, M, T, set, q, nd, path + threadIdx.x, pup + threadIdx.x, M.roots + lane0);
+    for (int q = lane0; q < count; q += gridDim.x * MC_SPW) mcts_search_one(P, M, T, set, q, lane0, path + threadIdx.x, pup + threadIdx.x);
 }
 
 #undef MC_EACH

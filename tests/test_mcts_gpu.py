@@ -52,7 +52,9 @@ def test_two_agent_mcts_vs_fixed_tick_by_tick():
         _cmp(g, o, t, full=(t % 10 == 0 or 70 < t < 80 or 140 < t < 150))
 
 
-def test_four_agents_all_mcts_odd_steps_and_timeout_resets():
+@pytest.mark.parametrize("persist_gb", ["64", "0"])
+def test_four_agents_all_mcts_odd_steps_and_timeout_resets(persist_gb, monkeypatch):
+    monkeypatch.setenv("HK_MCTS_PERSIST_GB", persist_gb)
     g, o = _pair(12, 4, [MC, MC, MC, MC], jitter_seed=7, mcts_iterations=16, max_episode_steps=260)
     t = 0
     for n in (3, 97, 1, 45, 60, 54, 7, 100, 133, 29, 71):
@@ -84,10 +86,14 @@ def test_create_rejects_bad_planner_budgets():
         hk.RacingEnv(hk.make_config(2, 2, high_mode=[MC, FX], tree_search_depth=[8, 5], section_window=5))   # sectionTimes ring: window <= 4
 
 
-def test_root_reuse_matches_the_oracles_persistent_trees():
-    """HKA:265-283: the kernel rebuilds a re-searched tree by replaying the searches it received, the oracle keeps the tree.
-    Kart 0 is pinned to its grid slot (never enters a section): searched at reset, at tick 100 and 200 on the same root, then not
-    at all; the other karts race on and drop their roots at every section they enter."""
+@pytest.mark.parametrize("persist_gb", ["64", "0"])
+def test_root_reuse_matches_the_oracles_persistent_trees(persist_gb, monkeypatch):
+    """HKA:265-283, both homes of the trees: one arena slice per agent (the tree survives between searches, as in the oracle) and,
+    when that does not fit the memory budget (forced here with HK_MCTS_PERSIST_GB=0), one per resident lane with the re-searched
+    tree rebuilt by replaying the searches it received.  Kart 0 is pinned to its grid slot (never enters a section): searched at
+    reset, at tick 100 and 200 on the same root, then not at all; the other karts race on and drop their roots at every section
+    they enter."""
+    monkeypatch.setenv("HK_MCTS_PERSIST_GB", persist_gb)
     g, o = _pair(6, 4, [MC, MC, MC, FX], jitter_seed=13, mcts_iterations=20)
     st = o.agent_state()
     t = 0
