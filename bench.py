@@ -164,7 +164,24 @@ def cpu_baseline(num_agents, seed, start_tick):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    threads = max(1, min(cores, E // 16))
+    # a container can see every host core and still be granted a fraction of them (cgroup CPU quota): threads beyond the grant
+    # only fight each other (a GPU box of this pool shows 256 cores and grants ~16)
+    granted = cores
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    granted = min(granted, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    granted = min(granted, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    threads = max(1, min(granted, E // 16))
     O.set_threads(threads)
     o = O.OracleEnv(hk.make_config(E, num_agents, jitter_seed=seed))
     o.reset()
@@ -182,8 +199,8 @@ def cpu_baseline(num_agents, seed, start_tick):
     O.set_threads(threads)
     return {"value": E * ticks_all / dt_all, "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": "CPU oracle (C port of the reference C#; the reference itself cannot run here), E = %d envs, ticks %d..%d "
-                      "of the same workload, OpenMP over envs on %d threads (%d host cores visible)"
-                      % (E, start_tick, start_tick + ticks_all, threads, cores),
+                      "of the same workload, OpenMP over envs on %d threads (%d host cores visible, %d granted to this container)"
+                      % (E, start_tick, start_tick + ticks_all, threads, cores, granted),
             "single_thread": {"value": E * ticks_one / dt_one, "unit": "env-steps/s", "cores": 1,
                               "sample": "same envs, the next %d ticks on 1 thread" % ticks_one}}
 

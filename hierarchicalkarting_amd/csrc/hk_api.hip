@@ -394,8 +394,39 @@ static int step_ticks(hk_handle h, int n_ticks)
     h->dev.mcts_defer = short_call;
     h->dev.ticks_since_reset += h->dev.call_ticks;      // the previous call's ticks
     h->dev.call_ticks = n_ticks; h->dev.call_ticks_issued = 0;
+    // Long calls of a planner handle without attached actors run in PAUSE mode: an env that requests a search stops at the next
+    // tick boundary until the search has run, the host runs a stretch of rounds (every env reaches its replan tick or the end of
+    // the call), launches ALL the searches of the stretch in one batch, looks at what is left and repeats.  Without the pause
+    // the requests of one replan wave trickle in over many rounds (envs that queue multi-player games advance 4 ticks a round,
+    // the others 8) and every partial batch costs a full search latency: 4-agent Complex, 16 384 envs: 11.8 -> see profiles/.
+    const bool pause = planner && !short_call && h->n_policies == 0 && h->done_host != nullptr && !std::getenv("HK_MCTS_NO_PAUSE");
+    h->dev.P.mcts_pause = pause ? 1 : 0;
     rc = hk::env_launch_arm(h->dev, h->cfg, n_ticks, h->stream, h->err);
     if (rc) { g_last_error = h->err; return rc; }
+    if (pause) {
+        h->dev.mcts_defer = true;                       // the rounds do not launch searches themselves
+        const int cadence = h->cfg.num_agents > 2 ? 4 : 1;
+        int maxleft = n_ticks;
+        for (int guard = 0; guard < 4096; guard++) {
+            // a stretch: enough rounds for an env that advances RUN_CAP ticks a round to reach its next replan (<= 100 ticks away);
+            // the slow ones (a solve cadence per round) get there in a later stretch
+            const int reach = std::min(maxleft, 100);
+            rc = issue_rounds(h, std::max(2, (reach + hk::RUN_CAP - 1) / hk::RUN_CAP + 2));
+            if (rc) return rc;
+            rc = hk::env_flush_mcts(h->dev, h->stream, h->err);
+            if (rc) { g_last_error = h->err; return rc; }
+            rc = issue_check(h, true);
+            if (rc) return rc;
+            HK_HIP(h, hipStreamSynchronize(h->stream));
+            maxleft = h->done_host[0];
+            if (maxleft <= 0 && !h->done_host[1]) break;
+            (void)cadence;
+        }
+        h->dev.mcts_defer = false;
+        h->dev.P.mcts_pause = 0;
+        if (maxleft > 0) return fail(h, HK_ERR_HIP, "hk_step: an env did not complete its ticks (internal scheduling error)");
+        return HK_OK;
+    }
     // Rounds.  An env that meets no multi-player game retires RUN_CAP ticks per round; one that does retires at least a solve
     // cadence.  Handles with a planner or attached actors issue the worst-case count up front (they step in short chunks and
     // must not stall on the host).  Everything else — the LQNG races of the headline — issues what a field without

@@ -60,6 +60,7 @@ struct EnvParams {
     const SecGeo* sec_geo; // [L]
     int team_of[ENV_MAXA], time_precision[ENV_MAXA], section_window[ENV_MAXA];
     int mcts_iter, mcts_iter0, mcts_lat, mcts_lat0, any_mcts;
+    int mcts_pause;     // set per hk_step call: an env that requested a planner search stops at the next tick boundary until the search has run (hk_api.hip step_ticks)
     uint32_t mcts_seed;
     // reward shaping (hk_env_reward.h)
     int rewards, n_teams, team_size[ENV_MAXA], training_agent[ENV_MAXA];

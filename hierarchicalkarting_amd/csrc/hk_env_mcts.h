@@ -36,7 +36,8 @@ constexpr int MC_SPW = HK_MC_SPW;             // searches per wave (see mcts_sea
 // the tree the reference would still hold, and the new search continues on it.  The CPU oracle really keeps its trees.
 struct MctsReq {
     int episode_steps, epoch, iterations, gen;      // of the latest request.  gen: bumped by every request of this ego (stale queue entries are skipped)
-    int last_sec, n_phases, tree_nodes, pad2;       // last_sec: m_SectionIndex at the last copy of bestStates (mcts_consume); tree_nodes: nodes of the kept tree (M.persist)
+    int last_sec, n_phases, tree_nodes, done_gen;   // last_sec: m_SectionIndex at the last copy of bestStates (mcts_consume); tree_nodes: nodes of the kept
+                                                    // tree (M.persist); done_gen: gen of the last request whose search has run (P.mcts_pause)
     int ph_step[HK_MCTS_MAX_ROOT_PHASES];           // the searches the current tree has received, oldest first: episode step of the request ...
     int ph_iter[HK_MCTS_MAX_ROOT_PHASES];           // ... and its iteration budget
     MctsKartSnap k[MC_MAXP];                        // the root position: every kart as the request that started the tree saw it
@@ -836,6 +837,15 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
     }
     mst->pend = plan;
     if (M.persist) R.tree_nodes = n_nodes;
+    R.done_gen = R.gen;
+}
+
+// P.mcts_pause: does this lane's agent wait for a search that has been requested but has not run yet?
+__device__ __forceinline__ bool mcts_search_outstanding(const EnvParams& P, const MctsDev& M, int env, int i)
+{
+    if (i >= P.A || P.high_mode[i] != HK_HIGH_MCTS) return false;
+    const MctsReq& R = mc_reqs(M)[(size_t)env * P.A + i];
+    return R.gen != R.done_gen;
 }
 
 // The search kernel: a fixed grid of waves (the arena holds one tree per resident lane, M.slots = gridDim.x * MC_SPW) walks the

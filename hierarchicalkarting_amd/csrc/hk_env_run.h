@@ -126,7 +126,10 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
     const LaneCfg LC = lane_cfg(P, i);                   // this lane's agent: modes and player list, read once
     RwAcc rwv = {0.0f, 0.0f, 0.0f};
     if (HAS_RW && P.rewards && arec) { rwv.cum = arec->cum_reward; rwv.step = arec->step_reward; rwv.group = arec->group_reward; }
-    while (env_ok && (phase != 0 || (left > 0 && budget > 0))) {
+    // P.mcts_pause (long hk_step calls of planner handles): an env with a requested, not yet run search waits at the tick boundary —
+    // the host launches the searches of a whole stretch of rounds in ONE batch (a launch lasts as long as one search however few it holds)
+    bool held = HAS_MCTS && P.mcts_pause && env_ok && group_or(mcts_search_outstanding(P, M, env, i) ? 1 : 0) != 0;
+    while (env_ok && (phase != 0 || (left > 0 && budget > 0 && !held))) {
         dirty = true;
         if (phase == 0) {
             const bool parked = phase_begin<HAS_RW, HAS_TRAIN>(P, env, i, env_ok, es, h, hfx, hfz, agents, results, M, mset, RD, rwv, act_branch);
@@ -143,6 +146,8 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
                     if (qn == n) queue[(size_t)(n - 2) * P.E * P.A + pos] = env * P.A + i;
                 }
                 if (M.st) phase_plan(P, M, mset, env, i, es, h.flags, h.section_index, h.lane, h.lane_changes, h.final_steer, arec);
+                // requests are posted on replan ticks (phase_plan) and on the reset tick (phase_begin): look again after those
+                if (HAS_MCTS && P.mcts_pause && es.episode_steps % 100 == 0) held = group_or(mcts_search_outstanding(P, M, env, i) ? 1 : 0) != 0;
             } else {
                 left -= 1; budget -= 1;         // a parked env lets the tick pass
                 continue;
@@ -208,7 +213,10 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
         // phase 2 = parked by this wave for its own solve (it resumes in the pass right after it)
         const bool resume = first ? phase != 0 : phase == 2;
         if (resume) phase = 1;
-        bool go = env_ok && (resume || (phase == 0 && left > 0 && budget > 0));
+        // P.mcts_pause (long hk_step calls of planner handles): an env with a requested, not yet run search waits at the tick boundary —
+        // the host launches the searches of a whole stretch of rounds in ONE batch (a launch lasts as long as one search however few it holds)
+        bool held = HAS_MCTS && P.mcts_pause && env_ok && group_or(mcts_search_outstanding(P, M, env, i) ? 1 : 0) != 0;
+        bool go = env_ok && (resume || (phase == 0 && left > 0 && budget > 0 && !held));
         while (__ballot(go) != 0ull) {
             int qn = 0;                  // player count of the multi-player game this ego assembled on this tick (0: none)
             bool began = false;          // this env ran phases A / B1 in this iteration (it was at a tick boundary and not parked)
@@ -254,6 +262,8 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
                     if (qn == n) queue[(size_t)(n - 2) * P.E * P.A + pos] = env * P.A + i;
                 }
                 if (M.st) phase_plan(P, M, mset, env, i, es, h.flags, h.section_index, h.lane, h.lane_changes, h.final_steer, arec);
+                // requests are posted on replan ticks (phase_plan) and on the reset tick (phase_begin): look again after those
+                if (HAS_MCTS && P.mcts_pause && es.episode_steps % 100 == 0) held = group_or(mcts_search_outstanding(P, M, env, i) ? 1 : 0) != 0;
                 HK_ST(h, 6);           // [6] queue binning (+ planner hooks)
                 // does any ego of this env wait for a queued multi-player solve?
                 if (group_or(qn ? 1 : 0)) { phase = 1; moving = false; go = false; }
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_s
                 phase = 0;
                 left -= 1; budget -= 1;
             }
-            go = go && (left > 0 && budget > 0);
+            go = go && (left > 0 && budget > 0 && !held);
         }
         HK_ST(h, 13);                      // [13] waiting for the other lane groups of the wave to leave the loop
 #ifdef HK_STAMPS

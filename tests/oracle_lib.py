@@ -1,4 +1,6 @@
 """ctypes loader for the CPU oracle (oracle/_build/libhk_oracle.so).  Test infrastructure only."""
+import os
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")     # before libgomp loads: idle team threads sleep instead of spinning
 import ctypes as C, os, subprocess
 import numpy as np
 
@@ -119,6 +121,14 @@ def _env_api():
         L.hko_get_actions.restype = C.c_int
         L.hko_get_actions.argtypes = [C.c_void_p, fp, C.POINTER(C.c_int32)]
         L._env_bound = True
+        # The oracle spreads envs over OpenMP threads.  A GPU box shows every host core (256) but grants a share of ~16: with the
+        # default team size the per-tick fork / join of the policy tests spins 256 threads on 16 CPUs and a 1-minute suite takes
+        # ten.  The tests' batches are small: cap the team (bench.py's cpu_baseline sets its own count).
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        L.hko_set_threads(max(1, min(16, cores, int(os.environ.get("HKO_THREADS", "16")))))
     return L
 
 
