@@ -850,7 +850,7 @@ __device__ __forceinline__ bool mcts_search_outstanding(const EnvParams& P, cons
 
 // The search kernel: a fixed grid of waves (the arena holds one tree per resident lane, M.slots = gridDim.x * MC_SPW) walks the
 // queue with a grid stride, so the arena does not grow with the number of envs and every wave ends when the queue is exhausted.
-#if HK_GA > 4
+#if HK_GA > 4 || defined(HK_MC_OCC2)
 #define HK_MC_BOUNDS __launch_bounds__(64, 2)      /* 8 karts: hold the kernel to 256 registers so that two waves fit a SIMD */
 #else
 #define HK_MC_BOUNDS __launch_bounds__(64)
