@@ -93,24 +93,20 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
     // Bulk or sparse?  The host cannot see the queues without a sync, but it knows how long ago the field stood on the start grid:
     // for BULK_TICKS after a reset of every env most egos hold a 2-player game (their row mate), later almost none does.
     const bool bulk = cfg.num_agents == 2 || d.ticks_since_reset + d.call_ticks_issued < BULK_TICKS;
-    if (bulk) {
-        // 2-player games (every game of a 1v1 race; the bulk of a race start): their own kernel, two waves per SIMD
-        const int nb = std::min((ngames + 7) / 8, cfg.num_agents == 2 ? 4096 : 2048);
-        hipLaunchKernelGGL(lqn_single_kernel<2>, dim3(nb), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status, d.game_stats);
-        if ((rc = launch_check(err, "lqn_single_kernel<2>"))) return rc;
+    {
+        // 2-player games (every game of a 1v1 race; the bulk of a race start; almost every game of a spread field): a pair of lanes
+        // per game, 32 games a wave, no barriers (hk_lq2_pair.h)
+        const int nb = std::min((ngames + 31) / 32, bulk ? 4096 : 1024);
+        hipLaunchKernelGGL(lq2_pair_kernel, dim3(nb), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status, d.game_stats);
+        if ((rc = launch_check(err, "lq2_pair_kernel"))) return rc;
     }
     if (cfg.num_agents > 2) {
-        // 1 024 workgroups per game size (one wave per SIMD at the 4-player body's registers) walking their queue grid-stride
+        // 3- and 4-player games: 1 024 workgroups per game size (one wave per SIMD at the 4-player body's registers) walking their
+        // queue grid-stride
         const int nb = std::min((ngames + 3) / 4, 1024);
-        if (bulk) {
-            const int sizes = std::min(cfg.num_agents, 4) - 2;     // player counts 3 .. min(A, 4)
-            hipLaunchKernelGGL(lqn_34_kernel, dim3(nb * sizes), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status, nb, d.game_stats);
-            if ((rc = launch_check(err, "lqn_34_kernel"))) return rc;
-        } else {
-            const int sizes = std::min(cfg.num_agents, 4) - 1;     // player counts 2 .. min(A, 4)
-            hipLaunchKernelGGL(lqn_all_kernel, dim3(nb * sizes), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status, nb, d.game_stats);
-            if ((rc = launch_check(err, "lqn_all_kernel"))) return rc;
-        }
+        const int sizes = std::min(cfg.num_agents, 4) - 2;     // player counts 3 .. min(A, 4)
+        hipLaunchKernelGGL(lqn_34_kernel, dim3(nb * sizes), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status, nb, d.game_stats);
+        if ((rc = launch_check(err, "lqn_34_kernel"))) return rc;
 #if HK_GA > 4
         if (cfg.num_agents > 4) {
             const int nbb = std::min((ngames + 1) / 2, 512);

@@ -844,6 +844,8 @@ __global__ __launch_bounds__(64) void lqn_single_kernel(EnvParams P, hk_agent_st
     lqn_body<NP>(blockIdx.x, gridDim.x, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
 }
 
+#include "hk_lq2_pair.h"
+
 #if HK_GA > 4
 // Games with 5..8 players (only the synthetic 8-agent configuration has them).  The generic core is the same; beyond 4 players a
 // lane's value-matrix rows (NP x 4 NP doubles) exceed the register file and spill — the more players the more — so the sizes
