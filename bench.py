@@ -458,7 +458,7 @@ def bench_lqng(a, D, hk):
             # dense flop count of the games it actually solved in this run (hk_prof_games)
             flop = sum(n * lq_flop(N) for N, n in games.items()) / dom_n
             achieved = flop / 1e12 / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
-            roof = {"bound": "fp64_valu", "kernel": "lqn_all_kernel (lqn_body<2,3,4>)", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS,
+            roof = {"bound": "fp64_valu", "kernel": "lqn_round_kernel (2-player pairs + lqn_body<3,4>)", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "dense_flop_per_launch": flop}
         roof.update({"avg_launch_ms": dom_ms, "launches": prof[dom][1], "chosen_as": "largest total_ms among the stages of this run",
                      "kernel_total_ms": tot, "kernel_avg_ms": avg, "multi_player_games_solved": {str(k): v for k, v in games.items() if v},

@@ -94,21 +94,19 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
     // for BULK_TICKS after a reset of every env most egos hold a 2-player game (their row mate), later almost none does.
     const bool bulk = cfg.num_agents == 2 || d.ticks_since_reset + d.call_ticks_issued < BULK_TICKS;
     {
-        // 2-player games (every game of a 1v1 race; the bulk of a race start; almost every game of a spread field): a pair of lanes
-        // per game, 32 games a wave, no barriers (hk_lq2_pair.h)
-        const int nb = std::min((ngames + 31) / 32, bulk ? 4096 : 1024);
-        hipLaunchKernelGGL(lq2_pair_kernel, dim3(nb), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status, d.game_stats);
-        if ((rc = launch_check(err, "lq2_pair_kernel"))) return rc;
+        // One launch for every game of up to 4 players (lqn_round_kernel): the 2-player queue goes to pairs of lanes, 32 games a wave,
+        // no barriers (hk_lq2_pair.h); the 3- and 4-player queues to the generic core, 1 024 workgroups per game size (one wave per
+        // SIMD) walking their queue grid-stride.
+        const int sizes = cfg.num_agents > 2 ? std::min(cfg.num_agents, 4) - 2 : 0;     // player counts 3 .. min(A, 4)
+        const int n34 = sizes ? std::min((ngames + 3) / 4, 1024) * sizes : 0;
+        const int n2 = std::min((ngames + 31) / 32, bulk ? 4096 : 1024);
+        hipLaunchKernelGGL(lqn_round_kernel, dim3(n34 + n2), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status,
+                           n34, sizes ? sizes : 1, n2, d.game_stats);
+        if ((rc = launch_check(err, "lqn_round_kernel"))) return rc;
     }
-    if (cfg.num_agents > 2) {
-        // 3- and 4-player games: 1 024 workgroups per game size (one wave per SIMD at the 4-player body's registers) walking their
-        // queue grid-stride
-        const int nb = std::min((ngames + 3) / 4, 1024);
-        const int sizes = std::min(cfg.num_agents, 4) - 2;     // player counts 3 .. min(A, 4)
-        hipLaunchKernelGGL(lqn_34_kernel, dim3(nb * sizes), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status, nb, d.game_stats);
-        if ((rc = launch_check(err, "lqn_34_kernel"))) return rc;
+    if (cfg.num_agents > 4) {
 #if HK_GA > 4
-        if (cfg.num_agents > 4) {
+        {
             const int nbb = std::min((ngames + 1) / 2, 512);
             hipLaunchKernelGGL(lqn_big_kernel<5>, dim3(nbb * (cfg.num_agents > 5 ? 2 : 1)), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu,
                                d.lq_debug, d.status, nbb, d.game_stats);

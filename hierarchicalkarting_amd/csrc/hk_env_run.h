@@ -5,12 +5,12 @@
 // single-player Riccati solve)  ->  phase C (ArcadeKart model, engine restatement, triggers)  with the env words and
 // the per-tick agent fields (Hot) in registers; only the plan arrays are touched in memory.  The only thing a quad cannot do alone is a multi-player LQ game
 // (2-4 players, 8-16 cooperating lanes): it writes the game, queues it by player count, stores its progress and
-// leaves the loop; lqn_all_kernel (lqn_body<N>) solves the queues, and the next launch resumes the env at phase C.  Once the field
+// leaves the loop; lqn_round_kernel (hk_lq2_pair.h / lqn_body<N>) solves the queues, and the next launch resumes the env at phase C.  Once the field
 // has spread out ~99 % of all games are single-player, so almost every env runs its RUN_CAP ticks without leaving.
 //
 // Progress words live in hk_env_state.reserved[]: [0] = ticks still to run for the current hk_step, [1] = phase
 // (0: at a tick boundary, 1: waiting for a queued game of this tick).  hk_step(n) arms [0] = n and launches
-// ceil(n / cadence) + 1 rounds of {env_run_kernel, lqn_all_kernel}: a round always retires at least one solve
+// ceil(n / cadence) + 1 rounds of {env_run_kernel, lqn_round_kernel}: a round always retires at least one solve
 // cadence (4 ticks for A > 2, 1 tick otherwise) of every env that is not finished, so that many rounds always suffice;
 // rounds that find nothing to do cost a few microseconds.  (RUN_CAP must exceed the cadence: a resumed env finishes its
 // pending tick and must be able to reach its next solve tick within the same launch.)  env_check_kernel flags any env

@@ -798,52 +798,10 @@ __device__ HK_INWAVE_CALL void inwave_solve(unsigned long long mask, const int g
     }
 }
 
-// One launch for the queued games of every size: blocks [0, nb) take the 2-player queue, [nb, 2 nb) the 3-player one,
-// [2 nb, 3 nb) the 4-player one.  This is the launch of a round while the field is spread out: the queues are nearly empty
-// (99.95 % of the games are single-player and solved inside the tick kernel), and what a round's solver launches cost is their
-// fixed latency — a kernel launch plus one cold pass through a body's code.  Its registers are the 4-player body's (one wave
-// per SIMD), which is why the bulk of a race start goes through the two kernels below instead (launch_lqn decides).
-__global__ __launch_bounds__(64) void lqn_all_kernel(EnvParams P, hk_agent_state* agents, const GameSoA games, const int* queue_cnt,
-                                                     const int* queue, hk_lq_debug* dbg_out, int* status, int nb, unsigned long long* gstats)
-{
-    constexpr size_t B2 = (sizeof(LqGameLds<2>) + sizeof(CostRows<2>)) * LqDims<2>::SLOTS;
-    constexpr size_t B3 = (sizeof(LqGameLds<3>) + sizeof(CostRows<3>)) * LqDims<3>::SLOTS;
-    constexpr size_t B4 = (sizeof(LqGameLds<4>) + sizeof(CostRows<4>)) * LqDims<4>::SLOTS;
-    constexpr size_t BMAX = B2 > B3 ? (B2 > B4 ? B2 : B4) : (B3 > B4 ? B3 : B4);
-    __shared__ __align__(16) unsigned char smem[BMAX];
-    const int which = blockIdx.x / nb, b = blockIdx.x - which * nb;
-    if (which == 0) lqn_body<2>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
-    else if (which == 1) lqn_body<3>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
-    else lqn_body<4>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
-}
-
-// The bulk variant, part 1: the queued games of 3 and 4 players (blocks [0, nb): 3 players, [nb, 2 nb): 4 players).  2-player games
-// — the start grid's row mates: every ego of a race start holds one — go to lqn_single_kernel<2>: the 4-player body needs 458
-// VGPRs (one wave per SIMD) and 39.7 KB of LDS per wave, and in the merged kernel the 2-player games run at that occupancy too
-// (0.6 ms for the 262 144 games of a race-start tick, 13 % of the fp64 vector peak).
-__global__ __launch_bounds__(64) void lqn_34_kernel(EnvParams P, hk_agent_state* agents, const GameSoA games, const int* queue_cnt,
-                                                    const int* queue, hk_lq_debug* dbg_out, int* status, int nb, unsigned long long* gstats)
-{
-    constexpr size_t B3 = (sizeof(LqGameLds<3>) + sizeof(CostRows<3>)) * LqDims<3>::SLOTS;
-    constexpr size_t B4 = (sizeof(LqGameLds<4>) + sizeof(CostRows<4>)) * LqDims<4>::SLOTS;
-    constexpr size_t BMAX = B3 > B4 ? B3 : B4;
-    __shared__ __align__(16) unsigned char smem[BMAX];
-    const int which = blockIdx.x / nb, b = blockIdx.x - which * nb;
-    if (which == 0) lqn_body<3>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
-    else lqn_body<4>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
-}
-
-// The solver for ONE game size, with that size's own register allocation and LDS footprint: 2-player games need 180 VGPRs and
-// 22.4 KB per wave, so two waves share a SIMD (seven workgroups a CU).
-template <int NP>
-__global__ __launch_bounds__(64) void lqn_single_kernel(EnvParams P, hk_agent_state* agents, const GameSoA games, const int* queue_cnt,
-                                                        const int* queue, hk_lq_debug* dbg_out, int* status, unsigned long long* gstats)
-{
-    constexpr size_t BYTES = (sizeof(LqGameLds<NP>) + sizeof(CostRows<NP>)) * LqDims<NP>::SLOTS;
-    __shared__ __align__(16) unsigned char smem[BYTES];
-    lqn_body<NP>(blockIdx.x, gridDim.x, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
-}
-
+// The solver kernel of a round (lqn_round_kernel: 2-player games on pairs of lanes, 3- / 4-player games on the generic core) lives
+// in hk_lq2_pair.h.  (Round 1 / early round 2 went through three stages here, all retired: three launches per round, one merged
+// launch at the 4-player body's occupancy — 0.6 ms for the 262 144 games of a race-start tick — and a 2-player kernel of its own at
+// two waves per SIMD, 0.38 ms per 100 000 games.)
 #include "hk_lq2_pair.h"
 
 #if HK_GA > 4

@@ -333,15 +333,15 @@ __device__ __forceinline__ void lq2_pair_solve(const int game, const int p, cons
 }
 
 #ifndef HK_LQ2_HOST_CHECK
-// The 2-player queue of a round, 32 games per wave (one workgroup = one wave), grid-stride
-__global__ __launch_bounds__(64) void lq2_pair_kernel(EnvParams P, hk_agent_state* agents, const GameSoA games, const int* queue_cnt,
-                                                      const int* queue, hk_lq_debug* dbg_out, int* status, unsigned long long* gstats)
+// The 2-player queue of a round, 32 games per wave (one workgroup = one wave), grid-stride over blocks [0, nblocks)
+__device__ __forceinline__ void lq2_pair_body(const int block, const int nblocks, const EnvParams& P, hk_agent_state* agents, const GameSoA& games,
+                                              const int* queue_cnt, const int* queue, hk_lq_debug* dbg_out, int* status, Lq2PairLds& S,
+                                              unsigned long long* gstats)
 {
-    __shared__ Lq2PairLds S;
     const int lane = threadIdx.x & 63, p = lane & 1, gs = lane >> 1;
     const int count = queue_cnt[2];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && count > 0) atomicAdd(&gstats[2], (unsigned long long)count);   // hk_prof_games
-    for (int base = blockIdx.x * 32; base < count; base += gridDim.x * 32) {
+    if (block == 0 && threadIdx.x == 0 && count > 0) atomicAdd(&gstats[2], (unsigned long long)count);   // hk_prof_games
+    for (int base = block * 32; base < count; base += nblocks * 32) {
         const int slot = base + gs;
         const bool live = slot < count;
         const int game = queue[live ? slot : count - 1];      // idle pairs recompute the last game and discard it (DPP needs full quads)
@@ -356,5 +356,25 @@ __global__ __launch_bounds__(64) void lq2_pair_kernel(EnvParams P, hk_agent_stat
             me->flags = fl; me->steering = st;
         }
     }
+}
+
+// ONE launch per round for every queued game of up to 4 players: blocks [0, n34) take the 3- and 4-player queues (the generic core,
+// n34 / sizes blocks per size; first in the grid: they are the long ones), blocks [n34, n34 + n2) the 2-player queue (pairs of
+// lanes).  Both bodies run one wave per SIMD (458 registers / 40 KB of LDS), so they share a kernel at no cost — and in a spread
+// field, where a round holds a handful of games of each kind, their latencies overlap instead of adding up.
+__global__ __launch_bounds__(64) void lqn_round_kernel(EnvParams P, hk_agent_state* agents, const GameSoA games, const int* queue_cnt,
+                                                       const int* queue, hk_lq_debug* dbg_out, int* status, int n34, int sizes, int n2,
+                                                       unsigned long long* gstats)
+{
+    constexpr size_t B3 = (sizeof(LqGameLds<3>) + sizeof(CostRows<3>)) * LqDims<3>::SLOTS;
+    constexpr size_t B4 = (sizeof(LqGameLds<4>) + sizeof(CostRows<4>)) * LqDims<4>::SLOTS;
+    constexpr size_t B34 = B3 > B4 ? B3 : B4;
+    constexpr size_t BMAX = B34 > sizeof(Lq2PairLds) ? B34 : sizeof(Lq2PairLds);
+    __shared__ __align__(16) unsigned char smem[BMAX];
+    const int b = blockIdx.x;
+    if (b >= n34) { lq2_pair_body(b - n34, n2, P, agents, games, queue_cnt, queue, dbg_out, status, *reinterpret_cast<Lq2PairLds*>(smem), gstats); return; }
+    const int per = n34 / sizes, which = b / per, bb = b - which * per;
+    if (which == 0) lqn_body<3>(bb, per, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
+    else lqn_body<4>(bb, per, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
 }
 #endif
