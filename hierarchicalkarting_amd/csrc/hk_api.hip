@@ -437,8 +437,20 @@ static int step_ticks(hk_handle h, int n_ticks)
                       !std::getenv("HK_FIXED_ROUNDS");
     int rounds = lazy ? hk::env_rounds_min(h->cfg, n_ticks) : hk::env_rounds_for(h->cfg, n_ticks);
     if (const char* dr = std::getenv("HK_DEBUG_MAX_ROUNDS")) rounds = std::min(rounds, std::atoi(dr));     // (diagnostic: look at the state between two rounds)
-    rc = issue_rounds(h, rounds);
-    if (rc) return rc;
+    {
+        // the rounds every env needs at RUN_CAP ticks a round, then — the laggards packed into the first lane groups — the tail
+        const int main_rounds = std::min(rounds, (n_ticks + hk::RUN_CAP - 1) / hk::RUN_CAP);
+        rc = issue_rounds(h, main_rounds);
+        if (rc) return rc;
+        if (rounds > main_rounds) {
+            if (!planner && h->n_policies == 0) {
+                rc = hk::env_launch_regroup(h->dev, h->cfg, h->stream, h->err);
+                if (rc) { g_last_error = h->err; return rc; }
+            }
+            rc = issue_rounds(h, rounds - main_rounds);
+            if (rc) return rc;
+        }
+    }
     if (planner && !short_call) {
         // searches requested in the last rounds of a long call run before it returns
         rc = hk::env_flush_mcts(h->dev, h->stream, h->err);

@@ -54,7 +54,7 @@ struct EnvDevice {
     SecGeo* sec_geo = nullptr;
     // lane-group -> env assignment of the tick kernel, regrouped by solve phase every REGROUP_ROUNDS rounds (hk_env_run.h)
     int* perm = nullptr;           // [E]
-    int* perm_counts = nullptr;    // [8]
+    int* perm_counts = nullptr;    // [16]
     bool perm_valid = false;
     int rounds_since_regroup = 0;
     EnvParams P{};

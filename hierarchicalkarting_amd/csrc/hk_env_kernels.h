@@ -282,7 +282,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     HK_ALLOC(d.games, na * HK_GA_CALL(d, game_doubles_per_ego()) * sizeof(double));
     HK_ALLOC(d.queue_cnt, 2 * 16 * sizeof(int));
     HK_ALLOC(d.perm, (size_t)E * sizeof(int));
-    HK_ALLOC(d.perm_counts, 8 * sizeof(int));
+    HK_ALLOC(d.perm_counts, 16 * sizeof(int));
     HK_ALLOC(d.queue, 2 * HK_GA_CALL(d, queue_ints_per_set(na)) * sizeof(int));
     if (cfg.rewards) {
         d.rw.S = cfg.laps * L + 2;
@@ -432,6 +432,12 @@ inline int env_launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream
     return HK_GA_CALL(d, launch_run(d, cfg, stream, err));
 }
 inline int env_launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_lqn(d, cfg, stream, err)); }
+// pack the envs that still have ticks to run into the first lane groups (the tail of a call; see env_regroup_count_kernel)
+inline int env_launch_regroup(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
+    d.rounds_since_regroup = 0;
+    return HK_GA_CALL(d, launch_regroup(d, cfg, stream, err));
+}
 // agent_mask: the agent slots whose observations are needed (all of them for the host's hk_get_observations / hk_observe)
 inline int env_launch_observe(EnvDevice& d, const hk_config& cfg, uint32_t agent_mask, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_observe(d, cfg, agent_mask, stream, err)); }
 

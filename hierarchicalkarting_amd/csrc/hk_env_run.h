@@ -45,23 +45,32 @@ __global__ __launch_bounds__(256) void env_check_kernel(const hk_env_state* envs
 // solve path for some of its lanes on EVERY tick.  Every few hundred ticks the lane groups are therefore re-assigned so that the
 // envs of a wave share their phase: perm[slot] = env, grouped by key = (episode_steps + ticks still to run) & 3, which does not
 // change while the call runs.  Envs are independent, so which lanes run an env changes nothing but the speed.
-__global__ __launch_bounds__(256) void env_regroup_count_kernel(const hk_env_state* envs, int E, int* counts /*[8]: 4 counts, 4 cursors*/)
+// Second use (round 2): the tail of a call.  Envs that met multi-player games lag behind, and the last rounds of an hk_step run for
+// them alone — scattered one or two to a wave, each such wave costing full ticks.  The key therefore also says whether an env is done
+// with the call (keys 4..7): unfinished envs are packed, by phase, into the first lane groups; blocks that hold only finished envs
+// leave at once.  (A 20-tick call: 8 rounds of which 5 are tail.)
+__device__ __forceinline__ int regroup_key(const hk_env_state& e)
+{
+    const int left = e.reserved[0];
+    return ((e.episode_steps + left) & 3) + ((left == 0 && e.reserved[1] == 0) ? 4 : 0);
+}
+__global__ __launch_bounds__(256) void env_regroup_count_kernel(const hk_env_state* envs, int E, int* counts /*[16]: 8 counts, 8 cursors*/)
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    const int key = env < E ? ((envs[env].episode_steps + envs[env].reserved[0]) & 3) : -1;
+    const int key = env < E ? regroup_key(envs[env]) : -1;
 #pragma unroll
-    for (int k = 0; k < 4; k++) (void)wave_agg_inc(&counts[k], key == k);
+    for (int k = 0; k < 8; k++) (void)wave_agg_inc(&counts[k], key == k);
 }
 __global__ __launch_bounds__(256) void env_regroup_scatter_kernel(const hk_env_state* envs, int E, int* counts, int* perm)
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    const int key = env < E ? ((envs[env].episode_steps + envs[env].reserved[0]) & 3) : -1;
-    const int c0 = counts[0], c1 = counts[1], c2 = counts[2];
+    const int key = env < E ? regroup_key(envs[env]) : -1;
+    int base = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int pos = wave_agg_inc(&counts[4 + k], key == k);
-        const int base = k == 0 ? 0 : (k == 1 ? c0 : (k == 2 ? c0 + c1 : c0 + c1 + c2));
+    for (int k = 0; k < 8; k++) {
+        const int pos = wave_agg_inc(&counts[8 + k], key == k);
         if (key == k) perm[base + pos] = env;
+        base += counts[k];
     }
 }
 

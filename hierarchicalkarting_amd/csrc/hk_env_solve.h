@@ -685,6 +685,9 @@ __device__ __forceinline__ void lqn_stage_solve(const int game, const int r, con
     lq_solve_game<NP, QCompact<NP>, true, SYNC>(r, LG, qp, 3, u0, singular);      // HKA:1201 horizon literal 3 (Q6)
 }
 
+#ifndef HK_LQN_SYNC
+#define HK_LQN_SYNC LqBlockSync
+#endif
 template <int NP>
 __device__ __forceinline__ void lqn_body(const int block, const int nblocks, const EnvParams& P, hk_agent_state* agents, const GameSoA games,
                                          const int* queue_cnt, const int* queue, hk_lq_debug* dbg_out, int* status, unsigned char* smem,
@@ -706,7 +709,7 @@ __device__ __forceinline__ void lqn_body(const int block, const int nblocks, con
         const int game = qbase[live ? slot : count - 1];      // idle slots recompute the last game and discard it
         double u0[2];
         int singular = 0;
-        lqn_stage_solve<NP, LqBlockSync>(game, r, (double)P.dt, games, LG, CR, u0, singular);
+        lqn_stage_solve<NP, HK_LQN_SYNC>(game, r, (double)P.dt, games, LG, CR, u0, singular);
         if (live && r == 0) {
             if (singular) atomicOr(status, 1);
             hk_agent_state* me = &agents[game];
