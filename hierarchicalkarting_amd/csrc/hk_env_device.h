@@ -98,6 +98,8 @@ struct MctsDev {
     float* load_tab;        // [L][4][20]: tireLoad of the move
     float* rad_tab;         // [L][4][4]: radiusOfLane(section, from, to)
     int nv;                 // velocity buckets of the action list (<= 5)
+    int ntab;               // entries of dt_tab
+    int lds_attr_set;       // host: the search kernel's dynamic-LDS limit has been raised on this device
     int pool_cap;
     int slots;              // trees the arena holds: one per resident lane of the search kernel (persist = 0) or one per agent (persist = 1)
     int grid_lanes;         // lanes of the search kernel's grid (<= MCTS_ARENA_WAVES waves)

@@ -87,6 +87,7 @@ namespace hk {
 struct GaOps {
     size_t (*mcts_req_bytes)();
     int (*mcts_searches_per_wave)();
+    size_t (*mcts_lds_bytes)(int ntab, int L, int waves);
     int (*mcts_root_words)();
     size_t (*game_doubles_per_ego)();
     size_t (*queue_ints_per_set)(size_t na);

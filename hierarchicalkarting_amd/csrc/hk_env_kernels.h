@@ -340,7 +340,15 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         HK_ALLOC(d.mcts.dt_tab, (size_t)ntab * sizeof(int));
         HK_ALLOC(d.mcts.load_tab, (size_t)L * 4 * HK_MCTS_MAX_ACTIONS * sizeof(float));
         HK_ALLOC(d.mcts.rad_tab, (size_t)L * 4 * 4 * sizeof(float));
+        d.mcts.ntab = ntab;
         if ((rc = HK_GA_CALL(d, launch_mcts_table(d, ego0, ntab, stream, err)))) return rc;
+        {   // the search kernel keeps the tables in LDS, dt as int16, 8 waves a workgroup: check the range and the fit
+            std::vector<int> hdt((size_t)ntab);
+            if ((e = hipMemcpyAsync(hdt.data(), d.mcts.dt_tab, (size_t)ntab * sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+                (e = hipStreamSynchronize(stream)) != hipSuccess) { err = std::string("hk_create: move tables: ") + hipGetErrorString(e); return HK_ERR_HIP; }
+            for (int v : hdt) if (v > 32767) { err = "hk_create: a move of the discrete game takes more than 32 767 time units (timePrecision too fine for the planner's tables)"; return HK_ERR_UNSUPPORTED; }
+            if (HK_GA_CALL(d, mcts_lds_bytes(ntab, L, 8)) > 160 * 1024) { err = "hk_create: the planner's move tables do not fit the LDS (track too long)"; return HK_ERR_UNSUPPORTED; }
+        }
     }
 #undef HK_ALLOC
     // REC.Start :148-168: every agent starts inactive; results carry episode = -1; RL branch defaults to "coast"

@@ -5,7 +5,8 @@
 namespace hk { namespace HK_GA_NS {
 
 inline size_t mcts_req_bytes() { return sizeof(MctsReq); }
-inline int mcts_searches_per_wave() { return MC_SPW; }
+inline int mcts_searches_per_wave() { return 64; }
+inline size_t mcts_lds_bytes(int ntab, int L, int waves) { return mcts_search_lds_bytes(ntab, L, waves); }
 inline int mcts_root_words() { return MC_ROOT_WORDS; }
 inline size_t game_doubles_per_ego() { return (size_t)GA * GP_FIELDS; }      // GameSoA: GA players x GP_FIELDS doubles
 inline size_t queue_ints_per_set(size_t na) { return (size_t)(GA - 1) * na; }   // one queue per player count 2 .. GA
@@ -32,7 +33,17 @@ inline int launch_mcts_invalidate(EnvDevice& d, const hk_config& cfg, hipStream_
 inline int flush_mcts(EnvDevice& d, hipStream_t stream, std::string& err)
 {
     if (!d.mcts.st) return HK_OK;
-    hipLaunchKernelGGL(mcts_search_kernel, dim3((d.mcts.grid_lanes + MC_SPW - 1) / MC_SPW), dim3(64), 0, stream, d.P, d.mcts, d.mset);
+    {
+        // one workgroup per CU, 4 waves (one per SIMD) while the grid is at most 1 024 waves, 8 beyond; the move tables ride in its LDS
+        const int total_waves = (d.mcts.grid_lanes + 63) / 64;
+        const int waves = total_waves <= 1024 ? 4 : 8;
+        const size_t lds = mcts_search_lds_bytes(d.mcts.ntab, d.P.L, waves);
+        if (!d.mcts.lds_attr_set) {
+            (void)hipFuncSetAttribute((const void*)mcts_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            d.mcts.lds_attr_set = 1;
+        }
+        hipLaunchKernelGGL(mcts_search_kernel, dim3((total_waves + waves - 1) / waves), dim3(waves * 64), lds, stream, d.P, d.mcts, d.mset, d.mcts.ntab);
+    }
     int rc = launch_check(err, "mcts_search_kernel");
     if (rc) return rc;
     d.mset ^= 1;
@@ -159,7 +170,7 @@ inline int launch_rewards_read(EnvDevice& d, int cnt, float* reward, float* grou
 
 inline const GaOps& make_ops()
 {
-    static const GaOps ops = {mcts_req_bytes, mcts_searches_per_wave, mcts_root_words, game_doubles_per_ego, queue_ints_per_set,
+    static const GaOps ops = {mcts_req_bytes, mcts_searches_per_wave, mcts_lds_bytes, mcts_root_words, game_doubles_per_ego, queue_ints_per_set,
                               launch_mcts_table, launch_mcts_invalidate, flush_mcts, launch_reset, launch_regroup, launch_run, launch_lqn,
                               launch_observe, launch_arm, launch_done_check, launch_rewards_read};
     return ops;

@@ -226,7 +226,7 @@ struct MctsCtx {
     const TabView* T;
     int bucket, precision, vmax, nact;
     uint32_t key0, key1, c1, c2, draw;
-    const int* dt_tab; const float* load_tab; const float* rad_tab; int nv;
+    const short* dt_tab; const float* load_tab; const float* rad_tab; int nv;      // the move tables (the search kernel's copy in LDS)
 };
 
 __device__ __forceinline__ void mc_draw(MctsCtx& C, uint32_t r[4]) { philox4x32(C.draw++, C.c1, C.c2, 0x4D435453u, C.key0, C.key1, r); }
@@ -426,7 +426,7 @@ __device__ __forceinline__ void mc_eval_moves(const MctsCtx& C, const DGame& g, 
     const float* rp = C.rad_tab + (sm * 4 + (cur.lane - 1)) * 4;
     const float v0 = mc_max_speed(C, rp[0], wear), v1 = mc_max_speed(C, rp[1], wear);      // lateral-g speed limit per target lane
     const float v2 = mc_max_speed(C, rp[2], wear), v3 = mc_max_speed(C, rp[3], wear);
-    const int* dtp = C.dt_tab + (size_t)((sm * 4 + (cur.lane - 1)) * (C.nv + 1) + mc_vb(C, cur.minv)) * MC_MAXA;
+    const short* dtp = C.dt_tab + ((sm * 4 + (cur.lane - 1)) * (C.nv + 1) + mc_vb(C, cur.minv)) * MC_MAXA;
     mv.n = 0; mv.legal = 0;
 #pragma unroll
     for (int a = 0; a < MC_MAXA; a++) {
@@ -452,7 +452,7 @@ __device__ __forceinline__ void mc_make_move(const MctsCtx& C, DGame& g, int np,
     if (mc_straight(C, k.section) != mc_straight(C, k.section + 1)) lchg = 0;
     else if (lane != k.lane) lchg = k.lchg + dl;
     else lchg = k.lchg;
-    const int dt = C.dt_tab[(size_t)((sm * 4 + (k.lane - 1)) * (C.nv + 1) + mc_vb(C, k.minv)) * MC_MAXA + a];
+    const int dt = C.dt_tab[((sm * 4 + (k.lane - 1)) * (C.nv + 1) + mc_vb(C, k.minv)) * MC_MAXA + a];
     const float load = C.load_tab[(sm * 4 + (k.lane - 1)) * MC_MAXA + a];
     k.tire = (int)(((float)k.tire / 10000.0f + load * C.P->st.TireWearFactor) * 10000.0f);
     k.time += dt;
@@ -572,7 +572,7 @@ __device__ inline void mc_ctx_init(MctsCtx& C, const EnvParams& P, const TabView
     C.nact = 0;
     for (int i = 6; i < C.vmax; i += C.bucket) C.nact += 4;
     if (C.nact > MC_MAXA) C.nact = MC_MAXA;
-    C.dt_tab = M.dt_tab; C.load_tab = M.load_tab; C.rad_tab = M.rad_tab; C.nv = M.nv;
+    C.dt_tab = nullptr; C.load_tab = M.load_tab; C.rad_tab = M.rad_tab; C.nv = M.nv;       // (the search kernel points these at its LDS copies)
     C.key0 = 0; C.key1 = 0; C.c1 = 0; C.c2 = 0; C.draw = 0;
 }
 
@@ -657,7 +657,8 @@ __device__ __forceinline__ DGame mc_root_load(const int* rootl, const int stride
 }
 
 // one queued search (queue entry q of `set`), its tree in the arena slice `nd`
-__device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDev& M, const TabView& T, const int set, const int q, const int lane0,
+struct MctsTabs { const short* dt; const float* load; const float* rad; };
+__device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDev& M, const TabView& T, const MctsTabs& tabs, const int set, const int q, const int lane0,
                                                 unsigned short* path /* LDS, [MC_MAXPATH][64], this lane's column */, unsigned char* pup)
 {
     const unsigned ent = (unsigned)M.queue[(size_t)set * 2 * P.E * P.A + q];
@@ -672,6 +673,7 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
 
     MctsCtx C;
     mc_ctx_init(C, P, T, M, ego);
+    C.dt_tab = tabs.dt; C.load_tab = tabs.load; C.rad_tab = tabs.rad;
     C.key0 = P.mcts_seed; C.key1 = (uint32_t)(P.env_id_base + env) * (uint32_t)P.A + (uint32_t)ego;
     C.c1 = (uint32_t)R.ph_step[0]; C.c2 = (uint32_t)R.epoch; C.draw = 0;
 
@@ -848,26 +850,37 @@ __device__ __forceinline__ bool mcts_search_outstanding(const EnvParams& P, cons
     return R.gen != R.done_gen;
 }
 
-// The search kernel: a fixed grid of waves (the arena holds one tree per resident lane, M.slots = gridDim.x * MC_SPW) walks the
-// queue with a grid stride, so the arena does not grow with the number of envs and every wave ends when the queue is exhausted.
-#if HK_GA > 4 || defined(HK_MC_OCC2)
-#define HK_MC_BOUNDS __launch_bounds__(64, 2)      /* 8 karts: hold the kernel to 256 registers so that two waves fit a SIMD */
-#else
-#define HK_MC_BOUNDS __launch_bounds__(64)
-#endif
-__global__ HK_MC_BOUNDS void mcts_search_kernel(EnvParams P, MctsDev M, int set)
+// The search kernel: a fixed grid of waves (<= MCTS_ARENA_WAVES) walks the queue with a grid stride, so every wave ends when the queue
+// is exhausted.  A workgroup is 4 or 8 waves that share ONE copy of the move tables in LDS (dt as int16: hk_create checks the range):
+// a position evaluation reads 24 table entries per lane, and from L2 those loads kept the wave waiting 44 % of the time
+// (SQ_WAIT_ANY, round 2).  One workgroup per CU: 4 waves = one per SIMD while the batch is small (<= 1 024 waves), 8 = two per SIMD
+// beyond that (the kernel is held to 256 registers) — two resident waves hide each other's tree loads: 65 536 x 4 searches of 64
+// iterations 93 -> 59 ms before the tables moved.
+#define HK_MC_BOUNDS __launch_bounds__(512)
+constexpr int MC_PATH_BYTES = MC_MAXPATH * 64 * 3;          // per wave: node indices (16 bit) + up-next players (8 bit) of one root-to-leaf path
+inline size_t mcts_table_lds_bytes(int ntab, int L) { return (((size_t)ntab * sizeof(short) + 15) & ~(size_t)15) + (size_t)L * 4 * MC_MAXA * sizeof(float) + (size_t)L * 4 * 4 * sizeof(float); }
+inline size_t mcts_search_lds_bytes(int ntab, int L, int waves) { return mcts_table_lds_bytes(ntab, L) + (size_t)waves * MC_PATH_BYTES; }
+__global__ HK_MC_BOUNDS void mcts_search_kernel(EnvParams P, MctsDev M, int set, int ntab)
 {
-    // MC_SPW searches per wave.  Measured (16 384 envs x 4 agents = 1 024 full waves, one per SIMD): 64 -> 11.2 M env-steps/s,
-    // 32 -> 11.0 M, 21 -> 10.3 M, 16 -> 9.7 M: a launch lasts as long as one search however the searches are spread, so
-    // thinner waves buy nothing
-    if ((int)threadIdx.x >= MC_SPW) return;
+    extern __shared__ __align__(16) unsigned char mc_smem[];
     const int count = M.qcnt[set * 2];
-    const int lane0 = blockIdx.x * MC_SPW + threadIdx.x;
+    if (count == 0) return;                                  // (uniform: nothing queued, no table copy either)
+    short* dt_s = reinterpret_cast<short*>(mc_smem);
+    float* load_s = reinterpret_cast<float*>(mc_smem + (((size_t)ntab * sizeof(short) + 15) & ~(size_t)15));
+    float* rad_s = load_s + P.L * 4 * MC_MAXA;
+    unsigned char* paths = reinterpret_cast<unsigned char*>(rad_s + P.L * 4 * 4);
+    for (int k = threadIdx.x; k < ntab; k += blockDim.x) { const int v = M.dt_tab[k]; dt_s[k] = (short)(v < 0 ? -1 : v); }     // < 0: infeasible (only the sign is read)
+    for (int k = threadIdx.x; k < P.L * 4 * MC_MAXA; k += blockDim.x) load_s[k] = M.load_tab[k];
+    for (int k = threadIdx.x; k < P.L * 4 * 4; k += blockDim.x) rad_s[k] = M.rad_tab[k];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = blockDim.x >> 6;
+    const int lane0 = (blockIdx.x * waves + wave) * 64 + lane;
     if (lane0 >= M.grid_lanes) return;
     const TabView T = tab_view(P, P.tab);
-    __shared__ unsigned short path[MC_MAXPATH * 64];        // node indices fit 16 bits: hk_create refuses pools beyond 65 535 nodes
-    __shared__ unsigned char pup[MC_MAXPATH * 64];
-    for (int q = lane0; q < count; q += gridDim.x * MC_SPW) mcts_search_one(P, M, T, set, q, lane0, path + threadIdx.x, pup + threadIdx.x);
+    unsigned short* path = reinterpret_cast<unsigned short*>(paths + (size_t)wave * MC_PATH_BYTES);       // [MC_MAXPATH][64]: node indices fit 16 bits
+    unsigned char* pup = reinterpret_cast<unsigned char*>(path + MC_MAXPATH * 64);                         //   (hk_create refuses pools beyond 65 535 nodes)
+    MctsTabs tabs = {dt_s, load_s, rad_s};
+    for (int q = lane0; q < count; q += gridDim.x * waves * 64) mcts_search_one(P, M, T, tabs, set, q, lane0, path + lane, pup + lane);
 }
 
 #undef MC_EACH

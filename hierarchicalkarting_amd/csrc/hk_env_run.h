@@ -78,7 +78,10 @@ __global__ __launch_bounds__(256) void env_regroup_scatter_kernel(const hk_env_s
 // Training-mode code compile away entirely.  Instantiated: every (HAS_MCTS, HAS_RW) pair without Training code, and
 // <true, true, true> for any handle that uses Training mode (its planner / reward parts are also guarded at run time).
 template <bool HAS_MCTS, bool HAS_RW, bool HAS_TRAIN>
-__global__ __launch_bounds__(256, 2) void env_run_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
+#ifndef HK_RUN_OCC
+#define HK_RUN_OCC 2
+#endif
+__global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
                                                       hk_episode_result* results, GameSoA games, int* queue_cnt_all,
                                                       int* queue_all, int set, const float* act_steer, const int* act_branch,
                                                       hk_lq_debug* dbg_out, int* status, int use_lds, MctsDev Marg, int mset, RwDev RD, const int* perm,
