@@ -16,6 +16,8 @@ namespace KartGame.AI.Native
         public const int HK_MAX_SECTIONS = 64;
         public const int HK_NUM_SENSORS = 9;
         public const int HK_MCTS_MAX_DEPTH = 8;
+        public const int HK_MCTS_SECTIME_RING = 8;
+        public const int HK_MCTS_MAX_ROOT_PHASES = 3;
         public const int HK_COMM_ID_BYTES = 128;
         public const int HK_PROF_STAGES = 5;
         // HierarchicalKartAgent.cs:21-33
