@@ -27,52 +27,54 @@ def _close(got, want, rel, abs_=1e-6):
 
 
 def _replay(make_env):
-    fx = json.load(open(FIX))
-    assert fx["record_bytes"] == AGENT_DT.itemsize
-    kw = fx["config"]
-    branches, n_games, n_free = set(), 0, 0
-    for case in fx["cases"]:
-        e = make_env(kw)
-        e.reset()
-        st = np.frombuffer(base64.b64decode(case["state_before_b64"]), AGENT_DT).reshape(kw["num_envs"], kw["num_agents"]).copy()
-        es = np.frombuffer(base64.b64decode(case["env_state_before_b64"]), ENV_DT).copy()
-        e.set_agent_state(st)
-        e.set_env_state(es)
-        e.step(1)
-        assert (e.env_state()["episode_steps"] % 4 == 0).all()
-        a = e.agent_state()
-        for env, rec in enumerate(case["envs"]):
-            for ego, g in enumerate(rec["games"]):
-                if g is None:
-                    continue
-                d = e.lq_debug(env, ego)
-                n = len(g["players"])
-                where = (case["episode_step_before"], env, ego)
-                assert d.n_players == n and list(d.player_agent)[:n] == g["players"], where
-                assert list(d.branch)[:n] == g["branch"], (where, list(d.branch)[:n], g["branch"])
-                for i in range(n):
-                    assert _close(list(d.initial[i]), g["initial"][i], 2e-6), (where, i, "initial")
-                    assert _close(list(d.target[i])[:3], g["target"][i][:3], 2e-6), (where, i, "target")
-                    assert _close(d.target[i][3], g["target"][i][3], 2e-6, 2e-6), (where, i, "target heading", d.target[i][3], g["target"][i][3])
-                    assert _close(list(d.target_w[i]), g["target_w"][i], 2e-6, 1e-12), (where, i, "weights")
-                    assert _close(d.control_w[i], g["control_w"][i], 1e-12), (where, i)
-                assert _close(list(d.u0), g["u0"], 1e-4, 1e-5), (where, list(d.u0), g["u0"])
-                fl = int(a["flags"][env, ego])
-                assert bool(fl & _lib.HK_F_ACCEL) == g["accelerate"] and bool(fl & _lib.HK_F_BRAKE) == g["brake"], where
-                assert _close(a["steering"][env, ego], g["steering"], 1e-4, 1e-5), (where, "steering")
-                branches.update(g["branch"]); n_games += 1
-            for k, m in enumerate(rec["after"]):
-                if m is None:
-                    continue
-                for name, want in m.items():
-                    got = float(a[name][env, k])
-                    if name == "yaw":
-                        dy = abs(got - want); dy = min(dy, abs(dy - 2 * np.pi))
-                        assert dy <= 2e-5, (case["episode_step_before"], env, k, name, got, want)
-                    else:
-                        assert _close(got, want, 2e-5, 2e-5), (case["episode_step_before"], env, k, name, got, want)
-                n_free += 1
-    assert len(branches) >= 4 and n_games >= 150 and n_free >= 150, (branches, n_games, n_free)
+    branches, n_games, n_free, n_players = set(), 0, 0, set()
+    for suite in json.load(open(FIX))["suites"]:
+        assert suite["record_bytes"] == AGENT_DT.itemsize
+        kw = suite["config"]
+        cadence = 4 if kw["num_agents"] > 2 else 1
+        for case in suite["cases"]:
+            e = make_env(kw)
+            e.reset()
+            st = np.frombuffer(base64.b64decode(case["state_before_b64"]), AGENT_DT).reshape(kw["num_envs"], kw["num_agents"]).copy()
+            es = np.frombuffer(base64.b64decode(case["env_state_before_b64"]), ENV_DT).copy()
+            e.set_agent_state(st)
+            e.set_env_state(es)
+            e.step(1)
+            assert (e.env_state()["episode_steps"] % cadence == 0).all()
+            a = e.agent_state()
+            for env, rec in enumerate(case["envs"]):
+                for ego, g in enumerate(rec["games"]):
+                    if g is None:
+                        continue
+                    d = e.lq_debug(env, ego)
+                    n = len(g["players"])
+                    where = (kw.get("track", "oval"), kw["num_agents"], case["episode_step_before"], env, ego)
+                    assert d.n_players == n and list(d.player_agent)[:n] == g["players"], where
+                    assert list(d.branch)[:n] == g["branch"], (where, list(d.branch)[:n], g["branch"])
+                    for i in range(n):
+                        assert _close(list(d.initial[i]), g["initial"][i], 2e-6), (where, i, "initial")
+                        assert _close(list(d.target[i])[:3], g["target"][i][:3], 2e-6), (where, i, "target")
+                        assert _close(d.target[i][3], g["target"][i][3], 2e-6, 2e-6), (where, i, "target heading", d.target[i][3], g["target"][i][3])
+                        assert _close(list(d.target_w[i]), g["target_w"][i], 2e-6, 1e-12), (where, i, "weights")
+                        assert _close(d.control_w[i], g["control_w"][i], 1e-12), (where, i)
+                    assert _close(list(d.u0), g["u0"], 1e-4, 1e-5), (where, list(d.u0), g["u0"])
+                    fl = int(a["flags"][env, ego])
+                    assert bool(fl & _lib.HK_F_ACCEL) == g["accelerate"] and bool(fl & _lib.HK_F_BRAKE) == g["brake"], where
+                    assert _close(a["steering"][env, ego], g["steering"], 1e-4, 1e-5), (where, "steering")
+                    branches.update(g["branch"]); n_games += 1; n_players.add(n)
+                for k, m in enumerate(rec["after"]):
+                    if m is None:
+                        continue
+                    for name, want in m.items():
+                        got = float(a[name][env, k])
+                        where = (kw.get("track", "oval"), kw["num_agents"], case["episode_step_before"], env, k, name, got, want)
+                        if name == "yaw":
+                            dy = abs(got - want); dy = min(dy, abs(dy - 2 * np.pi))
+                            assert dy <= 2e-5, where
+                        else:
+                            assert _close(got, want, 2e-5, 2e-5), where
+                    n_free += 1
+    assert len(branches) >= 5 and n_games >= 350 and n_free >= 300 and n_players >= {1, 2}, (branches, n_games, n_free, n_players)
 
 
 def test_oracle_matches_the_independent_mirror(monkeypatch):
@@ -90,11 +92,11 @@ def test_kernels_match_the_independent_mirror(monkeypatch):
 def test_mirror_regenerates_its_own_fixture():
     """the committed file IS what oracle/step_numpy.py computes today from the recorded states (no hand edits, no drift)"""
     from oracle import step_numpy as SN
-    fx = json.load(open(FIX))
-    kw = fx["config"]
-    M = SN.Mirror(make_config(**kw))
-    for case in fx["cases"][::3]:
-        st = np.frombuffer(base64.b64decode(case["state_before_b64"]), AGENT_DT).reshape(kw["num_envs"], kw["num_agents"])
-        for env in (0, kw["num_envs"] - 1):
-            games, after = M.solve_tick(st[env])
-            assert json.loads(json.dumps({"games": games, "after": after})) == case["envs"][env]
+    for suite in json.load(open(FIX))["suites"]:
+        kw = suite["config"]
+        M = SN.Mirror(make_config(**kw))
+        for case in suite["cases"][::3]:
+            st = np.frombuffer(base64.b64decode(case["state_before_b64"]), AGENT_DT).reshape(kw["num_envs"], kw["num_agents"])
+            for env in (0, kw["num_envs"] - 1):
+                games, after = M.solve_tick(st[env])
+                assert json.loads(json.dumps({"games": games, "after": after})) == case["envs"][env]
