@@ -11,7 +11,10 @@ import __graft_entry__ as ge
 
 def main():
     name = sys.argv[1]
-    defs = [a for a in sys.argv[2:] if a.startswith("-D") or a.startswith("-m") or a.startswith("-f")]
+    head = sys.argv[2:sys.argv.index("--flags")] if "--flags" in sys.argv else sys.argv[2:]
+    defs = [a for a in head if a.startswith("-D") or a.startswith("-m") or a.startswith("-f") or a.startswith("-O")]
+    if "--flags" in sys.argv:                       # everything after --flags goes to hipcc verbatim (e.g. --flags -mllvm -some-option=1)
+        defs += sys.argv[sys.argv.index("--flags") + 1:]
     unit = "hk_ga4.hip"
     if "--unit" in sys.argv:
         unit = sys.argv[sys.argv.index("--unit") + 1]
