@@ -63,6 +63,17 @@ def test_four_agents_all_mcts_odd_steps_and_timeout_resets(persist_gb, monkeypat
     assert (g.env_state()["episodes_done"] >= 2).all()
 
 
+def test_long_calls_without_the_pause_schedule(monkeypatch):
+    """HK_MCTS_NO_PAUSE=1: long calls keep the fully asynchronous deadline schedule (searches launched every few rounds, envs never
+    wait) — the schedule must not show in the results"""
+    monkeypatch.setenv("HK_MCTS_NO_PAUSE", "1")
+    g, o = _pair(10, 4, [MC, MC, MC, MC], jitter_seed=19, mcts_iterations=16)
+    t = 0
+    for n in (150, 90, 260):
+        g.step(n); o.step(n); t += n
+        _cmp(g, o, t)
+
+
 def test_mixed_team_complex_track():
     g, o = _pair(8, 4, [MC, FX, MC, FX], track="complex", jitter_seed=2, mcts_iterations=20)
     t = 0
