@@ -106,6 +106,9 @@ struct hk_context {
 };
 
 static int finish_ticks(hk_context* h);      // lazy completion of the last hk_step (defined with step_ticks)
+#ifndef HK_LAZY_MIN_TICKS
+#define HK_LAZY_MIN_TICKS 64      /* calls at least this long issue the rounds a spread field needs and finish the laggards after a look at the device */
+#endif
 
 namespace {
 
@@ -366,7 +369,9 @@ static int finish_ticks(hk_handle h)
         HK_HIP(h, hipStreamSynchronize(h->stream));
         const int maxleft = h->done_host[0], waiting = h->done_host[1];
         if (maxleft <= 0 && !waiting) { h->step_pending = false; break; }
-        int rc = issue_rounds(h, (maxleft + cadence - 1) / cadence + 1);
+        int rc = hk::env_launch_regroup(h->dev, h->cfg, h->stream, h->err);      // the laggards into the first lane groups
+        if (rc) { g_last_error = h->err; return rc; }
+        rc = issue_rounds(h, (maxleft + cadence - 1) / cadence + 1);
         if (rc) return rc;
         rc = issue_check(h, true);
         if (rc) return rc;
@@ -433,8 +438,7 @@ static int step_ticks(hk_handle h, int n_ticks)
     // multi-player games needs, and the stragglers are finished lazily by the next call that touches the state
     // (finish_ticks): most of the worst-case rounds found nothing to do, and on a 20-tick call they were 5 launches of 8.
     // (short calls — a host stepping tick by tick — keep the fixed count too: a handful of rounds, no host sync)
-    const bool lazy = HK_INWAVE && !planner && h->n_policies == 0 && h->done_host != nullptr && h->cfg.num_agents <= 4 && n_ticks >= 2 * hk::RUN_CAP &&
-                      !std::getenv("HK_FIXED_ROUNDS");
+    const bool lazy = !planner && h->n_policies == 0 && h->done_host != nullptr && n_ticks >= HK_LAZY_MIN_TICKS && !std::getenv("HK_FIXED_ROUNDS");
     int rounds = lazy ? hk::env_rounds_min(h->cfg, n_ticks) : hk::env_rounds_for(h->cfg, n_ticks);
     if (const char* dr = std::getenv("HK_DEBUG_MAX_ROUNDS")) rounds = std::min(rounds, std::atoi(dr));     // (diagnostic: look at the state between two rounds)
     {
