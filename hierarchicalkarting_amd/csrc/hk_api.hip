@@ -73,6 +73,8 @@ struct Prof {
 struct hk_context {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t qstream = nullptr;   // the solver kernels of long calls run here, beside the next round of the tick kernel (issue_rounds_overlapped)
+    hipEvent_t ev_run[2] = {nullptr, nullptr}, ev_lqn[2] = {nullptr, nullptr};
     bool env_ready = false;
     hk_config cfg{};
     std::vector<hk_section> sections;
@@ -93,6 +95,7 @@ struct hk_context {
     // multi-player games needs and a guard kernel that reports what is left; the NEXT entry point that touches the state
     // finishes the stragglers (finish_ticks)
     bool step_pending = false;
+    bool step_overlapped = false;  // the pending call runs its solver launches on qstream (issue_rounds_overlapped)
     int* done_host = nullptr;      // pinned: [0] max ticks left over the envs, [1] an env waits for a queued game
     void* pol_scratch = nullptr;   // hk_policy_forward staging
     size_t pol_scratch_bytes = 0;
@@ -221,6 +224,8 @@ void hk_destroy(hk_handle h)
     for (int p = 0; p < HK_MAX_POLICIES; p++) hk::policy_free(h->policy[p]);
     h->prof.fold();
     for (hipEvent_t e : h->prof.pool) (void)hipEventDestroy(e);
+    if (h->qstream) { (void)hipStreamSynchronize(h->qstream); (void)hipStreamDestroy(h->qstream); }
+    for (int k = 0; k < 2; k++) { if (h->ev_run[k]) (void)hipEventDestroy(h->ev_run[k]); if (h->ev_lqn[k]) (void)hipEventDestroy(h->ev_lqn[k]); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h == g_default_ctx) g_default_ctx = nullptr;
     delete h;
@@ -350,6 +355,47 @@ static int issue_rounds(hk_handle h, int rounds)
     return HK_OK;
 }
 
+// The same rounds with the solver on a second stream.  In a spread field a round's solver launch holds a handful of games and costs
+// one solve's latency (~40 us of an otherwise idle GPU, 8 % of the headline's wall time).  Here lqn(r) runs on `qstream` BESIDE the
+// tick kernel of round r + 1; an env that queued a game in round r sits out round r + 1 and resumes in r + 2 (EnvParams.lq_defer,
+// the queueing round rides in the env's phase word).  Queue set r & 1 is filled by run(r), read by lqn(r), and free again when
+// run(r + 2) wants it — which is the one thing the tick stream waits for.
+// MEASURED (round 2): correct (every GPU parity test passes with it) and a LOSS: 806 M env-steps/s instead of 926 M.  The hidden
+// latency (18 ms per 3 072 ticks) is outweighed by the laggards it creates — a queued game now costs its env two rounds, the
+// call needs 852 launches instead of 474 and the tick kernel's total grows from 194 to 230 ms.  Off unless HK_LQ_OVERLAP is set.
+static int issue_rounds_overlapped(hk_handle h, int rounds)
+{
+    if (!h->qstream) {
+        HK_HIP(h, hipStreamCreateWithFlags(&h->qstream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            HK_HIP(h, hipEventCreateWithFlags(&h->ev_run[k], hipEventDisableTiming));
+            HK_HIP(h, hipEventCreateWithFlags(&h->ev_lqn[k], hipEventDisableTiming));
+        }
+    }
+    h->dev.P.lq_defer = 1;
+    for (int r = 0; r < rounds; r++) {
+        const int k = h->dev.round & 1;
+        HK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_lqn[k], 0));            // lqn(round - 2) is done: its controls are there, set k is free
+        HK_HIP(h, hipMemsetAsync(h->dev.queue_cnt + k * 16, 0, 16 * sizeof(int), h->stream));
+        hipEvent_t e = h->prof.begin(h->stream);
+        int rc = hk::env_launch_run(h->dev, h->cfg, h->stream, h->err);
+        if (rc) { g_last_error = h->err; return rc; }
+        h->prof.end(0, e, h->stream);
+        HK_HIP(h, hipEventRecord(h->ev_run[k], h->stream));
+        HK_HIP(h, hipStreamWaitEvent(h->qstream, h->ev_run[k], 0));
+        e = h->prof.begin(h->qstream);
+        rc = hk::env_launch_lqn(h->dev, h->cfg, h->qstream, h->err);          // (advances dev.round)
+        if (rc) { g_last_error = h->err; return rc; }
+        h->prof.end(1, e, h->qstream);
+        HK_HIP(h, hipEventRecord(h->ev_lqn[k], h->qstream));
+    }
+    // what follows on the tick stream (the guard kernel, a getter's copy) sees every solve
+    HK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_lqn[0], 0));
+    HK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_lqn[1], 0));
+    h->dev.P.lq_defer = 0;
+    return HK_OK;
+}
+
 // guard kernel + (lazy mode) its report on the way to pinned host memory
 static int issue_check(hk_handle h, bool lazy)
 {
@@ -371,7 +417,8 @@ static int finish_ticks(hk_handle h)
         if (maxleft <= 0 && !waiting) { h->step_pending = false; break; }
         int rc = hk::env_launch_regroup(h->dev, h->cfg, h->stream, h->err);      // the laggards into the first lane groups
         if (rc) { g_last_error = h->err; return rc; }
-        rc = issue_rounds(h, (maxleft + cadence - 1) / cadence + 1);
+        // (deferred scheme: a queued game costs its env two rounds)
+        rc = h->step_overlapped ? issue_rounds_overlapped(h, 2 * ((maxleft + cadence - 1) / cadence) + 2) : issue_rounds(h, (maxleft + cadence - 1) / cadence + 1);
         if (rc) return rc;
         rc = issue_check(h, true);
         if (rc) return rc;
@@ -444,7 +491,9 @@ static int step_ticks(hk_handle h, int n_ticks)
     {
         // the rounds every env needs at RUN_CAP ticks a round, then — the laggards packed into the first lane groups — the tail
         const int main_rounds = std::min(rounds, (n_ticks + hk::RUN_CAP - 1) / hk::RUN_CAP);
-        rc = issue_rounds(h, main_rounds);
+        // (measured: a loss — see issue_rounds_overlapped — so only on request)
+        h->step_overlapped = lazy && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4 && !h->cfg.rewards && std::getenv("HK_LQ_OVERLAP") != nullptr;
+        rc = h->step_overlapped ? issue_rounds_overlapped(h, main_rounds) : issue_rounds(h, main_rounds);
         if (rc) return rc;
         if (rounds > main_rounds) {
             if (!planner && h->n_policies == 0) {

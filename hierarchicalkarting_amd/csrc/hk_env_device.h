@@ -60,6 +60,8 @@ struct EnvParams {
     const SecGeo* sec_geo; // [L]
     int team_of[ENV_MAXA], time_precision[ENV_MAXA], section_window[ENV_MAXA];
     int mcts_iter, mcts_iter0, mcts_lat, mcts_lat0, any_mcts;
+    int lq_defer;       // set per hk_step call: the solver kernels run on a second stream beside the NEXT round of the tick kernel, so an env that
+                        // queued a game in round r resumes in round r + 2 (hk_api.hip issue_rounds_overlapped)
     int mcts_pause;     // set per hk_step call: an env that requested a planner search stops at the next tick boundary until the search has run (hk_api.hip step_ticks)
     uint32_t mcts_seed;
     // reward shaping (hk_env_reward.h)

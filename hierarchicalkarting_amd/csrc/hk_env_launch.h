@@ -81,7 +81,7 @@ inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
     const long long threads = (long long)cfg.num_envs * GA;
 #define HK_RUN(MC, RWF, TRN)                                                                                                  \
     hipLaunchKernelGGL((env_run_kernel<MC, RWF, TRN>), dim3((unsigned)((threads + 255) / 256)), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs,   \
-                       d.results, GameSoA{d.games, (size_t)cfg.num_envs * cfg.num_agents}, d.queue_cnt, d.queue, d.round & 1, d.act_steer, d.act_branch, d.lq_debug, d.status,     \
+                       d.results, GameSoA{d.games, (size_t)cfg.num_envs * cfg.num_agents}, d.queue_cnt, d.queue, d.round, d.act_steer, d.act_branch, d.lq_debug, d.status,     \
                        d.tab_lds ? 1 : 0, d.mcts, d.mset, d.rw, d.perm_valid ? d.perm : nullptr, d.game_stats)
     bool train = d.P.training_reset != 0;
     for (int i = 0; i < cfg.num_agents; i++) train = train || d.P.training_agent[i] != 0;

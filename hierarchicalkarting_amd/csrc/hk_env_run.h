@@ -83,7 +83,7 @@ template <bool HAS_MCTS, bool HAS_RW, bool HAS_TRAIN>
 #endif
 __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
                                                       hk_episode_result* results, GameSoA games, int* queue_cnt_all,
-                                                      int* queue_all, int set, const float* act_steer, const int* act_branch,
+                                                      int* queue_all, int round, const float* act_steer, const int* act_branch,
                                                       hk_lq_debug* dbg_out, int* status, int use_lds, MctsDev Marg, int mset, RwDev RD, const int* perm,
                                                       unsigned long long* stats)
 {
@@ -112,9 +112,11 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
     const int env = (perm && env_ok) ? perm[slot] : slot;     // lane groups are re-assigned by solve phase (env_regroup_*)
     // the game queues are double buffered over rounds: this launch fills `set`, and clears the other one, which the
     // previous round's lqn kernels have finished reading
+    const int set = round & 1;
     int* queue_cnt = queue_cnt_all + set * 16;
     int* queue = queue_all + (size_t)set * (GA - 1) * P.E * P.A;
-    if (gid < 16) queue_cnt_all[(set ^ 1) * 16 + gid] = 0;
+    // (with the solver on its own stream the other set is still being read: the host clears this launch's set before it instead)
+    if (!P.lq_defer && gid < 16) queue_cnt_all[(set ^ 1) * 16 + gid] = 0;
 #if HK_GA != 4 || defined(HK_OLD_LOOP)
     // (lane groups of 8: the loop as it was before the in-wave path existed — nothing to gain there, and with the wave-uniform
     // form below the 8-lane build decoded single-player controls with a wrong final_steer: unexplained, so not used)
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
     if (env_ok) es = envs[env];
     else { es.episode_steps = 0; es.inactive_mask = 0; es.experiment_num = 0; es.episodes_done = 0; es.status = 0; es.initial_started = 0; es.reserved[0] = 0; es.reserved[1] = 0; }
     int left = es.reserved[0];
-    int phase = es.reserved[1];
+    int phase = es.reserved[1] & 15;           // (bits 4..: the round in which the env queued its game, read by the deferred scheme)
     // nothing to do in this block? (every env finished its ticks): skip the table staging too
     if (__syncthreads_or(left > 0 || phase != 0) == 0) return;
     const TabView T = tab_stage(P, smem, use_lds != 0);
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
     }
     if (env_ok && dirty && i == 0) {
         es.reserved[0] = left;
-        es.reserved[1] = phase;
+        es.reserved[1] = phase ? (phase | (round << 4)) : 0;
         envs[env] = es;
     }
 }
@@ -206,7 +208,10 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
     for (bool first = true;; first = false) {
         if (!first && env_ok) es = envs[env];
         int left = es.reserved[0];
-        int phase = es.reserved[1];
+        int phase = es.reserved[1] & 15;
+        // Deferred scheme (P.lq_defer): the solver of round r runs beside the tick kernel of round r + 1, so an env that queued a game
+        // in round r sits out round r + 1 and resumes in r + 2, when its controls are there (bits 4.. of the word: the queueing round)
+        const bool not_yet = P.lq_defer && phase == 1 && (round - (es.reserved[1] >> 4)) < 2;
         bool dirty = false;
         Hot h;
         if (arec) h = load_hot(arec); else { Hot z = {}; h = z; }
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
         // The loop is wave-uniform: a lane group whose env has nothing (more) to run in this launch stays in it, idle.
         // phase 1 = the env waits for the solver KERNELS (it resumes in the next launch, i.e. in the first pass of a launch);
         // phase 2 = parked by this wave for its own solve (it resumes in the pass right after it)
-        const bool resume = first ? phase != 0 : phase == 2;
+        const bool resume = (first ? phase != 0 : phase == 2) && !not_yet;
         if (resume) phase = 1;
         // P.mcts_pause (long hk_step calls of planner handles): an env with a requested, not yet run search waits at the tick boundary —
         // the host launches the searches of a whole stretch of rounds in ONE batch (a launch lasts as long as one search however few it holds)
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
         }
         if (env_ok && dirty && i == 0) {
             es.reserved[0] = left;
-            es.reserved[1] = phase;
+            es.reserved[1] = phase ? (phase | (round << 4)) : 0;
             envs[env] = es;
         }
         if ((inw2 | inw3) == 0ull) break;
