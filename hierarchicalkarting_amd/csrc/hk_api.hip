@@ -486,11 +486,15 @@ static int step_ticks(hk_handle h, int n_ticks)
     // (finish_ticks): most of the worst-case rounds found nothing to do, and on a 20-tick call they were 5 launches of 8.
     // (short calls — a host stepping tick by tick — keep the fixed count too: a handful of rounds, no host sync)
     const bool lazy = !planner && h->n_policies == 0 && h->done_host != nullptr && n_ticks >= HK_LAZY_MIN_TICKS && !std::getenv("HK_FIXED_ROUNDS");
-    int rounds = lazy ? hk::env_rounds_min(h->cfg, n_ticks) : hk::env_rounds_for(h->cfg, n_ticks);
+    // ticks per launch: longer launches once the field has spread out (see RUN_CAP_SPREAD)
+    static const int spread_cap = [] { const char* e = std::getenv("HK_RUN_CAP_SPREAD"); const int v = e ? std::atoi(e) : hk::RUN_CAP_SPREAD; return v > 4 && v <= 64 ? v : hk::RUN_CAP_SPREAD; }();
+    const int run_cap = (lazy && h->cfg.num_agents > 2 && h->dev.ticks_since_reset >= hk::BULK_TICKS) ? spread_cap : hk::RUN_CAP;
+    h->dev.P.run_cap = run_cap;
+    int rounds = lazy ? hk::env_rounds_min(h->cfg, n_ticks, run_cap) : hk::env_rounds_for(h->cfg, n_ticks);
     if (const char* dr = std::getenv("HK_DEBUG_MAX_ROUNDS")) rounds = std::min(rounds, std::atoi(dr));     // (diagnostic: look at the state between two rounds)
     {
         // the rounds every env needs at RUN_CAP ticks a round, then — the laggards packed into the first lane groups — the tail
-        const int main_rounds = std::min(rounds, (n_ticks + hk::RUN_CAP - 1) / hk::RUN_CAP);
+        const int main_rounds = std::min(rounds, (n_ticks + run_cap - 1) / run_cap);
         // (measured: a loss — see issue_rounds_overlapped — so only on request)
         h->step_overlapped = lazy && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4 && !h->cfg.rewards && std::getenv("HK_LQ_OVERLAP") != nullptr;
         rc = h->step_overlapped ? issue_rounds_overlapped(h, main_rounds) : issue_rounds(h, main_rounds);

@@ -12,7 +12,16 @@
 namespace hk {
 
 constexpr int ENV_MAXA = HK_MAX_AGENTS; // capacity of the per-agent parameter arrays; the kernels are compiled per lane-group width GA (hk_env_ga.h)
-constexpr int RUN_CAP = 8;      // ticks per env per launch (> cadence).  Measured at E = 65 536, 4-agent Oval: 8 -> 533 M env-steps/s,
+#ifndef HK_RUN_CAP
+#define HK_RUN_CAP 8
+#endif
+constexpr int RUN_CAP = HK_RUN_CAP;
+// Once the field has spread out (few queued games per round) longer launches pay: fewer rounds, fewer solver launches (each one
+// solve's latency).  Measured with the lazily completed long calls of round 2: 8 -> 909 M env-steps/s, 12 -> 925 M, 16 -> 911 M in the
+// steady state, but 437 / 397 / 368 M over the first 512 ticks of a race — so 12 only after BULK_TICKS.  (Same box, same call: 8 -> 893 M,
+// 12 -> 906 M; 10 and 14 -> 750 M: the cap must be a multiple of the solve cadence, or the envs of a wave end their launches in different
+// solve phases and the wave runs the solve path on every tick.)
+constexpr int RUN_CAP_SPREAD = 12;      // ticks per env per launch (> cadence).  Measured at E = 65 536, 4-agent Oval: 8 -> 533 M env-steps/s,
                                 // 6 -> 456 M, 5 -> 408 M (misaligned with the 4-tick cadence), 16 -> 503 M, 32 -> 450 M, 128 -> 264 M: a quad that
                                 // queues a game idles its lanes until the launch ends, so long launches waste lanes
 constexpr float DEG2RAD_F = 0.0174532924f;
@@ -60,6 +69,7 @@ struct EnvParams {
     const SecGeo* sec_geo; // [L]
     int team_of[ENV_MAXA], time_precision[ENV_MAXA], section_window[ENV_MAXA];
     int mcts_iter, mcts_iter0, mcts_lat, mcts_lat0, any_mcts;
+    int run_cap;        // ticks an env may run per launch (RUN_CAP; RUN_CAP_SPREAD for long calls on a spread field, hk_api.hip step_ticks)
     int lq_defer;       // set per hk_step call: the solver kernels run on a second stream beside the NEXT round of the tick kernel, so an env that
                         // queued a game in round r resumes in round r + 2 (hk_api.hip issue_rounds_overlapped)
     int mcts_pause;     // set per hk_step call: an env that requested a planner search stops at the next tick boundary until the search has run (hk_api.hip step_ticks)

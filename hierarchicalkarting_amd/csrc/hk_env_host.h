@@ -61,7 +61,7 @@ struct EnvDevice {
 };
 
 constexpr int MCTS_MIN_LATENCY = 40;   // (MCTS_FLUSH_ROUNDS + 1) * RUN_CAP: see flush_mcts (hk_env_launch.h)
-constexpr int MCTS_FLUSH_ROUNDS = 4;
+constexpr int MCTS_FLUSH_ROUNDS = MCTS_MIN_LATENCY / RUN_CAP - 1;      // 4 at RUN_CAP 8
 constexpr int MCTS_ARENA_WAVES = 2048;
 constexpr int BULK_TICKS = 384;        // after a full reset the field needs about this long to spread out (launch_lqn)
 constexpr int REGROUP_ROUNDS = 48;     // the tick kernel's lane groups are re-assigned by solve phase every so many rounds (~200 ticks)

@@ -131,6 +131,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         if (cfg.team_of[i] + 1 > P.n_teams) P.n_teams = cfg.team_of[i] + 1;
     }
     P.hold_dedupe = (P.any_mcts == 0 && !P.training_reset && !std::getenv("HK_NO_HOLD_DEDUPE")) ? 1 : 0;
+    P.run_cap = RUN_CAP;
     P.mcts_iter = cfg.mcts_iterations; P.mcts_iter0 = cfg.mcts_initial_iterations; P.mcts_lat = cfg.mcts_latency_ticks;
     P.mcts_lat0 = cfg.mcts_initial_latency_ticks; P.mcts_seed = cfg.mcts_seed;
     P.jitter_seed = cfg.jitter_seed; P.jitter_pos = cfg.jitter_pos; P.jitter_yaw = cfg.jitter_yaw; P.env_id_base = cfg.env_id_base;
@@ -424,10 +425,10 @@ inline int env_rounds_for(const hk_config& cfg, int n_ticks)
 
 // Rounds a field needs for n ticks when nothing is queued (2-player games are solved inside the tick kernel, HK_INWAVE): every
 // env retires RUN_CAP ticks per round.
-inline int env_rounds_min(const hk_config& cfg, int n_ticks)
+inline int env_rounds_min(const hk_config& cfg, int n_ticks, int cfg_run_cap = RUN_CAP)
 {
     (void)cfg;
-    return (n_ticks + RUN_CAP - 1) / RUN_CAP;
+    return (n_ticks + cfg_run_cap - 1) / cfg_run_cap;
 }
 
 inline int env_launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)

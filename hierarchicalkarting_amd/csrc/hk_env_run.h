@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
     const TabView T = tab_stage(P, smem, use_lds != 0);
     const int cadence = P.A > 2 ? 4 : 1;
     const uint32_t all_mask = (1u << P.A) - 1u;
-    int budget = RUN_CAP;
+    int budget = P.run_cap;
     bool dirty = false;
     hk_agent_state* arec = (env_ok && i < P.A) ? &agents[(size_t)env * P.A + i] : nullptr;
     Hot h;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
     const TabView T = tab_stage(P, smem, use_lds != 0);
     const int cadence = P.A > 2 ? 4 : 1;
     const uint32_t all_mask = (1u << P.A) - 1u;
-    int budget = RUN_CAP;
+    int budget = P.run_cap;
     hk_agent_state* arec = (env_ok && i < P.A) ? &agents[(size_t)env * P.A + i] : nullptr;
     const LaneCfg LC = lane_cfg(P, i);                   // this lane's agent: modes and player list, read once
 #ifdef HK_STAMPS

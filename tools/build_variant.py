@@ -20,6 +20,17 @@ def main():
         unit = sys.argv[sys.argv.index("--unit") + 1]
     ge.build()
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if "--all" in head:                             # every unit with the flags (constants the host code shares with the kernels)
+        objs, procs = [], []
+        for u in ge.UNITS:
+            o = os.path.join(ge.OBJ_DIR, "%s_%s.o" % (name, u.replace(".hip", "")))
+            objs.append(o)
+            procs.append(subprocess.Popen([hipcc] + ge.HIPCC_FLAGS + defs + ["-c", os.path.join(ge.CSRC, u), "-o", o]))
+        assert all(p.wait() == 0 for p in procs)
+        lib = os.path.join(ROOT, "build", "libhk_%s.so" % name)
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib] + objs)
+        print(lib)
+        return
     obj = os.path.join(ge.OBJ_DIR, "%s_%s.o" % (name, unit.replace(".hip", "")))
     subprocess.check_call([hipcc] + ge.HIPCC_FLAGS + defs + ["-c", os.path.join(ge.CSRC, unit), "-o", obj])
     objs = [obj if u == unit else os.path.join(ge.OBJ_DIR, u.replace(".hip", ".o")) for u in ge.UNITS]
