@@ -227,6 +227,7 @@ struct MctsCtx {
     int bucket, precision, vmax, nact;
     uint32_t key0, key1, c1, c2, draw;
     const short* dt_tab; const float* load_tab; const float* rad_tab; int nv;      // the move tables (the search kernel's copy in LDS)
+    const unsigned char* sec_flags;         // per section (mod L): bit 0 straight, bits 1.. optimal lane (LDS; nullptr: read the track table)
 };
 
 __device__ __forceinline__ void mc_draw(MctsCtx& C, uint32_t r[4]) { philox4x32(C.draw++, C.c1, C.c2, 0x4D435453u, C.key0, C.key1, r); }
@@ -297,7 +298,11 @@ __device__ __forceinline__ float mc_max_speed(const MctsCtx& C, float radius, fl
     if (__builtin_isinf(v) || __builtin_isnan(v)) v = st.TopSpeed;
     return v < 0.0001f ? 0.0001f : (v > st.TopSpeed ? st.TopSpeed : v);
 }
-__device__ __forceinline__ bool mc_straight(const MctsCtx& C, int section) { return C.T->sec[section % C.P->L].inside_radius == 0.0f; }
+__device__ __forceinline__ bool mc_straight(const MctsCtx& C, int section)
+{   // (asked several times per move: from the kernel's LDS copy, not the track table in global memory)
+    if (C.sec_flags) return (C.sec_flags[section % C.P->L] & 1) != 0;
+    return C.T->sec[section % C.P->L].inside_radius == 0.0f;
+}
 __device__ inline float mc_avgv(int minv, int maxv) { return (1.0f * (float)(minv + maxv)) / 2.0f; }
 
 __device__ inline float mc_toc(const MctsCtx& C, float distance, float radius, float wear, float initV, float finalV)
@@ -572,6 +577,7 @@ __device__ inline void mc_ctx_init(MctsCtx& C, const EnvParams& P, const TabView
     C.nact = 0;
     for (int i = 6; i < C.vmax; i += C.bucket) C.nact += 4;
     if (C.nact > MC_MAXA) C.nact = MC_MAXA;
+    C.sec_flags = nullptr;
     C.dt_tab = nullptr; C.load_tab = M.load_tab; C.rad_tab = M.rad_tab; C.nv = M.nv;       // (the search kernel points these at its LDS copies)
     C.key0 = 0; C.key1 = 0; C.c1 = 0; C.c2 = 0; C.draw = 0;
 }
@@ -657,7 +663,7 @@ __device__ __forceinline__ DGame mc_root_load(const int* rootl, const int stride
 }
 
 // one queued search (queue entry q of `set`), its tree in the arena slice `nd`
-struct MctsTabs { const short* dt; const float* load; const float* rad; };
+struct MctsTabs { const short* dt; const float* load; const float* rad; const unsigned char* flags; };
 __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDev& M, const TabView& T, const MctsTabs& tabs, const int set, const int q, const int lane0,
                                                 unsigned short* path /* LDS, [MC_MAXPATH][64], this lane's column */, unsigned char* pup)
 {
@@ -673,7 +679,7 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
 
     MctsCtx C;
     mc_ctx_init(C, P, T, M, ego);
-    C.dt_tab = tabs.dt; C.load_tab = tabs.load; C.rad_tab = tabs.rad;
+    C.dt_tab = tabs.dt; C.load_tab = tabs.load; C.rad_tab = tabs.rad; C.sec_flags = tabs.flags;
     C.key0 = P.mcts_seed; C.key1 = (uint32_t)(P.env_id_base + env) * (uint32_t)P.A + (uint32_t)ego;
     C.c1 = (uint32_t)R.ph_step[0]; C.c2 = (uint32_t)R.epoch; C.draw = 0;
 
@@ -764,7 +770,7 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
         int first_new = MC_MAXPATH;                    // depth of the first node created in this iteration
         while (true) {
             if (mc_is_over(C, g, np, mv.n, scores)) break;
-            const int ol = T.sec[g.last % P.L].optimal_lane;
+            const int ol = C.sec_flags[g.last % P.L] >> 1;
             const int sign = ol == 1 ? 1 : (ol == 4 ? -1 : 0);
             int index;
             if (mv.n > 2) index = (int)__builtin_rintf(f_abs(mc_gauss_bounded(C, 0.0f, (float)mv.n / 6.0f, -(float)mv.n + 1.0f, (float)mv.n - 1.0f)));
@@ -858,7 +864,7 @@ __device__ __forceinline__ bool mcts_search_outstanding(const EnvParams& P, cons
 // iterations 93 -> 59 ms before the tables moved.
 #define HK_MC_BOUNDS __launch_bounds__(512)
 constexpr int MC_PATH_BYTES = MC_MAXPATH * 64 * 3;          // per wave: node indices (16 bit) + up-next players (8 bit) of one root-to-leaf path
-inline size_t mcts_table_lds_bytes(int ntab, int L) { return (((size_t)ntab * sizeof(short) + 15) & ~(size_t)15) + (size_t)L * 4 * MC_MAXA * sizeof(float) + (size_t)L * 4 * 4 * sizeof(float); }
+inline size_t mcts_table_lds_bytes(int ntab, int L) { return (((size_t)ntab * sizeof(short) + 15) & ~(size_t)15) + (size_t)L * 4 * MC_MAXA * sizeof(float) + (size_t)L * 4 * 4 * sizeof(float) + HK_MAX_SECTIONS; }
 inline size_t mcts_search_lds_bytes(int ntab, int L, int waves) { return mcts_table_lds_bytes(ntab, L) + (size_t)waves * MC_PATH_BYTES; }
 __global__ HK_MC_BOUNDS void mcts_search_kernel(EnvParams P, MctsDev M, int set, int ntab)
 {
@@ -868,10 +874,15 @@ __global__ HK_MC_BOUNDS void mcts_search_kernel(EnvParams P, MctsDev M, int set,
     short* dt_s = reinterpret_cast<short*>(mc_smem);
     float* load_s = reinterpret_cast<float*>(mc_smem + (((size_t)ntab * sizeof(short) + 15) & ~(size_t)15));
     float* rad_s = load_s + P.L * 4 * MC_MAXA;
-    unsigned char* paths = reinterpret_cast<unsigned char*>(rad_s + P.L * 4 * 4);
+    unsigned char* flags_s = reinterpret_cast<unsigned char*>(rad_s + P.L * 4 * 4);          // [HK_MAX_SECTIONS]
+    unsigned char* paths = flags_s + HK_MAX_SECTIONS;
     for (int k = threadIdx.x; k < ntab; k += blockDim.x) { const int v = M.dt_tab[k]; dt_s[k] = (short)(v < 0 ? -1 : v); }     // < 0: infeasible (only the sign is read)
     for (int k = threadIdx.x; k < P.L * 4 * MC_MAXA; k += blockDim.x) load_s[k] = M.load_tab[k];
     for (int k = threadIdx.x; k < P.L * 4 * 4; k += blockDim.x) rad_s[k] = M.rad_tab[k];
+    {
+        const TabView Tg = tab_view(P, P.tab);
+        for (int k = threadIdx.x; k < P.L; k += blockDim.x) flags_s[k] = (unsigned char)((Tg.sec[k].inside_radius == 0.0f ? 1 : 0) | (Tg.sec[k].optimal_lane << 1));
+    }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = blockDim.x >> 6;
     const int lane0 = (blockIdx.x * waves + wave) * 64 + lane;
@@ -879,7 +890,7 @@ __global__ HK_MC_BOUNDS void mcts_search_kernel(EnvParams P, MctsDev M, int set,
     const TabView T = tab_view(P, P.tab);
     unsigned short* path = reinterpret_cast<unsigned short*>(paths + (size_t)wave * MC_PATH_BYTES);       // [MC_MAXPATH][64]: node indices fit 16 bits
     unsigned char* pup = reinterpret_cast<unsigned char*>(path + MC_MAXPATH * 64);                         //   (hk_create refuses pools beyond 65 535 nodes)
-    MctsTabs tabs = {dt_s, load_s, rad_s};
+    MctsTabs tabs = {dt_s, load_s, rad_s, flags_s};
     for (int q = lane0; q < count; q += gridDim.x * waves * 64) mcts_search_one(P, M, T, tabs, set, q, lane0, path + lane, pup + lane);
 }
 
