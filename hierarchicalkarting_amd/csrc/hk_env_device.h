@@ -109,6 +109,8 @@ struct MctsDev {
     int* dt_tab;            // [L][4 lanes][nv + 1 buckets][20 actions]: time added (x timePrecision); < 0 = infeasible
     float* load_tab;        // [L][4][20]: tireLoad of the move
     float* rad_tab;         // [L][4][4]: radiusOfLane(section, from, to)
+    uint32_t* mask_tab;     // [rows = L * 4 * (nv + 1)]: bit a: action a exists and is feasible from this row (dt >= 0)
+    unsigned char* order_tab;   // [rows][20]: the canonical actions in the rollout's order for this row (hk_env_mcts.h mcts_order_kernel)
     int nv;                 // velocity buckets of the action list (<= 5)
     int ntab;               // entries of dt_tab
     int lds_attr_set;       // host: the search kernel's dynamic-LDS limit has been raised on this device

@@ -50,7 +50,7 @@ int upload(T** dst, const std::vector<T>& v, std::string& err)
 inline void env_destroy(EnvDevice& d)
 {
     void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.reward_out, d.status, d.game_stats, d.games, d.queue_cnt, d.queue, d.env_ids, d.tab, d.perms,
-                    d.rw.sec_time, d.rw.sec_cnt, d.rw.hit_code, d.mcts.st, d.mcts.req, d.mcts.qcnt, d.mcts.queue, d.mcts.nodes, d.mcts.dt_tab, d.mcts.load_tab, d.mcts.rad_tab, d.mcts.roots, d.sec_geo, d.perm, d.perm_counts};
+                    d.rw.sec_time, d.rw.sec_cnt, d.rw.hit_code, d.mcts.st, d.mcts.req, d.mcts.qcnt, d.mcts.queue, d.mcts.nodes, d.mcts.dt_tab, d.mcts.load_tab, d.mcts.rad_tab, d.mcts.mask_tab, d.mcts.order_tab, d.mcts.roots, d.sec_geo, d.perm, d.perm_counts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d = EnvDevice{};
 }
@@ -341,6 +341,8 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         HK_ALLOC(d.mcts.dt_tab, (size_t)ntab * sizeof(int));
         HK_ALLOC(d.mcts.load_tab, (size_t)L * 4 * HK_MCTS_MAX_ACTIONS * sizeof(float));
         HK_ALLOC(d.mcts.rad_tab, (size_t)L * 4 * 4 * sizeof(float));
+        HK_ALLOC(d.mcts.mask_tab, (size_t)(ntab / HK_MCTS_MAX_ACTIONS) * sizeof(uint32_t));
+        HK_ALLOC(d.mcts.order_tab, (size_t)ntab);
         d.mcts.ntab = ntab;
         if ((rc = HK_GA_CALL(d, launch_mcts_table(d, ego0, ntab, stream, err)))) return rc;
         {   // the search kernel keeps the tables in LDS, dt as int16, 8 waves a workgroup: check the range and the fit
@@ -348,7 +350,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
             if ((e = hipMemcpyAsync(hdt.data(), d.mcts.dt_tab, (size_t)ntab * sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess ||
                 (e = hipStreamSynchronize(stream)) != hipSuccess) { err = std::string("hk_create: move tables: ") + hipGetErrorString(e); return HK_ERR_HIP; }
             for (int v : hdt) if (v > 32767) { err = "hk_create: a move of the discrete game takes more than 32 767 time units (timePrecision too fine for the planner's tables)"; return HK_ERR_UNSUPPORTED; }
-            if (HK_GA_CALL(d, mcts_lds_bytes(ntab, L, 8)) > 160 * 1024) { err = "hk_create: the planner's move tables do not fit the LDS (track too long)"; return HK_ERR_UNSUPPORTED; }
+            if (HK_GA_CALL(d, mcts_lds_bytes(ntab, L, 4)) > 160 * 1024) { err = "hk_create: the planner's move tables do not fit the LDS (track too long)"; return HK_ERR_UNSUPPORTED; }
         }
     }
 #undef HK_ALLOC

@@ -14,7 +14,11 @@ inline size_t queue_ints_per_set(size_t na) { return (size_t)(GA - 1) * na; }   
 inline int launch_mcts_table(EnvDevice& d, int ego0, int ntab, hipStream_t stream, std::string& err)
 {
     hipLaunchKernelGGL(mcts_table_kernel, dim3((ntab + 255) / 256), dim3(256), 0, stream, d.P, d.mcts, ego0);
-    return launch_check(err, "mcts_table_kernel");
+    int rc = launch_check(err, "mcts_table_kernel");
+    if (rc) return rc;
+    const int rows = ntab / HK_MCTS_MAX_ACTIONS;
+    hipLaunchKernelGGL(mcts_order_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, d.P, d.mcts, ego0, rows);
+    return launch_check(err, "mcts_order_kernel");
 }
 
 inline int launch_mcts_invalidate(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
@@ -36,7 +40,8 @@ inline int flush_mcts(EnvDevice& d, hipStream_t stream, std::string& err)
     {
         // one workgroup per CU, 4 waves (one per SIMD) while the grid is at most 1 024 waves, 8 beyond; the move tables ride in its LDS
         const int total_waves = (d.mcts.grid_lanes + 63) / 64;
-        const int waves = total_waves <= 1024 ? 4 : 8;
+        int waves = total_waves <= 1024 ? 4 : 8;
+        while (waves > 4 && mcts_search_lds_bytes(d.mcts.ntab, d.P.L, waves) > 160 * 1024) waves -= 2;      // (8 karts: the path arrays of 8 waves do not fit beside the tables)
         const size_t lds = mcts_search_lds_bytes(d.mcts.ntab, d.P.L, waves);
         if (!d.mcts.lds_attr_set) {
             (void)hipFuncSetAttribute((const void*)mcts_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

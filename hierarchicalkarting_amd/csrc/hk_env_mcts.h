@@ -219,7 +219,7 @@ template <int I> __device__ __forceinline__ int mc_t(const DGame& g)
 struct MoveEval {
     int n;
     uint32_t legal;
-    int dt[MC_MAXA];
+    int row;                    // table row of the position: (section % L, lane, velocity bucket) of the player who is up next
 };
 struct MctsCtx {
     const EnvParams* P;
@@ -227,6 +227,7 @@ struct MctsCtx {
     int bucket, precision, vmax, nact;
     uint32_t key0, key1, c1, c2, draw;
     const short* dt_tab; const float* load_tab; const float* rad_tab; int nv;      // the move tables (the search kernel's copy in LDS)
+    const uint32_t* mask_tab; const unsigned char* order_tab;      // per table row: feasible actions (dt >= 0), the 20 actions in rollout order
     const unsigned char* sec_flags;         // per section (mod L): bit 0 straight, bits 1.. optimal lane (LDS; nullptr: read the track table)
 };
 
@@ -421,7 +422,10 @@ __device__ __forceinline__ int mc_up_next(const DGame& g)
 
 __device__ __forceinline__ int mc_vb(const MctsCtx& C, int minv) { return minv == 0 ? 0 : 1 + (minv - 6) / C.bucket; }
 
-// nextMoves KDG:318-411 for the player who is up next (np), with the time each legal move adds (from the move tables)
+// nextMoves KDG:318-411 for the player who is up next (np): a bit per canonical action.  An action is legal when (i) it exists and is
+// feasible from this row of the move tables (dt >= 0: a precomputed 20-bit mask per row), (ii) on a straight the lane change it needs
+// fits the budget (KDG:355-361: a mask over the target lanes, the same for every velocity bucket), (iii) its min_velocity does not
+// exceed the lateral-g speed limit of its target lane at the kart's tire age (KDG:362-370: per lane the buckets below the limit).
 __device__ __forceinline__ void mc_eval_moves(const MctsCtx& C, const DGame& g, int np, MoveEval& mv)
 {
     const DKart cur = mc_get(g, np);
@@ -429,20 +433,23 @@ __device__ __forceinline__ void mc_eval_moves(const MctsCtx& C, const DGame& g, 
     const bool str = mc_straight(C, cur.section);
     const float wear = (float)cur.tire / 10000.0f;
     const float* rp = C.rad_tab + (sm * 4 + (cur.lane - 1)) * 4;
-    const float v0 = mc_max_speed(C, rp[0], wear), v1 = mc_max_speed(C, rp[1], wear);      // lateral-g speed limit per target lane
-    const float v2 = mc_max_speed(C, rp[2], wear), v3 = mc_max_speed(C, rp[3], wear);
-    const short* dtp = C.dt_tab + ((sm * 4 + (cur.lane - 1)) * (C.nv + 1) + mc_vb(C, cur.minv)) * MC_MAXA;
-    mv.n = 0; mv.legal = 0;
+    float vl[4];
 #pragma unroll
-    for (int a = 0; a < MC_MAXA; a++) {
-        const int lane = (a & 3) + 1, minv = 6 + (a >> 2) * C.bucket;
-        const int dl = lane > cur.lane ? lane - cur.lane : cur.lane - lane;
-        const float vl = (a & 3) == 0 ? v0 : ((a & 3) == 1 ? v1 : ((a & 3) == 2 ? v2 : v3));
-        const int dt = a < C.nact ? dtp[a] : -1;
-        const bool ok = a < C.nact && !(str && cur.lchg + dl > C.P->max_lane_changes) && !(vl < (float)minv) && dt >= 0;
-        mv.dt[a] = dt;
-        if (ok) { mv.legal |= 1u << a; mv.n++; }
+    for (int l = 0; l < 4; l++) vl[l] = mc_max_speed(C, rp[l], wear);                       // lateral-g speed limit per target lane
+    const int row = (sm * 4 + (cur.lane - 1)) * (C.nv + 1) + mc_vb(C, cur.minv);
+    uint32_t m = C.mask_tab[row];
+    uint32_t lanes = 0;                                                                     // bit l: target lane l + 1 passes (ii) and bucket 0 .. of (iii)
+    uint32_t speed = 0;                                                                     // bit 4 vi + l: bucket vi of lane l + 1 passes (iii)
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        const int dl = (l + 1) > cur.lane ? (l + 1) - cur.lane : cur.lane - (l + 1);
+        if (!(str && cur.lchg + dl > C.P->max_lane_changes)) lanes |= 1u << l;
+#pragma unroll
+        for (int vi = 0; vi < MC_MAXA / 4; vi++)
+            if (!(vl[l] < (float)(6 + vi * C.bucket))) speed |= 1u << (4 * vi + l);
     }
+    m &= (lanes * 0x11111u) & speed;
+    mv.legal = m; mv.n = __builtin_popcount(m); mv.row = row;
 }
 
 // makeMove KDG:416-443 on the running state (applyAction through the move tables)
@@ -471,32 +478,24 @@ __device__ __forceinline__ void mc_make_move(const MctsCtx& C, DGame& g, int np,
 }
 
 // The move the rollout picks (KM:255-270): the index-th of the legal moves ordered by
-// OrderBy(time added).ThenByDescending(max_velocity).ThenBy(|lane change|).ThenBy(sign * lane), a stable sort.  The four keys
-// pack into one integer; the index-th element is the one with exactly `index` legal moves before it (ties by canonical
-// order) — all in registers.
-__device__ __forceinline__ int mc_pick_move(const MctsCtx& C, const MoveEval& mv, int cur_lane, int sign, int index)
+// OrderBy(time added).ThenByDescending(max_velocity).ThenBy(|lane change|).ThenBy(sign * lane), a stable sort.  Every key is a
+// function of the table row — the time added and the lane change by definition, and sign comes from the optimal lane of section
+// `last`, which IS the section of the player who is up next — so the order of all 20 actions is precomputed per row
+// (mcts_order_kernel) and the pick walks it, counting the legal ones.
+__device__ __forceinline__ int mc_pick_move(const MctsCtx& C, const MoveEval& mv, int index)
 {
-    uint32_t key[MC_MAXA];
+    const uint32_t* ord = reinterpret_cast<const uint32_t*>(C.order_tab + (size_t)mv.row * MC_MAXA);      // 20 bytes = 5 words (rows are 4-byte aligned)
+    int move = 0, seen = 0;
 #pragma unroll
-    for (int a = 0; a < MC_MAXA; a++) {
-        const int lane = (a & 3) + 1, minv = 6 + (a >> 2) * C.bucket;
-        const int maxv = (minv + C.bucket) < C.vmax ? (minv + C.bucket) : C.vmax;
-        const int dl = lane > cur_lane ? lane - cur_lane : cur_lane - lane;
-        key[a] = ((uint32_t)mv.dt[a] << 12) | ((uint32_t)(C.vmax - maxv) << 6) | ((uint32_t)dl << 4) | (uint32_t)(sign * lane + 4);
-    }
-    // selection by repeated minimum: the draw is |gaussian| with sd n / 6, so `index` is almost always 0..3
-    uint32_t left = mv.legal;
-    int move = 0;
-    for (int r = 0; r <= index; r++) {
-        uint32_t best = 0xFFFFFFFFu;
-        move = 0;
+    for (int w = 0; w < MC_MAXA / 4; w++) {
+        const uint32_t four = ord[w];
 #pragma unroll
-        for (int a = 0; a < MC_MAXA; a++) {
-            const bool take = ((left >> a) & 1u) && key[a] < best;          // strict <: the lowest action wins ties (stable order)
-            best = take ? key[a] : best;
-            move = take ? a : move;
+        for (int b = 0; b < 4; b++) {
+            const int a = (int)((four >> (8 * b)) & 0xFFu);
+            const bool ok = (mv.legal >> a) & 1u;
+            move = (ok && seen == index) ? a : move;
+            seen += ok ? 1 : 0;
         }
-        left &= ~(1u << move);
     }
     return move;
 }
@@ -577,7 +576,7 @@ __device__ inline void mc_ctx_init(MctsCtx& C, const EnvParams& P, const TabView
     C.nact = 0;
     for (int i = 6; i < C.vmax; i += C.bucket) C.nact += 4;
     if (C.nact > MC_MAXA) C.nact = MC_MAXA;
-    C.sec_flags = nullptr;
+    C.sec_flags = nullptr; C.mask_tab = nullptr; C.order_tab = nullptr;
     C.dt_tab = nullptr; C.load_tab = M.load_tab; C.rad_tab = M.rad_tab; C.nv = M.nv;       // (the search kernel points these at its LDS copies)
     C.key0 = 0; C.key1 = 0; C.c1 = 0; C.c2 = 0; C.draw = 0;
 }
@@ -615,6 +614,41 @@ __global__ __launch_bounds__(256) void mcts_table_kernel(EnvParams P, MctsDev M,
     M.dt_tab[t] = dt;
     if (vb == 0) M.load_tab[(sec * 4 + l0) * MC_MAXA + a] = load;
     if (vb == 0 && a < 4) M.rad_tab[(sec * 4 + l0) * 4 + a] = mc_radius(C, sec, l0 + 1, a + 1);
+}
+
+// per table row: which actions are feasible, and the 20 actions in the order the rollout ranks them (see mc_pick_move).  The keys are
+// those of KM:255-270 for a kart in this row — time added, max_velocity descending, |lane change|, sign * lane — ties by the
+// canonical action index (a stable sort); infeasible actions (dt < 0) sort last and are never legal.
+__global__ __launch_bounds__(256) void mcts_order_kernel(EnvParams P, MctsDev M, int ego, int rows)
+{
+    const TabView T = tab_view(P, P.tab);
+    MctsCtx C;
+    mc_ctx_init(C, P, T, M, ego);
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const int nb = M.nv + 1;
+    const int cur_lane = (row / nb) % 4 + 1, sm = row / (nb * 4);
+    const int ol = T.sec[sm].optimal_lane;
+    const int sign = ol == 1 ? 1 : (ol == 4 ? -1 : 0);                       // DPT:221-231
+    uint32_t key[MC_MAXA], mask = 0;
+    for (int a = 0; a < MC_MAXA; a++) {
+        const int dt = M.dt_tab[(size_t)row * MC_MAXA + a];
+        const int lane = (a & 3) + 1, minv = 6 + (a >> 2) * C.bucket;
+        const int maxv = (minv + C.bucket) < C.vmax ? (minv + C.bucket) : C.vmax;
+        const int dl = lane > cur_lane ? lane - cur_lane : cur_lane - lane;
+        key[a] = ((uint32_t)dt << 12) | ((uint32_t)(C.vmax - maxv) << 6) | ((uint32_t)dl << 4) | (uint32_t)(sign * lane + 4);
+        if (dt >= 0) mask |= 1u << a;
+    }
+    uint32_t left = (1u << MC_MAXA) - 1u;
+    for (int r = 0; r < MC_MAXA; r++) {                                      // selection by repeated minimum, the lowest action wins ties
+        uint32_t best = 0xFFFFFFFFu;
+        int move = -1;
+        for (int a = 0; a < MC_MAXA; a++)
+            if (((left >> a) & 1u) && (move < 0 || key[a] < best)) { best = key[a]; move = a; }
+        left &= ~(1u << move);
+        M.order_tab[(size_t)row * MC_MAXA + r] = (unsigned char)move;
+    }
+    M.mask_tab[row] = mask;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -663,7 +697,7 @@ __device__ __forceinline__ DGame mc_root_load(const int* rootl, const int stride
 }
 
 // one queued search (queue entry q of `set`), its tree in the arena slice `nd`
-struct MctsTabs { const short* dt; const float* load; const float* rad; const unsigned char* flags; };
+struct MctsTabs { const short* dt; const float* load; const float* rad; const unsigned char* flags; const uint32_t* mask; const unsigned char* order; };
 __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDev& M, const TabView& T, const MctsTabs& tabs, const int set, const int q, const int lane0,
                                                 unsigned short* path /* LDS, [MC_MAXPATH][64], this lane's column */, unsigned char* pup)
 {
@@ -679,7 +713,7 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
 
     MctsCtx C;
     mc_ctx_init(C, P, T, M, ego);
-    C.dt_tab = tabs.dt; C.load_tab = tabs.load; C.rad_tab = tabs.rad; C.sec_flags = tabs.flags;
+    C.dt_tab = tabs.dt; C.load_tab = tabs.load; C.rad_tab = tabs.rad; C.sec_flags = tabs.flags; C.mask_tab = tabs.mask; C.order_tab = tabs.order;
     C.key0 = P.mcts_seed; C.key1 = (uint32_t)(P.env_id_base + env) * (uint32_t)P.A + (uint32_t)ego;
     C.c1 = (uint32_t)R.ph_step[0]; C.c2 = (uint32_t)R.epoch; C.draw = 0;
 
@@ -770,12 +804,10 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
         int first_new = MC_MAXPATH;                    // depth of the first node created in this iteration
         while (true) {
             if (mc_is_over(C, g, np, mv.n, scores)) break;
-            const int ol = C.sec_flags[g.last % P.L] >> 1;
-            const int sign = ol == 1 ? 1 : (ol == 4 ? -1 : 0);
             int index;
             if (mv.n > 2) index = (int)__builtin_rintf(f_abs(mc_gauss_bounded(C, 0.0f, (float)mv.n / 6.0f, -(float)mv.n + 1.0f, (float)mv.n - 1.0f)));
             else index = mc_rand_next(C, mv.n);
-            const int move = mc_pick_move(C, mv, mc_get(g, np).lane, sign, index);
+            const int move = mc_pick_move(C, mv, index);
             int c = -1;
             MNode nxt;
             if (cur.n_children > 0) {
@@ -864,7 +896,11 @@ __device__ __forceinline__ bool mcts_search_outstanding(const EnvParams& P, cons
 // iterations 93 -> 59 ms before the tables moved.
 #define HK_MC_BOUNDS __launch_bounds__(512)
 constexpr int MC_PATH_BYTES = MC_MAXPATH * 64 * 3;          // per wave: node indices (16 bit) + up-next players (8 bit) of one root-to-leaf path
-inline size_t mcts_table_lds_bytes(int ntab, int L) { return (((size_t)ntab * sizeof(short) + 15) & ~(size_t)15) + (size_t)L * 4 * MC_MAXA * sizeof(float) + (size_t)L * 4 * 4 * sizeof(float) + HK_MAX_SECTIONS; }
+inline size_t mcts_table_lds_bytes(int ntab, int L)
+{   // dt (int16) | load | rad | section flags | row masks | row orders
+    return (((size_t)ntab * sizeof(short) + 15) & ~(size_t)15) + (size_t)L * 4 * MC_MAXA * sizeof(float) + (size_t)L * 4 * 4 * sizeof(float) + HK_MAX_SECTIONS +
+           (size_t)(ntab / MC_MAXA) * sizeof(uint32_t) + (((size_t)ntab + 15) & ~(size_t)15);
+}
 inline size_t mcts_search_lds_bytes(int ntab, int L, int waves) { return mcts_table_lds_bytes(ntab, L) + (size_t)waves * MC_PATH_BYTES; }
 __global__ HK_MC_BOUNDS void mcts_search_kernel(EnvParams P, MctsDev M, int set, int ntab)
 {
@@ -875,10 +911,15 @@ __global__ HK_MC_BOUNDS void mcts_search_kernel(EnvParams P, MctsDev M, int set,
     float* load_s = reinterpret_cast<float*>(mc_smem + (((size_t)ntab * sizeof(short) + 15) & ~(size_t)15));
     float* rad_s = load_s + P.L * 4 * MC_MAXA;
     unsigned char* flags_s = reinterpret_cast<unsigned char*>(rad_s + P.L * 4 * 4);          // [HK_MAX_SECTIONS]
-    unsigned char* paths = flags_s + HK_MAX_SECTIONS;
+    const int rows = ntab / MC_MAXA;
+    uint32_t* mask_s = reinterpret_cast<uint32_t*>(flags_s + HK_MAX_SECTIONS);                // [rows]
+    unsigned char* order_s = reinterpret_cast<unsigned char*>(mask_s + rows);                 // [rows][20] = ntab bytes
+    unsigned char* paths = order_s + (((size_t)ntab + 15) & ~(size_t)15);
     for (int k = threadIdx.x; k < ntab; k += blockDim.x) { const int v = M.dt_tab[k]; dt_s[k] = (short)(v < 0 ? -1 : v); }     // < 0: infeasible (only the sign is read)
     for (int k = threadIdx.x; k < P.L * 4 * MC_MAXA; k += blockDim.x) load_s[k] = M.load_tab[k];
     for (int k = threadIdx.x; k < P.L * 4 * 4; k += blockDim.x) rad_s[k] = M.rad_tab[k];
+    for (int k = threadIdx.x; k < rows; k += blockDim.x) mask_s[k] = M.mask_tab[k];
+    for (int k = threadIdx.x; k < ntab / 4; k += blockDim.x) reinterpret_cast<uint32_t*>(order_s)[k] = reinterpret_cast<const uint32_t*>(M.order_tab)[k];
     {
         const TabView Tg = tab_view(P, P.tab);
         for (int k = threadIdx.x; k < P.L; k += blockDim.x) flags_s[k] = (unsigned char)((Tg.sec[k].inside_radius == 0.0f ? 1 : 0) | (Tg.sec[k].optimal_lane << 1));
@@ -890,7 +931,7 @@ __global__ HK_MC_BOUNDS void mcts_search_kernel(EnvParams P, MctsDev M, int set,
     const TabView T = tab_view(P, P.tab);
     unsigned short* path = reinterpret_cast<unsigned short*>(paths + (size_t)wave * MC_PATH_BYTES);       // [MC_MAXPATH][64]: node indices fit 16 bits
     unsigned char* pup = reinterpret_cast<unsigned char*>(path + MC_MAXPATH * 64);                         //   (hk_create refuses pools beyond 65 535 nodes)
-    MctsTabs tabs = {dt_s, load_s, rad_s, flags_s};
+    MctsTabs tabs = {dt_s, load_s, rad_s, flags_s, mask_s, order_s};
     for (int q = lane0; q < count; q += gridDim.x * waves * 64) mcts_search_one(P, M, T, tabs, set, q, lane0, path + lane, pup + lane);
 }
 
