@@ -460,10 +460,13 @@ static int step_ticks(hk_handle h, int n_ticks)
         const int cadence = h->cfg.num_agents > 2 ? 4 : 1;
         int maxleft = n_ticks;
         for (int guard = 0; guard < 4096; guard++) {
-            // a stretch: enough rounds for an env that advances RUN_CAP ticks a round to reach its next replan (<= 100 ticks away);
-            // the slow ones (a solve cadence per round) get there in a later stretch
+            // a stretch: enough rounds for EVERY env to reach its next replan (<= 100 ticks away) or the end of the call, also one
+            // that meets a multi-player game on every solve tick (a solve cadence per round).  The rounds in which most envs already
+            // wait cost tens of microseconds; a second search launch for the late ones would cost a full search latency
+            // (HK_MCTS_STRETCH=short: the earlier rule, RUN_CAP ticks a round: 3 launches per 100 ticks instead of ~1)
             const int reach = std::min(maxleft, 100);
-            rc = issue_rounds(h, std::max(2, (reach + hk::RUN_CAP - 1) / hk::RUN_CAP + 2));
+            static const bool short_stretch = [] { const char* e = std::getenv("HK_MCTS_STRETCH"); return e && e[0] == 's'; }();
+            rc = issue_rounds(h, short_stretch ? std::max(2, (reach + hk::RUN_CAP - 1) / hk::RUN_CAP + 2) : (reach + cadence - 1) / cadence + 2);
             if (rc) return rc;
             rc = hk::env_flush_mcts(h->dev, h->stream, h->err);
             if (rc) { g_last_error = h->err; return rc; }
@@ -472,7 +475,6 @@ static int step_ticks(hk_handle h, int n_ticks)
             HK_HIP(h, hipStreamSynchronize(h->stream));
             maxleft = h->done_host[0];
             if (maxleft <= 0 && !h->done_host[1]) break;
-            (void)cadence;
         }
         h->dev.mcts_defer = false;
         h->dev.P.mcts_pause = 0;
