@@ -65,7 +65,7 @@ constexpr int MCTS_FLUSH_ROUNDS = MCTS_MIN_LATENCY / RUN_CAP - 1;      // 4 at R
 constexpr int MCTS_ARENA_WAVES = 2048;
 constexpr int BULK_TICKS = 384;        // after a full reset the field needs about this long to spread out (launch_lqn)
 constexpr int REGROUP_ROUNDS = 48;     // the tick kernel's lane groups are re-assigned by solve phase every so many rounds (~200 ticks)
-constexpr int MCTS_DEFER_TICKS = 32;   // short hk_step calls share one search launch until this many ticks have been armed
+constexpr int MCTS_DEFER_TICKS = 38;   // short hk_step calls share one search launch until this many ticks have been armed
 static_assert(MCTS_DEFER_TICKS < MCTS_MIN_LATENCY, "a deferred search must still finish before its plan is due");
 static_assert((MCTS_FLUSH_ROUNDS + 1) * RUN_CAP <= MCTS_MIN_LATENCY, "a queued search must finish before its plan is due");
 

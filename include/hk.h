@@ -281,7 +281,7 @@ int hk_set_actions(hk_handle h, const float* steer, const int32_t* branch);
  * next hk_step / hk_reset, which also let the unfinished envs continue.  A zero pivot in an LQ solve is sticky in the same
  * way (status bit 0) but does not fail the getters: the reference throws nothing there either (MathNet returns inf / NaN),
  * and hk_env_state.status bit 0 flags the karts whose state went non-finite.
- * Planner handles (any HighMode MCTS agent): a call of more than 32 ticks without attached actors synchronises with the host
+ * Planner handles (any HighMode MCTS agent): a call of more than 38 ticks without attached actors synchronises with the host
  * between stretches of ~100 ticks — envs wait at the tick boundary after a search request so that the searches of a stretch run
  * as ONE batch (results do not depend on it; environment variable HK_MCTS_NO_PAUSE=1 restores the fully asynchronous schedule).
  * Where the planner's trees live is decided at hk_create: one arena slice per agent if that fits HK_MCTS_PERSIST_GB (environment,
