@@ -437,8 +437,11 @@ static int step_ticks(hk_handle h, int n_ticks)
     // ticks have been armed since the last one — early enough, because a plan is due > MCTS_MIN_LATENCY ticks after its
     // request.  (hk_get_mcts_state launches what is pending before it reads.)
     const bool planner = h->dev.mcts.st != nullptr;
-    const bool short_call = planner && n_ticks <= hk::MCTS_DEFER_TICKS;
-    if (planner && h->dev.mcts_ticks > 0 && (!short_call || h->dev.mcts_ticks + n_ticks > hk::MCTS_DEFER_TICKS)) {
+    // (how long a request may wait for its launch: a request posted on armed tick 1 is searched before armed tick defer + 1 runs, and its
+    // plan is due `latency` ticks after the request — so defer = the handle's smaller latency - 1, at least MCTS_DEFER_TICKS)
+    const int defer = std::max(hk::MCTS_DEFER_TICKS, std::min(h->cfg.mcts_latency_ticks, h->cfg.mcts_initial_latency_ticks) - 1);
+    const bool short_call = planner && n_ticks <= defer;
+    if (planner && h->dev.mcts_ticks > 0 && (!short_call || h->dev.mcts_ticks + n_ticks > defer)) {
         rc = hk::env_flush_mcts(h->dev, h->stream, h->err);
         if (rc) { g_last_error = h->err; return rc; }
     }
