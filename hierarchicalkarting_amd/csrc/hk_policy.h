@@ -22,6 +22,7 @@
 #include <vector>
 #include "../../include/hk.h"
 #include "../../include/hk_detmath.h"
+#include "hk_swish.h"      // Sigmoid then Mul in the exported graph
 #include "hk_env_device.h"
 
 namespace hk {
@@ -94,11 +95,6 @@ __global__ __launch_bounds__(256) void policy_invalidate_kernel(PolicyParams Q, 
     Q.epoch[(size_t)env * Q.n_slots + idx % Q.n_slots] = -1;
 }
 
-__device__ inline float swish(float s)
-{   // Sigmoid then Mul in the exported graph
-    const float sg = 1.0f / (1.0f + hk_expf_fast(-s));
-    return s * sg;
-}
 
 // One wave's share of a layer over kc inputs: acc0 (+ acc1 when HAS1) += A[32 rows][kc] * B[kc][32 cols], as MFMA
 // 32x32x2 f32 steps in ascending k.  a?p / b?p already point at this lane's first element (A from LDS, row stride PM_LD

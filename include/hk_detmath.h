@@ -240,9 +240,8 @@ HK_HD float hk_logf(float x) { return (float)hk_log((double)x); }
  * <= 2 ulp of fp32 on [-87, 88] (tests/test_detmath.py); inputs are clamped to that range.  NOT used where the reference
  * calls Math.Exp / Mathf.Exp (those go through hk_exp): the exp inside Barracuda's Sigmoid kernel is not bit-defined, so
  * here only oracle == GPU matters. */
-HK_HD float hk_expf_fast(float x)
+HK_HD float hk_expf_fast_core(float x)     /* x already inside [-87, 88] */
 {
-    x = x > 88.0f ? 88.0f : (x < -87.0f ? -87.0f : x);
     const float fk = __builtin_rintf(x * 1.44269504f);
     float r = __builtin_fmaf(fk, -0.693359375f, x);
     r = __builtin_fmaf(fk, 2.12194440e-4f, r);
@@ -257,6 +256,19 @@ HK_HD float hk_expf_fast(float x)
     union { unsigned int u; float f; } sc;
     sc.u = (unsigned int)((int)fk + 127) << 23;
     return e * sc.f;
+}
+HK_HD float hk_expf_fast(float x)
+{
+    x = x > 88.0f ? 88.0f : (x < -87.0f ? -87.0f : x);
+    return hk_expf_fast_core(x);
+}
+
+/* Swish of the RL actor (Sigmoid then Mul in the exported graph): s * (1 / (1 + exp(-s))) with the exp above.  The device
+ * evaluates the same expression with its clamp as one v_med3_f32 (csrc/hk_swish.h; tests/test_swish_device.py compares the two
+ * over every fp32 bit pattern on the GPU). */
+HK_HD float hk_swishf(float s)
+{
+    return s * (1.0f / (1.0f + hk_expf_fast(-s)));
 }
 
 #endif /* HK_DETMATH_H */

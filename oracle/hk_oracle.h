@@ -48,6 +48,7 @@ double hko_atan2(double y, double x);
 double hko_exp(double x);
 double hko_log(double x);
 float hko_expf_fast(float x);
+float hko_swishf(float x);
 void hko_sincos_near0(double x, double* s, double* c);   /* the kernels' small-angle path: also bit-identical */
 void hko_sincos(double x, double* s, double* c);   /* the kernels' fused pair: must equal (hko_sin, hko_cos) bit for bit */   /* the actor's Swish exp (fp32) */
 

@@ -14,6 +14,7 @@ double hko_atan2(double y, double x) { return hk_atan2(y, x); }
 double hko_exp(double x) { return hk_exp(x); }
 double hko_log(double x) { return hk_log(x); }
 float hko_expf_fast(float x) { return hk_expf_fast(x); }
+float hko_swishf(float x) { return hk_swishf(x); }
 void hko_sincos(double x, double* s, double* c) { hk_sincos(x, s, c); }
 void hko_sincos_near0(double x, double* s, double* c) { hk_sincos_near0(x, s, c); }
 

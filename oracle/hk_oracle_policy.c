@@ -94,11 +94,7 @@ void hko_policy_invalidate(hko_env* e, int env)
     for (int p = 0; p < e->n_policies; p++) e->policy[p]->epoch[env] = -1;
 }
 
-static inline float swish(float s)
-{   /* Sigmoid then Mul in the graph */
-    float sg = 1.0f / (1.0f + hk_expf_fast(-s));
-    return s * sg;
-}
+static inline float swish(float s) { return hk_swishf(s); }     /* Sigmoid then Mul in the graph */
 
 /* x: one stacked observation row [in_dim] (oldest first).  mu[1], logits[n_branch] */
 static void forward_row(const hk_policy_desc* d, const float* x, float* mu, float* logits)
