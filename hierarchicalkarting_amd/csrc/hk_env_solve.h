@@ -514,6 +514,7 @@ __device__ inline int phase_assemble(const EnvParams& P, const TabView& T, KartS
         // so the union of those five cells' lists contains it.  Lists are supersets; the minimum is what a scan of
         // every wall (the oracle) returns.
         const float ox = k.px + SENSOR_LZ * k.fx, oz = k.pz + SENSOR_LZ * k.fz;
+        HK_ST(h, 14);
         {
             float d0x, d0z;
             sensor_dir(P, 0, k.fx, k.fz, d0x, d0z);
@@ -533,6 +534,7 @@ __device__ inline int phase_assemble(const EnvParams& P, const TabView& T, KartS
             }
             k.ray[0] = best;
         }
+        HK_ST(h, 15);
         {
             const int ssel[4] = {2, 4, 8, 6};
             float ddx[4], ddz[4], best[4];
