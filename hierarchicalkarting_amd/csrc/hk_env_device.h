@@ -154,11 +154,15 @@ __host__ __device__ inline TabView tab_view(const EnvParams& P, const unsigned c
     T.tmask = reinterpret_cast<const uint2*>(base + P.o_tmask);
     return T;
 }
-// copy the packed tables into dynamic LDS (all threads of the block), or fall back to global memory when the launch
-// passed no dynamic LDS (tables larger than the budget)
-__device__ inline TabView tab_stage(const EnvParams& P, unsigned char* smem, bool use_lds)
+// copy the packed tables into dynamic LDS (all threads of the block); TAB_LDS false: the launch passed no dynamic LDS (tables
+// larger than the budget) and they are read from global memory.  A COMPILE-TIME choice: with a run-time one the table pointers
+// are generic, every table read is a flat_load that finds its way to LDS through the vector-memory path, and the dependent
+// reads of the wall lists (cell -> list -> segment) pay that latency in series — the four short sensor rays alone took 11 % of
+// the tick kernel; as ds_reads the headline gains 5 % (903 -> 952 M env-steps/s, same box).
+template <bool TAB_LDS>
+__device__ inline TabView tab_stage(const EnvParams& P, unsigned char* smem)
 {
-    if (!use_lds) return tab_view(P, P.tab);
+    if (!TAB_LDS) return tab_view(P, P.tab);
     const int n16 = P.tab_bytes >> 4;
     const uint4* src = reinterpret_cast<const uint4*>(P.tab);
     uint4* dst = reinterpret_cast<uint4*>(smem);
@@ -371,7 +375,7 @@ __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0
 // Diagnostic build only (-DHK_STAMPS, tools/stamp_profile.py): cycle stamps at the phase boundaries of the fused tick kernel,
 // accumulated per lane, reduced to the wave's maximum and added to game_stats[16 + k] when the kernel ends.
 #ifdef HK_STAMPS
-#define HK_NSTAMP 16
+#define HK_NSTAMP 20
 #define HK_ST(h, k) do { const unsigned long long n_ = __builtin_readcyclecounter(); (h).st_acc[k] += (unsigned)(n_ - (h).st_t); (h).st_t = n_; } while (0)
 #else
 #define HK_ST(h, k) do { } while (0)

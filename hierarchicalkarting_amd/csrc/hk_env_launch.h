@@ -84,15 +84,17 @@ inline int launch_regroup(EnvDevice& d, const hk_config& cfg, hipStream_t stream
 inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
 {
     const long long threads = (long long)cfg.num_envs * GA;
-#define HK_RUN(MC, RWF, TRN)                                                                                                  \
-    hipLaunchKernelGGL((env_run_kernel<MC, RWF, TRN>), dim3((unsigned)((threads + 255) / 256)), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs,   \
+#define HK_RUN_T(MC, RWF, TRN, TL)                                                                                            \
+    hipLaunchKernelGGL((env_run_kernel<MC, RWF, TRN, TL>), dim3((unsigned)((threads + 255) / 256)), dim3(256), TL ? d.tab_lds : 0, stream, d.P, d.agents, d.envs,   \
                        d.results, GameSoA{d.games, (size_t)cfg.num_envs * cfg.num_agents}, d.queue_cnt, d.queue, d.round, d.act_steer, d.act_branch, d.lq_debug, d.status,     \
-                       d.tab_lds ? 1 : 0, d.mcts, d.mset, d.rw, d.perm_valid ? d.perm : nullptr, d.game_stats)
+                       d.mcts, d.mset, d.rw, d.perm_valid ? d.perm : nullptr, d.game_stats)
+#define HK_RUN(MC, RWF, TRN) do { if (d.tab_lds) HK_RUN_T(MC, RWF, TRN, true); else HK_RUN_T(MC, RWF, TRN, false); } while (0)
     bool train = d.P.training_reset != 0;
     for (int i = 0; i < cfg.num_agents; i++) train = train || d.P.training_agent[i] != 0;
     if (train) HK_RUN(true, true, true);
     else if (d.mcts.st) { if (d.rw.sec_time) HK_RUN(true, true, false); else HK_RUN(true, false, false); }
     else { if (d.rw.sec_time) HK_RUN(false, true, false); else HK_RUN(false, false, false); }
+#undef HK_RUN_T
 #undef HK_RUN
     return launch_check(err, "env_run_kernel");
 }
@@ -146,8 +148,9 @@ inline int launch_observe(EnvDevice& d, const hk_config& cfg, uint32_t agent_mas
     // a block is only 16 agents: copying the tables into LDS pays for the Oval's 20 KB (+3 % on the RL workload), not for the
     // Complex track's 40 KB (the 8-agent workload lost 10 %), which keeps reading them through L1 / L2
     const int lds = (d.tab_lds && d.tab_lds <= 24 * 1024) ? d.tab_lds : 0;
-    hipLaunchKernelGGL(env_observe_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, stream, d.P, d.agents, d.obs, d.rw.hit_code,
-                       d.rw.hit_code ? 0xFFFFFFFFu : agent_mask, lds ? 1 : 0);      // the reward replay needs every agent's hit codes
+    const uint32_t mask = d.rw.hit_code ? 0xFFFFFFFFu : agent_mask;                  // the reward replay needs every agent's hit codes
+    if (lds) hipLaunchKernelGGL(env_observe_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, stream, d.P, d.agents, d.obs, d.rw.hit_code, mask);
+    else hipLaunchKernelGGL(env_observe_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d.P, d.agents, d.obs, d.rw.hit_code, mask);
     int rc = launch_check(err, "env_observe_kernel");
     if (rc || !d.rw.hit_code) return rc;
     // CollectObservations raised HitWall / HitOpponent events (HKA:580-598): replayed per env in agent / sensor order

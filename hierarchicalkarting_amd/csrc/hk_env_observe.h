@@ -32,12 +32,13 @@ __device__ inline void inv_transform_point(const hk_agent_state* a, float fx, fl
 // Lane l of the group first evaluates the forward vector of kart l % A (one fp64 sin/cos pair per lane instead of A per
 // agent) and the group shares them by shuffles.
 constexpr int OBS_LANES = 16;
+template <bool TAB_LDS>
 __global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_agent_state* agents, float* obs, unsigned char* hit_code,
-                                                          uint32_t agent_mask /* bit i: agent slot i is observed */, int use_lds)
+                                                          uint32_t agent_mask /* bit i: agent slot i is observed */)
 {
     // the track tables (wall grid walked by nine 20 m rays per agent) staged in LDS, as in the tick kernel
     extern __shared__ __align__(16) unsigned char smem[];
-    const TabView T = tab_stage(P, smem, use_lds != 0);
+    const TabView T = tab_stage<TAB_LDS>(P, smem);
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int gid0 = tid / OBS_LANES, l = tid % OBS_LANES;
     const int n_agents = P.E * P.A;

@@ -77,14 +77,14 @@ __global__ __launch_bounds__(256) void env_regroup_scatter_kernel(const hk_env_s
 // <false, false, false> is the headline path: the planner hooks (request / consume / beliefs), reward shaping and the
 // Training-mode code compile away entirely.  Instantiated: every (HAS_MCTS, HAS_RW) pair without Training code, and
 // <true, true, true> for any handle that uses Training mode (its planner / reward parts are also guarded at run time).
-template <bool HAS_MCTS, bool HAS_RW, bool HAS_TRAIN>
+template <bool HAS_MCTS, bool HAS_RW, bool HAS_TRAIN, bool TAB_LDS>
 #ifndef HK_RUN_OCC
 #define HK_RUN_OCC 2
 #endif
 __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
                                                       hk_episode_result* results, GameSoA games, int* queue_cnt_all,
                                                       int* queue_all, int round, const float* act_steer, const int* act_branch,
-                                                      hk_lq_debug* dbg_out, int* status, int use_lds, MctsDev Marg, int mset, RwDev RD, const int* perm,
+                                                      hk_lq_debug* dbg_out, int* status, MctsDev Marg, int mset, RwDev RD, const int* perm,
                                                       unsigned long long* stats)
 {
     MctsDev M{};
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
     int phase = es.reserved[1] & 15;           // (bits 4..: the round in which the env queued its game, read by the deferred scheme)
     // nothing to do in this block? (every env finished its ticks): skip the table staging too
     if (__syncthreads_or(left > 0 || phase != 0) == 0) return;
-    const TabView T = tab_stage(P, smem, use_lds != 0);
+    const TabView T = tab_stage<TAB_LDS>(P, smem);
     const int cadence = P.A > 2 ? 4 : 1;
     const uint32_t all_mask = (1u << P.A) - 1u;
     int budget = P.run_cap;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
     else { es.episode_steps = 0; es.inactive_mask = 0; es.experiment_num = 0; es.episodes_done = 0; es.status = 0; es.initial_started = 0; es.reserved[0] = 0; es.reserved[1] = 0; }
     // nothing to do in this block? (every env finished its ticks): skip the table staging too
     if (__syncthreads_or(es.reserved[0] > 0 || es.reserved[1] != 0) == 0) return;
-    const TabView T = tab_stage(P, smem, use_lds != 0);
+    const TabView T = tab_stage<TAB_LDS>(P, smem);
     const int cadence = P.A > 2 ? 4 : 1;
     const uint32_t all_mask = (1u << P.A) - 1u;
     int budget = P.run_cap;

@@ -557,7 +557,9 @@ __device__ inline int phase_assemble(const EnvParams& P, const TabView& T, KartS
             for (int q = 0; q < 4; q++) k.ray[1 + q] = best[q];
         }
     }
+    HK_ST(h, 16);
     ks[threadIdx.x] = k;
+    HK_ST(h, 17);
     wave_lds_sync();
     HK_ST(h, 2);                       // [2] own-kart staging + the five wall rays
     if (!me) return 0;

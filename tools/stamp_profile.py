@@ -14,7 +14,7 @@ LIB = os.path.join(ROOT, "build", "libhk_stamps.so")
 NAMES = ["prologue (tables -> LDS, state load)", "phase A: episode controller, kart-vs-kart rays", "own-kart staging + 5 wall rays",
          "players within 8 m", "single-player assembly (heading heuristic)", "lq1_solve", "queue binning", "multi-player assembly",
          "actions, planFixed, ArcadeKart, integrate", "kart-kart contacts", "kart-wall contacts", "Triggers, section / lane rules",
-         "telemetry, env words", "wait for the wave's other groups", "(of [2]) own-kart staging: atan2, max speed, Trigger distance", "(of [2]) forward wall ray"]
+         "telemetry, env words", "wait for the wave's other groups", "(of [2]) own-kart staging: atan2, max speed, Trigger distance", "(of [2]) forward wall ray", "(of [2]) four short rays", "(of [2]) KartS -> LDS", "-", "-"]
 
 
 def build():
@@ -48,10 +48,10 @@ def main():
         if p.returncode or not line:
             print(p.stderr[-3000:]); return 1
         v = [int(x) for x in line[-1].split()[1:]]
-        tot = sum(v[:16]) or 1
-        print("waves that entered the loop (summed over launches): %d" % v[16])
-        for k in range(16):
-            print("  [%2d] %-50s %6.2f %%   %8.1f kcycles / wave-launch" % (k, NAMES[k], 100.0 * v[k] / tot, v[k] / max(v[16], 1) / 1e3))
+        tot = sum(v[:20]) or 1
+        print("waves that entered the loop (summed over launches): %d" % v[20])
+        for k in range(20):
+            print("  [%2d] %-50s %6.2f %%   %8.1f kcycles / wave-launch" % (k, NAMES[k], 100.0 * v[k] / tot, v[k] / max(v[20], 1) / 1e3))
         return 0
     import hierarchicalkarting_amd as hk
     env = hk.RacingEnv(hk.make_config(a.envs, a.agents, jitter_seed=0x5EED0000))
