@@ -6,7 +6,10 @@
 
 Each lane accumulates the cycles between consecutive stamps; at the end of a launch the wave's maximum per counter is added
 to a device array.  The shares below are therefore wave time (two waves share a SIMD, so they include the partner's issue
-slots), summed over the waves that entered the tick loop."""
+slots), summed over the waves that entered the tick loop.  A lane that skips stamps (an env that is not on a solve tick while
+its wave neighbours are) books the whole skipped stretch on the next stamp it executes, and the wave's maximum picks that up: the
+counters behind a divergent stretch ([2] after [14] / [15], [6] after [3] .. [5]) are upper bounds.  (Round 2: [2] looked like
+12 % in four 2 m rays; making those rays division-free changed neither the stamp nor the kernel's time.)"""
 import argparse, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
