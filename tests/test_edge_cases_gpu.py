@@ -47,6 +47,29 @@ def test_track_without_walls():
     assert np.array_equal(obs, o.observations())
 
 
+def test_track_tables_too_large_for_lds_are_read_from_global_memory():
+    """the tick kernel keeps the track tables in LDS when they fit 48 KB (a compile-time choice: env_run_kernel<..., TAB_LDS>);
+    a track with finely tessellated walls takes the other instantiation — same results as the oracle on the same walls"""
+    import hierarchicalkarting_amd as hk
+    tr = copy.deepcopy(load_track("oval"))
+    k = 12
+    for w in tr["walls"]:
+        pts, out = w["points"], []
+        for (x0, z0), (x1, z1) in zip(pts[:-1], pts[1:]):
+            for j in range(k):
+                out.append([x0 + (x1 - x0) * j / k, z0 + (z1 - z0) * j / k])
+        out.append(list(pts[-1]))
+        w["points"] = out
+    b = hk.make_config(6, 4, track=tr, jitter_seed=5)
+    assert b.cfg.num_walls * 16 > 48 * 1024                                    # the wall segments alone exceed the LDS budget
+    g = hk.RacingEnv(b); o = O.OracleEnv(b)
+    g.reset(); o.reset()
+    for t in (100, 200, 300, 400):
+        g.step(100); o.step(100)
+        _same(g, o, t)
+    assert np.array_equal(g.observations(), o.observations())
+
+
 def test_maximum_section_count_and_many_laps():
     """HK_MAX_SECTIONS = 64 sections (the Complex track's 41 repeated would exceed it: take the Oval's 24 x 2 + 16 = 64) and a
     long race (reward tables sized laps * L + 2)"""
