@@ -30,7 +30,8 @@ thread_local std::string g_last_error;
 struct Prof {
     bool on = false;
     std::vector<hipEvent_t> pool;                                         // free events
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> rec[HK_PROF_STAGES];   // recorded, not yet folded
+    struct Span { hipEvent_t first, second; bool owns_first; };           // owns_first false: `first` is the `second` of the span before
+    std::vector<Span> rec[HK_PROF_STAGES];                                // recorded, not yet folded
     double ms[HK_PROF_STAGES] = {};
     int64_t n[HK_PROF_STAGES] = {};
     hipEvent_t get()
@@ -53,7 +54,18 @@ struct Prof {
         if (!e0) return;
         hipEvent_t e1 = get();
         if (!e1 || hipEventRecord(e1, st) != hipSuccess) { pool.push_back(e0); if (e1) pool.push_back(e1); return; }
-        rec[stage].emplace_back(e0, e1);
+        rec[stage].push_back(Span{e0, e1, true});
+    }
+    // back-to-back launches on one stream share their boundary event: chain() closes the span that began at `prev` and returns the
+    // event it recorded as the start of the next one (an event between two kernels costs ~5 us of the GPU's time: a round of
+    // {tick kernel, solver kernel} carries two of them this way, not four).  `first`: prev came from begin().
+    hipEvent_t chain(int stage, hipEvent_t prev, bool first, hipStream_t st)
+    {
+        if (!prev) return nullptr;
+        hipEvent_t e1 = get();
+        if (!e1 || hipEventRecord(e1, st) != hipSuccess) { if (first) pool.push_back(prev); if (e1) pool.push_back(e1); return nullptr; }
+        rec[stage].push_back(Span{prev, e1, first});
+        return e1;
     }
     void fold()
     {
@@ -61,7 +73,8 @@ struct Prof {
             for (auto& pr : rec[s]) {
                 float t = 0;
                 if (hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) { ms[s] += t; n[s]++; }
-                pool.push_back(pr.first); pool.push_back(pr.second);
+                if (pr.owns_first) pool.push_back(pr.first);
+                pool.push_back(pr.second);
             }
             rec[s].clear();
         }
@@ -342,16 +355,18 @@ int hk_set_actions(hk_handle h, const float* steer, const int32_t* branch)
 // `rounds` rounds of {fused tick kernel (up to RUN_CAP ticks per env), queued multi-player solves}
 static int issue_rounds(hk_handle h, int rounds)
 {
+    hipEvent_t e = h->prof.begin(h->stream);
+    bool first = true;
     for (int r = 0; r < rounds; r++) {
-        hipEvent_t e = h->prof.begin(h->stream);
         int rc = hk::env_launch_run(h->dev, h->cfg, h->stream, h->err);
         if (rc) { g_last_error = h->err; return rc; }
-        h->prof.end(0, e, h->stream);
-        e = h->prof.begin(h->stream);
+        e = h->prof.chain(0, e, first, h->stream);
         rc = hk::env_launch_lqn(h->dev, h->cfg, h->stream, h->err);
         if (rc) { g_last_error = h->err; return rc; }
-        h->prof.end(1, e, h->stream);
+        e = h->prof.chain(1, e, false, h->stream);
+        first = false;
     }
+    if (first && e) h->prof.pool.push_back(e);          // no round issued: the opening event goes back
     return HK_OK;
 }
 
