@@ -508,7 +508,15 @@ static int step_ticks(hk_handle h, int n_ticks)
     const bool lazy = !planner && h->n_policies == 0 && h->done_host != nullptr && n_ticks >= HK_LAZY_MIN_TICKS && !std::getenv("HK_FIXED_ROUNDS");
     // ticks per launch: longer launches once the field has spread out (see RUN_CAP_SPREAD)
     static const int spread_cap = [] { const char* e = std::getenv("HK_RUN_CAP_SPREAD"); const int v = e ? std::atoi(e) : hk::RUN_CAP_SPREAD; return v > 4 && v <= 64 ? v : hk::RUN_CAP_SPREAD; }();
-    const int run_cap = (lazy && h->cfg.num_agents > 2 && h->dev.ticks_since_reset >= hk::BULK_TICKS) ? spread_cap : hk::RUN_CAP;
+    // short calls of plain LQNG handles: one solve cadence per launch — with the eager assembly every env, in a pack or not, retires
+    // it, so a 20-tick call is 6 equal rounds and no tail (at 8 ticks per launch: 3 rounds + a regroup + 5 rounds for the laggards)
+    static const int short_cap = [] { const char* e = std::getenv("HK_RUN_CAP_SHORT"); const int v = e ? std::atoi(e) : 4; return v >= 4 && v <= 64 ? v : 4; }();
+    static const bool eager = std::getenv("HK_NO_EAGER") == nullptr;
+    const bool plain = !planner && h->n_policies == 0;
+    // (planner / actor handles keep their deadline arithmetic as it was; the 8-lane groups run the older loop without it)
+    h->dev.P.eager = (eager && plain && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4) ? 1 : 0;
+    const int run_cap = (lazy && h->cfg.num_agents > 2 && h->dev.ticks_since_reset >= hk::BULK_TICKS) ? spread_cap
+                        : (!lazy && plain && h->dev.P.eager) ? short_cap : hk::RUN_CAP;
     h->dev.P.run_cap = run_cap;
     int rounds = lazy ? hk::env_rounds_min(h->cfg, n_ticks, run_cap) : hk::env_rounds_for(h->cfg, n_ticks);
     if (const char* dr = std::getenv("HK_DEBUG_MAX_ROUNDS")) rounds = std::min(rounds, std::atoi(dr));     // (diagnostic: look at the state between two rounds)

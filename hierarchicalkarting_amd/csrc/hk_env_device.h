@@ -69,6 +69,7 @@ struct EnvParams {
     const SecGeo* sec_geo; // [L]
     int team_of[ENV_MAXA], time_precision[ENV_MAXA], section_window[ENV_MAXA];
     int mcts_iter, mcts_iter0, mcts_lat, mcts_lat0, any_mcts;
+    int eager;          // 1: an env whose budget ends at a solve tick still assembles that tick's games before the launch ends (hk_env_run.h)
     int run_cap;        // ticks an env may run per launch (RUN_CAP; RUN_CAP_SPREAD for long calls on a spread field, hk_api.hip step_ticks)
     int lq_defer;       // set per hk_step call: the solver kernels run on a second stream beside the NEXT round of the tick kernel, so an env that
                         // queued a game in round r resumes in round r + 2 (hk_api.hip issue_rounds_overlapped)

@@ -132,6 +132,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     }
     P.hold_dedupe = (P.any_mcts == 0 && !P.training_reset && !std::getenv("HK_NO_HOLD_DEDUPE")) ? 1 : 0;
     P.run_cap = RUN_CAP;
+    P.eager = 0;
     P.mcts_iter = cfg.mcts_iterations; P.mcts_iter0 = cfg.mcts_initial_iterations; P.mcts_lat = cfg.mcts_latency_ticks;
     P.mcts_lat0 = cfg.mcts_initial_latency_ticks; P.mcts_seed = cfg.mcts_seed;
     P.jitter_seed = cfg.jitter_seed; P.jitter_pos = cfg.jitter_pos; P.jitter_yaw = cfg.jitter_yaw; P.env_id_base = cfg.env_id_base;

@@ -264,6 +264,18 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
         // P.mcts_pause (long hk_step calls of planner handles): an env with a requested, not yet run search waits at the tick boundary —
         // the host launches the searches of a whole stretch of rounds in ONE batch (a launch lasts as long as one search however few it holds)
         bool held = HAS_MCTS && P.mcts_pause && env_ok && group_or(mcts_search_outstanding(P, M, env, i) ? 1 : 0) != 0;
+        // Eager assembly (P.eager, cadence 4).  A budget that ends on a solve tick would leave that tick's games to the NEXT launch:
+        // an env that then meets a multi-player game parks at once and sits out the whole launch.  Instead the budget is trimmed so
+        // that it ends on a solve tick (first launch of a call, after a reset), and the env runs phases A / B1 of that tick before
+        // the launch ends: its games go to this round's solver launch, and every env — racing alone or in a pack — advances one
+        // cadence per round at least.  The env waits in phase 1 ("controls ready"), exactly as if it had queued a game.
+        // (es.episode_steps is the index of the tick last BEGUN: phase_begin increments it.  An env at a tick boundary runs ticks
+        // e + 1 .. e + budget, one resuming its parked tick e runs e .. e + budget - 1; the tick after those should be a solve tick.)
+        if (P.eager && cadence > 1 && first) {
+            const int over = (es.episode_steps + budget + (phase == 0 ? 1 : 0)) % cadence;
+            if (over < budget) budget -= over;
+        }
+        bool eager_it = false;           // this iteration is the assembly-only one at the end of the budget
         bool go = env_ok && (resume || (phase == 0 && left > 0 && budget > 0 && !held));
         while (__ballot(go) != 0ull) {
             int qn = 0;                  // player count of the multi-player game this ego assembled on this tick (0: none)
@@ -313,8 +325,8 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
                 // requests are posted on replan ticks (phase_plan) and on the reset tick (phase_begin): look again after those
                 if (HAS_MCTS && P.mcts_pause && es.episode_steps % 100 == 0) held = group_or(mcts_search_outstanding(P, M, env, i) ? 1 : 0) != 0;
                 HK_ST(h, 6);           // [6] queue binning (+ planner hooks)
-                // does any ego of this env wait for a queued multi-player solve?
-                if (group_or(qn ? 1 : 0)) { phase = 1; moving = false; go = false; }
+                // does any ego of this env wait for a queued multi-player solve?  (or was this the assembly at the end of the budget)
+                if (group_or(qn ? 1 : 0) || eager_it) { phase = 1; moving = false; go = false; }
             }
             if (inw) {
                 if (moving) phase = 2;     // every env of the wave that is mid-tick: phases A / B1 done, controls in its record
@@ -325,7 +337,14 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
                 phase = 0;
                 left -= 1; budget -= 1;
             }
-            go = go && (left > 0 && budget > 0 && !held);
+            {
+                // the assembly-only iteration at the end of the budget (see above) is taken once, by an env that just ran out of budget on a
+                // solve tick; it ends the env's part in this launch
+                const bool again = left > 0 && budget > 0 && !held;
+                const bool last = P.eager != 0 && cadence > 1 && !eager_it && phase == 0 && left > 0 && budget <= 0 && !held && ((es.episode_steps + 1) % cadence) == 0;
+                go = go && !eager_it && (again || last);
+                eager_it = last;
+            }
         }
         HK_ST(h, 13);                      // [13] waiting for the other lane groups of the wave to leave the loop
 #ifdef HK_STAMPS
