@@ -507,7 +507,7 @@ static int step_ticks(hk_handle h, int n_ticks)
     // (short calls — a host stepping tick by tick — keep the fixed count too: a handful of rounds, no host sync)
     const bool lazy = !planner && h->n_policies == 0 && h->done_host != nullptr && n_ticks >= HK_LAZY_MIN_TICKS && !std::getenv("HK_FIXED_ROUNDS");
     // ticks per launch: longer launches once the field has spread out (see RUN_CAP_SPREAD)
-    static const int spread_cap = [] { const char* e = std::getenv("HK_RUN_CAP_SPREAD"); const int v = e ? std::atoi(e) : hk::RUN_CAP_SPREAD; return v > 4 && v <= 64 ? v : hk::RUN_CAP_SPREAD; }();
+    static const int spread_cap = [] { const char* e = std::getenv("HK_RUN_CAP_SPREAD"); const int v = e ? std::atoi(e) : hk::RUN_CAP_SPREAD; return v >= 4 && v <= 64 ? v : hk::RUN_CAP_SPREAD; }();
     // short calls of plain LQNG handles: one solve cadence per launch — with the eager assembly every env, in a pack or not, retires
     // it, so a 20-tick call is 6 equal rounds and no tail (at 8 ticks per launch: 3 rounds + a regroup + 5 rounds for the laggards)
     static const int short_cap = [] { const char* e = std::getenv("HK_RUN_CAP_SHORT"); const int v = e ? std::atoi(e) : 4; return v >= 4 && v <= 64 ? v : 4; }();
