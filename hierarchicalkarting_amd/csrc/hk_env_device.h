@@ -20,7 +20,8 @@ constexpr int RUN_CAP = HK_RUN_CAP;
 // solve's latency).  Measured with the lazily completed long calls of round 2: 8 -> 909 M env-steps/s, 12 -> 925 M, 16 -> 911 M in the
 // steady state, but 437 / 397 / 368 M over the first 512 ticks of a race — so 12 only after BULK_TICKS.  (Same box, same call: 8 -> 893 M,
 // 12 -> 906 M; 10 and 14 -> 750 M: the cap must be a multiple of the solve cadence, or the envs of a wave end their launches in different
-// solve phases and the wave runs the solve path on every tick.)
+// solve phases and the wave runs the solve path on every tick.)  With the eager assembly (hk_env_run.h): 4 -> 1 125 M, 8 -> 1 217 M,
+// 12 -> 1 217 M, 16 -> 1 194 M, 24 -> 1 123 M, 32 -> 1 050 M.
 constexpr int RUN_CAP_SPREAD = 12;      // ticks per env per launch (> cadence).  Measured at E = 65 536, 4-agent Oval: 8 -> 533 M env-steps/s,
                                 // 6 -> 456 M, 5 -> 408 M (misaligned with the 4-tick cadence), 16 -> 503 M, 32 -> 450 M, 128 -> 264 M: a quad that
                                 // queues a game idles its lanes until the launch ends, so long launches waste lanes
