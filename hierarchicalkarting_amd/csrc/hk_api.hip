@@ -109,6 +109,9 @@ struct hk_context {
     // finishes the stragglers (finish_ticks)
     bool step_pending = false;
     bool step_overlapped = false;  // the pending call runs its solver launches on qstream (issue_rounds_overlapped)
+    bool split = false;            // the current call runs the batch as two halves on two streams (issue_rounds)
+    int round_half[2] = {0, 0};    // each half's own round counter (the parity picks its queue set)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int* done_host = nullptr;      // pinned: [0] max ticks left over the envs, [1] an env waits for a queued game
     void* pol_scratch = nullptr;   // hk_policy_forward staging
     size_t pol_scratch_bytes = 0;
@@ -238,6 +241,7 @@ void hk_destroy(hk_handle h)
     h->prof.fold();
     for (hipEvent_t e : h->prof.pool) (void)hipEventDestroy(e);
     if (h->qstream) { (void)hipStreamSynchronize(h->qstream); (void)hipStreamDestroy(h->qstream); }
+    if (h->ev_fork) { (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
     for (int k = 0; k < 2; k++) { if (h->ev_run[k]) (void)hipEventDestroy(h->ev_run[k]); if (h->ev_lqn[k]) (void)hipEventDestroy(h->ev_lqn[k]); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h == g_default_ctx) g_default_ctx = nullptr;
@@ -353,8 +357,10 @@ int hk_set_actions(hk_handle h, const float* steer, const int32_t* branch)
 }
 
 // `rounds` rounds of {fused tick kernel (up to RUN_CAP ticks per env), queued multi-player solves}
+static int issue_rounds_split(hk_handle h, int rounds);
 static int issue_rounds(hk_handle h, int rounds)
 {
+    if (h->split && rounds > 0) return issue_rounds_split(h, rounds);
     hipEvent_t e = h->prof.begin(h->stream);
     bool first = true;
     for (int r = 0; r < rounds; r++) {
@@ -368,6 +374,51 @@ static int issue_rounds(hk_handle h, int rounds)
     }
     if (first && e) h->prof.pool.push_back(e);          // no round issued: the opening event goes back
     return HK_OK;
+}
+
+// The batch as two halves (lane groups [0, E/2) and [E/2, E), each with its own pair of queue sets) on two streams: a round of
+// one half is {tick kernel, solver kernel} back to back as before, but while one half waits for its handful of solves (one
+// solve's latency: 35 - 59 us of an otherwise idle GPU per round — a fifth of a 20-tick call) the other half's tick kernel has
+// the whole GPU.  Nothing is deferred: a queued game still costs its env one round.  Both streams are joined before anything
+// else touches the state (the guard kernel, a regroup, a getter).
+static int issue_rounds_split(hk_handle h, int rounds)
+{
+    if (!h->qstream) HK_HIP(h, hipStreamCreateWithFlags(&h->qstream, hipStreamNonBlocking));
+    if (!h->ev_fork) {
+        HK_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HK_HIP(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    const int E = h->cfg.num_envs, mid = (E / 2 + 63) / 64 * 64;      // (a block of the tick kernel holds 64 lane groups)
+    if ((h->dev.rounds_since_regroup += rounds) >= hk::REGROUP_ROUNDS) {  // the periodic regroup by solve phase, here where the streams are joined
+        int rcg = hk::env_launch_regroup(h->dev, h->cfg, h->stream, h->err);
+        if (rcg) { g_last_error = h->err; return rcg; }
+    }
+    hipStream_t st[2] = {h->stream, h->qstream};
+    h->round_half[0] = h->dev.round;          // sets 0 / 1 are also the unsplit launches' sets: continue their parity
+    HK_HIP(h, hipEventRecord(h->ev_fork, h->stream));
+    HK_HIP(h, hipStreamWaitEvent(h->qstream, h->ev_fork, 0));
+    hipEvent_t e[2] = {h->prof.begin(st[0]), h->prof.begin(st[1])};
+    bool first = true;
+    int rc = HK_OK;
+    for (int r = 0; r < rounds && rc == HK_OK; r++) {
+        for (int k = 0; k < 2 && rc == HK_OK; k++) {
+            h->dev.slot0 = k ? mid : 0; h->dev.slot1 = k ? E : mid; h->dev.qbase = 2 * k; h->dev.round = h->round_half[k];
+            rc = hk::env_launch_run_only(h->dev, h->cfg, st[k], h->err);
+            if (rc) break;
+            e[k] = h->prof.chain(0, e[k], first, st[k]);
+            rc = hk::env_launch_lqn(h->dev, h->cfg, st[k], h->err);          // (advances dev.round)
+            if (rc) break;
+            e[k] = h->prof.chain(1, e[k], false, st[k]);
+            h->round_half[k] = h->dev.round;
+        }
+        first = false;
+    }
+    h->dev.slot0 = 0; h->dev.slot1 = 0; h->dev.qbase = 0; h->dev.round = h->round_half[0];
+    if (first) for (int k = 0; k < 2; k++) if (e[k]) h->prof.pool.push_back(e[k]);
+    HK_HIP(h, hipEventRecord(h->ev_join, h->qstream));
+    HK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    if (rc) g_last_error = h->err;
+    return rc;
 }
 
 // The same rounds with the solver on a second stream.  In a spread field a round's solver launch holds a handful of games and costs
@@ -522,6 +573,9 @@ static int step_ticks(hk_handle h, int n_ticks)
     const int run_cap = (lazy && h->cfg.num_agents > 2 && h->dev.ticks_since_reset >= hk::BULK_TICKS) ? spread_cap
                         : (!lazy && plain && h->dev.P.eager) ? short_cap : hk::RUN_CAP;
     h->dev.P.run_cap = run_cap;
+    // two halves on two streams: plain handles with the eager assembly (every env of a half is at the same place in its round)
+    static const bool no_split = std::getenv("HK_NO_SPLIT") != nullptr;
+    h->split = !no_split && h->dev.P.eager && h->cfg.num_envs >= 8192 && !std::getenv("HK_LQ_OVERLAP");
     int rounds = lazy ? hk::env_rounds_min(h->cfg, n_ticks, run_cap) : hk::env_rounds_for(h->cfg, n_ticks);
     if (const char* dr = std::getenv("HK_DEBUG_MAX_ROUNDS")) rounds = std::min(rounds, std::atoi(dr));     // (diagnostic: look at the state between two rounds)
     {

@@ -33,7 +33,8 @@ struct EnvDevice {
     int* status = nullptr;
     unsigned long long* game_stats = nullptr;   // [16]: multi-player games solved by the lqn kernels, by player count (hk_prof_games)
     double* games = nullptr;       // queued multi-player games, structure-of-arrays (GameSoA, hk_env_solve.h)
-    int* queue_cnt = nullptr;      // [2 sets][16] number of queued multi-player games per player count
+    int* queue_cnt = nullptr;      // [4 sets][16] number of queued multi-player games per player count (sets 2, 3: the second half of a split batch)
+    int slot0 = 0, slot1 = 0, qbase = 0;   // the lane groups and queue sets of the next {tick, solver} launches (hk_api.hip issue_rounds; 0, E, 0 = everything)
     int* queue = nullptr;          // [2 sets][GA - 1][E*A] game ids with N = 2 .. GA
     int round = 0;                 // launches so far: round & 1 selects the queue set (double buffered over rounds)
     long long ticks_since_reset = 1ll << 40;   // ticks stepped since the last hk_reset of every env, up to the current hk_step call (launch_lqn: bulk or sparse)

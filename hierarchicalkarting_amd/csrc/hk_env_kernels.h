@@ -282,10 +282,10 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     HK_ALLOC(d.status, 4 * sizeof(int));
     HK_ALLOC(d.game_stats, 64 * sizeof(unsigned long long));     // [0, 16) games by player count, [16, 64) diagnostic stamps
     HK_ALLOC(d.games, na * HK_GA_CALL(d, game_doubles_per_ego()) * sizeof(double));
-    HK_ALLOC(d.queue_cnt, 2 * 16 * sizeof(int));
+    HK_ALLOC(d.queue_cnt, 4 * 16 * sizeof(int));
     HK_ALLOC(d.perm, (size_t)E * sizeof(int));
     HK_ALLOC(d.perm_counts, 16 * sizeof(int));
-    HK_ALLOC(d.queue, 2 * HK_GA_CALL(d, queue_ints_per_set(na)) * sizeof(int));
+    HK_ALLOC(d.queue, 4 * HK_GA_CALL(d, queue_ints_per_set(na)) * sizeof(int));
     if (cfg.rewards) {
         d.rw.S = cfg.laps * L + 2;
         const size_t n = na * (size_t)d.rw.S;
@@ -443,6 +443,8 @@ inline int env_launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream
     }
     return HK_GA_CALL(d, launch_run(d, cfg, stream, err));
 }
+// (the split batch: no periodic regroup between the halves' launches — the caller regroups where both streams are joined)
+inline int env_launch_run_only(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_run(d, cfg, stream, err)); }
 inline int env_launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_lqn(d, cfg, stream, err)); }
 // pack the envs that still have ticks to run into the first lane groups (the tail of a call; see env_regroup_count_kernel)
 inline int env_launch_regroup(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)

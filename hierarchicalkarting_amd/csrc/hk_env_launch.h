@@ -83,11 +83,12 @@ inline int launch_regroup(EnvDevice& d, const hk_config& cfg, hipStream_t stream
 // one round, part 1: the fused tick kernel (fills queue set round & 1)
 inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
 {
-    const long long threads = (long long)cfg.num_envs * GA;
+    const int s0 = d.slot1 > d.slot0 ? d.slot0 : 0, s1 = d.slot1 > d.slot0 ? d.slot1 : cfg.num_envs;
+    const long long threads = (long long)(s1 - s0) * GA;
 #define HK_RUN_T(MC, RWF, TRN, TL)                                                                                            \
     hipLaunchKernelGGL((env_run_kernel<MC, RWF, TRN, TL>), dim3((unsigned)((threads + 255) / 256)), dim3(256), TL ? d.tab_lds : 0, stream, d.P, d.agents, d.envs,   \
                        d.results, GameSoA{d.games, (size_t)cfg.num_envs * cfg.num_agents}, d.queue_cnt, d.queue, d.round, d.act_steer, d.act_branch, d.lq_debug, d.status,     \
-                       d.mcts, d.mset, d.rw, d.perm_valid ? d.perm : nullptr, d.game_stats)
+                       d.mcts, d.mset, d.rw, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase)
 #define HK_RUN(MC, RWF, TRN) do { if (d.tab_lds) HK_RUN_T(MC, RWF, TRN, true); else HK_RUN_T(MC, RWF, TRN, false); } while (0)
     bool train = d.P.training_reset != 0;
     for (int i = 0; i < cfg.num_agents; i++) train = train || d.P.training_agent[i] != 0;
@@ -103,7 +104,7 @@ inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
 inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
 {
     const int ngames = cfg.num_envs * cfg.num_agents;
-    const int set = d.round & 1;
+    const int set = d.qbase + (d.round & 1);
     if (d.mcts.st && !d.mcts_defer && ++d.mcts_rounds >= MCTS_FLUSH_ROUNDS) { int rcm = flush_mcts(d, stream, err); if (rcm) return rcm; }
     const int* qc = d.queue_cnt + set * 16;
     const int* qu = d.queue + (size_t)set * queue_ints_per_set((size_t)ngames);
@@ -138,7 +139,7 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
 #endif
     }
     d.round += 1;
-    d.call_ticks_issued = std::min(d.call_ticks_issued + (cfg.num_agents > 2 ? 4 : 1), d.call_ticks);      // a round retires at least one solve cadence
+    if (d.qbase == 0) d.call_ticks_issued = std::min(d.call_ticks_issued + (cfg.num_agents > 2 ? 4 : 1), d.call_ticks);      // a round retires at least one solve cadence
     return HK_OK;
 }
 

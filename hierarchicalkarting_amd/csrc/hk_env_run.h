@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
                                                       hk_episode_result* results, GameSoA games, int* queue_cnt_all,
                                                       int* queue_all, int round, const float* act_steer, const int* act_branch,
                                                       hk_lq_debug* dbg_out, int* status, MctsDev Marg, int mset, RwDev RD, const int* perm,
-                                                      unsigned long long* stats)
+                                                      unsigned long long* stats, int slot0, int slot1, int qbase)
 {
     MctsDev M{};
     if (HAS_MCTS) M = Marg;
@@ -137,17 +137,19 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
     if (P.E < -1) status[0] = dummy_lds[(threadIdx.x * 7) % (HK_DUMMY_LDS / 4)];
 #endif
     extern __shared__ __align__(16) unsigned char smem[];
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    // this launch runs the lane groups [slot0, slot1) and uses the queue sets qbase, qbase + 1 (one launch for every env: 0, E, 0;
+    // plain handles split the batch in two halves on two streams so that one half's solver launch hides behind the other's ticks)
+    const int gid = slot0 * GA + blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = gid / GA, i = gid % GA;
-    const bool env_ok = slot < P.E;
+    const bool env_ok = slot < slot1;
     const int env = (perm && env_ok) ? perm[slot] : slot;     // lane groups are re-assigned by solve phase (env_regroup_*)
     // the game queues are double buffered over rounds: this launch fills `set`, and clears the other one, which the
     // previous round's lqn kernels have finished reading
-    const int set = round & 1;
+    const int set = qbase + (round & 1);
     int* queue_cnt = queue_cnt_all + set * 16;
     int* queue = queue_all + (size_t)set * (GA - 1) * P.E * P.A;
     // (with the solver on its own stream the other set is still being read: the host clears this launch's set before it instead)
-    if (!P.lq_defer && gid < 16) queue_cnt_all[(set ^ 1) * 16 + gid] = 0;
+    if (!P.lq_defer && blockIdx.x == 0 && threadIdx.x < 16) queue_cnt_all[(set ^ 1) * 16 + threadIdx.x] = 0;
 #if HK_GA != 4 || defined(HK_OLD_LOOP)
     // (lane groups of 8: the loop as it was before the in-wave path existed — nothing to gain there, and with the wave-uniform
     // form below the 8-lane build decoded single-player controls with a wrong final_steer: unexplained, so not used)
