@@ -573,9 +573,12 @@ static int step_ticks(hk_handle h, int n_ticks)
     const int run_cap = (lazy && h->cfg.num_agents > 2 && h->dev.ticks_since_reset >= hk::BULK_TICKS) ? spread_cap
                         : (!lazy && plain && h->dev.P.eager) ? short_cap : hk::RUN_CAP;
     h->dev.P.run_cap = run_cap;
-    // two halves on two streams: plain handles with the eager assembly (every env of a half is at the same place in its round)
-    static const bool no_split = std::getenv("HK_NO_SPLIT") != nullptr;
-    h->split = !no_split && h->dev.P.eager && h->cfg.num_envs >= 8192 && !std::getenv("HK_LQ_OVERLAP");
+    // two halves on two streams (issue_rounds_split): on request.  Measured: headline 1 221 -> 1 292 M env-steps/s, race start 439 -> 458 M,
+    // a 20-tick call unchanged (the solver kernel needs a SIMD's whole register file and finds none while the other half's tick kernel
+    // fills the GPU, so on short launches its latency is not hidden but moved).  Off by default: two tick kernels that share the GPU
+    // each take longer, and bench.py's per-launch roofline (bytes of a launch / its duration) would no longer describe the kernel.
+    static const bool want_split = std::getenv("HK_SPLIT") != nullptr;
+    h->split = want_split && h->dev.P.eager && h->cfg.num_envs >= 8192 && !std::getenv("HK_LQ_OVERLAP");
     int rounds = lazy ? hk::env_rounds_min(h->cfg, n_ticks, run_cap) : hk::env_rounds_for(h->cfg, n_ticks);
     if (const char* dr = std::getenv("HK_DEBUG_MAX_ROUNDS")) rounds = std::min(rounds, std::atoi(dr));     // (diagnostic: look at the state between two rounds)
     {
