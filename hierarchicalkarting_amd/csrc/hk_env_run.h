@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void env_check_kernel(const hk_env_state* envs
 // Second use (round 2): the tail of a call.  Envs that met multi-player games lag behind, and the last rounds of an hk_step run for
 // them alone — scattered one or two to a wave, each such wave costing full ticks.  The key therefore also says whether an env is done
 // with the call (keys 4..7): unfinished envs are packed, by phase, into the first lane groups; blocks that hold only finished envs
-// leave at once.  (A 20-tick call: 8 rounds of which 5 are tail.)
+// leave at once.  (A 20-tick call at 8 ticks per launch: 8 rounds of which 5 are tail; with the eager assembly short calls have none.)
 __device__ __forceinline__ int regroup_key(const hk_env_state& e)
 {
     const int left = e.reserved[0];
