@@ -38,7 +38,7 @@ struct Prof {
     {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
         hipEvent_t e = nullptr;
-        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) return nullptr;   // (timing stays on; no system-scope fence per record)
         return e;
     }
     // bracket helpers: begin() records the first event of a pair on `st`, end() the second
