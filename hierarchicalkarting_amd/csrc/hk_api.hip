@@ -577,8 +577,11 @@ static int step_ticks(hk_handle h, int n_ticks)
     // a 20-tick call unchanged (the solver kernel needs a SIMD's whole register file and finds none while the other half's tick kernel
     // fills the GPU, so on short launches its latency is not hidden but moved).  Off by default: two tick kernels that share the GPU
     // each take longer, and bench.py's per-launch roofline (bytes of a launch / its duration) would no longer describe the kernel.
-    static const bool want_split = std::getenv("HK_SPLIT") != nullptr;
-    h->split = want_split && h->dev.P.eager && h->cfg.num_envs >= 8192 && !std::getenv("HK_LQ_OVERLAP");
+    // While the field stands close (BULK_TICKS after a reset of every env: every ego holds a multi-player game and a round's solver
+    // launch lasts hundreds of microseconds) the split is used without being asked: race start 440 -> 458 M.
+    static const bool want_split = std::getenv("HK_SPLIT") != nullptr, no_split = std::getenv("HK_NO_SPLIT") != nullptr;
+    const bool close_field = h->dev.ticks_since_reset < hk::BULK_TICKS;
+    h->split = (want_split || (close_field && !no_split)) && h->dev.P.eager && h->cfg.num_envs >= 8192 && !std::getenv("HK_LQ_OVERLAP");
     int rounds = lazy ? hk::env_rounds_min(h->cfg, n_ticks, run_cap) : hk::env_rounds_for(h->cfg, n_ticks);
     if (const char* dr = std::getenv("HK_DEBUG_MAX_ROUNDS")) rounds = std::min(rounds, std::atoi(dr));     // (diagnostic: look at the state between two rounds)
     {
