@@ -65,7 +65,7 @@ def make_config(num_envs, num_agents=4, track="oval", high_mode=_lib.HK_HIGH_FIX
                 device_id=0, wiring=None, env_mode=_lib.HK_MODE_EXPERIMENT, max_episode_steps=None, laps=None,
                 stats=None, time_precision=100, section_window=2, mcts_iterations=128, mcts_initial_iterations=None,
                 mcts_latency_ticks=45, mcts_initial_latency_ticks=75, mcts_seed=0x4D435453, rewards=0, training_agents=None,
-                reward_params=None, disable_on_end=None, train_seed=0x54524149):
+                reward_params=None, disable_on_end=None, train_seed=0x54524149, velocity_bucket_size=2, max_lane_changes=None):
     tr = load_track(track) if isinstance(track, str) else track
     secs = tr["sections"]
     L = len(secs)
@@ -107,9 +107,10 @@ def make_config(num_envs, num_agents=4, track="oval", high_mode=_lib.HK_HIGH_FIX
         cfg.high_mode[i] = high_mode[i] if isinstance(high_mode, (list, tuple)) else high_mode
         cfg.low_mode[i] = low_mode[i] if isinstance(low_mode, (list, tuple)) else low_mode
         cfg.tree_search_depth[i] = tree_search_depth[i] if isinstance(tree_search_depth, (list, tuple)) else tree_search_depth
-        cfg.velocity_bucket_size[i] = 2
-        cfg.time_precision[i] = time_precision
-        cfg.section_window[i] = section_window
+        per = lambda v: v[i] if isinstance(v, (list, tuple)) else v          # gameParams are per agent (HKA:38-52)
+        cfg.velocity_bucket_size[i] = per(velocity_bucket_size)
+        cfg.time_precision[i] = per(time_precision)
+        cfg.section_window[i] = per(section_window)
     st = dict(KART_STATS)
     if stats:
         st.update(stats)
@@ -118,7 +119,7 @@ def make_config(num_envs, num_agents=4, track="oval", high_mode=_lib.HK_HIGH_FIX
     rules = tr["rules"]
     cfg.laps = int(laps if laps is not None else rules["laps"])
     cfg.max_episode_steps = int(max_episode_steps if max_episode_steps is not None else rules["maxEpisodeSteps"])
-    cfg.max_lane_changes = int(rules["MaxLaneChanges"])
+    cfg.max_lane_changes = int(rules["MaxLaneChanges"] if max_lane_changes is None else max_lane_changes)
     cfg.section_horizon = int(rules["sectionHorizon"])
     cfg.disable_on_end = int(rules["disableOnEnd"] if disable_on_end is None else disable_on_end)
     cfg.env_mode = env_mode

@@ -97,6 +97,7 @@ struct MNode {
     int pad2;
 };
 static_assert(sizeof(MNode) == 32, "MNode layout");
+constexpr int HK_MCTS_MAX_CLASSES = 2;      // distinct (velocityBucketSize, timePrecision) pairs among the MCTS agents of one handle
 struct MctsDev {
     hk_mcts_state* st;      // [E][A]; nullptr: no agent plans with MCTS
     void* req;              // [E][A] MctsReq (its size depends on GA: one kart snapshot per lane of the group)

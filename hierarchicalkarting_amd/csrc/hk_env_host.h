@@ -47,6 +47,12 @@ struct EnvDevice {
     int tab_lds = 0;               // dynamic LDS bytes the env kernels are launched with (0: read tables from global)
     // MCTS planner (hk_env_mcts.h): all null / 0 when no agent is HighMode MCTS
     MctsDev mcts{};
+    // gameParams classes: MCTS agents that share (velocityBucketSize, timePrecision) share one set of move tables; the reference's
+    // MCTS-RL vs MCTS-LQR set-ups run two classes in one env (bucket 1 against 2).  d.mcts carries class 0's tables; a search launch
+    // runs once per class with that class's tables and agent mask (flush_mcts).
+    struct MctsClass { int* dt_tab; float* load_tab; float* rad_tab; uint32_t* mask_tab; unsigned char* order_tab; int nv, ntab; uint32_t agents; };
+    MctsClass mcls[HK_MCTS_MAX_CLASSES] = {};
+    int n_mcls = 0;
     RwDev rw{};                    // reward shaping tables (null when hk_config.rewards == 0)
     int mset = 0;                  // planner queue set the tick kernel currently fills
     int mcts_rounds = 0;           // rounds of the tick kernel since the last search launch

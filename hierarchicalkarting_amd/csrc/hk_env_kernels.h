@@ -47,11 +47,20 @@ int upload(T** dst, const std::vector<T>& v, std::string& err)
 
 }  // namespace detail
 
+// point d.mcts (the kernel argument) at the move tables of gameParams class c
+inline void mcts_use_class(EnvDevice& d, int c)
+{
+    const EnvDevice::MctsClass& K = d.mcls[c];
+    d.mcts.dt_tab = K.dt_tab; d.mcts.load_tab = K.load_tab; d.mcts.rad_tab = K.rad_tab; d.mcts.mask_tab = K.mask_tab; d.mcts.order_tab = K.order_tab;
+    d.mcts.nv = K.nv; d.mcts.ntab = K.ntab;
+}
+
 inline void env_destroy(EnvDevice& d)
 {
     void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.reward_out, d.status, d.game_stats, d.games, d.queue_cnt, d.queue, d.env_ids, d.tab, d.perms,
-                    d.rw.sec_time, d.rw.sec_cnt, d.rw.hit_code, d.mcts.st, d.mcts.req, d.mcts.qcnt, d.mcts.queue, d.mcts.nodes, d.mcts.dt_tab, d.mcts.load_tab, d.mcts.rad_tab, d.mcts.mask_tab, d.mcts.order_tab, d.mcts.roots, d.sec_geo, d.perm, d.perm_counts};
+                    d.rw.sec_time, d.rw.sec_cnt, d.rw.hit_code, d.mcts.st, d.mcts.req, d.mcts.qcnt, d.mcts.queue, d.mcts.nodes, d.mcts.roots, d.sec_geo, d.perm, d.perm_counts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int c = 0; c < d.n_mcls; c++) { void* t[] = {d.mcls[c].dt_tab, d.mcls[c].load_tab, d.mcls[c].rad_tab, d.mcls[c].mask_tab, d.mcls[c].order_tab}; for (void* p : t) if (p) (void)hipFree(p); }
     d = EnvDevice{};
 }
 
@@ -326,33 +335,44 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         HK_ALLOC(d.mcts.nodes, (size_t)d.mcts.slots * d.mcts.pool_cap * sizeof(MNode));
         HK_ALLOC(d.mcts.roots, (size_t)d.mcts.slots * HK_GA_CALL(d, mcts_root_words()) * sizeof(int));
         HK_ALLOC(d.mcts.qcnt, 4 * sizeof(int));
-        // move tables: one set for the whole handle, so every MCTS agent must share bucket size and time precision
-        int ego0 = -1;
+        // move tables: one set per gameParams class (velocityBucketSize, timePrecision) of the MCTS agents
         for (int i = 0; i < A; i++) {
             if (cfg.high_mode[i] != HK_HIGH_MCTS) continue;
-            if (ego0 < 0) ego0 = i;
-            else if (cfg.velocity_bucket_size[i] != cfg.velocity_bucket_size[ego0] || cfg.time_precision[i] != cfg.time_precision[ego0]) {
-                err = "hk_create: MCTS agents with different velocityBucketSize / timePrecision are not built yet"; return HK_ERR_UNSUPPORTED;
+            int c = 0;
+            for (; c < d.n_mcls; c++) {
+                const int rep = __builtin_ctz(d.mcls[c].agents);
+                if (cfg.velocity_bucket_size[i] == cfg.velocity_bucket_size[rep] && cfg.time_precision[i] == cfg.time_precision[rep]) break;
+            }
+            if (c == d.n_mcls) {
+                if (d.n_mcls == HK_MCTS_MAX_CLASSES) { err = "hk_create: more than two (velocityBucketSize, timePrecision) classes among the MCTS agents"; return HK_ERR_UNSUPPORTED; }
+                d.n_mcls++;
+            }
+            d.mcls[c].agents |= 1u << i;
+        }
+        for (int c = 0; c < d.n_mcls; c++) {
+            EnvDevice::MctsClass& K = d.mcls[c];
+            const int ego0 = __builtin_ctz(K.agents);
+            int nv = 0;
+            for (int v = 6; v < (int)P.max_speed && nv < 5; v += cfg.velocity_bucket_size[ego0]) nv++;
+            K.nv = nv;
+            const int ntab = L * 4 * (nv + 1) * HK_MCTS_MAX_ACTIONS;
+            K.ntab = ntab;
+            HK_ALLOC(K.dt_tab, (size_t)ntab * sizeof(int));
+            HK_ALLOC(K.load_tab, (size_t)L * 4 * HK_MCTS_MAX_ACTIONS * sizeof(float));
+            HK_ALLOC(K.rad_tab, (size_t)L * 4 * 4 * sizeof(float));
+            HK_ALLOC(K.mask_tab, (size_t)(ntab / HK_MCTS_MAX_ACTIONS) * sizeof(uint32_t));
+            HK_ALLOC(K.order_tab, (size_t)ntab);
+            mcts_use_class(d, c);
+            if ((rc = HK_GA_CALL(d, launch_mcts_table(d, ego0, ntab, stream, err)))) return rc;
+            {   // the search kernel keeps the tables in LDS, dt as int16, 8 waves a workgroup: check the range and the fit
+                std::vector<int> hdt((size_t)ntab);
+                if ((e = hipMemcpyAsync(hdt.data(), K.dt_tab, (size_t)ntab * sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+                    (e = hipStreamSynchronize(stream)) != hipSuccess) { err = std::string("hk_create: move tables: ") + hipGetErrorString(e); return HK_ERR_HIP; }
+                for (int v : hdt) if (v > 32767) { err = "hk_create: a move of the discrete game takes more than 32 767 time units (timePrecision too fine for the planner's tables)"; return HK_ERR_UNSUPPORTED; }
+                if (HK_GA_CALL(d, mcts_lds_bytes(ntab, L, 4)) > 160 * 1024) { err = "hk_create: the planner's move tables do not fit the LDS (track too long)"; return HK_ERR_UNSUPPORTED; }
             }
         }
-        int nv = 0;
-        for (int v = 6; v < (int)P.max_speed && nv < 5; v += cfg.velocity_bucket_size[ego0]) nv++;
-        d.mcts.nv = nv;
-        const int ntab = L * 4 * (nv + 1) * HK_MCTS_MAX_ACTIONS;
-        HK_ALLOC(d.mcts.dt_tab, (size_t)ntab * sizeof(int));
-        HK_ALLOC(d.mcts.load_tab, (size_t)L * 4 * HK_MCTS_MAX_ACTIONS * sizeof(float));
-        HK_ALLOC(d.mcts.rad_tab, (size_t)L * 4 * 4 * sizeof(float));
-        HK_ALLOC(d.mcts.mask_tab, (size_t)(ntab / HK_MCTS_MAX_ACTIONS) * sizeof(uint32_t));
-        HK_ALLOC(d.mcts.order_tab, (size_t)ntab);
-        d.mcts.ntab = ntab;
-        if ((rc = HK_GA_CALL(d, launch_mcts_table(d, ego0, ntab, stream, err)))) return rc;
-        {   // the search kernel keeps the tables in LDS, dt as int16, 8 waves a workgroup: check the range and the fit
-            std::vector<int> hdt((size_t)ntab);
-            if ((e = hipMemcpyAsync(hdt.data(), d.mcts.dt_tab, (size_t)ntab * sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess ||
-                (e = hipStreamSynchronize(stream)) != hipSuccess) { err = std::string("hk_create: move tables: ") + hipGetErrorString(e); return HK_ERR_HIP; }
-            for (int v : hdt) if (v > 32767) { err = "hk_create: a move of the discrete game takes more than 32 767 time units (timePrecision too fine for the planner's tables)"; return HK_ERR_UNSUPPORTED; }
-            if (HK_GA_CALL(d, mcts_lds_bytes(ntab, L, 4)) > 160 * 1024) { err = "hk_create: the planner's move tables do not fit the LDS (track too long)"; return HK_ERR_UNSUPPORTED; }
-        }
+        mcts_use_class(d, 0);
     }
 #undef HK_ALLOC
     // REC.Start :148-168: every agent starts inactive; results carry episode = -1; RL branch defaults to "coast"

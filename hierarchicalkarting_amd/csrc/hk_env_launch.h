@@ -37,17 +37,20 @@ inline int launch_mcts_invalidate(EnvDevice& d, const hk_config& cfg, hipStream_
 inline int flush_mcts(EnvDevice& d, hipStream_t stream, std::string& err)
 {
     if (!d.mcts.st) return HK_OK;
-    {
+    for (int c = 0; c < d.n_mcls; c++) {          // one launch per gameParams class: its tables ride in the workgroups' LDS, its agents' entries are searched
+        const EnvDevice::MctsClass& K = d.mcls[c];
+        MctsDev M = d.mcts;
+        M.dt_tab = K.dt_tab; M.load_tab = K.load_tab; M.rad_tab = K.rad_tab; M.mask_tab = K.mask_tab; M.order_tab = K.order_tab; M.nv = K.nv; M.ntab = K.ntab;
         // one workgroup per CU, 4 waves (one per SIMD) while the grid is at most 1 024 waves, 8 beyond; the move tables ride in its LDS
         const int total_waves = (d.mcts.grid_lanes + 63) / 64;
         int waves = total_waves <= 1024 ? 4 : 8;
-        while (waves > 4 && mcts_search_lds_bytes(d.mcts.ntab, d.P.L, waves) > 160 * 1024) waves -= 2;      // (8 karts: the path arrays of 8 waves do not fit beside the tables)
-        const size_t lds = mcts_search_lds_bytes(d.mcts.ntab, d.P.L, waves);
+        while (waves > 4 && mcts_search_lds_bytes(K.ntab, d.P.L, waves) > 160 * 1024) waves -= 2;      // (8 karts: the path arrays of 8 waves do not fit beside the tables)
+        const size_t lds = mcts_search_lds_bytes(K.ntab, d.P.L, waves);
         if (!d.mcts.lds_attr_set) {
             (void)hipFuncSetAttribute((const void*)mcts_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             d.mcts.lds_attr_set = 1;
         }
-        hipLaunchKernelGGL(mcts_search_kernel, dim3((total_waves + waves - 1) / waves), dim3(waves * 64), lds, stream, d.P, d.mcts, d.mset, d.mcts.ntab);
+        hipLaunchKernelGGL(mcts_search_kernel, dim3((total_waves + waves - 1) / waves), dim3(waves * 64), lds, stream, d.P, M, d.mset, K.ntab, K.agents);
     }
     int rc = launch_check(err, "mcts_search_kernel");
     if (rc) return rc;

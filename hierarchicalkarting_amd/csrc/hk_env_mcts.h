@@ -699,12 +699,13 @@ __device__ __forceinline__ DGame mc_root_load(const int* rootl, const int stride
 // one queued search (queue entry q of `set`), its tree in the arena slice `nd`
 struct MctsTabs { const short* dt; const float* load; const float* rad; const unsigned char* flags; const uint32_t* mask; const unsigned char* order; };
 __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDev& M, const TabView& T, const MctsTabs& tabs, const int set, const int q, const int lane0,
-                                                unsigned short* path /* LDS, [MC_MAXPATH][64], this lane's column */, unsigned char* pup)
+                                                unsigned short* path /* LDS, [MC_MAXPATH][64], this lane's column */, unsigned char* pup, const uint32_t cls_agents)
 {
     const unsigned ent = (unsigned)M.queue[(size_t)set * 2 * P.E * P.A + q];
     const int pair = (int)(ent & 0xFFFFFFu);
     if (((unsigned)mc_reqs(M)[pair].gen & 0xFFu) != (ent >> 24)) return;          // superseded by a later request of the same ego
     const int env = pair / P.A, ego = pair % P.A;
+    if (!((cls_agents >> ego) & 1u)) return;                                       // another gameParams class: its own launch, with its tables
     MctsReq& R = mc_reqs(M)[pair];
     const int slot = M.persist ? pair : lane0;                                    // whose arena slice: the agent's, or the resident lane's
     MNode* nd = M.nodes + (size_t)slot * M.pool_cap;
@@ -902,7 +903,7 @@ inline size_t mcts_table_lds_bytes(int ntab, int L)
            (size_t)(ntab / MC_MAXA) * sizeof(uint32_t) + (((size_t)ntab + 15) & ~(size_t)15);
 }
 inline size_t mcts_search_lds_bytes(int ntab, int L, int waves) { return mcts_table_lds_bytes(ntab, L) + (size_t)waves * MC_PATH_BYTES; }
-__global__ HK_MC_BOUNDS void mcts_search_kernel(EnvParams P, MctsDev M, int set, int ntab)
+__global__ HK_MC_BOUNDS void mcts_search_kernel(EnvParams P, MctsDev M, int set, int ntab, uint32_t cls_agents)
 {
     extern __shared__ __align__(16) unsigned char mc_smem[];
     const int count = M.qcnt[set * 2];
@@ -932,7 +933,7 @@ __global__ HK_MC_BOUNDS void mcts_search_kernel(EnvParams P, MctsDev M, int set,
     unsigned short* path = reinterpret_cast<unsigned short*>(paths + (size_t)wave * MC_PATH_BYTES);       // [MC_MAXPATH][64]: node indices fit 16 bits
     unsigned char* pup = reinterpret_cast<unsigned char*>(path + MC_MAXPATH * 64);                         //   (hk_create refuses pools beyond 65 535 nodes)
     MctsTabs tabs = {dt_s, load_s, rad_s, flags_s, mask_s, order_s};
-    for (int q = lane0; q < count; q += gridDim.x * waves * 64) mcts_search_one(P, M, T, tabs, set, q, lane0, path + lane, pup + lane);
+    for (int q = lane0; q < count; q += gridDim.x * waves * 64) mcts_search_one(P, M, T, tabs, set, q, lane0, path + lane, pup + lane, cls_agents);
 }
 
 #undef MC_EACH

@@ -69,6 +69,24 @@ class Policy:
         return cls([init[g["in"][1]] for g in body], [init[g["in"][2]] for g in body], init[mu[0]["in"][1]], init[mu[0]["in"][2]],
                    init[ls[0]], init[br[0]["in"][1]], init[br[0]["in"][2]], mean, std, stack, deterministic, seed)
 
+    # ---- plain-array form (an .npz fixture of a trained actor: tests/golden/reference_actors.npz, tools/make_actor_fixtures.py)
+    def arrays(self, prefix=""):
+        d = {"W%d" % l: w for l, w in enumerate(self.W)}
+        d.update({"b%d" % l: x for l, x in enumerate(self.b)})
+        d.update(W_mu=self.W_mu, b_mu=self.b_mu, log_sigma=self.log_sigma, W_branch=self.W_branch, b_branch=self.b_branch)
+        if self.norm_mean is not None:
+            d.update(norm_mean=self.norm_mean, norm_std=self.norm_std)
+        return {prefix + k: v for k, v in d.items()}
+
+    @classmethod
+    def from_arrays(cls, d, prefix="", stack=4, deterministic=False, seed=0):
+        n = 0
+        while prefix + "W%d" % n in d:
+            n += 1
+        g = lambda k: d[prefix + k] if prefix + k in d else None
+        return cls([d[prefix + "W%d" % l] for l in range(n)], [d[prefix + "b%d" % l] for l in range(n)], g("W_mu"), g("b_mu"),
+                   g("log_sigma"), g("W_branch"), g("b_branch"), g("norm_mean"), g("norm_std"), stack, deterministic, seed)
+
     @classmethod
     def random(cls, in_dim, hidden, n_layers, n_branch=3, stack=4, seed=0, normalize=True, deterministic=False):
         """synthetic actor (tests / bench): Kaiming-ish weights so that activations neither vanish nor saturate"""

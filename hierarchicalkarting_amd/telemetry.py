@@ -96,16 +96,18 @@ def read_experiment_log(path):
 
 def summarize_log(records):
     """per agent type (the name up to "("): races, finishes, wins (fastest Total Time among the finishers of a race), DNFs,
-    mean Total Time / Best Lap of the finishers, collisions and illegal lane changes per race"""
+    mean Total Time / Best Lap of the finishers, collisions and illegal lane changes per race, and the plan-tracking averages
+    (KartAgent.AverageLaneDifference / AverageVelDifference, KA:226-239) over all races"""
     import statistics
     acc = {}
     for rec in records:
         fin = {n: a for n, a in rec["agents"].items() if a.get("laps", (0, 1))[0] == a.get("laps", (0, 1))[1]}
         win = min(fin, key=lambda n: fin[n]["Total Time"]) if fin else None
         for n, a in rec["agents"].items():
-            t = acc.setdefault(n.split("(")[0], {"races": 0, "wins": 0, "dnfs": 0, "total": [], "best": [], "coll": [], "illegal": []})
+            t = acc.setdefault(n.split("(")[0], {"races": 0, "wins": 0, "dnfs": 0, "total": [], "best": [], "coll": [], "illegal": [], "lane": [], "vel": []})
             t["races"] += 1
             t["coll"].append(a.get("Collisions", 0)); t["illegal"].append(a.get("Illegal Lane Changes", 0))
+            t["lane"].append(a.get("Avg Target Lane Difference", 0.0)); t["vel"].append(a.get("Avg Target Vel Difference", 0.0))
             if n in fin:
                 t["total"].append(a["Total Time"]); t["best"].append(a["Best Lap"])
             else:
@@ -115,5 +117,6 @@ def summarize_log(records):
     return {k: {"races": v["races"], "wins": v["wins"], "dnfs": v["dnfs"],
                 "mean_total_time": statistics.fmean(v["total"]) if v["total"] else None,
                 "median_best_lap": statistics.median(v["best"]) if v["best"] else None,
-                "collisions_per_race": statistics.fmean(v["coll"]), "illegal_lane_changes_per_race": statistics.fmean(v["illegal"])}
+                "collisions_per_race": statistics.fmean(v["coll"]), "illegal_lane_changes_per_race": statistics.fmean(v["illegal"]),
+                "mean_lane_difference": statistics.fmean(v["lane"]), "mean_vel_difference": statistics.fmean(v["vel"])}
             for k, v in acc.items()}
