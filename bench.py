@@ -49,7 +49,7 @@ def launch_ranks(a, argv):
     if not selftest:
         import torch                                   # device_count() does not initialise the GPU on this image
         have = torch.cuda.device_count()
-        if have < a.gpus:
+        if have < (1 if a.same_device else a.gpus):
             print("bench.py: --gpus %d needs %d GPUs, this box has %d" % (a.gpus, a.gpus, have), file=sys.stderr)
             return 2
     port = int(os.environ.get("MASTER_PORT", 29500 + (os.getpid() % 2000)))
@@ -97,7 +97,7 @@ class Dist:
     def barrier(self, env=None):
         if self.dist:
             self.dist.barrier()
-        if self.backend == "nccl":
+        if self.backend == "nccl" or self.torch.cuda.is_initialized():
             self.torch.cuda.synchronize()
         if env is not None:
             env.synchronize()
@@ -423,7 +423,26 @@ def bench_lqng(a, D, hk):
         prof_full = env.prof_read()
         games_full = env.prof_games()
         env.prof_enable(False)
+        # host-driven mode: a Unity host calls hk_step(1) per FixedUpdate, an ML-Agents loop hk_step(2) between two
+        # decisions.  From the steady state (tick 512) of a fresh race: 256 one-tick calls, then 128 two-tick calls, no getter in between.
+        env.reset()
+        env.step(STEADY_TICK)
+
+        def short_calls(n_calls, n):
+            D.barrier(env)
+            t0 = time.perf_counter()
+            for _ in range(n_calls):
+                env.step(n)
+            env.synchronize()
+            D.barrier(env)
+            return D.max_time(time.perf_counter() - t0)
+        dt_1 = short_calls(256, 1)
+        dt_2 = short_calls(128, 2)
+        dt_20 = short_calls(16, 20)
         secondary = {
+            "host_driven": {"hk_step(1)_x256_from_tick_512": {"value": E * D.world * 256 / dt_1, "unit": "env-steps/s", "us_per_call": dt_1 / 256 * 1e6},
+                            "hk_step(2)_x128_from_tick_768": {"value": E * D.world * 256 / dt_2, "unit": "env-steps/s", "us_per_call": dt_2 / 128 * 1e6},
+                            "hk_step(20)_x16_from_tick_1024": {"value": E * D.world * 320 / dt_20, "unit": "env-steps/s", "us_per_call": dt_20 / 16 * 1e6}},
             "baseline_protocol_ticks_512_3584": {"value": E * D.world * 3072 / dt_full, "unit": "env-steps/s", "seconds": dt_full,
                                                  "kernel_total_ms": {k: v[0] for k, v in prof_full.items() if v[1]},
                                                  "launches": {k: v[1] for k, v in prof_full.items() if v[1]},
@@ -478,7 +497,7 @@ def bench_lqng(a, D, hk):
             "ms_per_step": tick_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d-agent Oval, Fixed-LQNG vs Fixed-LQNG (2v2), %d parallel envs per GPU, seeded start jitter, auto-reset"
-                                   % (A, E), "envs_per_gpu": E, "agents": A, "sharding": "envs split contiguously over ranks",
+                                   % (A, E), "envs_per_gpu": E, "agents": A, "sharding": "envs split contiguously over ranks", "same_device": bool(a.same_device),
                        "ticks": "race ticks %d..%d timed (untimed before: pre-roll 0..%d to the steady state of BASELINE.md §3, then %d warm-up ticks)"
                                 % (t_first, t_first + a.steps, a.preroll, a.warmup),
                        "timed_tick_range": [t_first, t_first + a.steps],
@@ -508,6 +527,8 @@ def main():
     ap.add_argument("--mcts-iterations", type=int, default=64)
     ap.add_argument("--lq-batch", type=int, default=262144)
     ap.add_argument("--selftest-launcher", action="store_true", help="CPU check of the N-rank plumbing (gloo; no GPU, no libhk compute)")
+    ap.add_argument("--same-device", action="store_true", help="every rank on GPU 0 with gloo in place of RCCL (a rehearsal of the N-rank code on a 1-GPU box; "
+                                                                "tests/test_two_ranks_one_gpu.py): not a scaling measurement")
     ap.add_argument("--workload", choices=("lqng", "rl", "mcts", "mctsrl", "a8", "lqbatch"), default="lqng",
                     help="lqng: BASELINE.json configs[1] (the headline); rl: 2v2 Oval with the RL low-level actor on device (configs[3] shape); "
                          "mcts: 4-agent Complex track, MCTS-LQNG, 16 384 envs (configs[2]); "
@@ -532,7 +553,9 @@ def main():
     import torch
     if torch.cuda.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libhk has no CPU fallback")
-    D = Dist("nccl")
+    D = Dist("gloo" if a.same_device else "nccl")
+    if a.same_device:
+        D.local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libhk has no CPU fallback")
     import __graft_entry__ as ge

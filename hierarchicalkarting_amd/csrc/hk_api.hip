@@ -83,11 +83,39 @@ struct Prof {
 
 }  // namespace
 
+// Scheduling switches: read from the environment ONCE, in hk_create, into the handle (listed in include/hk.h).  None of them changes a
+// result bit; they exist for the A/B measurements under profiles/ and for two tests.
+struct Tuning {
+    bool eager = true;           // HK_NO_EAGER=1: no eager assembly at the end of a launch's budget (hk_env_run.h)
+    bool lazy = true;            // HK_FIXED_ROUNDS=1: every call issues the worst-case round count up front (no look at the device)
+    bool mcts_pause = true;      // HK_MCTS_NO_PAUSE=1: long calls of planner handles keep the deadline schedule
+    bool want_split = false;     // HK_SPLIT=1: the batch as two halves on two streams in every long call
+    bool no_split = false;       // HK_NO_SPLIT=1: not even while the field stands close
+    int run_cap_spread = hk::RUN_CAP_SPREAD;   // HK_RUN_CAP_SPREAD: ticks per launch of long calls on a spread field (4 .. 64)
+    int run_cap_short = 4;       // HK_RUN_CAP_SHORT: ticks per launch of short calls of plain handles
+    int regroup_rounds = hk::REGROUP_ROUNDS;   // HK_REGROUP_ROUNDS: rounds between two re-assignments of the lane groups
+    int debug_max_rounds = 0;    // HK_DEBUG_MAX_ROUNDS (diagnostic): cap on the rounds of a call, to look at the state in between
+    bool debug_no_check = false; // HK_DEBUG_NO_CHECK (diagnostic): getters do not fail on the "did not complete" flag
+    bool stamps_dump = false;    // HK_STAMPS_DUMP (diagnostic builds, -DHK_STAMPS)
+    void read()
+    {
+        auto flag = [](const char* n) { return std::getenv(n) != nullptr; };
+        auto num = [](const char* n, int dflt, int lo, int hi) { const char* e = std::getenv(n); const int v = e ? std::atoi(e) : dflt; return v >= lo && v <= hi ? v : dflt; };
+        eager = !flag("HK_NO_EAGER"); lazy = !flag("HK_FIXED_ROUNDS"); mcts_pause = !flag("HK_MCTS_NO_PAUSE");
+        want_split = flag("HK_SPLIT"); no_split = flag("HK_NO_SPLIT");
+        run_cap_spread = num("HK_RUN_CAP_SPREAD", hk::RUN_CAP_SPREAD, 4, 64);
+        run_cap_short = num("HK_RUN_CAP_SHORT", 4, 4, 64);
+        regroup_rounds = num("HK_REGROUP_ROUNDS", hk::REGROUP_ROUNDS, 1, 1 << 20);
+        debug_max_rounds = num("HK_DEBUG_MAX_ROUNDS", 0, 0, 1 << 20);
+        debug_no_check = flag("HK_DEBUG_NO_CHECK"); stamps_dump = flag("HK_STAMPS_DUMP");
+    }
+};
+
 struct hk_context {
     int device = 0;
+    Tuning tune;
     hipStream_t stream = nullptr;
-    hipStream_t qstream = nullptr;   // the solver kernels of long calls run here, beside the next round of the tick kernel (issue_rounds_overlapped)
-    hipEvent_t ev_run[2] = {nullptr, nullptr}, ev_lqn[2] = {nullptr, nullptr};
+    hipStream_t qstream = nullptr;   // the second half of a split batch runs here (issue_rounds_split)
     bool env_ready = false;
     hk_config cfg{};
     std::vector<hk_section> sections;
@@ -108,7 +136,6 @@ struct hk_context {
     // multi-player games needs and a guard kernel that reports what is left; the NEXT entry point that touches the state
     // finishes the stragglers (finish_ticks)
     bool step_pending = false;
-    bool step_overlapped = false;  // the pending call runs its solver launches on qstream (issue_rounds_overlapped)
     bool split = false;            // the current call runs the batch as two halves on two streams (issue_rounds)
     int round_half[2] = {0, 0};    // each half's own round counter (the parity picks its queue set)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -212,8 +239,10 @@ int hk_create(const hk_config* cfg, hk_handle* out)
     }
     int rc = ensure_ctx_basics(h);
     if (rc) { g_last_error = h->err; delete h; return rc; }
+    h->tune.read();
     if (cfg) {
         h->cfg = *cfg;
+        h->dev.regroup_rounds = h->tune.regroup_rounds;
         rc = hk::env_create(h->cfg, h->sections, h->walls, h->dev, h->stream, h->err);
         if (rc) { g_last_error = h->err; hk_destroy(h); return rc; }
         h->env_ready = true;
@@ -242,7 +271,6 @@ void hk_destroy(hk_handle h)
     for (hipEvent_t e : h->prof.pool) (void)hipEventDestroy(e);
     if (h->qstream) { (void)hipStreamSynchronize(h->qstream); (void)hipStreamDestroy(h->qstream); }
     if (h->ev_fork) { (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
-    for (int k = 0; k < 2; k++) { if (h->ev_run[k]) (void)hipEventDestroy(h->ev_run[k]); if (h->ev_lqn[k]) (void)hipEventDestroy(h->ev_lqn[k]); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h == g_default_ctx) g_default_ctx = nullptr;
     delete h;
@@ -389,7 +417,7 @@ static int issue_rounds_split(hk_handle h, int rounds)
         HK_HIP(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     }
     const int E = h->cfg.num_envs, mid = (E / 2 + 63) / 64 * 64;      // (a block of the tick kernel holds 64 lane groups)
-    if ((h->dev.rounds_since_regroup += rounds) >= hk::REGROUP_ROUNDS) {  // the periodic regroup by solve phase, here where the streams are joined
+    if ((h->dev.rounds_since_regroup += rounds) >= h->dev.regroup_rounds) {  // the periodic regroup by solve phase, here where the streams are joined
         int rcg = hk::env_launch_regroup(h->dev, h->cfg, h->stream, h->err);
         if (rcg) { g_last_error = h->err; return rcg; }
     }
@@ -421,47 +449,6 @@ static int issue_rounds_split(hk_handle h, int rounds)
     return rc;
 }
 
-// The same rounds with the solver on a second stream.  In a spread field a round's solver launch holds a handful of games and costs
-// one solve's latency (~40 us of an otherwise idle GPU, 8 % of the headline's wall time).  Here lqn(r) runs on `qstream` BESIDE the
-// tick kernel of round r + 1; an env that queued a game in round r sits out round r + 1 and resumes in r + 2 (EnvParams.lq_defer,
-// the queueing round rides in the env's phase word).  Queue set r & 1 is filled by run(r), read by lqn(r), and free again when
-// run(r + 2) wants it — which is the one thing the tick stream waits for.
-// MEASURED (round 2): correct (every GPU parity test passes with it) and a LOSS: 806 M env-steps/s instead of 926 M.  The hidden
-// latency (18 ms per 3 072 ticks) is outweighed by the laggards it creates — a queued game now costs its env two rounds, the
-// call needs 852 launches instead of 474 and the tick kernel's total grows from 194 to 230 ms.  Off unless HK_LQ_OVERLAP is set.
-static int issue_rounds_overlapped(hk_handle h, int rounds)
-{
-    if (!h->qstream) {
-        HK_HIP(h, hipStreamCreateWithFlags(&h->qstream, hipStreamNonBlocking));
-        for (int k = 0; k < 2; k++) {
-            HK_HIP(h, hipEventCreateWithFlags(&h->ev_run[k], hipEventDisableTiming));
-            HK_HIP(h, hipEventCreateWithFlags(&h->ev_lqn[k], hipEventDisableTiming));
-        }
-    }
-    h->dev.P.lq_defer = 1;
-    for (int r = 0; r < rounds; r++) {
-        const int k = h->dev.round & 1;
-        HK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_lqn[k], 0));            // lqn(round - 2) is done: its controls are there, set k is free
-        HK_HIP(h, hipMemsetAsync(h->dev.queue_cnt + k * 16, 0, 16 * sizeof(int), h->stream));
-        hipEvent_t e = h->prof.begin(h->stream);
-        int rc = hk::env_launch_run(h->dev, h->cfg, h->stream, h->err);
-        if (rc) { g_last_error = h->err; return rc; }
-        h->prof.end(0, e, h->stream);
-        HK_HIP(h, hipEventRecord(h->ev_run[k], h->stream));
-        HK_HIP(h, hipStreamWaitEvent(h->qstream, h->ev_run[k], 0));
-        e = h->prof.begin(h->qstream);
-        rc = hk::env_launch_lqn(h->dev, h->cfg, h->qstream, h->err);          // (advances dev.round)
-        if (rc) { g_last_error = h->err; return rc; }
-        h->prof.end(1, e, h->qstream);
-        HK_HIP(h, hipEventRecord(h->ev_lqn[k], h->qstream));
-    }
-    // what follows on the tick stream (the guard kernel, a getter's copy) sees every solve
-    HK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_lqn[0], 0));
-    HK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_lqn[1], 0));
-    h->dev.P.lq_defer = 0;
-    return HK_OK;
-}
-
 // guard kernel + (lazy mode) its report on the way to pinned host memory
 static int issue_check(hk_handle h, bool lazy)
 {
@@ -483,8 +470,7 @@ static int finish_ticks(hk_handle h)
         if (maxleft <= 0 && !waiting) { h->step_pending = false; break; }
         int rc = hk::env_launch_regroup(h->dev, h->cfg, h->stream, h->err);      // the laggards into the first lane groups
         if (rc) { g_last_error = h->err; return rc; }
-        // (deferred scheme: a queued game costs its env two rounds)
-        rc = h->step_overlapped ? issue_rounds_overlapped(h, 2 * ((maxleft + cadence - 1) / cadence) + 2) : issue_rounds(h, (maxleft + cadence - 1) / cadence + 1);
+        rc = issue_rounds(h, (maxleft + cadence - 1) / cadence + 1);
         if (rc) return rc;
         rc = issue_check(h, true);
         if (rc) return rc;
@@ -520,12 +506,11 @@ static int step_ticks(hk_handle h, int n_ticks)
     // the call), launches ALL the searches of the stretch in one batch, looks at what is left and repeats.  Without the pause
     // the requests of one replan wave trickle in over many rounds (envs that queue multi-player games advance 4 ticks a round,
     // the others 8) and every partial batch costs a full search latency: 4-agent Complex, 16 384 envs: 11.8 -> see profiles/.
-    const bool pause = planner && !short_call && h->n_policies == 0 && h->done_host != nullptr && !std::getenv("HK_MCTS_NO_PAUSE");
+    const bool pause = planner && !short_call && h->n_policies == 0 && h->done_host != nullptr && h->tune.mcts_pause;
     h->dev.P.mcts_pause = pause ? 1 : 0;
     // the eager assembly (hk_env_run.h) in pause mode too: requests are posted on the same ticks, a round earlier at most
     // (configs[2]: 61.4 -> 63.6 M env-steps/s)
-    static const bool eager_planner = std::getenv("HK_NO_EAGER") == nullptr;
-    if (planner) h->dev.P.eager = (pause && eager_planner && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4) ? 1 : 0;
+    if (planner) h->dev.P.eager = (pause && h->tune.eager && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4) ? 1 : 0;
     rc = hk::env_launch_arm(h->dev, h->cfg, n_ticks, h->stream, h->err);
     if (rc) { g_last_error = h->err; return rc; }
     if (pause) {
@@ -536,10 +521,8 @@ static int step_ticks(hk_handle h, int n_ticks)
             // a stretch: enough rounds for EVERY env to reach its next replan (<= 100 ticks away) or the end of the call, also one
             // that meets a multi-player game on every solve tick (a solve cadence per round).  The rounds in which most envs already
             // wait cost tens of microseconds; a second search launch for the late ones would cost a full search latency
-            // (HK_MCTS_STRETCH=short: the earlier rule, RUN_CAP ticks a round: 3 launches per 100 ticks instead of ~1)
             const int reach = std::min(maxleft, 100);
-            static const bool short_stretch = [] { const char* e = std::getenv("HK_MCTS_STRETCH"); return e && e[0] == 's'; }();
-            rc = issue_rounds(h, short_stretch ? std::max(2, (reach + hk::RUN_CAP - 1) / hk::RUN_CAP + 2) : (reach + cadence - 1) / cadence + 2);
+            rc = issue_rounds(h, (reach + cadence - 1) / cadence + 2);
             if (rc) return rc;
             rc = hk::env_flush_mcts(h->dev, h->stream, h->err);
             if (rc) { g_last_error = h->err; return rc; }
@@ -560,13 +543,13 @@ static int step_ticks(hk_handle h, int n_ticks)
     // multi-player games needs, and the stragglers are finished lazily by the next call that touches the state
     // (finish_ticks): most of the worst-case rounds found nothing to do, and on a 20-tick call they were 5 launches of 8.
     // (short calls — a host stepping tick by tick — keep the fixed count too: a handful of rounds, no host sync)
-    const bool lazy = !planner && h->n_policies == 0 && h->done_host != nullptr && n_ticks >= HK_LAZY_MIN_TICKS && !std::getenv("HK_FIXED_ROUNDS");
+    const bool lazy = !planner && h->n_policies == 0 && h->done_host != nullptr && n_ticks >= HK_LAZY_MIN_TICKS && h->tune.lazy;
     // ticks per launch: longer launches once the field has spread out (see RUN_CAP_SPREAD)
-    static const int spread_cap = [] { const char* e = std::getenv("HK_RUN_CAP_SPREAD"); const int v = e ? std::atoi(e) : hk::RUN_CAP_SPREAD; return v >= 4 && v <= 64 ? v : hk::RUN_CAP_SPREAD; }();
+    const int spread_cap = h->tune.run_cap_spread;
     // short calls of plain LQNG handles: one solve cadence per launch — with the eager assembly every env, in a pack or not, retires
     // it, so a 20-tick call is 6 equal rounds and no tail (at 8 ticks per launch: 3 rounds + a regroup + 5 rounds for the laggards)
-    static const int short_cap = [] { const char* e = std::getenv("HK_RUN_CAP_SHORT"); const int v = e ? std::atoi(e) : 4; return v >= 4 && v <= 64 ? v : 4; }();
-    static const bool eager = std::getenv("HK_NO_EAGER") == nullptr;
+    const int short_cap = h->tune.run_cap_short;
+    const bool eager = h->tune.eager;
     const bool plain = !planner && h->n_policies == 0;
     // (planner / actor handles keep their deadline arithmetic as it was; the 8-lane groups run the older loop without it)
     h->dev.P.eager = (eager && plain && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4) ? 1 : 0;
@@ -579,17 +562,15 @@ static int step_ticks(hk_handle h, int n_ticks)
     // each take longer, and bench.py's per-launch roofline (bytes of a launch / its duration) would no longer describe the kernel.
     // While the field stands close (BULK_TICKS after a reset of every env: every ego holds a multi-player game and a round's solver
     // launch lasts hundreds of microseconds) the split is used without being asked: race start 440 -> 458 M.
-    static const bool want_split = std::getenv("HK_SPLIT") != nullptr, no_split = std::getenv("HK_NO_SPLIT") != nullptr;
+    const bool want_split = h->tune.want_split, no_split = h->tune.no_split;
     const bool close_field = h->dev.ticks_since_reset < hk::BULK_TICKS;
-    h->split = (want_split || (close_field && !no_split)) && h->dev.P.eager && h->cfg.num_envs >= 8192 && !std::getenv("HK_LQ_OVERLAP");
+    h->split = (want_split || (close_field && !no_split)) && h->dev.P.eager && h->cfg.num_envs >= 8192;
     int rounds = lazy ? hk::env_rounds_min(h->cfg, n_ticks, run_cap) : hk::env_rounds_for(h->cfg, n_ticks);
-    if (const char* dr = std::getenv("HK_DEBUG_MAX_ROUNDS")) rounds = std::min(rounds, std::atoi(dr));     // (diagnostic: look at the state between two rounds)
+    if (h->tune.debug_max_rounds > 0) rounds = std::min(rounds, h->tune.debug_max_rounds);     // (diagnostic: look at the state between two rounds)
     {
         // the rounds every env needs at RUN_CAP ticks a round, then — the laggards packed into the first lane groups — the tail
         const int main_rounds = std::min(rounds, (n_ticks + run_cap - 1) / run_cap);
-        // (measured: a loss — see issue_rounds_overlapped — so only on request)
-        h->step_overlapped = lazy && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4 && !h->cfg.rewards && std::getenv("HK_LQ_OVERLAP") != nullptr;
-        rc = h->step_overlapped ? issue_rounds_overlapped(h, main_rounds) : issue_rounds(h, main_rounds);
+        rc = issue_rounds(h, main_rounds);
         if (rc) return rc;
         if (rounds > main_rounds) {
             if (!planner && h->n_policies == 0) {
@@ -762,7 +743,7 @@ static int check_device_status(hk_handle h)
     int st[4] = {0, 0, 0, 0};
     HK_HIP(h, hipMemcpyAsync(st, h->dev.status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     HK_HIP(h, hipStreamSynchronize(h->stream));
-    if ((st[0] & 4) && !std::getenv("HK_DEBUG_NO_CHECK")) return fail(h, HK_ERR_HIP, "hk_step: an env did not complete its ticks (internal scheduling error)");
+    if ((st[0] & 4) && !h->tune.debug_no_check) return fail(h, HK_ERR_HIP, "hk_step: an env did not complete its ticks (internal scheduling error)");
     return HK_OK;
 }
 
@@ -1038,7 +1019,7 @@ int hk_prof_games(hk_handle h, int64_t* games)
     HK_HIP(h, hipMemcpyAsync(g, h->dev.game_stats, sizeof(g), hipMemcpyDeviceToHost, h->stream));
     HK_HIP(h, hipStreamSynchronize(h->stream));
     for (int n = 0; n <= HK_MAX_AGENTS; n++) games[n] = (int64_t)g[n];
-    if (std::getenv("HK_STAMPS_DUMP")) {       // diagnostic builds (-DHK_STAMPS): the phase cycle counters of the tick kernel
+    if (h->tune.stamps_dump) {       // diagnostic builds (-DHK_STAMPS): the phase cycle counters of the tick kernel
         std::fprintf(stderr, "HK_STAMPS");
         for (int k = 16; k < 64; k++) std::fprintf(stderr, " %llu", g[k]);
         std::fprintf(stderr, "\n");

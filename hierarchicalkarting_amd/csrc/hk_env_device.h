@@ -25,6 +25,8 @@ constexpr int RUN_CAP = HK_RUN_CAP;
 constexpr int RUN_CAP_SPREAD = 12;      // ticks per env per launch (> cadence).  Measured at E = 65 536, 4-agent Oval: 8 -> 533 M env-steps/s,
                                 // 6 -> 456 M, 5 -> 408 M (misaligned with the 4-tick cadence), 16 -> 503 M, 32 -> 450 M, 128 -> 264 M: a quad that
                                 // queues a game idles its lanes until the launch ends, so long launches waste lanes
+// hk_env_state.reserved[1]: bits 0..3 the env's phase inside a tick (0 between calls), bit 4 a scheduling hint that survives calls
+constexpr int ENV_PHASE_MASK = 15, ENV_PACK_HINT = 16;
 constexpr float DEG2RAD_F = 0.0174532924f;
 constexpr float TWO_PI_F = 2.0f * HK_PI_F;
 constexpr float CAP_R = 0.45f;          // kart capsule (BaseKartClassic.prefab): radius, core segment in kart-local z
@@ -72,8 +74,6 @@ struct EnvParams {
     int mcts_iter, mcts_iter0, mcts_lat, mcts_lat0, any_mcts;
     int eager;          // 1: an env whose budget ends at a solve tick still assembles that tick's games before the launch ends (hk_env_run.h)
     int run_cap;        // ticks an env may run per launch (RUN_CAP; RUN_CAP_SPREAD for long calls on a spread field, hk_api.hip step_ticks)
-    int lq_defer;       // set per hk_step call: the solver kernels run on a second stream beside the NEXT round of the tick kernel, so an env that
-                        // queued a game in round r resumes in round r + 2 (hk_api.hip issue_rounds_overlapped)
     int mcts_pause;     // set per hk_step call: an env that requested a planner search stops at the next tick boundary until the search has run (hk_api.hip step_ticks)
     uint32_t mcts_seed;
     // reward shaping (hk_env_reward.h)

@@ -12,13 +12,6 @@
 #include "hk_env_device.h"
 #include "hk_lq_core.h"
 
-// 1: a wave of the quad tick kernel solves its own sparse 2- / 3-player games between two passes of its tick loop (hk_env_run.h),
-// and hk_step issues only the rounds a field without queued games needs, finishing stragglers lazily (hk_api.hip).
-// 0: every multi-player game goes through the queues and the solver kernels; worst-case round count up front.
-#ifndef HK_INWAVE
-#define HK_INWAVE 0
-#endif
-
 namespace hk {
 
 struct EnvDevice {
@@ -61,7 +54,8 @@ struct EnvDevice {
     SecGeo* sec_geo = nullptr;
     // lane-group -> env assignment of the tick kernel, regrouped by solve phase every REGROUP_ROUNDS rounds (hk_env_run.h)
     int* perm = nullptr;           // [E]
-    int* perm_counts = nullptr;    // [16]
+    int* perm_counts = nullptr;    // [2 * REGROUP_KEYS]: counts, cursors
+    int regroup_rounds = 48;       // rounds between two periodic re-assignments (REGROUP_ROUNDS; HK_REGROUP_ROUNDS)
     bool perm_valid = false;
     int rounds_since_regroup = 0;
     EnvParams P{};

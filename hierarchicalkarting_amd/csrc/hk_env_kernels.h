@@ -293,7 +293,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     HK_ALLOC(d.games, na * HK_GA_CALL(d, game_doubles_per_ego()) * sizeof(double));
     HK_ALLOC(d.queue_cnt, 4 * 16 * sizeof(int));
     HK_ALLOC(d.perm, (size_t)E * sizeof(int));
-    HK_ALLOC(d.perm_counts, 16 * sizeof(int));
+    HK_ALLOC(d.perm_counts, 32 * sizeof(int));
     HK_ALLOC(d.queue, 4 * HK_GA_CALL(d, queue_ints_per_set(na)) * sizeof(int));
     if (cfg.rewards) {
         d.rw.S = cfg.laps * L + 2;
@@ -456,7 +456,7 @@ inline int env_rounds_min(const hk_config& cfg, int n_ticks, int cfg_run_cap = R
 
 inline int env_launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
 {
-    if (++d.rounds_since_regroup >= REGROUP_ROUNDS) {
+    if (++d.rounds_since_regroup >= d.regroup_rounds) {
         d.rounds_since_regroup = 0;
         int rc = HK_GA_CALL(d, launch_regroup(d, cfg, stream, err));
         if (rc) return rc;

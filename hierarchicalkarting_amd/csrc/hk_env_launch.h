@@ -76,7 +76,7 @@ inline int launch_regroup(EnvDevice& d, const hk_config& cfg, hipStream_t stream
 {
     if (cfg.num_agents <= 2 || !d.perm) return HK_OK;
     const int E = cfg.num_envs;
-    if (hipMemsetAsync(d.perm_counts, 0, 16 * sizeof(int), stream) != hipSuccess) { err = "regroup memset"; return HK_ERR_HIP; }
+    if (hipMemsetAsync(d.perm_counts, 0, 32 * sizeof(int), stream) != hipSuccess) { err = "regroup memset"; return HK_ERR_HIP; }
     hipLaunchKernelGGL(env_regroup_count_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, d.envs, E, d.perm_counts);
     hipLaunchKernelGGL(env_regroup_scatter_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, d.envs, E, d.perm_counts, d.perm);
     d.perm_valid = true;

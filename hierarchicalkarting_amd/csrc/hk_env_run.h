@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void env_check_kernel(const hk_env_state* envs
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= E) return;
-    const int left = envs[env].reserved[0], phase = envs[env].reserved[1];
+    const int left = envs[env].reserved[0], phase = envs[env].reserved[1] & ENV_PHASE_MASK;
     if (left != 0 || phase != 0) {
         if (!lazy) atomicOr(status, 4);          // sticky error for the getters (fixed-rounds mode)
         // what the lazy completion of hk_step needs (hk_api.hip finish_ticks): the host cleared both words before this launch
@@ -47,22 +47,28 @@ __global__ __launch_bounds__(256) void env_check_kernel(const hk_env_state* envs
 // change while the call runs.  Envs are independent, so which lanes run an env changes nothing but the speed.
 // Second use (round 2): the tail of a call.  Envs that met multi-player games lag behind, and the last rounds of an hk_step run for
 // them alone — scattered one or two to a wave, each such wave costing full ticks.  The key therefore also says whether an env is done
-// with the call (keys 4..7): unfinished envs are packed, by phase, into the first lane groups; blocks that hold only finished envs
+// with the call (keys 8..15): unfinished envs are packed, by phase, into the first lane groups; blocks that hold only finished envs
 // leave at once.  (A 20-tick call at 8 ticks per launch: 8 rounds of which 5 are tail; with the eager assembly short calls have none.)
+// Third use (round 3): packs.  An env whose karts race within 8 m of each other queues a multi-player game at (nearly) every solve
+// tick and leaves the launch there; scattered one to a wave, such envs left their 15 wave neighbours' lanes... running, but their own
+// idle for the rest of the launch, and the wave no shorter (in-kernel stamps: 22 % of the wave time was lanes waiting for the other
+// lane groups of their wave).  The tick kernel therefore leaves a hint in the env's phase word — did its last solve tick queue a game —
+// and the key carries it (keys 4..7): packs share waves with packs, which leave their launches together.
 __device__ __forceinline__ int regroup_key(const hk_env_state& e)
 {
     const int left = e.reserved[0];
-    return ((e.episode_steps + left) & 3) + ((left == 0 && e.reserved[1] == 0) ? 4 : 0);
+    return ((e.episode_steps + left) & 3) + ((e.reserved[1] & ENV_PACK_HINT) ? 4 : 0) + ((left == 0 && (e.reserved[1] & ENV_PHASE_MASK) == 0) ? 8 : 0);
 }
 // Both kernels aggregate per block: the waves' ballots go through LDS, then threads 0..7 issue ONE atomic per key, side by side
 // (per-wave atomics with their return values in series made the pair 125 us for 65 536 envs: 6 % of a 20-tick call).
-struct RegroupLds { int cnt[4][8]; int base[8]; };
+constexpr int REGROUP_KEYS = 16;
+struct RegroupLds { int cnt[4][REGROUP_KEYS]; int base[REGROUP_KEYS]; };
 __device__ __forceinline__ int regroup_block_counts(RegroupLds& L, int key, int& lane_rank)
 {   // fills L.cnt[wave][k]; returns nothing useful for key < 0; lane_rank = rank of this lane among its wave's lanes of the same key
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     lane_rank = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < REGROUP_KEYS; k++) {
         const unsigned long long m = __ballot(key == k);
         if (lane == 0) L.cnt[wave][k] = __popcll(m);
         if (key == k) lane_rank = __popcll(m & ((1ull << lane) - 1ull));
@@ -70,14 +76,14 @@ __device__ __forceinline__ int regroup_block_counts(RegroupLds& L, int key, int&
     __syncthreads();
     return wave;
 }
-__global__ __launch_bounds__(256) void env_regroup_count_kernel(const hk_env_state* envs, int E, int* counts /*[16]: 8 counts, 8 cursors*/)
+__global__ __launch_bounds__(256) void env_regroup_count_kernel(const hk_env_state* envs, int E, int* counts /*[2 * REGROUP_KEYS]: counts, cursors*/)
 {
     __shared__ RegroupLds L;
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     const int key = env < E ? regroup_key(envs[env]) : -1;
     int rank;
     (void)regroup_block_counts(L, key, rank);
-    if (threadIdx.x < 8) {
+    if (threadIdx.x < REGROUP_KEYS) {
         const int k = threadIdx.x;
         const int tot = L.cnt[0][k] + L.cnt[1][k] + L.cnt[2][k] + L.cnt[3][k];
         if (tot) atomicAdd(&counts[k], tot);
@@ -90,12 +96,12 @@ __global__ __launch_bounds__(256) void env_regroup_scatter_kernel(const hk_env_s
     const int key = env < E ? regroup_key(envs[env]) : -1;
     int rank;
     const int wave = regroup_block_counts(L, key, rank);
-    if (threadIdx.x < 8) {
+    if (threadIdx.x < REGROUP_KEYS) {
         const int k = threadIdx.x;
         const int tot = L.cnt[0][k] + L.cnt[1][k] + L.cnt[2][k] + L.cnt[3][k];
         int start = 0;                                   // where key k begins in perm: the counts of the keys before it
         for (int j = 0; j < k; j++) start += counts[j];
-        L.base[k] = start + (tot ? atomicAdd(&counts[8 + k], tot) : 0);
+        L.base[k] = start + (tot ? atomicAdd(&counts[REGROUP_KEYS + k], tot) : 0);
     }
     __syncthreads();
     if (key >= 0) {
@@ -121,21 +127,6 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
     MctsDev M{};
     if (HAS_MCTS) M = Marg;
     __shared__ KartS ks[256];
-#if HK_GA == 4 && HK_INWAVE
-    __shared__ InWaveLds inw[4];         // per-wave slices of the in-wave solver
-#endif
-#ifdef HK_DUMMY_SCRATCH
-    if (P.E < 0) {                                     // kernel-variant experiment: what does the scratch frame size alone cost? (never true)
-        volatile int big[HK_DUMMY_SCRATCH / 4];
-        for (int k = 0; k < HK_DUMMY_SCRATCH / 4; k++) big[k] = k * P.A;
-        status[1] = big[(threadIdx.x * 13 + P.L) % (HK_DUMMY_SCRATCH / 4)];
-    }
-#endif
-#ifdef HK_DUMMY_LDS
-    __shared__ int dummy_lds[HK_DUMMY_LDS / 4];        // kernel-variant experiment: what does the LDS footprint alone cost?
-    if (P.E < 0) dummy_lds[threadIdx.x] = P.A;         // (never true; keeps the array alive)
-    if (P.E < -1) status[0] = dummy_lds[(threadIdx.x * 7) % (HK_DUMMY_LDS / 4)];
-#endif
     extern __shared__ __align__(16) unsigned char smem[];
     // this launch runs the lane groups [slot0, slot1) and uses the queue sets qbase, qbase + 1 (one launch for every env: 0, E, 0;
     // plain handles split the batch in two halves on two streams so that one half's solver launch hides behind the other's ticks)
@@ -148,242 +139,123 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
     const int set = qbase + (round & 1);
     int* queue_cnt = queue_cnt_all + set * 16;
     int* queue = queue_all + (size_t)set * (GA - 1) * P.E * P.A;
-    // (with the solver on its own stream the other set is still being read: the host clears this launch's set before it instead)
-    if (!P.lq_defer && blockIdx.x == 0 && threadIdx.x < 16) queue_cnt_all[(set ^ 1) * 16 + threadIdx.x] = 0;
-#if HK_GA != 4 || defined(HK_OLD_LOOP)
-    // (lane groups of 8: the loop as it was before the in-wave path existed — nothing to gain there, and with the wave-uniform
-    // form below the 8-lane build decoded single-player controls with a wrong final_steer: unexplained, so not used)
+    if (blockIdx.x == 0 && threadIdx.x < 16) queue_cnt_all[(set ^ 1) * 16 + threadIdx.x] = 0;
     hk_env_state es;
     if (env_ok) es = envs[env];
     else { es.episode_steps = 0; es.inactive_mask = 0; es.experiment_num = 0; es.episodes_done = 0; es.status = 0; es.initial_started = 0; es.reserved[0] = 0; es.reserved[1] = 0; }
-    int left = es.reserved[0];
-    int phase = es.reserved[1] & 15;           // (bits 4..: the round in which the env queued its game, read by the deferred scheme)
     // nothing to do in this block? (every env finished its ticks): skip the table staging too
-    if (__syncthreads_or(left > 0 || phase != 0) == 0) return;
+    if (__syncthreads_or(es.reserved[0] > 0 || (es.reserved[1] & ENV_PHASE_MASK) != 0) == 0) return;
     const TabView T = tab_stage<TAB_LDS>(P, smem);
     const int cadence = P.A > 2 ? 4 : 1;
     const uint32_t all_mask = (1u << P.A) - 1u;
     int budget = P.run_cap;
-    bool dirty = false;
     hk_agent_state* arec = (env_ok && i < P.A) ? &agents[(size_t)env * P.A + i] : nullptr;
+    const LaneCfg LC = lane_cfg(P, i);                   // this lane's agent: modes and player list, read once
+    int left = es.reserved[0];
+    int phase = es.reserved[1] & ENV_PHASE_MASK;         // 0: at a tick boundary; 1: phases A / B1 of a tick done, waiting for (or holding) its controls
+    bool pack = (es.reserved[1] & ENV_PACK_HINT) != 0;   // did the env's last solve tick queue a multi-player game (regroup_key)
+    bool dirty = false;
     Hot h;
     if (arec) h = load_hot(arec); else { Hot z = {}; h = z; }
+#ifdef HK_STAMPS
+    for (int k = 0; k < HK_NSTAMP; k++) h.st_acc[k] = 0;
+    h.st_t = __builtin_readcyclecounter();
+#endif
     float hfx, hfz;                                      // the kart's forward, carried across ticks (changes only when yaw does)
     hk_sincosf(h.yaw, &hfx, &hfz);
-    const LaneCfg LC = lane_cfg(P, i);                   // this lane's agent: modes and player list, read once
     RwAcc rwv = {0.0f, 0.0f, 0.0f};
     if (HAS_RW && P.rewards && arec) { rwv.cum = arec->cum_reward; rwv.step = arec->step_reward; rwv.group = arec->group_reward; }
+    HK_ST(h, 0);                       // [0] prologue: (table staging,) state load
     // P.mcts_pause (long hk_step calls of planner handles): an env with a requested, not yet run search waits at the tick boundary —
     // the host launches the searches of a whole stretch of rounds in ONE batch (a launch lasts as long as one search however few it holds)
     bool held = HAS_MCTS && P.mcts_pause && env_ok && group_or(mcts_search_outstanding(P, M, env, i) ? 1 : 0) != 0;
-    while (env_ok && (phase != 0 || (left > 0 && budget > 0 && !held))) {
-        dirty = true;
-        if (phase == 0) {
-            const bool parked = phase_begin<HAS_RW, HAS_TRAIN>(P, env, i, env_ok, es, h, hfx, hfz, agents, results, M, mset, RD, rwv, act_branch);
-            int qn = 0;              // player count of the multi-player game this ego assembled on this tick (0: none)
-            if (!parked) {
-                const bool act = (es.episode_steps % cadence) == 0 &&                                  // HKA:317 (Q9)
-                                 !(!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u)) &&
-                                 !(P.hold_dedupe && es.episode_steps > cadence && es.episode_steps < P.hold);
-                qn = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
-                // bin the queued games by player count, one atomic per wave and count
-#pragma unroll
-                for (int n = 2; n <= GA; n++) {
-                    const int pos = wave_agg_inc(&queue_cnt[n], qn == n);
-                    if (qn == n) queue[(size_t)(n - 2) * P.E * P.A + pos] = env * P.A + i;
-                }
-                if (M.st) phase_plan(P, M, mset, env, i, es, h.flags, h.section_index, h.lane, h.lane_changes, h.final_steer, arec);
-                // requests are posted on replan ticks (phase_plan) and on the reset tick (phase_begin): look again after those
-                if (HAS_MCTS && P.mcts_pause && es.episode_steps % 100 == 0) held = group_or(mcts_search_outstanding(P, M, env, i) ? 1 : 0) != 0;
-            } else {
-                left -= 1; budget -= 1;         // a parked env lets the tick pass
-                continue;
-            }
-            // does any ego of this env wait for a multi-player solve?
-            if (group_or(qn ? 1 : 0)) { phase = 1; break; }
-        }
-        phase_move<HAS_RW, HAS_TRAIN>(P, T, env, i, env_ok, es, h, hfx, hfz, agents, act_steer, act_branch, M.st, RD, rwv, LC.low_mode, LC.high_mode);
-        phase = 0;
-        left -= 1; budget -= 1;
+    // Eager assembly (P.eager, cadence 4).  A budget that ends on a solve tick would leave that tick's games to the NEXT launch:
+    // an env that then meets a multi-player game parks at once and sits out the whole launch.  Instead the budget is trimmed so
+    // that it ends on a solve tick (first launch of a call, after a reset), and the env runs phases A / B1 of that tick before
+    // the launch ends: its games go to this round's solver launch, and every env — racing alone or in a pack — advances one
+    // cadence per round at least.  The env waits in phase 1 ("controls ready"), exactly as if it had queued a game.
+    // (es.episode_steps is the index of the tick last BEGUN: phase_begin increments it.  An env at a tick boundary runs ticks
+    // e + 1 .. e + budget, one resuming its parked tick e runs e .. e + budget - 1; the tick after those should be a solve tick.)
+    if (P.eager && cadence > 1) {
+        const int over = (es.episode_steps + budget + (phase == 0 ? 1 : 0)) % cadence;
+        if (over < budget) budget -= over;
     }
+    bool eager_it = false;           // this iteration is the assembly-only one at the end of the budget
+    // The loop is wave-uniform: a lane group whose env has nothing (more) to run in this launch stays in it, idle.  `go` depends on
+    // the env's words only, so a lane group is in or out as a whole, and the group-wide exchanges below (group_get / group_or:
+    // DPP quad permutes, which read 0 from a lane that is switched off) always run with whole groups.
+    bool go = env_ok && (phase != 0 || (left > 0 && budget > 0 && !held));
+    while (__ballot(go) != 0ull) {
+        int qn = 0;                  // player count of the multi-player game this ego assembled on this tick (0: none)
+        bool began = false;          // this env ran phases A / B1 in this iteration (it was at a tick boundary and not parked)
+        bool solved = false;         // ... and the tick was a solve tick
+        bool moving = go;            // this env runs phase C in this iteration
+        if (go) {
+            dirty = true;
+            if (phase == 0) {
+                const bool parked = phase_begin<HAS_RW, HAS_TRAIN>(P, env, i, env_ok, es, h, hfx, hfz, agents, results, M, mset, RD, rwv, act_branch);
+                HK_ST(h, 1);               // [1] phase A: episode controller + kart-vs-kart rays
+                if (!parked) {
+                    // Start hold (REC:721-744): the karts cannot move before episodeSteps reaches `hold`, nothing a solve reads changes, and
+                    // each SolveLQR overwrites the controls of the one before: the solves after the first cadence of the hold
+                    // (ticks 0 and `cadence`: the reset tick of an auto-reset, the first solve tick after hk_reset) would decode
+                    // bit-identical controls and are skipped (P.hold_dedupe: no planner whose first plan lands inside the hold,
+                    // and the host has not written kart states by hand).  18 of the 128 solve ticks of a race start.
+                    const bool act = (es.episode_steps % cadence) == 0 &&                                  // HKA:317 (Q9)
+                                     !(!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u)) &&
+                                     !(P.hold_dedupe && es.episode_steps > cadence && es.episode_steps < P.hold);
+                    qn = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
+                    began = true;
+                    solved = act;
+                } else {
+                    left -= 1; budget -= 1;         // a parked env lets the tick pass
+                    moving = false;
+                }
+            }
+        }
+        if (began) {
+            // bin the games for the solver kernels by player count, one atomic per wave and count
+#pragma unroll
+            for (int n = 2; n <= GA; n++) {
+                const int pos = wave_agg_inc(&queue_cnt[n], qn == n);
+                if (qn == n) queue[(size_t)(n - 2) * P.E * P.A + pos] = env * P.A + i;
+            }
+            if (M.st) phase_plan(P, M, mset, env, i, es, h.flags, h.section_index, h.lane, h.lane_changes, h.final_steer, arec);
+            // requests are posted on replan ticks (phase_plan) and on the reset tick (phase_begin): look again after those
+            if (HAS_MCTS && P.mcts_pause && es.episode_steps % 100 == 0) held = group_or(mcts_search_outstanding(P, M, env, i) ? 1 : 0) != 0;
+            HK_ST(h, 6);           // [6] queue binning (+ planner hooks)
+            // does any ego of this env wait for a queued multi-player solve?  (or was this the assembly at the end of the budget)
+            const bool queued = group_or(qn ? 1 : 0) != 0;
+            if (solved) pack = queued;
+            if (queued || eager_it) { phase = 1; moving = false; go = false; }
+        }
+        if (moving) {
+            phase_move<HAS_RW, HAS_TRAIN>(P, T, env, i, env_ok, es, h, hfx, hfz, agents, act_steer, act_branch, M.st, RD, rwv, LC.low_mode, LC.high_mode);
+            phase = 0;
+            left -= 1; budget -= 1;
+        }
+        {
+            // the assembly-only iteration at the end of the budget (see above) is taken once, by an env that just ran out of budget on a
+            // solve tick; it ends the env's part in this launch
+            const bool again = left > 0 && budget > 0 && !held;
+            const bool last = P.eager != 0 && cadence > 1 && !eager_it && phase == 0 && left > 0 && budget <= 0 && !held && ((es.episode_steps + 1) % cadence) == 0;
+            go = go && !eager_it && (again || last);
+            eager_it = last;
+        }
+    }
+    HK_ST(h, 13);                      // [13] waiting for the other lane groups of the wave to leave the loop
     if (arec && dirty) {
         store_hot(arec, h);
         if (HAS_RW && P.rewards) { arec->cum_reward = rwv.cum; arec->step_reward = rwv.step; arec->group_reward = rwv.group; }
     }
     if (env_ok && dirty && i == 0) {
         es.reserved[0] = left;
-        es.reserved[1] = phase ? (phase | (round << 4)) : 0;
+        es.reserved[1] = phase | (pack ? ENV_PACK_HINT : 0);
         envs[env] = es;
-    }
-}
-
-#else
-    hk_env_state es;
-    if (env_ok) es = envs[env];
-    else { es.episode_steps = 0; es.inactive_mask = 0; es.experiment_num = 0; es.episodes_done = 0; es.status = 0; es.initial_started = 0; es.reserved[0] = 0; es.reserved[1] = 0; }
-    // nothing to do in this block? (every env finished its ticks): skip the table staging too
-    if (__syncthreads_or(es.reserved[0] > 0 || es.reserved[1] != 0) == 0) return;
-    const TabView T = tab_stage<TAB_LDS>(P, smem);
-    const int cadence = P.A > 2 ? 4 : 1;
-    const uint32_t all_mask = (1u << P.A) - 1u;
-    int budget = P.run_cap;
-    hk_agent_state* arec = (env_ok && i < P.A) ? &agents[(size_t)env * P.A + i] : nullptr;
-    const LaneCfg LC = lane_cfg(P, i);                   // this lane's agent: modes and player list, read once
-#ifdef HK_STAMPS
-    unsigned st_sum[HK_NSTAMP];
-    for (int k = 0; k < HK_NSTAMP; k++) st_sum[k] = 0;
-#endif
-    // One pass = load the state, run the tick loop, store the state.  A wave that meets a few multi-player games (see
-    // inwave_solve) ends its pass right after the assembly of that tick, with every env it holds parked at "controls ready"
-    // (phase 1, the same state in which an env waits for the solver kernels between two launches), solves the games itself,
-    // and makes another pass.  Nothing but a handful of words is live across the solve, so the solver's registers and the tick
-    // loop's do not compete (with the solve inside the loop body the tick loop lost a third of its speed to spills).
-    for (bool first = true;; first = false) {
-        if (!first && env_ok) es = envs[env];
-        int left = es.reserved[0];
-        int phase = es.reserved[1] & 15;
-        // Deferred scheme (P.lq_defer): the solver of round r runs beside the tick kernel of round r + 1, so an env that queued a game
-        // in round r sits out round r + 1 and resumes in r + 2, when its controls are there (bits 4.. of the word: the queueing round)
-        const bool not_yet = P.lq_defer && phase == 1 && (round - (es.reserved[1] >> 4)) < 2;
-        bool dirty = false;
-        Hot h;
-        if (arec) h = load_hot(arec); else { Hot z = {}; h = z; }
-#ifdef HK_STAMPS
-        for (int k = 0; k < HK_NSTAMP; k++) h.st_acc[k] = 0;
-        h.st_t = __builtin_readcyclecounter();
-#endif
-        float hfx, hfz;                                      // the kart's forward, carried across ticks (changes only when yaw does)
-        hk_sincosf(h.yaw, &hfx, &hfz);
-        RwAcc rwv = {0.0f, 0.0f, 0.0f};
-        if (HAS_RW && P.rewards && arec) { rwv.cum = arec->cum_reward; rwv.step = arec->step_reward; rwv.group = arec->group_reward; }
-        HK_ST(h, 0);                       // [0] pass prologue: (table staging,) state load
-        unsigned long long inw2 = 0ull, inw3 = 0ull;         // lanes whose 2- / 3-player game this wave solves itself after the pass
-        // The loop is wave-uniform: a lane group whose env has nothing (more) to run in this launch stays in it, idle.
-        // phase 1 = the env waits for the solver KERNELS (it resumes in the next launch, i.e. in the first pass of a launch);
-        // phase 2 = parked by this wave for its own solve (it resumes in the pass right after it)
-        const bool resume = (first ? phase != 0 : phase == 2) && !not_yet;
-        if (resume) phase = 1;
-        // P.mcts_pause (long hk_step calls of planner handles): an env with a requested, not yet run search waits at the tick boundary —
-        // the host launches the searches of a whole stretch of rounds in ONE batch (a launch lasts as long as one search however few it holds)
-        bool held = HAS_MCTS && P.mcts_pause && env_ok && group_or(mcts_search_outstanding(P, M, env, i) ? 1 : 0) != 0;
-        // Eager assembly (P.eager, cadence 4).  A budget that ends on a solve tick would leave that tick's games to the NEXT launch:
-        // an env that then meets a multi-player game parks at once and sits out the whole launch.  Instead the budget is trimmed so
-        // that it ends on a solve tick (first launch of a call, after a reset), and the env runs phases A / B1 of that tick before
-        // the launch ends: its games go to this round's solver launch, and every env — racing alone or in a pack — advances one
-        // cadence per round at least.  The env waits in phase 1 ("controls ready"), exactly as if it had queued a game.
-        // (es.episode_steps is the index of the tick last BEGUN: phase_begin increments it.  An env at a tick boundary runs ticks
-        // e + 1 .. e + budget, one resuming its parked tick e runs e .. e + budget - 1; the tick after those should be a solve tick.)
-        if (P.eager && cadence > 1 && first) {
-            const int over = (es.episode_steps + budget + (phase == 0 ? 1 : 0)) % cadence;
-            if (over < budget) budget -= over;
-        }
-        bool eager_it = false;           // this iteration is the assembly-only one at the end of the budget
-        bool go = env_ok && (resume || (phase == 0 && left > 0 && budget > 0 && !held));
-        while (__ballot(go) != 0ull) {
-            int qn = 0;                  // player count of the multi-player game this ego assembled on this tick (0: none)
-            bool began = false;          // this env ran phases A / B1 in this iteration (it was at a tick boundary and not parked)
-            bool moving = go;            // this env runs phase C in this iteration
-            if (go) {
-                dirty = true;
-                if (phase == 0) {
-                    const bool parked = phase_begin<HAS_RW, HAS_TRAIN>(P, env, i, env_ok, es, h, hfx, hfz, agents, results, M, mset, RD, rwv, act_branch);
-                    HK_ST(h, 1);               // [1] phase A: episode controller + kart-vs-kart rays
-                    if (!parked) {
-                        // Start hold (REC:721-744): the karts cannot move before episodeSteps reaches `hold`, nothing a solve reads changes, and
-                        // each SolveLQR overwrites the controls of the one before: the solves after the first cadence of the hold
-                        // (ticks 0 and `cadence`: the reset tick of an auto-reset, the first solve tick after hk_reset) would decode
-                        // bit-identical controls and are skipped (P.hold_dedupe: no planner whose first plan lands inside the hold,
-                        // and the host has not written kart states by hand).  18 of the 128 solve ticks of a race start.
-                        const bool act = (es.episode_steps % cadence) == 0 &&                                  // HKA:317 (Q9)
-                                         !(!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u)) &&
-                                         !(P.hold_dedupe && es.episode_steps > cadence && es.episode_steps < P.hold);
-                        qn = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
-                        began = true;
-                    } else {
-                        left -= 1; budget -= 1;         // a parked env lets the tick pass
-                        moving = false;
-                    }
-                }
-            }
-            bool inw = false;
-#if HK_GA == 4 && HK_INWAVE
-            {
-                // 2-player games: always solved by the wave itself; 3-player games: when it holds few of them (see inwave_solve)
-                const unsigned long long m2 = __ballot(qn == 2), m3 = __ballot(qn == 3);
-                const bool do3 = __popcll(m3) <= INW_MAX3;
-                inw2 = m2; inw3 = do3 ? m3 : 0ull;
-                inw = __builtin_expect((inw2 | inw3) != 0ull, 0);
-                if (qn == 2 || (do3 && qn == 3)) qn = 0;
-            }
-#endif
-            if (began) {
-                // bin the games for the solver kernels by player count, one atomic per wave and count
-#pragma unroll
-                for (int n = 2; n <= GA; n++) {
-                    const int pos = wave_agg_inc(&queue_cnt[n], qn == n);
-                    if (qn == n) queue[(size_t)(n - 2) * P.E * P.A + pos] = env * P.A + i;
-                }
-                if (M.st) phase_plan(P, M, mset, env, i, es, h.flags, h.section_index, h.lane, h.lane_changes, h.final_steer, arec);
-                // requests are posted on replan ticks (phase_plan) and on the reset tick (phase_begin): look again after those
-                if (HAS_MCTS && P.mcts_pause && es.episode_steps % 100 == 0) held = group_or(mcts_search_outstanding(P, M, env, i) ? 1 : 0) != 0;
-                HK_ST(h, 6);           // [6] queue binning (+ planner hooks)
-                // does any ego of this env wait for a queued multi-player solve?  (or was this the assembly at the end of the budget)
-                if (group_or(qn ? 1 : 0) || eager_it) { phase = 1; moving = false; go = false; }
-            }
-            if (inw) {
-                if (moving) phase = 2;     // every env of the wave that is mid-tick: phases A / B1 done, controls in its record
-                break;
-            }
-            if (moving) {
-                phase_move<HAS_RW, HAS_TRAIN>(P, T, env, i, env_ok, es, h, hfx, hfz, agents, act_steer, act_branch, M.st, RD, rwv, LC.low_mode, LC.high_mode);
-                phase = 0;
-                left -= 1; budget -= 1;
-            }
-            {
-                // the assembly-only iteration at the end of the budget (see above) is taken once, by an env that just ran out of budget on a
-                // solve tick; it ends the env's part in this launch
-                const bool again = left > 0 && budget > 0 && !held;
-                const bool last = P.eager != 0 && cadence > 1 && !eager_it && phase == 0 && left > 0 && budget <= 0 && !held && ((es.episode_steps + 1) % cadence) == 0;
-                go = go && !eager_it && (again || last);
-                eager_it = last;
-            }
-        }
-        HK_ST(h, 13);                      // [13] waiting for the other lane groups of the wave to leave the loop
-#ifdef HK_STAMPS
-        for (int k = 0; k < HK_NSTAMP; k++) st_sum[k] += h.st_acc[k];
-#endif
-        if (arec && dirty) {
-            store_hot(arec, h);
-            if (HAS_RW && P.rewards) { arec->cum_reward = rwv.cum; arec->step_reward = rwv.step; arec->group_reward = rwv.group; }
-        }
-        if (env_ok && dirty && i == 0) {
-            es.reserved[0] = left;
-            es.reserved[1] = phase ? (phase | (round << 4)) : 0;
-            envs[env] = es;
-        }
-        if ((inw2 | inw3) == 0ull) break;
-#if HK_GA == 4 && HK_INWAVE
-        // the games (GameSoA) and the records were written by the wave's own lanes: make them visible to the others, solve,
-        // and make the controls visible to the egos' lanes again
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        {
-            InWaveLds& IW = inw[threadIdx.x >> 6];
-            const int my_game = env_ok ? env * P.A + i : 0;
-            if (inw2) inwave_solve2(inw2, env, P, agents, games, dbg_out, status);
-            if (inw3) inwave_solve<3, 1>(inw3, my_game, P, agents, games, IW.g, IW.c, dbg_out, status);
-            if ((threadIdx.x & 63) == 0) {                                                         // hk_prof_games
-                if (inw2) atomicAdd(&stats[2], (unsigned long long)__popcll(inw2));
-                if (inw3) atomicAdd(&stats[3], (unsigned long long)__popcll(inw3));
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#endif
     }
 #ifdef HK_STAMPS
     for (int k = 0; k < HK_NSTAMP; k++) {
-        unsigned v = st_sum[k];
+        unsigned v = h.st_acc[k];
         for (int o = 32; o > 0; o >>= 1) { const unsigned w = (unsigned)__shfl_xor((int)v, o, 64); v = w > v ? w : v; }
         if ((threadIdx.x & 63) == 0 && v) atomicAdd(&stats[16 + k], (unsigned long long)v);
     }
@@ -391,5 +263,4 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
 #endif
 }
 
-#endif
 } }  // namespace hk::HK_GA_NS

@@ -724,87 +724,6 @@ __device__ __forceinline__ void lqn_body(const int block, const int nblocks, con
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// In-wave path of the tick kernel (quads only).  Queueing a multi-player game costs its env a round: it leaves the tick loop,
-// waits for the solver kernels and resumes in the next launch, four ticks behind everyone else — and the rounds that only
-// serve such stragglers run at one wave's latency with a sixteenth of the lanes.  So a wave solves what it can itself, between
-// two passes of its tick loop (hk_env_run.h):
-//   2-player games (two karts within 8 m: the start grid's row mates, every overtake — by far the most common kind): always,
-//     by the quad of their own env, in registers (hk_lq2_quad.h), the quads of a wave side by side;
-//   3-player games: when the wave holds at most INW_MAX3 of them, one at a time on 12 lanes with the lq_solve_game<3> core in a
-//     per-wave LDS slice, wave-scope fences instead of workgroup barriers;
-//   everything else goes through the queues to the solver kernels.
-// ---------------------------------------------------------------------------------------------------------------
-#ifndef HK_INWAVE_CALL
-#define HK_INWAVE_CALL __attribute__((noinline))
-#endif
-#ifndef HK_INWAVE_MAX3
-#define HK_INWAVE_MAX3 8
-#endif
-constexpr int INW_MAX3 = HK_INWAVE_MAX3;
-struct __attribute__((aligned(16))) InWaveLds { LqGameLds<3> g[1]; CostRows<3> c[1]; };
-
-#if HK_GA == 4
-#include "hk_lq2_quad.h"
-
-// every 2-player game of the wave (mask: the egos' lanes), each by the quad of its env; every lane of the wave must call this
-__device__ __forceinline__ void inwave_solve2(const unsigned long long mask, const int env, const EnvParams& P, hk_agent_state* agents,
-                                              const GameSoA games, hk_lq_debug* dbg_out, int* status)
-{
-    const int lane = threadIdx.x & 63;
-    const unsigned mine = (unsigned)((mask >> (lane & ~3)) & 0xFull);      // this quad's egos (quad-uniform)
-#pragma unroll 1
-    for (int e = 0; e < 4; e++) {
-        if (!((mine >> e) & 1u)) continue;
-        const int game = env * P.A + e;
-        double u0[2];
-        int singular = 0;
-        lq2_quad_solve(game, lane & 3, (double)P.dt, games, u0, singular);
-        if ((lane & 3) == 0) {
-            if (singular) atomicOr(status, 1);
-            hk_agent_state* me = &agents[game];
-            uint32_t fl = me->flags; float st = me->steering;
-            decode_controls(me->final_steer, fl, st, u0[0], u0[1], (dbg_out && (P.debug & 1)) ? &dbg_out[game] : nullptr);
-            me->flags = fl; me->steering = st;
-        }
-    }
-}
-#endif
-
-// the games of the lanes in `mask` (NP players each), SLOTS at a time; game_of_lane = env * A + ego of the calling lane.
-// Every lane of the wave must call this.  The controls go into the egos' records, as in lqn_body.
-template <int NP, int SLOTS>
-__device__ HK_INWAVE_CALL void inwave_solve(unsigned long long mask, const int game_of_lane, const EnvParams& P, hk_agent_state* agents,
-                                            const GameSoA games, LqGameLds<NP>* LG, CostRows<NP>* CR, hk_lq_debug* dbg_out, int* status)
-{
-    constexpr int n = LqDims<NP>::n;
-    const int lane = threadIdx.x & 63;
-    const int gs = lane / n, r = lane % n;
-    while (mask) {
-        int src = -1;
-#pragma unroll
-        for (int s = 0; s < SLOTS; s++) {          // slot s takes the next lane of the mask
-            const int b = mask ? __ffsll((long long)mask) - 1 : -1;
-            if (mask) mask &= mask - 1ull;
-            if (gs == s) src = b;
-        }
-        const bool live = gs < SLOTS && src >= 0;
-        const int game = __shfl(game_of_lane, live ? src : lane, 64);
-        if (live) {
-            double u0[2];
-            int singular = 0;
-            lqn_stage_solve<NP, LqWaveSync>(game, r, (double)P.dt, games, LG[gs], CR[gs], u0, singular);
-            if (r == 0) {
-                if (singular) atomicOr(status, 1);
-                hk_agent_state* me = &agents[game];
-                uint32_t fl = me->flags; float st = me->steering;
-                decode_controls(me->final_steer, fl, st, u0[0], u0[1], (dbg_out && (P.debug & 1)) ? &dbg_out[game] : nullptr);
-                me->flags = fl; me->steering = st;
-            }
-        }
-    }
-}
-
 // The solver kernel of a round (lqn_round_kernel: 2-player games on pairs of lanes, 3- / 4-player games on the generic core) lives
 // in hk_lq2_pair.h.  (Round 1 / early round 2 went through three stages here, all retired: three launches per round, one merged
 // launch at the 4-player body's occupancy — 0.6 ms for the 262 144 games of a race-start tick — and a 2-player kernel of its own at
