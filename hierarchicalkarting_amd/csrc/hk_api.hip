@@ -298,9 +298,13 @@ int hk_lq_solve_batch_device(hk_handle h, int batch, int N, const double* dA, co
     HK_HIP(h, hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     hipEvent_t pe0 = h->prof.begin(st);
-    if (hk::lq_batch_launch(batch, N, dA, dB, dQ, dq, dR, dx0, horizon, du0, h->d_status, st) == HK_ERR_UNSUPPORTED)
-        return fail(h, HK_ERR_UNSUPPORTED, "hk_lq_solve_batch: N > 8 players not built");
-    HK_HIP(h, hipGetLastError());
+    const int rc = hk::lq_batch_launch(batch, N, dA, dB, dQ, dq, dR, dx0, horizon, du0, h->d_status, st);
+    const hipError_t le = hipGetLastError();
+    if (rc != HK_OK || le != hipSuccess) {
+        if (pe0) h->prof.pool.push_back(pe0);          // the opening event of the span goes back to the pool
+        if (rc == HK_ERR_UNSUPPORTED) return fail(h, HK_ERR_UNSUPPORTED, "hk_lq_solve_batch: N > 8 players not built");
+        return fail(h, HK_ERR_HIP, std::string("hk_lq_solve_batch: kernel launch: ") + hipGetErrorString(le));
+    }
     h->prof.end(2, pe0, st);
     return HK_OK;
 }

@@ -13,6 +13,7 @@
 #include <type_traits>
 #include "hk_env_device.h"
 #include "hk_lq_core.h"
+#include "hk_lq_mfma.h"
 
 namespace hk { namespace HK_GA_NS {
 

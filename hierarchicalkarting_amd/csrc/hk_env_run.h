@@ -239,8 +239,16 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
             // solve tick; it ends the env's part in this launch
             const bool again = left > 0 && budget > 0 && !held;
             const bool last = P.eager != 0 && cadence > 1 && !eager_it && phase == 0 && left > 0 && budget <= 0 && !held && ((es.episode_steps + 1) % cadence) == 0;
+#ifdef HK_LOOP_IFELSE
+            // the same truth table written as a chain of branches: the form that made round 2's Training-mode instantiation fail its
+            // parity test.  Built and run by tests/test_loop_form_gpu.py only.
+            if (eager_it) { go = false; eager_it = false; }
+            else if (last) eager_it = true;
+            else go = go && again;
+#else
             go = go && !eager_it && (again || last);
             eager_it = last;
+#endif
         }
     }
     HK_ST(h, 13);                      // [13] waiting for the other lane groups of the wave to leave the loop

@@ -93,7 +93,10 @@ __device__ inline void decode_controls(const float fs /*final_steer*/, uint32_t&
 // algorithm (k ascending, seeded +0.0); entries of A, B that are structural zeros are skipped (exact), entries
 // that are 1.0 enter through fma(z, 1.0, s) like any other value.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ inline void lq1_solve(const EnvParams& P, const GamePlayer& gp, Hot& h, hk_lq_debug* dbg, int* status)
+#ifndef HK_LQ1_ATTR
+#define HK_LQ1_ATTR inline
+#endif
+__device__ HK_LQ1_ATTR void lq1_solve(const EnvParams& P, const GamePlayer& gp, Hot& h, hk_lq_debug* dbg, int* status)
 {
     const double dt = (double)P.dt;
     double A[4][4] = {{1.0, 0.0, gp.a4[0], gp.a4[2]}, {0.0, 1.0, gp.a4[1], gp.a4[3]}, {0.0, 0.0, 1.0, 0.0}, {0.0, 0.0, 0.0, 1.0}};
@@ -470,7 +473,10 @@ __device__ __forceinline__ void wave_lds_sync()
 // game is written to games[] (the caller queues it by player count).  Returns the player count of a game to queue, else 0.
 // `act`: this env solves on this tick (cadence, not parked); it is quad-uniform.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ inline int phase_assemble(const EnvParams& P, const TabView& T, KartS* ks, const int env, const int ego,
+#ifndef HK_ASM_ATTR
+#define HK_ASM_ATTR inline
+#endif
+__device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, KartS* ks, const int env, const int ego,
                                       const bool act, const hk_env_state& es, Hot& h, const float hfx, const float hfz, hk_agent_state* agents,
                                       const GameSoA games,
                                       int* queue_cnt, int* queue, hk_lq_debug* dbg_out, int* status, const hk_mcts_state* mcts_all,
@@ -615,13 +621,12 @@ struct QCompact {
     __device__ double q(int i, int r) const { return C->QV[i][r]; }
 };
 
-// one queued game: inputs from the GameSoA buffer -> the game's LDS slice (lane r = row r), then the coupled Riccati recursion
-template <int NP, class SYNC>
-__device__ __forceinline__ void lqn_stage_solve(const int game, const int r, const double dt, const GameSoA& games, LqGameLds<NP>& LG,
-                                                CostRows<NP>& CR, double u0[2], int& singular)
+// one queued game: inputs from the GameSoA buffer -> the game's LDS slice LG (any type with Ab / Bb / Rb / x0) and its compact cost rows;
+// lane r = row r of the game, r < 4 NP
+template <int NP, class LDS>
+__device__ __forceinline__ void lqn_stage_inputs(const int game, const int r, const double dt, const GameSoA& games, LDS& LG, CostRows<NP>& CR)
 {
     constexpr int n = LqDims<NP>::n;
-    SYNC::sync();              // the slice may still be read by the previous game's last sweep
     // game inputs -> LDS
 #pragma unroll
     for (int i = 0; i < NP; i++) {
@@ -683,16 +688,59 @@ __device__ __forceinline__ void lqn_stage_solve(const int game, const int r, con
             CR.QV[i][r] = qv;
         }
     }
+}
+
+// ... then the coupled Riccati recursion on the lane-per-row core (hk_lq_core.h; games of 5 .. 8 players)
+template <int NP, class SYNC, bool MFMA = false>
+__device__ __forceinline__ void lqn_stage_solve(const int game, const int r, const double dt, const GameSoA& games, LqGameLds<NP>& LG,
+                                                CostRows<NP>& CR, double u0[2], int& singular, LqGameLds<NP>* slots = nullptr)
+{
+    SYNC::sync();              // the slice may still be read by the previous game's last sweep
+    lqn_stage_inputs<NP>(game, r, dt, games, LG, CR);
     SYNC::sync();
     QCompact<NP> qp;
     qp.C = &CR;
-    lq_solve_game<NP, QCompact<NP>, true, SYNC>(r, LG, qp, 3, u0, singular);      // HKA:1201 horizon literal 3 (Q6)
+    lq_solve_game<NP, QCompact<NP>, true, SYNC, MFMA>(r, LG, qp, 3, u0, singular, slots);      // HKA:1201 horizon literal 3 (Q6)
+}
+
+// 3- and 4-player games when a round holds a handful of them (a spread field): ONE game per wave, whole solve in 27 us instead of the
+// lane-per-row core's 59 (hk_lq_mfma.h).  When a round holds thousands (the race start) lqn_body<NP, true> serves 64 / n games per wave.
+template <int NP>
+__device__ __forceinline__ void lqn_body_mfma(const int block, const int nblocks, const EnvParams& P, hk_agent_state* agents, const GameSoA games,
+                                              const int* queue_cnt, const int* queue, hk_lq_debug* dbg_out, int* status, unsigned char* smem,
+                                              unsigned long long* gstats)
+{
+    constexpr int n = 4 * NP;
+    LqMfmaLds<NP>& LG = *reinterpret_cast<LqMfmaLds<NP>*>(smem);
+    CostRows<NP>& CR = *reinterpret_cast<CostRows<NP>*>(smem + sizeof(LqMfmaLds<NP>));
+    const int lane = threadIdx.x & 63;
+    const int count = queue_cnt[NP];
+    if (block == 0 && threadIdx.x == 0 && count > 0) atomicAdd(&gstats[NP], (unsigned long long)count);   // hk_prof_games
+    const int* qbase = queue + (size_t)(NP - 2) * P.E * P.A;
+    for (int slot = block; slot < count; slot += nblocks) {
+        const int game = qbase[slot];
+        LqmDev::sync();              // the slice may still be read by the previous game's last sweep
+        if (lane < n) lqn_stage_inputs<NP>(game, lane, (double)P.dt, games, LG, CR);
+        LqmDev::sync();
+        QCompact<NP> qp;
+        qp.C = &CR;
+        double u0[2];
+        int singular = 0;
+        lq_solve_game_mfma<NP, QCompact<NP>, LqmDev>(lane, LG, qp, 3, u0, singular);       // HKA:1201 horizon literal 3 (Q6)
+        if (lane == 0) {
+            if (singular) atomicOr(status, 1);
+            hk_agent_state* me = &agents[game];
+            uint32_t fl = me->flags; float st = me->steering;
+            decode_controls(me->final_steer, fl, st, u0[0], u0[1], (dbg_out && (P.debug & 1)) ? &dbg_out[game] : nullptr);
+            me->flags = fl; me->steering = st;
+        }
+    }
 }
 
 #ifndef HK_LQN_SYNC
 #define HK_LQN_SYNC LqBlockSync
 #endif
-template <int NP>
+template <int NP, bool MFMA = false>
 __device__ __forceinline__ void lqn_body(const int block, const int nblocks, const EnvParams& P, hk_agent_state* agents, const GameSoA games,
                                          const int* queue_cnt, const int* queue, hk_lq_debug* dbg_out, int* status, unsigned char* smem,
                                          unsigned long long* gstats)
@@ -713,7 +761,7 @@ __device__ __forceinline__ void lqn_body(const int block, const int nblocks, con
         const int game = qbase[live ? slot : count - 1];      // idle slots recompute the last game and discard it
         double u0[2];
         int singular = 0;
-        lqn_stage_solve<NP, HK_LQN_SYNC>(game, r, (double)P.dt, games, LG, CR, u0, singular);
+        lqn_stage_solve<NP, HK_LQN_SYNC, MFMA>(game, r, (double)P.dt, games, LG, CR, u0, singular, lds);
         if (live && r == 0) {
             if (singular) atomicOr(status, 1);
             hk_agent_state* me = &agents[game];

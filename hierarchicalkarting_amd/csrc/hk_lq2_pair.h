@@ -364,17 +364,23 @@ __device__ __forceinline__ void lq2_pair_body(const int block, const int nblocks
 // field, where a round holds a handful of games of each kind, their latencies overlap instead of adding up.
 __global__ __launch_bounds__(64) void lqn_round_kernel(EnvParams P, hk_agent_state* agents, const GameSoA games, const int* queue_cnt,
                                                        const int* queue, hk_lq_debug* dbg_out, int* status, int n34, int sizes, int n2,
-                                                       unsigned long long* gstats)
+                                                       unsigned long long* gstats, int bulk34)
 {
-    constexpr size_t B3 = (sizeof(LqGameLds<3>) + sizeof(CostRows<3>)) * LqDims<3>::SLOTS;
-    constexpr size_t B4 = (sizeof(LqGameLds<4>) + sizeof(CostRows<4>)) * LqDims<4>::SLOTS;
+    constexpr size_t B3a = sizeof(LqMfmaLds<3>) + sizeof(CostRows<3>), B3b = (sizeof(LqGameLds<3>) + sizeof(CostRows<3>)) * LqDims<3>::SLOTS;
+    constexpr size_t B4a = sizeof(LqMfmaLds<4>) + sizeof(CostRows<4>), B4b = (sizeof(LqGameLds<4>) + sizeof(CostRows<4>)) * LqDims<4>::SLOTS;
+    constexpr size_t B3 = B3a > B3b ? B3a : B3b, B4 = B4a > B4b ? B4a : B4b;
     constexpr size_t B34 = B3 > B4 ? B3 : B4;
     constexpr size_t BMAX = B34 > sizeof(Lq2PairLds) ? B34 : sizeof(Lq2PairLds);
     __shared__ __align__(16) unsigned char smem[BMAX];
     const int b = blockIdx.x;
     if (b >= n34) { lq2_pair_body(b - n34, n2, P, agents, games, queue_cnt, queue, dbg_out, status, *reinterpret_cast<Lq2PairLds*>(smem), gstats); return; }
     const int per = n34 / sizes, which = b / per, bb = b - which * per;
-    if (which == 0) lqn_body<3>(bb, per, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
-    else lqn_body<4>(bb, per, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
+    if (bulk34) {          // thousands of games (race start): 64 / n games per wave, the dense products on the matrix core
+        if (which == 0) lqn_body<3, true>(bb, per, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
+        else lqn_body<4, true>(bb, per, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
+    } else {               // a handful (spread field): one game per wave, half the latency
+        if (which == 0) lqn_body_mfma<3>(bb, per, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
+        else lqn_body_mfma<4>(bb, per, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
+    }
 }
 #endif

@@ -16,11 +16,29 @@ int lq_batch_launch(int batch, int N, const double* dA, const double* dB, const 
         hipLaunchKernelGGL(lq_batch_kernel<NP>, dim3((batch + gpw - 1) / gpw), dim3(64), 0, st, batch, dA, dB, dQ, dq, dR, \
                            dx0, horizon, du0, d_status);                                                                 \
     } break;
-        HK_LQ_CASE(1) HK_LQ_CASE(2) HK_LQ_CASE(3) HK_LQ_CASE(4) HK_LQ_CASE(5) HK_LQ_CASE(6) HK_LQ_CASE(7) HK_LQ_CASE(8)
+#ifndef HK_LQ_BATCH_MODE
+#define HK_LQ_BATCH_MODE 1      /* 3 / 4 players: 1 = lane-per-row core with the dense products on the matrix core (64 / n games per wave); 2 = one game per wave */
+#endif
+#if HK_LQ_BATCH_MODE == 1
+#define HK_LQM_CASE(NP)                                                                                                  \
+    case NP: {                                                                                                           \
+        const int gpw = LqDims<NP>::GPW;                                                                                 \
+        hipLaunchKernelGGL((lq_batch_kernel<NP, true>), dim3((batch + gpw - 1) / gpw), dim3(64), 0, st, batch, dA, dB, dQ, dq, dR, \
+                           dx0, horizon, du0, d_status);                                                                 \
+    } break;
+#else
+#define HK_LQM_CASE(NP)                                                                                                  \
+    case NP:                                                                                                             \
+        hipLaunchKernelGGL(lq_batch_mfma_kernel<NP>, dim3((batch + LQM_WPB - 1) / LQM_WPB), dim3(64 * LQM_WPB), 0, st, batch, dA, dB, dQ, dq, dR, \
+                           dx0, horizon, du0, d_status);                                                                 \
+        break;
+#endif
+        HK_LQ_CASE(1) HK_LQ_CASE(2) HK_LQM_CASE(3) HK_LQM_CASE(4) HK_LQ_CASE(5) HK_LQ_CASE(6) HK_LQ_CASE(7) HK_LQ_CASE(8)
 #undef HK_LQ_CASE
+#undef HK_LQM_CASE
     default: return HK_ERR_UNSUPPORTED;
     }
-    return hipGetLastError() == hipSuccess ? HK_OK : HK_ERR_HIP;
+    return HK_OK;          // (a launch failure stays in hipGetLastError for the caller to report)
 }
 
 }  // namespace hk

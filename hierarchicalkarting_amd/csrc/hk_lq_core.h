@@ -70,10 +70,20 @@ struct LqWaveSync {
 // KartLQRDynamics.cs:40-62).  Then the position rows (x, z) of F = A - sum B_k P_k are exactly +0.0 outside their own player's
 // block, whatever P is, and the chain W = Z_i F may leave those terms out (fma(z, +0.0, s) = s exactly): 37 % of the chain at
 // N = 4.  The generic hk_lq_solve_batch (arbitrary A, B) keeps every term.
-template <int NP, class QP, bool BICYCLE = false, class SYNC = LqBlockSync>
-__device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const int horizon, double u0[2], int& singular)
+// MFMA (NP = 3, 4; `slots` = the LDS slices of all the wave's games, this game's first): the two dense products of the value update run
+// on the fp64 matrix core, one game of the wave after the other with all 64 lanes (lane l = (g = l >> 4, cc = l & 15) supplies
+// Z_i[cc][4 s + g] and F[4 s + g][cc], K-step s), while everything else — the m x m solve, the small chains — keeps the lane-per-row
+// layout that serves 64 / n games per instruction.  v_mfma_f64_16x16x4_f64 is bit for bit the k-ascending fma chain of this contract
+// (tools/experiments/mfma_f64_check.hip), the rows / columns beyond n are zero padding, so the results are those of the chains below.
+// The chains read F and W back from LDS for every term (1 024 ds_read_b128 per game and sweep at N = 4, which bound the kernel);
+// the matrix core takes its operands from eight registers.
+typedef double lq_d4 __attribute__((ext_vector_type(4)));
+template <int NP, class QP, bool BICYCLE = false, class SYNC = LqBlockSync, bool MFMA = false>
+__device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const int horizon, double u0[2], int& singular,
+                              LqGameLds<NP>* slots = nullptr)
 {
     constexpr int n = LqDims<NP>::n, m = LqDims<NP>::m;
+    static_assert(!MFMA || NP == 3 || NP == 4, "one 16 x 16 tile per value matrix");
     const int ib = (r >> 2) < NP ? (r >> 2) : NP - 1;       // player block this lane's row belongs to
 
     double Z[NP][n];
@@ -278,6 +288,11 @@ __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const
         // ---------------- S6: per player Z_i, eta_i update (:113-119) ----------------
 #pragma unroll
         for (int i = 0; i < NP; i++) {
+            if (MFMA) {
+                // rows of Z_i -> this game's W slice
+#pragma unroll
+                for (int c = 0; c < n; c += 2) *reinterpret_cast<double2*>(&L.W[r][c]) = make_double2(Z[i][c], Z[i][c + 1]);
+            } else {
             // W = Z_i F (row r): four independent fma chains per pass (columns c..c+3)
             for (int c = 0; c < n; c += 4) {                // columns c .. c + 3 = the states of player c / 4
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -295,6 +310,7 @@ __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const
                 *reinterpret_cast<double2*>(&L.W[r][c]) = make_double2(s0, s1);
                 *reinterpret_cast<double2*>(&L.W[r][c + 2]) = make_double2(s2, s3);
             }
+            }
             // R_i P_i (column r): (RP)[a][r] = R[a][0] P[2i][r] + R[a][1] P[2i+1][r]
 #pragma unroll
             for (int a = 0; a < 2; a++) {
@@ -304,7 +320,53 @@ __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const
                 L.RP[a][r] = s;
             }
             SYNC::sync();
-            // Z_i <- (Q_i + P_i'(R_i P_i)) + F'(Z_i F)   (row r), written in place over W[r][*]
+            if (MFMA) {
+#ifdef __HIP_DEVICE_COMPILE__
+                // every game of the wave in turn, all 64 lanes: W = Z_i F, then W' F = (F' W)', back into the game's W slice
+                const int ml = threadIdx.x & 63, mg = ml >> 4, mc = ml & 15;
+#ifndef HK_LQ_MFMA_UNROLL
+#define HK_LQ_MFMA_UNROLL 1
+#endif
+#pragma unroll HK_LQ_MFMA_UNROLL
+                for (int q = 0; q < LqDims<NP>::GPW; q++) {
+                    LqGameLds<NP>& G = slots[q];
+                    double za[4], fb[4];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; s4++) {
+                        const int kk = 4 * s4 + mg;
+                        const bool in = mc < n && kk < n;
+                        za[s4] = in ? G.W[mc][kk] : 0.0;              // A operand: Z_i[mc][kk]
+                        fb[s4] = in ? G.F[kk][mc] : 0.0;              // B operand: F[kk][mc]
+                    }
+                    lq_d4 w4 = {0.0, 0.0, 0.0, 0.0}, o4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; s4++) w4 = __builtin_amdgcn_mfma_f64_16x16x4f64(za[s4], fb[s4], w4, 0, 0, 0);   // w4[j] = W[mg + 4 j][mc]
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; s4++) o4 = __builtin_amdgcn_mfma_f64_16x16x4f64(w4[s4], fb[s4], o4, 0, 0, 0);   // o4[j] = (F' W)[mc][4 j + mg]
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; s4++) {
+                        const int kk = 4 * s4 + mg;
+                        if (mc < n && kk < n) G.W[mc][kk] = o4[s4];    // (the wave's LDS requests are served in order: the reads above are done)
+                    }
+                }
+#endif
+                SYNC::sync();
+            }
+            // Z_i <- (Q_i + P_i'(R_i P_i)) + F'(Z_i F)   (row r)
+            if (MFMA) {
+#pragma unroll
+                for (int c = 0; c < n; c += 2) {
+                    const double2 w = *reinterpret_cast<const double2*>(&L.W[r][c]);        // (F' W)[r][c], [r][c + 1] from the matrix core
+                    double t20 = 0.0, t21 = 0.0;
+                    t20 = fma64(pc[2 * i + 0], L.RP[0][c], t20);
+                    t20 = fma64(pc[2 * i + 1], L.RP[1][c], t20);
+                    t21 = fma64(pc[2 * i + 0], L.RP[0][c + 1], t21);
+                    t21 = fma64(pc[2 * i + 1], L.RP[1][c + 1], t21);
+                    Z[i][c] = (qp.Q(i, r, c) + t20) + w.x;
+                    Z[i][c + 1] = (qp.Q(i, r, c + 1) + t21) + w.y;
+                }
+            } else {
+            // ... written in place over W[r][*]
             for (int c = 0; c < n; c += 2) {
                 double o0 = 0.0, o1 = 0.0;               // two independent chains (columns c, c+1)
 #pragma unroll
@@ -325,6 +387,7 @@ __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const
             SYNC::sync();
 #pragma unroll
             for (int c = 0; c < n; c++) Z[i][c] = L.W[r][c];
+            }
             // eta_i <- (q_i + P_i'(R_i alpha_i)) + F'(eta_i + Z_i beta)    with the NEW Z_i (Q2)
             double zb = 0.0;
 #pragma unroll

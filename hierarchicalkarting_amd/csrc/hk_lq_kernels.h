@@ -1,6 +1,7 @@
 // hk_lq_kernels.h — batched KartLQR.solveFeedbackLQR over explicit (A, B, Q, q, R, x0) inputs (hk_lq_solve_batch).
 #pragma once
 #include "hk_lq_core.h"
+#include "hk_lq_mfma.h"
 
 namespace hk {
 
@@ -14,7 +15,7 @@ struct QDenseP {
 };
 
 // one wave (64 threads) per block, 64/(4*NP) games per wave
-template <int NP>
+template <int NP, bool MFMA = false>
 __global__ __launch_bounds__(64) void lq_batch_kernel(int batch, const double* __restrict__ A, const double* __restrict__ B,
                                                        const double* __restrict__ Q, const double* __restrict__ q,
                                                        const double* __restrict__ R, const double* __restrict__ x0, int horizon,
@@ -42,8 +43,49 @@ __global__ __launch_bounds__(64) void lq_batch_kernel(int batch, const double* _
     qp.n = n;
     double u0[2];
     int singular;
-    lq_solve_game<NP>(r, L, qp, horizon, u0, singular);
+    lq_solve_game<NP, QDenseP, false, LqBlockSync, MFMA>(r, L, qp, horizon, u0, singular, lds);
     if (live && r == 0) {
+        u0_out[game * 2 + 0] = u0[0];
+        u0_out[game * 2 + 1] = u0[1];
+        if (singular) atomicOr(status, 1);
+    }
+}
+
+// 3 and 4 players: one game per wave on the fp64 matrix core (hk_lq_mfma.h); LQM_WPB waves (games) per workgroup, each with its own
+// LDS slice, no workgroup barrier after the staging
+constexpr int LQM_WPB = 4;
+#ifndef HK_LQM_OCC
+#define HK_LQM_OCC 2
+#endif
+template <int NP>
+__global__ __launch_bounds__(64 * LQM_WPB, HK_LQM_OCC) void lq_batch_mfma_kernel(int batch, const double* __restrict__ A, const double* __restrict__ B,
+                                                                      const double* __restrict__ Q, const double* __restrict__ q,
+                                                                      const double* __restrict__ R, const double* __restrict__ x0, int horizon,
+                                                                      double* __restrict__ u0_out, int* __restrict__ status)
+{
+    constexpr int n = 4 * NP;
+    __shared__ LqMfmaLds<NP> lds[LQM_WPB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long game = (long)blockIdx.x * LQM_WPB + wave;
+    const bool live = game < batch;
+    if (!live) game = batch - 1;                 // idle waves recompute the last game and discard it
+    LqMfmaLds<NP>& L = lds[wave];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        if (lane < 16) L.Ab[i][lane] = A[((size_t)game * NP + i) * 16 + lane];
+        if (lane < 8) L.Bb[i][lane] = B[((size_t)game * NP + i) * 8 + lane];
+        if (lane < 4) L.Rb[i][lane] = R[((size_t)game * NP + i) * 4 + lane];
+    }
+    if (lane < 16) L.x0[lane] = lane < n ? x0[(size_t)game * n + lane] : 0.0;
+    LqmDev::sync();
+    QDenseP qp;
+    qp.Qg = Q + (size_t)game * NP * n * n;
+    qp.qg = q + (size_t)game * NP * n;
+    qp.n = n;
+    double u0[2];
+    int singular;
+    lq_solve_game_mfma<NP, QDenseP, LqmDev>(lane, L, qp, horizon, u0, singular);
+    if (live && lane == 0) {
         u0_out[game * 2 + 0] = u0[0];
         u0_out[game * 2 + 1] = u0[1];
         if (singular) atomicOr(status, 1);
