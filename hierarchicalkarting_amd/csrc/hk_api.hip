@@ -569,7 +569,7 @@ static int step_ticks(hk_handle h, int n_ticks)
     const bool want_split = h->tune.want_split, no_split = h->tune.no_split;
     const bool close_field = h->dev.ticks_since_reset < hk::BULK_TICKS;
     h->split = (want_split || (close_field && !no_split)) && h->dev.P.eager && h->cfg.num_envs >= 8192;
-    int rounds = lazy ? hk::env_rounds_min(h->cfg, n_ticks, run_cap) : hk::env_rounds_for(h->cfg, n_ticks);
+    int rounds = lazy ? hk::env_rounds_min(h->cfg, n_ticks, run_cap) : hk::env_rounds_for(h->cfg, n_ticks, run_cap, h->dev.P.eager != 0);
     if (h->tune.debug_max_rounds > 0) rounds = std::min(rounds, h->tune.debug_max_rounds);     // (diagnostic: look at the state between two rounds)
     {
         // the rounds every env needs at RUN_CAP ticks a round, then — the laggards packed into the first lane groups — the tail

@@ -434,20 +434,25 @@ inline int env_launch_check(EnvDevice& d, const hk_config& cfg, bool lazy, hipSt
     return HK_GA_CALL(d, launch_done_check(d, cfg, lazy ? 1 : 0, stream, err));
 }
 
-// Number of {run, lqn} rounds issued for n ticks (see hk_env_run.h).  A round retires at least one solve cadence of every
-// unfinished env (resume the pending tick, run to the next solve tick) — except around an episode reset: the tick that
-// resets has episode_steps = 0, which is a solve tick whatever the phase of the old episode was, so the round that contains
-// a reset can retire fewer ticks.  An episode lasts at least the start hold (75 ticks), hence the n / 32 + 2 extra rounds;
-// rounds that find nothing to do cost a few microseconds, and env_check_kernel still guards the result.
-inline int env_rounds_for(const hk_config& cfg, int n_ticks)
+// Number of {run, lqn} rounds issued up front for n ticks when the host does not look at the device in between (short calls,
+// planner / actor handles).  An env's part in a round ends when it finishes its ticks, when it parks at a solve tick (it queued a
+// multi-player game, or — eager assembly — it assembled the games of the solve tick its budget ends on), or when its budget of
+// `cap` ticks is used up.  So rounds <= parks + budget ends + 1.  Parks: at most one per solve tick.  n consecutive ticks hold at most
+// ceil(n / cadence) solve ticks per episode segment, and every reset starts a segment with a solve tick of its own (episode_steps = 0
+// whatever the phase of the old episode was): S(n) = min(n, ceil(n / cadence) + resets), resets <= 1 + n / 32 (an episode outlasts the
+// start hold or, in Training mode, the ride to its first Trigger).  Budget ends: with the eager assembly (cap = cadence) they ARE
+// parks; otherwise at most ceil(n / cap) - 1.  A one-tick call is 2 rounds, a 20-tick call of a plain handle 7 (round 2 issued 4 and 8
+// by a looser bound).  env_check_kernel still guards the result.
+inline int env_rounds_for(const hk_config& cfg, int n_ticks, int cap = RUN_CAP, bool eager = false)
 {
     const int cadence = cfg.num_agents > 2 ? 4 : 1;
     static_assert(RUN_CAP > 4, "RUN_CAP must exceed the solve cadence");
-    return (n_ticks + cadence - 1) / cadence + 1 + n_ticks / 32 + 2;
+    const int solve_ticks = std::min(n_ticks, (n_ticks + cadence - 1) / cadence + 1 + n_ticks / 32);
+    return eager ? solve_ticks + 1 : solve_ticks + (n_ticks + cap - 1) / cap;
 }
 
-// Rounds a field needs for n ticks when nothing is queued (2-player games are solved inside the tick kernel, HK_INWAVE): every
-// env retires RUN_CAP ticks per round.
+// Rounds a field needs for n ticks when nothing is queued: every env retires the launch's budget of ticks per round (long calls of
+// plain handles issue these, look at the device and finish the laggards: hk_api.hip finish_ticks).
 inline int env_rounds_min(const hk_config& cfg, int n_ticks, int cfg_run_cap = RUN_CAP)
 {
     (void)cfg;

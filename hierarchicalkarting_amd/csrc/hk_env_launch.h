@@ -120,10 +120,10 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
         // no barriers (hk_lq2_pair.h); the 3- and 4-player queues to the matrix-core solver (hk_lq_mfma.h), one game per wave,
         // 1 024 workgroups per game size (one wave per SIMD) walking their queue grid-stride.
         const int sizes = cfg.num_agents > 2 ? std::min(cfg.num_agents, 4) - 2 : 0;     // player counts 3 .. min(A, 4)
-        const int n34 = sizes ? std::min(bulk ? (ngames + 3) / 4 : ngames, 1024) * sizes : 0;          // bulk: 64 / n games per wave; else one game per wave (hk_lq_mfma.h)
+        const int n34 = sizes ? std::min(ngames, 1024) * sizes : 0;          // 1 024 waves per game size walk their queue grid-stride; the queue length picks the solver (lqn_round_kernel)
         const int n2 = std::min((ngames + 31) / 32, bulk ? 4096 : 1024);
         hipLaunchKernelGGL(lqn_round_kernel, dim3(n34 + n2), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status,
-                           n34, sizes ? sizes : 1, n2, d.game_stats, bulk ? 1 : 0);
+                           n34, sizes ? sizes : 1, n2, d.game_stats, LQN_BULK_GAMES);
         if ((rc = launch_check(err, "lqn_round_kernel"))) return rc;
     }
     if (cfg.num_agents > 4) {

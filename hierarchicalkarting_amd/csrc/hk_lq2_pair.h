@@ -375,10 +375,13 @@ __global__ __launch_bounds__(64) void lqn_round_kernel(EnvParams P, hk_agent_sta
     const int b = blockIdx.x;
     if (b >= n34) { lq2_pair_body(b - n34, n2, P, agents, games, queue_cnt, queue, dbg_out, status, *reinterpret_cast<Lq2PairLds*>(smem), gstats); return; }
     const int per = n34 / sizes, which = b / per, bb = b - which * per;
-    if (bulk34) {          // thousands of games (race start): 64 / n games per wave, the dense products on the matrix core
+    // Which solver?  The queue length decides, on the device: a round that holds a handful of games (a spread field) wants the shortest
+    // latency — one game per wave; one that holds thousands (the race start, packs) wants 64 / n games per instruction of the m x m solve.
+    const int cnt = queue_cnt[which == 0 ? 3 : 4];
+    if (cnt > bulk34) {
         if (which == 0) lqn_body<3, true>(bb, per, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
         else lqn_body<4, true>(bb, per, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
-    } else {               // a handful (spread field): one game per wave, half the latency
+    } else {
         if (which == 0) lqn_body_mfma<3>(bb, per, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
         else lqn_body_mfma<4>(bb, per, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
     }

@@ -87,3 +87,25 @@ def test_maximum_section_count_and_many_laps():
     with pytest.raises(hk.HkError):
         tr2 = copy.deepcopy(tr); tr2["sections"] = tr["sections"] + secs[:1]       # 65 sections
         hk.RacingEnv(hk.make_config(2, 2, track=tr2))
+
+
+@pytest.mark.parametrize("A", [2, 4, 8])
+def test_short_calls_across_resets_need_no_more_rounds_than_issued(A):
+    """hk_step(1), (2), (3) ... issue a fixed number of rounds without looking at the device (env_rounds_for: solve ticks in the call + 1).
+    Episodes of at most 120 ticks put time-out resets — whose reset tick is a solve tick of its own — inside many of the calls; a call that
+    needed one round more would raise "an env did not complete its ticks" at the next getter, a wrong state would differ from the oracle."""
+    import hierarchicalkarting_amd as hk
+    b = hk.make_config(96, A, jitter_seed=0x5EED0000, laps=1, max_episode_steps=100 + 7 * (A % 3))
+    g = hk.RacingEnv(b); o = O.OracleEnv(b)
+    g.reset(); o.reset()
+    t = 0
+    for n, reps in ((1, 130), (2, 60), (3, 45), (4, 30), (5, 25), (7, 18), (20, 7), (33, 4)):
+        for _ in range(reps):
+            g.step(n); o.step(n); t += n
+        gs, os_ = g.agent_state(), o.agent_state()
+        for name in gs.dtype.names:
+            x, y = gs[name], os_[name]
+            if x.dtype.kind == "f":
+                x = x.view(np.uint32); y = y.view(np.uint32)
+            assert np.array_equal(x, y), (A, t, n, name)
+    assert (g.env_state()["episodes_done"] >= 5).all()
