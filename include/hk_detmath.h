@@ -25,6 +25,17 @@
 
 #define HK_PI_F 3.14159274f /* UnityEngine.Mathf.PI as float */
 
+/* Horner step of the polynomial kernels.  The contract is mul then add (two roundings); -DHK_DETMATH_FMA=1 is a TIMING experiment
+ * (tools/build_variant.py): one fused step, other bits, never shipped. */
+#ifndef HK_DETMATH_FMA
+#define HK_DETMATH_FMA 0
+#endif
+#if HK_DETMATH_FMA
+#define HK_HORNER(p, z, c) __builtin_fma((p), (z), (c))
+#else
+#define HK_HORNER(p, z, c) ((p) * (z) + (c))
+#endif
+
 HK_HD double hk_fabs(double x) { return x < 0.0 ? -x : x; }
 
 /* r = x - k*pi/2 (3-part Cody-Waite), returns k mod 4 */
@@ -46,15 +57,15 @@ HK_HD double hk__ksin(double r)
 {
     double z = r * r;
     double p = 1.9572941063391263e-20;
-    p = p * z + -8.2206352466243295e-18;
-    p = p * z + 2.8114572543455206e-15;
-    p = p * z + -7.6471637318198164e-13;
-    p = p * z + 1.6059043836821613e-10;
-    p = p * z + -2.505210838544172e-08;
-    p = p * z + 2.7557319223985893e-06;
-    p = p * z + -0.00019841269841269841;
-    p = p * z + 0.0083333333333333332;
-    p = p * z + -0.16666666666666666;
+    p = HK_HORNER(p, z, -8.2206352466243295e-18);
+    p = HK_HORNER(p, z, 2.8114572543455206e-15);
+    p = HK_HORNER(p, z, -7.6471637318198164e-13);
+    p = HK_HORNER(p, z, 1.6059043836821613e-10);
+    p = HK_HORNER(p, z, -2.505210838544172e-08);
+    p = HK_HORNER(p, z, 2.7557319223985893e-06);
+    p = HK_HORNER(p, z, -0.00019841269841269841);
+    p = HK_HORNER(p, z, 0.0083333333333333332);
+    p = HK_HORNER(p, z, -0.16666666666666666);
     return r + (r * z) * p;
 }
 
@@ -62,15 +73,15 @@ HK_HD double hk__kcos(double r)
 {
     double z = r * r;
     double p = -8.8967913924505741e-22;
-    p = p * z + 4.1103176233121648e-19;
-    p = p * z + -1.5619206968586225e-16;
-    p = p * z + 4.7794773323873853e-14;
-    p = p * z + -1.1470745597729725e-11;
-    p = p * z + 2.08767569878681e-09;
-    p = p * z + -2.7557319223985888e-07;
-    p = p * z + 2.4801587301587302e-05;
-    p = p * z + -0.0013888888888888889;
-    p = p * z + 0.041666666666666664;
+    p = HK_HORNER(p, z, 4.1103176233121648e-19);
+    p = HK_HORNER(p, z, -1.5619206968586225e-16);
+    p = HK_HORNER(p, z, 4.7794773323873853e-14);
+    p = HK_HORNER(p, z, -1.1470745597729725e-11);
+    p = HK_HORNER(p, z, 2.08767569878681e-09);
+    p = HK_HORNER(p, z, -2.7557319223985888e-07);
+    p = HK_HORNER(p, z, 2.4801587301587302e-05);
+    p = HK_HORNER(p, z, -0.0013888888888888889);
+    p = HK_HORNER(p, z, 0.041666666666666664);
     return (1.0 - 0.5 * z) + (z * z) * p;
 }
 
@@ -136,13 +147,13 @@ HK_HD double hk__atan01(double t)
     double u = (t - c) / (1.0 + t * c);
     double z = u * u;
     double p = 0.058823529411764705;
-    p = p * z + -0.066666666666666666;
-    p = p * z + 0.076923076923076927;
-    p = p * z + -0.090909090909090912;
-    p = p * z + 0.1111111111111111;
-    p = p * z + -0.14285714285714285;
-    p = p * z + 0.20000000000000001;
-    p = p * z + -0.33333333333333331;
+    p = HK_HORNER(p, z, -0.066666666666666666);
+    p = HK_HORNER(p, z, 0.076923076923076927);
+    p = HK_HORNER(p, z, -0.090909090909090912);
+    p = HK_HORNER(p, z, 0.1111111111111111);
+    p = HK_HORNER(p, z, -0.14285714285714285);
+    p = HK_HORNER(p, z, 0.20000000000000001);
+    p = HK_HORNER(p, z, -0.33333333333333331);
     double a = u + (u * z) * p;
     return TH[j] + (TL[j] + a);
 }
@@ -175,18 +186,18 @@ HK_HD double hk_exp(double x)
     double fk = (double)k;
     double r = (x - fk * LN2_HI) - fk * LN2_LO;
     double p = 1.1470745597729725e-11;
-    p = p * r + 1.6059043836821613e-10;
-    p = p * r + 2.08767569878681e-09;
-    p = p * r + 2.505210838544172e-08;
-    p = p * r + 2.7557319223985888e-07;
-    p = p * r + 2.7557319223985893e-06;
-    p = p * r + 2.4801587301587302e-05;
-    p = p * r + 0.00019841269841269841;
-    p = p * r + 0.0013888888888888889;
-    p = p * r + 0.0083333333333333332;
-    p = p * r + 0.041666666666666664;
-    p = p * r + 0.16666666666666666;
-    p = p * r + 0.5;
+    p = HK_HORNER(p, r, 1.6059043836821613e-10);
+    p = HK_HORNER(p, r, 2.08767569878681e-09);
+    p = HK_HORNER(p, r, 2.505210838544172e-08);
+    p = HK_HORNER(p, r, 2.7557319223985888e-07);
+    p = HK_HORNER(p, r, 2.7557319223985893e-06);
+    p = HK_HORNER(p, r, 2.4801587301587302e-05);
+    p = HK_HORNER(p, r, 0.00019841269841269841);
+    p = HK_HORNER(p, r, 0.0013888888888888889);
+    p = HK_HORNER(p, r, 0.0083333333333333332);
+    p = HK_HORNER(p, r, 0.041666666666666664);
+    p = HK_HORNER(p, r, 0.16666666666666666);
+    p = HK_HORNER(p, r, 0.5);
     double e = 1.0 + (r + (r * r) * p);
     /* scale by 2^k, k in [-1022, 1023] on this path */
     union { unsigned long long u; double d; } s;
@@ -209,18 +220,18 @@ HK_HD double hk_log(double x)
     double s = (m - 1.0) / (m + 1.0);
     double z = s * s;
     double p = 0.037037037037037035;          /* 1/27 */
-    p = p * z + 0.040000000000000001;         /* 1/25 */
-    p = p * z + 0.043478260869565216;         /* 1/23 */
-    p = p * z + 0.047619047619047616;         /* 1/21 */
-    p = p * z + 0.052631578947368418;         /* 1/19 */
-    p = p * z + 0.058823529411764705;         /* 1/17 */
-    p = p * z + 0.066666666666666666;         /* 1/15 */
-    p = p * z + 0.076923076923076927;         /* 1/13 */
-    p = p * z + 0.090909090909090912;         /* 1/11 */
-    p = p * z + 0.1111111111111111;           /* 1/9 */
-    p = p * z + 0.14285714285714285;          /* 1/7 */
-    p = p * z + 0.20000000000000001;          /* 1/5 */
-    p = p * z + 0.33333333333333331;          /* 1/3 */
+    p = HK_HORNER(p, z, 0.040000000000000001);         /* 1/25 */
+    p = HK_HORNER(p, z, 0.043478260869565216);         /* 1/23 */
+    p = HK_HORNER(p, z, 0.047619047619047616);         /* 1/21 */
+    p = HK_HORNER(p, z, 0.052631578947368418);         /* 1/19 */
+    p = HK_HORNER(p, z, 0.058823529411764705);         /* 1/17 */
+    p = HK_HORNER(p, z, 0.066666666666666666);         /* 1/15 */
+    p = HK_HORNER(p, z, 0.076923076923076927);         /* 1/13 */
+    p = HK_HORNER(p, z, 0.090909090909090912);         /* 1/11 */
+    p = HK_HORNER(p, z, 0.1111111111111111);           /* 1/9 */
+    p = HK_HORNER(p, z, 0.14285714285714285);          /* 1/7 */
+    p = HK_HORNER(p, z, 0.20000000000000001);          /* 1/5 */
+    p = HK_HORNER(p, z, 0.33333333333333331);          /* 1/3 */
     double l = 2.0 * (s + (s * z) * p);
     double fe = (double)e;
     return fe * LN2_HI + (l + fe * LN2_LO);
