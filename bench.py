@@ -33,6 +33,34 @@ HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VECTOR_PEAK_TFLOPS = 78.6         # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32-input MFMA = the fp32 vector rate
 STEADY_TICK = 512                      # steady state = ticks 512 .. 3584
+# HBM bytes and SQ counters cannot be read in-process: they come from the separate rocprofv3 --pmc passes of THIS command that
+# tools/pmc_summary.py folded into this file (committed with the profile it belongs to; `commit` / `command` inside say which)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+
+
+def pmc_fields(kernel, env_steps_per_launch=None):
+    """-> (traffic bytes per launch or None, provenance dict, binding dict) for `kernel` from the committed PMC summary; the bytes are
+    scaled to this run's env-steps per launch (the fused tick kernel advances a variable number of ticks per launch)"""
+    try:
+        d = json.load(open(PMC_SUMMARY))
+    except (OSError, ValueError):
+        return None, {"note": "no PMC summary committed for this round"}, None
+    k = d.get(kernel) or {}
+    prov = {"file": os.path.relpath(PMC_SUMMARY, ROOT), "commit": d.get("commit"), "command": d.get("command"),
+            "method": "separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, mean of the kernel's 30 largest launches"}
+    sq = (k.get("sq") or {}).get("derived")
+    binding = None
+    if sq:
+        binding = {"resource": "VALU issue", "wave_issuing_valu_frac": sq.get("wave_issuing_valu_frac"), "wave_issuing_any_frac": sq.get("wave_issuing_any_frac"),
+                   "wave_waiting_frac": sq.get("wave_waiting_frac"), "waves_per_simd": 2,
+                   "simd_valu_busy_frac": min(1.0, 2.0 * (sq.get("wave_issuing_valu_frac") or 0.0)),
+                   "valu_lanes_active_of_64": sq.get("valu_lanes_active_of_64"), "valu_insts_per_launch": sq.get("valu_insts_per_launch"),
+                   "source": "SQ counters of the same PMC summary (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave; two waves share a SIMD)"}
+    traffic = k.get("hbm_bytes_per_launch")
+    if traffic is not None and env_steps_per_launch and d.get("env_steps_per_launch"):
+        prov["measured_bytes_per_env_step"] = traffic / d["env_steps_per_launch"]
+        traffic = traffic * env_steps_per_launch / d["env_steps_per_launch"]
+    return traffic, prov, binding
 
 
 def lq_flop(N, sweeps=4):
@@ -474,9 +502,10 @@ def bench_lqng(a, D, hk):
             # env-steps of the timed region / launches of the timed region; algorithmic bytes = 1 056 B x that
             algo = ALGO_BYTES_PER_ENV_STEP * (A / 4.0) * E * a.steps / dom_n
             achieved = algo / 1e9 / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
+            traffic, prov, binding = pmc_fields("env_run_kernel", float(E) * a.steps / dom_n)
             roof = {"bound": "hbm", "kernel": "env_run_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": algo,
-                    "traffic_note": "HBM bytes are not measurable in-process; the --pmc passes of this command are under profiles/ (r02_pmc_summary.json)"}
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo,
+                    "traffic_provenance": prov, "binding": binding}
         else:
             # the multi-player solver dominates (race start / close racing): price it against the fp64 vector peak with the
             # dense flop count of the games it actually solved in this run (hk_prof_games)

@@ -424,6 +424,7 @@ static int issue_rounds_split(hk_handle h, int rounds)
     if ((h->dev.rounds_since_regroup += rounds) >= h->dev.regroup_rounds) {  // the periodic regroup by solve phase, here where the streams are joined
         int rcg = hk::env_launch_regroup(h->dev, h->cfg, h->stream, h->err);
         if (rcg) { g_last_error = h->err; return rcg; }
+        h->dev.rounds_since_regroup = rounds;      // (the rounds issued below count toward the next one)
     }
     hipStream_t st[2] = {h->stream, h->qstream};
     h->round_half[0] = h->dev.round;          // sets 0 / 1 are also the unsplit launches' sets: continue their parity
@@ -474,6 +475,7 @@ static int finish_ticks(hk_handle h)
         if (maxleft <= 0 && !waiting) { h->step_pending = false; break; }
         int rc = hk::env_launch_regroup(h->dev, h->cfg, h->stream, h->err);      // the laggards into the first lane groups
         if (rc) { g_last_error = h->err; return rc; }
+        h->split = false;                // ... which all lie in the first half: the tail runs as one batch on one stream
         rc = issue_rounds(h, (maxleft + cadence - 1) / cadence + 1);
         if (rc) return rc;
         rc = issue_check(h, true);
@@ -562,9 +564,9 @@ static int step_ticks(hk_handle h, int n_ticks)
     h->dev.P.run_cap = run_cap;
     // two halves on two streams (issue_rounds_split): on request.  Measured: headline 1 221 -> 1 292 M env-steps/s, race start 439 -> 458 M,
     // a 20-tick call unchanged (the solver kernel needs a SIMD's whole register file and finds none while the other half's tick kernel
-    // fills the GPU, so on short launches its latency is not hidden but moved).  Off by default: two tick kernels that share the GPU
-    // each take longer, and bench.py's per-launch roofline (bytes of a launch / its duration) would no longer describe the kernel.
-    // While the field stands close (BULK_TICKS after a reset of every env: every ego holds a multi-player game and a round's solver
+    // fills the GPU, so on short launches its latency is not hidden but moved).  On a spread field it is off unless HK_SPLIT=1: two tick
+    // kernels that share the GPU each take longer, and bench.py's per-launch roofline (bytes of a launch / its duration) would no longer
+    // describe the kernel (hk_prof's stage totals then add up the spans of two concurrent streams).  While the field stands close (BULK_TICKS after a reset of every env: every ego holds a multi-player game and a round's solver
     // launch lasts hundreds of microseconds) the split is used without being asked: race start 440 -> 458 M.
     const bool want_split = h->tune.want_split, no_split = h->tune.no_split;
     const bool close_field = h->dev.ticks_since_reset < hk::BULK_TICKS;
@@ -747,7 +749,12 @@ static int check_device_status(hk_handle h)
     int st[4] = {0, 0, 0, 0};
     HK_HIP(h, hipMemcpyAsync(st, h->dev.status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     HK_HIP(h, hipStreamSynchronize(h->stream));
-    if ((st[0] & 4) && !h->tune.debug_no_check) return fail(h, HK_ERR_HIP, "hk_step: an env did not complete its ticks (internal scheduling error)");
+    if ((st[0] & 4) && !h->tune.debug_no_check) {
+        // reported once: the flag is cleared here (and by hk_reset), the unfinished envs keep their leftover ticks for the next hk_step
+        const int keep = ~4;
+        hipLaunchKernelGGL(hk::status_and_kernel, dim3(1), dim3(1), 0, h->stream, h->dev.status, keep);
+        return fail(h, HK_ERR_HIP, "hk_step: an env did not complete its ticks (internal scheduling error)");
+    }
     return HK_OK;
 }
 

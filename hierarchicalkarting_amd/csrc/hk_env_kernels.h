@@ -47,6 +47,8 @@ int upload(T** dst, const std::vector<T>& v, std::string& err)
 
 }  // namespace detail
 
+__global__ void status_and_kernel(int* status, int mask) { atomicAnd(status, mask); }
+
 // point d.mcts (the kernel argument) at the move tables of gameParams class c
 inline void mcts_use_class(EnvDevice& d, int c)
 {

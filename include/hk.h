@@ -224,7 +224,7 @@ typedef struct hk_env_state {
     int32_t episodes_done;     /* finished episodes since hk_create */
     uint32_t status;           /* bit0 NaN/Inf seen in a kart state, bit1 timeout ended last episode */
     int32_t initial_started;   /* REC.initialStarted (REC:132): the very first all-inactive tick resets without logging */
-    int32_t reserved[2];       /* library-internal progress words of hk_step ([0] ticks left, [1] phase); 0 between calls */
+    int32_t reserved[2];       /* library-internal progress words of hk_step: [0] ticks left, [1] bits 0..3 phase inside a tick (both 0 between calls), bit 4 a scheduling hint */
 } hk_env_state;
 
 /* TelemetryViewer / experiment-log quantities of the last finished episode (TelemetryViewer.cs:49-108) */
@@ -275,12 +275,21 @@ int hk_set_actions(hk_handle h, const float* steer, const int32_t* branch);
 
 /* n_ticks Unity FixedUpdate ticks: REC.FixedUpdate -> [HKA.FixedUpdate incl. SolveLQR] ->
  * ArcadeKart.FixedUpdate -> engine step (integrate, contacts, triggers). Asynchronous on the handle's stream.
- * Error surface: hk_step only reports launch errors.  The library issues a bounded number of kernel rounds per call; a
- * completion guard (env_check_kernel) runs last, and if any env still had ticks to run the NEXT hk_get_* / hk_gather_results
- * call fails with HK_ERR_HIP "an env did not complete its ticks" instead of returning stale state.  The flag is cleared by the
- * next hk_step / hk_reset, which also let the unfinished envs continue.  A zero pivot in an LQ solve is sticky in the same
- * way (status bit 0) but does not fail the getters: the reference throws nothing there either (MathNet returns inf / NaN),
- * and hk_env_state.status bit 0 flags the karts whose state went non-finite.
+ * Completion.  hk_step returns when the work is ISSUED.  Calls of fewer than 64 ticks, and every call of a handle with a planner or
+ * an attached actor, issue a fixed number of kernel rounds (the solve ticks the call can hold + 1) and need no host sync.  Calls of
+ * >= 64 ticks of plain handles issue the rounds a field without queued games needs and leave the rest to the NEXT entry point that
+ * touches the state (any hk_get_* / hk_set_* / hk_reset / hk_step / hk_prof_read / hk_gather_results, or hk_synchronize): it waits
+ * for a two-word report of the device and issues what the laggard envs still need ("lazy completion").  hk_synchronize is the
+ * completion point: a host that overlaps its own work with hk_step, or times it, calls hk_synchronize where it needs the ticks done.
+ * Error surface: hk_step only reports launch errors.  A completion guard (env_check_kernel) runs after the rounds of a call; if an
+ * env still had ticks to run (an internal scheduling error) the next hk_get_agent_state / hk_get_env_state fails ONCE with
+ * HK_ERR_HIP "an env did not complete its ticks" instead of returning stale state; the flag is sticky until that report (or
+ * hk_reset), and the unfinished envs keep their leftover ticks, which the next hk_step runs first.  A zero pivot in an LQ solve is
+ * sticky in the same way (status bit 0) but does not fail the getters: the reference throws nothing there either (MathNet returns
+ * inf / NaN), and hk_env_state.status bit 0 flags the karts whose state went non-finite.
+ * Scheduling switches, read from the environment ONCE in hk_create (none changes a result bit): HK_NO_EAGER, HK_FIXED_ROUNDS,
+ * HK_MCTS_NO_PAUSE, HK_SPLIT / HK_NO_SPLIT, HK_RUN_CAP_SPREAD, HK_RUN_CAP_SHORT, HK_REGROUP_ROUNDS, HK_MCTS_PERSIST_GB,
+ * HK_NO_HOLD_DEDUPE, HK_LQ_DEBUG; diagnostics HK_DEBUG_MAX_ROUNDS, HK_DEBUG_NO_CHECK, HK_STAMPS_DUMP.
  * Planner handles (any HighMode MCTS agent): a call of more than 38 ticks without attached actors synchronises with the host
  * between stretches of ~100 ticks — envs wait at the tick boundary after a search request so that the searches of a stretch run
  * as ONE batch (results do not depend on it; environment variable HK_MCTS_NO_PAUSE=1 restores the fully asynchronous schedule).
