@@ -83,6 +83,9 @@ struct Prof {
 
 }  // namespace
 
+#ifndef HK_LAZY_MIN_TICKS
+#define HK_LAZY_MIN_TICKS 64      /* calls at least this long issue the rounds a spread field needs and finish the laggards after a look at the device */
+#endif
 // Scheduling switches: read from the environment ONCE, in hk_create, into the handle (listed in include/hk.h).  None of them changes a
 // result bit; they exist for the A/B measurements under profiles/ and for two tests.
 struct Tuning {
@@ -94,6 +97,7 @@ struct Tuning {
     int run_cap_spread = hk::RUN_CAP_SPREAD;   // HK_RUN_CAP_SPREAD: ticks per launch of long calls on a spread field (4 .. 64)
     int run_cap_short = 4;       // HK_RUN_CAP_SHORT: ticks per launch of short calls of plain handles
     int regroup_rounds = hk::REGROUP_ROUNDS;   // HK_REGROUP_ROUNDS: rounds between two re-assignments of the lane groups
+    int lazy_min_ticks = HK_LAZY_MIN_TICKS;    // HK_LAZY_MIN_TICKS: calls at least this long complete lazily (a look at the device instead of the worst-case rounds)
     int debug_max_rounds = 0;    // HK_DEBUG_MAX_ROUNDS (diagnostic): cap on the rounds of a call, to look at the state in between
     bool debug_no_check = false; // HK_DEBUG_NO_CHECK (diagnostic): getters do not fail on the "did not complete" flag
     bool stamps_dump = false;    // HK_STAMPS_DUMP (diagnostic builds, -DHK_STAMPS)
@@ -106,6 +110,7 @@ struct Tuning {
         run_cap_spread = num("HK_RUN_CAP_SPREAD", hk::RUN_CAP_SPREAD, 4, 64);
         run_cap_short = num("HK_RUN_CAP_SHORT", 4, 4, 64);
         regroup_rounds = num("HK_REGROUP_ROUNDS", hk::REGROUP_ROUNDS, 1, 1 << 20);
+        lazy_min_ticks = num("HK_LAZY_MIN_TICKS", HK_LAZY_MIN_TICKS, 1, 1 << 20);
         debug_max_rounds = num("HK_DEBUG_MAX_ROUNDS", 0, 0, 1 << 20);
         debug_no_check = flag("HK_DEBUG_NO_CHECK"); stamps_dump = flag("HK_STAMPS_DUMP");
     }
@@ -152,9 +157,6 @@ struct hk_context {
 };
 
 static int finish_ticks(hk_context* h);      // lazy completion of the last hk_step (defined with step_ticks)
-#ifndef HK_LAZY_MIN_TICKS
-#define HK_LAZY_MIN_TICKS 64      /* calls at least this long issue the rounds a spread field needs and finish the laggards after a look at the device */
-#endif
 
 namespace {
 
@@ -549,7 +551,7 @@ static int step_ticks(hk_handle h, int n_ticks)
     // multi-player games needs, and the stragglers are finished lazily by the next call that touches the state
     // (finish_ticks): most of the worst-case rounds found nothing to do, and on a 20-tick call they were 5 launches of 8.
     // (short calls — a host stepping tick by tick — keep the fixed count too: a handful of rounds, no host sync)
-    const bool lazy = !planner && h->n_policies == 0 && h->done_host != nullptr && n_ticks >= HK_LAZY_MIN_TICKS && h->tune.lazy;
+    const bool lazy = !planner && h->n_policies == 0 && h->done_host != nullptr && n_ticks >= h->tune.lazy_min_ticks && h->tune.lazy;
     // ticks per launch: longer launches once the field has spread out (see RUN_CAP_SPREAD)
     const int spread_cap = h->tune.run_cap_spread;
     // short calls of plain LQNG handles: one solve cadence per launch — with the eager assembly every env, in a pack or not, retires
