@@ -519,8 +519,15 @@ static int step_ticks(hk_handle h, int n_ticks)
     // the eager assembly (hk_env_run.h) in pause mode too: requests are posted on the same ticks, a round earlier at most
     // (configs[2]: 61.4 -> 63.6 M env-steps/s)
     if (planner) h->dev.P.eager = (pause && h->tune.eager && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4) ? 1 : 0;
-    rc = hk::env_launch_arm(h->dev, h->cfg, n_ticks, h->stream, h->err);
-    if (rc) { g_last_error = h->err; return rc; }
+    // Arming: a kernel of its own, except in fixed-round calls that are not split, where the first tick launch adds the ticks itself and the
+    // last one raises the "did not complete" flag the guard kernel would (a one-tick call: 4 launches instead of 9 with round 2's tail regroup)
+    const bool lazy_call = !planner && h->n_policies == 0 && h->done_host != nullptr && n_ticks >= h->tune.lazy_min_ticks && h->tune.lazy;
+    const bool fold = !pause && !lazy_call && !(h->tune.want_split || (h->dev.ticks_since_reset < hk::BULK_TICKS && !h->tune.no_split));
+    if (fold) h->dev.arm_ticks = n_ticks;
+    else {
+        rc = hk::env_launch_arm(h->dev, h->cfg, n_ticks, h->stream, h->err);
+        if (rc) { g_last_error = h->err; return rc; }
+    }
     if (pause) {
         h->dev.mcts_defer = true;                       // the rounds do not launch searches themselves
         const int cadence = h->cfg.num_agents > 2 ? 4 : 1;
@@ -578,10 +585,13 @@ static int step_ticks(hk_handle h, int n_ticks)
     {
         // the rounds every env needs at RUN_CAP ticks a round, then — the laggards packed into the first lane groups — the tail
         const int main_rounds = std::min(rounds, (n_ticks + run_cap - 1) / run_cap);
+        h->dev.guard_rounds_left = fold ? rounds : 0;          // the tick launch that brings this to 0 is the call's last: it is the guard
         rc = issue_rounds(h, main_rounds);
         if (rc) return rc;
         if (rounds > main_rounds) {
-            if (!planner && h->n_policies == 0) {
+            // (with the eager assembly every env retires a cadence per round: there are no laggards to pack, and a one-tick call
+            // would pay three more GPU operations for the regroup than for its tick)
+            if (!planner && h->n_policies == 0 && !h->dev.P.eager) {
                 rc = hk::env_launch_regroup(h->dev, h->cfg, h->stream, h->err);
                 if (rc) { g_last_error = h->err; return rc; }
             }
@@ -594,8 +604,10 @@ static int step_ticks(hk_handle h, int n_ticks)
         rc = hk::env_flush_mcts(h->dev, h->stream, h->err);
         if (rc) { g_last_error = h->err; return rc; }
     }
-    rc = issue_check(h, lazy);
-    if (rc) return rc;
+    if (!fold) {
+        rc = issue_check(h, lazy);
+        if (rc) return rc;
+    }
     h->step_pending = lazy;
     return HK_OK;
 }

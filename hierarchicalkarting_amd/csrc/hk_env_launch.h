@@ -88,10 +88,12 @@ inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
 {
     const int s0 = d.slot1 > d.slot0 ? d.slot0 : 0, s1 = d.slot1 > d.slot0 ? d.slot1 : cfg.num_envs;
     const long long threads = (long long)(s1 - s0) * GA;
+    const int arm = d.arm_ticks, guard = (d.guard_rounds_left > 0 && --d.guard_rounds_left == 0) ? 1 : 0;
+    d.arm_ticks = 0;
 #define HK_RUN_T(MC, RWF, TRN, TL)                                                                                            \
     hipLaunchKernelGGL((env_run_kernel<MC, RWF, TRN, TL>), dim3((unsigned)((threads + 255) / 256)), dim3(256), TL ? d.tab_lds : 0, stream, d.P, d.agents, d.envs,   \
                        d.results, GameSoA{d.games, (size_t)cfg.num_envs * cfg.num_agents}, d.queue_cnt, d.queue, d.round, d.act_steer, d.act_branch, d.lq_debug, d.status,     \
-                       d.mcts, d.mset, d.rw, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase)
+                       d.mcts, d.mset, d.rw, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase, arm, guard)
 #define HK_RUN(MC, RWF, TRN) do { if (d.tab_lds) HK_RUN_T(MC, RWF, TRN, true); else HK_RUN_T(MC, RWF, TRN, false); } while (0)
     bool train = d.P.training_reset != 0;
     for (int i = 0; i < cfg.num_agents; i++) train = train || d.P.training_agent[i] != 0;

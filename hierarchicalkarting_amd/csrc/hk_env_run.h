@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
                                                       hk_episode_result* results, GameSoA games, int* queue_cnt_all,
                                                       int* queue_all, int round, const float* act_steer, const int* act_branch,
                                                       hk_lq_debug* dbg_out, int* status, MctsDev Marg, int mset, RwDev RD, const int* perm,
-                                                      unsigned long long* stats, int slot0, int slot1, int qbase)
+                                                      unsigned long long* stats, int slot0, int slot1, int qbase, int arm_ticks, int guard)
 {
     MctsDev M{};
     if (HAS_MCTS) M = Marg;
@@ -145,6 +145,7 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
     hk_env_state es;
     if (env_ok) es = envs[env];
     else { es.episode_steps = 0; es.inactive_mask = 0; es.experiment_num = 0; es.episodes_done = 0; es.status = 0; es.initial_started = 0; es.reserved[0] = 0; es.reserved[1] = 0; }
+    if (env_ok) es.reserved[0] += arm_ticks;             // the first launch of a fixed-round call arms the envs (else env_arm_kernel did)
     // nothing to do in this block? (every env finished its ticks): skip the table staging too
     if (__syncthreads_or(es.reserved[0] > 0 || (es.reserved[1] & ENV_PHASE_MASK) != 0) == 0) return;
     const TabView T = tab_stage<TAB_LDS>(P, smem);
@@ -263,6 +264,8 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
         es.reserved[1] = phase | (pack ? ENV_PACK_HINT : 0);
         envs[env] = es;
     }
+    // the last launch of a fixed-round call is its completion guard (what env_check_kernel does for the other calls)
+    if (guard && env_ok && i == 0 && (left != 0 || phase != 0)) atomicOr(status, 4);
 #ifdef HK_STAMPS
     for (int k = 0; k < HK_NSTAMP; k++) {
         unsigned v = h.st_acc[k];
