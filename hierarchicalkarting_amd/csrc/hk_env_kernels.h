@@ -271,7 +271,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         int rc0;
         if ((rc0 = detail::upload(&d.tab, pk, err))) return rc0;
         P.tab = d.tab;
-        d.tab_lds = P.tab_bytes <= 48 * 1024 ? P.tab_bytes : 0;      // Oval: ~20 KB per block
+        d.tab_lds = (P.tab_bytes <= 48 * 1024 && !std::getenv("HK_TAB_GLOBAL")) ? P.tab_bytes : 0;      // Oval: ~20 KB per block (HK_TAB_GLOBAL=1: the global-memory instantiation, for tests)
     }
     int rc;
     if ((rc = detail::upload(&d.perms, perms, err))) return rc;

@@ -1,0 +1,56 @@
+"""Parity of every instantiation of the tick kernel under every scheduling mode (a kernel whose results once depended
+on its loop form deserves a test per instantiated <HAS_MCTS, HAS_RW, HAS_TRAIN, TAB_LDS> x {eager assembly on / off, planner pause on / off,
+split batch}).  The switches are read once per process (hk_create), so every combination runs in a child process; each child steps a
+small batch through resets, short and long calls against the CPU oracle, every field of every agent record bit for bit."""
+import os
+import subprocess
+import sys
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import sys, os
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import oracle_lib as O
+import hierarchicalkarting_amd as hk
+from hierarchicalkarting_amd import _lib
+MC, FX, LQ = _lib.HK_HIGH_MCTS, _lib.HK_HIGH_FIXED, _lib.HK_LOW_LQR
+kind = %(kind)r
+kw = dict(jitter_seed=0x5EED0000, laps=1, max_episode_steps=260)
+E = 8192 + 64 if os.environ.get("HK_SPLIT") else 160
+if kind == "plain":          cfg = hk.make_config(E, 4, **kw)                                              # <false, false, false>
+elif kind == "rewards":      cfg = hk.make_config(E, 4, rewards=1, **kw)                                   # <false, true, false>
+elif kind == "planner":      cfg = hk.make_config(E, 4, high_mode=[MC, MC, FX, FX], tree_search_depth=[8, 8, 5, 5], mcts_iterations=12, **kw)          # <true, false, false>
+elif kind == "planner_rw":   cfg = hk.make_config(E, 4, high_mode=[MC, FX, MC, FX], tree_search_depth=[8, 5, 8, 5], mcts_iterations=12, rewards=1, **kw)  # <true, true, false>
+elif kind == "training":     cfg = hk.make_config(E, 4, env_mode=_lib.HK_MODE_TRAINING, training_agents=[1, 1, 0, 0], rewards=1, jitter_seed=0, laps=1, max_episode_steps=260)   # <true, true, true>
+g = hk.RacingEnv(cfg); o = O.OracleEnv(cfg)
+g.reset(); o.reset()
+t = 0
+for n in (90, 70, 1, 2, 3, 20, 7, 107, 300):          # start hold, race start, short calls, long calls (lazy / pause), a time-out reset inside
+    g.step(n); o.step(n); t += n
+    gs, os_ = g.agent_state(), o.agent_state()
+    for name in gs.dtype.names:
+        x, y = gs[name], os_[name]
+        if x.dtype.kind == "f":
+            x = x.view(np.uint32); y = y.view(np.uint32)
+        assert np.array_equal(x, y), (kind, t, name, np.argwhere(x != y)[:3].tolist())
+assert (g.env_state()["episodes_done"] >= 1).all()
+print("matrix ok", kind)
+"""
+
+MODES = {"default": {}, "no_eager": {"HK_NO_EAGER": "1"}, "tab_global": {"HK_TAB_GLOBAL": "1"}, "fixed_rounds": {"HK_FIXED_ROUNDS": "1"}}
+CASES = [(k, m) for k in ("plain", "rewards", "planner", "planner_rw", "training") for m in MODES]
+CASES += [("plain", "split"), ("rewards", "split"), ("planner", "no_pause"), ("planner_rw", "no_pause"), ("training", "no_pause")]
+MODES.update({"split": {"HK_SPLIT": "1"}, "no_pause": {"HK_MCTS_NO_PAUSE": "1"}})
+
+
+@pytest.mark.parametrize("kind,mode", CASES)
+def test_every_instantiation_under_every_mode(kind, mode):
+    env = {k: v for k, v in os.environ.items() if not k.startswith("HK_") or k in ("HK_LIB_PATH",)}
+    env.update(MODES[mode])
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "kind": kind}], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "matrix ok " + kind in r.stdout
