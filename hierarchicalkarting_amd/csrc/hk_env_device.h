@@ -9,6 +9,13 @@
 #include "../../include/hk.h"
 #include "../../include/hk_detmath.h"
 
+// the block's dynamic LDS (tests/host_emu substitutes a host buffer)
+#ifdef HK_HOST_EMU
+#define HK_DYN_SHARED(name) unsigned char* name = hk_emu::dyn_shared
+#else
+#define HK_DYN_SHARED(name) extern __shared__ __align__(16) unsigned char name[]
+#endif
+
 namespace hk {
 
 constexpr int ENV_MAXA = HK_MAX_AGENTS; // capacity of the per-agent parameter arrays; the kernels are compiled per lane-group width GA (hk_env_ga.h)
@@ -16,6 +23,7 @@ constexpr int ENV_MAXA = HK_MAX_AGENTS; // capacity of the per-agent parameter a
 #define HK_RUN_CAP 8
 #endif
 constexpr int RUN_CAP = HK_RUN_CAP;
+constexpr int MCTS_MIN_LATENCY = 40;   // (MCTS_FLUSH_ROUNDS + 1) * RUN_CAP: see flush_mcts (hk_env_launch.h)
 // Once the field has spread out (few queued games per round) longer launches pay: fewer rounds, fewer solver launches (each one
 // solve's latency).  Measured with the lazily completed long calls of round 2: 8 -> 909 M env-steps/s, 12 -> 925 M, 16 -> 911 M in the
 // steady state, but 437 / 397 / 368 M over the first 512 ticks of a race — so 12 only after BULK_TICKS.  (Same box, same call: 8 -> 893 M,
@@ -351,12 +359,22 @@ __device__ __forceinline__ void kart_core(float fx, float fz, float px, float pz
 __device__ __forceinline__ int wave_agg_inc(int* counter, bool pred)
 {
     const unsigned long long mask = __ballot(pred);
+#ifdef HK_HOST_EMU          // the host stand-in's __shfl is an exchange among ALL lanes of the group: run it before the lanes part
+    if (mask == 0ull) return -1;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (!pred) return -1;
+#else
     if (!pred) return -1;
     const int lane = threadIdx.x & 63;
     const int leader = __ffsll((long long)mask) - 1;
     int base = 0;
     if (lane == leader) base = atomicAdd(counter, __popcll(mask));
     base = __shfl(base, leader, 64);
+#endif
     return base + __popcll(mask & ((1ull << lane) - 1ull));
 }
 

@@ -13,7 +13,9 @@
 #include <type_traits>
 #include "hk_env_device.h"
 #include "hk_lq_core.h"
+#ifndef HK_HOST_EMU
 #include "hk_lq_mfma.h"
+#endif
 
 namespace hk { namespace HK_GA_NS {
 
@@ -53,5 +55,7 @@ __device__ __forceinline__ int group_or(int v)
 #include "hk_env_step.h"
 #include "hk_env_solve.h"
 #include "hk_env_run.h"
+#ifndef HK_HOST_EMU          // (the host emulation of the tick kernel stops here: tests/env_run_host_check.cpp)
 #include "hk_env_observe.h"
 #include "hk_env_launch.h"
+#endif

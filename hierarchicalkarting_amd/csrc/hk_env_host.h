@@ -64,7 +64,6 @@ struct EnvDevice {
 };
 
 constexpr int LQN_BULK_GAMES = 2048; // a round with more 3- (4-) player games than this runs them 5 (4) to a wave (hk_lq2_pair.h lqn_round_kernel)
-constexpr int MCTS_MIN_LATENCY = 40;   // (MCTS_FLUSH_ROUNDS + 1) * RUN_CAP: see flush_mcts (hk_env_launch.h)
 constexpr int MCTS_FLUSH_ROUNDS = MCTS_MIN_LATENCY / RUN_CAP - 1;      // 4 at RUN_CAP 8
 constexpr int MCTS_ARENA_WAVES = 2048;
 constexpr int BULK_TICKS = 384;        // after a full reset the field needs about this long to spread out (launch_lqn)

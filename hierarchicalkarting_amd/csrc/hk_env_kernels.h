@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <vector>
 #include "hk_env_host.h"
+#include "hk_env_params.h"
 
 namespace hk {
 
@@ -14,23 +15,6 @@ namespace hk {
 #define HK_GA_CALL(d, call) (ga_ops(d).call)
 
 namespace detail {
-
-inline double seg_seg_dist(double p1x, double p1z, double q1x, double q1z, double p2x, double p2z, double q2x, double q2z)
-{   // host-only, used for culling radii (not on the parity path)
-    auto pt_seg = [](double px, double pz, double ax, double az, double bx, double bz) {
-        double dx = bx - ax, dz = bz - az, l2 = dx * dx + dz * dz;
-        double t = l2 > 0 ? ((px - ax) * dx + (pz - az) * dz) / l2 : 0.0;
-        t = std::min(1.0, std::max(0.0, t));
-        double cx = ax + t * dx - px, cz = az + t * dz - pz;
-        return std::sqrt(cx * cx + cz * cz);
-    };
-    auto cross = [](double ax, double az, double bx, double bz) { return ax * bz - az * bx; };
-    double d1 = cross(q1x - p1x, q1z - p1z, p2x - p1x, p2z - p1z), d2 = cross(q1x - p1x, q1z - p1z, q2x - p1x, q2z - p1z);
-    double d3 = cross(q2x - p2x, q2z - p2z, p1x - p2x, p1z - p2z), d4 = cross(q2x - p2x, q2z - p2z, q1x - p2x, q1z - p2z);
-    if (((d1 > 0) != (d2 > 0)) && ((d3 > 0) != (d4 > 0))) return 0.0;
-    return std::min(std::min(pt_seg(p1x, p1z, p2x, p2z, q2x, q2z), pt_seg(q1x, q1z, p2x, p2z, q2x, q2z)),
-                    std::min(pt_seg(p2x, p2z, p1x, p1z, q1x, q1z), pt_seg(q2x, q2z, p1x, p1z, q1x, q1z)));
-}
 
 template <class T>
 int upload(T** dst, const std::vector<T>& v, std::string& err)
@@ -70,205 +54,12 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
                       hipStream_t stream, std::string& err)
 {
     const int A = cfg.num_agents, L = cfg.num_sections, E = cfg.num_envs;
-    if (E < 1 || A < 1 || L < 1 || L > HK_MAX_SECTIONS || cfg.num_walls < 0 || !cfg.sections || (cfg.num_walls > 0 && !cfg.walls)) {
-        err = "hk_create: bad num_envs / num_agents / track table"; return HK_ERR_INVALID;
-    }
-    if (A > ENV_MAXA) { err = "hk_create: num_agents > 8"; return HK_ERR_UNSUPPORTED; }
-    // The round scheduler (env_rounds_for) and the planner's request queues (two requests per agent between flushes) assume an
-    // episode outlasts the start hold and a 100-tick replan period; every reference scene uses 6 000.
-    if (cfg.max_episode_steps < 100 || cfg.max_episode_steps <= cfg.start_hold_ticks) {
-        err = "hk_create: max_episode_steps must be >= 100 and exceed start_hold_ticks"; return HK_ERR_INVALID;
-    }
-    if (cfg.start_hold_ticks < 0 || cfg.laps < 1 || cfg.section_horizon < 1 || cfg.section_horizon > 16 || !(cfg.dt > 0.0f)) {
-        err = "hk_create: bad start_hold_ticks / laps / section_horizon / dt"; return HK_ERR_INVALID;
-    }
-    for (int i = 0; i < A; i++) {
-        if (cfg.n_team[i] < 0 || cfg.n_other[i] < 0 || cfg.n_team[i] + cfg.n_other[i] != A - 1) {
-            err = "hk_create: teamAgents + otherAgents of every agent must list every other agent exactly once"; return HK_ERR_INVALID;
-        }
-        // every entry in range, not the agent itself, no duplicates (the kernels index kart arrays with them)
-        uint32_t seen = 1u << i;
-        for (int j = 0; j < cfg.n_team[i] + cfg.n_other[i]; j++) {
-            const int o = j < cfg.n_team[i] ? cfg.team_agents[i][j] : cfg.other_agents[i][j - cfg.n_team[i]];
-            if (o < 0 || o >= A || ((seen >> o) & 1u)) {
-                err = "hk_create: teamAgents / otherAgents entries must be distinct agent indices in [0, num_agents) other than the agent itself"; return HK_ERR_INVALID;
-            }
-            seen |= 1u << o;
-        }
-        if (cfg.high_mode[i] != HK_HIGH_FIXED && cfg.high_mode[i] != HK_HIGH_MCTS) { err = "hk_create: bad high_mode"; return HK_ERR_INVALID; }
-        if (cfg.high_mode[i] == HK_HIGH_MCTS) {
-            if (cfg.tree_search_depth[i] < 1 || cfg.tree_search_depth[i] > HK_MCTS_MAX_DEPTH || cfg.velocity_bucket_size[i] < 1 ||
-                cfg.time_precision[i] < 1 || cfg.section_window[i] < 1 || cfg.section_window[i] > 4) { err = "hk_create: bad MCTS gameParams (depth 1..8, bucket, precision, window 1..4)"; return HK_ERR_INVALID; }
-            // a search requested on tick t runs between two launches of the tick kernel (<= RUN_CAP ticks each) and must be
-            // finished before tick t + latency; it must also have been consumed before the next request (every 100 ticks)
-            if (cfg.mcts_iterations < 1 || cfg.mcts_initial_iterations < 1 || cfg.mcts_latency_ticks <= MCTS_MIN_LATENCY || cfg.mcts_latency_ticks >= 100 ||
-                cfg.mcts_initial_latency_ticks <= MCTS_MIN_LATENCY || cfg.mcts_initial_latency_ticks >= 100) {
-                err = "hk_create: MCTS budget / latency out of range (iterations >= 1, 40 < latency ticks < 100)"; return HK_ERR_INVALID;
-            }
-        }
-        if (cfg.low_mode[i] != HK_LOW_LQR && cfg.low_mode[i] != HK_LOW_RL) { err = "hk_create: LowMode MPC is dead code in the reference"; return HK_ERR_UNSUPPORTED; }
-        if (cfg.tree_search_depth[i] < 0 || cfg.tree_search_depth[i] > L) { err = "hk_create: bad tree_search_depth"; return HK_ERR_INVALID; }
-    }
-    sections.assign(cfg.sections, cfg.sections + L);
-    walls.assign(cfg.walls, cfg.walls + cfg.num_walls);
-    cfg.sections = sections.data();
-    cfg.walls = walls.data();
     EnvParams& P = d.P;
-    std::memset(&P, 0, sizeof(P));
-    P.E = E; P.A = A; P.L = L; P.NW = cfg.num_walls;
-    P.dt = cfg.dt; P.kart_y = cfg.kart_y; P.st = cfg.stats;
-    P.laps = cfg.laps; P.max_steps = cfg.max_episode_steps; P.max_lane_changes = cfg.max_lane_changes;
-    P.H = cfg.section_horizon; P.disable_on_end = cfg.disable_on_end; P.hold = cfg.start_hold_ticks; P.auto_reset = cfg.auto_reset;
-    for (int i = 0; i < A; i++) {
-        P.high_mode[i] = cfg.high_mode[i]; P.low_mode[i] = cfg.low_mode[i]; P.depth[i] = cfg.tree_search_depth[i];
-        P.vbucket[i] = cfg.velocity_bucket_size[i];
-        P.team_of[i] = cfg.team_of[i]; P.time_precision[i] = cfg.time_precision[i]; P.section_window[i] = cfg.section_window[i];
-        if (cfg.high_mode[i] == HK_HIGH_MCTS) P.any_mcts += 1;
-        P.n_team[i] = cfg.n_team[i]; P.n_other[i] = cfg.n_other[i];
-        for (int j = 0; j < ENV_MAXA; j++) { P.team[i][j] = cfg.team_agents[i][j]; P.other[i][j] = cfg.other_agents[i][j]; }
-    }
-    for (int i = 0; i < HK_NUM_SENSORS; i++) {
-        const float dl = cfg.sensor_yaw_deg[i] * DEG2RAD_F;
-        P.sens_c[i] = hk_cosf(dl); P.sens_s[i] = hk_sinf(dl); P.ray_dist[i] = cfg.ray_distance[i];
-    }
-    P.training_reset = cfg.env_mode == HK_MODE_TRAINING ? 1 : 0; P.train_seed = cfg.train_seed;
-    P.hold_dedupe = 0;          // set below, once the planner count is known
-    P.rewards = cfg.rewards; P.rw = cfg.rw;
-    for (int i = 0; i < HK_NUM_SENSORS; i++) { P.wall_val[i] = cfg.wall_hit_validation[i]; P.agent_val[i] = cfg.agent_hit_validation[i]; }
-    for (int i = 0; i < A; i++) {
-        if (cfg.team_of[i] < 0 || cfg.team_of[i] >= A) { err = "hk_create: team_of out of range"; return HK_ERR_INVALID; }
-        P.training_agent[i] = cfg.training_agent[i];
-        P.team_size[cfg.team_of[i]] += 1;
-        if (cfg.team_of[i] + 1 > P.n_teams) P.n_teams = cfg.team_of[i] + 1;
-    }
-    P.hold_dedupe = (P.any_mcts == 0 && !P.training_reset && !std::getenv("HK_NO_HOLD_DEDUPE")) ? 1 : 0;
-    P.run_cap = RUN_CAP;
-    P.eager = 0;
-    P.mcts_iter = cfg.mcts_iterations; P.mcts_iter0 = cfg.mcts_initial_iterations; P.mcts_lat = cfg.mcts_latency_ticks;
-    P.mcts_lat0 = cfg.mcts_initial_latency_ticks; P.mcts_seed = cfg.mcts_seed;
-    P.jitter_seed = cfg.jitter_seed; P.jitter_pos = cfg.jitter_pos; P.jitter_yaw = cfg.jitter_yaw; P.env_id_base = cfg.env_id_base;
-    P.max_speed = cfg.stats.TopSpeed > cfg.stats.ReverseSpeed ? cfg.stats.TopSpeed : cfg.stats.ReverseSpeed;   // AK:210
-    P.init_acc = -cfg.stats.TireWearRate * hk_logf(1 - ((cfg.stats.MaxSteer - cfg.stats.MinSteer) * 0.25f / cfg.stats.MaxSteer));  // REC:588
+    std::vector<int> perms;
     {
-        const float dyc = 0.5f - 0.582f;   // sensor height - capsule centre height (kart-local)
-        P.ray_agent_r = sqrtf(CAP_R * CAP_R - dyc * dyc);
-    }
-    { const char* dbg = std::getenv("HK_LQ_DEBUG"); P.debug = cfg.debug_taps | (dbg ? std::atoi(dbg) : 0); }   // hk_get_lq_debug taps (hk.h: debug_taps)
-    // sections with forward precomputed (same float expressions as everywhere else)
-    std::vector<SecDev> sd(L);
-    for (int i = 0; i < L; i++) {
-        const hk_section& s = sections[i];
-        SecDev& o = sd[i];
-        o.trig_x = s.trig_x; o.trig_z = s.trig_z;
-        o.yaw_rad = s.yaw_deg * DEG2RAD_F;
-        o.fx = hk_sinf(o.yaw_rad); o.fz = hk_cosf(o.yaw_rad);
-        o.marker_y = s.marker_y; o.inside_radius = s.track_inside_radius; o.optimal_lane = s.optimal_lane;
-        for (int l = 0; l < 4; l++) { o.lane_x[l] = s.lane_x[l]; o.lane_z[l] = s.lane_z[l]; }
-    }
-    // uniform wall grid: per cell every wall segment within GRID_REACH of the cell rectangle, ascending wall index
-    std::vector<unsigned short> goff, gidx;
-    {
-        float x0 = 0, x1 = 1, z0 = 0, z1 = 1;
-        for (size_t w = 0; w < walls.size(); w++) {
-            const hk_wall_seg& s = walls[w];
-            float lx = std::min(s.x0, s.x1), hx = std::max(s.x0, s.x1), lz = std::min(s.z0, s.z1), hz = std::max(s.z0, s.z1);
-            if (w == 0) { x0 = lx; x1 = hx; z0 = lz; z1 = hz; }
-            x0 = std::min(x0, lx); x1 = std::max(x1, hx); z0 = std::min(z0, lz); z1 = std::max(z1, hz);
-        }
-        P.grid_x0 = std::floor(x0) - 1.0f; P.grid_z0 = std::floor(z0) - 1.0f;
-        P.grid_inv = 1.0f / GRID_CELL;
-        P.grid_nx = (int)std::ceil((x1 + 1.0f - P.grid_x0) / GRID_CELL) + 1;
-        P.grid_nz = (int)std::ceil((z1 + 1.0f - P.grid_z0) / GRID_CELL) + 1;
-        const size_t ncell = (size_t)P.grid_nx * P.grid_nz;
-        goff.assign(ncell + 1, 0);
-        for (int iz = 0; iz < P.grid_nz; iz++)
-            for (int ix = 0; ix < P.grid_nx; ix++) {
-                const double cx0 = P.grid_x0 + ix * (double)GRID_CELL, cz0 = P.grid_z0 + iz * (double)GRID_CELL;
-                const double cx1 = cx0 + GRID_CELL, cz1 = cz0 + GRID_CELL;
-                const size_t c = (size_t)iz * P.grid_nx + ix;
-                if (gidx.size() > 65000) { err = "hk_create: wall grid too large"; return HK_ERR_UNSUPPORTED; }
-                goff[c] = (unsigned short)gidx.size();
-                for (size_t w = 0; w < walls.size(); w++) {
-                    const hk_wall_seg& s = walls[w];
-                    auto inside = [&](double x, double z) { return x >= cx0 && x <= cx1 && z >= cz0 && z <= cz1; };
-                    double dmin = (inside(s.x0, s.z0) || inside(s.x1, s.z1)) ? 0.0 : 1e30;
-                    const double ex[5] = {cx0, cx1, cx1, cx0, cx0}, ez[5] = {cz0, cz0, cz1, cz1, cz0};
-                    for (int q = 0; q < 4 && dmin > 0.0; q++)
-                        dmin = std::min(dmin, detail::seg_seg_dist(s.x0, s.z0, s.x1, s.z1, ex[q], ez[q], ex[q + 1], ez[q + 1]));
-                    if (dmin <= (double)GRID_REACH) gidx.push_back((unsigned short)w);
-                }
-            }
-        goff[ncell] = (unsigned short)gidx.size();
-    }
-    // cut table: Physics.Raycast(lane marker -> next lane marker) vs every wall (HKA:832), static geometry
-    std::vector<unsigned char> cut((size_t)L * 25, 0);
-    for (int s = 0; s < L; s++)
-        for (int la = 0; la < 5; la++)
-            for (int lb = 0; lb < 5; lb++) {
-                const hk_section& a = sections[s];
-                const hk_section& b = sections[(s + 1) % L];
-                float lx = la ? a.lane_x[la - 1] : a.trig_x, lz = la ? a.lane_z[la - 1] : a.trig_z;
-                float nx = lb ? b.lane_x[lb - 1] : b.trig_x, nz = lb ? b.lane_z[lb - 1] : b.trig_z;
-                float cdx = nx - lx, cdz = nz - lz;
-                float clen = sqrtf((lx - nx) * (lx - nx) + 0.0f * 0.0f + (lz - nz) * (lz - nz));
-                bool hit = false;
-                if (clen > 0.0f) {
-                    float dx = cdx / clen, dz = cdz / clen;
-                    for (size_t w = 0; w < walls.size() && !hit; w++) {
-                        float t = ray_seg_host(lx, lz, dx, dz, walls[w]);
-                        if (t >= 0.0f && t <= clen) hit = true;
-                    }
-                }
-                cut[((size_t)s * 5 + la) * 5 + lb] = hit ? 1 : 0;
-            }
-    // lexicographic permutations (REC:137-145,166)
-    std::vector<int> perm(A), perms;
-    for (int i = 0; i < A; i++) perm[i] = i;
-    do { perms.insert(perms.end(), perm.begin(), perm.end()); } while (std::next_permutation(perm.begin(), perm.end()));
-    P.nperm = (int)(perms.size() / A);
-    // pack the tables: [SecDev L][walls NW][grid_off u16][grid_idx u16][cut u8], 16-B aligned
-    {
-        if (walls.size() > 65535) { err = "hk_create: more than 65535 wall segments"; return HK_ERR_UNSUPPORTED; }
         std::vector<unsigned char> pk;
-        auto seg = [&](const void* src, size_t bytes) {
-            size_t off = (pk.size() + 15) & ~size_t(15);
-            pk.resize(off + bytes);
-            if (bytes) std::memcpy(pk.data() + off, src, bytes);
-            return (int)off;
-        };
-        seg(sd.data(), sd.size() * sizeof(SecDev));
-        P.o_walls = seg(walls.data(), walls.size() * sizeof(hk_wall_seg));
-        P.o_goff = seg(goff.data(), goff.size() * sizeof(unsigned short));
-        P.o_gidx = seg(gidx.data(), gidx.size() * sizeof(unsigned short));
-        P.o_cut = seg(cut.data(), cut.size());
-        {   // Trigger candidate masks over a coarse grid whose box holds the wall grid and every Trigger centre
-            double bx0 = P.grid_x0, bz0 = P.grid_z0, bx1 = P.grid_x0 + P.grid_nx * (double)GRID_CELL, bz1 = P.grid_z0 + P.grid_nz * (double)GRID_CELL;
-            for (int t = 0; t < L; t++) {
-                bx0 = std::min(bx0, (double)sections[t].trig_x - 1.0); bx1 = std::max(bx1, (double)sections[t].trig_x + 1.0);
-                bz0 = std::min(bz0, (double)sections[t].trig_z - 1.0); bz1 = std::max(bz1, (double)sections[t].trig_z + 1.0);
-            }
-            P.tgrid_x0 = (float)std::floor(bx0); P.tgrid_z0 = (float)std::floor(bz0);
-            P.tgrid_inv = 1.0f / TRIG_CELL;
-            P.tgrid_nx = (int)std::ceil((bx1 - P.tgrid_x0) / TRIG_CELL) + 1;
-            P.tgrid_nz = (int)std::ceil((bz1 - P.tgrid_z0) / TRIG_CELL) + 1;
-            if ((long long)P.tgrid_nx * P.tgrid_nz > 65536) { err = "hk_create: track too large for the Trigger grid"; return HK_ERR_UNSUPPORTED; }
-            std::vector<uint32_t> tm((size_t)P.tgrid_nx * P.tgrid_nz * 2, 0u);
-            for (int iz = 0; iz < P.tgrid_nz; iz++)
-                for (int ix = 0; ix < P.tgrid_nx; ix++) {
-                    // 0.25 m slack on the cell rectangle for the float rounding of the cell index
-                    const double cx0 = P.tgrid_x0 + ix * (double)TRIG_CELL - 0.25, cz0 = P.tgrid_z0 + iz * (double)TRIG_CELL - 0.25;
-                    const double cx1 = cx0 + TRIG_CELL + 0.5, cz1 = cz0 + TRIG_CELL + 0.5;
-                    for (int t = 0; t < L; t++) {
-                        const double tx = sections[t].trig_x, tz = sections[t].trig_z;
-                        const double ddx = tx < cx0 ? cx0 - tx : (tx > cx1 ? tx - cx1 : 0.0), ddz = tz < cz0 ? cz0 - tz : (tz > cz1 ? tz - cz1 : 0.0);
-                        if (ddx * ddx + ddz * ddz <= (double)TRIG_REACH * TRIG_REACH) tm[((size_t)iz * P.tgrid_nx + ix) * 2 + (t >> 5)] |= 1u << (t & 31);
-                    }
-                }
-            P.o_tmask = seg(tm.data(), tm.size() * sizeof(uint32_t));
-        }
-        pk.resize((pk.size() + 15) & ~size_t(15));
-        P.tab_bytes = (int)pk.size();
         int rc0;
+        if ((rc0 = env_build_params(cfg, sections, walls, P, pk, perms, err))) return rc0;
         if ((rc0 = detail::upload(&d.tab, pk, err))) return rc0;
         P.tab = d.tab;
         d.tab_lds = (P.tab_bytes <= 48 * 1024 && !std::getenv("HK_TAB_GLOBAL")) ? P.tab_bytes : 0;      // Oval: ~20 KB per block (HK_TAB_GLOBAL=1: the global-memory instantiation, for tests)

@@ -905,7 +905,7 @@ inline size_t mcts_table_lds_bytes(int ntab, int L)
 inline size_t mcts_search_lds_bytes(int ntab, int L, int waves) { return mcts_table_lds_bytes(ntab, L) + (size_t)waves * MC_PATH_BYTES; }
 __global__ HK_MC_BOUNDS void mcts_search_kernel(EnvParams P, MctsDev M, int set, int ntab, uint32_t cls_agents)
 {
-    extern __shared__ __align__(16) unsigned char mc_smem[];
+    HK_DYN_SHARED(mc_smem);
     const int count = M.qcnt[set * 2];
     if (count == 0) return;                                  // (uniform: nothing queued, no table copy either)
     short* dt_s = reinterpret_cast<short*>(mc_smem);

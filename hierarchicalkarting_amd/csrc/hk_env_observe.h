@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_
                                                           uint32_t agent_mask /* bit i: agent slot i is observed */)
 {
     // the track tables (wall grid walked by nine 20 m rays per agent) staged in LDS, as in the tick kernel
-    extern __shared__ __align__(16) unsigned char smem[];
+    HK_DYN_SHARED(smem);
     const TabView T = tab_stage<TAB_LDS>(P, smem);
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int gid0 = tid / OBS_LANES, l = tid % OBS_LANES;

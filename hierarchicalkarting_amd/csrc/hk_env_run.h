@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
     MctsDev M{};
     if (HAS_MCTS) M = Marg;
     __shared__ KartS ks[256];
-    extern __shared__ __align__(16) unsigned char smem[];
+    HK_DYN_SHARED(smem);
     // this launch runs the lane groups [slot0, slot1) and uses the queue sets qbase, qbase + 1 (one launch for every env: 0, E, 0;
     // plain handles split the batch in two halves on two streams so that one half's solver launch hides behind the other's ticks)
     const int gid = slot0 * GA + blockIdx.x * blockDim.x + threadIdx.x;

@@ -606,6 +606,7 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
     return N;                // the caller bins the game by N (wave-aggregated slot allocation needs every queued lane together)
 }
 
+#ifndef HK_HOST_EMU          // the solver kernels are not part of the host emulation of the tick kernel
 // ---------------------------------------------------------------------------------------------------------------
 // K_B2b: multi-player games of one size NP from queue[NP-2], 64/(4*NP) per wave
 // ---------------------------------------------------------------------------------------------------------------
@@ -799,5 +800,7 @@ __global__ __launch_bounds__(64) void lqn_big_kernel(EnvParams P, hk_agent_state
     else lqn_body<NB>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
 }
 #endif
+
+#endif  // HK_HOST_EMU
 
 } }  // namespace hk::HK_GA_NS
