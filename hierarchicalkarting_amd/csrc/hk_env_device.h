@@ -68,8 +68,9 @@ struct EnvParams {
     int debug;
     // the read-only track tables live in ONE packed buffer (16-B aligned segments); kernels copy it to LDS
     const unsigned char* tab;   // packed tables in global memory
-    int tab_bytes, o_walls, o_goff, o_gidx, o_cut, o_tmask;
-    // uniform grid over the walls' bounding box: cell (ix, iz) lists every wall segment within GRID_REACH of the cell
+    int tab_bytes, o_walls, o_goff, o_gidx, o_cut, o_tmask, o_noff, o_nidx;
+    // uniform grid over the walls' bounding box: cell (ix, iz) lists every wall segment within GRID_REACH of the cell, and (the
+    // "near" list) every one within NEAR_REACH
     float grid_x0, grid_z0, grid_inv;   // origin and 1 / cell size
     int grid_nx, grid_nz;
     // coarse grid over the same box: per TRIG_CELL x TRIG_CELL cell a 64-bit mask of the section Triggers a kart in that cell can overlap
@@ -142,8 +143,9 @@ struct RwDev {
 constexpr float TRIG_CELL = 8.0f;       // coarse cell of the Trigger candidate masks
 constexpr float TRIG_REACH = 6.6f;      // a kart overlaps a Trigger only within 6.5 m of its centre (box half diagonal 5.03 + capsule reach 1.11)
 constexpr float GRID_CELL = 2.0f;       // cell size (m)
-constexpr float GRID_REACH = 2.2f;      // list radius: 2 m side rays / 1 m half-spacing of the long-ray samples / 1.11 m
-                                        // contact reach, plus slack for float rounding of the cell index
+constexpr float GRID_REACH = 2.2f;      // list radius: the 2 m side rays, plus slack for float rounding of the cell index
+constexpr float NEAR_REACH = 1.3f;      // the near list: 1 m half-spacing of the long-ray samples / 1.11 m contact reach, plus slack.
+                                        // On the racing line it is empty: a tick's wall-contact pass then costs two LDS reads.
 
 // where a kernel reads the track tables from: the packed global buffer, or its per-block LDS copy
 struct TabView {
@@ -151,6 +153,8 @@ struct TabView {
     const hk_wall_seg* walls;     // [NW]
     const unsigned short* grid_off;   // [nx*nz + 1] candidate wall segments per grid cell (ascending wall index)
     const unsigned short* grid_idx;
+    const unsigned short* near_off;   // [nx*nz + 1] the same for NEAR_REACH (a subset of the cell's list, same order)
+    const unsigned short* near_idx;
     const unsigned char* cut;     // [L][5][5]: does the ray lane marker -> next lane marker hit a wall (HKA:832)
     const uint2* tmask;           // [tgrid_nx * tgrid_nz] Trigger candidates per coarse cell (bit t = section t)
 };
@@ -161,6 +165,8 @@ __host__ __device__ inline TabView tab_view(const EnvParams& P, const unsigned c
     T.walls = reinterpret_cast<const hk_wall_seg*>(base + P.o_walls);
     T.grid_off = reinterpret_cast<const unsigned short*>(base + P.o_goff);
     T.grid_idx = reinterpret_cast<const unsigned short*>(base + P.o_gidx);
+    T.near_off = reinterpret_cast<const unsigned short*>(base + P.o_noff);
+    T.near_idx = reinterpret_cast<const unsigned short*>(base + P.o_nidx);
     T.cut = base + P.o_cut;
     T.tmask = reinterpret_cast<const uint2*>(base + P.o_tmask);
     return T;

@@ -516,8 +516,8 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
         }
         // sensor rays of the own kart (Physics.Raycast vs TrackMask, HKA:834-844,906) through the wall grid.  Sensors
         // 2, 4, 8, 6 are at most 2 m long: every wall they can hit is in the list of the origin's cell.  Sensor 0 is
-        // compared with up to 8 m: a hit at distance t <= 9 lies within 1 m of one of the samples o + {0,2,4,6,8} d,
-        // so the union of those five cells' lists contains it.  Lists are supersets; the minimum is what a scan of
+        // compared with up to 8 m (and with speed / 2): a hit at distance t <= 11 lies within 1 m of one of the samples
+        // o + {0,2,4,6,8,10} d, so the union of those six cells' NEAR lists (NEAR_REACH 1.3 m) contains it.  Lists are supersets; the minimum is what a scan of
         // every wall (the oracle) returns.
         const float ox = k.px + SENSOR_LZ * k.fx, oz = k.pz + SENSOR_LZ * k.fz;
         HK_ST(h, 14);
@@ -527,14 +527,14 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
             float best = 3.0e38f;
             int prev = -1;
 #pragma unroll 1
-            for (int sm = 0; sm < 5; sm++) {
+            for (int sm = 0; sm < 6; sm++) {
                 const float sd = 2.0f * (float)sm;
                 const int cell = grid_cell(P, ox + d0x * sd, oz + d0z * sd);
                 if (cell == prev) continue;
                 prev = cell;
-                const int w0 = T.grid_off[cell], w1 = T.grid_off[cell + 1];
+                const int w0 = T.near_off[cell], w1 = T.near_off[cell + 1];
                 for (int w = w0; w < w1; w++) {
-                    float t = ray_seg(ox, oz, d0x, d0z, T.walls[T.grid_idx[w]]);
+                    float t = ray_seg(ox, oz, d0x, d0z, T.walls[T.near_idx[w]]);
                     if (t >= 0.0f && t < best) best = t;
                 }
             }
@@ -553,6 +553,11 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
             const int w0 = T.grid_off[cell], w1 = T.grid_off[cell + 1];
             for (int w = w0; w < w1; w++) {
                 const hk_wall_seg ws = T.walls[T.grid_idx[w]];
+#ifndef HK_NO_SHORT_RAY_CULL
+                // the four rays are compared with 2 m and 1.5 m only (side, below): a wall whose box is further than that from the
+                // origin cannot change any of the comparisons (1 cm margin >> float rounding); most of a cell's list is
+                if (f_max(ws.x0, ws.x1) < ox - 2.01f || f_min(ws.x0, ws.x1) > ox + 2.01f || f_max(ws.z0, ws.z1) < oz - 2.01f || f_min(ws.z0, ws.z1) > oz + 2.01f) continue;
+#endif
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     float t = ray_seg(ox, oz, ddx[q], ddz[q], ws);

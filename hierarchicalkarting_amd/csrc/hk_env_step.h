@@ -466,9 +466,9 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
         for (int pass = 0; pass < 2; pass++) {
             float ax, az, bx, bz;
             kart_core(cfx, cfz, px, pz, ax, az, bx, bz);
-            // a contact needs a wall within CAP_R of the core, i.e. within 1.11 m of the kart origin: the cell's list
+            // a contact needs a wall within CAP_R of the core, i.e. within 1.11 m of the kart origin: the cell's near list
             const int cell = grid_cell(P, px, pz);
-            const int w0 = T.grid_off[cell], w1 = T.grid_off[cell + 1];
+            const int w0 = T.near_off[cell], w1 = T.near_off[cell + 1];
             float bestpen = 0.0f, bnx = 0.0f, bnz = 0.0f;
             bool found = false;
             // Two passes over the cell's list, 32 walls at a time: a cheap bounding-box test marks the walls that can be within
@@ -486,7 +486,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                     // this pass costs); slots past the end re-read the last wall and are masked out
                     hk_wall_seg ws[4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) ws[j] = T.walls[T.grid_idx[base + ((q + j) < nq ? (q + j) : (nq - 1))]];
+                    for (int j = 0; j < 4; j++) ws[j] = T.walls[T.near_idx[base + ((q + j) < nq ? (q + j) : (nq - 1))]];
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const bool apart = f_max(ws[j].x0, ws[j].x1) < kx0 || f_min(ws[j].x0, ws[j].x1) > kx1 ||
@@ -497,7 +497,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                 while (cand) {
                     const int q = __ffs((int)cand) - 1;
                     cand &= cand - 1u;
-                    const hk_wall_seg ws = T.walls[T.grid_idx[base + q]];
+                    const hk_wall_seg ws = T.walls[T.near_idx[base + q]];
                     float c1x, c1z, c2x, c2z;
                     float d2 = seg_seg_closest(ax, az, bx, bz, ws.x0, ws.z0, ws.x1, ws.z1, c1x, c1z, c2x, c2z);
                     if (d2 < CAP_R * CAP_R) {
@@ -511,7 +511,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                             nx = -ez / el; nz = ex / el;
                             if ((px - ws.x0) * nx + (pz - ws.z0) * nz < 0.0f) { nx = -nx; nz = -nz; }
                         }
-                        // grid_idx is ascending per cell, so "first strictly deeper" == the oracle's lowest-index tie break
+                        // near_idx is ascending per cell, so "first strictly deeper" == the oracle's lowest-index tie break
                         if (!found || pen > bestpen) { found = true; bestpen = pen; bnx = nx; bnz = nz; }
                     }
                 }
@@ -548,6 +548,12 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                 const SecDev& s = T.sec[t];
                 // exact cull: box half diagonal 5.03 + capsule reach 1.11 < 6.5
                 if ((px - s.trig_x) * (px - s.trig_x) + (pz - s.trig_z) * (pz - s.trig_z) > 6.5f * 6.5f) continue;
+#ifndef HK_NO_TRIG_SLAB_CULL
+                // exact cull: the box is 1 m thick along its forward axis and every point of the capsule lies within 1.107 m of the kart
+                // origin, so an origin further than 0.5 + 1.107 (+ 1 cm >> float rounding) from the mid plane cannot overlap — true on most
+                // of the ticks that pass the distance cull (a kart is within 6.5 m of the next Trigger for a third of every section)
+                if (f_abs((px - s.trig_x) * s.fx + (pz - s.trig_z) * s.fz) > TRIG_HZ + 1.117f) continue;
+#endif
                 float rax = ax - s.trig_x, raz = az - s.trig_z, rbx = bx - s.trig_x, rbz = bz - s.trig_z;
                 float lax = rax * s.fz - raz * s.fx, laz = rax * s.fx + raz * s.fz;
                 float lbx = rbx * s.fz - rbz * s.fx, lbz = rbx * s.fx + rbz * s.fz;

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 
 #define __global__
 #define __device__
@@ -42,16 +43,28 @@ namespace hk_emu {
 constexpr int LANES = 4;
 // a reusable barrier for LANES threads that reports a hang instead of deadlocking
 struct Barrier {
-    std::mutex m; std::condition_variable cv; int count = 0; unsigned gen = 0;
+    // sense-reversing spin barrier (the lanes meet thousands of times per tick: a condition variable's wake-up latency dominated the run)
+    std::atomic<int> count{0};
+    std::atomic<unsigned> gen{0};
     void wait(const char* what)
     {
-        std::unique_lock<std::mutex> lk(m);
-        const unsigned g = gen;
-        if (++count == LANES) { count = 0; gen++; cv.notify_all(); return; }
-        if (!cv.wait_for(lk, std::chrono::seconds(20), [&] { return gen != g; })) {
-            std::fprintf(stderr, "HK_EMU: cross-lane primitive '%s' reached by only part of the lane group (lane %u waited)\n", what, threadIdx.x);
-            std::fflush(stderr);
-            std::_Exit(3);
+        const unsigned g = gen.load(std::memory_order_acquire);
+        if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == LANES) {
+            count.store(0, std::memory_order_relaxed);
+            gen.store(g + 1, std::memory_order_release);
+            return;
+        }
+        unsigned long spins = 0;
+        std::chrono::steady_clock::time_point t0;
+        while (gen.load(std::memory_order_acquire) == g) {
+            if (++spins < 200) continue;
+            std::this_thread::yield();
+            if (spins == 200) t0 = std::chrono::steady_clock::now();
+            else if ((spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                std::fprintf(stderr, "HK_EMU: cross-lane primitive '%s' reached by only part of the lane group (lane %u waited)\n", what, threadIdx.x);
+                std::fflush(stderr);
+                std::_Exit(3);
+            }
         }
     }
 };
