@@ -116,8 +116,10 @@ void hko_cost_build(int M, const double target[4], const double target_w[4], dou
 /*
  * MathNet.Numerics 4.15.0 Matrix<double>.Solve for a square (sparse-storage) matrix = UserLU (JAMA-style
  * left-looking Doolittle with partial pivoting, pivot = first strictly larger |.|), then L-forward / U-backward
- * substitution on the pivoted right-hand sides.  Restated from MathNet's published algorithm (the DLL has no source
- * under /root/reference): parity unpinned at this boundary; any backward-stable LU agrees to ~1e-14 here (cond <= ~8).
+ * substitution on the pivoted right-hand sides.  Restated from MathNet's published algorithm and checked against the IL of the
+ * binary the reference ships (tools/mathnet_il.py, tests/test_mathnet_il.py: dispatch Solve -> LU() -> UserLU.Create for sparse
+ * storage, accumulation s = s + a * b with k ascending, strict '>' pivot test, division by the pivot, substitution order).  The
+ * products around it (MathNet's sparse multiply) stay unpinned; any backward-stable LU agrees to ~1e-14 here (cond <= ~8).
  * LU (m x m) row-major is overwritten by the factors; Bm (m x nb) row-major by the solution.
  */
 static int lu_solve(int m, double* LU, int nb, double* Bm)
