@@ -1030,7 +1030,7 @@ int hk_prof_reset(hk_handle h)
     h->prof.fold();
     for (int s = 0; s < HK_PROF_STAGES; s++) { h->prof.ms[s] = 0; h->prof.n[s] = 0; }
     if (h->env_ready && h->dev.game_stats) {
-        HK_HIP(h, hipMemsetAsync(h->dev.game_stats, 0, 64 * sizeof(unsigned long long), h->stream));
+        HK_HIP(h, hipMemsetAsync(h->dev.game_stats, 0, hk::GAME_STATS_N * sizeof(unsigned long long), h->stream));
         HK_HIP(h, hipStreamSynchronize(h->stream));
     }
     return HK_OK;
@@ -1040,13 +1040,13 @@ int hk_prof_games(hk_handle h, int64_t* games)
 {
     HK_NEED_ENV(h);
     if (!games) return fail(h, HK_ERR_INVALID, "hk_prof_games: NULL pointer");
-    unsigned long long g[64];
+    unsigned long long g[hk::GAME_STATS_N];
     HK_HIP(h, hipMemcpyAsync(g, h->dev.game_stats, sizeof(g), hipMemcpyDeviceToHost, h->stream));
     HK_HIP(h, hipStreamSynchronize(h->stream));
     for (int n = 0; n <= HK_MAX_AGENTS; n++) games[n] = (int64_t)g[n];
     if (h->tune.stamps_dump) {       // diagnostic builds (-DHK_STAMPS): the phase cycle counters of the tick kernel
         std::fprintf(stderr, "HK_STAMPS");
-        for (int k = 16; k < 64; k++) std::fprintf(stderr, " %llu", g[k]);
+        for (int k = 16; k < hk::GAME_STATS_N; k++) std::fprintf(stderr, " %llu", g[k]);
         std::fprintf(stderr, "\n");
     }
     return HK_OK;

@@ -399,6 +399,16 @@ __device__ inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_
 }
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
+constexpr int GAME_STATS_N = 160;      // game_stats: [0, 16) games by player count, [16, 64) cycle stamps, [64, 160) lane-participation probes
+// Diagnostic build only (-DHK_LANEPROF, tools/lane_profile.py): probe k counts the waves that reach it and the lanes switched on when they do
+// (game_stats[64 + 2k] lanes, [65 + 2k] waves) — where in the tick kernel the masked half of the average vector instruction lives.
+#ifdef HK_LANEPROF
+__device__ unsigned long long* hk_lp_ptr;
+#define HK_LP(k) do { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) { \
+    atomicAdd(&hk_lp_ptr[64 + 2 * (k)], (unsigned long long)__popcll(m_)); atomicAdd(&hk_lp_ptr[65 + 2 * (k)], 1ull); } } while (0)
+#else
+#define HK_LP(k) do { } while (0)
+#endif
 // Diagnostic build only (-DHK_STAMPS, tools/stamp_profile.py): cycle stamps at the phase boundaries of the fused tick kernel,
 // accumulated per lane, reduced to the wave's maximum and added to game_stats[16 + k] when the kernel ends.
 #ifdef HK_STAMPS

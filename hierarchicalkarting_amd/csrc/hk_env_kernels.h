@@ -82,7 +82,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     HK_ALLOC(d.act_branch, na * sizeof(int32_t));
     HK_ALLOC(d.reward_out, 2 * na * sizeof(float));
     HK_ALLOC(d.status, 4 * sizeof(int));
-    HK_ALLOC(d.game_stats, 64 * sizeof(unsigned long long));     // [0, 16) games by player count, [16, 64) diagnostic stamps
+    HK_ALLOC(d.game_stats, GAME_STATS_N * sizeof(unsigned long long));     // (hk_env_device.h: GAME_STATS_N)
     HK_ALLOC(d.games, na * HK_GA_CALL(d, game_doubles_per_ego()) * sizeof(double));
     HK_ALLOC(d.queue_cnt, 4 * 16 * sizeof(int));
     HK_ALLOC(d.perm, (size_t)E * sizeof(int));

@@ -128,6 +128,9 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
 {
     MctsDev M{};
     if (HAS_MCTS) M = Marg;
+#ifdef HK_LANEPROF
+    hk_lp_ptr = stats;                 // (every thread stores the same value)
+#endif
     __shared__ KartS ks[256];
     HK_DYN_SHARED(smem);
     // this launch runs the lane groups [slot0, slot1) and uses the queue sets qbase, qbase + 1 (one launch for every env: 0, E, 0;
@@ -193,7 +196,9 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
         bool began = false;          // this env ran phases A / B1 in this iteration (it was at a tick boundary and not parked)
         bool solved = false;         // ... and the tick was a solve tick
         bool moving = go;            // this env runs phase C in this iteration
+        HK_LP(23);                   // every lane of a wave that is still in the loop
         if (go) {
+            HK_LP(0);
             dirty = true;
             if (phase == 0) {
                 const bool parked = phase_begin<HAS_RW, HAS_TRAIN>(P, env, i, env_ok, es, h, hfx, hfz, agents, results, M, mset, RD, rwv, act_branch);
@@ -217,6 +222,7 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
             }
         }
         if (began) {
+            HK_LP(22);
             // bin the games for the solver kernels by player count, one atomic per wave and count
 #pragma unroll
             for (int n = 2; n <= GA; n++) {

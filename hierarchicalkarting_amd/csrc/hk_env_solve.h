@@ -484,6 +484,7 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
 {
     const int A = P.A, L = P.L;
     const bool me = act && ego < A;
+    HK_LP(3);
     const hk_agent_state* a = me ? &agents[(size_t)env * A + ego] : nullptr;
     KartS k;
     k.px = k.pz = k.yaw = k.fx = k.fz = k.speed = k.heading = k.msfs = k.dC = 0.0f;
@@ -491,6 +492,7 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
 #pragma unroll
     for (int q = 0; q < 5; q++) k.ray[q] = 3.0e38f;
     if (me) {
+        HK_LP(4);
         k.px = h.px; k.pz = h.pz; k.yaw = h.yaw;
         k.fx = hfx; k.fz = hfz;
         const float vx = h.vx, vz = h.vz;
@@ -532,8 +534,10 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
                 const int cell = grid_cell(P, ox + d0x * sd, oz + d0z * sd);
                 if (cell == prev) continue;
                 prev = cell;
+                HK_LP(5);
                 const int w0 = T.near_off[cell], w1 = T.near_off[cell + 1];
                 for (int w = w0; w < w1; w++) {
+                    HK_LP(6);
                     float t = ray_seg(ox, oz, d0x, d0z, T.walls[T.near_idx[w]]);
                     if (t >= 0.0f && t < best) best = t;
                 }
@@ -553,11 +557,13 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
             const int w0 = T.grid_off[cell], w1 = T.grid_off[cell + 1];
             for (int w = w0; w < w1; w++) {
                 const hk_wall_seg ws = T.walls[T.grid_idx[w]];
+                HK_LP(7);
 #ifndef HK_NO_SHORT_RAY_CULL
                 // the four rays are compared with 2 m and 1.5 m only (side, below): a wall whose box is further than that from the
                 // origin cannot change any of the comparisons (1 cm margin >> float rounding); most of a cell's list is
                 if (f_max(ws.x0, ws.x1) < ox - 2.01f || f_min(ws.x0, ws.x1) > ox + 2.01f || f_max(ws.z0, ws.z1) < oz - 2.01f || f_min(ws.z0, ws.z1) > oz + 2.01f) continue;
 #endif
+                HK_LP(8);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     float t = ray_seg(ox, oz, ddx[q], ddz[q], ws);
@@ -598,13 +604,16 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
     if (N == 1) {
         // single-player game: assemble into registers and run the whole Riccati recursion right here
         GamePlayer loc;
+        HK_LP(9);
         assemble_player<true>(P, T, env, ego, 0, N, nearbyAgents, plm, kq, fixed, LC.vbucket, dy, &loc, dbg_out, bel, games, 0);
         HK_ST(h, 4);                   // [4] single-player assembly (heading heuristic, weights)
         if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = 1;
+        HK_LP(10);
         lq1_solve(P, loc, h, (dbg_out && (P.debug & 1)) ? &dbg_out[(size_t)env * A + ego] : nullptr, status);
         HK_ST(h, 5);                   // [5] lq1_solve
         return 0;
     }
+    for (int i = 0; i < N; i++) { HK_LP(11); } 
     for (int i = 0; i < N; i++) assemble_player<false>(P, T, env, ego, i, N, nearbyAgents, plm, kq, fixed, LC.vbucket, dy, nullptr, dbg_out, bel, games, env * A + ego);
     if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = N;
     HK_ST(h, 7);                       // [7] multi-player assembly

@@ -157,6 +157,7 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
 {
     const bool RW = RWT && P.rewards != 0;     // the <true, true, true> instantiation also serves handles without rewards
     const bool me = env_ok && i < P.A;
+    HK_LP(1);
     hk_agent_state* a = me ? &agents[(size_t)env * P.A + i] : nullptr;
     const uint32_t all_mask = (1u << P.A) - 1u;
     bool skip = !env_ok;       // envs that stay parked (auto_reset off and finished)
@@ -265,6 +266,7 @@ __device__ inline bool phase_begin(const EnvParams& P, const int env, const int 
             // exact cull: a 0.9 m ray from 0.1 m ahead of this kart cannot reach a capsule whose origin is > 2.2 m away
             // (0.1 + 0.9 + core half length 0.657 + slice radius 0.4425 = 2.10)
             if ((jpx - px) * (jpx - px) + (jpz - pz) * (jpz - pz) > 2.2f * 2.2f) return;
+            HK_LP(2);
 #pragma unroll
             for (int q = 0; q < 3; q++) {
                 float t = ray_stadium(ox, oz, ddx[q], ddz[q], jpx, jpz, jfx, jfz, P.ray_agent_r);
@@ -336,6 +338,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
     if (live) { fl = h.flags; px = h.px; pz = h.pz; yaw = h.yaw; vx = h.vx; vz = h.vz; wy = h.wy; }
     const bool enabled = live && (fl & HK_F_ENABLED);
     const bool inactive_before = (inactive_mask >> i) & 1u;
+    HK_LP(12);
     if (enabled) {
         // KA.OnActionReceived / InterpretDiscreteActions (HKA:1371-1379) for RL agents
         if (my_low_mode == HK_LOW_RL && (fl & HK_F_ACTIVE)) {
@@ -345,6 +348,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             if (br < 1) fl |= HK_F_BRAKE; else fl &= ~HK_F_BRAKE;
         }
         if (episode_steps % 100 == 0 && episode_steps < P.max_steps && episode_steps > 0 && !inactive_before) {
+            HK_LP(21);
             if (TRAIN && P.training_agent[i]) plan_randomly(P, T, env, i, h.section_index, episode_steps, es.episodes_done, a);   // HKA:357-360
             else if (my_high_mode == HK_HIGH_FIXED) plan_fixed(P, T, i, h.section_index, a);
         }
@@ -355,6 +359,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
         const float final_steer = kart_steer(P, acc_ang_v);               // UpdateStats AK:295-302
         h.final_steer = final_steer;
         if (fl & HK_F_CAN_MOVE) {                                         // MoveVehicle AK:363-503
+            HK_LP(13);
             const float dt = P.dt;
             const float fx = cfx, fz = cfz;
             float accelInput = (accelerate ? 1.0f : 0.0f) - (brake ? 1.0f : 0.0f);
@@ -434,6 +439,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             if (j >= P.A || j == i || !enabled || !(jfl & HK_F_ENABLED)) return;
             // exact cull: two capsules (reach 0.657 + 0.45 from their origins) cannot touch when the origins are > 2.3 m apart
             if ((jpx - px) * (jpx - px) + (jpz - pz) * (jpz - pz) > 2.3f * 2.3f) return;
+            HK_LP(14);
             float cx, cz, dx, dz, c1x, c1z, c2x, c2z;
             kart_core(jfx, jfz, jpx, jpz, cx, cz, dx, dz);
             float d2 = seg_seg_closest(ax, az, bx, bz, cx, cz, dx, dz, c1x, c1z, c2x, c2z);
@@ -464,6 +470,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
     // ---- kart-wall contacts: deepest penetration, two passes
     if (enabled && (fl & HK_F_CAN_MOVE)) {
         for (int pass = 0; pass < 2; pass++) {
+            HK_LP(15);
             float ax, az, bx, bz;
             kart_core(cfx, cfz, px, pz, ax, az, bx, bz);
             // a contact needs a wall within CAP_R of the core, i.e. within 1.11 m of the kart origin: the cell's near list
@@ -482,6 +489,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                 const int nq = (w1 - base) < 32 ? (w1 - base) : 32;
                 uint32_t cand = 0;
                 for (int q = 0; q < nq; q += 4) {
+                    HK_LP(16);
                     // four independent index -> wall load chains in flight (the LDS round trips, not the arithmetic, are what
                     // this pass costs); slots past the end re-read the last wall and are masked out
                     hk_wall_seg ws[4];
@@ -497,6 +505,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                 while (cand) {
                     const int q = __ffs((int)cand) - 1;
                     cand &= cand - 1u;
+                    HK_LP(17);
                     const hk_wall_seg ws = T.walls[T.near_idx[base + q]];
                     float c1x, c1z, c2x, c2z;
                     float d2 = seg_seg_closest(ax, az, bx, bz, ws.x0, ws.z0, ws.x1, ws.z1, c1x, c1z, c2x, c2z);
@@ -545,6 +554,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             while (bits) {
                 const int t = (__ffs((int)bits) - 1) + 32 * half;
                 bits &= bits - 1u;
+                HK_LP(18);
                 const SecDev& s = T.sec[t];
                 // exact cull: box half diagonal 5.03 + capsule reach 1.11 < 6.5
                 if ((px - s.trig_x) * (px - s.trig_x) + (pz - s.trig_z) * (pz - s.trig_z) > 6.5f * 6.5f) continue;
@@ -554,6 +564,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                 // of the ticks that pass the distance cull (a kart is within 6.5 m of the next Trigger for a third of every section)
                 if (f_abs((px - s.trig_x) * s.fx + (pz - s.trig_z) * s.fz) > TRIG_HZ + 1.117f) continue;
 #endif
+                HK_LP(19);
                 float rax = ax - s.trig_x, raz = az - s.trig_z, rbx = bx - s.trig_x, rbz = bz - s.trig_z;
                 float lax = rax * s.fz - raz * s.fx, laz = rax * s.fx + raz * s.fz;
                 float lbx = rbx * s.fz - rbz * s.fx, lbz = rbx * s.fx + rbz * s.fz;
@@ -572,6 +583,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                 int t;
                 if (elo) { t = __ffs((int)elo) - 1; elo &= elo - 1u; } else { t = (__ffs((int)ehi) - 1) + 32; ehi &= ehi - 1u; }
                 if (!(fl & HK_F_ACTIVE)) continue;
+                HK_LP(20);
                 const int L = P.L, H = P.H;
                 const int sec = h.section_index, init = h.init_checkpoint_index;
                 int index = -1, lane = -1;
