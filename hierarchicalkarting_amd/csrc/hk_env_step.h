@@ -588,12 +588,23 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                 const int sec = h.section_index, init = h.init_checkpoint_index;
                 int index = -1, lane = -1;
                 int lo_i = sec - H; if (lo_i < init) lo_i = init;
-                for (int ii = lo_i; ii < sec + H; ii++) {                  // KA.FindSectionIndex :348-364
-                    int idx = ii < 0 ? ii + L : ii;
-                    if (idx % L == t) { index = idx; lane = calculate_lane(P, T.sec[idx % L], px, pz); break; }
+                // KA.FindSectionIndex :348-364: the first ii in [lo_i, sec + H) whose section (ii mod L) is this Trigger's.  The loop of the
+                // C# costs a run-time modulo per step (typically seven steps) for the two lanes of a wave that are here: closed form.
+                if (lo_i >= 0) {
+                    int delta = t - lo_i % L;
+                    if (delta < 0) delta += L;
+                    if (lo_i + delta < sec + H) index = lo_i + delta;
+                } else {
+                    for (int ii = lo_i; ii < sec + H; ii++) {
+                        int idx = ii < 0 ? ii + L : ii;
+                        if (idx % L == t) { index = idx; break; }
+                    }
                 }
-                if (index != -1 && ((index > sec) || (index % L == 0 && sec % L == L - 1))) {
-                    const int key = index % L;
+                if (index != -1) lane = calculate_lane(P, T.sec[t], px, pz);        // (index mod L == t)
+                const int secm = sec % L;
+                const bool sec_straight = T.sec[secm].inside_radius == 0.0f;       // is_straight(sec)
+                if (index != -1 && ((index > sec) || (t == 0 && secm == L - 1))) {
+                    const int key = t;
                     const int pl = a->plan_lane[key];
                     float lane_div = 1.0f, vel_div = 1.0f;                 // HKA:618-619
                     if (pl != 0) {
@@ -609,13 +620,13 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                     const int cur_lane = h.lane;
                     int dl = cur_lane - lane; if (dl < 0) dl = -dl;
                     int lc = h.lane_changes;
-                    const bool swerve = lc + dl > P.max_lane_changes && is_straight(P, T, sec);
+                    const bool swerve = lc + dl > P.max_lane_changes && sec_straight;
                     if (swerve) h.illegal_lane_changes += 1;
                     if (RW && nev < RW_MAX_EVENTS) {
                         ev[nev].kind = 1; ev[nev].section = index; ev[nev].swerve = swerve ? 1 : 0;
                         ev[nev].lane_div = lane_div; ev[nev].vel_div = vel_div; nev++;
                     }
-                    if (is_straight(P, T, sec) != is_straight(P, T, index)) lc = 0;
+                    if (sec_straight != (T.sec[t].inside_radius == 0.0f)) lc = 0;
                     else if (cur_lane != lane) lc += dl;
                     h.lane_changes = lc;
                     h.section_index = index; h.lane = lane;
@@ -630,7 +641,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                         vx = 0; vz = 0; wy = 0;
                         newly_inactive |= 1u << i;
                     }
-                } else if (index != -1 && ((index < sec) || (sec % L == 0 && index % L == L - 1))) {
+                } else if (index != -1 && ((index < sec) || (secm == 0 && t == L - 1))) {
                     if (RW && nev < RW_MAX_EVENTS) {
                         ev[nev].kind = 2; ev[nev].section = sec - index + 1; ev[nev].swerve = 0;
                         ev[nev].lane_div = 1.0f; ev[nev].vel_div = 1.0f; nev++;
