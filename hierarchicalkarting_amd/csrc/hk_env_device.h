@@ -68,9 +68,9 @@ struct EnvParams {
     int debug;
     // the read-only track tables live in ONE packed buffer (16-B aligned segments); kernels copy it to LDS
     const unsigned char* tab;   // packed tables in global memory
-    int tab_bytes, o_walls, o_goff, o_gidx, o_cut, o_tmask, o_noff, o_nidx;
-    // uniform grid over the walls' bounding box: cell (ix, iz) lists every wall segment within GRID_REACH of the cell, and (the
-    // "near" list) every one within NEAR_REACH
+    int tab_bytes, o_walls, o_goff, o_gidx, o_cut, o_tmask, o_ncnt;
+    // uniform grid over the walls' bounding box: cell (ix, iz) lists every wall segment within GRID_REACH of the cell; those within
+    // NEAR_REACH come first (the "near" list: the first near_cnt[cell] entries), each part in ascending wall index
     float grid_x0, grid_z0, grid_inv;   // origin and 1 / cell size
     int grid_nx, grid_nz;
     // coarse grid over the same box: per TRIG_CELL x TRIG_CELL cell a 64-bit mask of the section Triggers a kart in that cell can overlap
@@ -153,8 +153,7 @@ struct TabView {
     const hk_wall_seg* walls;     // [NW]
     const unsigned short* grid_off;   // [nx*nz + 1] candidate wall segments per grid cell (ascending wall index)
     const unsigned short* grid_idx;
-    const unsigned short* near_off;   // [nx*nz + 1] the same for NEAR_REACH (a subset of the cell's list, same order)
-    const unsigned short* near_idx;
+    const unsigned char* near_cnt;    // [nx*nz] how many entries at the head of the cell's list lie within NEAR_REACH
     const unsigned char* cut;     // [L][5][5]: does the ray lane marker -> next lane marker hit a wall (HKA:832)
     const uint2* tmask;           // [tgrid_nx * tgrid_nz] Trigger candidates per coarse cell (bit t = section t)
 };
@@ -165,8 +164,7 @@ __host__ __device__ inline TabView tab_view(const EnvParams& P, const unsigned c
     T.walls = reinterpret_cast<const hk_wall_seg*>(base + P.o_walls);
     T.grid_off = reinterpret_cast<const unsigned short*>(base + P.o_goff);
     T.grid_idx = reinterpret_cast<const unsigned short*>(base + P.o_gidx);
-    T.near_off = reinterpret_cast<const unsigned short*>(base + P.o_noff);
-    T.near_idx = reinterpret_cast<const unsigned short*>(base + P.o_nidx);
+    T.near_cnt = base + P.o_ncnt;
     T.cut = base + P.o_cut;
     T.tmask = reinterpret_cast<const uint2*>(base + P.o_tmask);
     return T;

@@ -132,7 +132,8 @@ inline int env_build_params(hk_config& cfg, std::vector<hk_section>& sections, s
         for (int l = 0; l < 4; l++) { o.lane_x[l] = s.lane_x[l]; o.lane_z[l] = s.lane_z[l]; }
     }
     // uniform wall grid: per cell every wall segment within GRID_REACH of the cell rectangle, ascending wall index
-    std::vector<unsigned short> goff, gidx, noff, nidx;
+    std::vector<unsigned short> goff, gidx;
+    std::vector<unsigned char> ncnt;           // walls of the cell's list within NEAR_REACH: they come first in the list
     {
         float x0 = 0, x1 = 1, z0 = 0, z1 = 1;
         for (size_t w = 0; w < walls.size(); w++) {
@@ -146,14 +147,15 @@ inline int env_build_params(hk_config& cfg, std::vector<hk_section>& sections, s
         P.grid_nx = (int)std::ceil((x1 + 1.0f - P.grid_x0) / GRID_CELL) + 1;
         P.grid_nz = (int)std::ceil((z1 + 1.0f - P.grid_z0) / GRID_CELL) + 1;
         const size_t ncell = (size_t)P.grid_nx * P.grid_nz;
-        goff.assign(ncell + 1, 0); noff.assign(ncell + 1, 0);
+        goff.assign(ncell + 1, 0); ncnt.assign(ncell, 0);
         for (int iz = 0; iz < P.grid_nz; iz++)
             for (int ix = 0; ix < P.grid_nx; ix++) {
                 const double cx0 = P.grid_x0 + ix * (double)GRID_CELL, cz0 = P.grid_z0 + iz * (double)GRID_CELL;
                 const double cx1 = cx0 + GRID_CELL, cz1 = cz0 + GRID_CELL;
                 const size_t c = (size_t)iz * P.grid_nx + ix;
                 if (gidx.size() > 65000) { err = "hk_create: wall grid too large"; return HK_ERR_UNSUPPORTED; }
-                goff[c] = (unsigned short)gidx.size(); noff[c] = (unsigned short)nidx.size();
+                goff[c] = (unsigned short)gidx.size();
+                std::vector<unsigned short> far;
                 for (size_t w = 0; w < walls.size(); w++) {
                     const hk_wall_seg& s = walls[w];
                     auto inside = [&](double x, double z) { return x >= cx0 && x <= cx1 && z >= cz0 && z <= cz1; };
@@ -161,11 +163,15 @@ inline int env_build_params(hk_config& cfg, std::vector<hk_section>& sections, s
                     const double ex[5] = {cx0, cx1, cx1, cx0, cx0}, ez[5] = {cz0, cz0, cz1, cz1, cz0};
                     for (int q = 0; q < 4 && dmin > 0.0; q++)
                         dmin = std::min(dmin, detail::seg_seg_dist(s.x0, s.z0, s.x1, s.z1, ex[q], ez[q], ex[q + 1], ez[q + 1]));
-                    if (dmin <= (double)GRID_REACH) gidx.push_back((unsigned short)w);
-                    if (dmin <= (double)NEAR_REACH) nidx.push_back((unsigned short)w);
+                    if (dmin <= (double)NEAR_REACH) gidx.push_back((unsigned short)w);
+                    else if (dmin <= (double)GRID_REACH) far.push_back((unsigned short)w);
                 }
+                const size_t nn = gidx.size() - goff[c];
+                if (nn > 255) { err = "hk_create: more than 255 wall segments within 1.3 m of a grid cell"; return HK_ERR_UNSUPPORTED; }
+                ncnt[c] = (unsigned char)nn;
+                gidx.insert(gidx.end(), far.begin(), far.end());
             }
-        goff[ncell] = (unsigned short)gidx.size(); noff[ncell] = (unsigned short)nidx.size();
+        goff[ncell] = (unsigned short)gidx.size();
     }
     // cut table: Physics.Raycast(lane marker -> next lane marker) vs every wall (HKA:832), static geometry
     std::vector<unsigned char> cut((size_t)L * 25, 0);
@@ -207,8 +213,7 @@ inline int env_build_params(hk_config& cfg, std::vector<hk_section>& sections, s
         P.o_walls = seg(walls.data(), walls.size() * sizeof(hk_wall_seg));
         P.o_goff = seg(goff.data(), goff.size() * sizeof(unsigned short));
         P.o_gidx = seg(gidx.data(), gidx.size() * sizeof(unsigned short));
-        P.o_noff = seg(noff.data(), noff.size() * sizeof(unsigned short));
-        P.o_nidx = seg(nidx.data(), nidx.size() * sizeof(unsigned short));
+        P.o_ncnt = seg(ncnt.data(), ncnt.size());
         P.o_cut = seg(cut.data(), cut.size());
         {   // Trigger candidate masks over a coarse grid whose box holds the wall grid and every Trigger centre
             double bx0 = P.grid_x0, bz0 = P.grid_z0, bx1 = P.grid_x0 + P.grid_nx * (double)GRID_CELL, bz1 = P.grid_z0 + P.grid_nz * (double)GRID_CELL;

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
     if (__syncthreads_or(es.reserved[0] > 0 || (es.reserved[1] & ENV_PHASE_MASK) != 0) == 0) return;
     const TabView T = tab_stage<TAB_LDS>(P, smem);
     const int cadence = P.A > 2 ? 4 : 1;
+    const int cmask = cadence - 1;                       // cadence is 1 or 4 and episode_steps >= 0: x % cadence == x & cmask
     const uint32_t all_mask = (1u << P.A) - 1u;
     int budget = P.run_cap;
     hk_agent_state* arec = (env_ok && i < P.A) ? &agents[(size_t)env * P.A + i] : nullptr;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
     // (es.episode_steps is the index of the tick last BEGUN: phase_begin increments it.  An env at a tick boundary runs ticks
     // e + 1 .. e + budget, one resuming its parked tick e runs e .. e + budget - 1; the tick after those should be a solve tick.)
     if (P.eager && cadence > 1) {
-        const int over = (es.episode_steps + budget + (phase == 0 ? 1 : 0)) % cadence;
+        const int over = (es.episode_steps + budget + (phase == 0 ? 1 : 0)) & cmask;
         if (over < budget) budget -= over;
     }
     bool eager_it = false;           // this iteration is the assembly-only one at the end of the budget
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
                     // (ticks 0 and `cadence`: the reset tick of an auto-reset, the first solve tick after hk_reset) would decode
                     // bit-identical controls and are skipped (P.hold_dedupe: no planner whose first plan lands inside the hold,
                     // and the host has not written kart states by hand).  18 of the 128 solve ticks of a race start.
-                    const bool act = (es.episode_steps % cadence) == 0 &&                                  // HKA:317 (Q9)
+                    const bool act = (es.episode_steps & cmask) == 0 &&                                    // HKA:317 (Q9): episodeSteps % cadence
                                      !(!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u)) &&
                                      !(P.hold_dedupe && es.episode_steps > cadence && es.episode_steps < P.hold);
                     qn = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
             // the assembly-only iteration at the end of the budget (see above) is taken once, by an env that just ran out of budget on a
             // solve tick; it ends the env's part in this launch
             const bool again = left > 0 && budget > 0 && !held;
-            const bool last = P.eager != 0 && cadence > 1 && !eager_it && phase == 0 && left > 0 && budget <= 0 && !held && ((es.episode_steps + 1) % cadence) == 0;
+            const bool last = P.eager != 0 && cadence > 1 && !eager_it && phase == 0 && left > 0 && budget <= 0 && !held && ((es.episode_steps + 1) & cmask) == 0;
 #ifdef HK_LOOP_IFELSE
             // the same truth table written as a chain of branches: the form that made round 2's Training-mode instantiation fail its
             // parity test.  Built and run by tests/test_loop_form_gpu.py only.

@@ -518,9 +518,9 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
         }
         // sensor rays of the own kart (Physics.Raycast vs TrackMask, HKA:834-844,906) through the wall grid.  Sensors
         // 2, 4, 8, 6 are at most 2 m long: every wall they can hit is in the list of the origin's cell.  Sensor 0 is
-        // compared with up to 8 m (and with speed / 2): a hit at distance t <= 11 lies within 1 m of one of the samples
-        // o + {0,2,4,6,8,10} d, so the union of those six cells' NEAR lists (NEAR_REACH 1.3 m) contains it.  Lists are supersets; the minimum is what a scan of
-        // every wall (the oracle) returns.
+        // compared with up to 8 m (and with speed / 2): a hit at distance t <= 2 (ns - 1) + 1.3 lies within 1.3 m of one of the
+        // samples o + {0, 2, .., 2 (ns - 1)} d, so the union of those cells' NEAR lists (NEAR_REACH 1.3 m) contains it.  Lists are
+        // supersets; below the largest threshold the minimum is what a scan of every wall (the oracle) returns.
         const float ox = k.px + SENSOR_LZ * k.fx, oz = k.pz + SENSOR_LZ * k.fz;
         HK_ST(h, 14);
         {
@@ -528,17 +528,22 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
             sensor_dir(P, 0, k.fx, k.fz, d0x, d0z);
             float best = 3.0e38f;
             int prev = -1;
+            // the largest distance this kart's ray is ever compared with (assemble_player: speed / 2, 8 m on a straight, 5 m in a curve):
+            // samples up to 2 (ns - 1) >= thr - 1.25 cover every hit that can decide a comparison
+            const float thr = f_max(k.speed * 0.5f, k.straight ? 8.0f : 5.0f);
+            int ns = 1 + (int)ceilf((thr - 1.25f) * 0.5f);
+            ns = ns > 6 ? 6 : ns;
 #pragma unroll 1
-            for (int sm = 0; sm < 6; sm++) {
+            for (int sm = 0; sm < ns; sm++) {
                 const float sd = 2.0f * (float)sm;
                 const int cell = grid_cell(P, ox + d0x * sd, oz + d0z * sd);
                 if (cell == prev) continue;
                 prev = cell;
                 HK_LP(5);
-                const int w0 = T.near_off[cell], w1 = T.near_off[cell + 1];
+                const int w0 = T.grid_off[cell], w1 = w0 + T.near_cnt[cell];
                 for (int w = w0; w < w1; w++) {
                     HK_LP(6);
-                    float t = ray_seg(ox, oz, d0x, d0z, T.walls[T.near_idx[w]]);
+                    float t = ray_seg(ox, oz, d0x, d0z, T.walls[T.grid_idx[w]]);
                     if (t >= 0.0f && t < best) best = t;
                 }
             }

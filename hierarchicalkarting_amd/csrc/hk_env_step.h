@@ -475,7 +475,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             kart_core(cfx, cfz, px, pz, ax, az, bx, bz);
             // a contact needs a wall within CAP_R of the core, i.e. within 1.11 m of the kart origin: the cell's near list
             const int cell = grid_cell(P, px, pz);
-            const int w0 = T.near_off[cell], w1 = T.near_off[cell + 1];
+            const int w0 = T.grid_off[cell], w1 = w0 + T.near_cnt[cell];
             float bestpen = 0.0f, bnx = 0.0f, bnz = 0.0f;
             bool found = false;
             // Two passes over the cell's list, 32 walls at a time: a cheap bounding-box test marks the walls that can be within
@@ -494,7 +494,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                     // this pass costs); slots past the end re-read the last wall and are masked out
                     hk_wall_seg ws[4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) ws[j] = T.walls[T.near_idx[base + ((q + j) < nq ? (q + j) : (nq - 1))]];
+                    for (int j = 0; j < 4; j++) ws[j] = T.walls[T.grid_idx[base + ((q + j) < nq ? (q + j) : (nq - 1))]];
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const bool apart = f_max(ws[j].x0, ws[j].x1) < kx0 || f_min(ws[j].x0, ws[j].x1) > kx1 ||
@@ -506,7 +506,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                     const int q = __ffs((int)cand) - 1;
                     cand &= cand - 1u;
                     HK_LP(17);
-                    const hk_wall_seg ws = T.walls[T.near_idx[base + q]];
+                    const hk_wall_seg ws = T.walls[T.grid_idx[base + q]];
                     float c1x, c1z, c2x, c2z;
                     float d2 = seg_seg_closest(ax, az, bx, bz, ws.x0, ws.z0, ws.x1, ws.z1, c1x, c1z, c2x, c2z);
                     if (d2 < CAP_R * CAP_R) {
@@ -520,7 +520,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                             nx = -ez / el; nz = ex / el;
                             if ((px - ws.x0) * nx + (pz - ws.z0) * nz < 0.0f) { nx = -nx; nz = -nz; }
                         }
-                        // near_idx is ascending per cell, so "first strictly deeper" == the oracle's lowest-index tie break
+                        // the near part of grid_idx is ascending per cell, so "first strictly deeper" == the oracle's lowest-index tie break
                         if (!found || pen > bestpen) { found = true; bestpen = pen; bnx = nx; bnz = nz; }
                     }
                 }

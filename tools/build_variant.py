@@ -6,6 +6,7 @@ with extra -D flags.  Run a variant with HK_LIB_PATH=build/libhk_<name>.so (it t
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import __graft_entry__ as ge
 
 
@@ -20,23 +21,29 @@ def main():
         unit = sys.argv[sys.argv.index("--unit") + 1]
     ge.build()
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    if "--all" in head:                             # every unit with the flags (constants the host code shares with the kernels)
-        objs, procs = [], []
-        for u in ge.UNITS:
-            o = os.path.join(ge.OBJ_DIR, "%s_%s.o" % (name, u.replace(".hip", "")))
-            objs.append(o)
-            procs.append(subprocess.Popen([hipcc] + ge.HIPCC_FLAGS + defs + ["-c", os.path.join(ge.CSRC, u), "-o", o]))
-        assert all(p.wait() == 0 for p in procs)
-        lib = os.path.join(ROOT, "build", "libhk_%s.so" % name)
-        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib] + objs)
-        print(lib)
-        return
-    obj = os.path.join(ge.OBJ_DIR, "%s_%s.o" % (name, unit.replace(".hip", "")))
-    subprocess.check_call([hipcc] + ge.HIPCC_FLAGS + defs + ["-c", os.path.join(ge.CSRC, unit), "-o", obj])
-    objs = [obj if u == unit else os.path.join(ge.OBJ_DIR, u.replace(".hip", ".o")) for u in ge.UNITS]
+    units = list(ge.UNITS) if "--all" in head else [unit]       # --all: every unit with the flags (constants the host code shares with the kernels)
+    objs, procs, listings = [], [], []
+    for u in ge.UNITS:
+        if u not in units:
+            objs.append(os.path.join(ge.OBJ_DIR, u.replace(".hip", ".o")))
+            continue
+        o = os.path.join(ge.OBJ_DIR, "%s_%s.o" % (name, u.replace(".hip", "")))
+        objs.append(o)
+        listings.append(o[:-2] + ".s")
+        procs.append(subprocess.Popen([hipcc] + ge.HIPCC_FLAGS + defs + ["-c", os.path.join(ge.CSRC, u), "-o", o]))
+        procs.append(subprocess.Popen([hipcc] + ge.HIPCC_FLAGS + defs + ["--cuda-device-only", "-S", os.path.join(ge.CSRC, u), "-o", o[:-2] + ".s"], stderr=subprocess.DEVNULL))
+    assert all(p.wait() == 0 for p in procs)
     lib = os.path.join(ROOT, "build", "libhk_%s.so" % name)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib] + objs)
-    print(lib)
+    # the code-generation guard (tools/check_spill_exec.py): a variant may be AFFECTED — it is an experiment, not the product — and says so
+    import json
+    import check_spill_exec as guard
+    bad = []
+    for lst in listings:
+        for kname, insts in guard.device_asm(lst).items():
+            bad += [{"listing": os.path.basename(lst), "kernel": kname, "instruction": ins} for _, ins in guard.check(insts)]
+    json.dump({"library": os.path.basename(lib), "flags": defs, "spill_stores_ahead_of_exec_restore": bad}, open(lib[:-3] + ".guard.json", "w"), indent=1)
+    print(lib, "(code-generation guard: %s)" % ("AFFECTED in %d place(s)" % len(bad) if bad else "clean"))
 
 
 if __name__ == "__main__":
