@@ -584,6 +584,10 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                 if (elo) { t = __ffs((int)elo) - 1; elo &= elo - 1u; } else { t = (__ffs((int)ehi) - 1) + 32; ehi &= ehi - 1u; }
                 if (!(fl & HK_F_ACTIVE)) continue;
                 HK_LP(20);
+                // this Trigger's plan entry, asked for before anything else: the two global loads used to sit behind each other and behind
+                // the section search, and the wave waited for both (two lanes of it are here on most ticks)
+                const int pl_t = a->plan_lane[t];
+                const float pv_t = a->plan_vel[t];
                 const int L = P.L, H = P.H;
                 const int sec = h.section_index, init = h.init_checkpoint_index;
                 int index = -1, lane = -1;
@@ -605,16 +609,16 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                 const bool sec_straight = T.sec[secm].inside_radius == 0.0f;       // is_straight(sec)
                 if (index != -1 && ((index > sec) || (t == 0 && secm == L - 1))) {
                     const int key = t;
-                    const int pl = a->plan_lane[key];
+                    const int pl = pl_t;                                   // (key == t)
                     float lane_div = 1.0f, vel_div = 1.0f;                 // HKA:618-619
                     if (pl != 0) {
-                        if (RW) rw_dividers(P, T, i, key, lane, pl, a->plan_vel[key], px, pz, vx, vz, lane_div, vel_div);
+                        if (RW) rw_dividers(P, T, i, key, lane, pl, pv_t, px, pz, vx, vz, lane_div, vel_div);
                         float lmx, lmz;
                         lane_marker(T, key, pl, lmx, lmz);
                         float dist = mag3(px - lmx, P.kart_y - T.sec[key].marker_y, pz - lmz);
                         h.avg_lane_diff = (f_max(dist - 1.3f, 0.0f) + h.avg_lane_diff * (index - init - 1)) / (index - init);
                         float velocity = mag3(vx, 0.0f, vz);
-                        h.avg_vel_diff = ((velocity - a->plan_vel[key]) + h.avg_vel_diff * (index - init - 1)) / (index - init);
+                        h.avg_vel_diff = ((velocity - pv_t) + h.avg_vel_diff * (index - init - 1)) / (index - init);
                         a->plan_lane[key] = 0; a->plan_vel[key] = 0.0f;
                     }
                     const int cur_lane = h.lane;
