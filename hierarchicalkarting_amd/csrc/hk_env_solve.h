@@ -541,10 +541,14 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
                 prev = cell;
                 HK_LP(5);
                 const int w0 = T.grid_off[cell], w1 = w0 + T.near_cnt[cell];
-                for (int w = w0; w < w1; w++) {
+                // two walls per trip: their index -> segment load chains are in flight together (the LDS round trips, not the arithmetic, are
+                // what a trip costs); an odd list tests its last wall twice, which a minimum does not notice
+                for (int w = w0; w < w1; w += 2) {
                     HK_LP(6);
-                    float t = ray_seg(ox, oz, d0x, d0z, T.walls[T.grid_idx[w]]);
-                    if (t >= 0.0f && t < best) best = t;
+                    const hk_wall_seg wa = T.walls[T.grid_idx[w]], wb = T.walls[T.grid_idx[w + 1 < w1 ? w + 1 : w]];
+                    const float ta = ray_seg(ox, oz, d0x, d0z, wa), tb = ray_seg(ox, oz, d0x, d0z, wb);
+                    if (ta >= 0.0f && ta < best) best = ta;
+                    if (tb >= 0.0f && tb < best) best = tb;
                 }
             }
             k.ray[0] = best;
@@ -560,13 +564,12 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
             }
             const int cell = grid_cell(P, ox, oz);
             const int w0 = T.grid_off[cell], w1 = T.grid_off[cell + 1];
-            for (int w = w0; w < w1; w++) {
-                const hk_wall_seg ws = T.walls[T.grid_idx[w]];
+            auto short_rays = [&](const hk_wall_seg& ws) {
                 HK_LP(7);
 #ifndef HK_NO_SHORT_RAY_CULL
                 // the four rays are compared with 2 m and 1.5 m only (side, below): a wall whose box is further than that from the
                 // origin cannot change any of the comparisons (1 cm margin >> float rounding); most of a cell's list is
-                if (f_max(ws.x0, ws.x1) < ox - 2.01f || f_min(ws.x0, ws.x1) > ox + 2.01f || f_max(ws.z0, ws.z1) < oz - 2.01f || f_min(ws.z0, ws.z1) > oz + 2.01f) continue;
+                if (f_max(ws.x0, ws.x1) < ox - 2.01f || f_min(ws.x0, ws.x1) > ox + 2.01f || f_max(ws.z0, ws.z1) < oz - 2.01f || f_min(ws.z0, ws.z1) > oz + 2.01f) return;
 #endif
                 HK_LP(8);
 #pragma unroll
@@ -574,6 +577,11 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
                     float t = ray_seg(ox, oz, ddx[q], ddz[q], ws);
                     if (t >= 0.0f && t < best[q]) best[q] = t;
                 }
+            };
+            for (int w = w0; w < w1; w += 2) {          // (two load chains in flight, as for the forward ray)
+                const hk_wall_seg wa = T.walls[T.grid_idx[w]], wb = T.walls[T.grid_idx[w + 1 < w1 ? w + 1 : w]];
+                short_rays(wa);
+                if (w + 1 < w1) short_rays(wb);
             }
 #pragma unroll
             for (int q = 0; q < 4; q++) k.ray[1 + q] = best[q];

@@ -548,31 +548,34 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
         // only the Triggers listed for the kart's coarse cell can be within reach (the others fail the distance cull below
         // by construction): a couple of trips instead of one per section, each a dependent LDS round trip
         const uint2 tc = trig_candidates(P, T, px, pz);
+        auto trig_test = [&](const int t, const float tx, const float tz, const float tfx, const float tfz) {
+            HK_LP(18);
+            // exact cull: box half diagonal 5.03 + capsule reach 1.11 < 6.5
+            if ((px - tx) * (px - tx) + (pz - tz) * (pz - tz) > 6.5f * 6.5f) return;
+#ifndef HK_NO_TRIG_SLAB_CULL
+            // exact cull: the box is 1 m thick along its forward axis and every point of the capsule lies within 1.107 m of the kart
+            // origin, so an origin further than 0.5 + 1.107 (+ 1 cm >> float rounding) from the mid plane cannot overlap — true on most
+            // of the ticks that pass the distance cull (a kart is within 6.5 m of the next Trigger for a third of every section)
+            if (f_abs((px - tx) * tfx + (pz - tz) * tfz) > TRIG_HZ + 1.117f) return;
+#endif
+            HK_LP(19);
+            float rax = ax - tx, raz = az - tz, rbx = bx - tx, rbz = bz - tz;
+            float lax = rax * tfz - raz * tfx, laz = rax * tfx + raz * tfz;
+            float lbx = rbx * tfz - rbz * tfx, lbz = rbx * tfx + rbz * tfz;
+            float zlo = f_min(laz, lbz) - CAP_R, zhi = f_max(laz, lbz) + CAP_R;
+            float xlo = f_min(lax, lbx) - CAP_R, xhi = f_max(lax, lbx) + CAP_R;
+            if (zlo <= TRIG_HZ && zhi >= -TRIG_HZ && xlo <= TRIG_HX && xhi >= -TRIG_HX) {
+                if (t < 32) lo |= 1u << t; else hi |= 1u << (t - 32);
+            }
+        };
 #pragma unroll 1
         for (int half = 0; half < 2; half++) {
             uint32_t bits = half ? tc.y : tc.x;
             while (bits) {
                 const int t = (__ffs((int)bits) - 1) + 32 * half;
                 bits &= bits - 1u;
-                HK_LP(18);
                 const SecDev& s = T.sec[t];
-                // exact cull: box half diagonal 5.03 + capsule reach 1.11 < 6.5
-                if ((px - s.trig_x) * (px - s.trig_x) + (pz - s.trig_z) * (pz - s.trig_z) > 6.5f * 6.5f) continue;
-#ifndef HK_NO_TRIG_SLAB_CULL
-                // exact cull: the box is 1 m thick along its forward axis and every point of the capsule lies within 1.107 m of the kart
-                // origin, so an origin further than 0.5 + 1.107 (+ 1 cm >> float rounding) from the mid plane cannot overlap — true on most
-                // of the ticks that pass the distance cull (a kart is within 6.5 m of the next Trigger for a third of every section)
-                if (f_abs((px - s.trig_x) * s.fx + (pz - s.trig_z) * s.fz) > TRIG_HZ + 1.117f) continue;
-#endif
-                HK_LP(19);
-                float rax = ax - s.trig_x, raz = az - s.trig_z, rbx = bx - s.trig_x, rbz = bz - s.trig_z;
-                float lax = rax * s.fz - raz * s.fx, laz = rax * s.fx + raz * s.fz;
-                float lbx = rbx * s.fz - rbz * s.fx, lbz = rbx * s.fx + rbz * s.fz;
-                float zlo = f_min(laz, lbz) - CAP_R, zhi = f_max(laz, lbz) + CAP_R;
-                float xlo = f_min(lax, lbx) - CAP_R, xhi = f_max(lax, lbx) + CAP_R;
-                if (zlo <= TRIG_HZ && zhi >= -TRIG_HZ && xlo <= TRIG_HX && xhi >= -TRIG_HX) {
-                    if (t < 32) lo |= 1u << t; else hi |= 1u << (t - 32);
-                }
+                trig_test(t, s.trig_x, s.trig_z, s.fx, s.fz);
             }
         }
         const uint32_t nlo = lo & ~h.trig_lo, nhi = hi & ~h.trig_hi;
