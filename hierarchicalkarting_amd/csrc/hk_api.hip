@@ -97,6 +97,7 @@ struct Tuning {
     int run_cap_spread = hk::RUN_CAP_SPREAD;   // HK_RUN_CAP_SPREAD: ticks per launch of long calls on a spread field (4 .. 64)
     int run_cap_short = 4;       // HK_RUN_CAP_SHORT: ticks per launch of short calls of plain handles
     int regroup_rounds = hk::REGROUP_ROUNDS;   // HK_REGROUP_ROUNDS: rounds between two re-assignments of the lane groups
+    bool tail_worst_case = false; // HK_TAIL_WORST_CASE=1: the laggards' batches issue a round per cadence of the slowest env (the older schedule)
     int lazy_min_ticks = HK_LAZY_MIN_TICKS;    // HK_LAZY_MIN_TICKS: calls at least this long complete lazily (a look at the device instead of the worst-case rounds)
     int debug_max_rounds = 0;    // HK_DEBUG_MAX_ROUNDS (diagnostic): cap on the rounds of a call, to look at the state in between
     bool debug_no_check = false; // HK_DEBUG_NO_CHECK (diagnostic): getters do not fail on the "did not complete" flag
@@ -106,7 +107,7 @@ struct Tuning {
         auto flag = [](const char* n) { return std::getenv(n) != nullptr; };
         auto num = [](const char* n, int dflt, int lo, int hi) { const char* e = std::getenv(n); const int v = e ? std::atoi(e) : dflt; return v >= lo && v <= hi ? v : dflt; };
         eager = !flag("HK_NO_EAGER"); lazy = !flag("HK_FIXED_ROUNDS"); mcts_pause = !flag("HK_MCTS_NO_PAUSE");
-        want_split = flag("HK_SPLIT"); no_split = flag("HK_NO_SPLIT");
+        want_split = flag("HK_SPLIT"); no_split = flag("HK_NO_SPLIT"); tail_worst_case = flag("HK_TAIL_WORST_CASE");
         run_cap_spread = num("HK_RUN_CAP_SPREAD", hk::RUN_CAP_SPREAD, 4, 64);
         run_cap_short = num("HK_RUN_CAP_SHORT", 4, 4, 64);
         regroup_rounds = num("HK_REGROUP_ROUNDS", hk::REGROUP_ROUNDS, 1, 1 << 20);
@@ -478,7 +479,11 @@ static int finish_ticks(hk_handle h)
         int rc = hk::env_launch_regroup(h->dev, h->cfg, h->stream, h->err);      // the laggards into the first lane groups
         if (rc) { g_last_error = h->err; return rc; }
         h->split = false;                // ... which all lie in the first half: the tail runs as one batch on one stream
-        rc = issue_rounds(h, (maxleft + cadence - 1) / cadence + 1);
+        // Rounds for the slowest env if it met no further multi-player game (+ 1), not for the worst case (a round per cadence): the
+        // batch ends with a look at the device anyway, and two thirds of the worst-case rounds used to find nothing to do (94 of 141 in
+        // the headline's 3 072-tick call, ~18 us each).  An env that does park on every solve tick still gets a third of its ticks per batch.
+        const int cap = std::max(h->dev.P.run_cap, cadence);
+        rc = issue_rounds(h, h->tune.tail_worst_case ? (maxleft + cadence - 1) / cadence + 1 : (maxleft + cap - 1) / cap + 1);
         if (rc) return rc;
         rc = issue_check(h, true);
         if (rc) return rc;
