@@ -97,6 +97,7 @@ struct Tuning {
     int run_cap_spread = hk::RUN_CAP_SPREAD;   // HK_RUN_CAP_SPREAD: ticks per launch of long calls on a spread field (4 .. 64)
     int run_cap_short = 4;       // HK_RUN_CAP_SHORT: ticks per launch of short calls of plain handles
     int regroup_rounds = hk::REGROUP_ROUNDS;   // HK_REGROUP_ROUNDS: rounds between two re-assignments of the lane groups
+    bool keep_last_solve = false; // HK_KEEP_LAST_SOLVE=1: the last round of a fixed-round call launches its (empty) solver kernel, as before
     bool tail_worst_case = false; // HK_TAIL_WORST_CASE=1: the laggards' batches issue a round per cadence of the slowest env (the older schedule)
     int lazy_min_ticks = HK_LAZY_MIN_TICKS;    // HK_LAZY_MIN_TICKS: calls at least this long complete lazily (a look at the device instead of the worst-case rounds)
     int debug_max_rounds = 0;    // HK_DEBUG_MAX_ROUNDS (diagnostic): cap on the rounds of a call, to look at the state in between
@@ -107,7 +108,7 @@ struct Tuning {
         auto flag = [](const char* n) { return std::getenv(n) != nullptr; };
         auto num = [](const char* n, int dflt, int lo, int hi) { const char* e = std::getenv(n); const int v = e ? std::atoi(e) : dflt; return v >= lo && v <= hi ? v : dflt; };
         eager = !flag("HK_NO_EAGER"); lazy = !flag("HK_FIXED_ROUNDS"); mcts_pause = !flag("HK_MCTS_NO_PAUSE");
-        want_split = flag("HK_SPLIT"); no_split = flag("HK_NO_SPLIT"); tail_worst_case = flag("HK_TAIL_WORST_CASE");
+        want_split = flag("HK_SPLIT"); no_split = flag("HK_NO_SPLIT"); tail_worst_case = flag("HK_TAIL_WORST_CASE"); keep_last_solve = flag("HK_KEEP_LAST_SOLVE");
         run_cap_spread = num("HK_RUN_CAP_SPREAD", hk::RUN_CAP_SPREAD, 4, 64);
         run_cap_short = num("HK_RUN_CAP_SHORT", 4, 4, 64);
         regroup_rounds = num("HK_REGROUP_ROUNDS", hk::REGROUP_ROUNDS, 1, 1 << 20);
@@ -591,6 +592,7 @@ static int step_ticks(hk_handle h, int n_ticks)
         // the rounds every env needs at RUN_CAP ticks a round, then — the laggards packed into the first lane groups — the tail
         const int main_rounds = std::min(rounds, (n_ticks + run_cap - 1) / run_cap);
         h->dev.guard_rounds_left = fold ? rounds : 0;          // the tick launch that brings this to 0 is the call's last: it is the guard
+        h->dev.last_solve_skippable = fold && plain && !h->split && h->tune.debug_max_rounds == 0 && !h->tune.keep_last_solve;
         rc = issue_rounds(h, main_rounds);
         if (rc) return rc;
         if (rounds > main_rounds) {

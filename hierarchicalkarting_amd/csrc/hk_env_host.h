@@ -55,6 +55,7 @@ struct EnvDevice {
     // lane-group -> env assignment of the tick kernel, regrouped by solve phase every REGROUP_ROUNDS rounds (hk_env_run.h)
     int* perm = nullptr;           // [E]
     int arm_ticks = 0;             // > 0: the next tick launch adds these ticks to every env's count (a fixed-round call arms itself)
+    bool last_solve_skippable = false;   // fixed-round call of a plain handle: no env can park in its last round, so that round queues no game (launch_lqn)
     int guard_rounds_left = 0;     // > 0: fixed-round call; the tick launch that brings it to 0 flags the envs that are not done (the guard)
     int* perm_counts = nullptr;    // [2 * REGROUP_KEYS]: counts, cursors
     int regroup_rounds = 48;       // rounds between two periodic re-assignments (REGROUP_ROUNDS; HK_REGROUP_ROUNDS)

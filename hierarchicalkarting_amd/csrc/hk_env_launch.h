@@ -114,6 +114,14 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
     const int* qc = d.queue_cnt + set * 16;
     const int* qu = d.queue + (size_t)set * queue_ints_per_set((size_t)ngames);
     int rc = HK_OK;
+    if (d.last_solve_skippable && d.guard_rounds_left == 0) {
+        // The tick launch before this one was the call's last (its completion guard): an env that queued a game there would be parked, i.e.
+        // the call incomplete, which the round count rules out (and the guard reports).  Nothing to solve: a one-tick call is 3 launches, not 4.
+        d.last_solve_skippable = false;
+        d.round += 1;
+        if (d.qbase == 0) d.call_ticks_issued = std::min(d.call_ticks_issued + (cfg.num_agents > 2 ? 4 : 1), d.call_ticks);
+        return HK_OK;
+    }
     // Bulk or sparse?  The host cannot see the queues without a sync, but it knows how long ago the field stood on the start grid:
     // for BULK_TICKS after a reset of every env most egos hold a 2-player game (their row mate), later almost none does.
     const bool bulk = cfg.num_agents == 2 || d.ticks_since_reset + d.call_ticks_issued < BULK_TICKS;
