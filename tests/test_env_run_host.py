@@ -90,6 +90,13 @@ def test_tick_kernel_device_code_is_clean_under_sanitizers(harness, tmp_path, ea
     assert stats["queued_games"] > 100          # the start grid: packs of 2-4 players
 
 
+def test_complex_track_long_run_under_sanitizers(harness, tmp_path):
+    """the Complex track (41 sections, 842 wall segments: curves of 32 one-metre segments), 6 envs, two episodes with a restart in between"""
+    built = make_config(6, 4, track="complex", jitter_seed=23, max_episode_steps=420)
+    stats = _run(harness, tmp_path, built, 600, 40, 1, 12)
+    assert stats["queued_games"] > 200
+
+
 def test_rewarded_handle_under_sanitizers(harness, tmp_path):
     built = make_config(2, 4, jitter_seed=5, max_episode_steps=220, rewards=1)
     _run(harness, tmp_path, built, 260, 10, 1, 32)
