@@ -469,10 +469,24 @@ def bench_lqng(a, D, hk):
         dt_1 = short_calls(256, 1)
         dt_2 = short_calls(128, 2)
         dt_20 = short_calls(16, 20)
+        # the same protocol window with the batch as two halves on two streams (HK_SPLIT=1, read in hk_create): a half's solver launch
+        # hides behind the other half's ticks.  Not the default: two tick launches then share the GPU and the per-launch roofline of the
+        # contract (bytes of a launch / its duration) no longer describes the kernel — the throughput it buys is reported here
+        env.close()                                       # (its streams go back first: the halves need two hardware queues of their own)
+        os.environ["HK_SPLIT"] = "1"
+        try:
+            env2 = hk.RacingEnv(hk.make_config(E, A, jitter_seed=seed, env_id_base=D.rank * E, device_id=D.local_rank))
+        finally:
+            del os.environ["HK_SPLIT"]
+        env2.reset(); env2.step(STEADY_TICK); env2.synchronize()
+        dt_split = timed_ticks(D, env2, 3072)
+        del env2
         secondary = {
             "host_driven": {"hk_step(1)_x256_from_tick_512": {"value": E * D.world * 256 / dt_1, "unit": "env-steps/s", "us_per_call": dt_1 / 256 * 1e6},
                             "hk_step(2)_x128_from_tick_768": {"value": E * D.world * 256 / dt_2, "unit": "env-steps/s", "us_per_call": dt_2 / 128 * 1e6},
                             "hk_step(20)_x16_from_tick_1024": {"value": E * D.world * 320 / dt_20, "unit": "env-steps/s", "us_per_call": dt_20 / 16 * 1e6}},
+            "two_halves_on_two_streams_ticks_512_3584": {"value": E * D.world * 3072 / dt_split, "unit": "env-steps/s",
+                                                         "note": "HK_SPLIT=1 (not the default): the solver launch of one half hides behind the other half's tick launch"},
             "baseline_protocol_ticks_512_3584": {"value": E * D.world * 3072 / dt_full, "unit": "env-steps/s", "seconds": dt_full,
                                                  "kernel_total_ms": {k: v[0] for k, v in prof_full.items() if v[1]},
                                                  "launches": {k: v[1] for k, v in prof_full.items() if v[1]},
