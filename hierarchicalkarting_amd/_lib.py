@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("HK_LIB_PATH") or os.path.join(_HERE, "libhk.so")   # 
 HK_MAX_AGENTS = 8
 HK_MAX_SECTIONS = 64
 HK_NUM_SENSORS = 9
-HK_ABI_VERSION = 4
+HK_ABI_VERSION = 5
 HK_PROF_STAGES = 5
 PROF_STAGE_NAMES = ("env_run_kernel", "lqn_kernel<2,3,4>", "lq_batch_kernel", "policy_mlp_kernel", "observe+stack")
 HK_COMM_ID_BYTES = 128
@@ -54,6 +54,15 @@ class RewardParams(C.Structure):
         "TowardsCheckpointReward", "SpeedReward", "SlowMovingPenalty", "AccelerationReward", "NotAtGoalPenalty")]
 
 
+class EngineParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "mass", "inertia_y", "gravity", "axle_zf", "axle_zr", "max_steer_deg", "steer_damping", "side_ext_slip", "side_ext_value",
+        "side_asy_slip", "side_asy_value", "side_stiffness", "side_slope0", "slip_min_speed", "wheel_mass", "wheel_radius_f",
+        "wheel_radius_r", "wheel_damping", "fwd_ext_slip", "fwd_ext_value", "fwd_asy_slip", "fwd_asy_value", "fwd_stiffness",
+        "long_slip_min_speed")] + [
+        ("wheel_friction", C.c_int32), ("contact_yaw", C.c_int32), ("wheel_rolling", C.c_int32)]
+
+
 class Config(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32), ("num_envs", C.c_int32), ("num_agents", C.c_int32), ("device_id", C.c_int32),
@@ -72,12 +81,12 @@ class Config(C.Structure):
         ("time_precision", _I8), ("section_window", _I8), ("mcts_iterations", C.c_int32),
         ("mcts_initial_iterations", C.c_int32), ("mcts_latency_ticks", C.c_int32), ("mcts_initial_latency_ticks", C.c_int32),
         ("mcts_seed", C.c_uint32), ("rewards", C.c_int32), ("training_agent", _I8), ("rw", RewardParams),
-        ("train_seed", C.c_uint32), ("debug_taps", C.c_int32),
+        ("train_seed", C.c_uint32), ("debug_taps", C.c_int32), ("engine", EngineParams),
     ]
 
 
 HK_MCTS_MAX_DEPTH = 8
-HK_MCTS_MAX_ACTIONS = 20
+HK_MCTS_MAX_ACTIONS = 36
 HK_MCTS_SECTIME_RING = 8
 HK_MCTS_MAX_ROOT_PHASES = 3
 _U8A = C.c_uint8 * HK_MAX_AGENTS
@@ -108,7 +117,8 @@ class AgentState(C.Structure):
         ("tele_completed_laps", C.c_int32), ("tele_lap_end_step", C.c_int32), ("tele_last_lap", C.c_float),
         ("tele_best_lap", C.c_float), ("tele_total_time", C.c_float),
         ("plan_lane", C.c_uint8 * HK_MAX_SECTIONS), ("plan_vel", C.c_float * HK_MAX_SECTIONS),
-        ("step_reward", C.c_float), ("group_reward", C.c_float),
+        ("step_reward", C.c_float), ("group_reward", C.c_float), ("steer_smoothed", C.c_float),
+        ("wheel_uf", C.c_float), ("wheel_ur", C.c_float),
     ]
 
 

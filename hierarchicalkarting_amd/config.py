@@ -8,8 +8,13 @@ from . import _lib
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
-# MLAgent_Sensors.prefab: index -> yaw (positive = right)
-SENSOR_YAW_DEG = [0.0, 30.0, 60.0, 90.0, -30.0, -60.0, -90.0, 45.0, -45.0]
+# KartAgent.Sensors[] as the Compete SCENES hold it: index -> yaw of the MLAgent_Sensors child the entry points at (positive = right).
+# The scenes re-point the entries of every HierarchicalKartAgent (113 of 115; tools/extract_experiments.py resolves the references;
+# tests/golden/reference_experiments.json "sensors"), so the order is NOT the prefab's {0, 30, 60, 90, -30, -60, -90, 45, -45} that
+# SURVEY App. A lists: SolveLQR's rays 0, 2, 4, 8, 6 (HKA:834-844) are 0, +45, +90, -90, -45 degrees, KA.FixedUpdate's 0, 1, 5
+# (KA:138-143) are 0, +30, -30, and the validation distances below are mirror-symmetric as they should be.  The running means of the
+# reference's trained actors' input normalisers (ray 4: 5.0 m, ray 8: 4.7 m = half the track width) say the same.
+SENSOR_YAW_DEG = [0.0, 30.0, 45.0, 60.0, 90.0, -30.0, -45.0, -60.0, -90.0]
 RAY_DISTANCE = [20.0] * 9
 WALL_HIT_VALIDATION = [0.8, 0.9, 1.0, 0.8, 0.6, 0.9, 1.0, 0.8, 0.6]
 AGENT_HIT_VALIDATION = [1.5] * 9
@@ -18,6 +23,15 @@ AGENT_HIT_VALIDATION = [1.5] * 9
 KART_STATS = dict(TopSpeed=15.0, Acceleration=7.0, ReverseSpeed=10.0, ReverseAcceleration=3.0, AccelerationCurve=0.5,
                   Braking=16.0, CoastingDrag=5.0, Grip=0.97, MaxSteer=4.0, MinSteer=1.0, TireWearFactor=0.001,
                   MinGs=0.5, MaxGs=2.0, AddedGravity=1.0, TireWearRate=10000.0, AngularDrag=0.05)
+
+
+# Engine restatement (include/hk.h hk_engine_params): Rigidbody / CapsuleCollider / WheelCollider / KartAnimation values of
+# BaseKartClassic.prefab; inertia_y = the capsule's (r 0.45, h 2) transverse inertia at mass 250; side_slope0 is the one fitted number
+ENGINE_PARAMS = dict(mass=250.0, inertia_y=74.71, gravity=9.81, axle_zf=0.58625615, axle_zr=-0.68122816, max_steer_deg=30.0,
+                     steer_damping=10.0, side_ext_slip=0.2, side_ext_value=1.0, side_asy_slip=0.5, side_asy_value=0.75,
+                     side_stiffness=1.0, side_slope0=1.0, slip_min_speed=1.0, wheel_mass=20.0, wheel_radius_f=0.1372984,
+                     wheel_radius_r=0.1630791, wheel_damping=0.56, fwd_ext_slip=0.4, fwd_ext_value=1.0, fwd_asy_slip=0.8, fwd_asy_value=0.5,
+                     fwd_stiffness=1.0, long_slip_min_speed=4.0, wheel_friction=1, contact_yaw=1, wheel_rolling=1)
 
 
 def load_track(name="oval"):
@@ -65,7 +79,8 @@ def make_config(num_envs, num_agents=4, track="oval", high_mode=_lib.HK_HIGH_FIX
                 device_id=0, wiring=None, env_mode=_lib.HK_MODE_EXPERIMENT, max_episode_steps=None, laps=None,
                 stats=None, time_precision=100, section_window=2, mcts_iterations=128, mcts_initial_iterations=None,
                 mcts_latency_ticks=45, mcts_initial_latency_ticks=75, mcts_seed=0x4D435453, rewards=0, training_agents=None,
-                reward_params=None, disable_on_end=None, train_seed=0x54524149, velocity_bucket_size=2, max_lane_changes=None):
+                reward_params=None, disable_on_end=None, train_seed=0x54524149, velocity_bucket_size=2, max_lane_changes=None,
+                engine=None, sensors=None):
     tr = load_track(track) if isinstance(track, str) else track
     secs = tr["sections"]
     L = len(secs)
@@ -116,6 +131,15 @@ def make_config(num_envs, num_agents=4, track="oval", high_mode=_lib.HK_HIGH_FIX
         st.update(stats)
     for k, v in st.items():
         setattr(cfg.stats, k, v)
+    eng = dict(ENGINE_PARAMS)
+    if engine:
+        eng.update(engine)
+    if os.environ.get("HK_ENG"):                      # model fitting (tools/fit_engine.py): "key=value,..."
+        for kv in os.environ["HK_ENG"].split(","):
+            k, v = kv.split("=")
+            eng[k] = float(v)
+    for k, v in eng.items():
+        setattr(cfg.engine, k, int(v) if k in ("wheel_friction", "contact_yaw", "wheel_rolling") else v)
     rules = tr["rules"]
     cfg.laps = int(laps if laps is not None else rules["laps"])
     cfg.max_episode_steps = int(max_episode_steps if max_episode_steps is not None else rules["maxEpisodeSteps"])
@@ -130,10 +154,11 @@ def make_config(num_envs, num_agents=4, track="oval", high_mode=_lib.HK_HIGH_FIX
     cfg.dt = 0.02
     cfg.kart_y = 0.28
     for i in range(_lib.HK_NUM_SENSORS):
-        cfg.sensor_yaw_deg[i] = SENSOR_YAW_DEG[i]
-        cfg.ray_distance[i] = RAY_DISTANCE[i]
-        cfg.wall_hit_validation[i] = WALL_HIT_VALIDATION[i]
-        cfg.agent_hit_validation[i] = AGENT_HIT_VALIDATION[i]
+        sn = sensors[i] if sensors else None     # one scene entry: {"yaw_deg", "RayDistance", "WallHitValidationDistance", "AgentHitValidationDistance"}
+        cfg.sensor_yaw_deg[i] = sn["yaw_deg"] if sn else SENSOR_YAW_DEG[i]
+        cfg.ray_distance[i] = sn["RayDistance"] if sn else RAY_DISTANCE[i]
+        cfg.wall_hit_validation[i] = sn["WallHitValidationDistance"] if sn else WALL_HIT_VALIDATION[i]
+        cfg.agent_hit_validation[i] = sn["AgentHitValidationDistance"] if sn else AGENT_HIT_VALIDATION[i]
     # MCTS planner budget: iterations stand for the reference's wall-clock T (0.9 s per replan, 1.5 s at reset)
     cfg.mcts_iterations = int(mcts_iterations)
     cfg.mcts_initial_iterations = int(mcts_initial_iterations if mcts_initial_iterations is not None else (mcts_iterations * 5 + 2) // 3)

@@ -92,8 +92,9 @@ struct Tuning {
     bool eager = true;           // HK_NO_EAGER=1: no eager assembly at the end of a launch's budget (hk_env_run.h)
     bool lazy = true;            // HK_FIXED_ROUNDS=1: every call issues the worst-case round count up front (no look at the device)
     bool mcts_pause = true;      // HK_MCTS_NO_PAUSE=1: long calls of planner handles keep the deadline schedule
-    bool want_split = false;     // HK_SPLIT=1: the batch as two halves on two streams in every long call
-    bool no_split = false;       // HK_NO_SPLIT=1: not even while the field stands close
+    bool want_split = false;     // HK_SPLIT=1: the batch as two halves on two streams in EVERY call of a plain handle (short ones too)
+    bool split_long = true;      // the default: ... in the long (lazily completed) calls of plain handles; HK_NO_SPLIT=1 / HK_SPLIT=0 switch it off
+    bool no_split = false;       // HK_NO_SPLIT=1: one stream always, also while the field stands close
     int run_cap_spread = hk::RUN_CAP_SPREAD;   // HK_RUN_CAP_SPREAD: ticks per launch of long calls on a spread field (4 .. 64)
     int run_cap_short = 4;       // HK_RUN_CAP_SHORT: ticks per launch of short calls of plain handles
     int regroup_rounds = hk::REGROUP_ROUNDS;   // HK_REGROUP_ROUNDS: rounds between two re-assignments of the lane groups
@@ -108,7 +109,7 @@ struct Tuning {
         auto flag = [](const char* n) { return std::getenv(n) != nullptr; };
         auto num = [](const char* n, int dflt, int lo, int hi) { const char* e = std::getenv(n); const int v = e ? std::atoi(e) : dflt; return v >= lo && v <= hi ? v : dflt; };
         eager = !flag("HK_NO_EAGER"); lazy = !flag("HK_FIXED_ROUNDS"); mcts_pause = !flag("HK_MCTS_NO_PAUSE");
-        want_split = flag("HK_SPLIT"); no_split = flag("HK_NO_SPLIT"); tail_worst_case = flag("HK_TAIL_WORST_CASE"); keep_last_solve = flag("HK_KEEP_LAST_SOLVE");
+        { const char* sp = std::getenv("HK_SPLIT"); want_split = sp && std::atoi(sp) != 0; no_split = flag("HK_NO_SPLIT"); split_long = !no_split && !(sp && std::atoi(sp) == 0); } tail_worst_case = flag("HK_TAIL_WORST_CASE"); keep_last_solve = flag("HK_KEEP_LAST_SOLVE");
         run_cap_spread = num("HK_RUN_CAP_SPREAD", hk::RUN_CAP_SPREAD, 4, 64);
         run_cap_short = num("HK_RUN_CAP_SHORT", 4, 4, 64);
         regroup_rounds = num("HK_REGROUP_ROUNDS", hk::REGROUP_ROUNDS, 1, 1 << 20);
@@ -528,7 +529,8 @@ static int step_ticks(hk_handle h, int n_ticks)
     // Arming: a kernel of its own, except in fixed-round calls that are not split, where the first tick launch adds the ticks itself and the
     // last one raises the "did not complete" flag the guard kernel would (a one-tick call: 4 launches instead of 9 with round 2's tail regroup)
     const bool lazy_call = !planner && h->n_policies == 0 && h->done_host != nullptr && n_ticks >= h->tune.lazy_min_ticks && h->tune.lazy;
-    const bool fold = !pause && !lazy_call && !(h->tune.want_split || (h->dev.ticks_since_reset < hk::BULK_TICKS && !h->tune.no_split));
+    const bool split_req = h->tune.want_split || (h->tune.split_long && lazy_call);      // (HK_SPLIT=1: every call; default: the long ones)
+    const bool fold = !pause && !lazy_call && !(split_req || (h->dev.ticks_since_reset < hk::BULK_TICKS && !h->tune.no_split));
     if (fold) h->dev.arm_ticks = n_ticks;
     else {
         rc = hk::env_launch_arm(h->dev, h->cfg, n_ticks, h->stream, h->err);
@@ -577,13 +579,15 @@ static int step_ticks(hk_handle h, int n_ticks)
     const int run_cap = (lazy && h->cfg.num_agents > 2 && h->dev.ticks_since_reset >= hk::BULK_TICKS) ? spread_cap
                         : (!lazy && plain && h->dev.P.eager) ? short_cap : hk::RUN_CAP;
     h->dev.P.run_cap = run_cap;
-    // two halves on two streams (issue_rounds_split): on request.  Measured: headline 1 221 -> 1 292 M env-steps/s, race start 439 -> 458 M,
+    // two halves on two streams (issue_rounds_split): the default for the long calls of plain handles since round 4 (1 472 vs 1 392 M
+    // env-steps/s in round 3's protocol window; bench.py then reports the roofline fraction of the whole job, see there), on request
+    // (HK_SPLIT=1) for every call.  The notes of the rounds before:  Measured: headline 1 221 -> 1 292 M env-steps/s, race start 439 -> 458 M,
     // a 20-tick call unchanged (the solver kernel needs a SIMD's whole register file and finds none while the other half's tick kernel
     // fills the GPU, so on short launches its latency is not hidden but moved).  On a spread field it is off unless HK_SPLIT=1: two tick
     // kernels that share the GPU each take longer, and bench.py's per-launch roofline (bytes of a launch / its duration) would no longer
     // describe the kernel (hk_prof's stage totals then add up the spans of two concurrent streams).  While the field stands close (BULK_TICKS after a reset of every env: every ego holds a multi-player game and a round's solver
     // launch lasts hundreds of microseconds) the split is used without being asked: race start 440 -> 458 M.
-    const bool want_split = h->tune.want_split, no_split = h->tune.no_split;
+    const bool want_split = split_req, no_split = h->tune.no_split;
     const bool close_field = h->dev.ticks_since_reset < hk::BULK_TICKS;
     h->split = (want_split || (close_field && !no_split)) && h->dev.P.eager && h->cfg.num_envs >= 8192;
     int rounds = lazy ? hk::env_rounds_min(h->cfg, n_ticks, run_cap) : hk::env_rounds_for(h->cfg, n_ticks, run_cap, h->dev.P.eager != 0);

@@ -52,6 +52,16 @@ struct SecDev {                         // one DiscretePositionTracker + Waypoin
 
 struct SecGeo { float track_width, track_length, turn_degrees; int left_turn; };   // DPT fields only the MCTS planner reads
 
+// the engine restatement's derived constants, formed once on the host (env_build_params); the CPU oracle forms them with the same expressions
+struct EngCurve { float inv_ext, inv_span, ext, asy, a3, a2, a1, b3, b2, b0, flat; };
+struct EngDerived {
+    float inv_m, inv_i, inv_mw;
+    float side_kf, side_kr, fwd_kf, fwd_kr;     // stiffness * axle load * dt: the impulse of friction coefficient 1 in one tick
+    float inv_damp_f, inv_damp_r;               // 1 / (1 + dt * wheelDampingRate / (m_wheel r^2 / 2))
+    float jden_r, jlden_r;                      // rear axle (not steered: levers zr and 0): 1 / (1/m + zr^2 / I),  1 / (1/m_wheel + 1/m)
+    EngCurve side, fwd;
+};
+
 struct EnvParams {
     int E, A, L, NW;
     float dt, kart_y;
@@ -95,6 +105,10 @@ struct EnvParams {
     // Training mode (hk_env_training.h)
     int training_reset;
     uint32_t train_seed;
+    // engine restatement (hk.h hk_engine_params), with the derived constants the oracle computes per call: 1 / mass, 1 / inertia and
+    // the axles' static loads share * mass * gravity (front: -zr / (zf - zr), rear: zf / (zf - zr))
+    hk_engine_params eng;
+    EngDerived engd;
 };
 // ---- device buffers of the MCTS planner (hk_env_mcts.h) and of the reward shaping (hk_env_reward.h): the same for every GA
 struct MctsKartSnap { int section, lane, lane_changes, tire_age; int sec_time[HK_MCTS_SECTIME_RING]; };
@@ -118,12 +132,14 @@ struct MctsDev {
     // move tables, filled once by mcts_table_kernel with the same device functions the search would call (so they are
     // bit-identical to evaluating applyAction on the spot): what a move costs depends only on the section (mod L), the
     // kart's lane and velocity bucket and the action — not on the tree
-    int* dt_tab;            // [L][4 lanes][nv + 1 buckets][20 actions]: time added (x timePrecision); < 0 = infeasible
-    float* load_tab;        // [L][4][20]: tireLoad of the move
+    int* dt_tab;            // [L][4 lanes][nv + 1 buckets][na actions]: time added (x timePrecision); < 0 = infeasible
+    float* load_tab;        // [L][4][na]: tireLoad of the move
     float* rad_tab;         // [L][4][4]: radiusOfLane(section, from, to)
-    uint32_t* mask_tab;     // [rows = L * 4 * (nv + 1)]: bit a: action a exists and is feasible from this row (dt >= 0)
-    unsigned char* order_tab;   // [rows][20]: the canonical actions in the rollout's order for this row (hk_env_mcts.h mcts_order_kernel)
-    int nv;                 // velocity buckets of the action list (<= 5)
+    unsigned long long* mask_tab;   // [rows = L * 4 * (nv + 1)]: bit a: action a exists and is feasible from this row (dt >= 0)
+    unsigned char* order_tab;   // [rows][na]: the canonical actions in the rollout's order for this row (hk_env_mcts.h mcts_order_kernel)
+    int nv;                 // velocity buckets of the action list (<= 9)
+    int na;                 // actions of the list = 4 nv: the row stride of dt_tab / load_tab / order_tab
+    int lds_tier;           // which tables the search kernel stages in LDS beside dt / rad / flags: bit 0 masks, bit 1 loads, bit 2 orders
     int ntab;               // entries of dt_tab
     int lds_attr_set;       // host: the search kernel's dynamic-LDS limit has been raised on this device
     int pool_cap;
@@ -356,6 +372,80 @@ __device__ __forceinline__ void kart_core(float fx, float fz, float px, float pz
     bx = px + CAP_Z1 * fx; bz = pz + CAP_Z1 * fz;
 }
 
+// ------------------------------------------------------------------ engine restatement: tire forces (hk.h hk_engine_params)
+// Arithmetic contract shared with oracle/hk_oracle_env.c engine_wheels: divisions by configuration constants are multiplications by
+// reciprocals formed once on the host (env_build_params); a WheelFrictionCurve is ONE cubic in Horner form on its piece.
+__device__ __forceinline__ float curve_eval(const EngCurve& c, float slip)
+{
+    const bool in1 = slip <= c.ext;
+    const float t = in1 ? slip * c.inv_ext : (slip - c.ext) * c.inv_span;
+    const float c3 = in1 ? c.a3 : c.b3, c2 = in1 ? c.a2 : c.b2, c1 = in1 ? c.a1 : 0.0f, c0 = in1 ? 0.0f : c.b0;
+    const float v = ((c3 * t + c2) * t + c1) * t + c0;
+    return slip <= c.asy ? v : c.flat;
+}
+// One tick of the four WheelColliders' tire forces on a free rigid body (centre of mass at the kart origin), both axles from the same
+// velocities; the front pair is steered by KartAnimation (steer_smoothed * max_steer_deg).
+//   sideways  the lateral impulse mu(slip) * load * dt against the axle's sideways motion, capped at what stops that motion
+//   rolling   nothing drives or brakes the wheels: the pair's rim speed u follows the ground speed through forwardFriction of the slip
+//             (u - v_long) / (|v_long| + 4); the reaction acts on the body; wheelDampingRate slows the spin (implicit, as PhysX does)
+__device__ __forceinline__ void engine_wheels(const EnvParams& P, const float fx, const float fz, const float steer_smoothed,
+                                              float& vx, float& vz, float& wy, float& uf, float& ur)
+{
+    const hk_engine_params& g = P.eng;
+    const EngDerived& E = P.engd;
+    const float rx = fz, rz = -fx;
+    float sd, cd;
+    hk_sincosf_near0(steer_smoothed * g.max_steer_deg * DEG2RAD_F, &sd, &cd);      // |delta| <= 30 degrees: the reduction-free path of the same function
+    float dvx = 0.0f, dvz = 0.0f, dw = 0.0f;
+    {   // front axle: levers zf cos(delta) (sideways impulse) and zf sin(delta) (rolling impulse)
+        const float zk = g.axle_zf;
+        const float wfx = cd * fx + sd * rx, wfz = cd * fz + sd * rz;
+        const float wlx = cd * rx - sd * fx, wlz = cd * rz - sd * fz;
+        const float vkx = vx + wy * zk * rx, vkz = vz + wy * zk * rz;
+        const float vlong = vkx * wfx + vkz * wfz, vlat = vkx * wlx + vkz * wlz;
+        const float slip = f_abs(vlat) / (f_abs(vlong) + g.slip_min_speed);
+        float jn = curve_eval(E.side, slip) * E.side_kf;
+        const float lev = zk * cd;
+        const float jmax = f_abs(vlat) / (E.inv_m + lev * lev * E.inv_i);
+        if (jn > jmax) jn = jmax;
+        if (vlat > 0.0f) jn = -jn;
+        dvx += wlx * (jn * E.inv_m); dvz += wlz * (jn * E.inv_m); dw += jn * lev * E.inv_i;
+        if (g.wheel_rolling) {
+            const float du = uf - vlong;
+            const float ls = du / (f_abs(vlong) + g.long_slip_min_speed);
+            float jl = curve_eval(E.fwd, f_abs(ls)) * E.fwd_kf;
+            const float levl = zk * sd;
+            const float jlmax = f_abs(du) / (E.inv_mw + E.inv_m + levl * levl * E.inv_i);
+            if (jl > jlmax) jl = jlmax;
+            if (ls < 0.0f) jl = -jl;
+            dvx += wfx * (jl * E.inv_m); dvz += wfz * (jl * E.inv_m); dw += jl * levl * E.inv_i;
+            uf = (uf - jl * E.inv_mw) * E.inv_damp_f;
+        }
+    }
+    {   // rear axle (not steered): levers zr and 0
+        const float zk = g.axle_zr;
+        const float vkx = vx + wy * zk * rx, vkz = vz + wy * zk * rz;
+        const float vlong = vkx * fx + vkz * fz, vlat = vkx * rx + vkz * rz;
+        const float slip = f_abs(vlat) / (f_abs(vlong) + g.slip_min_speed);
+        float jn = curve_eval(E.side, slip) * E.side_kr;
+        const float jmax = f_abs(vlat) * E.jden_r;
+        if (jn > jmax) jn = jmax;
+        if (vlat > 0.0f) jn = -jn;
+        dvx += rx * (jn * E.inv_m); dvz += rz * (jn * E.inv_m); dw += jn * zk * E.inv_i;
+        if (g.wheel_rolling) {
+            const float du = ur - vlong;
+            const float ls = du / (f_abs(vlong) + g.long_slip_min_speed);
+            float jl = curve_eval(E.fwd, f_abs(ls)) * E.fwd_kr;
+            const float jlmax = f_abs(du) * E.jlden_r;
+            if (jl > jlmax) jl = jlmax;
+            if (ls < 0.0f) jl = -jl;
+            dvx += fx * (jl * E.inv_m); dvz += fz * (jl * E.inv_m);
+            ur = (ur - jl * E.inv_mw) * E.inv_damp_r;
+        }
+    }
+    vx += dvx; vz += dvz; wy += dw;
+}
+
 // Wave-aggregated queue slot allocation: the active lanes whose `pred` holds get consecutive slots from ONE atomicAdd per
 // wave (the lowest such lane adds their count, the others take base + their rank).  With a lane-level atomicAdd every queued
 // ego hit the same counter: 131 072 serialised atomics per tick in the 2-agent configuration (every tick queues a 2-player game
@@ -452,6 +542,9 @@ struct Hot {
     float tele_last_lap;
     float tele_best_lap;
     float tele_total_time;
+    float steer_smoothed;
+    float wheel_uf;
+    float wheel_ur;
 };
 __device__ __forceinline__ Hot load_hot(const hk_agent_state* a)
 {
@@ -485,6 +578,9 @@ __device__ __forceinline__ Hot load_hot(const hk_agent_state* a)
     h.tele_last_lap = a->tele_last_lap;
     h.tele_best_lap = a->tele_best_lap;
     h.tele_total_time = a->tele_total_time;
+    h.steer_smoothed = a->steer_smoothed;
+    h.wheel_uf = a->wheel_uf;
+    h.wheel_ur = a->wheel_ur;
     return h;
 }
 __device__ __forceinline__ void store_hot(hk_agent_state* a, const Hot& h)
@@ -518,6 +614,9 @@ __device__ __forceinline__ void store_hot(hk_agent_state* a, const Hot& h)
     a->tele_last_lap = h.tele_last_lap;
     a->tele_best_lap = h.tele_best_lap;
     a->tele_total_time = h.tele_total_time;
+    a->steer_smoothed = h.steer_smoothed;
+    a->wheel_uf = h.wheel_uf;
+    a->wheel_ur = h.wheel_ur;
 }
 
 // Sensor.Transform.forward: the kart's forward (fx, fz) turned by the sensor's local yaw (Unity Y rotation, +z toward +x)

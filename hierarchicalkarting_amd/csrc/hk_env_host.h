@@ -43,7 +43,7 @@ struct EnvDevice {
     // gameParams classes: MCTS agents that share (velocityBucketSize, timePrecision) share one set of move tables; the reference's
     // MCTS-RL vs MCTS-LQR set-ups run two classes in one env (bucket 1 against 2).  d.mcts carries class 0's tables; a search launch
     // runs once per class with that class's tables and agent mask (flush_mcts).
-    struct MctsClass { int* dt_tab; float* load_tab; float* rad_tab; uint32_t* mask_tab; unsigned char* order_tab; int nv, ntab; uint32_t agents; };
+    struct MctsClass { int* dt_tab; float* load_tab; float* rad_tab; unsigned long long* mask_tab; unsigned char* order_tab; int nv, na, ntab, lds_tier; uint32_t agents; };
     MctsClass mcls[HK_MCTS_MAX_CLASSES] = {};
     int n_mcls = 0;
     RwDev rw{};                    // reward shaping tables (null when hk_config.rewards == 0)
@@ -91,7 +91,7 @@ namespace hk {
 struct GaOps {
     size_t (*mcts_req_bytes)();
     int (*mcts_searches_per_wave)();
-    size_t (*mcts_lds_bytes)(int ntab, int L, int waves);
+    size_t (*mcts_lds_bytes)(int ntab, int L, int na, int tier, int waves);
     int (*mcts_root_words)();
     size_t (*game_doubles_per_ego)();
     size_t (*queue_ints_per_set)(size_t na);

@@ -38,7 +38,7 @@ inline void mcts_use_class(EnvDevice& d, int c)
 {
     const EnvDevice::MctsClass& K = d.mcls[c];
     d.mcts.dt_tab = K.dt_tab; d.mcts.load_tab = K.load_tab; d.mcts.rad_tab = K.rad_tab; d.mcts.mask_tab = K.mask_tab; d.mcts.order_tab = K.order_tab;
-    d.mcts.nv = K.nv; d.mcts.ntab = K.ntab;
+    d.mcts.nv = K.nv; d.mcts.na = K.na; d.mcts.lds_tier = K.lds_tier; d.mcts.ntab = K.ntab;
 }
 
 inline void env_destroy(EnvDevice& d)
@@ -146,14 +146,15 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
             EnvDevice::MctsClass& K = d.mcls[c];
             const int ego0 = __builtin_ctz(K.agents);
             int nv = 0;
-            for (int v = 6; v < (int)P.max_speed && nv < 5; v += cfg.velocity_bucket_size[ego0]) nv++;
-            K.nv = nv;
-            const int ntab = L * 4 * (nv + 1) * HK_MCTS_MAX_ACTIONS;
+            for (int v = 6; v < (int)P.max_speed; v += cfg.velocity_bucket_size[ego0]) nv++;       // KDG:329
+            if (nv < 1 || 4 * nv > HK_MCTS_MAX_ACTIONS) { err = "hk_create: the planner's action list (4 lanes x velocity buckets of velocity_bucket_size from 6 m/s up to the top speed) must hold 4 .. 36 actions"; return HK_ERR_UNSUPPORTED; }
+            K.nv = nv; K.na = 4 * nv; K.lds_tier = 7;
+            const int ntab = L * 4 * (nv + 1) * K.na;
             K.ntab = ntab;
             HK_ALLOC(K.dt_tab, (size_t)ntab * sizeof(int));
-            HK_ALLOC(K.load_tab, (size_t)L * 4 * HK_MCTS_MAX_ACTIONS * sizeof(float));
+            HK_ALLOC(K.load_tab, (size_t)L * 4 * K.na * sizeof(float));
             HK_ALLOC(K.rad_tab, (size_t)L * 4 * 4 * sizeof(float));
-            HK_ALLOC(K.mask_tab, (size_t)(ntab / HK_MCTS_MAX_ACTIONS) * sizeof(uint32_t));
+            HK_ALLOC(K.mask_tab, (size_t)(ntab / K.na) * sizeof(unsigned long long));
             HK_ALLOC(K.order_tab, (size_t)ntab);
             mcts_use_class(d, c);
             if ((rc = HK_GA_CALL(d, launch_mcts_table(d, ego0, ntab, stream, err)))) return rc;
@@ -162,7 +163,13 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
                 if ((e = hipMemcpyAsync(hdt.data(), K.dt_tab, (size_t)ntab * sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess ||
                     (e = hipStreamSynchronize(stream)) != hipSuccess) { err = std::string("hk_create: move tables: ") + hipGetErrorString(e); return HK_ERR_HIP; }
                 for (int v : hdt) if (v > 32767) { err = "hk_create: a move of the discrete game takes more than 32 767 time units (timePrecision too fine for the planner's tables)"; return HK_ERR_UNSUPPORTED; }
-                if (HK_GA_CALL(d, mcts_lds_bytes(ntab, L, 4)) > 160 * 1024) { err = "hk_create: the planner's move tables do not fit the LDS (track too long)"; return HK_ERR_UNSUPPORTED; }
+                // what rides in LDS beside the int16 time table: everything if it fits (tier 7), else only the radii and section flags (tier 0:
+                // rollout orders, tire loads and row masks are read from global memory / L2: a long track at velocityBucketSize 1)
+                const int tiers[2] = {7, 0};
+                int t = 0;
+                while (t < 2 && HK_GA_CALL(d, mcts_lds_bytes(ntab, L, K.na, tiers[t], 4)) > 160 * 1024) t++;
+                if (t == 2) { err = "hk_create: the planner's move tables do not fit the LDS (track too long)"; return HK_ERR_UNSUPPORTED; }
+                K.lds_tier = tiers[t];
             }
         }
         mcts_use_class(d, 0);

@@ -6,7 +6,7 @@ namespace hk { namespace HK_GA_NS {
 
 inline size_t mcts_req_bytes() { return sizeof(MctsReq); }
 inline int mcts_searches_per_wave() { return 64; }
-inline size_t mcts_lds_bytes(int ntab, int L, int waves) { return mcts_search_lds_bytes(ntab, L, waves); }
+inline size_t mcts_lds_bytes(int ntab, int L, int na, int tier, int waves) { return mcts_search_lds_bytes(ntab, L, na, tier, waves); }
 inline int mcts_root_words() { return MC_ROOT_WORDS; }
 inline size_t game_doubles_per_ego() { return (size_t)GA * GP_FIELDS; }      // GameSoA: GA players x GP_FIELDS doubles
 inline size_t queue_ints_per_set(size_t na) { return (size_t)(GA - 1) * na; }   // one queue per player count 2 .. GA
@@ -16,7 +16,7 @@ inline int launch_mcts_table(EnvDevice& d, int ego0, int ntab, hipStream_t strea
     hipLaunchKernelGGL(mcts_table_kernel, dim3((ntab + 255) / 256), dim3(256), 0, stream, d.P, d.mcts, ego0);
     int rc = launch_check(err, "mcts_table_kernel");
     if (rc) return rc;
-    const int rows = ntab / HK_MCTS_MAX_ACTIONS;
+    const int rows = ntab / d.mcts.na;
     hipLaunchKernelGGL(mcts_order_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, d.P, d.mcts, ego0, rows);
     return launch_check(err, "mcts_order_kernel");
 }
@@ -40,17 +40,19 @@ inline int flush_mcts(EnvDevice& d, hipStream_t stream, std::string& err)
     for (int c = 0; c < d.n_mcls; c++) {          // one launch per gameParams class: its tables ride in the workgroups' LDS, its agents' entries are searched
         const EnvDevice::MctsClass& K = d.mcls[c];
         MctsDev M = d.mcts;
-        M.dt_tab = K.dt_tab; M.load_tab = K.load_tab; M.rad_tab = K.rad_tab; M.mask_tab = K.mask_tab; M.order_tab = K.order_tab; M.nv = K.nv; M.ntab = K.ntab;
+        M.dt_tab = K.dt_tab; M.load_tab = K.load_tab; M.rad_tab = K.rad_tab; M.mask_tab = K.mask_tab; M.order_tab = K.order_tab; M.nv = K.nv; M.na = K.na; M.lds_tier = K.lds_tier; M.ntab = K.ntab;
         // one workgroup per CU, 4 waves (one per SIMD) while the grid is at most 1 024 waves, 8 beyond; the move tables ride in its LDS
         const int total_waves = (d.mcts.grid_lanes + 63) / 64;
         int waves = total_waves <= 1024 ? 4 : 8;
-        while (waves > 4 && mcts_search_lds_bytes(K.ntab, d.P.L, waves) > 160 * 1024) waves -= 2;      // (8 karts: the path arrays of 8 waves do not fit beside the tables)
-        const size_t lds = mcts_search_lds_bytes(K.ntab, d.P.L, waves);
+        while (waves > 4 && mcts_search_lds_bytes(K.ntab, d.P.L, K.na, K.lds_tier, waves) > 160 * 1024) waves -= 2;      // (8 karts: the path arrays of 8 waves do not fit beside the tables)
+        const size_t lds = mcts_search_lds_bytes(K.ntab, d.P.L, K.na, K.lds_tier, waves);
         if (!d.mcts.lds_attr_set) {
-            (void)hipFuncSetAttribute((const void*)mcts_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)mcts_search_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)mcts_search_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             d.mcts.lds_attr_set = 1;
         }
-        hipLaunchKernelGGL(mcts_search_kernel, dim3((total_waves + waves - 1) / waves), dim3(waves * 64), lds, stream, d.P, M, d.mset, K.ntab, K.agents);
+        if (K.lds_tier == 7) hipLaunchKernelGGL(mcts_search_kernel<true>, dim3((total_waves + waves - 1) / waves), dim3(waves * 64), lds, stream, d.P, M, d.mset, K.ntab, K.agents);
+        else hipLaunchKernelGGL(mcts_search_kernel<false>, dim3((total_waves + waves - 1) / waves), dim3(waves * 64), lds, stream, d.P, M, d.mset, K.ntab, K.agents);
     }
     int rc = launch_check(err, "mcts_search_kernel");
     if (rc) return rc;

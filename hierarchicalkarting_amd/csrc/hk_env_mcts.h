@@ -22,7 +22,7 @@
 namespace hk { namespace HK_GA_NS {
 
 constexpr int MC_MAXP = GA;                   // players of a discrete game (<= agents of an env)
-constexpr int MC_MAXA = HK_MCTS_MAX_ACTIONS;  // 20
+constexpr int MC_MAXA = HK_MCTS_MAX_ACTIONS;  // 36: capacity; a class of agents has C.nact = 4 x its velocity buckets (20 at bucket size 2, 36 at 1)
 #ifndef HK_MC_SPW
 #define HK_MC_SPW 64
 #endif
@@ -218,7 +218,7 @@ template <int I> __device__ __forceinline__ int mc_t(const DGame& g)
 // hundreds of cycles at the one-wave-per-SIMD occupancy this kernel runs at, and there were hundreds per position).
 struct MoveEval {
     int n;
-    uint32_t legal;
+    unsigned long long legal;
     int row;                    // table row of the position: (section % L, lane, velocity bucket) of the player who is up next
 };
 struct MctsCtx {
@@ -227,7 +227,7 @@ struct MctsCtx {
     int bucket, precision, vmax, nact;
     uint32_t key0, key1, c1, c2, draw;
     const short* dt_tab; const float* load_tab; const float* rad_tab; int nv;      // the move tables (the search kernel's copy in LDS)
-    const uint32_t* mask_tab; const unsigned char* order_tab;      // per table row: feasible actions (dt >= 0), the 20 actions in rollout order
+    const unsigned long long* mask_tab; const unsigned char* order_tab;      // per table row: feasible actions (dt >= 0), the nact actions in rollout order
     const unsigned char* sec_flags;         // per section (mod L): bit 0 straight, bits 1.. optimal lane (LDS; nullptr: read the track table)
 };
 
@@ -437,19 +437,20 @@ __device__ __forceinline__ void mc_eval_moves(const MctsCtx& C, const DGame& g, 
 #pragma unroll
     for (int l = 0; l < 4; l++) vl[l] = mc_max_speed(C, rp[l], wear);                       // lateral-g speed limit per target lane
     const int row = (sm * 4 + (cur.lane - 1)) * (C.nv + 1) + mc_vb(C, cur.minv);
-    uint32_t m = C.mask_tab[row];
+    unsigned long long m = C.mask_tab[row];
     uint32_t lanes = 0;                                                                     // bit l: target lane l + 1 passes (ii) and bucket 0 .. of (iii)
-    uint32_t speed = 0;                                                                     // bit 4 vi + l: bucket vi of lane l + 1 passes (iii)
+    unsigned long long speed = 0;                                                           // bit 4 vi + l: bucket vi of lane l + 1 passes (iii)
+    const int nvb = C.nact >> 2;
 #pragma unroll
     for (int l = 0; l < 4; l++) {
         const int dl = (l + 1) > cur.lane ? (l + 1) - cur.lane : cur.lane - (l + 1);
         if (!(str && cur.lchg + dl > C.P->max_lane_changes)) lanes |= 1u << l;
 #pragma unroll
         for (int vi = 0; vi < MC_MAXA / 4; vi++)
-            if (!(vl[l] < (float)(6 + vi * C.bucket))) speed |= 1u << (4 * vi + l);
+            if (vi < nvb && !(vl[l] < (float)(6 + vi * C.bucket))) speed |= 1ull << (4 * vi + l);
     }
-    m &= (lanes * 0x11111u) & speed;
-    mv.legal = m; mv.n = __builtin_popcount(m); mv.row = row;
+    m &= ((unsigned long long)lanes * 0x111111111ull) & speed;
+    mv.legal = m; mv.n = __builtin_popcountll(m); mv.row = row;
 }
 
 // makeMove KDG:416-443 on the running state (applyAction through the move tables)
@@ -464,8 +465,8 @@ __device__ __forceinline__ void mc_make_move(const MctsCtx& C, DGame& g, int np,
     if (mc_straight(C, k.section) != mc_straight(C, k.section + 1)) lchg = 0;
     else if (lane != k.lane) lchg = k.lchg + dl;
     else lchg = k.lchg;
-    const int dt = C.dt_tab[((sm * 4 + (k.lane - 1)) * (C.nv + 1) + mc_vb(C, k.minv)) * MC_MAXA + a];
-    const float load = C.load_tab[(sm * 4 + (k.lane - 1)) * MC_MAXA + a];
+    const int dt = C.dt_tab[((sm * 4 + (k.lane - 1)) * (C.nv + 1) + mc_vb(C, k.minv)) * C.nact + a];
+    const float load = C.load_tab[(sm * 4 + (k.lane - 1)) * C.nact + a];
     k.tire = (int)(((float)k.tire / 10000.0f + load * C.P->st.TireWearFactor) * 10000.0f);
     k.time += dt;
     k.section += 1; k.minv = minv; k.maxv = maxv; k.lane = lane; k.lchg = lchg;
@@ -484,15 +485,17 @@ __device__ __forceinline__ void mc_make_move(const MctsCtx& C, DGame& g, int np,
 // (mcts_order_kernel) and the pick walks it, counting the legal ones.
 __device__ __forceinline__ int mc_pick_move(const MctsCtx& C, const MoveEval& mv, int index)
 {
-    const uint32_t* ord = reinterpret_cast<const uint32_t*>(C.order_tab + (size_t)mv.row * MC_MAXA);      // 20 bytes = 5 words (rows are 4-byte aligned)
+    const uint32_t* ord = reinterpret_cast<const uint32_t*>(C.order_tab + (size_t)mv.row * C.nact);      // nact bytes = 5 or 9 words (rows are 4-byte aligned)
     int move = 0, seen = 0;
+    const int nw = C.nact >> 2;
 #pragma unroll
     for (int w = 0; w < MC_MAXA / 4; w++) {
+        if (w >= nw) break;                                  // (uniform: every search of a launch belongs to one gameParams class)
         const uint32_t four = ord[w];
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             const int a = (int)((four >> (8 * b)) & 0xFFu);
-            const bool ok = (mv.legal >> a) & 1u;
+            const bool ok = (mv.legal >> a) & 1ull;
             move = (ok && seen == index) ? a : move;
             seen += ok ? 1 : 0;
         }
@@ -575,7 +578,7 @@ __device__ inline void mc_ctx_init(MctsCtx& C, const EnvParams& P, const TabView
     C.vmax = (int)P.max_speed;
     C.nact = 0;
     for (int i = 6; i < C.vmax; i += C.bucket) C.nact += 4;
-    if (C.nact > MC_MAXA) C.nact = MC_MAXA;
+    if (C.nact > MC_MAXA) C.nact = MC_MAXA;                // (hk_create refuses such a list)
     C.sec_flags = nullptr; C.mask_tab = nullptr; C.order_tab = nullptr;
     C.dt_tab = nullptr; C.load_tab = M.load_tab; C.rad_tab = M.rad_tab; C.nv = M.nv;       // (the search kernel points these at its LDS copies)
     C.key0 = 0; C.key1 = 0; C.c1 = 0; C.c2 = 0; C.draw = 0;
@@ -596,8 +599,9 @@ __global__ __launch_bounds__(256) void mcts_table_kernel(EnvParams P, MctsDev M,
     mc_ctx_init(C, P, T, M, ego);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int nb = M.nv + 1;
-    if (t >= P.L * 4 * nb * MC_MAXA) return;
-    const int a = t % MC_MAXA, vb = (t / MC_MAXA) % nb, l0 = (t / (MC_MAXA * nb)) % 4, sec = t / (MC_MAXA * nb * 4);
+    const int na = M.na;
+    if (t >= P.L * 4 * nb * na) return;
+    const int a = t % na, vb = (t / na) % nb, l0 = (t / (na * nb)) % 4, sec = t / (na * nb * 4);
     int dt = -1;
     float load = 0.0f;
     if (a < C.nact) {
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(256) void mcts_table_kernel(EnvParams P, MctsDev M,
         load = mc_tire_load(C, sec, (float)maxv, l0 + 1, lane);
     }
     M.dt_tab[t] = dt;
-    if (vb == 0) M.load_tab[(sec * 4 + l0) * MC_MAXA + a] = load;
+    if (vb == 0) M.load_tab[(sec * 4 + l0) * na + a] = load;
     if (vb == 0 && a < 4) M.rad_tab[(sec * 4 + l0) * 4 + a] = mc_radius(C, sec, l0 + 1, a + 1);
 }
 
@@ -630,23 +634,25 @@ __global__ __launch_bounds__(256) void mcts_order_kernel(EnvParams P, MctsDev M,
     const int cur_lane = (row / nb) % 4 + 1, sm = row / (nb * 4);
     const int ol = T.sec[sm].optimal_lane;
     const int sign = ol == 1 ? 1 : (ol == 4 ? -1 : 0);                       // DPT:221-231
-    uint32_t key[MC_MAXA], mask = 0;
-    for (int a = 0; a < MC_MAXA; a++) {
-        const int dt = M.dt_tab[(size_t)row * MC_MAXA + a];
+    const int na = M.na;
+    uint32_t key[MC_MAXA];
+    unsigned long long mask = 0;
+    for (int a = 0; a < na; a++) {
+        const int dt = M.dt_tab[(size_t)row * na + a];
         const int lane = (a & 3) + 1, minv = 6 + (a >> 2) * C.bucket;
         const int maxv = (minv + C.bucket) < C.vmax ? (minv + C.bucket) : C.vmax;
         const int dl = lane > cur_lane ? lane - cur_lane : cur_lane - lane;
         key[a] = ((uint32_t)dt << 12) | ((uint32_t)(C.vmax - maxv) << 6) | ((uint32_t)dl << 4) | (uint32_t)(sign * lane + 4);
-        if (dt >= 0) mask |= 1u << a;
+        if (dt >= 0) mask |= 1ull << a;
     }
-    uint32_t left = (1u << MC_MAXA) - 1u;
-    for (int r = 0; r < MC_MAXA; r++) {                                      // selection by repeated minimum, the lowest action wins ties
+    unsigned long long left = (1ull << na) - 1ull;
+    for (int r = 0; r < na; r++) {                                           // selection by repeated minimum, the lowest action wins ties
         uint32_t best = 0xFFFFFFFFu;
         int move = -1;
-        for (int a = 0; a < MC_MAXA; a++)
-            if (((left >> a) & 1u) && (move < 0 || key[a] < best)) { best = key[a]; move = a; }
-        left &= ~(1u << move);
-        M.order_tab[(size_t)row * MC_MAXA + r] = (unsigned char)move;
+        for (int a = 0; a < na; a++)
+            if (((left >> a) & 1ull) && (move < 0 || key[a] < best)) { best = key[a]; move = a; }
+        left &= ~(1ull << move);
+        M.order_tab[(size_t)row * na + r] = (unsigned char)move;
     }
     M.mask_tab[row] = mask;
 }
@@ -697,7 +703,7 @@ __device__ __forceinline__ DGame mc_root_load(const int* rootl, const int stride
 }
 
 // one queued search (queue entry q of `set`), its tree in the arena slice `nd`
-struct MctsTabs { const short* dt; const float* load; const float* rad; const unsigned char* flags; const uint32_t* mask; const unsigned char* order; };
+struct MctsTabs { const short* dt; const float* load; const float* rad; const unsigned char* flags; const unsigned long long* mask; const unsigned char* order; };
 __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDev& M, const TabView& T, const MctsTabs& tabs, const int set, const int q, const int lane0,
                                                 unsigned short* path /* LDS, [MC_MAXPATH][64], this lane's column */, unsigned char* pup, const uint32_t cls_agents)
 {
@@ -897,30 +903,42 @@ __device__ __forceinline__ bool mcts_search_outstanding(const EnvParams& P, cons
 // iterations 93 -> 59 ms before the tables moved.
 #define HK_MC_BOUNDS __launch_bounds__(512)
 constexpr int MC_PATH_BYTES = MC_MAXPATH * 64 * 3;          // per wave: node indices (16 bit) + up-next players (8 bit) of one root-to-leaf path
-inline size_t mcts_table_lds_bytes(int ntab, int L)
-{   // dt (int16) | load | rad | section flags | row masks | row orders
-    return (((size_t)ntab * sizeof(short) + 15) & ~(size_t)15) + (size_t)L * 4 * MC_MAXA * sizeof(float) + (size_t)L * 4 * 4 * sizeof(float) + HK_MAX_SECTIONS +
-           (size_t)(ntab / MC_MAXA) * sizeof(uint32_t) + (((size_t)ntab + 15) & ~(size_t)15);
+__host__ __device__ inline size_t mcts_table_lds_bytes(int ntab, int L, int na, int tier)
+{   // dt (int16) | rad | section flags | [tier bit 0] row masks | [bit 1] load | [bit 2] row orders
+    size_t b = (((size_t)ntab * sizeof(short) + 15) & ~(size_t)15) + (size_t)L * 4 * 4 * sizeof(float) + HK_MAX_SECTIONS;
+    if (tier & 1) b += (size_t)(ntab / na) * sizeof(unsigned long long);
+    if (tier & 2) b += (size_t)L * 4 * na * sizeof(float);
+    if (tier & 4) b += ((size_t)ntab + 15) & ~(size_t)15;
+    return (b + 15) & ~(size_t)15;
 }
-inline size_t mcts_search_lds_bytes(int ntab, int L, int waves) { return mcts_table_lds_bytes(ntab, L) + (size_t)waves * MC_PATH_BYTES; }
+inline size_t mcts_search_lds_bytes(int ntab, int L, int na, int tier, int waves) { return mcts_table_lds_bytes(ntab, L, na, tier) + (size_t)waves * MC_PATH_BYTES; }
+// ALL_LDS: every table rides in LDS (tier 7).  false (tier 0: a long track at velocityBucketSize 1, whose tables exceed the CU's LDS): only
+// the time table, the radii and the section flags do; masks, loads and orders are read from global memory.  A COMPILE-TIME choice: with a
+// run-time one the table pointers are generic and every LDS read becomes a flat_load (see tab_stage, hk_env_device.h).
+template <bool ALL_LDS>
 __global__ HK_MC_BOUNDS void mcts_search_kernel(EnvParams P, MctsDev M, int set, int ntab, uint32_t cls_agents)
 {
     HK_DYN_SHARED(mc_smem);
     const int count = M.qcnt[set * 2];
     if (count == 0) return;                                  // (uniform: nothing queued, no table copy either)
+    constexpr int tier = ALL_LDS ? 7 : 0;
+    const int na = M.na, rows = ntab / na;
     short* dt_s = reinterpret_cast<short*>(mc_smem);
-    float* load_s = reinterpret_cast<float*>(mc_smem + (((size_t)ntab * sizeof(short) + 15) & ~(size_t)15));
-    float* rad_s = load_s + P.L * 4 * MC_MAXA;
+    float* rad_s = reinterpret_cast<float*>(mc_smem + (((size_t)ntab * sizeof(short) + 15) & ~(size_t)15));
     unsigned char* flags_s = reinterpret_cast<unsigned char*>(rad_s + P.L * 4 * 4);          // [HK_MAX_SECTIONS]
-    const int rows = ntab / MC_MAXA;
-    uint32_t* mask_s = reinterpret_cast<uint32_t*>(flags_s + HK_MAX_SECTIONS);                // [rows]
-    unsigned char* order_s = reinterpret_cast<unsigned char*>(mask_s + rows);                 // [rows][20] = ntab bytes
-    unsigned char* paths = order_s + (((size_t)ntab + 15) & ~(size_t)15);
+    unsigned char* nextp = flags_s + HK_MAX_SECTIONS;                                         // (8-byte aligned: 16 + L * 64 + 64)
+    unsigned long long* mask_s = reinterpret_cast<unsigned long long*>(nextp);                // [rows]
+    if (tier & 1) nextp += (size_t)rows * sizeof(unsigned long long);
+    float* load_s = reinterpret_cast<float*>(nextp);                                          // [L][4][na]
+    if (tier & 2) nextp += (size_t)P.L * 4 * na * sizeof(float);
+    unsigned char* order_s = nextp;                                                           // [rows][na] = ntab bytes
+    if (tier & 4) nextp += ((size_t)ntab + 15) & ~(size_t)15;
+    unsigned char* paths = mc_smem + mcts_table_lds_bytes(ntab, P.L, na, tier);
     for (int k = threadIdx.x; k < ntab; k += blockDim.x) { const int v = M.dt_tab[k]; dt_s[k] = (short)(v < 0 ? -1 : v); }     // < 0: infeasible (only the sign is read)
-    for (int k = threadIdx.x; k < P.L * 4 * MC_MAXA; k += blockDim.x) load_s[k] = M.load_tab[k];
     for (int k = threadIdx.x; k < P.L * 4 * 4; k += blockDim.x) rad_s[k] = M.rad_tab[k];
-    for (int k = threadIdx.x; k < rows; k += blockDim.x) mask_s[k] = M.mask_tab[k];
-    for (int k = threadIdx.x; k < ntab / 4; k += blockDim.x) reinterpret_cast<uint32_t*>(order_s)[k] = reinterpret_cast<const uint32_t*>(M.order_tab)[k];
+    if (tier & 1) for (int k = threadIdx.x; k < rows; k += blockDim.x) mask_s[k] = M.mask_tab[k];
+    if (tier & 2) for (int k = threadIdx.x; k < P.L * 4 * na; k += blockDim.x) load_s[k] = M.load_tab[k];
+    if (tier & 4) for (int k = threadIdx.x; k < ntab / 4; k += blockDim.x) reinterpret_cast<uint32_t*>(order_s)[k] = reinterpret_cast<const uint32_t*>(M.order_tab)[k];
     {
         const TabView Tg = tab_view(P, P.tab);
         for (int k = threadIdx.x; k < P.L; k += blockDim.x) flags_s[k] = (unsigned char)((Tg.sec[k].inside_radius == 0.0f ? 1 : 0) | (Tg.sec[k].optimal_lane << 1));
@@ -932,7 +950,9 @@ __global__ HK_MC_BOUNDS void mcts_search_kernel(EnvParams P, MctsDev M, int set,
     const TabView T = tab_view(P, P.tab);
     unsigned short* path = reinterpret_cast<unsigned short*>(paths + (size_t)wave * MC_PATH_BYTES);       // [MC_MAXPATH][64]: node indices fit 16 bits
     unsigned char* pup = reinterpret_cast<unsigned char*>(path + MC_MAXPATH * 64);                         //   (hk_create refuses pools beyond 65 535 nodes)
-    MctsTabs tabs = {dt_s, load_s, rad_s, flags_s, mask_s, order_s};
+    MctsTabs tabs;
+    if constexpr (ALL_LDS) tabs = MctsTabs{dt_s, load_s, rad_s, flags_s, mask_s, order_s};
+    else tabs = MctsTabs{dt_s, M.load_tab, rad_s, flags_s, M.mask_tab, M.order_tab};
     for (int q = lane0; q < count; q += gridDim.x * waves * 64) mcts_search_one(P, M, T, tabs, set, q, lane0, path + lane, pup + lane, cls_agents);
 }
 

@@ -113,7 +113,54 @@ inline int env_build_params(hk_config& cfg, std::vector<hk_section>& sections, s
     P.mcts_iter = cfg.mcts_iterations; P.mcts_iter0 = cfg.mcts_initial_iterations; P.mcts_lat = cfg.mcts_latency_ticks;
     P.mcts_lat0 = cfg.mcts_initial_latency_ticks; P.mcts_seed = cfg.mcts_seed;
     P.jitter_seed = cfg.jitter_seed; P.jitter_pos = cfg.jitter_pos; P.jitter_yaw = cfg.jitter_yaw; P.env_id_base = cfg.env_id_base;
+    {   // engine restatement (hk.h hk_engine_params)
+        const hk_engine_params& g = cfg.engine;
+        if (g.wheel_friction || g.contact_yaw) {
+            if (!(g.mass > 0.0f) || !(g.inertia_y > 0.0f)) { err = "hk_create: engine.mass / engine.inertia_y must be positive"; return HK_ERR_INVALID; }
+        }
+        if (g.wheel_friction) {
+            if (!(g.axle_zf > g.axle_zr) || !(g.side_ext_slip > 0.0f) || !(g.side_asy_slip > g.side_ext_slip) || !(g.slip_min_speed > 0.0f) ||
+                !(g.side_slope0 >= 0.0f && g.side_slope0 <= 3.0f)) {
+                err = "hk_create: engine wheel parameters out of range (axle_zf > axle_zr, 0 < ext_slip < asy_slip, slip_min_speed > 0, 0 <= side_slope0 <= 3)"; return HK_ERR_INVALID;
+            }
+        }
+        P.eng = g;
+        EngDerived& D = P.engd;
+        std::memset(&D, 0, sizeof(D));
+        auto curve = [](EngCurve& c, float ext_slip, float ext_value, float asy_slip, float asy_value, float slope0) {
+            c.ext = ext_slip; c.asy = asy_slip;
+            c.inv_ext = 1.0f / ext_slip; c.inv_span = 1.0f / (asy_slip - ext_slip);
+            c.a3 = ext_value * (slope0 - 2.0f); c.a2 = ext_value * (3.0f - 2.0f * slope0); c.a1 = ext_value * slope0;
+            c.b3 = -2.0f * (asy_value - ext_value); c.b2 = 3.0f * (asy_value - ext_value); c.b0 = ext_value;
+            c.flat = asy_value;
+        };
+        if (g.mass > 0.0f && g.inertia_y > 0.0f) {
+            D.inv_m = 1.0f / g.mass; D.inv_i = 1.0f / g.inertia_y;
+            const float span = g.axle_zf - g.axle_zr;
+            if (g.wheel_friction) {
+                const float load_f = (-g.axle_zr / span) * g.mass * g.gravity, load_r = (g.axle_zf / span) * g.mass * g.gravity;
+                D.side_kf = g.side_stiffness * load_f * cfg.dt; D.side_kr = g.side_stiffness * load_r * cfg.dt;
+                D.jden_r = 1.0f / (D.inv_m + g.axle_zr * g.axle_zr * D.inv_i);
+                curve(D.side, g.side_ext_slip, g.side_ext_value, g.side_asy_slip, g.side_asy_value, g.side_slope0);
+                if (g.wheel_rolling) {
+                    if (!(g.wheel_mass > 0.0f) || !(g.wheel_radius_f > 0.0f) || !(g.wheel_radius_r > 0.0f) || !(g.wheel_damping >= 0.0f) ||
+                        !(g.fwd_ext_slip > 0.0f) || !(g.fwd_asy_slip > g.fwd_ext_slip) || !(g.long_slip_min_speed > 0.0f)) {
+                        err = "hk_create: engine rolling parameters out of range (wheel_mass, radii > 0, damping >= 0, 0 < fwd_ext_slip < fwd_asy_slip, long_slip_min_speed > 0)"; return HK_ERR_INVALID;
+                    }
+                    D.inv_mw = 1.0f / g.wheel_mass;
+                    D.fwd_kf = g.fwd_stiffness * load_f * cfg.dt; D.fwd_kr = g.fwd_stiffness * load_r * cfg.dt;
+                    D.inv_damp_f = 1.0f / (1.0f + cfg.dt * g.wheel_damping / (0.5f * g.wheel_mass * g.wheel_radius_f * g.wheel_radius_f));
+                    D.inv_damp_r = 1.0f / (1.0f + cfg.dt * g.wheel_damping / (0.5f * g.wheel_mass * g.wheel_radius_r * g.wheel_radius_r));
+                    D.jlden_r = 1.0f / (D.inv_mw + D.inv_m);
+                    curve(D.fwd, g.fwd_ext_slip, g.fwd_ext_value, g.fwd_asy_slip, g.fwd_asy_value, g.side_slope0);
+                }
+            }
+        }
+    }
     P.max_speed = cfg.stats.TopSpeed > cfg.stats.ReverseSpeed ? cfg.stats.TopSpeed : cfg.stats.ReverseSpeed;   // AK:210
+    // phase_assemble walks at most 6 two-metre samples of the forward ray: hits up to 11.25 m are found, and the ray is compared with
+    // speed / 2 (HKA:834) — exact for speeds up to 22.5 m/s (the reference's karts: 15)
+    if (P.max_speed * 0.5f > 11.25f) { err = "hk_create: TopSpeed / ReverseSpeed above 22.5 m/s is outside the forward ray's sampled range"; return HK_ERR_UNSUPPORTED; }
     P.init_acc = -cfg.stats.TireWearRate * hk_logf(1 - ((cfg.stats.MaxSteer - cfg.stats.MinSteer) * 0.25f / cfg.stats.MaxSteer));  // REC:588
     {
         const float dyc = 0.5f - 0.582f;   // sensor height - capsule centre height (kart-local)

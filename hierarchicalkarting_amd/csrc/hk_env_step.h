@@ -358,6 +358,13 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
         float acc_ang_v = h.acc_ang_v;
         const float final_steer = kart_steer(P, acc_ang_v);               // UpdateStats AK:295-302
         h.final_steer = final_steer;
+        {   // KartAnimation.FixedUpdate (KartAnimation.cs:54-63, after ArcadeKart's): the front WheelColliders' steerAngle / maxSteeringAngle
+            const float maxDelta = P.eng.steer_damping * P.dt;
+            float ss = h.steer_smoothed;
+            if (f_abs(turnInput - ss) <= maxDelta) ss = turnInput;
+            else ss = ss + f_sign(turnInput - ss) * maxDelta;
+            h.steer_smoothed = ss;
+        }
         if (fl & HK_F_CAN_MOVE) {                                         // MoveVehicle AK:363-503
             HK_LP(13);
             const float dt = P.dt;
@@ -414,7 +421,8 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             acc_ang_v += f_abs(wy);
             h.acc_ang_v = acc_ang_v;
             rot_y(turningPower * f_sign(localVelZ) * 25.0f * P.st.Grip * dt * DEG2RAD_F, vx, vz);
-            // ---- engine: integrate
+            // ---- engine: the wheels' sideways friction, then integrate
+            if (P.eng.wheel_friction) engine_wheels(P, cfx, cfz, h.steer_smoothed, vx, vz, wy, h.wheel_uf, h.wheel_ur);
             wy = wy * (1.0f - P.st.AngularDrag * dt);
             yaw = yaw + wy * dt;
             if (yaw < 0.0f) yaw += TWO_PI_F;
@@ -429,12 +437,12 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
     {
         float ax = 0, az = 0, bx = 0, bz = 0;
         kart_core(cfx, cfz, px, pz, ax, az, bx, bz);
-        float cpx = 0, cpz = 0, cvx = 0, cvz = 0;
+        float cpx = 0, cpz = 0, cvx = 0, cvz = 0, cwy = 0;
         bool touched = false;
         for_each_lane([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             const float jpx = group_get<j>(px), jpz = group_get<j>(pz), jfx = group_get<j>(cfx), jfz = group_get<j>(cfz);
-            const float jvx = group_get<j>(vx), jvz = group_get<j>(vz);
+            const float jvx = group_get<j>(vx), jvz = group_get<j>(vz), jwy = group_get<j>(wy);
             const uint32_t jfl = group_get<j>(fl);
             if (j >= P.A || j == i || !enabled || !(jfl & HK_F_ENABLED)) return;
             // exact cull: two capsules (reach 0.657 + 0.45 from their origins) cannot touch when the origins are > 2.3 m apart
@@ -456,13 +464,28 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                 float pen = rr - d;
                 float share = (jfl & HK_F_CAN_MOVE) ? 0.5f : 1.0f;
                 cpx += nx * (pen * share); cpz += nz * (pen * share);
-                float vrel = (vx - jvx) * nx + (vz - jvz) * nz;
-                if (vrel < 0.0f) { cvx -= nx * (vrel * share); cvz -= nz * (vrel * share); }
+                if (!P.eng.contact_yaw) {
+                    float vrel = (vx - jvx) * nx + (vz - jvz) * nz;
+                    if (vrel < 0.0f) { cvx -= nx * (vrel * share); cvz -= nz * (vrel * share); }
+                } else {
+                    // frictionless inelastic contact of two free rigid bodies at the surface points (c1 - R n on this kart, c2 + R n on j)
+                    const float inv_m = P.engd.inv_m, inv_i = P.engd.inv_i;
+                    const float rix = (c1x - nx * CAP_R) - px, riz = (c1z - nz * CAP_R) - pz;
+                    const float rjx = (c2x + nx * CAP_R) - jpx, rjz = (c2z + nz * CAP_R) - jpz;
+                    const float ki = riz * nx - rix * nz, kj = rjz * nx - rjx * nz;
+                    float vrel = (vx - jvx) * nx + (vz - jvz) * nz + wy * ki - jwy * kj;
+                    if (vrel < 0.0f) {
+                        float den = inv_m + ki * ki * inv_i;
+                        if (jfl & HK_F_CAN_MOVE) den = den + (inv_m + kj * kj * inv_i);
+                        const float jn = -vrel / den;
+                        cvx += nx * (jn * inv_m); cvz += nz * (jn * inv_m); cwy += jn * ki * inv_i;
+                    }
+                }
                 touched = true;
             }
         });
         if (live) {
-            if (touched && (fl & HK_F_CAN_MOVE)) { px += cpx; pz += cpz; vx += cvx; vz += cvz; }
+            if (touched && (fl & HK_F_CAN_MOVE)) { px += cpx; pz += cpz; vx += cvx; vz += cvz; wy += cwy; }
             if (touched) fl |= HK_F_HAS_COLLISION; else fl &= ~HK_F_HAS_COLLISION;
         }
     }
@@ -476,7 +499,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             // a contact needs a wall within CAP_R of the core, i.e. within 1.11 m of the kart origin: the cell's near list
             const int cell = grid_cell(P, px, pz);
             const int w0 = T.grid_off[cell], w1 = w0 + T.near_cnt[cell];
-            float bestpen = 0.0f, bnx = 0.0f, bnz = 0.0f;
+            float bestpen = 0.0f, bnx = 0.0f, bnz = 0.0f, bcx = 0.0f, bcz = 0.0f;
             bool found = false;
             // Two passes over the cell's list, 32 walls at a time: a cheap bounding-box test marks the walls that can be within
             // CAP_R of the core at all (a bit per wall), then only those get the closest-point computation, in ascending list
@@ -521,14 +544,27 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                             if ((px - ws.x0) * nx + (pz - ws.z0) * nz < 0.0f) { nx = -nx; nz = -nz; }
                         }
                         // the near part of grid_idx is ascending per cell, so "first strictly deeper" == the oracle's lowest-index tie break
-                        if (!found || pen > bestpen) { found = true; bestpen = pen; bnx = nx; bnz = nz; }
+                        if (!found || pen > bestpen) { found = true; bestpen = pen; bnx = nx; bnz = nz; bcx = c1x; bcz = c1z; }
                     }
                 }
             }
             if (!found) break;
+            if (!P.eng.contact_yaw) {
+                float vn = vx * bnx + vz * bnz;
+                if (vn < 0.0f) { vx -= bnx * vn; vz -= bnz * vn; }
+            } else {
+                // frictionless inelastic contact at the capsule's surface point c1 - R n (lever about the centre of mass = the kart origin,
+                // taken before the push-out): the impulse stops the POINT's approach and turns the kart along the wall
+                const float inv_m = P.engd.inv_m, inv_i = P.engd.inv_i;
+                const float rx = (bcx - bnx * CAP_R) - px, rz = (bcz - bnz * CAP_R) - pz;
+                const float k = rz * bnx - rx * bnz;
+                const float vn = vx * bnx + vz * bnz + wy * k;
+                if (vn < 0.0f) {
+                    const float jn = -vn / (inv_m + k * k * inv_i);
+                    vx += bnx * (jn * inv_m); vz += bnz * (jn * inv_m); wy += jn * k * inv_i;
+                }
+            }
             px += bnx * bestpen; pz += bnz * bestpen;
-            float vn = vx * bnx + vz * bnz;
-            if (vn < 0.0f) { vx -= bnx * vn; vz -= bnz * vn; }
             fl |= HK_F_HAS_COLLISION;
             h.contact_nx = bnx; h.contact_nz = bnz;
         }

@@ -28,6 +28,9 @@ class RacingEnv:
         _lib.check(rc, None)
         self.E, self.A = self.built.cfg.num_envs, self.built.cfg.num_agents
         self.obs_dim = self.L.hk_obs_dim(self.h)
+        import os
+        # what hk_create read from the environment (include/hk.h): long calls of plain handles run as two halves on two streams
+        self.split_default = os.environ.get("HK_NO_SPLIT") is None and os.environ.get("HK_SPLIT", "1") != "0" and self.E >= 8192 and 2 < self.A <= 4
 
     def close(self):
         if getattr(self, "h", None):

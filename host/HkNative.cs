@@ -1,4 +1,4 @@
-// HkNative.cs — P/Invoke binding of libhk.so (include/hk.h, HK_ABI_VERSION 4) for the reference's Unity C# host.
+// HkNative.cs — P/Invoke binding of libhk.so (include/hk.h, HK_ABI_VERSION 5) for the reference's Unity C# host.
 //
 // Drop it under Assets/Karting/Scripts/AI/Native/ with libhk.so in Assets/Plugins/x86_64.  Every struct mirrors its C
 // twin field for field (tests/test_csharp_layout.py parses this file and checks field order, types, array lengths and
@@ -11,7 +11,7 @@ namespace KartGame.AI.Native
 {
     public static class HkConst
     {
-        public const int HK_ABI_VERSION = 4;
+        public const int HK_ABI_VERSION = 5;
         public const int HK_MAX_AGENTS = 8;
         public const int HK_MAX_SECTIONS = 64;
         public const int HK_NUM_SENSORS = 9;
@@ -107,6 +107,39 @@ namespace KartGame.AI.Native
         public float NotAtGoalPenalty;
     }
 
+    // hk_engine_params: the engine restatement's constants (Rigidbody / CapsuleCollider / WheelCollider / KartAnimation values of the kart prefab)
+    [StructLayout(LayoutKind.Sequential)]
+    public struct HkEngineParams
+    {
+        public float mass;
+        public float inertia_y;
+        public float gravity;
+        public float axle_zf;
+        public float axle_zr;
+        public float max_steer_deg;
+        public float steer_damping;
+        public float side_ext_slip;
+        public float side_ext_value;
+        public float side_asy_slip;
+        public float side_asy_value;
+        public float side_stiffness;
+        public float side_slope0;
+        public float slip_min_speed;
+        public float wheel_mass;
+        public float wheel_radius_f;
+        public float wheel_radius_r;
+        public float wheel_damping;
+        public float fwd_ext_slip;
+        public float fwd_ext_value;
+        public float fwd_asy_slip;
+        public float fwd_asy_value;
+        public float fwd_stiffness;
+        public float long_slip_min_speed;
+        public int wheel_friction;
+        public int contact_yaw;
+        public int wheel_rolling;
+    }
+
     // hk_config
     [StructLayout(LayoutKind.Sequential)]
     public unsafe struct HkConfig
@@ -159,6 +192,7 @@ namespace KartGame.AI.Native
         public HkRewardParams rw;
         public uint train_seed;
         public int debug_taps;
+        public HkEngineParams engine;
     }
 
     // hk_mcts_plan: bestStates (HKA:70,252)
@@ -228,6 +262,9 @@ namespace KartGame.AI.Native
         public fixed float plan_vel[64];
         public float step_reward;
         public float group_reward;
+        public float steer_smoothed;
+        public float wheel_uf;
+        public float wheel_ur;
     }
 
     // hk_env_state

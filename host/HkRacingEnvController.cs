@@ -97,10 +97,19 @@ public unsafe class HkRacingEnvController : MonoBehaviour
         cfg.disable_on_end = disableOnEnd ? 1 : 0; cfg.env_mode = (int)mode;
         cfg.start_hold_ticks = mode == EnvironmentMode.Training ? 0 : 75;       // WaitForSeconds(1.5f), REC:721-724
         cfg.auto_reset = 1; cfg.dt = Time.fixedDeltaTime; cfg.kart_y = 0.28f;  // REC:715
-        float[] yaw = { 0f, 30f, 60f, 90f, -30f, -60f, -90f, 45f, -45f };      // MLAgent_Sensors.prefab
+        // KartAgent.Sensors[] as the Compete scenes hold it (the scenes re-point the prefab's entries): 0, then +30 .. +90, then -30 .. -90.
+        // A host with the reference's agents in the scene reads Sensors[k].Transform.localEulerAngles.y instead.
+        float[] yaw = { 0f, 30f, 45f, 60f, 90f, -30f, -45f, -60f, -90f };
         float[] wallVal = { 0.8f, 0.9f, 1f, 0.8f, 0.6f, 0.9f, 1f, 0.8f, 0.6f };
         for (int k = 0; k < HkConst.HK_NUM_SENSORS; k++)
         { cfg.sensor_yaw_deg[k] = yaw[k]; cfg.ray_distance[k] = 20f; cfg.wall_hit_validation[k] = wallVal[k]; cfg.agent_hit_validation[k] = 1.5f; }
+        // engine restatement (hk.h hk_engine_params): Rigidbody / CapsuleCollider / WheelCollider / KartAnimation values of BaseKartClassic.prefab
+        cfg.engine = new HkEngineParams { mass = 250f, inertia_y = 74.71f, gravity = 9.81f, axle_zf = 0.58625615f, axle_zr = -0.68122816f,
+                                          max_steer_deg = 30f, steer_damping = 10f, side_ext_slip = 0.2f, side_ext_value = 1f, side_asy_slip = 0.5f,
+                                          side_asy_value = 0.75f, side_stiffness = 1f, side_slope0 = 1f, slip_min_speed = 1f, wheel_mass = 20f,
+                                          wheel_radius_f = 0.1372984f, wheel_radius_r = 0.1630791f, wheel_damping = 0.56f, fwd_ext_slip = 0.4f, fwd_ext_value = 1f,
+                                          fwd_asy_slip = 0.8f, fwd_asy_value = 0.5f, fwd_stiffness = 1f, long_slip_min_speed = 4f,
+                                          wheel_friction = 1, contact_yaw = 1, wheel_rolling = 1 };
         cfg.env_id_base = EnvIdBase; cfg.num_sections = L; cfg.num_walls = walls.Length;
         cfg.mcts_iterations = mctsIterations; cfg.mcts_initial_iterations = (mctsIterations * 5 + 2) / 3;
         cfg.mcts_latency_ticks = 45; cfg.mcts_initial_latency_ticks = 75; cfg.mcts_seed = 0x4D435453;

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define HK_ABI_VERSION 4
+#define HK_ABI_VERSION 5
 #define HK_MAX_AGENTS 8      /* the largest reference scene has 4; 5..8 agents per env is the synthetic extension of BASELINE configs[4] (start grid continued row by row) */
 #define HK_MAX_SECTIONS 64   /* Oval 24, Complex 41 */
 #define HK_NUM_SENSORS 9     /* MLAgent_Sensors.prefab */
@@ -78,6 +78,37 @@ typedef struct hk_reward_params {
     float ReversePenalty, SwervingPenalty, ReachGoalCheckpointRewardMultplier, ReachGoalCheckpointRewardBase;
     float TowardsCheckpointReward, SpeedReward, SlowMovingPenalty, AccelerationReward, NotAtGoalPenalty;
 } hk_reward_params;
+
+/* Engine restatement: what Unity / PhysX does between two FixedUpdates and the C# never spells out.  Every
+ * constant is read from the reference's prefabs / assets; `side_slope0` is the one fitted number.
+ *   rigid body   Rigidbody mass 250, free rotation (m_Constraints 0; BaseKartClassic.prefab:164-178); centre of mass = the
+ *                WheelColliders transform, kart-local (0, 0.12, 0) (AK:254, BaseKartClassic.prefab:203); inertia about y = that of the
+ *                capsule collider (r 0.45, h 2, axis z) at mass 250 = 74.7 kg m^2 (PhysX computes it from the shapes)
+ *   contacts     kart capsule: PhysicsMaterials/NoFriction (friction 0, bounciness 0); track MeshColliders: CarWheels (friction 0,
+ *                combine Minimum) -> frictionless, inelastic contacts; an off-centre contact impulse turns the body
+ *   wheels       four WheelColliders (BaseKartClassic.prefab:35-63,...): axles at kart-local z +0.586 / -0.681, sidewaysFriction
+ *                {extremum (0.2, 1), asymptote (0.5, 0.75), stiffness 1}; the front pair is steered by KartAnimation.FixedUpdate
+ *                (KartAnimation.cs:54-63): steerAngle = MoveTowards(smoothed, TurnInput, 10 dt) * maxSteeringAngle 30 */
+typedef struct hk_engine_params {
+    float mass, inertia_y, gravity;
+    float axle_zf, axle_zr;          /* front / rear axle, metres ahead of the centre of mass */
+    float max_steer_deg;             /* KartAnimation.maxSteeringAngle */
+    float steer_damping;             /* KartAnimation.steeringAnimationDamping (1 / s) */
+    float side_ext_slip, side_ext_value, side_asy_slip, side_asy_value, side_stiffness;   /* WheelCollider.sidewaysFriction */
+    float side_slope0;               /* FITTED: slope of the friction curve at zero slip, in units of ext_value / ext_slip (0 .. 3) */
+    float slip_min_speed;            /* m/s added to |longitudinal speed| in the slip ratio (PhysX vehicle tire model: 1) */
+    /* rolling: no script drives or brakes the wheels (motorTorque = brakeTorque = 0), so their spin follows the ground through the
+     * forwardFriction curve and is damped by wheelDampingRate; the force that keeps them turning is a drag on the body, and every change
+     * of the kart's speed has to spin 4 x 20 kg of wheel up or down */
+    float wheel_mass;                /* WheelCollider.mass 20 (moment of inertia m r^2 / 2) */
+    float wheel_radius_f, wheel_radius_r;   /* 0.1372984 / 0.1630791 */
+    float wheel_damping;             /* WheelCollider.wheelDampingRate 0.56 (kg m^2 / s) */
+    float fwd_ext_slip, fwd_ext_value, fwd_asy_slip, fwd_asy_value, fwd_stiffness;        /* WheelCollider.forwardFriction */
+    float long_slip_min_speed;       /* m/s added to |longitudinal speed| in the longitudinal slip ratio (PhysX minLongSlipDenominator: 4) */
+    int32_t wheel_friction;          /* 0: no tire forces (the model of ABI <= 4) */
+    int32_t contact_yaw;             /* 0: contacts change the linear velocity only (the model of ABI <= 4) */
+    int32_t wheel_rolling;           /* 0: no longitudinal tire forces */
+} hk_engine_params;
 
 typedef struct hk_config {
     int32_t abi_version;         /* HK_ABI_VERSION */
@@ -140,10 +171,12 @@ typedef struct hk_config {
     int32_t debug_taps;          /* bit 0: record the LQ debug taps read by hk_get_lq_debug (costs a few %).  The environment variable
                                   * HK_LQ_DEBUG=<bits>, read once by hk_create, ORs into this field (tests switch the taps on without
                                   * rebuilding their configs) */
+    hk_engine_params engine;     /* ABI 5 */
 } hk_config;
 
 #define HK_MCTS_MAX_DEPTH 8      /* gameParams.treeSearchDepth <= 8 */
-#define HK_MCTS_MAX_ACTIONS 20   /* 5 velocity buckets x 4 lanes (KartDiscreteGame.cs:333-347) */
+#define HK_MCTS_MAX_ACTIONS 36   /* velocity buckets x 4 lanes (KartDiscreteGame.cs:329-338: for (i = 6; i < 15; i += velocityBucketSize)): 5 x 4 at
+                                  * velocityBucketSize 2 (the MCTS-LQR agents of the Compete scenes), 9 x 4 at 1 (their MCTS-RL / Fixed-RL agents) */
 #define HK_MCTS_SECTIME_RING 8   /* sectionTimes entries kept per kart (sectionWindow <= 4) */
 #define HK_MCTS_MAX_ROOT_PHASES 3 /* searches one tree can receive (the reference: CyclesRootProcessed < 3); see hk_mcts_state.root_phases */
 
@@ -215,6 +248,8 @@ typedef struct hk_agent_state {
      * read them (Agent.SendInfo resets m_Reward / m_GroupReward the same way) */
     float step_reward;
     float group_reward;
+    float steer_smoothed;         /* KartAnimation.m_SmoothedSteeringInput (KartAnimation.cs:43,56): the front WheelColliders' steerAngle / 30 deg (ABI 5) */
+    float wheel_uf, wheel_ur;     /* rim speed (angular velocity x radius, m/s) of the front / rear WheelCollider pair (ABI 5) */
 } hk_agent_state;
 
 typedef struct hk_env_state {

@@ -843,6 +843,122 @@ static void arcade_kart_update(const hko_env* e, hk_agent_state* a, int rl_agent
     rot_y(turningPower * f_sign(localVelZ) * 25.0f * st->Grip * dt * DEG2RAD_F, &a->vx, &a->vz);   /* :466 */
 }
 
+/* ------------------------------------------------------------------ engine: KartAnimation steering + the WheelColliders' tire forces
+ * (hk.h hk_engine_params).  The reference never calls this: Unity does, between two FixedUpdates.
+ * Arithmetic contract (the kernels evaluate the same float expressions in the same order): divisions by configuration constants are
+ * multiplications by reciprocals formed once (hko_engine_derive); a friction curve is ONE cubic in Horner form on its piece. */
+static void curve_derive(hko_curve* c, float ext_slip, float ext_value, float asy_slip, float asy_value, float slope0)
+{   /* WheelFrictionCurve: Hermite pieces through (0, 0) [slope slope0 * ext_value / ext_slip], (ext_slip, ext_value) and (asy_slip, asy_value),
+     * flat at both knots and beyond.  Piece 1 in t = slip / ext_slip: E ((p - 2) t^3 + (3 - 2 p) t^2 + p t); piece 2 in
+     * t = (slip - ext_slip) / (asy_slip - ext_slip): E + (A - E) (3 t^2 - 2 t^3) */
+    c->ext = ext_slip; c->asy = asy_slip;
+    c->inv_ext = 1.0f / ext_slip; c->inv_span = 1.0f / (asy_slip - ext_slip);
+    c->a3 = ext_value * (slope0 - 2.0f); c->a2 = ext_value * (3.0f - 2.0f * slope0); c->a1 = ext_value * slope0;
+    c->b3 = -2.0f * (asy_value - ext_value); c->b2 = 3.0f * (asy_value - ext_value); c->b0 = ext_value;
+    c->flat = asy_value;
+}
+static inline float curve_eval(const hko_curve* c, float slip)
+{
+    const int in1 = slip <= c->ext;
+    const float t = in1 ? slip * c->inv_ext : (slip - c->ext) * c->inv_span;
+    const float c3 = in1 ? c->a3 : c->b3, c2 = in1 ? c->a2 : c->b2, c1 = in1 ? c->a1 : 0.0f, c0 = in1 ? 0.0f : c->b0;
+    const float v = ((c3 * t + c2) * t + c1) * t + c0;
+    return slip <= c->asy ? v : c->flat;
+}
+static void hko_engine_derive(const hk_config* cfg, hko_engine* E)
+{
+    const hk_engine_params* g = &cfg->engine;
+    memset(E, 0, sizeof(*E));
+    if (!(g->mass > 0.0f) || !(g->inertia_y > 0.0f)) return;
+    E->inv_m = 1.0f / g->mass; E->inv_i = 1.0f / g->inertia_y;
+    const float span = g->axle_zf - g->axle_zr;
+    if (!g->wheel_friction || !(span > 0.0f)) return;
+    const float load_f = (-g->axle_zr / span) * g->mass * g->gravity, load_r = (g->axle_zf / span) * g->mass * g->gravity;   /* static axle loads */
+    E->side_kf = g->side_stiffness * load_f * cfg->dt; E->side_kr = g->side_stiffness * load_r * cfg->dt;
+    E->jden_r = 1.0f / (E->inv_m + g->axle_zr * g->axle_zr * E->inv_i);
+    curve_derive(&E->side, g->side_ext_slip, g->side_ext_value, g->side_asy_slip, g->side_asy_value, g->side_slope0);
+    if (!g->wheel_rolling) return;
+    E->inv_mw = 1.0f / g->wheel_mass;
+    E->fwd_kf = g->fwd_stiffness * load_f * cfg->dt; E->fwd_kr = g->fwd_stiffness * load_r * cfg->dt;
+    E->inv_damp_f = 1.0f / (1.0f + cfg->dt * g->wheel_damping / (0.5f * g->wheel_mass * g->wheel_radius_f * g->wheel_radius_f));
+    E->inv_damp_r = 1.0f / (1.0f + cfg->dt * g->wheel_damping / (0.5f * g->wheel_mass * g->wheel_radius_r * g->wheel_radius_r));
+    E->jlden_r = 1.0f / (E->inv_mw + E->inv_m);
+    curve_derive(&E->fwd, g->fwd_ext_slip, g->fwd_ext_value, g->fwd_asy_slip, g->fwd_asy_value, g->side_slope0);
+}
+
+static void engine_wheels(const hko_env* e, hk_agent_state* a)
+{
+    const hk_engine_params* g = &e->cfg.engine;
+    const float dt = e->cfg.dt;
+    /* KartAnimation.cs:56: m_SmoothedSteeringInput = MoveTowards(., kartController.Input.TurnInput, steeringAnimationDamping * dt) */
+    {
+        const float turn = (a->flags & HK_F_ACTIVE) ? a->steering : 0.0f;
+        const float maxDelta = g->steer_damping * dt;
+        if (f_abs(turn - a->steer_smoothed) <= maxDelta) a->steer_smoothed = turn;
+        else a->steer_smoothed = a->steer_smoothed + f_sign(turn - a->steer_smoothed) * maxDelta;
+    }
+    if (!g->wheel_friction || !(a->flags & HK_F_CAN_MOVE)) return;
+    const hko_engine E = e->eng;                                       /* derived once in hko_create */
+    const float fx = hk_sinf(a->yaw), fz = hk_cosf(a->yaw);
+    const float rx = fz, rz = -fx;                                     /* right */
+    const float delta = a->steer_smoothed * g->max_steer_deg * DEG2RAD_F;   /* :59-63 steerAngle of both front wheels */
+    const float sd = hk_sinf(delta), cd = hk_cosf(delta);
+    float dvx = 0.0f, dvz = 0.0f, dw = 0.0f;
+    /* ---- front axle: wheels turned by delta about y (positive = to the right); an impulse along the wheels' right axis at the axle has
+     * the lever zf cos(delta) about y, one along their forward axis zf sin(delta) */
+    {
+        const float zk = g->axle_zf;
+        const float wfx = cd * fx + sd * rx, wfz = cd * fz + sd * rz;
+        const float wlx = cd * rx - sd * fx, wlz = cd * rz - sd * fz;
+        const float vkx = a->vx + a->wy * zk * rx, vkz = a->vz + a->wy * zk * rz;        /* v + omega x r, r = zk * forward */
+        const float vlong = vkx * wfx + vkz * wfz, vlat = vkx * wlx + vkz * wlz;
+        const float slip = f_abs(vlat) / (f_abs(vlong) + g->slip_min_speed);
+        float jn = curve_eval(&E.side, slip) * E.side_kf;
+        const float lev = zk * cd;
+        const float jmax = f_abs(vlat) / (E.inv_m + lev * lev * E.inv_i);                /* what stops the axle's sideways motion */
+        if (jn > jmax) jn = jmax;
+        if (vlat > 0.0f) jn = -jn;
+        dvx += wlx * (jn * E.inv_m); dvz += wlz * (jn * E.inv_m); dw += jn * lev * E.inv_i;
+        if (g->wheel_rolling) {
+            /* the pair's rim speed u against the ground speed along the wheel: slip = (u - v_long) / (|v_long| + 4), the longitudinal force
+             * forwardFriction(|slip|) * load on the body (forwards if the wheels turn faster), the opposite torque on the wheels, whose spin
+             * wheelDampingRate also slows (implicitly, as PhysX integrates it).  A pair = 2 wheels: in u = omega r, du/dt = -F / m_wheel - ... */
+            const float du = a->wheel_uf - vlong;
+            const float ls = du / (f_abs(vlong) + g->long_slip_min_speed);
+            float jl = curve_eval(&E.fwd, f_abs(ls)) * E.fwd_kf;
+            const float levl = zk * sd;
+            const float jlmax = f_abs(du) / (E.inv_mw + E.inv_m + levl * levl * E.inv_i);    /* what makes rim and ground speed equal */
+            if (jl > jlmax) jl = jlmax;
+            if (ls < 0.0f) jl = -jl;                                    /* wheels slower than the ground: the body is held back */
+            dvx += wfx * (jl * E.inv_m); dvz += wfz * (jl * E.inv_m); dw += jl * levl * E.inv_i;
+            a->wheel_uf = (a->wheel_uf - jl * E.inv_mw) * E.inv_damp_f;
+        }
+    }
+    /* ---- rear axle (not steered): levers zr and 0 */
+    {
+        const float zk = g->axle_zr;
+        const float vkx = a->vx + a->wy * zk * rx, vkz = a->vz + a->wy * zk * rz;
+        const float vlong = vkx * fx + vkz * fz, vlat = vkx * rx + vkz * rz;
+        const float slip = f_abs(vlat) / (f_abs(vlong) + g->slip_min_speed);
+        float jn = curve_eval(&E.side, slip) * E.side_kr;
+        const float jmax = f_abs(vlat) * E.jden_r;
+        if (jn > jmax) jn = jmax;
+        if (vlat > 0.0f) jn = -jn;
+        dvx += rx * (jn * E.inv_m); dvz += rz * (jn * E.inv_m); dw += jn * zk * E.inv_i;
+        if (g->wheel_rolling) {
+            const float du = a->wheel_ur - vlong;
+            const float ls = du / (f_abs(vlong) + g->long_slip_min_speed);
+            float jl = curve_eval(&E.fwd, f_abs(ls)) * E.fwd_kr;
+            const float jlmax = f_abs(du) * E.jlden_r;
+            if (jl > jlmax) jl = jlmax;
+            if (ls < 0.0f) jl = -jl;
+            dvx += fx * (jl * E.inv_m); dvz += fz * (jl * E.inv_m);
+            a->wheel_ur = (a->wheel_ur - jl * E.inv_mw) * E.inv_damp_r;
+        }
+    }
+    a->vx += dvx; a->vz += dvz; a->wy += dw;
+}
+
 /* ------------------------------------------------------------------ trigger callbacks: HKA.OnTriggerEnter :611-675 */
 static int calculate_lane(const hko_env* e, const hk_section* s, float px, float pz)
 {   /* DPT.CalculateLane :116-148 (3-D distances, first minimum wins) */
@@ -1047,6 +1163,13 @@ static void step_env(hko_env* e, int env)
     }
     /* (d) engine restatement --------------------------------------------------------------- */
     const float dt = cfg->dt;
+    /* KartAnimation.FixedUpdate (execution order 100: after ArcadeKart; KartAnimation.cs:54-63) steers the front WheelColliders,
+     * then the engine applies the four wheels' sideways friction as forces on the rigid body */
+    for (int i = 0; i < A; i++) {
+        hk_agent_state* a = &ags[i];
+        if (!(a->flags & HK_F_ENABLED)) continue;
+        engine_wheels(e, a);
+    }
     /* integrate (semi-implicit Euler; angular damping 1 - angularDrag*dt as PhysX applies it) */
     for (int i = 0; i < A; i++) {
         hk_agent_state* a = &ags[i];
@@ -1060,9 +1183,9 @@ static void step_env(hko_env* e, int env)
     }
     /* kart-kart contacts: every pair from ONE snapshot (Jacobi), corrections summed in partner order */
     {
-        float cpx[HK_MAX_AGENTS], cpz[HK_MAX_AGENTS], cvx[HK_MAX_AGENTS], cvz[HK_MAX_AGENTS];
+        float cpx[HK_MAX_AGENTS], cpz[HK_MAX_AGENTS], cvx[HK_MAX_AGENTS], cvz[HK_MAX_AGENTS], cwy[HK_MAX_AGENTS];
         int touched[HK_MAX_AGENTS];
-        for (int i = 0; i < A; i++) { cpx[i] = 0; cpz[i] = 0; cvx[i] = 0; cvz[i] = 0; touched[i] = 0; }
+        for (int i = 0; i < A; i++) { cpx[i] = 0; cpz[i] = 0; cvx[i] = 0; cvz[i] = 0; cwy[i] = 0; touched[i] = 0; }
         for (int i = 0; i < A; i++) {
             if (!(ags[i].flags & HK_F_ENABLED)) continue;
             float ax, az, bx, bz;
@@ -1086,8 +1209,24 @@ static void step_env(hko_env* e, int env)
                     /* a held (frozen) kart does not move: the free one takes the whole correction */
                     float share = (ags[j].flags & HK_F_CAN_MOVE) ? 0.5f : 1.0f;
                     cpx[i] += nx * (pen * share); cpz[i] += nz * (pen * share);
-                    float vrel = (ags[i].vx - ags[j].vx) * nx + (ags[i].vz - ags[j].vz) * nz;
-                    if (vrel < 0.0f) { cvx[i] -= nx * (vrel * share); cvz[i] -= nz * (vrel * share); }
+                    if (!cfg->engine.contact_yaw) {
+                        float vrel = (ags[i].vx - ags[j].vx) * nx + (ags[i].vz - ags[j].vz) * nz;
+                        if (vrel < 0.0f) { cvx[i] -= nx * (vrel * share); cvz[i] -= nz * (vrel * share); }
+                    } else {
+                        /* frictionless inelastic contact of two free rigid bodies at the surface points (c1 - R n on i, c2 + R n on j):
+                         * the impulse along n that stops the approach of the two points, acting off-centre on both */
+                        const float inv_m = 1.0f / cfg->engine.mass, inv_i = 1.0f / cfg->engine.inertia_y;
+                        const float rix = (c1x - nx * KART_CAP_R) - ags[i].px, riz = (c1z - nz * KART_CAP_R) - ags[i].pz;
+                        const float rjx = (c2x + nx * KART_CAP_R) - ags[j].px, rjz = (c2z + nz * KART_CAP_R) - ags[j].pz;
+                        const float ki = riz * nx - rix * nz, kj = rjz * nx - rjx * nz;
+                        float vrel = (ags[i].vx - ags[j].vx) * nx + (ags[i].vz - ags[j].vz) * nz + ags[i].wy * ki - ags[j].wy * kj;
+                        if (vrel < 0.0f) {
+                            float den = inv_m + ki * ki * inv_i;
+                            if (ags[j].flags & HK_F_CAN_MOVE) den = den + (inv_m + kj * kj * inv_i);
+                            const float jn = -vrel / den;
+                            cvx[i] += nx * (jn * inv_m); cvz[i] += nz * (jn * inv_m); cwy[i] += jn * ki * inv_i;
+                        }
+                    }
                     touched[i] = 1;
                 }
             }
@@ -1095,7 +1234,7 @@ static void step_env(hko_env* e, int env)
         for (int i = 0; i < A; i++) {
             hk_agent_state* a = &ags[i];
             if (!touched[i] || !(a->flags & HK_F_CAN_MOVE)) continue;
-            a->px += cpx[i]; a->pz += cpz[i]; a->vx += cvx[i]; a->vz += cvz[i];
+            a->px += cpx[i]; a->pz += cpz[i]; a->vx += cvx[i]; a->vz += cvz[i]; a->wy += cwy[i];
         }
         for (int i = 0; i < A; i++) if (touched[i]) ags[i].flags |= HK_F_HAS_COLLISION; else ags[i].flags &= ~HK_F_HAS_COLLISION;
     }
@@ -1106,7 +1245,7 @@ static void step_env(hko_env* e, int env)
         for (int pass = 0; pass < 2; pass++) {
             float ax, az, bx, bz;
             kart_core(a, a->px, a->pz, &ax, &az, &bx, &bz);
-            float bestpen = 0.0f, bnx = 0.0f, bnz = 0.0f;
+            float bestpen = 0.0f, bnx = 0.0f, bnz = 0.0f, bcx = 0.0f, bcz = 0.0f;
             int found = 0;
             for (int w = 0; w < e->NW; w++) {
                 const hk_wall_seg* ws = &e->walls[w];
@@ -1124,13 +1263,26 @@ static void step_env(hko_env* e, int env)
                         nx = -ez / el; nz = ex / el;
                         if ((a->px - ws->x0) * nx + (a->pz - ws->z0) * nz < 0.0f) { nx = -nx; nz = -nz; }
                     }
-                    if (!found || pen > bestpen) { found = 1; bestpen = pen; bnx = nx; bnz = nz; }
+                    if (!found || pen > bestpen) { found = 1; bestpen = pen; bnx = nx; bnz = nz; bcx = c1x; bcz = c1z; }
                 }
             }
             if (!found) break;
+            if (!cfg->engine.contact_yaw) {
+                float vn = a->vx * bnx + a->vz * bnz;
+                if (vn < 0.0f) { a->vx -= bnx * vn; a->vz -= bnz * vn; }
+            } else {
+                /* frictionless inelastic contact at the capsule's surface point c1 - R n (lever arm about the centre of mass = the
+                 * kart origin, taken before the push-out): the impulse stops the POINT's approach and turns the kart along the wall */
+                const float inv_m = 1.0f / cfg->engine.mass, inv_i = 1.0f / cfg->engine.inertia_y;
+                const float rx = (bcx - bnx * KART_CAP_R) - a->px, rz = (bcz - bnz * KART_CAP_R) - a->pz;
+                const float k = rz * bnx - rx * bnz;
+                const float vn = a->vx * bnx + a->vz * bnz + a->wy * k;
+                if (vn < 0.0f) {
+                    const float jn = -vn / (inv_m + k * k * inv_i);
+                    a->vx += bnx * (jn * inv_m); a->vz += bnz * (jn * inv_m); a->wy += jn * k * inv_i;
+                }
+            }
             a->px += bnx * bestpen; a->pz += bnz * bestpen;
-            float vn = a->vx * bnx + a->vz * bnz;
-            if (vn < 0.0f) { a->vx -= bnx * vn; a->vz -= bnz * vn; }
             a->flags |= HK_F_HAS_COLLISION;
             a->contact_nx = bnx; a->contact_nz = bnz;
         }
@@ -1195,6 +1347,7 @@ hko_env* hko_create(const hk_config* cfg)
         return NULL;
     hko_env* e = (hko_env*)calloc(1, sizeof(*e));
     e->cfg = *cfg;
+    hko_engine_derive(&e->cfg, &e->eng);
     e->E = cfg->num_envs; e->A = cfg->num_agents; e->L = cfg->num_sections; e->NW = cfg->num_walls;
     e->sec = (hk_section*)malloc(sizeof(hk_section) * e->L);
     memcpy(e->sec, cfg->sections, sizeof(hk_section) * e->L);

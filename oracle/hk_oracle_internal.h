@@ -14,8 +14,19 @@ typedef struct {
     float yaw_rad;
 } sec_pre;
 
+/* the engine restatement's derived constants (hk_oracle_env.c hko_engine_derive; the kernels: EngDerived, formed by the same expressions) */
+typedef struct { float inv_ext, inv_span, ext, asy, a3, a2, a1, b3, b2, b0, flat; } hko_curve;
+typedef struct {
+    float inv_m, inv_i, inv_mw;
+    float side_kf, side_kr, fwd_kf, fwd_kr;     /* stiffness * axle load * dt: the impulse of friction coefficient 1 in one tick */
+    float inv_damp_f, inv_damp_r;               /* 1 / (1 + dt * wheelDampingRate / (m_wheel r^2 / 2)) */
+    float jden_r, jlden_r;                      /* rear axle (not steered: levers zr and 0): 1 / (1/m + zr^2 / I),  1 / (1/m_wheel + 1/m) */
+    hko_curve side, fwd;
+} hko_engine;
+
 struct hko_env {
     hk_config cfg;
+    hko_engine eng;
     hk_section* sec;
     sec_pre* sp;
     hk_wall_seg* walls;

@@ -7,7 +7,8 @@ the hot path, in plain Python / numpy, written from the reference C# (not from o
                                         decode of the controls); AngleDifference :1339-1342; GenerateInput :1347-1366
   a1-a3 via oracle/lq_numpy.py          (its own independent mirror of KartLQR / LinearizedBicycle / LQRCheckpointReachAvoidCost)
   a6  ArcadeKart.UpdateStats / MoveVehicle  KartSystems/ArcadeKart.cs:295-302, 363-466, 503-547
-  engine, free motion only               DESIGN.md §4: w <- w (1 - angularDrag dt), yaw += w dt, p += v dt (no contact handling:
+  engine, free motion only               DESIGN.md §4: KartAnimation's front-wheel steering, the WheelColliders' sideways friction (hk_engine_params),
+                                        w <- w (1 - angularDrag dt), yaw += w dt, p += v dt (no contact handling:
                                         `near_contact` marks the karts this mirror does not predict)
 
 It exists so that tests/golden/step_mirror_fixtures.json is emitted by something the C oracle did NOT produce: the C oracle
@@ -402,11 +403,79 @@ class Mirror:
             rot = math.radians(turning_power * sign(local_z) * 25.0 * float(s.Grip) * dt)
             vx = nvx * math.cos(rot) + nvz * math.sin(rot)
             vz = -nvx * math.sin(rot) + nvz * math.cos(rot)
-        # engine, free motion
+        # engine.  KartAnimation.FixedUpdate (KartAnimation.cs:54-63, execution order 100) steers the front WheelColliders ...
+        g = self.c.engine
+        turn = turn_input if (int(a["flags"]) & 4) else 0.0                  # ArcadeKart.Input.TurnInput (zero inputs when inactive)
+        ss = float(a["steer_smoothed"])
+        step = float(g.steer_damping) * dt
+        ss = turn if abs(turn - ss) <= step else ss + sign(turn - ss) * step
+        # ... then the four WheelColliders' sideways friction acts on the rigid body (free rotation, centre of mass at the kart origin)
+        uf, ur = float(a["wheel_uf"]), float(a["wheel_ur"])
+        if g.wheel_friction and (int(a["flags"]) & 32):
+            vx, vz, wy, uf, ur = self.wheel_forces(fx, fz, vx, vz, wy, ss, uf, ur)
         wy = wy * (1.0 - float(s.AngularDrag) * dt)
         yaw = float(a["yaw"]) + wy * dt
         yaw = yaw % (2.0 * math.pi)
-        return {"px": float(a["px"]) + vx * dt, "pz": float(a["pz"]) + vz * dt, "yaw": yaw, "vx": vx, "vz": vz, "wy": wy, "acc_ang_v": acc_ang}
+        return {"px": float(a["px"]) + vx * dt, "pz": float(a["pz"]) + vz * dt, "yaw": yaw, "vx": vx, "vz": vz, "wy": wy, "acc_ang_v": acc_ang,
+                "steer_smoothed": ss, "wheel_uf": uf, "wheel_ur": ur}
+
+    def friction_mu(self, slip, which="side"):
+        """WheelFrictionCurve (sidewaysFriction / forwardFriction): Hermite pieces through (0, 0) [slope side_slope0 * value / slip], the
+        extremum and the asymptote point, flat at both and beyond"""
+        g = self.c.engine
+        es, ev, as_, av = (float(getattr(g, "%s_%s" % (which, k))) for k in ("ext_slip", "ext_value", "asy_slip", "asy_value"))
+        if slip <= es:
+            t = slip / es
+            return ev * ((t ** 3 - 2 * t * t + t) * float(g.side_slope0) + (3 * t * t - 2 * t ** 3))
+        if slip <= as_:
+            t = (slip - es) / (as_ - es)
+            return ev + (av - ev) * (3 * t * t - 2 * t ** 3)
+        return av
+
+    def wheel_forces(self, fx, fz, vx, vz, wy, steer_smoothed, uf, ur):
+        """one tick of tire forces, both axles from the same velocities.  Sideways: per axle the lateral impulse mu(slip) * load * dt against
+        the axle's sideways motion, capped at what stops that motion; slip = |v_lat| / (|v_long| + slip_min_speed).  Rolling (nothing
+        drives or brakes the wheels): the pair's rim speed u follows the ground speed through forwardFriction of the slip
+        (u - v_long) / (|v_long| + 4), the reaction acts on the body, and wheelDampingRate slows the spin (implicitly, as PhysX does)."""
+        g, dt = self.c.engine, self.dt
+        m, inertia = float(g.mass), float(g.inertia_y)
+        zf, zr = float(g.axle_zf), float(g.axle_zr)
+        rx, rz = fz, -fx                                                     # the kart's right
+        delta = math.radians(steer_smoothed * float(g.max_steer_deg))        # steerAngle of both front wheels
+        dvx = dvz = dw = 0.0
+        rim = [uf, ur]
+        for k, (zk, load, ang) in enumerate(((zf, -zr / (zf - zr), delta), (zr, zf / (zf - zr), 0.0))):
+            c, sn = math.cos(ang), math.sin(ang)
+            wf = (c * fx + sn * rx, c * fz + sn * rz)                        # wheel forward / wheel right, turned about +y
+            wl = (c * rx - sn * fx, c * rz - sn * fz)
+            px_, pz_ = zk * fx, zk * fz                                      # axle centre relative to the centre of mass
+            ax_v = (vx + wy * pz_, vz - wy * px_)                            # v + omega x r  (omega = (0, wy, 0))
+            v_long = ax_v[0] * wf[0] + ax_v[1] * wf[1]
+            v_lat = ax_v[0] * wl[0] + ax_v[1] * wl[1]
+            slip = abs(v_lat) / (abs(v_long) + float(g.slip_min_speed))
+            imp = self.friction_mu(slip) * float(g.side_stiffness) * load * m * float(g.gravity) * dt
+            lever = pz_ * wl[0] - px_ * wl[1]                                # (r x wl).y
+            imp = min(imp, abs(v_lat) / (1.0 / m + lever * lever / inertia))
+            if v_lat > 0.0:
+                imp = -imp
+            dvx += imp * wl[0] / m
+            dvz += imp * wl[1] / m
+            dw += imp * lever / inertia
+            if g.wheel_rolling:
+                mw = float(g.wheel_mass)
+                rad = float(g.wheel_radius_f if k == 0 else g.wheel_radius_r)
+                u = rim[k]
+                ls = (u - v_long) / (abs(v_long) + float(g.long_slip_min_speed))
+                jl = self.friction_mu(abs(ls), "fwd") * float(g.fwd_stiffness) * load * m * float(g.gravity) * dt
+                lev_l = pz_ * wf[0] - px_ * wf[1]                            # (r x wf).y
+                jl = min(jl, abs(u - v_long) / (1.0 / mw + 1.0 / m + lev_l * lev_l / inertia))
+                if ls < 0.0:
+                    jl = -jl
+                dvx += jl * wf[0] / m
+                dvz += jl * wf[1] / m
+                dw += jl * lev_l / inertia
+                rim[k] = (u - jl / mw) / (1.0 + dt * float(g.wheel_damping) / (0.5 * mw * rad * rad))
+        return vx + dvx, vz + dvz, wy + dw, rim[0], rim[1]
 
     def near_contact(self, ags, k, margin=0.25):
         """could kart k touch a wall or another kart during the tick?  (capsule r 0.45, core segment local z in [-0.657, 0.443])"""

@@ -64,7 +64,8 @@ class Setup:
             time_precision=[g["timePrecision"] for g in gp], section_window=[g["sectionWindow"] for g in gp],
             wiring=(team_of, [a["teamAgents"] for a in ag], [a["otherAgents"] for a in ag]),
             laps=e["laps"], max_episode_steps=e["maxEpisodeSteps"], max_lane_changes=e["MaxLaneChanges"], disable_on_end=e["disableOnEnd"],
-            jitter_seed=0, auto_reset=0, mcts_iterations=mcts_iterations, mcts_seed=0x4D435453 + seed)
+            jitter_seed=0, auto_reset=0, mcts_iterations=mcts_iterations, mcts_seed=0x4D435453 + seed, sensors=ag[0]["sensors"])
+        assert all(a["sensors"] == ag[0]["sensors"] for a in ag)     # one Sensors[] layout per scene (hk_config holds one)
         assert self.built.cfg.section_horizon == e["sectionHorizon"]
         # one attached policy per distinct (actor, stack, period): BehaviorParameters.m_Model / DecisionRequester of each RL agent
         groups = {}

@@ -15,7 +15,8 @@ sys.path.insert(0, ROOT)
 from hierarchicalkarting_amd import _lib  # noqa: E402
 
 PAIRS = [("hk_kart_stats", "HkKartStats", _lib.KartStats), ("hk_section", "HkSection", _lib.Section), ("hk_wall_seg", "HkWallSeg", _lib.WallSeg),
-         ("hk_reward_params", "HkRewardParams", _lib.RewardParams), ("hk_config", "HkConfig", _lib.Config),
+         ("hk_reward_params", "HkRewardParams", _lib.RewardParams), ("hk_engine_params", "HkEngineParams", _lib.EngineParams),
+         ("hk_config", "HkConfig", _lib.Config),
          ("hk_mcts_plan", "HkMctsPlan", _lib.MctsPlan), ("hk_mcts_state", "HkMctsState", _lib.MctsState),
          ("hk_agent_state", "HkAgentState", _lib.AgentState), ("hk_env_state", "HkEnvState", _lib.EnvState),
          ("hk_episode_result", "HkEpisodeResult", _lib.EpisodeResult), ("hk_lq_debug", "HkLqDebug", _lib.LqDebug),

@@ -58,7 +58,7 @@ def _pinned_bytes(st):
     """the 440 bytes per record the pin was taken over (px .. plan_vel); fields appended to hk_agent_state later
     (reward accumulators) stay out of it, so the pin keeps certifying the same trajectory"""
     raw = np.ascontiguousarray(st).view(np.uint8).reshape(st.shape + (st.dtype.itemsize,))
-    return np.ascontiguousarray(raw[..., :440]).tobytes()
+    return np.ascontiguousarray(np.concatenate([raw[..., :440], raw[..., 448:460]], axis=-1)).tobytes()    # ... and the engine's wheel state (ABI 5)
 
 
 def test_trajectory_hash_matches_the_committed_pin():

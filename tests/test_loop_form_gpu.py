@@ -66,7 +66,7 @@ def test_parity_does_not_depend_on_the_loop_form(variant):
     store — in the join block of a divergent branch, ahead of the instruction that restores EXEC, so that the lanes of the other side
     reload a stale value (in the chain form of the current sources: m_FinalStats.Steer of the Training-mode
     instantiation, four ticks old, for the karts faster than 5 m/s).  tools/check_spill_exec.py finds such stores in the listing; the
-    product build refuses to ship one (__graft_entry__._check_codegen).  Here: a build the guard calls clean must be bit-identical to the
+    product build recompiles a flagged unit with the next of its result-neutral variants and refuses to ship one no variant cleans (__graft_entry__.build).  Here: a build the guard calls clean must be bit-identical to the
     oracle; a variant it flags may fail — and a variant that fails must have been flagged (no unexplained difference)."""
     import json
     env = dict(os.environ)
@@ -79,7 +79,8 @@ def test_parity_does_not_depend_on_the_loop_form(variant):
         flagged = json.load(open(LIB[:-3] + ".guard.json"))["spill_stores_ahead_of_exec_restore"]
     else:
         env.pop("HK_LIB_PATH", None)
-        assert os.path.exists(os.path.join(ROOT, "build", "obj", "codegen_guard.ok")), "the product library was built without its code-generation guard"
+        rec = json.load(open(os.path.join(ROOT, "build", "obj", "codegen_guard.json")))       # written by __graft_entry__.build()
+        assert rec and all(not v["findings"] for v in rec.values()), "the product library was built without a clean code-generation guard: %s" % rec
     r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, ROOT, lib)], env=env, capture_output=True, text=True, timeout=900)
     ok = r.returncode == 0 and "loop form ok" in r.stdout
     if flagged:

@@ -185,8 +185,9 @@ def test_observation_layout():
     o2.reset(experiment_num=0)
     o2.step(10)
     r = o2.observations()[0][:, -9:]
-    assert abs(r[0][3] - (2.5 - 0.4425)) < 5e-3 and abs(r[0][6] - (14.62 - 11.28)) < 5e-3
-    assert abs(r[1][6] - (2.5 - 0.4425)) < 5e-3 and abs(r[1][3] - (20.48 - 17.12)) < 5e-3
+    # (Sensors[] in the scenes' order: index 4 = +90 degrees, index 8 = -90 degrees)
+    assert abs(r[0][4] - (2.5 - 0.4425)) < 5e-3 and abs(r[0][8] - (14.62 - 11.28)) < 5e-3
+    assert abs(r[1][8] - (2.5 - 0.4425)) < 5e-3 and abs(r[1][4] - (20.48 - 17.12)) < 5e-3
     assert r[0][0] == 20.0                                            # nothing ahead within RayDistance
 
 
@@ -194,7 +195,7 @@ def _pinned_bytes(st):
     """the 440 bytes per record the pin was taken over (px .. plan_vel); fields appended to hk_agent_state later
     (reward accumulators) stay out of it, so the pin keeps certifying the same trajectory"""
     raw = np.ascontiguousarray(st).view(np.uint8).reshape(st.shape + (st.dtype.itemsize,))
-    return np.ascontiguousarray(raw[..., :440]).tobytes()
+    return np.ascontiguousarray(np.concatenate([raw[..., :440], raw[..., 448:460]], axis=-1)).tobytes()    # ... and the engine's wheel state (ABI 5)
 
 
 def test_trajectory_hash_pin():

@@ -60,11 +60,14 @@ def test_rl_vs_lq_episode_tick_by_tick():
     g, o = _pair(6, 2, [_lib.HK_LOW_RL, _lib.HK_LOW_LQR], jitter_seed=21)
     pol = Policy.random(g.obs_dim * 4, 128, 3, seed=5)
     g.attach_policy(pol, [0], 2); o.attach_policy(pol, [0], 2)
+    seen = set()
     for t in range(1, 241):
         g.step(1); o.step(1)
         _cmp_agents(g, o, t)
-    s, br = g.get_actions()
-    assert len(np.unique(s[:, 0])) > 1 and (s[:, 1] == 0).all()
+        s, br = g.get_actions()
+        seen.update(np.unique(s[:, 0]).tolist())
+        assert (s[:, 1] == 0).all()                      # nothing latches an action for the LQ agent
+    assert len(seen) > 6                                 # the actor's (sampled) steering varied over the episode and the envs
 
 
 def test_two_team_policies_with_timeout_resets():

@@ -23,6 +23,8 @@ def main():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     units = list(ge.UNITS) if "--all" in head else [unit]       # --all: every unit with the flags (constants the host code shares with the kernels)
     objs, procs, listings = [], [], []
+    import json
+    record = json.load(open(os.path.join(ge.OBJ_DIR, "codegen_guard.json")))      # the product's units may carry a guard variant's flags: an A/B keeps them
     for u in ge.UNITS:
         if u not in units:
             objs.append(os.path.join(ge.OBJ_DIR, u.replace(".hip", ".o")))
@@ -30,13 +32,13 @@ def main():
         o = os.path.join(ge.OBJ_DIR, "%s_%s.o" % (name, u.replace(".hip", "")))
         objs.append(o)
         listings.append(o[:-2] + ".s")
-        procs.append(subprocess.Popen([hipcc] + ge.HIPCC_FLAGS + defs + ["-c", os.path.join(ge.CSRC, u), "-o", o]))
-        procs.append(subprocess.Popen([hipcc] + ge.HIPCC_FLAGS + defs + ["--cuda-device-only", "-S", os.path.join(ge.CSRC, u), "-o", o[:-2] + ".s"], stderr=subprocess.DEVNULL))
+        base = ge.HIPCC_FLAGS + record.get(u, {}).get("flags", [])
+        procs.append(subprocess.Popen([hipcc] + base + defs + ["-c", os.path.join(ge.CSRC, u), "-o", o]))
+        procs.append(subprocess.Popen([hipcc] + base + defs + ["--cuda-device-only", "-S", os.path.join(ge.CSRC, u), "-o", o[:-2] + ".s"], stderr=subprocess.DEVNULL))
     assert all(p.wait() == 0 for p in procs)
     lib = os.path.join(ROOT, "build", "libhk_%s.so" % name)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib] + objs)
     # the code-generation guard (tools/check_spill_exec.py): a variant may be AFFECTED — it is an experiment, not the product — and says so
-    import json
     import check_spill_exec as guard
     bad = []
     for lst in listings:

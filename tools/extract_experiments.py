@@ -140,6 +140,7 @@ class SceneExperiments:
         for k in list(agent_doc):
             if k in keep or k.lower().endswith(("reward", "penalty", "divider")):
                 out[k] = agent_doc[k]
+        out["sensors"] = self.sensors(agent_doc.get("Sensors") or [], src["guid"])
         _, bp = self.component_of_instance(inst, prefab_guid, GUID_BP)
         if bp:
             model = bp.get("m_Model") or {}
@@ -159,6 +160,35 @@ class SceneExperiments:
         # the chained-XOR id, so its overrides are recognised by their property path instead
         out["baseStats_overrides"] = {m["propertyPath"][len("baseStats."):]: num(m["value"])
                                       for m in inst["m_Modification"]["m_Modifications"] if m["propertyPath"].startswith("baseStats.")}
+        return out
+
+    def sensors(self, sens, agent_prefab_guid):
+        """KartAgent.Sensors[] (KA:20-26) as the SCENE holds them: each entry's Transform is a reference — the agent prefab's own, or a
+        scene override (the Compete scenes re-point the entries: their order is NOT the prefab's) — to a child of the nested
+        MLAgent_Sensors prefab; its local Y rotation is the ray's yaw."""
+        import math
+        pf = uy.load(self.guid[agent_prefab_guid])
+        out = []
+        for s in sens:
+            s = s or {}
+            ref = s.get("Transform") or {}
+            fid = ref.get("fileID", 0)
+            ent = self.scene.docs.get(fid)
+            if ent and ent[1] and isinstance(ent[3], dict):          # a stripped Transform of the scene -> its id in the agent prefab
+                fid = ent[3]["m_CorrespondingSourceObject"]["fileID"]
+            yaw = None
+            pent = pf.docs.get(fid)
+            if pent and pent[1] and isinstance(pent[3], dict):       # stripped in the agent prefab -> the MLAgent_Sensors prefab's Transform
+                so = pent[3]["m_CorrespondingSourceObject"]
+                sp = uy.load(self.guid[so["guid"]])
+                t = sp.docs.get(so["fileID"])
+                if t and isinstance(t[3], dict):
+                    q = t[3]["m_LocalRotation"]
+                    x, y, z, w = (float(q[k]) for k in "xyzw")
+                    yaw = round(math.degrees(math.atan2(2 * (x * z + w * y), 1 - 2 * (x * x + y * y))), 4)
+            out.append({"yaw_deg": yaw, "RayDistance": num(s.get("RayDistance")),
+                        "WallHitValidationDistance": num(s.get("WallHitValidationDistance")),
+                        "AgentHitValidationDistance": num(s.get("AgentHitValidationDistance"))})
         return out
 
     def envs(self):
@@ -206,6 +236,7 @@ def main():
             e.get("MaxLaneChanges"), e.get("mode"), e["n_sections"], e.get("sectionHorizon")))
         for i, ag in enumerate(e["agents"]):
             b = ag.get("behavior") or {}
+            print("        sensors yaw %s ray %s wall %s agent %s" % tuple([x.get(k) for x in ag.get("sensors", [])] for k in ("yaw_deg", "RayDistance", "WallHitValidationDistance", "AgentHitValidationDistance")))
             print("    [%d] %-14s %-26s high=%s low=%s H=%s depth=%s team=%s others=%s model=%s obs=%sx%s teamId=%s" % (
                 i, ag.get("name"), ag.get("script"), HIGH.get(ag.get("HighMode"), ag.get("HighMode")), LOW.get(ag.get("LowMode"), ag.get("LowMode")),
                 ag.get("sectionHorizon"), (ag.get("gameParams") or {}).get("treeSearchDepth"), ag.get("teamAgents"), ag.get("otherAgents"),
