@@ -101,6 +101,7 @@ struct Tuning {
     bool keep_last_solve = false; // HK_KEEP_LAST_SOLVE=1: the last round of a fixed-round call launches its (empty) solver kernel, as before
     bool tail_worst_case = false; // HK_TAIL_WORST_CASE=1: the laggards' batches issue a round per cadence of the slowest env (the older schedule)
     int lazy_min_ticks = HK_LAZY_MIN_TICKS;    // HK_LAZY_MIN_TICKS: calls at least this long complete lazily (a look at the device instead of the worst-case rounds)
+    bool fission = true;         // plain 3- / 4-agent handles run the tick kernel without phase B1 + env_b1_kernel per solve cadence (hk_env_run.h); HK_FISSION=0: the fused kernel
     int debug_max_rounds = 0;    // HK_DEBUG_MAX_ROUNDS (diagnostic): cap on the rounds of a call, to look at the state in between
     bool debug_no_check = false; // HK_DEBUG_NO_CHECK (diagnostic): getters do not fail on the "did not complete" flag
     bool stamps_dump = false;    // HK_STAMPS_DUMP (diagnostic builds, -DHK_STAMPS)
@@ -116,6 +117,7 @@ struct Tuning {
         lazy_min_ticks = num("HK_LAZY_MIN_TICKS", HK_LAZY_MIN_TICKS, 1, 1 << 20);
         debug_max_rounds = num("HK_DEBUG_MAX_ROUNDS", 0, 0, 1 << 20);
         debug_no_check = flag("HK_DEBUG_NO_CHECK"); stamps_dump = flag("HK_STAMPS_DUMP");
+        { const char* f = std::getenv("HK_FISSION"); fission = !(f && std::atoi(f) == 0); }
     }
 };
 
@@ -576,7 +578,11 @@ static int step_ticks(hk_handle h, int n_ticks)
     const bool plain = !planner && h->n_policies == 0;
     // (planner / actor handles keep their deadline arithmetic as it was; the 8-lane groups run the older loop without it)
     h->dev.P.eager = (eager && plain && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4) ? 1 : 0;
-    const int run_cap = (lazy && h->cfg.num_agents > 2 && h->dev.ticks_since_reset >= hk::BULK_TICKS) ? spread_cap
+    // FISSION: every env parks at every solve tick, so a round retires exactly one cadence
+    bool shaped = h->cfg.rewards != 0 || h->cfg.env_mode == HK_MODE_TRAINING;       // reward shaping / Training mode: their own instantiations of the fused kernel
+    for (int i = 0; i < h->cfg.num_agents; i++) shaped = shaped || h->cfg.training_agent[i] != 0;
+    h->dev.fission = h->tune.fission && plain && !shaped && h->dev.P.eager && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4;
+    const int run_cap = h->dev.fission ? 4 : (lazy && h->cfg.num_agents > 2 && h->dev.ticks_since_reset >= hk::BULK_TICKS) ? spread_cap
                         : (!lazy && plain && h->dev.P.eager) ? short_cap : hk::RUN_CAP;
     h->dev.P.run_cap = run_cap;
     // two halves on two streams (issue_rounds_split): the default for the long calls of plain handles since round 4 (1 472 vs 1 392 M

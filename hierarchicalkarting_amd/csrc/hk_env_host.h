@@ -54,6 +54,7 @@ struct EnvDevice {
     SecGeo* sec_geo = nullptr;
     // lane-group -> env assignment of the tick kernel, regrouped by solve phase every REGROUP_ROUNDS rounds (hk_env_run.h)
     int* perm = nullptr;           // [E]
+    bool fission = false;          // the current call runs the tick kernel without phase B1 + env_b1_kernel (hk_env_run.h FISSION; hk_api.hip step_ticks)
     int arm_ticks = 0;             // > 0: the next tick launch adds these ticks to every env's count (a fixed-round call arms itself)
     bool last_solve_skippable = false;   // fixed-round call of a plain handle: no env can park in its last round, so that round queues no game (launch_lqn)
     int guard_rounds_left = 0;     // > 0: fixed-round call; the tick launch that brings it to 0 flags the envs that are not done (the guard)

@@ -99,6 +99,24 @@ inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
 #define HK_RUN(MC, RWF, TRN) do { if (d.tab_lds) HK_RUN_T(MC, RWF, TRN, true); else HK_RUN_T(MC, RWF, TRN, false); } while (0)
     bool train = d.P.training_reset != 0;
     for (int i = 0; i < cfg.num_agents; i++) train = train || d.P.training_agent[i] != 0;
+#if HK_GA == 4
+    if (d.fission && !train && !d.mcts.st && !d.rw.sec_time) {
+        // FISSION (hk_env_run.h): the tick kernel without phase B1, then phase B1 of every env it parked at its solve tick
+        const GameSoA G{d.games, (size_t)cfg.num_envs * cfg.num_agents};
+        const unsigned blocks = (unsigned)((threads + 255) / 256);
+        if (d.tab_lds) {
+            hipLaunchKernelGGL((env_run_kernel<false, false, false, true, true>), dim3(blocks), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs, d.results, G, d.queue_cnt,
+                               d.queue, d.round, d.act_steer, d.act_branch, d.lq_debug, d.status, d.mcts, d.mset, d.rw, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase, arm, guard);
+            hipLaunchKernelGGL((env_b1_kernel<true>), dim3(blocks), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs, G, d.queue_cnt, d.queue, d.round, d.lq_debug, d.status,
+                               d.mcts, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase);
+        } else {
+            hipLaunchKernelGGL((env_run_kernel<false, false, false, false, true>), dim3(blocks), dim3(256), 0, stream, d.P, d.agents, d.envs, d.results, G, d.queue_cnt,
+                               d.queue, d.round, d.act_steer, d.act_branch, d.lq_debug, d.status, d.mcts, d.mset, d.rw, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase, arm, guard);
+            hipLaunchKernelGGL((env_b1_kernel<false>), dim3(blocks), dim3(256), 0, stream, d.P, d.agents, d.envs, G, d.queue_cnt, d.queue, d.round, d.lq_debug, d.status,
+                               d.mcts, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase);
+        }
+    } else
+#endif
     if (train) HK_RUN(true, true, true);
     else if (d.mcts.st) { if (d.rw.sec_time) HK_RUN(true, true, false); else HK_RUN(true, false, false); }
     else { if (d.rw.sec_time) HK_RUN(false, true, false); else HK_RUN(false, false, false); }

@@ -116,11 +116,20 @@ __global__ __launch_bounds__(256) void env_regroup_scatter_kernel(const hk_env_s
 // <false, false, false> is the headline path: the planner hooks (request / consume / beliefs), reward shaping and the
 // Training-mode code compile away entirely.  Instantiated: every (HAS_MCTS, HAS_RW) pair without Training code, and
 // <true, true, true> for any handle that uses Training mode (its planner / reward parts are also guarded at run time).
-template <bool HAS_MCTS, bool HAS_RW, bool HAS_TRAIN, bool TAB_LDS>
+// FISSION (round 4): the tick kernel WITHOUT phase B1.  An env that reaches a solve tick parks there (phase 2) after its phase A;
+// env_b1_kernel — the next launch on the stream — runs the sensor rays, the assembly and the single-player solves for every parked env
+// at once (phase 2 -> 1; multi-player games go to the queues as before), then the solver launch, and the next tick launch resumes the
+// envs at phase C.  What it buys: the fused body's register peak is phase B1 (the 4 x 4 Riccati recursion in fp64) ON TOP of the
+// per-tick state; without it the tick loop fits its registers and runs more waves per SIMD.  What it costs: a launch per solve
+// cadence (4 ticks) instead of per RUN_CAP_SPREAD (12), and the kart records travel through HBM in between.
 #ifndef HK_RUN_OCC
 #define HK_RUN_OCC 2
 #endif
-__global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
+#ifndef HK_FIS_OCC
+#define HK_FIS_OCC 2
+#endif
+template <bool HAS_MCTS, bool HAS_RW, bool HAS_TRAIN, bool TAB_LDS, bool FISSION = false>
+__global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_run_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
                                                       hk_episode_result* results, GameSoA games, int* queue_cnt_all,
                                                       int* queue_all, int round, const float* act_steer, const int* act_branch,
                                                       hk_lq_debug* dbg_out, int* status, MctsDev Marg, int mset, RwDev RD, const int* perm,
@@ -160,6 +169,7 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
     const LaneCfg LC = lane_cfg(P, i);                   // this lane's agent: modes and player list, read once
     int left = es.reserved[0];
     int phase = es.reserved[1] & ENV_PHASE_MASK;         // 0: at a tick boundary; 1: phases A / B1 of a tick done, waiting for (or holding) its controls
+    if (FISSION && phase == 2) phase = 0, left = 0;      // (cannot happen: env_b1_kernel runs between two tick launches; such an env would trip the guard)
     bool pack = (es.reserved[1] & ENV_PACK_HINT) != 0;   // did the env's last solve tick queue a multi-player game (regroup_key)
     bool dirty = false;
     Hot h;
@@ -196,6 +206,7 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
         int qn = 0;                  // player count of the multi-player game this ego assembled on this tick (0: none)
         bool began = false;          // this env ran phases A / B1 in this iteration (it was at a tick boundary and not parked)
         bool solved = false;         // ... and the tick was a solve tick
+        bool b1_pending = false;     // FISSION: ... whose phase B1 is left to env_b1_kernel
         bool moving = go;            // this env runs phase C in this iteration
         HK_LP(23);                   // every lane of a wave that is still in the loop
         if (go) {
@@ -213,7 +224,8 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
                     const bool act = (es.episode_steps & cmask) == 0 &&                                    // HKA:317 (Q9): episodeSteps % cadence
                                      !(!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u)) &&
                                      !(P.hold_dedupe && es.episode_steps > cadence && es.episode_steps < P.hold);
-                    qn = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
+                    if constexpr (FISSION) b1_pending = act;
+                    else qn = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
                     began = true;
                     solved = act;
                 } else {
@@ -225,19 +237,22 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
         if (began) {
             HK_LP(22);
             // bin the games for the solver kernels by player count, one atomic per wave and count
+            if constexpr (!FISSION) {
 #pragma unroll
-            for (int n = 2; n <= GA; n++) {
-                const int pos = wave_agg_inc(&queue_cnt[n], qn == n);
-                if (qn == n) queue[(size_t)(n - 2) * P.E * P.A + pos] = env * P.A + i;
+                for (int n = 2; n <= GA; n++) {
+                    const int pos = wave_agg_inc(&queue_cnt[n], qn == n);
+                    if (qn == n) queue[(size_t)(n - 2) * P.E * P.A + pos] = env * P.A + i;
+                }
             }
             if (M.st) phase_plan(P, M, mset, env, i, es, h.flags, h.section_index, h.lane, h.lane_changes, h.final_steer, arec);
             // requests are posted on replan ticks (phase_plan) and on the reset tick (phase_begin): look again after those
             if (HAS_MCTS && P.mcts_pause && es.episode_steps % 100 == 0) held = group_or(mcts_search_outstanding(P, M, env, i) ? 1 : 0) != 0;
             HK_ST(h, 6);           // [6] queue binning (+ planner hooks)
             // does any ego of this env wait for a queued multi-player solve?  (or was this the assembly at the end of the budget)
-            const bool queued = group_or(qn ? 1 : 0) != 0;
-            if (solved) pack = queued;
+            const bool queued = FISSION ? false : group_or(qn ? 1 : 0) != 0;
+            if (!FISSION && solved) pack = queued;
             if (queued || eager_it) { phase = 1; moving = false; go = false; }
+            if (FISSION && b1_pending) { phase = 2; moving = false; go = false; }      // (quad-uniform: act depends on the env words only)
         }
         if (moving) {
             phase_move<HAS_RW, HAS_TRAIN>(P, T, env, i, env_ok, es, h, hfx, hfz, agents, act_steer, act_branch, M.st, RD, rwv, LC.low_mode, LC.high_mode);
@@ -281,6 +296,53 @@ __global__ __launch_bounds__(256, HK_RUN_OCC) void env_run_kernel(EnvParams P, h
     }
     if ((threadIdx.x & 63) == 0) atomicAdd(&stats[16 + HK_NSTAMP], 1ull);     // waves that entered the loop
 #endif
+}
+
+// FISSION, part 2: phase B1 of the solve tick for every env the tick launch parked there (phase 2).  Same lane groups, same device
+// functions (phase_assemble: sensor rays through the LDS wall grid, players within 8 m, assembly, lq1_solve in the ego's lane, multi-player
+// games to GameSoA + queues); of the kart record only what B1 reads is loaded and only what it decodes (flags, steering) is stored.
+template <bool TAB_LDS>
+__global__ __launch_bounds__(256, 2) void env_b1_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs, GameSoA games, int* queue_cnt_all,
+                                                        int* queue_all, int round, hk_lq_debug* dbg_out, int* status, MctsDev M, const int* perm,
+                                                        unsigned long long* stats, int slot0, int slot1, int qbase)
+{
+#ifdef HK_LANEPROF
+    hk_lp_ptr = stats;
+#endif
+    (void)stats;
+    __shared__ KartS ks[256];
+    HK_DYN_SHARED(smem);
+    const int gid = slot0 * GA + blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = gid / GA, i = gid % GA;
+    const bool env_ok = slot < slot1;
+    const int env = (perm && env_ok) ? perm[slot] : slot;
+    const int set = qbase + (round & 1);
+    int* queue_cnt = queue_cnt_all + set * 16;
+    int* queue = queue_all + (size_t)set * (GA - 1) * P.E * P.A;
+    hk_env_state es;
+    if (env_ok) es = envs[env];
+    else { es.episode_steps = 0; es.inactive_mask = 0; es.experiment_num = 0; es.episodes_done = 0; es.status = 0; es.initial_started = 0; es.reserved[0] = 0; es.reserved[1] = 0; }
+    const bool pend = env_ok && (es.reserved[1] & ENV_PHASE_MASK) == 2;
+    if (__syncthreads_or(pend ? 1 : 0) == 0) return;
+    const TabView T = tab_stage<TAB_LDS>(P, smem);
+    const LaneCfg LC = lane_cfg(P, i);
+    hk_agent_state* arec = (pend && i < P.A) ? &agents[(size_t)env * P.A + i] : nullptr;
+    Hot h = {};
+    if (arec) {
+        h.px = arec->px; h.pz = arec->pz; h.yaw = arec->yaw; h.vx = arec->vx; h.vz = arec->vz; h.wy = arec->wy;
+        h.final_steer = arec->final_steer; h.section_index = arec->section_index; h.flags = arec->flags; h.steering = arec->steering;
+    }
+    float hfx, hfz;
+    hk_sincosf(h.yaw, &hfx, &hfz);
+    const int qn = phase_assemble(P, T, ks, env, i, pend, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
+#pragma unroll
+    for (int n = 2; n <= GA; n++) {
+        const int pos = wave_agg_inc(&queue_cnt[n], qn == n);
+        if (qn == n) queue[(size_t)(n - 2) * P.E * P.A + pos] = env * P.A + i;
+    }
+    const bool queued = group_or(qn ? 1 : 0) != 0;
+    if (arec) { arec->flags = h.flags; arec->steering = h.steering; }
+    if (pend && i == 0) envs[env].reserved[1] = 1 | (queued ? ENV_PACK_HINT : 0);
 }
 
 } }  // namespace hk::HK_GA_NS

@@ -536,6 +536,9 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
 #pragma unroll 1
             for (int sm = 0; sm < ns; sm++) {
                 const float sd = 2.0f * (float)sm;
+                // every hit up to 2 (sm - 1) + 1 m lies within 1 m of one of the samples walked so far, i.e. in their near lists: a hit that
+                // close is final (the walls a later sample adds can only be hit further out)
+                if (best <= sd - 1.0f) break;
                 const int cell = grid_cell(P, ox + d0x * sd, oz + d0z * sd);
                 if (cell == prev) continue;
                 prev = cell;

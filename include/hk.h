@@ -322,7 +322,8 @@ int hk_set_actions(hk_handle h, const float* steer, const int32_t* branch);
  * hk_reset), and the unfinished envs keep their leftover ticks, which the next hk_step runs first.  A zero pivot in an LQ solve is
  * sticky in the same way (status bit 0) but does not fail the getters: the reference throws nothing there either (MathNet returns
  * inf / NaN), and hk_env_state.status bit 0 flags the karts whose state went non-finite.
- * Scheduling switches, read from the environment ONCE in hk_create (none changes a result bit): HK_NO_EAGER, HK_FIXED_ROUNDS,
+ * Scheduling switches, read from the environment ONCE in hk_create (none changes a result bit): HK_FISSION (0: the fused tick kernel instead of
+ * the tick kernel without phase B1 + env_b1_kernel per solve cadence), HK_NO_EAGER, HK_FIXED_ROUNDS,
  * HK_MCTS_NO_PAUSE, HK_SPLIT / HK_NO_SPLIT, HK_RUN_CAP_SPREAD, HK_RUN_CAP_SHORT, HK_LAZY_MIN_TICKS, HK_TAIL_WORST_CASE, HK_KEEP_LAST_SOLVE, HK_REGROUP_ROUNDS, HK_MCTS_PERSIST_GB,
  * HK_NO_HOLD_DEDUPE, HK_LQ_DEBUG, HK_TAB_GLOBAL (track tables read from global memory, as for tracks that exceed the LDS budget);
  * diagnostics HK_DEBUG_MAX_ROUNDS, HK_DEBUG_NO_CHECK, HK_STAMPS_DUMP.

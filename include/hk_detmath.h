@@ -237,13 +237,129 @@ HK_HD double hk_log(double x)
     return fe * LN2_HI + (l + fe * LN2_LO);
 }
 
-/* Mathf.* = libm in double, result rounded to float (Q8) */
-HK_HD float hk_sinf(float x) { return (float)hk_sin((double)x); }
-HK_HD float hk_cosf(float x) { return (float)hk_cos((double)x); }
-HK_HD void hk_sincosf(float x, float* s, float* c) { double ds, dc; hk_sincos((double)x, &ds, &dc); *s = (float)ds; *c = (float)dc; }
-HK_HD void hk_sincosf_near0(float x, float* s, float* c) { double ds, dc; hk_sincos_near0((double)x, &ds, &dc); *s = (float)ds; *c = (float)dc; }
-HK_HD float hk_atan2f(float y, float x) { return (float)hk_atan2((double)y, (double)x); }
-HK_HD float hk_expf(float x) { return (float)hk_exp((double)x); }
+/* ---- Mathf.* = libm in double, result ROUNDED TO FLOAT (Q8).
+ * The float callers (the per-tick physics: four sine / cosine pairs and an exponential per kart and tick) do not need the last 29 bits of
+ * the double: these kernels evaluate in double to <= 2^-44 relative (truncated series on the reduced argument, every step ONE explicit
+ * fused multiply-add: exact IEEE, the same bits from gcc and hipcc) and round once.  The result is the correctly rounded float — what
+ * (float)Math.Sin((double)x) gives for any libm — except where the true value lies within 2^-44 of a rounding boundary (a fraction of
+ * ~1e-6 of the arguments: there it is the neighbouring float).  tests/test_detmath.py bounds both against mpmath.  The double entry points
+ * above (Math.Sin / Math.Cos / Math.Atan2 of KartLQRDynamics.cs and HKA.AngleDifference) keep their full <= 2 ulp kernels. */
+#define HK_FMA(a, b, c) __builtin_fma((a), (b), (c))
+HK_HD double hk__ksin_f(double r)       /* |r| <= pi/4 (+ rounding): r - r^3/3! + ... - r^15/15!, remainder < 2^-52 r */
+{
+    const double z = r * r;
+    double p = -7.6471637318198164e-13;                 /* -1/15! */
+    p = HK_FMA(p, z, 1.6059043836821613e-10);           /*  1/13! */
+    p = HK_FMA(p, z, -2.505210838544172e-08);           /* -1/11! */
+    p = HK_FMA(p, z, 2.7557319223985893e-06);           /*  1/9!  */
+    p = HK_FMA(p, z, -0.00019841269841269841);          /* -1/7!  */
+    p = HK_FMA(p, z, 0.0083333333333333332);            /*  1/5!  */
+    p = HK_FMA(p, z, -0.16666666666666666);             /* -1/3!  */
+    return HK_FMA(r * z, p, r);
+}
+HK_HD double hk__kcos_f(double r)       /* 1 - r^2/2! + ... + r^16/16! */
+{
+    const double z = r * r;
+    double p = 4.7794773323873853e-14;                  /*  1/16! */
+    p = HK_FMA(p, z, -1.1470745597729725e-11);          /* -1/14! */
+    p = HK_FMA(p, z, 2.08767569878681e-09);             /*  1/12! */
+    p = HK_FMA(p, z, -2.7557319223985888e-07);          /* -1/10! */
+    p = HK_FMA(p, z, 2.4801587301587302e-05);           /*  1/8!  */
+    p = HK_FMA(p, z, -0.0013888888888888889);           /* -1/6!  */
+    p = HK_FMA(p, z, 0.041666666666666664);             /*  1/4!  */
+    p = HK_FMA(p, z, -0.5);
+    return HK_FMA(p, z, 1.0);
+}
+HK_HD int hk__rem_pio2_f(double x, double* r)     /* the reduction of hk__rem_pio2 with fused steps */
+{
+    const double INV_PIO2 = 0.63661977236758138;
+    const double P1 = 1.5707963267341256, P2 = 6.077100506303966e-11, P3 = 2.0222662487959506e-21;
+    const double t = x * INV_PIO2;
+    const int k = (int)(t < 0.0 ? t - 0.5 : t + 0.5);
+    const double fk = (double)k;
+    double y = HK_FMA(-fk, P1, x);
+    y = HK_FMA(-fk, P2, y);
+    y = HK_FMA(-fk, P3, y);
+    *r = y;
+    return (int)(k & 3);
+}
+HK_HD void hk__sincos_f(double x, double* s, double* c)
+{
+    double r;
+    const int q = hk__rem_pio2_f(x, &r);
+    const double ks = hk__ksin_f(r), kc = hk__kcos_f(r);
+    const double a = (q & 1) ? kc : ks;
+    const double b = (q & 1) ? ks : kc;
+    *s = (q & 2) ? -a : a;
+    *c = ((q + 1) & 2) ? -b : b;
+}
+HK_HD void hk_sincosf(float x, float* s, float* c) { double ds, dc; hk__sincos_f((double)x, &ds, &dc); *s = (float)ds; *c = (float)dc; }
+HK_HD float hk_sinf(float x) { float s, c; hk_sincosf(x, &s, &c); (void)c; return s; }
+HK_HD float hk_cosf(float x) { float s, c; hk_sincosf(x, &s, &c); (void)s; return c; }
+/* an argument that is almost always near zero (the per-tick AngleAxis rotations, the wheels' steer angle): for |x| < 0.78 < pi/4 the
+ * reduction picks k = 0 and leaves r = x exactly, so the kernels run on x directly — bit-identical to hk_sincosf */
+HK_HD void hk_sincosf_near0(float x, float* s, float* c)
+{
+    const double dx = (double)x;
+    if (hk_fabs(dx) < 0.78) { *s = (float)hk__ksin_f(dx); *c = (float)hk__kcos_f(dx); return; }
+    hk_sincosf(x, s, c);
+}
+HK_HD double hk__atan01_f(double t)     /* atan(t), t in [0, 1]: the table of hk__atan01, the series of the remainder to u^9 (|u| <= 1/16: next term < 2^-47) */
+{
+    const double TH[9] = {0, 0.12435499454676144, 0.24497866312686414, 0.35877067027057225, 0.46364760900080609,
+                          0.55859931534356244, 0.64350110879328437, 0.71882999962162453, 0.78539816339744828};
+    const int j = (int)(t * 8.0 + 0.5);
+    const double c = (double)j * 0.125;
+    const double u = (t - c) / HK_FMA(t, c, 1.0);
+    const double z = u * u;
+    double p = 0.1111111111111111;
+    p = HK_FMA(p, z, -0.14285714285714285);
+    p = HK_FMA(p, z, 0.20000000000000001);
+    p = HK_FMA(p, z, -0.33333333333333331);
+    return TH[j] + HK_FMA(u * z, p, u);
+}
+HK_HD float hk_atan2f(float fy, float fx)
+{
+    const double PI = 3.1415926535897931, PIO2 = 1.5707963267948966;
+    const double x = (double)fx, y = (double)fy;
+    const double ax = hk_fabs(x), ay = hk_fabs(y);
+    const int lower = ay <= ax;
+    const double num = lower ? ay : ax;
+    double dnm = lower ? ax : ay;
+    if (dnm == 0.0) dnm = 1.0;
+    const double a = hk__atan01_f(num / dnm);
+    double r = lower ? a : PIO2 - a;
+    if (x < 0.0) r = PI - r;
+    return (float)(y < 0.0 ? -r : r);
+}
+HK_HD float hk_expf(float fx)           /* x = k ln2 + r, |r| <= ln2 / 2: e^r to r^11 / 11! (next term < 2^-47), scaled by 2^k */
+{
+    const double INV_LN2 = 1.4426950408889634, LN2_HI = 0.69314718036912382, LN2_LO = 1.9082149292705877e-10;
+    const double x = (double)fx;
+    double t = x * INV_LN2;
+    if (t > 2000.0) t = 2000.0;
+    if (t < -2000.0) t = -2000.0;
+    int k = (int)(t < 0.0 ? t - 0.5 : t + 0.5);
+    const double fk = (double)k;
+    const double r = HK_FMA(-fk, LN2_LO, HK_FMA(-fk, LN2_HI, x));
+    double p = 2.505210838544172e-08;                   /* 1/11! */
+    p = HK_FMA(p, r, 2.7557319223985888e-07);           /* 1/10! */
+    p = HK_FMA(p, r, 2.7557319223985893e-06);           /* 1/9!  */
+    p = HK_FMA(p, r, 2.4801587301587302e-05);           /* 1/8!  */
+    p = HK_FMA(p, r, 0.00019841269841269841);           /* 1/7!  */
+    p = HK_FMA(p, r, 0.0013888888888888889);            /* 1/6!  */
+    p = HK_FMA(p, r, 0.0083333333333333332);            /* 1/5!  */
+    p = HK_FMA(p, r, 0.041666666666666664);             /* 1/4!  */
+    p = HK_FMA(p, r, 0.16666666666666666);              /* 1/3!  */
+    p = HK_FMA(p, r, 0.5);
+    p = HK_FMA(p, r, 1.0);
+    const double e = HK_FMA(p, r, 1.0);
+    union { unsigned long long u; double d; } sc;
+    if (k < -1022) return 0.0f;
+    if (k > 1023) k = 1023;
+    sc.u = (unsigned long long)(k + 1023) << 52;
+    return (float)(e * sc.d);
+}
 HK_HD float hk_logf(float x) { return (float)hk_log((double)x); }
 
 /* Pure-fp32 exp for the RL actor's Swish (x * 1 / (1 + exp(-x))): Cody-Waite reduction + degree-5 polynomial (the classic

@@ -17,6 +17,13 @@ float hko_expf_fast(float x) { return hk_expf_fast(x); }
 float hko_swishf(float x) { return hk_swishf(x); }
 void hko_sincos(double x, double* s, double* c) { hk_sincos(x, s, c); }
 void hko_sincos_near0(double x, double* s, double* c) { hk_sincos_near0(x, s, c); }
+/* the float entry points (Mathf.*: double evaluation to <= 2^-44, rounded once) */
+float hko_sinf(float x) { return hk_sinf(x); }
+float hko_cosf(float x) { return hk_cosf(x); }
+void hko_sincosf(float x, float* s, float* c) { hk_sincosf(x, s, c); }
+void hko_sincosf_near0(float x, float* s, float* c) { hk_sincosf_near0(x, s, c); }
+float hko_atan2f(float y, float x) { return hk_atan2f(y, x); }
+float hko_expf(float x) { return hk_expf(x); }
 
 /* KartMPC index constants (AI/MPC/KartMPC.cs:15-18) */
 enum { XI = 0, ZI = 1, VI = 2, HI = 3 };

@@ -81,6 +81,59 @@ def test_matches_libm_within_float_rounding():
     assert diff <= 2
 
 
+def _float_api(L):
+    import ctypes as C
+    for n, args in (("hko_sinf", 1), ("hko_cosf", 1), ("hko_expf", 1), ("hko_atan2f", 2)):
+        getattr(L, n).restype = C.c_float
+        getattr(L, n).argtypes = [C.c_float] * args
+    fp = C.POINTER(C.c_float)
+    for n in ("hko_sincosf", "hko_sincosf_near0"):
+        getattr(L, n).restype = None
+        getattr(L, n).argtypes = [C.c_float, fp, fp]
+    return L
+
+
+def test_float_entry_points_are_the_correctly_rounded_float_almost_always():
+    """Mathf.Sin / Cos / Atan2 / Exp of the per-tick physics: evaluated in double to <= 2^-44 relative and rounded once.  Against mpmath: never
+    more than one float ulp away, and equal to the correctly rounded float — what (float)Math.Sin((double)x) returns under any libm — on all
+    but a ~1e-6 fraction of the arguments (where the true value sits within 2^-44 of a rounding boundary)."""
+    L = _float_api(lib()); rng = np.random.default_rng(12)
+
+    def check(fn, exact, args):
+        wrong = 0
+        for a in args:
+            a = tuple(float(np.float32(v)) for v in (a if isinstance(a, tuple) else (a,)))
+            got = np.float32(fn(*a))
+            ex = exact(*[mp.mpf(v) for v in a])
+            want = np.float32(float(ex))               # (double rounding: mpmath -> double -> float; a 2^-29 fraction of the cases could differ)
+            if got != want:
+                wrong += 1
+                assert abs(float(got) - float(ex)) <= 1.0001 * float(np.spacing(np.abs(want))), (a, got, want)
+        return wrong
+    xs = np.concatenate([rng.uniform(-7, 7, 6000), rng.uniform(-0.6, 0.6, 3000), rng.uniform(-400, 400, 1000), [0.0, 1e-6, -1e-6, 0.5235988, 6.2831855]])
+    assert check(L.hko_sinf, mp.sin, xs) <= 1 and check(L.hko_cosf, mp.cos, xs) <= 1
+    assert check(L.hko_expf, mp.exp, np.concatenate([rng.uniform(-3, 1, 6000), rng.uniform(-80, 80, 500), [0.0]])) <= 1
+    pts = [(a, b) for a, b in rng.uniform(-60, 60, (6000, 2))] + [(0.0, 1.0), (1.0, 0.0), (0.0, -1.0), (-1.0, 0.0), (1.0, 1.0), (-1.0, -1.0), (3.0, -4.0)]
+    assert check(L.hko_atan2f, mp.atan2, pts) <= 1
+    assert L.hko_atan2f(0.0, 0.0) == 0.0 and L.hko_expf(0.0) == 1.0 and L.hko_sinf(0.0) == 0.0 and L.hko_cosf(0.0) == 1.0
+    assert L.hko_expf(-1000.0) == 0.0
+
+
+def test_float_sincos_pair_and_small_angle_path_are_bit_identical():
+    """the kernels call hk_sincosf / hk_sincosf_near0 where the oracle calls hk_sinf and hk_cosf: same bits"""
+    import ctypes as C
+    L = _float_api(lib()); r = np.random.default_rng(13)
+    xs = np.concatenate([r.uniform(-7, 7, 20000), r.uniform(-1e3, 1e3, 3000), r.uniform(-0.79, 0.79, 20000),
+                         [0.0, -0.0, 0.78, -0.78, np.nextafter(np.float32(0.78), np.float32(0)), np.nextafter(np.float32(0.78), np.float32(1)), 0.7853982]]).astype(np.float32)
+    s, c, s0, c0 = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+    for x in xs:
+        L.hko_sincosf(float(x), C.byref(s), C.byref(c))
+        L.hko_sincosf_near0(float(x), C.byref(s0), C.byref(c0))
+        a, b = np.float32(L.hko_sinf(float(x))), np.float32(L.hko_cosf(float(x)))
+        for u, v in ((s.value, a), (c.value, b), (s0.value, a), (c0.value, b)):
+            assert np.float32(u).view(np.uint32) == v.view(np.uint32), x
+
+
 def test_expf_fast_within_2ulp_and_saturates():
     """the fp32 exp of the RL actor's Swish: <= 2 ulp on its clamped domain, monotone at the clamps"""
     import ctypes as C
