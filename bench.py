@@ -35,7 +35,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32-input MFMA = t
 STEADY_TICK = 512                      # steady state = ticks 512 .. 3584
 # HBM bytes and SQ counters cannot be read in-process: they come from the separate rocprofv3 --pmc passes of THIS command that
 # tools/pmc_summary.py folded into this file (committed with the profile it belongs to; `commit` / `command` inside say which)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
 
 
 def pmc_fields(kernel, env_steps_per_launch=None):
@@ -45,15 +45,21 @@ def pmc_fields(kernel, env_steps_per_launch=None):
         d = json.load(open(PMC_SUMMARY))
     except (OSError, ValueError):
         return None, {"note": "no PMC summary committed for this round"}, None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from source_hash import source_hash
+    if d.get("sources_sha16") != source_hash():
+        # the kernels changed after the counters were taken: no stale bytes in the line
+        return None, {"file": os.path.relpath(PMC_SUMMARY, ROOT), "stale": True,
+                      "note": "the committed PMC summary was measured on other kernel sources (sources_sha16 %s, this tree %s)" % (d.get("sources_sha16"), source_hash())}, None
     k = d.get(kernel) or {}
-    prov = {"file": os.path.relpath(PMC_SUMMARY, ROOT), "commit": d.get("commit"), "command": d.get("command"),
+    prov = {"file": os.path.relpath(PMC_SUMMARY, ROOT), "commit": d.get("commit"), "command": d.get("command"), "sources_sha16": d.get("sources_sha16"),
             "method": "separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, mean of the kernel's 30 largest launches"}
     sq = (k.get("sq") or {}).get("derived")
     binding = None
     if sq:
         binding = {"resource": "VALU issue", "wave_issuing_valu_frac": sq.get("wave_issuing_valu_frac"), "wave_issuing_any_frac": sq.get("wave_issuing_any_frac"),
-                   "wave_waiting_frac": sq.get("wave_waiting_frac"), "waves_per_simd": 2,
-                   "simd_valu_busy_frac": min(1.0, 2.0 * (sq.get("wave_issuing_valu_frac") or 0.0)),
+                   "wave_waiting_frac": sq.get("wave_waiting_frac"), "waves_per_simd": d.get("waves_per_simd", 2),
+                   "simd_valu_busy_frac": min(1.0, d.get("waves_per_simd", 2) * (sq.get("wave_issuing_valu_frac") or 0.0)),
                    "valu_lanes_active_of_64": sq.get("valu_lanes_active_of_64"), "valu_insts_per_launch": sq.get("valu_insts_per_launch"),
                    "source": "SQ counters of the same PMC summary (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave; two waves share a SIMD)"}
     traffic = k.get("hbm_bytes_per_launch")

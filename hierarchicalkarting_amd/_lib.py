@@ -10,8 +10,8 @@ HK_MAX_AGENTS = 8
 HK_MAX_SECTIONS = 64
 HK_NUM_SENSORS = 9
 HK_ABI_VERSION = 5
-HK_PROF_STAGES = 5
-PROF_STAGE_NAMES = ("env_run_kernel", "lqn_kernel<2,3,4>", "lq_batch_kernel", "policy_mlp_kernel", "observe+stack")
+HK_PROF_STAGES = 6
+PROF_STAGE_NAMES = ("env_run_kernel", "lqn_kernel<2,3,4>", "lq_batch_kernel", "policy_mlp_kernel", "observe+stack", "env_b1_kernel")
 HK_COMM_ID_BYTES = 128
 HK_MAX_POLICIES = 4
 HK_POLICY_MAX_LAYERS = 4

@@ -109,6 +109,13 @@ struct EnvParams {
     // the axles' static loads share * mass * gravity (front: -zr / (zf - zr), rear: zf / (zf - zr))
     hk_engine_params eng;
     EngDerived engd;
+    // floor(2^32 / L) + 1: x / L == (x * L_magic) >> 32 exactly for 0 <= x < 2^32 / L (sections count in the thousands); the hardware has no
+    // integer divide, and the tick loop divides by the section count on every tick (TelemetryViewer's lap number) and several times per Trigger
+    uint32_t L_magic;
+    // tight Trigger candidates: per cell of the wall grid the Triggers whose box, grown by the capsule's reach, meets the cell
+    int o_tmask2;
+    int tab_stage_bytes;    // bytes of the packed tables a block copies to LDS: all of them, or (a long track) all but the last segment, tmask2, which is
+                            // then read from global memory (one 8-byte load per kart and tick)
 };
 // ---- device buffers of the MCTS planner (hk_env_mcts.h) and of the reward shaping (hk_env_reward.h): the same for every GA
 struct MctsKartSnap { int section, lane, lane_changes, tire_age; int sec_time[HK_MCTS_SECTIME_RING]; };
@@ -172,6 +179,7 @@ struct TabView {
     const unsigned char* near_cnt;    // [nx*nz] how many entries at the head of the cell's list lie within NEAR_REACH
     const unsigned char* cut;     // [L][5][5]: does the ray lane marker -> next lane marker hit a wall (HKA:832)
     const uint2* tmask;           // [tgrid_nx * tgrid_nz] Trigger candidates per coarse cell (bit t = section t)
+    const uint2* tmask2;          // [grid_nx * grid_nz] Triggers a kart in this 2 m cell of the wall grid can overlap (bit t = section t)
 };
 __host__ __device__ inline TabView tab_view(const EnvParams& P, const unsigned char* base)
 {
@@ -183,6 +191,7 @@ __host__ __device__ inline TabView tab_view(const EnvParams& P, const unsigned c
     T.near_cnt = base + P.o_ncnt;
     T.cut = base + P.o_cut;
     T.tmask = reinterpret_cast<const uint2*>(base + P.o_tmask);
+    T.tmask2 = reinterpret_cast<const uint2*>(base + P.o_tmask2);
     return T;
 }
 // copy the packed tables into dynamic LDS (all threads of the block); TAB_LDS false: the launch passed no dynamic LDS (tables
@@ -190,16 +199,19 @@ __host__ __device__ inline TabView tab_view(const EnvParams& P, const unsigned c
 // are generic, every table read is a flat_load that finds its way to LDS through the vector-memory path, and the dependent
 // reads of the wall lists (cell -> list -> segment) pay that latency in series — the four short sensor rays alone took 11 % of
 // the tick kernel; as ds_reads the headline gains 5 % (903 -> 952 M env-steps/s, same box).
+// (stage_bytes: what the caller needs — phase B1 reads neither Trigger mask table, the last two segments)
 template <bool TAB_LDS>
-__device__ inline TabView tab_stage(const EnvParams& P, unsigned char* smem)
+__device__ inline TabView tab_stage(const EnvParams& P, unsigned char* smem, const int stage_bytes = 0)
 {
     if (!TAB_LDS) return tab_view(P, P.tab);
-    const int n16 = P.tab_bytes >> 4;
+    const int n16 = (stage_bytes ? stage_bytes : P.tab_stage_bytes) >> 4;
     const uint4* src = reinterpret_cast<const uint4*>(P.tab);
     uint4* dst = reinterpret_cast<uint4*>(smem);
     for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
-    return tab_view(P, smem);
+    TabView T = tab_view(P, smem);
+    if (P.tab_stage_bytes < P.tab_bytes) T.tmask2 = reinterpret_cast<const uint2*>(P.tab + P.o_tmask2);
+    return T;
 }
 
 // ------------------------------------------------------------------ float helpers (Unity Mathf semantics, Q10)
@@ -212,7 +224,10 @@ __device__ __forceinline__ float mag2(float x, float z) { return sqrtf(x * x + 0
 __device__ __forceinline__ float mag3(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }
 __device__ __forceinline__ bool f_finite(float x) { return !(isinf(x) || isnan(x)); }
 
-__device__ __forceinline__ bool is_straight(const EnvParams& P, const TabView& T, int section) { return T.sec[section % P.L].inside_radius == 0.0f; }
+// x / L and x % L for 0 <= x < 2^32 / L (exact: see EnvParams::L_magic)
+__device__ __forceinline__ int div_L(const EnvParams& P, int x) { return (int)(((unsigned long long)(uint32_t)x * (unsigned long long)P.L_magic) >> 32); }
+__device__ __forceinline__ int mod_L(const EnvParams& P, int x) { return x - div_L(P, x) * P.L; }
+__device__ __forceinline__ bool is_straight(const EnvParams& P, const TabView& T, int section) { return T.sec[mod_L(P, section)].inside_radius == 0.0f; }
 
 __device__ __forceinline__ float kart_steer(const EnvParams& P, float acc_ang_v)
 {   // AK:300
@@ -254,6 +269,13 @@ __device__ __forceinline__ int grid_cell(const EnvParams& P, float x, float z)
 // Triggers a kart at (x, z) can overlap: every Trigger within TRIG_REACH of the kart's coarse cell (a superset of those within
 // 6.5 m of the kart; a position outside the grid's box clamps to the border cell, and since every Trigger centre lies inside
 // the box the clamped point is nearer to each of them than the kart is)
+// The tight version: the kart's cell of the 2 m wall grid lists the Triggers whose box, grown by the capsule's reach (1.107 m + margin),
+// meets the cell — a kart is inside such a region for a sixth of every section, so most ticks find no candidate at all (the coarse
+// masks below: 2.5 candidates per kart and tick).  Border cells stand for everything outside the grid on their side.
+__device__ __forceinline__ uint2 trig_candidates_tight(const EnvParams& P, const TabView& T, float x, float z)
+{
+    return T.tmask2[grid_cell(P, x, z)];
+}
 __device__ __forceinline__ uint2 trig_candidates(const EnvParams& P, const TabView& T, float x, float z)
 {
     int ix = (int)((x - P.tgrid_x0) * P.tgrid_inv), iz = (int)((z - P.tgrid_z0) * P.tgrid_inv);
@@ -372,16 +394,33 @@ __device__ __forceinline__ void kart_core(float fx, float fz, float px, float pz
     bx = px + CAP_Z1 * fx; bz = pz + CAP_Z1 * fz;
 }
 
+// Is the wall segment within `reach` of the point?  (no division: the three cases of the closest point — beyond either end, or the foot of the
+// perpendicular, where dist^2 = cross^2 / |e|^2 is compared as cross^2 <= reach^2 |e|^2.)  Used as an exact CULL with a reach a centimetre or
+// two beyond what the following test needs, so float rounding cannot drop a wall that matters.
+__device__ __forceinline__ bool wall_within(const hk_wall_seg& w, const float px, const float pz, const float reach)
+{
+    const float ex = w.x1 - w.x0, ez = w.z1 - w.z0, rx = px - w.x0, rz = pz - w.z0;
+    const float u = rx * ex + rz * ez, ee = ex * ex + ez * ez, r2 = reach * reach;
+    if (u <= 0.0f) return rx * rx + rz * rz <= r2;
+    if (u >= ee) { const float qx = px - w.x1, qz = pz - w.z1; return qx * qx + qz * qz <= r2; }
+    const float cr = rx * ez - rz * ex;
+    return cr * cr <= r2 * ee;
+}
+
 // ------------------------------------------------------------------ engine restatement: tire forces (hk.h hk_engine_params)
 // Arithmetic contract shared with oracle/hk_oracle_env.c engine_wheels: divisions by configuration constants are multiplications by
 // reciprocals formed once on the host (env_build_params); a WheelFrictionCurve is ONE cubic in Horner form on its piece.
 __device__ __forceinline__ float curve_eval(const EngCurve& c, float slip)
 {
-    const bool in1 = slip <= c.ext;
-    const float t = in1 ? slip * c.inv_ext : (slip - c.ext) * c.inv_span;
-    const float c3 = in1 ? c.a3 : c.b3, c2 = in1 ? c.a2 : c.b2, c1 = in1 ? c.a1 : 0.0f, c0 = in1 ? 0.0f : c.b0;
-    const float v = ((c3 * t + c2) * t + c1) * t + c0;
-    return slip <= c.asy ? v : c.flat;
+    // Both pieces are evaluated and the VALUE is selected.  (`in1 ? c.a3 : c.b3` is a conditional between two lvalues: C++ selects the
+    // ADDRESS and loads once, and with `c` in the kernel-argument segment that load is a per-lane global_load — eight of them per call,
+    // four calls a tick, made the tire forces the most expensive part of the tick: 11.7 of 39 kcycles, profiles/r04_c_*.)
+    const float t1 = slip * c.inv_ext, t2 = (slip - c.ext) * c.inv_span;
+    const float v1 = ((c.a3 * t1 + c.a2) * t1 + c.a1) * t1 + 0.0f;
+    const float v2 = ((c.b3 * t2 + c.b2) * t2 + 0.0f) * t2 + c.b0;
+    const float v = slip <= c.ext ? v1 : v2;
+    const float flat = c.flat;
+    return slip <= c.asy ? v : flat;
 }
 // One tick of the four WheelColliders' tire forces on a free rigid body (centre of mass at the kart origin), both axles from the same
 // velocities; the front pair is steered by KartAnimation (steer_smoothed * max_steer_deg).
@@ -631,9 +670,9 @@ __device__ inline void plan_fixed(const EnvParams& P, const TabView& T, int agen
 {
     int hi = sec + P.depth[agent]; if (hi > 1000) hi = 1000;
     for (int i = sec + 1; i < hi + 1; i++) {
-        int key = i % P.L;
+        int key = mod_L(P, i);
         if (a->plan_lane[key] == 0) {
-            a->plan_lane[key] = (uint8_t)T.sec[(i - 1) % P.L].optimal_lane;
+            a->plan_lane[key] = (uint8_t)T.sec[mod_L(P, i - 1)].optimal_lane;
             a->plan_vel[key] = P.max_speed;
         }
     }

@@ -54,6 +54,7 @@ struct EnvDevice {
     SecGeo* sec_geo = nullptr;
     // lane-group -> env assignment of the tick kernel, regrouped by solve phase every REGROUP_ROUNDS rounds (hk_env_run.h)
     int* perm = nullptr;           // [E]
+    bool b1_due = false;           // FISSION: the tick launch just issued parked its envs at their solve tick: env_b1_kernel is next on that stream
     bool fission = false;          // the current call runs the tick kernel without phase B1 + env_b1_kernel (hk_env_run.h FISSION; hk_api.hip step_ticks)
     int arm_ticks = 0;             // > 0: the next tick launch adds these ticks to every env's count (a fixed-round call arms itself)
     bool last_solve_skippable = false;   // fixed-round call of a plain handle: no env can park in its last round, so that round queues no game (launch_lqn)
@@ -102,6 +103,7 @@ struct GaOps {
     int (*launch_reset)(EnvDevice& d, const int* dids, int cnt, int experiment_num, hipStream_t stream, std::string& err);
     int (*launch_regroup)(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err);
     int (*launch_run)(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err);
+    int (*launch_b1)(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err);
     int (*launch_lqn)(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err);
     int (*launch_observe)(EnvDevice& d, const hk_config& cfg, uint32_t agent_mask, hipStream_t stream, std::string& err);
     int (*launch_arm)(EnvDevice& d, const hk_config& cfg, int n_ticks, hipStream_t stream, std::string& err);

@@ -62,7 +62,11 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         if ((rc0 = env_build_params(cfg, sections, walls, P, pk, perms, err))) return rc0;
         if ((rc0 = detail::upload(&d.tab, pk, err))) return rc0;
         P.tab = d.tab;
-        d.tab_lds = (P.tab_bytes <= 48 * 1024 && !std::getenv("HK_TAB_GLOBAL")) ? P.tab_bytes : 0;      // Oval: ~20 KB per block (HK_TAB_GLOBAL=1: the global-memory instantiation, for tests)
+        // Oval: 42 KB per block, all of it in LDS; a longer track (Complex: 40 KB + 30 KB of tight Trigger masks) keeps the masks in global memory;
+        // beyond that the global-memory instantiation (HK_TAB_GLOBAL=1 forces it, for tests)
+        const int stage = P.tab_bytes <= 48 * 1024 ? P.tab_bytes : P.o_tmask2;
+        d.tab_lds = (stage <= 48 * 1024 && !std::getenv("HK_TAB_GLOBAL")) ? stage : 0;
+        P.tab_stage_bytes = d.tab_lds ? d.tab_lds : P.tab_bytes;
     }
     int rc;
     if ((rc = detail::upload(&d.perms, perms, err))) return rc;
@@ -270,6 +274,7 @@ inline int env_launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream
 }
 // (the split batch: no periodic regroup between the halves' launches — the caller regroups where both streams are joined)
 inline int env_launch_run_only(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_run(d, cfg, stream, err)); }
+inline int env_launch_b1(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_b1(d, cfg, stream, err)); }
 inline int env_launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_lqn(d, cfg, stream, err)); }
 // pack the envs that still have ticks to run into the first lane groups (the tail of a call; see env_regroup_count_kernel)
 inline int env_launch_regroup(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)

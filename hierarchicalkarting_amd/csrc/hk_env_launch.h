@@ -101,20 +101,16 @@ inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
     for (int i = 0; i < cfg.num_agents; i++) train = train || d.P.training_agent[i] != 0;
 #if HK_GA == 4
     if (d.fission && !train && !d.mcts.st && !d.rw.sec_time) {
-        // FISSION (hk_env_run.h): the tick kernel without phase B1, then phase B1 of every env it parked at its solve tick
+        // FISSION (hk_env_run.h): the tick kernel without phase B1; launch_b1 follows on the same stream
         const GameSoA G{d.games, (size_t)cfg.num_envs * cfg.num_agents};
         const unsigned blocks = (unsigned)((threads + 255) / 256);
-        if (d.tab_lds) {
+        if (d.tab_lds)
             hipLaunchKernelGGL((env_run_kernel<false, false, false, true, true>), dim3(blocks), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs, d.results, G, d.queue_cnt,
                                d.queue, d.round, d.act_steer, d.act_branch, d.lq_debug, d.status, d.mcts, d.mset, d.rw, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase, arm, guard);
-            hipLaunchKernelGGL((env_b1_kernel<true>), dim3(blocks), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs, G, d.queue_cnt, d.queue, d.round, d.lq_debug, d.status,
-                               d.mcts, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase);
-        } else {
+        else
             hipLaunchKernelGGL((env_run_kernel<false, false, false, false, true>), dim3(blocks), dim3(256), 0, stream, d.P, d.agents, d.envs, d.results, G, d.queue_cnt,
                                d.queue, d.round, d.act_steer, d.act_branch, d.lq_debug, d.status, d.mcts, d.mset, d.rw, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase, arm, guard);
-            hipLaunchKernelGGL((env_b1_kernel<false>), dim3(blocks), dim3(256), 0, stream, d.P, d.agents, d.envs, G, d.queue_cnt, d.queue, d.round, d.lq_debug, d.status,
-                               d.mcts, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase);
-        }
+        d.b1_due = true;
     } else
 #endif
     if (train) HK_RUN(true, true, true);
@@ -123,6 +119,29 @@ inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
 #undef HK_RUN_T
 #undef HK_RUN
     return launch_check(err, "env_run_kernel");
+}
+
+// one round, part 1b (FISSION): phase B1 of every env the tick launch parked at its solve tick
+inline int launch_b1(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
+#if HK_GA == 4
+    if (!d.b1_due) return HK_OK;
+    d.b1_due = false;
+    const int s0 = d.slot1 > d.slot0 ? d.slot0 : 0, s1 = d.slot1 > d.slot0 ? d.slot1 : cfg.num_envs;
+    const long long threads = (long long)(s1 - s0) * GA;
+    const GameSoA G{d.games, (size_t)cfg.num_envs * cfg.num_agents};
+    const unsigned blocks = (unsigned)((threads + 255) / 256);
+    if (d.tab_lds)
+        hipLaunchKernelGGL((env_b1_kernel<true>), dim3(blocks), dim3(256), d.P.o_tmask, stream, d.P, d.agents, d.envs, G, d.queue_cnt, d.queue, d.round, d.lq_debug, d.status,
+                           d.mcts, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase);
+    else
+        hipLaunchKernelGGL((env_b1_kernel<false>), dim3(blocks), dim3(256), 0, stream, d.P, d.agents, d.envs, G, d.queue_cnt, d.queue, d.round, d.lq_debug, d.status,
+                           d.mcts, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase);
+    return launch_check(err, "env_b1_kernel");
+#else
+    (void)d; (void)cfg; (void)stream; (void)err;
+    return HK_OK;
+#endif
 }
 
 // one round, part 2: the Riccati solves of the queued multi-player games, binned by player count
@@ -213,7 +232,7 @@ inline int launch_rewards_read(EnvDevice& d, int cnt, float* reward, float* grou
 inline const GaOps& make_ops()
 {
     static const GaOps ops = {mcts_req_bytes, mcts_searches_per_wave, mcts_lds_bytes, mcts_root_words, game_doubles_per_ego, queue_ints_per_set,
-                              launch_mcts_table, launch_mcts_invalidate, flush_mcts, launch_reset, launch_regroup, launch_run, launch_lqn,
+                              launch_mcts_table, launch_mcts_invalidate, flush_mcts, launch_reset, launch_regroup, launch_run, launch_b1, launch_lqn,
                               launch_observe, launch_arm, launch_done_check, launch_rewards_read};
     return ops;
 }

@@ -287,8 +287,44 @@ inline int env_build_params(hk_config& cfg, std::vector<hk_section>& sections, s
                 }
             P.o_tmask = seg(tm.data(), tm.size() * sizeof(uint32_t));
         }
+        {   // tight Trigger candidates per cell of the wall grid.  A kart overlaps Trigger t only if its origin lies within the box (half extents
+            // TRIG_HX x TRIG_HZ about the Trigger, turned by the section's yaw) grown by the capsule's reach 1.107 m; + 3 cm for the float rounding
+            // of the cell index.  A border cell also stands for every position beyond it (grid_cell clamps).
+            const double grow = 1.107 + 0.03;
+            std::vector<uint32_t> tm2((size_t)P.grid_nx * P.grid_nz * 2, 0u);
+            for (int iz = 0; iz < P.grid_nz; iz++)
+                for (int ix = 0; ix < P.grid_nx; ix++) {
+                    double cx0 = P.grid_x0 + ix * (double)GRID_CELL, cz0 = P.grid_z0 + iz * (double)GRID_CELL;
+                    double cx1 = cx0 + GRID_CELL, cz1 = cz0 + GRID_CELL;
+                    if (ix == 0) cx0 = -1e9;
+                    if (iz == 0) cz0 = -1e9;
+                    if (ix == P.grid_nx - 1) cx1 = 1e9;
+                    if (iz == P.grid_nz - 1) cz1 = 1e9;
+                    for (int t = 0; t < L; t++) {
+                        // conservative: the cell rectangle against the bounding circle ... no: against the grown box's own axes (separating axes)
+                        const double tx = sections[t].trig_x, tz = sections[t].trig_z;
+                        const double yaw = (double)sd[t].yaw_rad, fxx = std::sin(yaw), fzz = std::cos(yaw);      // box forward; right = (fzz, -fxx)
+                        const double hx = TRIG_HX + grow, hz = TRIG_HZ + grow;
+                        // clamp the infinite border cells to something finite around the box for the axis tests
+                        const double bx0 = std::max(cx0, tx - 100.0), bx1 = std::min(cx1, tx + 100.0), bz0 = std::max(cz0, tz - 100.0), bz1 = std::min(cz1, tz + 100.0);
+                        if (bx0 > bx1 || bz0 > bz1) continue;
+                        // axes of the cell (x, z): the box's projection
+                        const double ex = std::fabs(fzz) * hx + std::fabs(fxx) * hz, ez = std::fabs(fxx) * hx + std::fabs(fzz) * hz;
+                        if (tx + ex < bx0 || tx - ex > bx1 || tz + ez < bz0 || tz - ez > bz1) continue;
+                        // axes of the box: the cell's projection
+                        const double ccx = 0.5 * (bx0 + bx1) - tx, ccz = 0.5 * (bz0 + bz1) - tz, hcx = 0.5 * (bx1 - bx0), hcz = 0.5 * (bz1 - bz0);
+                        const double pr = ccx * fzz - ccz * fxx, pf = ccx * fxx + ccz * fzz;                      // cell centre in the box frame (right, forward)
+                        const double rr = hcx * std::fabs(fzz) + hcz * std::fabs(fxx), rf = hcx * std::fabs(fxx) + hcz * std::fabs(fzz);
+                        if (std::fabs(pr) > hx + rr || std::fabs(pf) > hz + rf) continue;
+                        tm2[((size_t)iz * P.grid_nx + ix) * 2 + (t >> 5)] |= 1u << (t & 31);
+                    }
+                }
+            P.o_tmask2 = seg(tm2.data(), tm2.size() * sizeof(uint32_t));
+        }
+        P.L_magic = (uint32_t)((1ull << 32) / (unsigned long long)L) + 1u;
         pk.resize((pk.size() + 15) & ~size_t(15));
         P.tab_bytes = (int)pk.size();
+        P.tab_stage_bytes = P.tab_bytes;      // (env_create narrows it when the tight Trigger masks do not fit the LDS budget)
     }
     return HK_OK;
 }

@@ -301,8 +301,11 @@ __global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_ru
 // FISSION, part 2: phase B1 of the solve tick for every env the tick launch parked there (phase 2).  Same lane groups, same device
 // functions (phase_assemble: sensor rays through the LDS wall grid, players within 8 m, assembly, lq1_solve in the ego's lane, multi-player
 // games to GameSoA + queues); of the kart record only what B1 reads is loaded and only what it decodes (flags, steering) is stored.
+#ifndef HK_B1_OCC
+#define HK_B1_OCC 2
+#endif
 template <bool TAB_LDS>
-__global__ __launch_bounds__(256, 2) void env_b1_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs, GameSoA games, int* queue_cnt_all,
+__global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs, GameSoA games, int* queue_cnt_all,
                                                         int* queue_all, int round, hk_lq_debug* dbg_out, int* status, MctsDev M, const int* perm,
                                                         unsigned long long* stats, int slot0, int slot1, int qbase)
 {
@@ -324,16 +327,20 @@ __global__ __launch_bounds__(256, 2) void env_b1_kernel(EnvParams P, hk_agent_st
     else { es.episode_steps = 0; es.inactive_mask = 0; es.experiment_num = 0; es.episodes_done = 0; es.status = 0; es.initial_started = 0; es.reserved[0] = 0; es.reserved[1] = 0; }
     const bool pend = env_ok && (es.reserved[1] & ENV_PHASE_MASK) == 2;
     if (__syncthreads_or(pend ? 1 : 0) == 0) return;
-    const TabView T = tab_stage<TAB_LDS>(P, smem);
+    const TabView T = tab_stage<TAB_LDS>(P, smem, P.o_tmask);      // (the segments before the Trigger masks: sections, walls, wall grid, cut table)
     const LaneCfg LC = lane_cfg(P, i);
     hk_agent_state* arec = (pend && i < P.A) ? &agents[(size_t)env * P.A + i] : nullptr;
     Hot h = {};
+#ifdef HK_STAMPS
+    h.st_t = __builtin_readcyclecounter();
+#endif
     if (arec) {
         h.px = arec->px; h.pz = arec->pz; h.yaw = arec->yaw; h.vx = arec->vx; h.vz = arec->vz; h.wy = arec->wy;
         h.final_steer = arec->final_steer; h.section_index = arec->section_index; h.flags = arec->flags; h.steering = arec->steering;
     }
     float hfx, hfz;
     hk_sincosf(h.yaw, &hfx, &hfz);
+    HK_ST(h, 19);                      // [19] B1 kernel: table staging, record loads, sincos
     const int qn = phase_assemble(P, T, ks, env, i, pend, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
 #pragma unroll
     for (int n = 2; n <= GA; n++) {
@@ -343,6 +350,14 @@ __global__ __launch_bounds__(256, 2) void env_b1_kernel(EnvParams P, hk_agent_st
     const bool queued = group_or(qn ? 1 : 0) != 0;
     if (arec) { arec->flags = h.flags; arec->steering = h.steering; }
     if (pend && i == 0) envs[env].reserved[1] = 1 | (queued ? ENV_PACK_HINT : 0);
+#ifdef HK_STAMPS
+    HK_ST(h, 18);                      // [18] B1 kernel: binning, stores
+    for (int k = 0; k < HK_NSTAMP; k++) {
+        unsigned v = h.st_acc[k];
+        for (int o = 32; o > 0; o >>= 1) { const unsigned w = (unsigned)__shfl_xor((int)v, o, 64); v = w > v ? w : v; }
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&stats[16 + k], (unsigned long long)v);
+    }
+#endif
 }
 
 } }  // namespace hk::HK_GA_NS

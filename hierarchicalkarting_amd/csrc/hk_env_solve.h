@@ -284,7 +284,7 @@ __device__ __forceinline__ void assemble_player(const EnvParams& P, const TabVie
             else { games.put(game, i, GP_A4 + 0, a40); games.put(game, i, GP_A4 + 1, a41); games.put(game, i, GP_A4 + 2, a42); games.put(game, i, GP_A4 + 3, a43); }
         }
         const int s = kk.sec + 1;                                                     // :746
-        const int idx = s % L, idx2 = (s + 1) % L;
+        const int idx = mod_L(P, s), idx2 = mod_L(P, s + 1);
         int laneSel = 0, nextSel = 0;
         double vel = P.max_speed, nextVel = P.max_speed;
         if (ki == ego) {                                                              // :752-764, :782-794
@@ -403,7 +403,7 @@ __device__ __forceinline__ void assemble_player(const EnvParams& P, const TabVie
                 if (!isteam) nearbyOpponents += 1;
             }
             if (SINGLE) gp->aw[M] = w; else games.put(game, i, GP_AW + M, w);
-            const int io = (o.sec + 1) % L;
+            const int io = mod_L(P, o.sec + 1);
             float olx, olz; double ov;
             if (oi == ego) {
                 lane_marker(T, io, mek.pl1, olx, olz);
@@ -504,7 +504,7 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
         k.sec = h.section_index;
         k.straight = is_straight(P, T, k.sec) ? 1 : 0;
         k.flags = h.flags;
-        const int i1 = (k.sec + 1) % L, i2 = (k.sec + 2) % L;
+        const int i1 = mod_L(P, k.sec + 1), i2 = mod_L(P, k.sec + 2);
         k.pl1 = a->plan_lane[i1]; k.pv1 = a->plan_vel[i1];
         k.pl2 = a->plan_lane[i2]; k.pv2 = a->plan_vel[i2];
         {   // BoxCollider.ClosestPoint distance to the next section's Trigger (HKA:846,876)
@@ -523,6 +523,7 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
         // supersets; below the largest threshold the minimum is what a scan of every wall (the oracle) returns.
         const float ox = k.px + SENSOR_LZ * k.fx, oz = k.pz + SENSOR_LZ * k.fz;
         HK_ST(h, 14);
+#ifndef HK_DUMMY_NO_RAYS          /* (timing / counter experiments only: tools/build_variant.py) */
         {
             float d0x, d0z;
             sensor_dir(P, 0, k.fx, k.fz, d0x, d0z);
@@ -572,7 +573,8 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
 #ifndef HK_NO_SHORT_RAY_CULL
                 // the four rays are compared with 2 m and 1.5 m only (side, below): a wall whose box is further than that from the
                 // origin cannot change any of the comparisons (1 cm margin >> float rounding); most of a cell's list is
-                if (f_max(ws.x0, ws.x1) < ox - 2.01f || f_min(ws.x0, ws.x1) > ox + 2.01f || f_max(ws.z0, ws.z1) < oz - 2.01f || f_min(ws.z0, ws.z1) > oz + 2.01f) return;
+                // (round 4: by the wall's distance from the ray origin, not by bounding boxes — tighter for the diagonal segments of the curves)
+                if (!wall_within(ws, ox, oz, 2.0f + 0.02f)) return;
 #endif
                 HK_LP(8);
 #pragma unroll
@@ -589,6 +591,7 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
 #pragma unroll
             for (int q = 0; q < 4; q++) k.ray[1 + q] = best[q];
         }
+#endif
     }
     HK_ST(h, 16);
     ks[threadIdx.x] = k;
@@ -625,7 +628,11 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
         HK_ST(h, 4);                   // [4] single-player assembly (heading heuristic, weights)
         if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = 1;
         HK_LP(10);
+#ifndef HK_DUMMY_NO_LQ1
         lq1_solve(P, loc, h, (dbg_out && (P.debug & 1)) ? &dbg_out[(size_t)env * A + ego] : nullptr, status);
+#else
+        h.steering = (float)loc.tgt[3] * 0.01f; h.flags |= HK_F_ACCEL;
+#endif
         HK_ST(h, 5);                   // [5] lq1_solve
         return 0;
     }

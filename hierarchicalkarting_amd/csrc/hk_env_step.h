@@ -39,7 +39,7 @@ __device__ inline void reset_agent(const EnvParams& P, const TabView& T, int env
     a->init_checkpoint_index = sec;
     a->acc_ang_v = acc0;
     a->lane = lane;
-    const SecDev& s = T.sec[sec % P.L];
+    const SecDev& s = T.sec[mod_L(P, sec)];
     float yaw = s.yaw_rad;
     float px = s.lane_x[lane - 1] + s.fx * spawn;
     float pz = s.lane_z[lane - 1] + s.fz * spawn;
@@ -365,7 +365,11 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             else ss = ss + f_sign(turnInput - ss) * maxDelta;
             h.steer_smoothed = ss;
         }
+#ifdef HK_DUMMY_NO_MOVE
+        if (false) {
+#else
         if (fl & HK_F_CAN_MOVE) {                                         // MoveVehicle AK:363-503
+#endif
             HK_LP(13);
             const float dt = P.dt;
             const float fx = cfx, fz = cfz;
@@ -373,12 +377,15 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             float localVelZ = vx * fx + vz * fz;
             bool accelDirectionIsFwd = accelInput >= 0;
             bool localVelDirectionIsFwd = localVelZ >= 0;
-            float maxSpeed = localVelDirectionIsFwd ? P.st.TopSpeed : P.st.ReverseSpeed;
+            // (kernel-argument fields are read into values BEFORE a conditional picks one: `c ? P.a : P.b` is a conditional between two
+            // lvalues, i.e. a select of the ADDRESS and one per-lane global_load from the argument segment, on every tick)
+            const float st_top = P.st.TopSpeed, st_rev = P.st.ReverseSpeed, st_acc = P.st.Acceleration, st_racc = P.st.ReverseAcceleration;
+            float maxSpeed = localVelDirectionIsFwd ? st_top + 0.0f : st_rev + 0.0f;
             float wear = tire_wear(P, final_steer);
             float maxAllowedSpeed = sqrtf(max_lat_gs(P, wear) * 9.81f * f_abs(turning_radius(vx, vz, fx, fz, wy)));
             if (!(isinf(maxAllowedSpeed) || isnan(maxAllowedSpeed)))
                 maxSpeed = f_clamp(maxSpeed, 0.001f, f_max(maxAllowedSpeed, 0.001f));
-            float accelPower = accelDirectionIsFwd ? P.st.Acceleration : P.st.ReverseAcceleration;
+            float accelPower = accelDirectionIsFwd ? st_acc + 0.0f : st_racc + 0.0f;
             float currentSpeed = mag3(vx, 0.0f, vz);
             float accelRampT = currentSpeed / maxSpeed;
             float multipliedAccelerationCurve = P.st.AccelerationCurve * 5;
@@ -422,7 +429,12 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             h.acc_ang_v = acc_ang_v;
             rot_y(turningPower * f_sign(localVelZ) * 25.0f * P.st.Grip * dt * DEG2RAD_F, vx, vz);
             // ---- engine: the wheels' sideways friction, then integrate
-            if (P.eng.wheel_friction) engine_wheels(P, cfx, cfz, h.steer_smoothed, vx, vz, wy, h.wheel_uf, h.wheel_ur);
+#ifndef HK_DUMMY_NO_ENGINE          /* HK_DUMMY_*: region-cost experiments only (tools/experiments/region_cost.py); never in the product */
+            if (P.eng.wheel_friction)
+#else
+            if (false)
+#endif
+                engine_wheels(P, cfx, cfz, h.steer_smoothed, vx, vz, wy, h.wheel_uf, h.wheel_ur);
             wy = wy * (1.0f - P.st.AngularDrag * dt);
             yaw = yaw + wy * dt;
             if (yaw < 0.0f) yaw += TWO_PI_F;
@@ -434,6 +446,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
     }
     HK_ST(h, 8);                       // [8] actions, planFixed, ArcadeKart model, integration
     // ---- kart-kart contacts (Jacobi over one snapshot)
+#ifndef HK_DUMMY_NO_KART
     {
         float ax = 0, az = 0, bx = 0, bz = 0;
         kart_core(cfx, cfz, px, pz, ax, az, bx, bz);
@@ -489,8 +502,10 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             if (touched) fl |= HK_F_HAS_COLLISION; else fl &= ~HK_F_HAS_COLLISION;
         }
     }
+#endif
     HK_ST(h, 9);                       // [9] kart-kart contacts
     // ---- kart-wall contacts: deepest penetration, two passes
+#ifndef HK_DUMMY_NO_WALL
     if (enabled && (fl & HK_F_CAN_MOVE)) {
         for (int pass = 0; pass < 2; pass++) {
             HK_LP(15);
@@ -506,8 +521,9 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             // order.  The lanes of a wave sit in different cells: with the full test on every listed wall the wave paid the
             // longest list (a curve's ~7 one-metre segments) times the full test on every tick, although almost no kart
             // touches a wall.  The box test is conservative (1 cm margin >> float rounding), so the result is unchanged.
-            const float kx0 = f_min(ax, bx) - (CAP_R + 0.01f), kx1 = f_max(ax, bx) + (CAP_R + 0.01f);
-            const float kz0 = f_min(az, bz) - (CAP_R + 0.01f), kz1 = f_max(az, bz) + (CAP_R + 0.01f);
+            // (round 4: the cull is the wall's distance from the kart ORIGIN — every point of the capsule lies within 0.657 + 0.45 = 1.107 m of it —
+            // not a bounding-box overlap: the one-metre diagonal segments of a curve's inner wall, 1.2 - 1.5 m from a kart on the racing line, passed
+            // the box test on most ticks and went through the closest-point computation for nothing)
             for (int base = w0; base < w1; base += 32) {
                 const int nq = (w1 - base) < 32 ? (w1 - base) : 32;
                 uint32_t cand = 0;
@@ -520,8 +536,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                     for (int j = 0; j < 4; j++) ws[j] = T.walls[T.grid_idx[base + ((q + j) < nq ? (q + j) : (nq - 1))]];
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const bool apart = f_max(ws[j].x0, ws[j].x1) < kx0 || f_min(ws[j].x0, ws[j].x1) > kx1 ||
-                                           f_max(ws[j].z0, ws[j].z1) < kz0 || f_min(ws[j].z0, ws[j].z1) > kz1;
+                        const bool apart = !wall_within(ws[j], px, pz, 1.107f + 0.02f);
                         cand |= ((apart || (q + j) >= nq) ? 0u : 1u) << (q + j);
                     }
                 }
@@ -569,6 +584,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             h.contact_nx = bnx; h.contact_nz = bnz;
         }
     }
+#endif
     HK_ST(h, 10);                      // [10] kart-wall contacts
     bool bad = false;
     if (live) bad = !f_finite(px) || !f_finite(pz) || !f_finite(vx) || !f_finite(vz) || !f_finite(yaw) || !f_finite(wy);
@@ -578,12 +594,13 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
     int nev = 0;
     if (enabled) {
         h.px = px; h.pz = pz; h.yaw = yaw; h.vx = vx; h.vz = vz; h.wy = wy;
+#ifndef HK_DUMMY_NO_TRIG
         float ax, az, bx, bz;
         kart_core(cfx, cfz, px, pz, ax, az, bx, bz);
         uint32_t lo = 0, hi = 0;
         // only the Triggers listed for the kart's coarse cell can be within reach (the others fail the distance cull below
         // by construction): a couple of trips instead of one per section, each a dependent LDS round trip
-        const uint2 tc = trig_candidates(P, T, px, pz);
+        const uint2 tc = trig_candidates_tight(P, T, px, pz);
         auto trig_test = [&](const int t, const float tx, const float tz, const float tfx, const float tfz) {
             HK_LP(18);
             // exact cull: box half diagonal 5.03 + capsule reach 1.11 < 6.5
@@ -616,7 +633,11 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
         }
         const uint32_t nlo = lo & ~h.trig_lo, nhi = hi & ~h.trig_hi;
         h.trig_lo = lo; h.trig_hi = hi;
+#ifdef HK_DUMMY_NO_ENTER
+        if (false) {
+#else
         if (nlo | nhi) {
+#endif
             uint32_t elo = nlo, ehi = nhi;
             while (elo | ehi) {                                        // newly entered Triggers in section order
                 int t;
@@ -634,7 +655,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                 // KA.FindSectionIndex :348-364: the first ii in [lo_i, sec + H) whose section (ii mod L) is this Trigger's.  The loop of the
                 // C# costs a run-time modulo per step (typically seven steps) for the two lanes of a wave that are here: closed form.
                 if (lo_i >= 0) {
-                    int delta = t - lo_i % L;
+                    int delta = t - mod_L(P, lo_i);
                     if (delta < 0) delta += L;
                     if (lo_i + delta < sec + H) index = lo_i + delta;
                 } else {
@@ -644,7 +665,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                     }
                 }
                 if (index != -1) lane = calculate_lane(P, T.sec[t], px, pz);        // (index mod L == t)
-                const int secm = sec % L;
+                const int secm = mod_L(P, sec);
                 const bool sec_straight = T.sec[secm].inside_radius == 0.0f;       // is_straight(sec)
                 if (index != -1 && ((index > sec) || (t == 0 && secm == L - 1))) {
                     const int key = t;
@@ -699,6 +720,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                 }
             }
         }
+    #endif
     }
     HK_ST(h, 11);                      // [11] Trigger overlap / enter, section and lane rules
     hfx = cfx; hfz = cfz;
@@ -706,7 +728,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
     if (live) {
         h.flags = fl;
         // TelemetryViewer.Update :49-88 (once per tick)
-        const int currentLap = h.section_index / P.L;
+        const int currentLap = div_L(P, h.section_index);
         const int done = h.tele_completed_laps;
         if (currentLap > done) {
             h.tele_completed_laps = currentLap;

@@ -19,7 +19,7 @@ namespace KartGame.AI.Native
         public const int HK_MCTS_SECTIME_RING = 8;
         public const int HK_MCTS_MAX_ROOT_PHASES = 3;
         public const int HK_COMM_ID_BYTES = 128;
-        public const int HK_PROF_STAGES = 5;
+        public const int HK_PROF_STAGES = 6;
         // HierarchicalKartAgent.cs:21-33
         public const int HK_LOW_RL = 0, HK_LOW_MPC = 1, HK_LOW_LQR = 2;
         public const int HK_HIGH_MCTS = 0, HK_HIGH_FIXED = 1;

@@ -447,9 +447,9 @@ int hk_comm_destroy(hk_handle h);
 /* timing taps for bench.py's roofline object: accumulated HIP-event time (ms) and launch count per kernel stage since
  * the last hk_prof_reset.  Stages: [0] env_run_kernel (the fused tick kernel), [1] the lqn_kernel<2,3,4> launches of a
  * round (one bracket), [2] lq_batch_kernel, [3] policy_mlp_kernel,
- * [4] env_observe_kernel + policy_stack_kernel of a decision tick.  Events are recorded on the handle's own stream around every launch
+ * [4] env_observe_kernel + policy_stack_kernel of a decision tick, [5] env_b1_kernel (phase B1 of the solve tick when the tick kernel runs without it).  Events are recorded on the handle's own stream around every launch
  * (no host sync per launch; the tick kernel and the solver launch of a round share the event between them) and folded when read. */
-#define HK_PROF_STAGES 5
+#define HK_PROF_STAGES 6
 int hk_prof_enable(hk_handle h, int on);
 int hk_prof_reset(hk_handle h);
 int hk_prof_read(hk_handle h, double* ms /*[HK_PROF_STAGES]*/, int64_t* launches /*[HK_PROF_STAGES]*/);

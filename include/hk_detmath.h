@@ -133,15 +133,28 @@ HK_HD void hk_sincos_near0(double x, double* s, double* c)
     hk_sincos(x, s, c);
 }
 
+/* atan(j / 8), j = 0 .. 8, split hi + lo — as a chain of selects on literals, not a table: a table indexed by a computed j sits in constant
+ * memory, and on the GPU every lookup is a per-lane global load in the middle of a dependent chain (seven of them per assembled player) */
+HK_HD double hk__atan_hi(int j)
+{
+    double r = 0.0;
+    r = j == 1 ? 0.12435499454676144 : r; r = j == 2 ? 0.24497866312686414 : r; r = j == 3 ? 0.35877067027057225 : r;
+    r = j == 4 ? 0.46364760900080609 : r; r = j == 5 ? 0.55859931534356244 : r; r = j == 6 ? 0.64350110879328437 : r;
+    r = j == 7 ? 0.71882999962162453 : r; r = j == 8 ? 0.78539816339744828 : r;
+    return r;
+}
+HK_HD double hk__atan_lo(int j)
+{
+    double r = 0.0;
+    r = j == 1 ? -3.1253241424539383e-18 : r; r = j == 2 ? 1.0698755618734451e-17 : r; r = j == 3 ? -2.4623815582638635e-17 : r;
+    r = j == 4 ? 2.2698777452961687e-17 : r; r = j == 5 ? -5.4556305485916264e-18 : r; r = j == 6 ? 1.5834785051444286e-17 : r;
+    r = j == 7 ? -2.1478388444456983e-17 : r; r = j == 8 ? 3.061616997868383e-17 : r;
+    return r;
+}
+
 /* atan(t) for t in [0,1] */
 HK_HD double hk__atan01(double t)
 {
-    /* atan(j/8), j = 0..8, split hi + lo */
-    const double TH[9] = {0, 0.12435499454676144, 0.24497866312686414, 0.35877067027057225, 0.46364760900080609,
-                          0.55859931534356244, 0.64350110879328437, 0.71882999962162453, 0.78539816339744828};
-    const double TL[9] = {0, -3.1253241424539383e-18, 1.0698755618734451e-17, -2.4623815582638635e-17,
-                          2.2698777452961687e-17, -5.4556305485916264e-18, 1.5834785051444286e-17,
-                          -2.1478388444456983e-17, 3.061616997868383e-17};
     int j = (int)(t * 8.0 + 0.5);
     double c = (double)j * 0.125;
     double u = (t - c) / (1.0 + t * c);
@@ -155,7 +168,7 @@ HK_HD double hk__atan01(double t)
     p = HK_HORNER(p, z, 0.20000000000000001);
     p = HK_HORNER(p, z, -0.33333333333333331);
     double a = u + (u * z) * p;
-    return TH[j] + (TL[j] + a);
+    return hk__atan_hi(j) + (hk__atan_lo(j) + a);
 }
 
 /* atan2 with the usual quadrant conventions; atan2(0,0) = 0, atan2(+-0, x<0) = +-pi */
@@ -306,8 +319,6 @@ HK_HD void hk_sincosf_near0(float x, float* s, float* c)
 }
 HK_HD double hk__atan01_f(double t)     /* atan(t), t in [0, 1]: the table of hk__atan01, the series of the remainder to u^9 (|u| <= 1/16: next term < 2^-47) */
 {
-    const double TH[9] = {0, 0.12435499454676144, 0.24497866312686414, 0.35877067027057225, 0.46364760900080609,
-                          0.55859931534356244, 0.64350110879328437, 0.71882999962162453, 0.78539816339744828};
     const int j = (int)(t * 8.0 + 0.5);
     const double c = (double)j * 0.125;
     const double u = (t - c) / HK_FMA(t, c, 1.0);
@@ -316,7 +327,7 @@ HK_HD double hk__atan01_f(double t)     /* atan(t), t in [0, 1]: the table of hk
     p = HK_FMA(p, z, -0.14285714285714285);
     p = HK_FMA(p, z, 0.20000000000000001);
     p = HK_FMA(p, z, -0.33333333333333331);
-    return TH[j] + HK_FMA(u * z, p, u);
+    return hk__atan_hi(j) + HK_FMA(u * z, p, u);
 }
 HK_HD float hk_atan2f(float fy, float fx)
 {

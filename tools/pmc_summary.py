@@ -56,6 +56,10 @@ def main():
             i += 1
     fetch = top_mean(rows(fetch_csv), "FETCH_SIZE")
     write = top_mean(rows(write_csv), "WRITE_SIZE")
+    import os, sys as _sys
+    _sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from source_hash import source_hash
+    meta["sources_sha16"] = source_hash()                 # the tree the counters were measured on (bench.py checks it)
     out = {"note": "HBM bytes per launch from separate --pmc FETCH_SIZE / WRITE_SIZE passes (KiB -> bytes; fetch doubled: gfx950 correction); "
                    "SQ counters from their own passes; per kernel the mean over its 30 largest launches", **meta}
     for k in sorted(set(fetch) | set(write)):

@@ -17,7 +17,7 @@ LIB = os.path.join(ROOT, "build", "libhk_stamps.so")
 NAMES = ["prologue (tables -> LDS, state load)", "phase A: episode controller, kart-vs-kart rays", "own-kart staging + 5 wall rays",
          "players within 8 m", "single-player assembly (heading heuristic)", "lq1_solve", "queue binning", "multi-player assembly",
          "actions, planFixed, ArcadeKart, integrate", "kart-kart contacts", "kart-wall contacts", "Triggers, section / lane rules",
-         "telemetry, env words", "wait for the wave's other groups", "(of [2]) own-kart staging: atan2, max speed, Trigger distance", "(of [2]) forward wall ray", "(of [2]) four short rays", "(of [2]) KartS -> LDS", "-", "-"]
+         "telemetry, env words", "wait for the wave's other groups", "(of [2]) own-kart staging: atan2, max speed, Trigger distance", "(of [2]) forward wall ray", "(of [2]) four short rays", "(of [2]) KartS -> LDS", "B1 kernel: queue binning, stores", "B1 kernel: table staging, record loads"]
 
 
 def build():
