@@ -94,6 +94,7 @@ struct Tuning {
     bool mcts_pause = true;      // HK_MCTS_NO_PAUSE=1: long calls of planner handles keep the deadline schedule
     bool want_split = false;     // HK_SPLIT=1: the batch as two halves on two streams in EVERY call of a plain handle (short ones too)
     bool split_long = true;      // the default: ... in the long (lazily completed) calls of plain handles; HK_NO_SPLIT=1 / HK_SPLIT=0 switch it off
+    int split_ways = 2;          // HK_SPLIT_WAYS: parts of a split batch (2 .. SPLIT_WAYS_MAX), each on its own stream
     int split_min_ticks = 8;     // HK_SPLIT_MIN_TICKS: ... and in the calls of at least this many ticks that are not (a 20-tick call: 1 050 -> 1 120 M env-steps/s)
     bool no_split = false;       // HK_NO_SPLIT=1: one stream always, also while the field stands close
     int run_cap_spread = hk::RUN_CAP_SPREAD;   // HK_RUN_CAP_SPREAD: ticks per launch of long calls on a spread field (4 .. 64)
@@ -111,7 +112,7 @@ struct Tuning {
         auto flag = [](const char* n) { return std::getenv(n) != nullptr; };
         auto num = [](const char* n, int dflt, int lo, int hi) { const char* e = std::getenv(n); const int v = e ? std::atoi(e) : dflt; return v >= lo && v <= hi ? v : dflt; };
         eager = !flag("HK_NO_EAGER"); lazy = !flag("HK_FIXED_ROUNDS"); mcts_pause = !flag("HK_MCTS_NO_PAUSE");
-        { const char* sp = std::getenv("HK_SPLIT"); want_split = sp && std::atoi(sp) != 0; no_split = flag("HK_NO_SPLIT"); split_long = !no_split && !(sp && std::atoi(sp) == 0); } split_min_ticks = num("HK_SPLIT_MIN_TICKS", 8, 1, 1 << 20); tail_worst_case = flag("HK_TAIL_WORST_CASE"); keep_last_solve = flag("HK_KEEP_LAST_SOLVE");
+        { const char* sp = std::getenv("HK_SPLIT"); want_split = sp && std::atoi(sp) != 0; no_split = flag("HK_NO_SPLIT"); split_long = !no_split && !(sp && std::atoi(sp) == 0); } split_min_ticks = num("HK_SPLIT_MIN_TICKS", 8, 1, 1 << 20); split_ways = num("HK_SPLIT_WAYS", 2, 2, hk::SPLIT_WAYS_MAX); tail_worst_case = flag("HK_TAIL_WORST_CASE"); keep_last_solve = flag("HK_KEEP_LAST_SOLVE");
         run_cap_spread = num("HK_RUN_CAP_SPREAD", hk::RUN_CAP_SPREAD, 4, 64);
         run_cap_short = num("HK_RUN_CAP_SHORT", 4, 4, 64);
         regroup_rounds = num("HK_REGROUP_ROUNDS", hk::REGROUP_ROUNDS, 1, 1 << 20);
@@ -126,7 +127,7 @@ struct hk_context {
     int device = 0;
     Tuning tune;
     hipStream_t stream = nullptr;
-    hipStream_t qstream = nullptr;   // the second half of a split batch runs here (issue_rounds_split)
+    hipStream_t qstream[hk::SPLIT_WAYS_MAX - 1] = {};   // the other parts of a split batch run here (issue_rounds_split)
     bool env_ready = false;
     hk_config cfg{};
     std::vector<hk_section> sections;
@@ -148,8 +149,8 @@ struct hk_context {
     // finishes the stragglers (finish_ticks)
     bool step_pending = false;
     bool split = false;            // the current call runs the batch as two halves on two streams (issue_rounds)
-    int round_half[2] = {0, 0};    // each half's own round counter (the parity picks its queue set)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int round_half[hk::SPLIT_WAYS_MAX] = {};    // each part's own round counter (the parity picks its queue set)
+    hipEvent_t ev_fork = nullptr, ev_join[hk::SPLIT_WAYS_MAX - 1] = {};
     int* done_host = nullptr;      // pinned: [0] max ticks left over the envs, [1] an env waits for a queued game
     void* pol_scratch = nullptr;   // hk_policy_forward staging
     size_t pol_scratch_bytes = 0;
@@ -277,8 +278,9 @@ void hk_destroy(hk_handle h)
     for (int p = 0; p < HK_MAX_POLICIES; p++) hk::policy_free(h->policy[p]);
     h->prof.fold();
     for (hipEvent_t e : h->prof.pool) (void)hipEventDestroy(e);
-    if (h->qstream) { (void)hipStreamSynchronize(h->qstream); (void)hipStreamDestroy(h->qstream); }
-    if (h->ev_fork) { (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
+    for (hipStream_t q : h->qstream) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (hipEvent_t e : h->ev_join) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h == g_default_ctx) g_default_ctx = nullptr;
     delete h;
@@ -428,27 +430,33 @@ static int issue_rounds(hk_handle h, int rounds)
 // else touches the state (the guard kernel, a regroup, a getter).
 static int issue_rounds_split(hk_handle h, int rounds)
 {
-    if (!h->qstream) HK_HIP(h, hipStreamCreateWithFlags(&h->qstream, hipStreamNonBlocking));
-    if (!h->ev_fork) {
-        HK_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        HK_HIP(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    const int K = h->tune.split_ways;
+    for (int k = 0; k < K - 1; k++) {
+        if (!h->qstream[k]) HK_HIP(h, hipStreamCreateWithFlags(&h->qstream[k], hipStreamNonBlocking));
+        if (!h->ev_join[k]) HK_HIP(h, hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
     }
-    const int E = h->cfg.num_envs, mid = (E / 2 + 63) / 64 * 64;      // (a block of the tick kernel holds 64 lane groups)
+    if (!h->ev_fork) HK_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    const int E = h->cfg.num_envs;
+    int cut[hk::SPLIT_WAYS_MAX + 1];                       // part k: lane groups [cut[k], cut[k + 1]) (a block of the tick kernel holds 64 lane groups)
+    for (int k = 0; k <= K; k++) cut[k] = k == K ? E : (int)(((long long)E * k / K + 63) / 64 * 64);
     if ((h->dev.rounds_since_regroup += rounds) >= h->dev.regroup_rounds) {  // the periodic regroup by solve phase, here where the streams are joined
         int rcg = hk::env_launch_regroup(h->dev, h->cfg, h->stream, h->err);
         if (rcg) { g_last_error = h->err; return rcg; }
         h->dev.rounds_since_regroup = rounds;      // (the rounds issued below count toward the next one)
     }
-    hipStream_t st[2] = {h->stream, h->qstream};
+    hipStream_t st[hk::SPLIT_WAYS_MAX];
+    hipEvent_t e[hk::SPLIT_WAYS_MAX];
+    st[0] = h->stream;
+    for (int k = 1; k < K; k++) st[k] = h->qstream[k - 1];
     h->round_half[0] = h->dev.round;          // sets 0 / 1 are also the unsplit launches' sets: continue their parity
     HK_HIP(h, hipEventRecord(h->ev_fork, h->stream));
-    HK_HIP(h, hipStreamWaitEvent(h->qstream, h->ev_fork, 0));
-    hipEvent_t e[2] = {h->prof.begin(st[0]), h->prof.begin(st[1])};
+    for (int k = 1; k < K; k++) HK_HIP(h, hipStreamWaitEvent(st[k], h->ev_fork, 0));
+    for (int k = 0; k < K; k++) e[k] = h->prof.begin(st[k]);
     bool first = true;
     int rc = HK_OK;
     for (int r = 0; r < rounds && rc == HK_OK; r++) {
-        for (int k = 0; k < 2 && rc == HK_OK; k++) {
-            h->dev.slot0 = k ? mid : 0; h->dev.slot1 = k ? E : mid; h->dev.qbase = 2 * k; h->dev.round = h->round_half[k];
+        for (int k = 0; k < K && rc == HK_OK; k++) {
+            h->dev.slot0 = cut[k]; h->dev.slot1 = cut[k + 1]; h->dev.qbase = 2 * k; h->dev.round = h->round_half[k];
             rc = hk::env_launch_run_only(h->dev, h->cfg, st[k], h->err);
             if (rc) break;
             e[k] = h->prof.chain(0, e[k], first, st[k]);
@@ -465,9 +473,11 @@ static int issue_rounds_split(hk_handle h, int rounds)
         first = false;
     }
     h->dev.slot0 = 0; h->dev.slot1 = 0; h->dev.qbase = 0; h->dev.round = h->round_half[0];
-    if (first) for (int k = 0; k < 2; k++) if (e[k]) h->prof.pool.push_back(e[k]);
-    HK_HIP(h, hipEventRecord(h->ev_join, h->qstream));
-    HK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    if (first) for (int k = 0; k < K; k++) if (e[k]) h->prof.pool.push_back(e[k]);
+    for (int k = 1; k < K; k++) {
+        HK_HIP(h, hipEventRecord(h->ev_join[k - 1], st[k]));
+        HK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join[k - 1], 0));
+    }
     if (rc) g_last_error = h->err;
     return rc;
 }

@@ -69,6 +69,7 @@ struct EnvDevice {
 constexpr int LQN_BULK_GAMES = 2048; // a round with more 3- (4-) player games than this runs them 5 (4) to a wave (hk_lq2_pair.h lqn_round_kernel)
 constexpr int MCTS_FLUSH_ROUNDS = MCTS_MIN_LATENCY / RUN_CAP - 1;      // 4 at RUN_CAP 8
 constexpr int MCTS_ARENA_WAVES = 2048;
+constexpr int SPLIT_WAYS_MAX = 4;   // parts a split batch can have (hk_api.hip issue_rounds_split): each owns a pair of queue sets
 constexpr int BULK_TICKS = 384;        // after a full reset the field needs about this long to spread out (launch_lqn)
 constexpr int REGROUP_ROUNDS = 48;     // the tick kernel's lane groups are re-assigned by solve phase every so many rounds (~200 ticks)
 constexpr int MCTS_DEFER_TICKS = 38;   // short hk_step calls share one search launch until this many ticks have been armed

@@ -88,10 +88,10 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     HK_ALLOC(d.status, 4 * sizeof(int));
     HK_ALLOC(d.game_stats, GAME_STATS_N * sizeof(unsigned long long));     // (hk_env_device.h: GAME_STATS_N)
     HK_ALLOC(d.games, na * HK_GA_CALL(d, game_doubles_per_ego()) * sizeof(double));
-    HK_ALLOC(d.queue_cnt, 4 * 16 * sizeof(int));
+    HK_ALLOC(d.queue_cnt, 2 * SPLIT_WAYS_MAX * 16 * sizeof(int));
     HK_ALLOC(d.perm, (size_t)E * sizeof(int));
     HK_ALLOC(d.perm_counts, 32 * sizeof(int));
-    HK_ALLOC(d.queue, 4 * HK_GA_CALL(d, queue_ints_per_set(na)) * sizeof(int));
+    HK_ALLOC(d.queue, 2 * SPLIT_WAYS_MAX * HK_GA_CALL(d, queue_ints_per_set(na)) * sizeof(int));
     if (cfg.rewards) {
         d.rw.S = cfg.laps * L + 2;
         const size_t n = na * (size_t)d.rw.S;

@@ -137,6 +137,9 @@ __global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_ru
 {
     MctsDev M{};
     if (HAS_MCTS) M = Marg;
+#ifdef HK_STAMPS
+    const unsigned long long st_entry = __builtin_readcyclecounter();
+#endif
 #ifdef HK_LANEPROF
     hk_lp_ptr = stats;                 // (every thread stores the same value)
 #endif
@@ -160,23 +163,30 @@ __global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_ru
     if (env_ok) es.reserved[0] += arm_ticks;             // the first launch of a fixed-round call arms the envs (else env_arm_kernel did)
     // nothing to do in this block? (every env finished its ticks): skip the table staging too
     if (__syncthreads_or(es.reserved[0] > 0 || (es.reserved[1] & ENV_PHASE_MASK) != 0) == 0) return;
+#ifdef HK_STAMPS
+    const unsigned long long st_a = __builtin_readcyclecounter();
+#endif
     const TabView T = tab_stage<TAB_LDS>(P, smem);
+#ifdef HK_STAMPS
+    const unsigned long long st_b = __builtin_readcyclecounter();
+#endif
+    hk_agent_state* arec = (env_ok && i < P.A) ? &agents[(size_t)env * P.A + i] : nullptr;
+    Hot h;
+    if (arec) h = load_hot(arec); else { Hot z = {}; h = z; }
     const int cadence = P.A > 2 ? 4 : 1;
     const int cmask = cadence - 1;                       // cadence is 1 or 4 and episode_steps >= 0: x % cadence == x & cmask
     const uint32_t all_mask = (1u << P.A) - 1u;
     int budget = P.run_cap;
-    hk_agent_state* arec = (env_ok && i < P.A) ? &agents[(size_t)env * P.A + i] : nullptr;
     const LaneCfg LC = lane_cfg(P, i);                   // this lane's agent: modes and player list, read once
     int left = es.reserved[0];
     int phase = es.reserved[1] & ENV_PHASE_MASK;         // 0: at a tick boundary; 1: phases A / B1 of a tick done, waiting for (or holding) its controls
     if (FISSION && phase == 2) phase = 0, left = 0;      // (cannot happen: env_b1_kernel runs between two tick launches; such an env would trip the guard)
     bool pack = (es.reserved[1] & ENV_PACK_HINT) != 0;   // did the env's last solve tick queue a multi-player game (regroup_key)
     bool dirty = false;
-    Hot h;
-    if (arec) h = load_hot(arec); else { Hot z = {}; h = z; }
 #ifdef HK_STAMPS
     for (int k = 0; k < HK_NSTAMP; k++) h.st_acc[k] = 0;
-    h.st_t = __builtin_readcyclecounter();
+    h.st_acc[20] = (unsigned)(st_a - st_entry); h.st_acc[21] = (unsigned)(st_b - st_a);     // the head of the launch: lane group + env words; table staging
+    h.st_t = st_b;
 #endif
     float hfx, hfz;                                      // the kart's forward, carried across ticks (changes only when yaw does)
     hk_sincosf(h.yaw, &hfx, &hfz);
@@ -277,7 +287,11 @@ __global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_ru
         }
     }
     HK_ST(h, 13);                      // [13] waiting for the other lane groups of the wave to leave the loop
+#ifdef HK_DUMMY_NO_STORE
+    if (arec && dirty && h.px == 12345.678f) {       // (timing experiments only: the record stores compiled to a branch never taken)
+#else
     if (arec && dirty) {
+#endif
         store_hot(arec, h);
         if (HAS_RW && P.rewards) { arec->cum_reward = rwv.cum; arec->step_reward = rwv.step; arec->group_reward = rwv.group; }
     }
@@ -289,6 +303,8 @@ __global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_ru
     // the last launch of a fixed-round call is its completion guard (what env_check_kernel does for the other calls)
     if (guard && env_ok && i == 0 && (left != 0 || phase != 0)) atomicOr(status, 4);
 #ifdef HK_STAMPS
+    __builtin_amdgcn_s_waitcnt(0); HK_ST(h, 22);        // [22] the record stores, waited for
+    h.st_acc[24] = (unsigned)(h.st_t - st_entry);       // [24] the wave's whole life in this launch
     for (int k = 0; k < HK_NSTAMP; k++) {
         unsigned v = h.st_acc[k];
         for (int o = 32; o > 0; o >>= 1) { const unsigned w = (unsigned)__shfl_xor((int)v, o, 64); v = w > v ? w : v; }
@@ -313,6 +329,9 @@ __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_
     hk_lp_ptr = stats;
 #endif
     (void)stats;
+#ifdef HK_STAMPS
+    const unsigned long long st_entry = __builtin_readcyclecounter();
+#endif
     __shared__ KartS ks[256];
     HK_DYN_SHARED(smem);
     const int gid = slot0 * GA + blockIdx.x * blockDim.x + threadIdx.x;
@@ -327,17 +346,18 @@ __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_
     else { es.episode_steps = 0; es.inactive_mask = 0; es.experiment_num = 0; es.episodes_done = 0; es.status = 0; es.initial_started = 0; es.reserved[0] = 0; es.reserved[1] = 0; }
     const bool pend = env_ok && (es.reserved[1] & ENV_PHASE_MASK) == 2;
     if (__syncthreads_or(pend ? 1 : 0) == 0) return;
-    const TabView T = tab_stage<TAB_LDS>(P, smem, P.o_tmask);      // (the segments before the Trigger masks: sections, walls, wall grid, cut table)
-    const LaneCfg LC = lane_cfg(P, i);
     hk_agent_state* arec = (pend && i < P.A) ? &agents[(size_t)env * P.A + i] : nullptr;
     Hot h = {};
 #ifdef HK_STAMPS
     h.st_t = __builtin_readcyclecounter();
+    h.st_acc[23] = (unsigned)(h.st_t - st_entry);      // [23] B1 kernel: lane group + env words
 #endif
+    const TabView T = tab_stage<TAB_LDS>(P, smem, P.o_tmask);      // (the segments before the Trigger masks: sections, walls, wall grid, cut table)
     if (arec) {
         h.px = arec->px; h.pz = arec->pz; h.yaw = arec->yaw; h.vx = arec->vx; h.vz = arec->vz; h.wy = arec->wy;
         h.final_steer = arec->final_steer; h.section_index = arec->section_index; h.flags = arec->flags; h.steering = arec->steering;
     }
+    const LaneCfg LC = lane_cfg(P, i);
     float hfx, hfz;
     hk_sincosf(h.yaw, &hfx, &hfz);
     HK_ST(h, 19);                      // [19] B1 kernel: table staging, record loads, sincos
@@ -351,7 +371,10 @@ __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_
     if (arec) { arec->flags = h.flags; arec->steering = h.steering; }
     if (pend && i == 0) envs[env].reserved[1] = 1 | (queued ? ENV_PACK_HINT : 0);
 #ifdef HK_STAMPS
-    HK_ST(h, 18);                      // [18] B1 kernel: binning, stores
+    __builtin_amdgcn_s_waitcnt(0);
+    HK_ST(h, 18);                      // [18] B1 kernel: binning, stores (waited for)
+    h.st_acc[25] = (unsigned)(h.st_t - st_entry);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&stats[16 + HK_NSTAMP + 1], 1ull);     // waves of the B1 kernel that had work
     for (int k = 0; k < HK_NSTAMP; k++) {
         unsigned v = h.st_acc[k];
         for (int o = 32; o > 0; o >>= 1) { const unsigned w = (unsigned)__shfl_xor((int)v, o, 64); v = w > v ? w : v; }

@@ -20,13 +20,15 @@ thread_local hk_emu_dim3 threadIdx;
 hk_emu_dim3 blockIdx, blockDim, gridDim;
 namespace hk_emu { Barrier bar; uint64_t slot[LANES]; unsigned char* dyn_shared; }
 
+#ifndef HK_GA
 #define HK_GA 4
 #define HK_GA_NS g4
+#endif
 #include "hk_env_ga.h"
 #include "hk_env_params.h"
 
 using namespace hk;
-using namespace hk::g4;
+using namespace hk::HK_GA_NS;
 
 struct Ctl { uint32_t flags; float steering; };
 
@@ -54,8 +56,8 @@ template <bool HAS_MCTS, bool HAS_RW, bool HAS_TRAIN>
 static void launch_quad(World& W, int env, int round, int arm)
 {
     GameSoA G{W.games.data(), W.agents.size()};
-    std::thread th[4];
-    for (unsigned l = 0; l < 4; l++)
+    std::thread th[GA];
+    for (unsigned l = 0; l < (unsigned)GA; l++)
         th[l] = std::thread([&, l] {
             threadIdx = {l, 0, 0};
             env_run_kernel<HAS_MCTS, HAS_RW, HAS_TRAIN, false>(W.P, W.agents.data(), W.envs.data(), W.results.data(), G, W.queue_cnt.data(), W.queue.data(), round,
@@ -77,7 +79,7 @@ int main(int argc, char** argv)
     auto wall_in = read_n<hk_wall_seg>(f, NW);
     const auto ctl = read_n<Ctl>(f, (size_t)n_ticks * E * A);
     std::fclose(f);
-    if (cfg.num_envs != E || cfg.num_agents != A || cfg.num_sections != L || cfg.num_walls != NW || A > 4) { std::fprintf(stderr, "header / config mismatch\n"); return 2; }
+    if (cfg.num_envs != E || cfg.num_agents != A || cfg.num_sections != L || cfg.num_walls != NW || A > GA) { std::fprintf(stderr, "header / config mismatch\n"); return 2; }
     cfg.sections = sec_in.data(); cfg.walls = wall_in.data();
 
     World W;
@@ -97,7 +99,7 @@ int main(int argc, char** argv)
     }
     std::vector<unsigned char> lds(64 * 1024, 0);
     hk_emu::dyn_shared = lds.data();
-    blockIdx = {0, 0, 0}; blockDim = {4, 1, 1}; gridDim = {1, 1, 1};
+    blockIdx = {0, 0, 0}; blockDim = {(unsigned)GA, 1, 1}; gridDim = {1, 1, 1};
 
     // hk_reset of every env: env_reset_kernel is lane-local, one host thread walks the lanes
     blockDim = {(unsigned)(E * GA), 1, 1};
@@ -105,7 +107,7 @@ int main(int argc, char** argv)
         threadIdx = {t, 0, 0};
         env_reset_kernel(W.P, W.agents.data(), W.envs.data(), nullptr, E, -1, MctsDev{}, 0, W.RD, W.status);
     }
-    blockDim = {4, 1, 1};
+    blockDim = {(unsigned)GA, 1, 1};
 
     FILE* out = std::fopen(argv[2], "wb");
     if (!out) { std::perror(argv[2]); return 2; }

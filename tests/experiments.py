@@ -8,11 +8,12 @@ tests/golden/reference_actors.npz        those trained actors as float32 arrays 
 tests/golden/reference_log_stats.json    statistics of the reference's own ExperimentLogs/<ExperimentName>.txt
 
 Nothing here reads /root/reference (it does not exist on the GPU box)."""
+import copy
 import json
 import os
 import numpy as np
 from hierarchicalkarting_amd import _lib, telemetry as T
-from hierarchicalkarting_amd.config import make_config
+from hierarchicalkarting_amd.config import make_config, load_track
 from hierarchicalkarting_amd.policy import Policy
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -51,6 +52,13 @@ class Setup:
         self.name, self.env = name, e
         self.A = len(ag)
         self.track = "oval" if "Oval" in e["scene"] else "complex"
+        # every RacingEnvController of the reference's scenes owns a copy of the track, and the copies differ in DiscretePositionTracker.optimalLane
+        # (what planFixed follows, HKA:145-152): the 1v1 set-ups of CompeteAgents-OvalAll / -ComplexAll are not the track fixture's lanes
+        track = copy.deepcopy(load_track(self.track))
+        if e.get("optimal_lanes"):
+            assert len(e["optimal_lanes"]) == len(track["sections"])
+            for sec, lane in zip(track["sections"], e["optimal_lanes"]):
+                sec["optimalLane"] = int(lane)
         self.names = [a["name"] for a in ag]
         self.n_exp = int(n_exp if n_exp is not None else e["TotalExperiments"])
         team_of = [0] * self.A
@@ -59,7 +67,7 @@ class Setup:
                 team_of[m] = t
         gp = [a["gameParams"] for a in ag]
         self.built = make_config(
-            self.n_exp, self.A, track=self.track, high_mode=[a["HighMode"] for a in ag], low_mode=[a["LowMode"] for a in ag],
+            self.n_exp, self.A, track=track, high_mode=[a["HighMode"] for a in ag], low_mode=[a["LowMode"] for a in ag],
             tree_search_depth=[g["treeSearchDepth"] for g in gp], velocity_bucket_size=[g["velocityBucketSize"] for g in gp],
             time_precision=[g["timePrecision"] for g in gp], section_window=[g["sectionWindow"] for g in gp],
             wiring=(team_of, [a["teamAgents"] for a in ag], [a["otherAgents"] for a in ag]),

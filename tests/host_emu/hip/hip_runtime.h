@@ -40,7 +40,10 @@ using std::isinf; using std::isnan;
 typedef int hipStream_t;
 
 namespace hk_emu {
-constexpr int LANES = 4;
+#ifndef HK_EMU_LANES
+#define HK_EMU_LANES 4          /* the lanes of a group: 4, or 8 for the hk::g8 build of the harness (-DHK_GA=8 -DHK_GA_NS=g8 -DHK_EMU_LANES=8) */
+#endif
+constexpr int LANES = HK_EMU_LANES;
 // a reusable barrier for LANES threads that reports a hang instead of deadlocking
 struct Barrier {
     // sense-reversing spin barrier (the lanes meet thousands of times per tick: a condition variable's wake-up latency dominated the run)

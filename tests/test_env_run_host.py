@@ -38,6 +38,12 @@ def harness_ifelse(tmp_path_factory):
     return _build(tmp_path_factory, "env_run_host_check_ifelse", "-DHK_LOOP_IFELSE=1")
 
 
+@pytest.fixture(scope="module")
+def harness_g8(tmp_path_factory):
+    """the 8-lane groups (hk::g8, configs[4]): eight host threads per race instance"""
+    return _build(tmp_path_factory, "env_run_host_check_g8", "-DHK_GA=8", "-DHK_GA_NS=g8", "-DHK_EMU_LANES=8")
+
+
 def _run(harness, tmp_path, built, n_ticks, chunk, eager, run_cap):
     E, A = built.cfg.num_envs, built.cfg.num_agents
     o = O.OracleEnv(built)
@@ -121,3 +127,16 @@ def test_training_mode_instantiation_under_sanitizers(harness, tmp_path):
 
 def test_training_mode_with_the_other_loop_form(harness_ifelse, tmp_path):
     _run(harness_ifelse, tmp_path, _training(track="complex"), 200, 50, 1, 32)
+
+
+def test_eight_lane_groups_under_sanitizers(harness_g8, tmp_path):
+    """hk::g8 (configs[4]: 8 agents, two teams of four): the start grid queues games of up to 8 players; an episode restarts inside the run"""
+    built = make_config(2, 8, jitter_seed=7, max_episode_steps=240)
+    stats = _run(harness_g8, tmp_path, built, 300, 25, 0, 8)
+    assert stats["queued_games"] > 100
+
+
+def test_six_agents_in_eight_lane_groups_under_sanitizers(harness_g8, tmp_path):
+    """6 agents in a group of 8: two idle lanes take part in every group exchange"""
+    built = make_config(2, 6, jitter_seed=9, max_episode_steps=200)
+    _run(harness_g8, tmp_path, built, 230, 10, 0, 8)

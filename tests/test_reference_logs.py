@@ -137,6 +137,13 @@ def test_trained_actors_of_the_reference_drive_and_win_as_in_the_reference():
     for n in ("MCTS_LQR_vs_Fixed_LQR_Oval2", "MCTS_LQR_vs_Fixed_LQR_OvalDuos2", "MCTS_LQR_vs_Fixed_LQR_Complex3", "MCTS_LQR_vs_Fixed_LQR_ComplexDuos2"):
         tot = g(n, "MCTS-LQR")["wins"] + g(n, "Fixed-LQR")["wins"]
         assert g(n, "MCTS-LQR")["wins"] >= tot // 3
+    # The fixed plan follows each scene's own DiscretePositionTracker.optimalLane (tests/experiments.py: the 1v1 scenes' copies of the Oval keep
+    # to lanes 3 / 2 where the track fixture says 4 / 3).  With the fixture's lanes the Fixed-LQR kart swerved on every lap of the 1v1 Oval
+    # (3.5 - 3.9 illegal lane changes a race; reference 0.00 - 0.02) and lost 35 : 15 to the planner; with the scene's: 0.0, and 31 : 19
+    # (reference 24 : 26).  The 2v2 Oval scenes do use lanes 4 / 3, and there the reference swerves too (2.1 - 3.0 a race; here 3.2 - 3.5).
+    for n in ("Fixed_RL_vs_Fixed_LQR_Oval2", "MCTS_LQR_vs_Fixed_LQR_Oval2", "MCTS_RL_vs_Fixed_LQR_Oval2"):
+        assert g(n, "Fixed-LQR")["illegal_lane_changes_per_race"] <= 0.1, (n, g(n, "Fixed-LQR")["illegal_lane_changes_per_race"])
+    assert abs(g("MCTS_LQR_vs_Fixed_LQR_Oval2", "MCTS-LQR")["wins"] - g("MCTS_LQR_vs_Fixed_LQR_Oval2", "MCTS-LQR", REF)["wins"]) <= 8
     # win counts over all 22 set-ups: the side that wins in the reference wins here in all but the closest match-ups (a handful of races apart)
     agree = sum((ORA[n]["stats"][a]["wins"] > ORA[n]["stats"][b]["wins"]) == (REF[n]["stats"][a]["wins"] > REF[n]["stats"][b]["wins"])
                 for n in ALL for a, b in [tuple(ORA[n]["stats"])])

@@ -221,6 +221,18 @@ class SceneExperiments:
         return res
 
 
+def optimal_lanes(scene, env_id):
+    """DiscretePositionTracker.optimalLane of the env's Sections[], in order (tools/extract_track.py resolves the prefab instances and the
+    scene's overrides).  Every RacingEnvController of an "All" scene owns a copy of the track, and the copies differ in exactly this field:
+    CompeteAgents-OvalAll's 1v1 set-ups keep to lanes 3 / 2 on the straights where CompeteAgents-Oval (the track fixture) says 4 / 3."""
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "t.json")
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "extract_track.py"), "--scene", "Karting/Scenes/Compete/" + scene, "--env", str(env_id),
+                        "--name", "t", "--out", out], check=True, stdout=subprocess.DEVNULL)
+        return [int(x["optimalLane"]) for x in json.load(open(out))["sections"]]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--update", action="store_true")
@@ -231,9 +243,11 @@ def main():
     for p in sorted(glob.glob(os.path.join(SCENES, "CompeteAgents-%s.unity" % a.scenes))):
         allenv += SceneExperiments(p, guid).envs()
     for e in allenv:
+        e["optimal_lanes"] = optimal_lanes(e["scene"], e["env_id"])
         print("%-34s %-36s active=%s laps=%s maxSteps=%s MaxLaneChanges=%s mode=%s sections=%d H=%s" % (
             e["scene"], e.get("ExperimentName"), e["game_object_active"], e.get("laps"), e.get("maxEpisodeSteps"),
             e.get("MaxLaneChanges"), e.get("mode"), e["n_sections"], e.get("sectionHorizon")))
+        print("        optimal lanes " + "".join(str(x) for x in e["optimal_lanes"]))
         for i, ag in enumerate(e["agents"]):
             b = ag.get("behavior") or {}
             print("        sensors yaw %s ray %s wall %s agent %s" % tuple([x.get(k) for x in ag.get("sensors", [])] for k in ("yaw_deg", "RayDistance", "WallHitValidationDistance", "AgentHitValidationDistance")))

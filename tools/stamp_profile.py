@@ -17,7 +17,10 @@ LIB = os.path.join(ROOT, "build", "libhk_stamps.so")
 NAMES = ["prologue (tables -> LDS, state load)", "phase A: episode controller, kart-vs-kart rays", "own-kart staging + 5 wall rays",
          "players within 8 m", "single-player assembly (heading heuristic)", "lq1_solve", "queue binning", "multi-player assembly",
          "actions, planFixed, ArcadeKart, integrate", "kart-kart contacts", "kart-wall contacts", "Triggers, section / lane rules",
-         "telemetry, env words", "wait for the wave's other groups", "(of [2]) own-kart staging: atan2, max speed, Trigger distance", "(of [2]) forward wall ray", "(of [2]) four short rays", "(of [2]) KartS -> LDS", "B1 kernel: queue binning, stores", "B1 kernel: table staging, record loads"]
+         "telemetry, env words", "wait for the wave's other groups", "(of [2]) own-kart staging: atan2, max speed, Trigger distance", "(of [2]) forward wall ray", "(of [2]) four short rays", "(of [2]) KartS -> LDS", "B1 kernel: queue binning, stores (waited for)", "B1 kernel: table staging, record loads, sincos",
+         "tick kernel head: lane group + env words", "tick kernel head: table staging", "tick kernel tail: record stores (waited for)", "B1 kernel head: lane group + env words",
+         "tick kernel: a wave's whole life in a launch (not in the %)", "B1 kernel: a wave's whole life in a launch (not in the %)"]
+NST = len(NAMES)
 
 
 def build():
@@ -51,10 +54,12 @@ def main():
         if p.returncode or not line:
             print(p.stderr[-3000:]); return 1
         v = [int(x) for x in line[-1].split()[1:]]
-        tot = sum(v[:20]) or 1
-        print("waves that entered the loop (summed over launches): %d" % v[20])
-        for k in range(20):
-            print("  [%2d] %-50s %6.2f %%   %8.1f kcycles / wave-launch" % (k, NAMES[k], 100.0 * v[k] / tot, v[k] / max(v[20], 1) / 1e3))
+        tot = sum(v[:NST - 2]) or 1
+        print("waves of the tick kernel that entered the loop (summed over launches): %d; waves of the B1 kernel with work: %d" % (v[NST], v[NST + 1]))
+        B1 = (2, 3, 4, 5, 6, 7, 14, 15, 16, 17, 18, 19, 23, 25)        # (with the fission these phases run in the B1 kernel: per wave-launch of THAT kernel)
+        for k in range(NST):
+            waves = v[NST + 1] if (k in B1 and v[NST + 1]) else v[NST]
+            print("  [%2d] %-50s %6.2f %%   %8.1f kcycles / wave-launch" % (k, NAMES[k], 100.0 * v[k] / tot, v[k] / max(waves, 1) / 1e3))
         return 0
     import hierarchicalkarting_amd as hk
     env = hk.RacingEnv(hk.make_config(a.envs, a.agents, jitter_seed=0x5EED0000))
