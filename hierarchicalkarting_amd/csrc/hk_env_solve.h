@@ -598,49 +598,78 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
     HK_ST(h, 17);
     wave_lds_sync();
     HK_ST(h, 2);                       // [2] own-kart staging + the five wall rays
-    if (!me) return 0;
     const KartS* kq = &ks[threadIdx.x & ~(GA - 1)];   // the env's karts
-    const bool solving = (k.flags & HK_F_ENABLED) && LC.low_mode == HK_LOW_LQR && !((es.inactive_mask >> ego) & 1u);
-    if (!solving) return 0;
-    // ---- players (HKA:702-725)
-    uint32_t plm = 0;
-    int N = 0, nearbyAgents = -1;
-    for (int q = 0; q < LC.nall; q++) {
-        const uint32_t who = (LC.order >> (4 * q)) & 15u;
-        bool in = true;
-        if (A > 2) {
-            const KartS& o = kq[who];
-            in = mag3(o.px - k.px, 0.0f, o.pz - k.pz) < 8;
-            if (in) nearbyAgents += 1;
-        }
-        if (in) { plm |= who << (4 * N); N++; }
-    }
-    nearbyAgents = nearbyAgents > 1 ? nearbyAgents : 1;
-    const bool fixed = LC.high_mode == HK_HIGH_FIXED;
-    const hk_mcts_state* bel = mcts_all ? &mcts_all[(size_t)env * A + ego] : nullptr;
+    const bool solving = me && (k.flags & HK_F_ENABLED) && LC.low_mode == HK_LOW_LQR && !((es.inactive_mask >> ego) & 1u);
     const float dy = T.sec[0].marker_y - P.kart_y;                                    // Q13
-    HK_ST(h, 3);                       // [3] players within 8 m
-    if (N == 1) {
-        // single-player game: assemble into registers and run the whole Riccati recursion right here
-        GamePlayer loc;
-        HK_LP(9);
-        assemble_player<true>(P, T, env, ego, 0, N, nearbyAgents, plm, kq, fixed, LC.vbucket, dy, &loc, dbg_out, bel, games, 0);
-        HK_ST(h, 4);                   // [4] single-player assembly (heading heuristic, weights)
-        if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = 1;
-        HK_LP(10);
+    // my multi-player game, if I hold one: players (4 bits each), their count, HKA:721's count
+    uint32_t plm = 0;
+    int Nmp = 0, nearbyAgents = -1;
+    const bool fixed = LC.high_mode == HK_HIGH_FIXED;
+    if (solving) {
+        // ---- players (HKA:702-725)
+        int N = 0;
+        for (int q = 0; q < LC.nall; q++) {
+            const uint32_t who = (LC.order >> (4 * q)) & 15u;
+            bool in = true;
+            if (A > 2) {
+                const KartS& o = kq[who];
+                in = mag3(o.px - k.px, 0.0f, o.pz - k.pz) < 8;
+                if (in) nearbyAgents += 1;
+            }
+            if (in) { plm |= who << (4 * N); N++; }
+        }
+        nearbyAgents = nearbyAgents > 1 ? nearbyAgents : 1;
+        HK_ST(h, 3);                       // [3] players within 8 m
+        if (N == 1) {
+            // single-player game: assemble into registers and run the whole Riccati recursion right here
+            const hk_mcts_state* bel = mcts_all ? &mcts_all[(size_t)env * A + ego] : nullptr;
+            GamePlayer loc;
+            HK_LP(9);
+            assemble_player<true>(P, T, env, ego, 0, N, nearbyAgents, plm, kq, fixed, LC.vbucket, dy, &loc, dbg_out, bel, games, 0);
+            HK_ST(h, 4);                   // [4] single-player assembly (heading heuristic, weights)
+            if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = 1;
+            HK_LP(10);
 #ifndef HK_DUMMY_NO_LQ1
-        lq1_solve(P, loc, h, (dbg_out && (P.debug & 1)) ? &dbg_out[(size_t)env * A + ego] : nullptr, status);
+            lq1_solve(P, loc, h, (dbg_out && (P.debug & 1)) ? &dbg_out[(size_t)env * A + ego] : nullptr, status);
 #else
-        h.steering = (float)loc.tgt[3] * 0.01f; h.flags |= HK_F_ACCEL;
+            h.steering = (float)loc.tgt[3] * 0.01f; h.flags |= HK_F_ACCEL;
 #endif
-        HK_ST(h, 5);                   // [5] lq1_solve
-        return 0;
+            HK_ST(h, 5);                   // [5] lq1_solve
+        } else {
+            Nmp = N;
+            if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = N;
+        }
     }
-    for (int i = 0; i < N; i++) { HK_LP(11); } 
-    for (int i = 0; i < N; i++) assemble_player<false>(P, T, env, ego, i, N, nearbyAgents, plm, kq, fixed, LC.vbucket, dy, nullptr, dbg_out, bel, games, env * A + ego);
-    if (dbg_out && (P.debug & 1)) dbg_out[(size_t)env * A + ego].n_players = N;
+    // ---- multi-player games: every (ego, player) share of the lane group's games is an item, and the group's lanes take the items in turn.
+    // An ego used to assemble its N players one after the other in its own lane while the lanes without a game waited: once the field has
+    // spread, a game is a rare event (77 two-player games per solve launch of 262 144 egos), but the few waves that hold one finished
+    // 10 us after the others and the launch ended when they did (B1 kernel 106 -> 83 us with the assembly compiled out).  The two egos of a
+    // two-player game now take one share each of both games: half the time.  Same function, same arguments: the descriptors are unchanged.
+    // (The exchanges are among the lanes of the group, and the trip count is the same in all of them.)
+    {
+        const int lane0 = threadIdx.x & ~(GA - 1), li = threadIdx.x & (GA - 1);
+        int offs[GA], tot = 0;
+#pragma unroll
+        for (int q = 0; q < GA; q++) { offs[q] = tot; tot += quad_get(Nmp, q); }
+        for (int it0 = 0; it0 < tot; it0 += GA) {
+            HK_LP(11);
+            const int it = it0 + li;
+            int e = 0;
+#pragma unroll
+            for (int q = 0; q < GA; q++) if (it >= offs[q]) e = q;          // the last ego whose first item is not beyond `it` (egos without a game share their successor's offset)
+            int off_e = 0;
+#pragma unroll
+            for (int q = 0; q < GA; q++) if (e == q) off_e = offs[q];
+            const uint32_t plm_e = (uint32_t)__shfl((int)plm, lane0 | e, 64);
+            const int N_e = __shfl(Nmp, lane0 | e, 64), nb_e = __shfl(nearbyAgents, lane0 | e, 64);
+            const int fixed_e = __shfl(fixed ? 1 : 0, lane0 | e, 64), vb_e = __shfl(LC.vbucket, lane0 | e, 64);
+            if (it < tot)
+                assemble_player<false>(P, T, env, e, it - off_e, N_e, nb_e, plm_e, kq, fixed_e != 0, vb_e, dy, nullptr, dbg_out,
+                                       mcts_all ? &mcts_all[(size_t)env * A + e] : nullptr, games, env * A + e);
+        }
+    }
     HK_ST(h, 7);                       // [7] multi-player assembly
-    return N;                // the caller bins the game by N (wave-aggregated slot allocation needs every queued lane together)
+    return Nmp;              // the caller bins the game by its player count (wave-aggregated slot allocation needs every queued lane together)
 }
 
 #ifndef HK_HOST_EMU          // the solver kernels are not part of the host emulation of the tick kernel
