@@ -53,7 +53,7 @@ def pmc_fields(kernel, env_steps_per_launch=None):
                       "note": "the committed PMC summary was measured on other kernel sources (sources_sha16 %s, this tree %s)" % (d.get("sources_sha16"), source_hash())}, None
     k = d.get(kernel) or {}
     prov = {"file": os.path.relpath(PMC_SUMMARY, ROOT), "commit": d.get("commit"), "command": d.get("command"), "sources_sha16": d.get("sources_sha16"),
-            "method": "separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, mean of the kernel's 30 largest launches"}
+            "method": "separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE; " + str(d.get("note", ""))}
     sq = (k.get("sq") or {}).get("derived")
     binding = None
     if sq:

@@ -25,15 +25,21 @@ def rows(path):
     return per
 
 
+LAST = 0          # --last N: average the LAST N launches of each kernel (the steady state at the end of the profiled run) instead of the 30 largest
+
+
 def top_mean(per, key, top=30):
     by = collections.defaultdict(list)
-    for (name, _), v in per.items():
+    for (name, disp), v in sorted(per.items(), key=lambda kv: kv[0][1]):
         if key in v:
             by[name].append(v)
     out = {}
     for name, lst in by.items():
-        lst.sort(key=lambda v: -v[key])
-        sel = lst[:top]
+        if LAST:
+            sel = lst[-LAST:]
+        else:
+            lst.sort(key=lambda v: -v[key])
+            sel = lst[:top]
         out[name] = ({c: sum(v.get(c, 0.0) for v in sel) / len(sel) for c in sel[0]}, len(lst))
     return out
 
@@ -50,6 +56,9 @@ def main():
                 sq.append(a[i]); i += 1
         elif a[i] in ("--commit", "--command"):
             meta[a[i][2:]] = a[i + 1]; i += 2
+        elif a[i] == "--last":
+            global LAST
+            LAST = int(a[i + 1]); i += 2
         elif a[i] == "--env-steps-per-launch":          # what one full-size launch of the tick kernel advances in the profiled window (E x ticks per launch)
             meta["env_steps_per_launch"] = float(a[i + 1]); i += 2
         else:
@@ -61,7 +70,7 @@ def main():
     from source_hash import source_hash
     meta["sources_sha16"] = source_hash()                 # the tree the counters were measured on (bench.py checks it)
     out = {"note": "HBM bytes per launch from separate --pmc FETCH_SIZE / WRITE_SIZE passes (KiB -> bytes; fetch doubled: gfx950 correction); "
-                   "SQ counters from their own passes; per kernel the mean over its 30 largest launches", **meta}
+                   "SQ counters from their own passes; per kernel the mean over " + ("its last %d launches (the steady state at the end of the run)" % LAST if LAST else "its 30 largest launches"), **meta}
     for k in sorted(set(fetch) | set(write)):
         f = fetch.get(k, ({}, 0))[0].get("FETCH_SIZE", 0.0) * 1024.0
         w = write.get(k, ({}, 0))[0].get("WRITE_SIZE", 0.0) * 1024.0
