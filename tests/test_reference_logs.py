@@ -31,10 +31,10 @@ ALL = sorted(ORA)
 
 # statistic -> (low, high) of oracle / reference.  Round 4 (engine restatement with the WheelColliders' tire forces and contact yaw
 # response, KartAgent.Sensors[] in the scenes' order, the planner's full action list): every one of the 44 agent rows inside +-4 %.
-BANDS = {"median_best_lap": (0.96, 1.04), "mean_total_time": (0.96, 1.04)}
+BANDS = {"median_best_lap": (0.97, 1.03), "mean_total_time": (0.97, 1.03)}
 # The reference's lane-tracking metric (KartAgent.AverageLaneDifference, KA:226-239: distance to the target lane marker when a
 # Trigger is entered, minus 1.3 m): 0.8 - 1.45 x the reference's over the 44 rows (rounds 1 - 3, without tire side forces: 1.5 - 6 x)
-LANE_DIFF_BAND = (0.7, 2.0)
+LANE_DIFF_BAND = (0.75, 1.5)
 # AverageVelDifference (KA:235-239: speed minus planned speed at the Triggers) of the agents that follow a FIXED plan (15 m/s everywhere):
 # how fast the karts really are where the reference measures it; oracle - reference, m/s
 FIXED_VEL_DIFF_BAND = (-0.15, 0.45)
