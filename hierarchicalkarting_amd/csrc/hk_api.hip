@@ -805,6 +805,7 @@ static int check_device_status(hk_handle h)
         // reported once: the flag is cleared here (and by hk_reset), the unfinished envs keep their leftover ticks for the next hk_step
         const int keep = ~4;
         hipLaunchKernelGGL(hk::status_and_kernel, dim3(1), dim3(1), 0, h->stream, h->dev.status, keep);
+        HK_HIP(h, hipGetLastError());
         return fail(h, HK_ERR_HIP, "hk_step: an env did not complete its ticks (internal scheduling error)");
     }
     return HK_OK;
@@ -849,6 +850,8 @@ int hk_set_env_state(hk_handle h, const hk_env_state* in)
     if (!in) return fail(h, HK_ERR_INVALID, "NULL pointer");
     h->dev.P.hold_dedupe = 0;          // (as hk_set_agent_state: episode_steps may be rewound into a hold whose solves were skipped)
     HK_HIP(h, hipMemcpyAsync(h->dev.envs, in, (size_t)h->cfg.num_envs * sizeof(hk_env_state), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(hk::env_words_sanitize_kernel, dim3((h->cfg.num_envs + 255) / 256), dim3(256), 0, h->stream, h->dev.envs, h->cfg.num_envs);
+    HK_HIP(h, hipGetLastError());
     HK_HIP(h, hipStreamSynchronize(h->stream));
     return HK_OK;
 }

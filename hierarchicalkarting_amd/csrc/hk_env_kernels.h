@@ -32,6 +32,13 @@ int upload(T** dst, const std::vector<T>& v, std::string& err)
 }  // namespace detail
 
 __global__ void status_and_kernel(int* status, int mask) { atomicAnd(status, mask); }
+// hk_set_env_state: the progress words of hk_step are the library's (both 0 between calls but for the scheduling hint); a record the host
+// saved in the middle of nothing — or filled by hand — must not arm ticks or resume a phase (arming ADDS to reserved[0])
+__global__ void env_words_sanitize_kernel(hk_env_state* envs, int E)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env < E) { envs[env].reserved[0] = 0; envs[env].reserved[1] &= 16 /* ENV_PACK_HINT */; }
+}
 
 // point d.mcts (the kernel argument) at the move tables of gameParams class c
 inline void mcts_use_class(EnvDevice& d, int c)

@@ -155,7 +155,8 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
     int rc = HK_OK;
     if (d.last_solve_skippable && d.guard_rounds_left == 0) {
         // The tick launch before this one was the call's last (its completion guard): an env that queued a game there would be parked, i.e.
-        // the call incomplete, which the round count rules out (and the guard reports).  Nothing to solve: a one-tick call is 3 launches, not 4.
+        // the call incomplete, which the round count rules out.  The skip is verified ON THE DEVICE by that very launch: as the guard it
+        // raises status bit 2 for any env it leaves with ticks or a phase (a parked env has phase 1 or 2), and the next getter reports it.  Nothing to solve: a one-tick call is 3 launches, not 4.
         d.last_solve_skippable = false;
         d.round += 1;
         if (d.qbase == 0) d.call_ticks_issued = std::min(d.call_ticks_issued + (cfg.num_agents > 2 ? 4 : 1), d.call_ticks);

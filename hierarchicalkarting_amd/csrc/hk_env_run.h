@@ -23,7 +23,7 @@ namespace hk { namespace HK_GA_NS {
 __global__ __launch_bounds__(256) void env_arm_kernel(hk_env_state* envs, int E, int n_ticks, int* status)
 {
     // ADD to the ticks left: every env is at 0 here unless an earlier call failed its completion guard, and then its leftover ticks are
-    // not dropped.  The "did not complete" flag (status bit 2) is sticky: only the getter that reports it, hk_synchronize or hk_reset clear it.
+    // not dropped.  The "did not complete" flag (status bit 2) is sticky: only the getter that reports it (hk_get_agent_state / hk_get_env_state) and hk_reset clear it.
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env < E) envs[env].reserved[0] += n_ticks;
     (void)status;

@@ -341,7 +341,7 @@ int hk_get_observations(hk_handle h, float* obs);
 int hk_get_agent_state(hk_handle h, hk_agent_state* out /*[E][A]*/);
 int hk_set_agent_state(hk_handle h, const hk_agent_state* in /*[E][A]*/);   /* (MCTS agents: bestStates are copied into the new records on the next tick) */
 int hk_get_env_state(hk_handle h, hk_env_state* out /*[E]*/);
-int hk_set_env_state(hk_handle h, const hk_env_state* in /*[E]*/);
+int hk_set_env_state(hk_handle h, const hk_env_state* in /*[E]*/);            /* (reserved[0] is stored as 0 and reserved[1] keeps its hint bit only: the progress words are the library's) */
 int hk_get_episode_results(hk_handle h, hk_episode_result* out /*[E][A]*/);
 /* Agent.SendInfo: reward[E][A] = m_Reward, group_reward[E][A] = m_GroupReward collected since the last call; both reset to 0 */
 int hk_get_rewards(hk_handle h, float* reward, float* group_reward);

@@ -139,3 +139,24 @@ def test_complex_track_four_agents():
     g, o = _run(4, 24, 1200, 150, track="complex", jitter_seed=0x5EED0000)
     assert np.array_equal(g.observations(), o.observations())
     _run(2, 8, 600, 1, track="complex", jitter_seed=11)
+
+
+def test_restored_env_words_cannot_arm_ticks_or_resume_a_phase():
+    """hk_set_env_state stores the library's progress words as 0 / hint only (arming ADDS to reserved[0]): a snapshot restored with garbage in
+    them — a record filled by hand — runs exactly the ticks of the next hk_step, as the oracle does"""
+    import hierarchicalkarting_amd as hk
+    b = hk.make_config(64, 4, jitter_seed=0x5EED0000)
+    g = hk.RacingEnv(b); o = O.OracleEnv(b)
+    g.reset(); o.reset()
+    g.step(137); o.step(137)
+    ag, es = g.agent_state(), g.env_state()
+    bad = es.copy()
+    bad["reserved"][:, 0] = 7                 # "seven ticks left"
+    bad["reserved"][:, 1] = 1 | 16            # "waiting for controls", hint bit
+    g2 = hk.RacingEnv(b); g2.reset()
+    g2.set_agent_state(ag); g2.set_env_state(bad)
+    back = g2.env_state()
+    assert (back["reserved"][:, 0] == 0).all() and (back["reserved"][:, 1] == 16).all()
+    for n in (1, 3, 60):
+        g2.step(n); o.step(n)
+        _cmp(g2.agent_state(), o.agent_state(), g2.env_state(), o.env_state(), 137 + n)
