@@ -103,6 +103,7 @@ struct Tuning {
     bool keep_last_solve = false; // HK_KEEP_LAST_SOLVE=1: the last round of a fixed-round call launches its (empty) solver kernel, as before
     bool tail_worst_case = false; // HK_TAIL_WORST_CASE=1: the laggards' batches issue a round per cadence of the slowest env (the older schedule)
     int lazy_min_ticks = HK_LAZY_MIN_TICKS;    // HK_LAZY_MIN_TICKS: calls at least this long complete lazily (a look at the device instead of the worst-case rounds)
+    bool fission_mcts = true;    // ... and long calls of planner handles with LQNG low levels (HK_NO_FISSION_MCTS: the fused kernel for those)
     bool fission = true;         // plain 3- / 4-agent handles run the tick kernel without phase B1 + env_b1_kernel per solve cadence (hk_env_run.h); HK_FISSION=0: the fused kernel
     int debug_max_rounds = 0;    // HK_DEBUG_MAX_ROUNDS (diagnostic): cap on the rounds of a call, to look at the state in between
     bool debug_no_check = false; // HK_DEBUG_NO_CHECK (diagnostic): getters do not fail on the "did not complete" flag
@@ -119,7 +120,7 @@ struct Tuning {
         lazy_min_ticks = num("HK_LAZY_MIN_TICKS", HK_LAZY_MIN_TICKS, 1, 1 << 20);
         debug_max_rounds = num("HK_DEBUG_MAX_ROUNDS", 0, 0, 1 << 20);
         debug_no_check = flag("HK_DEBUG_NO_CHECK"); stamps_dump = flag("HK_STAMPS_DUMP");
-        { const char* f = std::getenv("HK_FISSION"); fission = !(f && std::atoi(f) == 0); }
+        { const char* f = std::getenv("HK_FISSION"); fission = !(f && std::atoi(f) == 0); fission_mcts = !flag("HK_NO_FISSION_MCTS"); }
     }
 };
 
@@ -560,6 +561,11 @@ static int step_ticks(hk_handle h, int n_ticks)
         if (rc) { g_last_error = h->err; return rc; }
     }
     if (pause) {
+        // the fission schedule for planner handles too (long calls, LQNG low levels; round 4): the same two kernels with the planner hooks
+        bool shaped_p = h->cfg.rewards != 0 || h->cfg.env_mode == HK_MODE_TRAINING;
+        for (int i = 0; i < h->cfg.num_agents; i++) shaped_p = shaped_p || h->cfg.training_agent[i] != 0;
+        h->dev.fission = h->tune.fission && h->tune.fission_mcts && !shaped_p && h->dev.P.eager && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4;
+        if (h->dev.fission) h->dev.P.run_cap = 4;
         h->dev.mcts_defer = true;                       // the rounds do not launch searches themselves
         const int cadence = h->cfg.num_agents > 2 ? 4 : 1;
         int maxleft = n_ticks;

@@ -100,16 +100,16 @@ inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
     bool train = d.P.training_reset != 0;
     for (int i = 0; i < cfg.num_agents; i++) train = train || d.P.training_agent[i] != 0;
 #if HK_GA == 4
-    if (d.fission && !train && !d.mcts.st && !d.rw.sec_time) {
+    if (d.fission && !train && !d.rw.sec_time) {
         // FISSION (hk_env_run.h): the tick kernel without phase B1; launch_b1 follows on the same stream
         const GameSoA G{d.games, (size_t)cfg.num_envs * cfg.num_agents};
         const unsigned blocks = (unsigned)((threads + 255) / 256);
-        if (d.tab_lds)
-            hipLaunchKernelGGL((env_run_kernel<false, false, false, true, true>), dim3(blocks), dim3(256), d.tab_lds, stream, d.P, d.agents, d.envs, d.results, G, d.queue_cnt,
-                               d.queue, d.round, d.act_steer, d.act_branch, d.lq_debug, d.status, d.mcts, d.mset, d.rw, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase, arm, guard);
-        else
-            hipLaunchKernelGGL((env_run_kernel<false, false, false, false, true>), dim3(blocks), dim3(256), 0, stream, d.P, d.agents, d.envs, d.results, G, d.queue_cnt,
-                               d.queue, d.round, d.act_steer, d.act_branch, d.lq_debug, d.status, d.mcts, d.mset, d.rw, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase, arm, guard);
+#define HK_FIS_RUN(MC, TL) hipLaunchKernelGGL((env_run_kernel<MC, false, false, TL, true>), dim3(blocks), dim3(256), TL ? d.tab_lds : 0, stream, d.P, d.agents, d.envs, \
+                               d.results, G, d.queue_cnt, d.queue, d.round, d.act_steer, d.act_branch, d.lq_debug, d.status, d.mcts, d.mset, d.rw, d.perm_valid ? d.perm : nullptr,        \
+                               d.game_stats, s0, s1, d.qbase, arm, guard)
+        if (d.mcts.st) { if (d.tab_lds) HK_FIS_RUN(true, true); else HK_FIS_RUN(true, false); }
+        else { if (d.tab_lds) HK_FIS_RUN(false, true); else HK_FIS_RUN(false, false); }
+#undef HK_FIS_RUN
         d.b1_due = true;
     } else
 #endif
@@ -131,12 +131,11 @@ inline int launch_b1(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std
     const long long threads = (long long)(s1 - s0) * GA;
     const GameSoA G{d.games, (size_t)cfg.num_envs * cfg.num_agents};
     const unsigned blocks = (unsigned)((threads + 255) / 256);
-    if (d.tab_lds)
-        hipLaunchKernelGGL((env_b1_kernel<true>), dim3(blocks), dim3(256), d.P.o_tmask, stream, d.P, d.agents, d.envs, G, d.queue_cnt, d.queue, d.round, d.lq_debug, d.status,
-                           d.mcts, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase);
-    else
-        hipLaunchKernelGGL((env_b1_kernel<false>), dim3(blocks), dim3(256), 0, stream, d.P, d.agents, d.envs, G, d.queue_cnt, d.queue, d.round, d.lq_debug, d.status,
-                           d.mcts, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase);
+#define HK_FIS_B1(TL, MC) hipLaunchKernelGGL((env_b1_kernel<TL, MC>), dim3(blocks), dim3(256), TL ? d.P.o_tmask : 0, stream, d.P, d.agents, d.envs, G, d.queue_cnt, d.queue, \
+                           d.round, d.lq_debug, d.status, d.mcts, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase, d.mset)
+    if (d.mcts.st) { if (d.tab_lds) HK_FIS_B1(true, true); else HK_FIS_B1(false, true); }
+    else { if (d.tab_lds) HK_FIS_B1(true, false); else HK_FIS_B1(false, false); }
+#undef HK_FIS_B1
     return launch_check(err, "env_b1_kernel");
 #else
     (void)d; (void)cfg; (void)stream; (void)err;

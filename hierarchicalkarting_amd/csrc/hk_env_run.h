@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_ru
                     if (qn == n) queue[(size_t)(n - 2) * P.E * P.A + pos] = env * P.A + i;
                 }
             }
-            if (M.st) phase_plan(P, M, mset, env, i, es, h.flags, h.section_index, h.lane, h.lane_changes, h.final_steer, arec);
+            // (FISSION: on a solve tick the planner hook follows SolveLQR, i.e. it runs in env_b1_kernel)
+            if (M.st && !(FISSION && b1_pending)) phase_plan(P, M, mset, env, i, es, h.flags, h.section_index, h.lane, h.lane_changes, h.final_steer, arec);
             // requests are posted on replan ticks (phase_plan) and on the reset tick (phase_begin): look again after those
             if (HAS_MCTS && P.mcts_pause && es.episode_steps % 100 == 0) held = group_or(mcts_search_outstanding(P, M, env, i) ? 1 : 0) != 0;
             HK_ST(h, 6);           // [6] queue binning (+ planner hooks)
@@ -320,11 +321,13 @@ __global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_ru
 #ifndef HK_B1_OCC
 #define HK_B1_OCC 2
 #endif
-template <bool TAB_LDS>
+template <bool TAB_LDS, bool HAS_MCTS = false>
 __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs, GameSoA games, int* queue_cnt_all,
-                                                        int* queue_all, int round, hk_lq_debug* dbg_out, int* status, MctsDev M, const int* perm,
-                                                        unsigned long long* stats, int slot0, int slot1, int qbase)
+                                                        int* queue_all, int round, hk_lq_debug* dbg_out, int* status, MctsDev Marg, const int* perm,
+                                                        unsigned long long* stats, int slot0, int slot1, int qbase, int mset)
 {
+    MctsDev M{};
+    if (HAS_MCTS) M = Marg;
 #ifdef HK_LANEPROF
     hk_lp_ptr = stats;
 #endif
@@ -356,6 +359,7 @@ __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_
     if (arec) {
         h.px = arec->px; h.pz = arec->pz; h.yaw = arec->yaw; h.vx = arec->vx; h.vz = arec->vz; h.wy = arec->wy;
         h.final_steer = arec->final_steer; h.section_index = arec->section_index; h.flags = arec->flags; h.steering = arec->steering;
+        if (HAS_MCTS) { h.lane = arec->lane; h.lane_changes = arec->lane_changes; }
     }
     const LaneCfg LC = lane_cfg(P, i);
     float hfx, hfz;
@@ -368,6 +372,8 @@ __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_
         if (qn == n) queue[(size_t)(n - 2) * P.E * P.A + pos] = env * P.A + i;
     }
     const bool queued = group_or(qn ? 1 : 0) != 0;
+    // the planner hook of a solve tick (HKA:330-402, after SolveLQR; every lane of the group calls it): replan request, bestStates -> plan entries
+    if (HAS_MCTS && M.st && pend) phase_plan(P, M, mset, env, i, es, h.flags, h.section_index, h.lane, h.lane_changes, h.final_steer, arec);
     if (arec) { arec->flags = h.flags; arec->steering = h.steering; }
     if (pend && i == 0) envs[env].reserved[1] = 1 | (queued ? ENV_PACK_HINT : 0);
 #ifdef HK_STAMPS
