@@ -609,7 +609,10 @@ static int step_ticks(hk_handle h, int n_ticks)
     bool shaped = h->cfg.rewards != 0 || h->cfg.env_mode == HK_MODE_TRAINING;       // reward shaping / Training mode: their own instantiations of the fused kernel
     for (int i = 0; i < h->cfg.num_agents; i++) shaped = shaped || h->cfg.training_agent[i] != 0;
     h->dev.fission = h->tune.fission && plain && !shaped && h->dev.P.eager && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4;
-    const int run_cap = h->dev.fission ? 4 : (lazy && h->cfg.num_agents > 2 && h->dev.ticks_since_reset >= hk::BULK_TICKS) ? spread_cap
+    // handles without an LQ agent (every low level an RL actor, attached or driven through hk_set_actions): the tick kernel of the fission
+    // schedule alone — phase B1 has nothing to solve, no env parks for it, no B1 launch
+    if (h->tune.fission && !shaped && h->dev.P.any_lqr == 0 && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4) h->dev.fission = true;     // (with a planner too: its hook stays in the tick loop)
+    const int run_cap = (h->dev.fission && h->dev.P.any_lqr != 0) ? 4 : (lazy && h->cfg.num_agents > 2 && h->dev.ticks_since_reset >= hk::BULK_TICKS) ? spread_cap
                         : (!lazy && plain && h->dev.P.eager) ? short_cap : hk::RUN_CAP;
     h->dev.P.run_cap = run_cap;
     // two halves on two streams (issue_rounds_split): the default for the long calls of plain handles since round 4 (1 472 vs 1 392 M

@@ -91,6 +91,7 @@ struct EnvParams {
     const SecGeo* sec_geo; // [L]
     int team_of[ENV_MAXA], time_precision[ENV_MAXA], section_window[ENV_MAXA];
     int mcts_iter, mcts_iter0, mcts_lat, mcts_lat0, any_mcts;
+    int any_lqr;            // agents whose low level is the LQ game (none: phase B1 has nothing to solve, the fission tick kernel never parks for it)
     int eager;          // 1: an env whose budget ends at a solve tick still assembles that tick's games before the launch ends (hk_env_run.h)
     int run_cap;        // ticks an env may run per launch (RUN_CAP; RUN_CAP_SPREAD for long calls on a spread field, hk_api.hip step_ticks)
     int mcts_pause;     // set per hk_step call: an env that requested a planner search stops at the next tick boundary until the search has run (hk_api.hip step_ticks)

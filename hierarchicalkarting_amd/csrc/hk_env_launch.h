@@ -110,7 +110,7 @@ inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
         if (d.mcts.st) { if (d.tab_lds) HK_FIS_RUN(true, true); else HK_FIS_RUN(true, false); }
         else { if (d.tab_lds) HK_FIS_RUN(false, true); else HK_FIS_RUN(false, false); }
 #undef HK_FIS_RUN
-        d.b1_due = true;
+        d.b1_due = d.P.any_lqr != 0;
     } else
 #endif
     if (train) HK_RUN(true, true, true);

@@ -90,6 +90,7 @@ inline int env_build_params(hk_config& cfg, std::vector<hk_section>& sections, s
         P.vbucket[i] = cfg.velocity_bucket_size[i];
         P.team_of[i] = cfg.team_of[i]; P.time_precision[i] = cfg.time_precision[i]; P.section_window[i] = cfg.section_window[i];
         if (cfg.high_mode[i] == HK_HIGH_MCTS) P.any_mcts += 1;
+        if (cfg.low_mode[i] == HK_LOW_LQR) P.any_lqr += 1;
         P.n_team[i] = cfg.n_team[i]; P.n_other[i] = cfg.n_other[i];
         for (int j = 0; j < ENV_MAXA; j++) { P.team[i][j] = cfg.team_agents[i][j]; P.other[i][j] = cfg.other_agents[i][j]; }
     }

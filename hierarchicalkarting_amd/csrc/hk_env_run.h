@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_ru
                     const bool act = (es.episode_steps & cmask) == 0 &&                                    // HKA:317 (Q9): episodeSteps % cadence
                                      !(!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u)) &&
                                      !(P.hold_dedupe && es.episode_steps > cadence && es.episode_steps < P.hold);
-                    if constexpr (FISSION) b1_pending = act;
+                    if constexpr (FISSION) b1_pending = act && P.any_lqr != 0;      // (no LQ agent: nothing for env_b1_kernel to do, the env moves on)
                     else qn = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
                     began = true;
                     solved = act;
