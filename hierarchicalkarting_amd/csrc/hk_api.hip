@@ -94,6 +94,7 @@ struct Tuning {
     bool mcts_pause = true;      // HK_MCTS_NO_PAUSE=1: long calls of planner handles keep the deadline schedule
     bool want_split = false;     // HK_SPLIT=1: the batch as two halves on two streams in EVERY call of a plain handle (short ones too)
     bool split_long = true;      // the default: ... in the long (lazily completed) calls of plain handles; HK_NO_SPLIT=1 / HK_SPLIT=0 switch it off
+    int lqn_sparse_blocks = 1024;   // HK_LQN_SPARSE_BLOCKS: workgroups per queue of a solver launch once the field has spread
     int split_ways = 2;          // HK_SPLIT_WAYS: parts of a split batch (2 .. SPLIT_WAYS_MAX), each on its own stream
     int split_min_ticks = 8;     // HK_SPLIT_MIN_TICKS: ... and in the calls of at least this many ticks that are not (a 20-tick call: 1 050 -> 1 120 M env-steps/s)
     bool no_split = false;       // HK_NO_SPLIT=1: one stream always, also while the field stands close
@@ -113,7 +114,7 @@ struct Tuning {
         auto flag = [](const char* n) { return std::getenv(n) != nullptr; };
         auto num = [](const char* n, int dflt, int lo, int hi) { const char* e = std::getenv(n); const int v = e ? std::atoi(e) : dflt; return v >= lo && v <= hi ? v : dflt; };
         eager = !flag("HK_NO_EAGER"); lazy = !flag("HK_FIXED_ROUNDS"); mcts_pause = !flag("HK_MCTS_NO_PAUSE");
-        { const char* sp = std::getenv("HK_SPLIT"); want_split = sp && std::atoi(sp) != 0; no_split = flag("HK_NO_SPLIT"); split_long = !no_split && !(sp && std::atoi(sp) == 0); } split_min_ticks = num("HK_SPLIT_MIN_TICKS", 8, 1, 1 << 20); split_ways = num("HK_SPLIT_WAYS", 2, 2, hk::SPLIT_WAYS_MAX); tail_worst_case = flag("HK_TAIL_WORST_CASE"); keep_last_solve = flag("HK_KEEP_LAST_SOLVE");
+        { const char* sp = std::getenv("HK_SPLIT"); want_split = sp && std::atoi(sp) != 0; no_split = flag("HK_NO_SPLIT"); split_long = !no_split && !(sp && std::atoi(sp) == 0); } split_min_ticks = num("HK_SPLIT_MIN_TICKS", 8, 1, 1 << 20); split_ways = num("HK_SPLIT_WAYS", 2, 2, hk::SPLIT_WAYS_MAX); lqn_sparse_blocks = num("HK_LQN_SPARSE_BLOCKS", 1024, 16, 4096); tail_worst_case = flag("HK_TAIL_WORST_CASE"); keep_last_solve = flag("HK_KEEP_LAST_SOLVE");
         run_cap_spread = num("HK_RUN_CAP_SPREAD", hk::RUN_CAP_SPREAD, 4, 64);
         run_cap_short = num("HK_RUN_CAP_SHORT", 4, 4, 64);
         regroup_rounds = num("HK_REGROUP_ROUNDS", hk::REGROUP_ROUNDS, 1, 1 << 20);
@@ -539,6 +540,7 @@ static int step_ticks(hk_handle h, int n_ticks)
     if (short_call) h->dev.mcts_ticks += n_ticks;
     h->dev.mcts_defer = short_call;
     h->dev.ticks_since_reset += h->dev.call_ticks;      // the previous call's ticks
+    h->dev.lqn_sparse_blocks = h->tune.lqn_sparse_blocks;
     h->dev.call_ticks = n_ticks; h->dev.call_ticks_issued = 0;
     // Long calls of a planner handle without attached actors run in PAUSE mode: an env that requests a search stops at the next
     // tick boundary until the search has run, the host runs a stretch of rounds (every env reaches its replan tick or the end of

@@ -169,8 +169,11 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
         // no barriers (hk_lq2_pair.h); the 3- and 4-player queues to the matrix-core solver (hk_lq_mfma.h), one game per wave,
         // 1 024 workgroups per game size (one wave per SIMD) walking their queue grid-stride.
         const int sizes = cfg.num_agents > 2 ? std::min(cfg.num_agents, 4) - 2 : 0;     // player counts 3 .. min(A, 4)
-        const int n34 = sizes ? std::min(ngames, 1024) * sizes : 0;          // 1 024 waves per game size walk their queue grid-stride; the queue length picks the solver (lqn_round_kernel)
-        const int n2 = std::min((ngames + 31) / 32, bulk ? 4096 : 1024);
+        // (a spread field queues a few dozen games per launch: d.lqn_sparse_blocks workgroups per queue then — every wave of this kernel needs a SIMD's
+        // whole register file, and in the two-stream schedule each one waits for a SIMD the other half's tick / B1 waves have left)
+        const int per = bulk ? 1024 : d.lqn_sparse_blocks;
+        const int n34 = sizes ? std::min(ngames, per) * sizes : 0;          // `per` waves per game size walk their queue grid-stride; the queue length picks the solver (lqn_round_kernel)
+        const int n2 = std::min((ngames + 31) / 32, bulk ? 4096 : per);
         hipLaunchKernelGGL(lqn_round_kernel, dim3(n34 + n2), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status,
                            n34, sizes ? sizes : 1, n2, d.game_stats, LQN_BULK_GAMES);
         if ((rc = launch_check(err, "lqn_round_kernel"))) return rc;
