@@ -8,7 +8,12 @@ bodies), disassembles the methods on that call path and checks the facts the res
     pivot = the first row whose |.| is STRICTLY larger (ble.un skips on <= and on NaN); whole-row swap; the entries below the diagonal
     are DIVIDED by the pivot (no reciprocal);
   * UserLU.Solve(Matrix, Matrix) and (Vector, Vector): row swaps of the right-hand side in pivot order, forward substitution k ascending
-    with temp = B[k,j] * LU[i,k]; B[i,j] = B[i,j] - temp, backward substitution k descending with B[k,j] /= LU[k,k] first.
+    with temp = B[k,j] * LU[i,k]; B[i,j] = B[i,j] - temp, backward substitution k descending with B[k,j] /= LU[k,k] first;
+  * (round 4) the sparse products of KartLQR.cs:78-117 — Multiply on two SparseMatrix (DoMultiplySparse, Gustavson's row product),
+    TransposeThisAndMultiply with a Matrix (Double.Matrix's dense triple loop: SparseMatrix does not override it) and with a Vector: every
+    one accumulates k ASCENDING and as `s = s + a * b`, a multiply and an add with a rounding each (IL `mul add`; Mono does not contract).
+    The arithmetic contract of this repository keeps that order and fuses the two roundings (`s = fma(a, b, s)`, which is what
+    the fp64 matrix core computes): that one rounding per term is the whole difference to MathNet, bounded in tests/test_lq_numpy_mirror.py.
 
 Nothing of the binary is copied: the tool reads it where it lies, and tests/test_mathnet_il.py keeps only these facts and the file's SHA-256
 (tests/golden/mathnet_userlu_facts.json).  usage: python tools/mathnet_il.py [--dump TYPE::METHOD ...] [--update]"""
@@ -260,6 +265,27 @@ def check(asm):
         # the forward sweep counts up (add before the mul ... blt), the backward sweep starts at n - 1 and counts down
         assert re.search(r"ldc\.i4\.1 sub " + ST + r"br", body[i_fwd:i_div + 400])
         F["Solve(%s): pivots' row swaps, forward k ascending (temp = B[k]*LU[i,k]; B[i] -= temp), backward k descending with B[k] /= LU[k,k] first" % kind] = True
+    # ---- the sparse products of KartLQR.cs:78-117 (every matrix there is CreateMatrix.Sparse: SparseMatrix on CSR storage)
+    dm = [shape(asm.disasm(m)) for m in asm.find(NS + ".Double", "SparseMatrix", "DoMultiply")]
+    assert sum("call Double.SparseMatrix::DoMultiplySparse " in x for x in dm) == 1
+    F["SparseMatrix.DoMultiply(Matrix, Matrix) hands sparse operands to DoMultiplySparse"] = True
+    g = shape(asm.disasm(asm.find(NS + ".Double", "SparseMatrix", "DoMultiplySparse")[0]))
+    # Gustavson's row product: for row i, for each stored (i, k) of this in storage order (CSR: k ascending), for each stored (k, j) of other:
+    # first touch of column j in this row: c[j] = a * b (stored as it is); later: c[j] = c[j] + a * b  (mul, then add: two roundings)
+    assert re.search(V + V + r"mul stelem\.r8 ", g) and re.search(r"ldelema Double dup ldind\.r8 " + V + V + r"mul add stind\.r8 ", g)
+    assert g.count(" mul ") == 2 and " sub " not in g and " div " not in g and "callvirt spec::Normalize" in g
+    assert len(re.findall(r"ldc\.i4\.1 add " + ST, g)) >= 6 and "ldc.i4.1 sub" not in g          # every loop counts up
+    F["DoMultiplySparse: rows of this, its stored entries k ascending, other's row k; c[j] = a*b on first touch, else c[j] = c[j] + a*b (mul, then add)"] = True
+    tt = asm.find(NS + ".Double", "SparseMatrix", "DoTransposeThisAndMultiply")
+    assert len(tt) == 1
+    t = shape(asm.disasm(tt[0]))
+    assert "callvirt spec::get_Item" in t and re.search(r"callvirt spec::get_Item " + V + V + r"ldelem\.r8 " + V + r"mul add callvirt spec::set_Item ", t) and "ldc.i4.1 sub" not in t
+    F["SparseMatrix.DoTransposeThisAndMultiply exists for (Vector, Vector) only: rows k ascending, result[j] = result[j] + value * right[k] (mul, then add)"] = True
+    base = [shape(asm.disasm(m)) for m in asm.find(NS + ".Double", "Matrix", "DoTransposeThisAndMultiply")]
+    mm = [b for b in base if b.count("spec::At ") == 3]
+    assert len(mm) == 1 and re.search(r"ldc\.r8 0\.0 " + ST, mm[0]) and re.search(V + V + V + V + r"call spec::At " + V + V + V + r"callvirt spec::At mul add " + ST, mm[0])
+    assert "ldc.i4.1 sub" not in mm[0] and mm[0].count(" mul ") == 1
+    F["TransposeThisAndMultiply(Matrix) on a SparseMatrix runs Double.Matrix's loop: s = 0.0; s = s + this.At(k, j) * other.At(k, i) for EVERY k ascending (mul, then add)"] = True
     return F
 
 
