@@ -104,6 +104,7 @@ struct Tuning {
     bool keep_last_solve = false; // HK_KEEP_LAST_SOLVE=1: the last round of a fixed-round call launches its (empty) solver kernel, as before
     bool tail_worst_case = false; // HK_TAIL_WORST_CASE=1: the laggards' batches issue a round per cadence of the slowest env (the older schedule)
     int lazy_min_ticks = HK_LAZY_MIN_TICKS;    // HK_LAZY_MIN_TICKS: calls at least this long complete lazily (a look at the device instead of the worst-case rounds)
+    bool fission_chunks = true;  // ... and the short fixed-round calls of planner / actor handles (HK_NO_FISSION_CHUNKS: the fused kernel)
     bool fission_mcts = true;    // ... and long calls of planner handles with LQNG low levels (HK_NO_FISSION_MCTS: the fused kernel for those)
     bool fission = true;         // plain 3- / 4-agent handles run the tick kernel without phase B1 + env_b1_kernel per solve cadence (hk_env_run.h); HK_FISSION=0: the fused kernel
     int debug_max_rounds = 0;    // HK_DEBUG_MAX_ROUNDS (diagnostic): cap on the rounds of a call, to look at the state in between
@@ -121,7 +122,7 @@ struct Tuning {
         lazy_min_ticks = num("HK_LAZY_MIN_TICKS", HK_LAZY_MIN_TICKS, 1, 1 << 20);
         debug_max_rounds = num("HK_DEBUG_MAX_ROUNDS", 0, 0, 1 << 20);
         debug_no_check = flag("HK_DEBUG_NO_CHECK"); stamps_dump = flag("HK_STAMPS_DUMP");
-        { const char* f = std::getenv("HK_FISSION"); fission = !(f && std::atoi(f) == 0); fission_mcts = !flag("HK_NO_FISSION_MCTS"); }
+        { const char* f = std::getenv("HK_FISSION"); fission = !(f && std::atoi(f) == 0); fission_mcts = !flag("HK_NO_FISSION_MCTS"); fission_chunks = !flag("HK_NO_FISSION_CHUNKS"); }
     }
 };
 
@@ -614,6 +615,10 @@ static int step_ticks(hk_handle h, int n_ticks)
     // handles without an LQ agent (every low level an RL actor, attached or driven through hk_set_actions): the tick kernel of the fission
     // schedule alone — phase B1 has nothing to solve, no env parks for it, no B1 launch
     if (h->tune.fission && !shaped && h->dev.P.any_lqr == 0 && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4) h->dev.fission = true;     // (with a planner too: its hook stays in the tick loop)
+    // handles that step in short fixed-round chunks (attached actors: a chunk per decision; planners outside their long calls): the same two
+    // kernels without the eager assembly — an env parks at its solve tick, B1 + solver run, the next round resumes it; the rounds issued
+    // are the worst case the fused kernel was given too (a round per solve tick of the chunk + 1)
+    if (h->tune.fission && h->tune.fission_chunks && !shaped && (planner || h->n_policies > 0) && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4) h->dev.fission = true;
     const int run_cap = (h->dev.fission && h->dev.P.any_lqr != 0) ? 4 : (lazy && h->cfg.num_agents > 2 && h->dev.ticks_since_reset >= hk::BULK_TICKS) ? spread_cap
                         : (!lazy && plain && h->dev.P.eager) ? short_cap : hk::RUN_CAP;
     h->dev.P.run_cap = run_cap;
