@@ -57,7 +57,7 @@ def pmc_fields(kernel, env_steps_per_launch=None):
     sq = (k.get("sq") or {}).get("derived")
     binding = None
     if sq:
-        binding = {"resource": "VALU issue", "wave_issuing_valu_frac": sq.get("wave_issuing_valu_frac"), "wave_issuing_any_frac": sq.get("wave_issuing_any_frac"),
+        binding = {"resource": "neither roof: VALU issue (two waves per SIMD) + waits at the head and tail of a launch (profiles/r04_e_launch_head_tail.txt)", "wave_issuing_valu_frac": sq.get("wave_issuing_valu_frac"), "wave_issuing_any_frac": sq.get("wave_issuing_any_frac"),
                    "wave_waiting_frac": sq.get("wave_waiting_frac"), "waves_per_simd": d.get("waves_per_simd", 2),
                    "simd_valu_busy_frac": min(1.0, d.get("waves_per_simd", 2) * (sq.get("wave_issuing_valu_frac") or 0.0)),
                    "valu_lanes_active_of_64": sq.get("valu_lanes_active_of_64"), "valu_insts_per_launch": sq.get("valu_insts_per_launch"),
