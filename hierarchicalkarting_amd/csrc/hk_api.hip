@@ -681,7 +681,7 @@ static int policy_decide(hk_handle h)
         const hk::PolicyDevice& pd = h->policy[p];
         const int pairs = E * pd.q.n_slots;
         const int w = (int)(decision % (unsigned long long)pd.q.stack);
-        hipLaunchKernelGGL(hk::policy_stack_kernel, dim3((pairs + 1) / 2), dim3(256), 0, h->stream, pd.q, E, A, h->dev.envs,
+        hipLaunchKernelGGL(hk::policy_stack_kernel, dim3((pairs + 1) / 2), dim3(256), 0, h->stream, pd.q, E, A, h->dev.envs, h->dev.slot_of,
                            h->dev.obs, w);
         HK_HIP(h, hipGetLastError());
     }
@@ -833,6 +833,8 @@ int hk_get_agent_state(hk_handle h, hk_agent_state* out)
     if (!out) return fail(h, HK_ERR_INVALID, "NULL pointer");
     { int rc = check_device_status(h); if (rc) return rc; }
     const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
+    // the per-tick fields live in the hot tiles (hk_env_device.h): gather them into the records first
+    { int rc = hk::ga_ops(h->dev).launch_hot_gather(h->dev, h->cfg, h->stream, h->err); if (rc) { g_last_error = h->err; return rc; } }
     HK_HIP(h, hipMemcpyAsync(out, h->dev.agents, cnt * sizeof(hk_agent_state), hipMemcpyDeviceToHost, h->stream));
     HK_HIP(h, hipStreamSynchronize(h->stream));
     return HK_OK;
@@ -843,8 +845,17 @@ int hk_set_agent_state(hk_handle h, const hk_agent_state* in)
     HK_NEED_ENV(h);
     if (!in) return fail(h, HK_ERR_INVALID, "NULL pointer");
     const size_t cnt = (size_t)h->cfg.num_envs * h->cfg.num_agents;
+    // the device divides by the section count with a multiply-shift that is exact for 0 <= x < 2^32 / L (hk_env_device.h div_L): a rewound or
+    // hand-built record outside that range would index the track tables with garbage
+    {
+        const int64_t lim = (int64_t)(0x100000000ull / (uint64_t)std::max(1, h->cfg.num_sections)) - 2048;
+        for (size_t t = 0; t < cnt; t++)
+            if (in[t].section_index < 0 || in[t].init_checkpoint_index < 0 || in[t].section_index >= lim || in[t].init_checkpoint_index >= lim)
+                return fail(h, HK_ERR_INVALID, "hk_set_agent_state: section_index / init_checkpoint_index out of range (negative, or beyond 2^32 / num_sections)");
+    }
     h->dev.P.hold_dedupe = 0;          // the host moves karts by hand: a held kart is no longer guaranteed to be where its last solve saw it
     HK_HIP(h, hipMemcpyAsync(h->dev.agents, in, cnt * sizeof(hk_agent_state), hipMemcpyHostToDevice, h->stream));
+    { int rc = hk::ga_ops(h->dev).launch_hot_scatter(h->dev, h->cfg, h->stream, h->err); if (rc) { g_last_error = h->err; return rc; } }
     { int rc = hk::env_mcts_invalidate(h->dev, h->cfg, h->stream, h->err); if (rc) { g_last_error = h->err; return rc; } }   // plans were rewritten
     HK_HIP(h, hipStreamSynchronize(h->stream));
     return HK_OK;
@@ -855,7 +866,8 @@ int hk_get_env_state(hk_handle h, hk_env_state* out)
     HK_NEED_ENV(h);
     if (!out) return fail(h, HK_ERR_INVALID, "NULL pointer");
     { int rc = check_device_status(h); if (rc) return rc; }
-    HK_HIP(h, hipMemcpyAsync(out, h->dev.envs, (size_t)h->cfg.num_envs * sizeof(hk_env_state), hipMemcpyDeviceToHost, h->stream));
+    { int rc = hk::ga_ops(h->dev).launch_envs_gather(h->dev, h->cfg, h->stream, h->err); if (rc) { g_last_error = h->err; return rc; } }
+    HK_HIP(h, hipMemcpyAsync(out, h->dev.envs_stage, (size_t)h->cfg.num_envs * sizeof(hk_env_state), hipMemcpyDeviceToHost, h->stream));
     HK_HIP(h, hipStreamSynchronize(h->stream));
     return HK_OK;
 }
@@ -865,9 +877,8 @@ int hk_set_env_state(hk_handle h, const hk_env_state* in)
     HK_NEED_ENV(h);
     if (!in) return fail(h, HK_ERR_INVALID, "NULL pointer");
     h->dev.P.hold_dedupe = 0;          // (as hk_set_agent_state: episode_steps may be rewound into a hold whose solves were skipped)
-    HK_HIP(h, hipMemcpyAsync(h->dev.envs, in, (size_t)h->cfg.num_envs * sizeof(hk_env_state), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(hk::env_words_sanitize_kernel, dim3((h->cfg.num_envs + 255) / 256), dim3(256), 0, h->stream, h->dev.envs, h->cfg.num_envs);
-    HK_HIP(h, hipGetLastError());
+    HK_HIP(h, hipMemcpyAsync(h->dev.envs_stage, in, (size_t)h->cfg.num_envs * sizeof(hk_env_state), hipMemcpyHostToDevice, h->stream));
+    { int rc = hk::ga_ops(h->dev).launch_envs_scatter(h->dev, h->cfg, h->stream, h->err); if (rc) { g_last_error = h->err; return rc; } }   // (progress words sanitized on the way)
     HK_HIP(h, hipStreamSynchronize(h->stream));
     return HK_OK;
 }
@@ -1043,7 +1054,15 @@ int hk_get_lq_debug(hk_handle h, int env, int ego, hk_lq_debug* out)
 }
 
 void* hk_device_results_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.results : nullptr; }
-void* hk_device_agents_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.agents : nullptr; }
+void* hk_device_agents_ptr(hk_handle h)
+{
+    // a SNAPSHOT: the per-tick fields are gathered from the hot tiles into the records (asynchronously, on the handle's stream) by this call
+    if (!h || !h->env_ready) return nullptr;
+    if (hipSetDevice(h->device) != hipSuccess) return nullptr;
+    if (h->step_pending && finish_ticks(h) != HK_OK) return nullptr;
+    if (hk::ga_ops(h->dev).launch_hot_gather(h->dev, h->cfg, h->stream, h->err) != HK_OK) { g_last_error = h->err; return nullptr; }
+    return (void*)h->dev.agents;
+}
 void* hk_device_obs_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.obs : nullptr; }
 void* hk_device_act_steer_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.act_steer : nullptr; }
 void* hk_device_act_branch_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.act_branch : nullptr; }

@@ -546,117 +546,80 @@ __device__ unsigned long long* hk_lp_ptr;
 #define HK_ST(h, k) do { } while (0)
 #endif
 
-// the fields of hk_agent_state that change every tick, kept in registers across the ticks of the fused kernel
-// (the plan arrays and the reward stay in the global record)
+// The fields of hk_agent_state that change every tick ("hot" fields).  On the device they do NOT live in the 460-byte AoS records:
+// their home is the HOT TILE array — one tile per wave of the tick kernel, field-major, 64 consecutive dwords per field (AoSoA) — so that
+// the head and the tail of a launch are 32 coalesced 256-byte rows per wave instead of 32 x 64 scattered dwords (round 5; the scattered
+// form kept a CU's address path busy for ~14 us per launch: 2 x 32 instructions x 64 lines x 8 waves).  Tiles are indexed by the lane-group
+// SLOT, not by the env id: a regroup moves tiles and env words physically (env_regroup_scatter_kernel), `perm[slot] = env` and
+// `slot_of[env] = slot` translate for everything that is indexed by env id (cold records, results, queues, planner state).  The hot
+// fields of the AoS record are a staging copy only: written by hot_gather_kernel for hk_get_agent_state, read by hot_scatter_kernel
+// after hk_set_agent_state, and used as scratch by the reset path (reset_agent rewrites the whole record, plans included).
+#define HK_HOT_FIELDS(X)                                                                                                              \
+    X(float, px) X(float, pz) X(float, yaw) X(float, vx) X(float, vz) X(float, wy) X(float, acc_ang_v) X(float, steering)             \
+    X(float, avg_lane_diff) X(float, avg_vel_diff) X(float, final_steer) X(float, contact_nx) X(float, contact_nz)                    \
+    X(int, section_index) X(int, lane) X(int, lane_changes) X(int, illegal_lane_changes) X(int, forward_collisions)                   \
+    X(int, last_collision_time) X(int, time_steps) X(int, init_checkpoint_index) X(uint32_t, flags) X(uint32_t, trig_lo)              \
+    X(uint32_t, trig_hi) X(int, tele_completed_laps) X(int, tele_lap_end_step) X(float, tele_last_lap) X(float, tele_best_lap)        \
+    X(float, tele_total_time) X(float, steer_smoothed) X(float, wheel_uf) X(float, wheel_ur)
+enum HotField {
+#define HK_X(T, n) HF_##n,
+    HK_HOT_FIELDS(HK_X)
+#undef HK_X
+    HF_N
+};
+static_assert(HF_N == 32, "a hot tile is 32 rows of 64 dwords");
+constexpr int HOT_TILE_WORDS = HF_N * 64;
+// words of the tile array for E lane groups of GA lanes (whole tiles)
+__host__ __device__ inline size_t hot_words(int E, int GA) { const int gpw = 64 / GA; return (size_t)((E + gpw - 1) / gpw) * HOT_TILE_WORDS; }
+// word index of field 0 of lane (slot, i); field f sits f * 64 words further.  For the tick kernel's own lane this is
+// (gid / 64) * HOT_TILE_WORDS + gid % 64 with gid = slot * GA + i: a wave's row is one contiguous 256-byte run.
+template <int GA>
+__host__ __device__ __forceinline__ size_t hot_base(int slot, int i)
+{
+    constexpr int GPW = 64 / GA;
+    return (size_t)(slot / GPW) * HOT_TILE_WORDS + (size_t)((slot % GPW) * GA + i);
+}
+template <class T> __host__ __device__ __forceinline__ T hot_get(const uint32_t* p, int f) { return __builtin_bit_cast(T, p[f * 64]); }
+template <class T> __host__ __device__ __forceinline__ void hot_put(uint32_t* p, int f, T v) { p[f * 64] = __builtin_bit_cast(uint32_t, v); }
+
 struct Hot {
 #ifdef HK_STAMPS
     unsigned long long st_t;
     unsigned st_acc[HK_NSTAMP];
 #endif
-    float px;
-    float pz;
-    float yaw;
-    float vx;
-    float vz;
-    float wy;
-    float acc_ang_v;
-    float steering;
-    float avg_lane_diff;
-    float avg_vel_diff;
-    float final_steer;
-    float contact_nx;
-    float contact_nz;
-    int section_index;
-    int lane;
-    int lane_changes;
-    int illegal_lane_changes;
-    int forward_collisions;
-    int last_collision_time;
-    int time_steps;
-    int init_checkpoint_index;
-    uint32_t flags;
-    uint32_t trig_lo;
-    uint32_t trig_hi;
-    int tele_completed_laps;
-    int tele_lap_end_step;
-    float tele_last_lap;
-    float tele_best_lap;
-    float tele_total_time;
-    float steer_smoothed;
-    float wheel_uf;
-    float wheel_ur;
+#define HK_X(T, n) T n;
+    HK_HOT_FIELDS(HK_X)
+#undef HK_X
 };
-__device__ __forceinline__ Hot load_hot(const hk_agent_state* a)
+// AoS record <-> registers (the staging copy: reset path, hk_get / hk_set_agent_state)
+__host__ __device__ __forceinline__ Hot load_hot(const hk_agent_state* a)
 {
     Hot h;
-    h.px = a->px;
-    h.pz = a->pz;
-    h.yaw = a->yaw;
-    h.vx = a->vx;
-    h.vz = a->vz;
-    h.wy = a->wy;
-    h.acc_ang_v = a->acc_ang_v;
-    h.steering = a->steering;
-    h.avg_lane_diff = a->avg_lane_diff;
-    h.avg_vel_diff = a->avg_vel_diff;
-    h.final_steer = a->final_steer;
-    h.contact_nx = a->contact_nx;
-    h.contact_nz = a->contact_nz;
-    h.section_index = a->section_index;
-    h.lane = a->lane;
-    h.lane_changes = a->lane_changes;
-    h.illegal_lane_changes = a->illegal_lane_changes;
-    h.forward_collisions = a->forward_collisions;
-    h.last_collision_time = a->last_collision_time;
-    h.time_steps = a->time_steps;
-    h.init_checkpoint_index = a->init_checkpoint_index;
-    h.flags = a->flags;
-    h.trig_lo = a->trig_lo;
-    h.trig_hi = a->trig_hi;
-    h.tele_completed_laps = a->tele_completed_laps;
-    h.tele_lap_end_step = a->tele_lap_end_step;
-    h.tele_last_lap = a->tele_last_lap;
-    h.tele_best_lap = a->tele_best_lap;
-    h.tele_total_time = a->tele_total_time;
-    h.steer_smoothed = a->steer_smoothed;
-    h.wheel_uf = a->wheel_uf;
-    h.wheel_ur = a->wheel_ur;
+#define HK_X(T, n) h.n = a->n;
+    HK_HOT_FIELDS(HK_X)
+#undef HK_X
     return h;
 }
-__device__ __forceinline__ void store_hot(hk_agent_state* a, const Hot& h)
+__host__ __device__ __forceinline__ void store_hot(hk_agent_state* a, const Hot& h)
 {
-    a->px = h.px;
-    a->pz = h.pz;
-    a->yaw = h.yaw;
-    a->vx = h.vx;
-    a->vz = h.vz;
-    a->wy = h.wy;
-    a->acc_ang_v = h.acc_ang_v;
-    a->steering = h.steering;
-    a->avg_lane_diff = h.avg_lane_diff;
-    a->avg_vel_diff = h.avg_vel_diff;
-    a->final_steer = h.final_steer;
-    a->contact_nx = h.contact_nx;
-    a->contact_nz = h.contact_nz;
-    a->section_index = h.section_index;
-    a->lane = h.lane;
-    a->lane_changes = h.lane_changes;
-    a->illegal_lane_changes = h.illegal_lane_changes;
-    a->forward_collisions = h.forward_collisions;
-    a->last_collision_time = h.last_collision_time;
-    a->time_steps = h.time_steps;
-    a->init_checkpoint_index = h.init_checkpoint_index;
-    a->flags = h.flags;
-    a->trig_lo = h.trig_lo;
-    a->trig_hi = h.trig_hi;
-    a->tele_completed_laps = h.tele_completed_laps;
-    a->tele_lap_end_step = h.tele_lap_end_step;
-    a->tele_last_lap = h.tele_last_lap;
-    a->tele_best_lap = h.tele_best_lap;
-    a->tele_total_time = h.tele_total_time;
-    a->steer_smoothed = h.steer_smoothed;
-    a->wheel_uf = h.wheel_uf;
-    a->wheel_ur = h.wheel_ur;
+#define HK_X(T, n) a->n = h.n;
+    HK_HOT_FIELDS(HK_X)
+#undef HK_X
+}
+// hot tile <-> registers; p = tiles + hot_base<GA>(slot, i)
+__host__ __device__ __forceinline__ Hot load_hot_tile(const uint32_t* p)
+{
+    Hot h;
+#define HK_X(T, n) h.n = hot_get<T>(p, HF_##n);
+    HK_HOT_FIELDS(HK_X)
+#undef HK_X
+    return h;
+}
+__host__ __device__ __forceinline__ void store_hot_tile(uint32_t* p, const Hot& h)
+{
+#define HK_X(T, n) hot_put<T>(p, HF_##n, h.n);
+    HK_HOT_FIELDS(HK_X)
+#undef HK_X
 }
 
 // Sensor.Transform.forward: the kart's forward (fx, fz) turned by the sensor's local yaw (Unity Y rotation, +z toward +x)

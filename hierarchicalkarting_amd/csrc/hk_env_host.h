@@ -15,8 +15,14 @@
 namespace hk {
 
 struct EnvDevice {
-    hk_agent_state* agents = nullptr;
-    hk_env_state* envs = nullptr;
+    hk_agent_state* agents = nullptr;   // [E][A] by env id: the cold fields (plans, rewards); its hot fields are a staging copy (hk_env_device.h)
+    // Stored by lane-group SLOT and moved physically by a regroup (double buffered; launch_regroup swaps the pairs):
+    uint32_t* hot = nullptr;       // hot tiles [ceil(E / (64 / GA))][32 fields][64 lanes]
+    uint32_t* hot_alt = nullptr;
+    hk_env_state* envs = nullptr;  // [E] env words of the lane group in each slot
+    hk_env_state* envs_alt = nullptr;
+    hk_env_state* envs_stage = nullptr;   // [E] by env id: what hk_get / hk_set_env_state copy
+    int* slot_of = nullptr;        // [E] env id -> slot (perm below is the inverse)
     hk_episode_result* results = nullptr;
     hk_lq_debug* lq_debug = nullptr;
     float* obs = nullptr;
@@ -53,7 +59,8 @@ struct EnvDevice {
     bool mcts_defer = false;       // the current hk_step call is short: its rounds do not launch searches themselves
     SecGeo* sec_geo = nullptr;
     // lane-group -> env assignment of the tick kernel, regrouped by solve phase every REGROUP_ROUNDS rounds (hk_env_run.h)
-    int* perm = nullptr;           // [E]
+    int* perm = nullptr;           // [E] slot -> env id (identity until the first regroup)
+    int* perm_alt = nullptr;
     bool b1_due = false;           // FISSION: the tick launch just issued parked its envs at their solve tick: env_b1_kernel is next on that stream
     int lqn_sparse_blocks = 1024;  // workgroups per queue of a solver launch once the field has spread (HK_LQN_SPARSE_BLOCKS)
     bool fission = false;          // the current call runs the tick kernel without phase B1 + env_b1_kernel (hk_env_run.h FISSION; hk_api.hip step_ticks)
@@ -62,7 +69,6 @@ struct EnvDevice {
     int guard_rounds_left = 0;     // > 0: fixed-round call; the tick launch that brings it to 0 flags the envs that are not done (the guard)
     int* perm_counts = nullptr;    // [2 * REGROUP_KEYS]: counts, cursors
     int regroup_rounds = 48;       // rounds between two periodic re-assignments (REGROUP_ROUNDS; HK_REGROUP_ROUNDS)
-    bool perm_valid = false;
     int rounds_since_regroup = 0;
     EnvParams P{};
 };
@@ -111,6 +117,11 @@ struct GaOps {
     int (*launch_arm)(EnvDevice& d, const hk_config& cfg, int n_ticks, hipStream_t stream, std::string& err);
     int (*launch_done_check)(EnvDevice& d, const hk_config& cfg, int lazy, hipStream_t stream, std::string& err);
     int (*launch_rewards_read)(EnvDevice& d, int cnt, float* reward, float* group_reward, hipStream_t stream, std::string& err);
+    int (*launch_hot_gather)(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err);    // hot tiles -> the AoS records' hot fields
+    int (*launch_hot_scatter)(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err);   // ... and back
+    int (*launch_envs_gather)(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err);   // env words by slot -> envs_stage by env id
+    int (*launch_envs_scatter)(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err);  // ... and back (progress words sanitized)
+    size_t (*hot_tile_words)(int E);
 };
 const GaOps& ga_ops_g4();      // hk_ga4.hip
 const GaOps& ga_ops_g8();      // hk_ga8.hip

@@ -32,13 +32,6 @@ int upload(T** dst, const std::vector<T>& v, std::string& err)
 }  // namespace detail
 
 __global__ void status_and_kernel(int* status, int mask) { atomicAnd(status, mask); }
-// hk_set_env_state: the progress words of hk_step are the library's (both 0 between calls but for the scheduling hint); a record the host
-// saved in the middle of nothing — or filled by hand — must not arm ticks or resume a phase (arming ADDS to reserved[0])
-__global__ void env_words_sanitize_kernel(hk_env_state* envs, int E)
-{
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    if (env < E) { envs[env].reserved[0] = 0; envs[env].reserved[1] &= 16 /* ENV_PACK_HINT */; }
-}
 
 // point d.mcts (the kernel argument) at the move tables of gameParams class c
 inline void mcts_use_class(EnvDevice& d, int c)
@@ -51,7 +44,8 @@ inline void mcts_use_class(EnvDevice& d, int c)
 inline void env_destroy(EnvDevice& d)
 {
     void* ptrs[] = {d.agents, d.envs, d.results, d.lq_debug, d.obs, d.act_steer, d.act_branch, d.reward_out, d.status, d.game_stats, d.games, d.queue_cnt, d.queue, d.env_ids, d.tab, d.perms,
-                    d.rw.sec_time, d.rw.sec_cnt, d.rw.hit_code, d.mcts.st, d.mcts.req, d.mcts.qcnt, d.mcts.queue, d.mcts.nodes, d.mcts.roots, d.sec_geo, d.perm, d.perm_counts};
+                    d.rw.sec_time, d.rw.sec_cnt, d.rw.hit_code, d.mcts.st, d.mcts.req, d.mcts.qcnt, d.mcts.queue, d.mcts.nodes, d.mcts.roots, d.sec_geo, d.perm, d.perm_counts,
+                    d.hot, d.hot_alt, d.envs_alt, d.envs_stage, d.slot_of, d.perm_alt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int c = 0; c < d.n_mcls; c++) { void* t[] = {d.mcls[c].dt_tab, d.mcls[c].load_tab, d.mcls[c].rad_tab, d.mcls[c].mask_tab, d.mcls[c].order_tab}; for (void* p : t) if (p) (void)hipFree(p); }
     d = EnvDevice{};
@@ -86,6 +80,12 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
     if ((e = hipMemsetAsync((ptr), 0, (bytes), stream)) != hipSuccess) { err = std::string("hipMemset: ") + hipGetErrorString(e); return HK_ERR_HIP; }
     HK_ALLOC(d.agents, na * sizeof(hk_agent_state));
     HK_ALLOC(d.envs, (size_t)E * sizeof(hk_env_state));
+    HK_ALLOC(d.envs_alt, (size_t)E * sizeof(hk_env_state));
+    HK_ALLOC(d.envs_stage, (size_t)E * sizeof(hk_env_state));
+    HK_ALLOC(d.hot, HK_GA_CALL(d, hot_tile_words(E)) * sizeof(uint32_t));
+    HK_ALLOC(d.hot_alt, HK_GA_CALL(d, hot_tile_words(E)) * sizeof(uint32_t));
+    HK_ALLOC(d.slot_of, (size_t)E * sizeof(int));
+    HK_ALLOC(d.perm_alt, (size_t)E * sizeof(int));
     HK_ALLOC(d.results, na * sizeof(hk_episode_result));
     HK_ALLOC(d.lq_debug, na * sizeof(hk_lq_debug));
     HK_ALLOC(d.obs, na * obs_dim * sizeof(float));
@@ -195,6 +195,12 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         std::memset(rs.data(), 0, sizeof(hk_episode_result) * na);
         for (size_t i = 0; i < na; i++) rs[i].episode = -1;
         std::vector<int32_t> br(na, 1);
+        std::vector<int> ident(E);                      // slot <-> env: the identity until the first regroup
+        for (int i = 0; i < E; i++) ident[i] = i;
+        if ((e = hipMemcpyAsync(d.perm, ident.data(), sizeof(int) * E, hipMemcpyHostToDevice, stream)) != hipSuccess ||
+            (e = hipMemcpyAsync(d.slot_of, ident.data(), sizeof(int) * E, hipMemcpyHostToDevice, stream)) != hipSuccess) {
+            err = std::string("hipMemcpy: ") + hipGetErrorString(e); return HK_ERR_HIP;
+        }
         if ((e = hipMemcpyAsync(d.envs, es.data(), sizeof(hk_env_state) * E, hipMemcpyHostToDevice, stream)) != hipSuccess ||
             (e = hipMemcpyAsync(d.results, rs.data(), sizeof(hk_episode_result) * na, hipMemcpyHostToDevice, stream)) != hipSuccess ||
             (e = hipMemcpyAsync(d.act_branch, br.data(), sizeof(int32_t) * na, hipMemcpyHostToDevice, stream)) != hipSuccess ||

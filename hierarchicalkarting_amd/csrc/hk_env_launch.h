@@ -66,7 +66,7 @@ inline int flush_mcts(EnvDevice& d, hipStream_t stream, std::string& err)
 inline int launch_reset(EnvDevice& d, const int* dids, int cnt, int experiment_num, hipStream_t stream, std::string& err)
 {
     const int threads = cnt * GA;
-    hipLaunchKernelGGL(env_reset_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.envs, dids, cnt, experiment_num,
+    hipLaunchKernelGGL(env_reset_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, d.P, d.agents, d.hot, d.slot_of, d.envs, dids, cnt, experiment_num,
                        d.mcts, d.mset, d.rw, d.status);
     int rc = launch_check(err, "env_reset_kernel");
     if (rc) return rc;
@@ -80,8 +80,10 @@ inline int launch_regroup(EnvDevice& d, const hk_config& cfg, hipStream_t stream
     const int E = cfg.num_envs;
     if (hipMemsetAsync(d.perm_counts, 0, 32 * sizeof(int), stream) != hipSuccess) { err = "regroup memset"; return HK_ERR_HIP; }
     hipLaunchKernelGGL(env_regroup_count_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, d.envs, E, d.perm_counts);
-    hipLaunchKernelGGL(env_regroup_scatter_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, d.envs, E, d.perm_counts, d.perm);
-    d.perm_valid = true;
+    hipLaunchKernelGGL(env_regroup_scatter_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, d.envs, d.envs_alt, d.hot, d.hot_alt, d.perm, d.perm_alt, d.slot_of,
+                       E, d.perm_counts);
+    // the move is physical: from here on the stream's kernels use the new buffers (everything is issued in stream order)
+    std::swap(d.envs, d.envs_alt); std::swap(d.hot, d.hot_alt); std::swap(d.perm, d.perm_alt);
     return launch_check(err, "env_regroup kernels");
 }
 
@@ -93,9 +95,9 @@ inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
     const int arm = d.arm_ticks, guard = (d.guard_rounds_left > 0 && --d.guard_rounds_left == 0) ? 1 : 0;
     d.arm_ticks = 0;
 #define HK_RUN_T(MC, RWF, TRN, TL)                                                                                            \
-    hipLaunchKernelGGL((env_run_kernel<MC, RWF, TRN, TL>), dim3((unsigned)((threads + 255) / 256)), dim3(256), TL ? d.tab_lds : 0, stream, d.P, d.agents, d.envs,   \
+    hipLaunchKernelGGL((env_run_kernel<MC, RWF, TRN, TL>), dim3((unsigned)((threads + 255) / 256)), dim3(256), TL ? d.tab_lds : 0, stream, d.P, d.agents, d.hot, d.envs,   \
                        d.results, GameSoA{d.games, (size_t)cfg.num_envs * cfg.num_agents}, d.queue_cnt, d.queue, d.round, d.act_steer, d.act_branch, d.lq_debug, d.status,     \
-                       d.mcts, d.mset, d.rw, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase, arm, guard)
+                       d.mcts, d.mset, d.rw, d.perm, d.game_stats, s0, s1, d.qbase, arm, guard)
 #define HK_RUN(MC, RWF, TRN) do { if (d.tab_lds) HK_RUN_T(MC, RWF, TRN, true); else HK_RUN_T(MC, RWF, TRN, false); } while (0)
     bool train = d.P.training_reset != 0;
     for (int i = 0; i < cfg.num_agents; i++) train = train || d.P.training_agent[i] != 0;
@@ -104,8 +106,8 @@ inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
         // FISSION (hk_env_run.h): the tick kernel without phase B1; launch_b1 follows on the same stream
         const GameSoA G{d.games, (size_t)cfg.num_envs * cfg.num_agents};
         const unsigned blocks = (unsigned)((threads + 255) / 256);
-#define HK_FIS_RUN(MC, TL) hipLaunchKernelGGL((env_run_kernel<MC, false, false, TL, true>), dim3(blocks), dim3(256), TL ? d.tab_lds : 0, stream, d.P, d.agents, d.envs, \
-                               d.results, G, d.queue_cnt, d.queue, d.round, d.act_steer, d.act_branch, d.lq_debug, d.status, d.mcts, d.mset, d.rw, d.perm_valid ? d.perm : nullptr,        \
+#define HK_FIS_RUN(MC, TL) hipLaunchKernelGGL((env_run_kernel<MC, false, false, TL, true>), dim3(blocks), dim3(256), TL ? d.tab_lds : 0, stream, d.P, d.agents, d.hot, d.envs, \
+                               d.results, G, d.queue_cnt, d.queue, d.round, d.act_steer, d.act_branch, d.lq_debug, d.status, d.mcts, d.mset, d.rw, d.perm,        \
                                d.game_stats, s0, s1, d.qbase, arm, guard)
         if (d.mcts.st) { if (d.tab_lds) HK_FIS_RUN(true, true); else HK_FIS_RUN(true, false); }
         else { if (d.tab_lds) HK_FIS_RUN(false, true); else HK_FIS_RUN(false, false); }
@@ -131,8 +133,8 @@ inline int launch_b1(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std
     const long long threads = (long long)(s1 - s0) * GA;
     const GameSoA G{d.games, (size_t)cfg.num_envs * cfg.num_agents};
     const unsigned blocks = (unsigned)((threads + 255) / 256);
-#define HK_FIS_B1(TL, MC) hipLaunchKernelGGL((env_b1_kernel<TL, MC>), dim3(blocks), dim3(256), TL ? d.P.o_tmask : 0, stream, d.P, d.agents, d.envs, G, d.queue_cnt, d.queue, \
-                           d.round, d.lq_debug, d.status, d.mcts, d.perm_valid ? d.perm : nullptr, d.game_stats, s0, s1, d.qbase, d.mset)
+#define HK_FIS_B1(TL, MC) hipLaunchKernelGGL((env_b1_kernel<TL, MC>), dim3(blocks), dim3(256), TL ? d.P.o_tmask : 0, stream, d.P, d.agents, d.hot, d.envs, G, d.queue_cnt, d.queue, \
+                           d.round, d.lq_debug, d.status, d.mcts, d.perm, d.game_stats, s0, s1, d.qbase, d.mset)
     if (d.mcts.st) { if (d.tab_lds) HK_FIS_B1(true, true); else HK_FIS_B1(false, true); }
     else { if (d.tab_lds) HK_FIS_B1(true, false); else HK_FIS_B1(false, false); }
 #undef HK_FIS_B1
@@ -174,7 +176,7 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
         const int per = bulk ? 1024 : d.lqn_sparse_blocks;
         const int n34 = sizes ? std::min(ngames, per) * sizes : 0;          // `per` waves per game size walk their queue grid-stride; the queue length picks the solver (lqn_round_kernel)
         const int n2 = std::min((ngames + 31) / 32, bulk ? 4096 : per);
-        hipLaunchKernelGGL(lqn_round_kernel, dim3(n34 + n2), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status,
+        hipLaunchKernelGGL(lqn_round_kernel, dim3(n34 + n2), dim3(64), 0, stream, d.P, HotRef{d.hot, d.slot_of}, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status,
                            n34, sizes ? sizes : 1, n2, d.game_stats, LQN_BULK_GAMES);
         if ((rc = launch_check(err, "lqn_round_kernel"))) return rc;
     }
@@ -182,11 +184,11 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
 #if HK_GA > 4
         {
             const int nbb = std::min((ngames + 1) / 2, 512);
-            hipLaunchKernelGGL(lqn_big_kernel<5>, dim3(nbb * (cfg.num_agents > 5 ? 2 : 1)), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu,
+            hipLaunchKernelGGL(lqn_big_kernel<5>, dim3(nbb * (cfg.num_agents > 5 ? 2 : 1)), dim3(64), 0, stream, d.P, HotRef{d.hot, d.slot_of}, GameSoA{d.games, (size_t)ngames}, qc, qu,
                                d.lq_debug, d.status, nbb, d.game_stats);
             if ((rc = launch_check(err, "lqn_big_kernel<5>"))) return rc;
             if (cfg.num_agents > 6) {
-                hipLaunchKernelGGL(lqn_big_kernel<7>, dim3(nbb * (cfg.num_agents > 7 ? 2 : 1)), dim3(64), 0, stream, d.P, d.agents, GameSoA{d.games, (size_t)ngames}, qc, qu,
+                hipLaunchKernelGGL(lqn_big_kernel<7>, dim3(nbb * (cfg.num_agents > 7 ? 2 : 1)), dim3(64), 0, stream, d.P, HotRef{d.hot, d.slot_of}, GameSoA{d.games, (size_t)ngames}, qc, qu,
                                    d.lq_debug, d.status, nbb, d.game_stats);
                 if ((rc = launch_check(err, "lqn_big_kernel<7>"))) return rc;
             }
@@ -205,12 +207,12 @@ inline int launch_observe(EnvDevice& d, const hk_config& cfg, uint32_t agent_mas
     // Complex track's 40 KB (the 8-agent workload lost 10 %), which keeps reading them through L1 / L2
     const int lds = (d.tab_lds && d.tab_lds <= 24 * 1024) ? d.tab_lds : 0;
     const uint32_t mask = d.rw.hit_code ? 0xFFFFFFFFu : agent_mask;                  // the reward replay needs every agent's hit codes
-    if (lds) hipLaunchKernelGGL(env_observe_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, stream, d.P, d.agents, d.obs, d.rw.hit_code, mask);
-    else hipLaunchKernelGGL(env_observe_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d.P, d.agents, d.obs, d.rw.hit_code, mask);
+    if (lds) hipLaunchKernelGGL(env_observe_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, stream, d.P, d.agents, d.hot, d.slot_of, d.obs, d.rw.hit_code, mask);
+    else hipLaunchKernelGGL(env_observe_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d.P, d.agents, d.hot, d.slot_of, d.obs, d.rw.hit_code, mask);
     int rc = launch_check(err, "env_observe_kernel");
     if (rc || !d.rw.hit_code) return rc;
     // CollectObservations raised HitWall / HitOpponent events (HKA:580-598): replayed per env in agent / sensor order
-    hipLaunchKernelGGL(reward_hits_kernel, dim3((cfg.num_envs + 127) / 128), dim3(128), 0, stream, d.P, d.agents, d.rw.hit_code);
+    hipLaunchKernelGGL(reward_hits_kernel, dim3((cfg.num_envs + 127) / 128), dim3(128), 0, stream, d.P, d.agents, d.hot, d.slot_of, d.rw.hit_code);
     return launch_check(err, "reward_hits_kernel");
 }
 
@@ -232,11 +234,37 @@ inline int launch_rewards_read(EnvDevice& d, int cnt, float* reward, float* grou
     return launch_check(err, "rewards_read_kernel");
 }
 
+// host-facing views of the device layout (hk_env_run.h: hot_gather_kernel ...)
+inline int launch_hot_gather(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
+    const int n = cfg.num_envs * cfg.num_agents;
+    hipLaunchKernelGGL(hot_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d.agents, d.hot, d.slot_of, n, cfg.num_agents);
+    return launch_check(err, "hot_gather_kernel");
+}
+inline int launch_hot_scatter(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
+    const int n = cfg.num_envs * cfg.num_agents;
+    hipLaunchKernelGGL(hot_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d.agents, d.hot, d.slot_of, n, cfg.num_agents);
+    return launch_check(err, "hot_scatter_kernel");
+}
+inline int launch_envs_gather(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
+    hipLaunchKernelGGL(envs_gather_kernel, dim3((cfg.num_envs + 255) / 256), dim3(256), 0, stream, d.envs_stage, d.envs, d.slot_of, cfg.num_envs);
+    return launch_check(err, "envs_gather_kernel");
+}
+inline int launch_envs_scatter(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
+{
+    hipLaunchKernelGGL(envs_scatter_kernel, dim3((cfg.num_envs + 255) / 256), dim3(256), 0, stream, d.envs_stage, d.envs, d.slot_of, cfg.num_envs);
+    return launch_check(err, "envs_scatter_kernel");
+}
+inline size_t hot_tile_words(int E) { return hot_words(E, GA); }
+
 inline const GaOps& make_ops()
 {
     static const GaOps ops = {mcts_req_bytes, mcts_searches_per_wave, mcts_lds_bytes, mcts_root_words, game_doubles_per_ego, queue_ints_per_set,
                               launch_mcts_table, launch_mcts_invalidate, flush_mcts, launch_reset, launch_regroup, launch_run, launch_b1, launch_lqn,
-                              launch_observe, launch_arm, launch_done_check, launch_rewards_read};
+                              launch_observe, launch_arm, launch_done_check, launch_rewards_read, launch_hot_gather, launch_hot_scatter, launch_envs_gather,
+                              launch_envs_scatter, hot_tile_words};
     return ops;
 }
 

@@ -6,21 +6,37 @@
 
 namespace hk { namespace HK_GA_NS {
 
+// what CollectObservations reads of a kart's per-tick state: a view of its hot-tile rows (hk_env_device.h)
+struct KartObs {
+    const uint32_t* p;
+    __device__ __forceinline__ float px() const { return hot_get<float>(p, HF_px); }
+    __device__ __forceinline__ float pz() const { return hot_get<float>(p, HF_pz); }
+    __device__ __forceinline__ float vx() const { return hot_get<float>(p, HF_vx); }
+    __device__ __forceinline__ float vz() const { return hot_get<float>(p, HF_vz); }
+    __device__ __forceinline__ float yaw() const { return hot_get<float>(p, HF_yaw); }
+    __device__ __forceinline__ float final_steer() const { return hot_get<float>(p, HF_final_steer); }
+    __device__ __forceinline__ uint32_t flags() const { return hot_get<uint32_t>(p, HF_flags); }
+    __device__ __forceinline__ int lane() const { return hot_get<int>(p, HF_lane); }
+    __device__ __forceinline__ int lane_changes() const { return hot_get<int>(p, HF_lane_changes); }
+    __device__ __forceinline__ int section_index() const { return hot_get<int>(p, HF_section_index); }
+};
+
 // (fx, fz) = the kart's forward (sin yaw, cos yaw): evaluated once per kart by the caller, not per use
-__device__ inline float local_speed(const EnvParams& P, const hk_agent_state* a, float fx, float fz)
+__device__ inline float local_speed(const EnvParams& P, const KartObs a, float fx, float fz)
 {   // AK:325-342
-    if (!(a->flags & HK_F_CAN_MOVE)) return 0.0f;
-    float dot = fx * a->vx + fz * a->vz;
+    if (!(a.flags() & HK_F_CAN_MOVE)) return 0.0f;
+    const float vx = a.vx(), vz = a.vz();
+    float dot = fx * vx + fz * vz;
     if (f_abs(dot) > 0.1f) {
-        float speed = mag3(a->vx, 0.0f, a->vz);
+        float speed = mag3(vx, 0.0f, vz);
         return dot < 0 ? -(speed / P.st.ReverseSpeed) : (speed / P.st.TopSpeed);
     }
     return 0.0f;
 }
 
-__device__ inline void inv_transform_point(const hk_agent_state* a, float fx, float fz, float wx, float wy, float wz, float ky, float out[3])
+__device__ inline void inv_transform_point(const float apx, const float apz, float fx, float fz, float wx, float wy, float wz, float ky, float out[3])
 {   // Transform.InverseTransformPoint of a yaw-only transform
-    float rx = wx - a->px, rz = wz - a->pz;
+    float rx = wx - apx, rz = wz - apz;
     out[0] = rx * fz + rz * (-fx);
     out[1] = wy - ky;
     out[2] = rx * fx + rz * fz;
@@ -33,7 +49,7 @@ __device__ inline void inv_transform_point(const hk_agent_state* a, float fx, fl
 // agent) and the group shares them by shuffles.
 constexpr int OBS_LANES = 16;
 template <bool TAB_LDS>
-__global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_agent_state* agents, float* obs, unsigned char* hit_code,
+__global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_agent_state* agents, const uint32_t* hot, const int* slot_of, float* obs, unsigned char* hit_code,
                                                           uint32_t agent_mask /* bit i: agent slot i is observed */)
 {
     // the track tables (wall grid walked by nine 20 m rays per agent) staged in LDS, as in the tick kernel
@@ -48,13 +64,15 @@ __global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_
     const int A = P.A, L = P.L, H = P.H;
     const int dim = HK_NUM_SENSORS + H * 5 + 8 + 12 * (A - 1);
     const int goal = P.laps * L + 1;
-    const hk_agent_state* ags = agents + (size_t)env * A;
-    const hk_agent_state* a = &ags[i];
+    const hk_agent_state* cold = &agents[(size_t)env * A + i];      // the plan arrays
+    const uint32_t* const hrow = hot + hot_base<GA>(slot_of[env], 0);   // the env's lane group: kart j is hrow + j
+    const KartObs a{hrow + i};
+    const float apx = a.px(), apz = a.pz();
     float* o = obs + (size_t)gid * dim;
     // forward vectors of the env's karts: lane l evaluates kart l % A, the group shares them
     float kfx[GA], kfz[GA];
     {
-        const float yl = ags[l % A].yaw;
+        const float yl = KartObs{hrow + l % A}.yaw();
         float sx, cz;
         hk_sincosf(yl, &sx, &cz);
         const int base = (threadIdx.x & 63) & ~(OBS_LANES - 1);
@@ -70,13 +88,13 @@ __global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_
     if (!valid || !((agent_mask >> i) & 1u)) return;
     if (l == 14) {                                                           // own block HKA:489-496
         o[0] = local_speed(P, a, fx, fz);
-        o[1] = (a->flags & HK_F_ACCEL) ? 1.0f : 0.0f;
-        o[2] = (float)a->lane;
-        o[3] = a->lane_changes * 1.0f / P.max_lane_changes;
-        o[4] = (a->flags & HK_F_ACTIVE) ? 1.0f : 0.0f;
-        o[5] = a->section_index * 1.0f / goal;
-        o[6] = is_straight(P, T, a->section_index) ? 1.0f : 0.0f;
-        o[7] = tire_wear(P, a->final_steer);
+        o[1] = (a.flags() & HK_F_ACCEL) ? 1.0f : 0.0f;
+        o[2] = (float)a.lane();
+        o[3] = a.lane_changes() * 1.0f / P.max_lane_changes;
+        o[4] = (a.flags() & HK_F_ACTIVE) ? 1.0f : 0.0f;
+        o[5] = a.section_index() * 1.0f / goal;
+        o[6] = is_straight(P, T, a.section_index()) ? 1.0f : 0.0f;
+        o[7] = tire_wear(P, a.final_steer());
     }
     // team mates, then opponents HKA:500-527: block q of the list is written by lane q of the group (one kart each, side by side,
     // instead of one lane walking all of them while the other fifteen wait)
@@ -84,39 +102,40 @@ __global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_
         const int nt = P.n_team[i];
         const int bj = l < nt ? P.team[i][l] : P.other[i][l - nt];
         int p = 8 + 12 * l;
-        const hk_agent_state* b = &ags[bj];
+        const KartObs b{hrow + bj};
         float bfx = kfx[0], bfz = kfz[0];
 #pragma unroll
         for (int q = 1; q < GA; q++) if (bj == q) { bfx = kfx[q]; bfz = kfz[q]; }
         o[p++] = local_speed(P, b, bfx, bfz);
-        o[p++] = (b->flags & HK_F_ACCEL) ? 1.0f : 0.0f;
-        o[p++] = (float)b->lane;
-        o[p++] = b->lane_changes * 1.0f / P.max_lane_changes;
-        o[p++] = (b->flags & HK_F_ACTIVE) ? 1.0f : 0.0f;
-        o[p++] = is_straight(P, T, b->section_index) ? 1.0f : 0.0f;
-        o[p++] = tire_wear(P, b->final_steer);
-        o[p++] = b->section_index * 1.0f / goal;
-        o[p++] = mag3(b->px - a->px, 0.0f, b->pz - a->pz);
+        o[p++] = (b.flags() & HK_F_ACCEL) ? 1.0f : 0.0f;
+        o[p++] = (float)b.lane();
+        o[p++] = b.lane_changes() * 1.0f / P.max_lane_changes;
+        o[p++] = (b.flags() & HK_F_ACTIVE) ? 1.0f : 0.0f;
+        o[p++] = is_straight(P, T, b.section_index()) ? 1.0f : 0.0f;
+        o[p++] = tire_wear(P, b.final_steer());
+        o[p++] = b.section_index() * 1.0f / goal;
+        const float bpx = b.px(), bpz = b.pz();
+        o[p++] = mag3(bpx - apx, 0.0f, bpz - apz);
         float lp[3];
-        inv_transform_point(a, fx, fz, b->px, P.kart_y, b->pz, P.kart_y, lp);
+        inv_transform_point(apx, apz, fx, fz, bpx, P.kart_y, bpz, P.kart_y, lp);
         o[p++] = lp[0]; o[p++] = lp[1]; o[p++] = lp[2];
     }
     if (l == 14 || l == 15) {
         // (lane 14 wrote the own block above)
     } else if (l >= 9) {                                                     // upcoming sections HKA:530-552
         for (int q = l - 9; q < H; q += 5) {
-            const int next = (a->section_index + 1 + q) % L;
+            const int next = (a.section_index() + 1 + q) % L;
             float* os = o + 8 + 12 * (A - 1) + 5 * q;
             float lp[3];
-            const int pl = a->plan_lane[next];
+            const int pl = cold->plan_lane[next];
             if (pl != 0) {
                 float mx, mz;
                 lane_marker(T, next, pl, mx, mz);
-                inv_transform_point(a, fx, fz, mx, T.sec[next].marker_y, mz, P.kart_y, lp);
+                inv_transform_point(apx, apz, fx, fz, mx, T.sec[next].marker_y, mz, P.kart_y, lp);
                 os[0] = lp[0]; os[1] = lp[1]; os[2] = lp[2];
-                os[3] = a->plan_vel[next] / P.max_speed;
+                os[3] = cold->plan_vel[next] / P.max_speed;
             } else {
-                inv_transform_point(a, fx, fz, T.sec[next].trig_x, T.sec[next].marker_y, T.sec[next].trig_z, P.kart_y, lp);
+                inv_transform_point(apx, apz, fx, fz, T.sec[next].trig_x, T.sec[next].marker_y, T.sec[next].trig_z, P.kart_y, lp);
                 os[0] = lp[0]; os[1] = lp[1]; os[2] = lp[2];
                 os[3] = 1.0f;
             }
@@ -124,8 +143,8 @@ __global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_
         }
     } else {                                                                 // sensor l HKA:553-603
         const int si = l;
-        const float ox = a->px + SENSOR_LZ * fx, oz = a->pz + SENSOR_LZ * fz;
-        const bool see = (a->flags & HK_F_ENABLED) != 0;
+        const float ox = apx + SENSOR_LZ * fx, oz = apz + SENSOR_LZ * fz;
+        const bool see = (a.flags() & HK_F_ENABLED) != 0;
         float dx, dz;
         sensor_dir(P, si, fx, fz, dx, dz);
         const float maxd = P.ray_dist[si];
@@ -152,8 +171,9 @@ __global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_
         if (see) {
 #pragma unroll
             for (int j = 0; j < GA; j++) {
-                if (j >= A || j == i || !(ags[j].flags & HK_F_ENABLED)) continue;
-                float t = ray_stadium(ox, oz, dx, dz, ags[j].px, ags[j].pz, kfx[j], kfz[j], P.ray_agent_r);
+                const KartObs kj{hrow + j};
+                if (j >= A || j == i || !(kj.flags() & HK_F_ENABLED)) continue;
+                float t = ray_stadium(ox, oz, dx, dz, kj.px(), kj.pz(), kfx[j], kfz[j], P.ray_agent_r);
                 if (t >= 0.0f && t <= maxd && (ha < 0.0f || t < ha)) { ha = t; who = j; }
             }
         }

@@ -194,13 +194,14 @@ __device__ inline void rw_goal_timing(const EnvParams& P, const int i, const int
 }
 
 // REC.ResolveEvent :438-462 for the HitWall / HitOpponent events of the last observation pass; one thread per env
-__global__ __launch_bounds__(128) void reward_hits_kernel(EnvParams P, hk_agent_state* agents, const unsigned char* hit_code)
+__global__ __launch_bounds__(128) void reward_hits_kernel(EnvParams P, hk_agent_state* agents, const uint32_t* hot, const int* slot_of, const unsigned char* hit_code)
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= P.E) return;
     hk_agent_state* ags = agents + (size_t)env * P.A;
+    const uint32_t* hrow = hot + hot_base<GA>(slot_of[env], 0);
     for (int i = 0; i < P.A; i++) {
-        if (!(ags[i].flags & HK_F_ACTIVE)) continue;                                     // :441
+        if (!(hot_get<uint32_t>(hrow + i, HF_flags) & HK_F_ACTIVE)) continue;             // :441
         for (int si = 0; si < HK_NUM_SENSORS; si++) {
             const int code = hit_code[((size_t)env * P.A + i) * HK_NUM_SENSORS + si];
             if (code == 0) continue;

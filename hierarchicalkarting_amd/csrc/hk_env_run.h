@@ -78,11 +78,12 @@ __device__ __forceinline__ int regroup_block_counts(RegroupLds& L, int key, int&
     __syncthreads();
     return wave;
 }
+// (both kernels walk the lane-group SLOTS: envs[] is stored by slot)
 __global__ __launch_bounds__(256) void env_regroup_count_kernel(const hk_env_state* envs, int E, int* counts /*[2 * REGROUP_KEYS]: counts, cursors*/)
 {
     __shared__ RegroupLds L;
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    const int key = env < E ? regroup_key(envs[env]) : -1;
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const int key = slot < E ? regroup_key(envs[slot]) : -1;
     int rank;
     (void)regroup_block_counts(L, key, rank);
     if (threadIdx.x < REGROUP_KEYS) {
@@ -91,17 +92,24 @@ __global__ __launch_bounds__(256) void env_regroup_count_kernel(const hk_env_sta
         if (tot) atomicAdd(&counts[k], tot);
     }
 }
-__global__ __launch_bounds__(256) void env_regroup_scatter_kernel(const hk_env_state* envs, int E, int* counts, int* perm)
+// The regroup is PHYSICAL (round 5): the lane group that sat in `slot` moves to `pos` with its env words and its rows of the hot tiles
+// (GA consecutive dwords of each of the 32 fields: one 16-byte piece per field for a quad), from the old buffers to the new ones — the host
+// swaps the pointers after this launch — so that a wave of the tick kernel keeps reading ONE contiguous tile.  perm / slot_of follow.
+struct alignas(16) HotPiece { uint32_t v[4]; };
+__global__ __launch_bounds__(256) void env_regroup_scatter_kernel(const hk_env_state* envs_old, hk_env_state* envs_new, const uint32_t* hot_old,
+                                                                  uint32_t* hot_new, const int* perm_old, int* perm_new, int* slot_of, int E, int* counts)
 {
     __shared__ RegroupLds L;
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    const int key = env < E ? regroup_key(envs[env]) : -1;
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    hk_env_state es{};
+    if (slot < E) es = envs_old[slot];
+    const int key = slot < E ? regroup_key(es) : -1;
     int rank;
     const int wave = regroup_block_counts(L, key, rank);
     if (threadIdx.x < REGROUP_KEYS) {
         const int k = threadIdx.x;
         const int tot = L.cnt[0][k] + L.cnt[1][k] + L.cnt[2][k] + L.cnt[3][k];
-        int start = 0;                                   // where key k begins in perm: the counts of the keys before it
+        int start = 0;                                   // where key k begins in the new order: the counts of the keys before it
         for (int j = 0; j < k; j++) start += counts[j];
         L.base[k] = start + (tot ? atomicAdd(&counts[REGROUP_KEYS + k], tot) : 0);
     }
@@ -109,8 +117,50 @@ __global__ __launch_bounds__(256) void env_regroup_scatter_kernel(const hk_env_s
     if (key >= 0) {
         int pos = L.base[key] + rank;
         for (int w = 0; w < wave; w++) pos += L.cnt[w][key];
-        perm[pos] = env;
+        const int env = perm_old[slot];
+        perm_new[pos] = env;
+        slot_of[env] = pos;              // (one writer per env; nobody reads slot_of in this launch)
+        envs_new[pos] = es;
+        const HotPiece* src = reinterpret_cast<const HotPiece*>(hot_old + hot_base<GA>(slot, 0));
+        HotPiece* dst = reinterpret_cast<HotPiece*>(hot_new + hot_base<GA>(pos, 0));
+#pragma unroll 8
+        for (int f = 0; f < HF_N; f++) {
+#pragma unroll
+            for (int q = 0; q < GA / 4; q++) dst[f * 16 + q] = src[f * 16 + q];        // a row is 64 dwords = 16 pieces
+        }
     }
+}
+
+// The host-facing views ("a host-facing view is produced only by hk_get_*"): hk_get_agent_state / hk_device_agents_ptr gather the hot
+// rows into the AoS records, hk_set_agent_state scatters them back; hk_get / hk_set_env_state translate the slot order into env order.
+__global__ __launch_bounds__(256) void hot_gather_kernel(hk_agent_state* agents, const uint32_t* hot, const int* slot_of, int n, int A)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int env = t / A, i = t - env * A;
+    store_hot(&agents[t], load_hot_tile(hot + hot_base<GA>(slot_of[env], i)));
+}
+__global__ __launch_bounds__(256) void hot_scatter_kernel(const hk_agent_state* agents, uint32_t* hot, const int* slot_of, int n, int A)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int env = t / A, i = t - env * A;
+    store_hot_tile(hot + hot_base<GA>(slot_of[env], i), load_hot(&agents[t]));
+}
+__global__ __launch_bounds__(256) void envs_gather_kernel(hk_env_state* by_env, const hk_env_state* by_slot, const int* slot_of, int E)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env < E) by_env[env] = by_slot[slot_of[env]];
+}
+// hk_set_env_state: the progress words of hk_step are the library's (both 0 between calls but for the scheduling hint); a record the host
+// saved in the middle of nothing — or filled by hand — must not arm ticks or resume a phase (arming ADDS to reserved[0])
+__global__ __launch_bounds__(256) void envs_scatter_kernel(const hk_env_state* by_env, hk_env_state* by_slot, const int* slot_of, int E)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= E) return;
+    hk_env_state es = by_env[env];
+    es.reserved[0] = 0; es.reserved[1] &= ENV_PACK_HINT;
+    by_slot[slot_of[env]] = es;
 }
 
 // <false, false, false> is the headline path: the planner hooks (request / consume / beliefs), reward shaping and the
@@ -129,7 +179,7 @@ __global__ __launch_bounds__(256) void env_regroup_scatter_kernel(const hk_env_s
 #define HK_FIS_OCC 2
 #endif
 template <bool HAS_MCTS, bool HAS_RW, bool HAS_TRAIN, bool TAB_LDS, bool FISSION = false>
-__global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_run_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
+__global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_run_kernel(EnvParams P, hk_agent_state* agents, uint32_t* hot, hk_env_state* envs,
                                                       hk_episode_result* results, GameSoA games, int* queue_cnt_all,
                                                       int* queue_all, int round, const float* act_steer, const int* act_branch,
                                                       hk_lq_debug* dbg_out, int* status, MctsDev Marg, int mset, RwDev RD, const int* perm,
@@ -150,7 +200,10 @@ __global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_ru
     const int gid = slot0 * GA + blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = gid / GA, i = gid % GA;
     const bool env_ok = slot < slot1;
-    const int env = (perm && env_ok) ? perm[slot] : slot;     // lane groups are re-assigned by solve phase (env_regroup_*)
+    // Hot tiles and env words are stored by SLOT (a regroup moves them physically): neither load waits for the env id, which only
+    // addresses what is indexed by env (cold records, results, queues, planner state)
+    const int env = env_ok ? perm[slot] : 0;
+    uint32_t* const htile = hot + (size_t)(gid >> 6) * HOT_TILE_WORDS + (gid & 63);      // == hot + hot_base<GA>(slot, i)
     // the game queues are double buffered over rounds: this launch fills `set`, and clears the other one, which the
     // previous round's lqn kernels have finished reading
     const int set = qbase + (round & 1);
@@ -158,7 +211,7 @@ __global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_ru
     int* queue = queue_all + (size_t)set * (GA - 1) * P.E * P.A;
     if (blockIdx.x == 0 && threadIdx.x < 16) queue_cnt_all[(set ^ 1) * 16 + threadIdx.x] = 0;
     hk_env_state es;
-    if (env_ok) es = envs[env];
+    if (env_ok) es = envs[slot];
     else { es.episode_steps = 0; es.inactive_mask = 0; es.experiment_num = 0; es.episodes_done = 0; es.status = 0; es.initial_started = 0; es.reserved[0] = 0; es.reserved[1] = 0; }
     if (env_ok) es.reserved[0] += arm_ticks;             // the first launch of a fixed-round call arms the envs (else env_arm_kernel did)
     // nothing to do in this block? (every env finished its ticks): skip the table staging too
@@ -172,7 +225,7 @@ __global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_ru
 #endif
     hk_agent_state* arec = (env_ok && i < P.A) ? &agents[(size_t)env * P.A + i] : nullptr;
     Hot h;
-    if (arec) h = load_hot(arec); else { Hot z = {}; h = z; }
+    if (arec) h = load_hot_tile(htile); else { Hot z = {}; h = z; }
     const int cadence = P.A > 2 ? 4 : 1;
     const int cmask = cadence - 1;                       // cadence is 1 or 4 and episode_steps >= 0: x % cadence == x & cmask
     const uint32_t all_mask = (1u << P.A) - 1u;
@@ -293,13 +346,13 @@ __global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_ru
 #else
     if (arec && dirty) {
 #endif
-        store_hot(arec, h);
+        store_hot_tile(htile, h);
         if (HAS_RW && P.rewards) { arec->cum_reward = rwv.cum; arec->step_reward = rwv.step; arec->group_reward = rwv.group; }
     }
     if (env_ok && dirty && i == 0) {
         es.reserved[0] = left;
         es.reserved[1] = phase | (pack ? ENV_PACK_HINT : 0);
-        envs[env] = es;
+        envs[slot] = es;
     }
     // the last launch of a fixed-round call is its completion guard (what env_check_kernel does for the other calls)
     if (guard && env_ok && i == 0 && (left != 0 || phase != 0)) atomicOr(status, 4);
@@ -322,7 +375,7 @@ __global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_ru
 #define HK_B1_OCC 2
 #endif
 template <bool TAB_LDS, bool HAS_MCTS = false>
-__global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs, GameSoA games, int* queue_cnt_all,
+__global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_agent_state* agents, uint32_t* hot, hk_env_state* envs, GameSoA games, int* queue_cnt_all,
                                                         int* queue_all, int round, hk_lq_debug* dbg_out, int* status, MctsDev Marg, const int* perm,
                                                         unsigned long long* stats, int slot0, int slot1, int qbase, int mset)
 {
@@ -340,12 +393,13 @@ __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_
     const int gid = slot0 * GA + blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = gid / GA, i = gid % GA;
     const bool env_ok = slot < slot1;
-    const int env = (perm && env_ok) ? perm[slot] : slot;
+    const int env = env_ok ? perm[slot] : 0;
+    uint32_t* const htile = hot + (size_t)(gid >> 6) * HOT_TILE_WORDS + (gid & 63);
     const int set = qbase + (round & 1);
     int* queue_cnt = queue_cnt_all + set * 16;
     int* queue = queue_all + (size_t)set * (GA - 1) * P.E * P.A;
     hk_env_state es;
-    if (env_ok) es = envs[env];
+    if (env_ok) es = envs[slot];
     else { es.episode_steps = 0; es.inactive_mask = 0; es.experiment_num = 0; es.episodes_done = 0; es.status = 0; es.initial_started = 0; es.reserved[0] = 0; es.reserved[1] = 0; }
     const bool pend = env_ok && (es.reserved[1] & ENV_PHASE_MASK) == 2;
     if (__syncthreads_or(pend ? 1 : 0) == 0) return;
@@ -357,9 +411,11 @@ __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_
 #endif
     const TabView T = tab_stage<TAB_LDS>(P, smem, P.o_tmask);      // (the segments before the Trigger masks: sections, walls, wall grid, cut table)
     if (arec) {
-        h.px = arec->px; h.pz = arec->pz; h.yaw = arec->yaw; h.vx = arec->vx; h.vz = arec->vz; h.wy = arec->wy;
-        h.final_steer = arec->final_steer; h.section_index = arec->section_index; h.flags = arec->flags; h.steering = arec->steering;
-        if (HAS_MCTS) { h.lane = arec->lane; h.lane_changes = arec->lane_changes; }
+#define HK_B1_LOAD(T, n) h.n = hot_get<T>(htile, HF_##n)
+        HK_B1_LOAD(float, px); HK_B1_LOAD(float, pz); HK_B1_LOAD(float, yaw); HK_B1_LOAD(float, vx); HK_B1_LOAD(float, vz); HK_B1_LOAD(float, wy);
+        HK_B1_LOAD(float, final_steer); HK_B1_LOAD(int, section_index); HK_B1_LOAD(uint32_t, flags); HK_B1_LOAD(float, steering);
+        if (HAS_MCTS) { HK_B1_LOAD(int, lane); HK_B1_LOAD(int, lane_changes); }
+#undef HK_B1_LOAD
     }
     const LaneCfg LC = lane_cfg(P, i);
     float hfx, hfz;
@@ -374,8 +430,8 @@ __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_
     const bool queued = group_or(qn ? 1 : 0) != 0;
     // the planner hook of a solve tick (HKA:330-402, after SolveLQR; every lane of the group calls it): replan request, bestStates -> plan entries
     if (HAS_MCTS && M.st && pend) phase_plan(P, M, mset, env, i, es, h.flags, h.section_index, h.lane, h.lane_changes, h.final_steer, arec);
-    if (arec) { arec->flags = h.flags; arec->steering = h.steering; }
-    if (pend && i == 0) envs[env].reserved[1] = 1 | (queued ? ENV_PACK_HINT : 0);
+    if (arec) { hot_put<uint32_t>(htile, HF_flags, h.flags); hot_put<float>(htile, HF_steering, h.steering); }
+    if (pend && i == 0) envs[slot].reserved[1] = 1 | (queued ? ENV_PACK_HINT : 0);
 #ifdef HK_STAMPS
     __builtin_amdgcn_s_waitcnt(0);
     HK_ST(h, 18);                      // [18] B1 kernel: binning, stores (waited for)

@@ -88,6 +88,18 @@ __device__ inline void decode_controls(const float fs /*final_steer*/, uint32_t&
     if (dbg) { dbg->u0[0] = u0a; dbg->u0[1] = u0b; }
 }
 
+// The solver kernels decode into the ego's hot-tile rows (flags, steering), found through slot_of: a queued game is named by env * A + ego
+struct HotRef { uint32_t* w; const int* slot_of; };
+__device__ __forceinline__ void decode_store(const EnvParams& P, const HotRef& HR, const int game, const double u0a, const double u0b, hk_lq_debug* dbg)
+{
+    const int env = game / P.A, ego = game - env * P.A;
+    uint32_t* p = HR.w + hot_base<GA>(HR.slot_of[env], ego);
+    uint32_t fl = hot_get<uint32_t>(p, HF_flags);
+    float st = hot_get<float>(p, HF_steering);
+    decode_controls(hot_get<float>(p, HF_final_steer), fl, st, u0a, u0b, dbg);
+    hot_put<uint32_t>(p, HF_flags, fl); hot_put<float>(p, HF_steering, st);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // single-player games, solved by the assembling thread itself (lq1_solve).  Dense 4x4 / 2x2 algebra with the SAME fma chains as the generic
 // algorithm (k ascending, seeded +0.0); entries of A, B that are structural zeros are skipped (exact), entries
@@ -773,7 +785,7 @@ __device__ __forceinline__ void lqn_stage_solve(const int game, const int r, con
 // 3- and 4-player games when a round holds a handful of them (a spread field): ONE game per wave, whole solve in 27 us instead of the
 // lane-per-row core's 59 (hk_lq_mfma.h).  When a round holds thousands (the race start) lqn_body<NP, true> serves 64 / n games per wave.
 template <int NP>
-__device__ __forceinline__ void lqn_body_mfma(const int block, const int nblocks, const EnvParams& P, hk_agent_state* agents, const GameSoA games,
+__device__ __forceinline__ void lqn_body_mfma(const int block, const int nblocks, const EnvParams& P, const HotRef hr, const GameSoA games,
                                               const int* queue_cnt, const int* queue, hk_lq_debug* dbg_out, int* status, unsigned char* smem,
                                               unsigned long long* gstats)
 {
@@ -796,10 +808,7 @@ __device__ __forceinline__ void lqn_body_mfma(const int block, const int nblocks
         lq_solve_game_mfma<NP, QCompact<NP>, LqmDev>(lane, LG, qp, 3, u0, singular);       // HKA:1201 horizon literal 3 (Q6)
         if (lane == 0) {
             if (singular) atomicOr(status, 1);
-            hk_agent_state* me = &agents[game];
-            uint32_t fl = me->flags; float st = me->steering;
-            decode_controls(me->final_steer, fl, st, u0[0], u0[1], (dbg_out && (P.debug & 1)) ? &dbg_out[game] : nullptr);
-            me->flags = fl; me->steering = st;
+            decode_store(P, hr, game, u0[0], u0[1], (dbg_out && (P.debug & 1)) ? &dbg_out[game] : nullptr);
         }
     }
 }
@@ -808,7 +817,7 @@ __device__ __forceinline__ void lqn_body_mfma(const int block, const int nblocks
 #define HK_LQN_SYNC LqBlockSync
 #endif
 template <int NP, bool MFMA = false>
-__device__ __forceinline__ void lqn_body(const int block, const int nblocks, const EnvParams& P, hk_agent_state* agents, const GameSoA games,
+__device__ __forceinline__ void lqn_body(const int block, const int nblocks, const EnvParams& P, const HotRef hr, const GameSoA games,
                                          const int* queue_cnt, const int* queue, hk_lq_debug* dbg_out, int* status, unsigned char* smem,
                                          unsigned long long* gstats)
 {
@@ -831,10 +840,7 @@ __device__ __forceinline__ void lqn_body(const int block, const int nblocks, con
         lqn_stage_solve<NP, HK_LQN_SYNC, MFMA>(game, r, (double)P.dt, games, LG, CR, u0, singular, lds);
         if (live && r == 0) {
             if (singular) atomicOr(status, 1);
-            hk_agent_state* me = &agents[game];
-            uint32_t fl = me->flags; float st = me->steering;
-            decode_controls(me->final_steer, fl, st, u0[0], u0[1], (dbg_out && (P.debug & 1)) ? &dbg_out[game] : nullptr);
-            me->flags = fl; me->steering = st;
+            decode_store(P, hr, game, u0[0], u0[1], (dbg_out && (P.debug & 1)) ? &dbg_out[game] : nullptr);
         }
     }
 }
@@ -852,7 +858,7 @@ __device__ __forceinline__ void lqn_body(const int block, const int nblocks, con
 // 5- and 6-player games would otherwise run with the 8-player allocation).  Blocks [0, nb) take the lower size, [nb, 2 nb) the
 // higher one.  Functional, not tuned: such games need more than 4 karts within 8 m of each other.
 template <int NA>
-__global__ __launch_bounds__(64) void lqn_big_kernel(EnvParams P, hk_agent_state* agents, const GameSoA games, const int* queue_cnt,
+__global__ __launch_bounds__(64) void lqn_big_kernel(EnvParams P, const HotRef hr, const GameSoA games, const int* queue_cnt,
                                                      const int* queue, hk_lq_debug* dbg_out, int* status, int nb, unsigned long long* gstats)
 {
     constexpr int NB = NA + 1;
@@ -862,8 +868,8 @@ __global__ __launch_bounds__(64) void lqn_big_kernel(EnvParams P, hk_agent_state
     static_assert(BMAX <= 160 * 1024, "one workgroup's games must fit the CU's LDS");
     __shared__ __align__(16) unsigned char smem[BMAX];
     const int which = blockIdx.x / nb, b = blockIdx.x - which * nb;
-    if (which == 0) lqn_body<NA>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
-    else lqn_body<NB>(b, nb, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
+    if (which == 0) lqn_body<NA>(b, nb, P, hr, games, queue_cnt, queue, dbg_out, status, smem, gstats);
+    else lqn_body<NB>(b, nb, P, hr, games, queue_cnt, queue, dbg_out, status, smem, gstats);
 }
 #endif
 

@@ -108,19 +108,25 @@ __device__ inline void snapshot_result(const Hot& h, float cum_reward, float gro
 }
 
 // explicit hk_reset
-__global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_state* agents, hk_env_state* envs,
+__global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_state* agents, uint32_t* hot, const int* slot_of, hk_env_state* envs_by_slot,
                                                         const int* env_ids, int n, int experiment_num, MctsDev M, int set, RwDev RD, int* status)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid == 0) atomicAnd(status, ~4);       // (see env_arm_kernel)
-    const int slot = gid / GA, i = gid % GA;
-    if (slot >= n || i >= P.A) return;
-    const int env = env_ids ? env_ids[slot] : slot;
+    const int idx = gid / GA, i = gid % GA;
+    if (idx >= n || i >= P.A) return;
+    const int env = env_ids ? env_ids[idx] : idx;
+    const int slot = slot_of[env];
+    hk_env_state* const esp = &envs_by_slot[slot];             // the env's words live at its slot
     const int ex = experiment_num >= 0 ? experiment_num : (P.env_id_base + env) % P.nperm;
     const TabView T = tab_view(P, P.tab);
     hk_agent_state* ar = &agents[(size_t)env * P.A + i];
+    uint32_t* const htile = hot + hot_base<GA>(slot, i);
+    // the AoS record is the staging copy of the reset (reset_agent rewrites all of it, plans included, and keeps the telemetry fields it finds)
+    store_hot(ar, load_hot_tile(htile));
     const float old_steer = ar->final_steer;        // m_FinalStats.Steer as the previous episode left it (mcts_post_request)
-    reset_agent<true>(P, T, env, i, ex, envs[env].episodes_done, ar);
+    reset_agent<true>(P, T, env, i, ex, esp->episodes_done, ar);
+    store_hot_tile(htile, load_hot(ar));
     if (RD.sec_time) {
         const int nn = P.A * RD.S;
         for (int q = i; q < nn; q += P.A) { RD.sec_time[(size_t)env * nn + q] = -1; RD.sec_cnt[(size_t)env * nn + q] = 0; }
@@ -128,14 +134,14 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, hk_agent_st
     if (M.st) {
         mcts_reset_state(&M.st[(size_t)env * P.A + i]);
         mc_reqs(M)[(size_t)env * P.A + i].last_sec = -1;
-        mcts_backfill_section_times<true>(P, T, env, i, ex, envs[env].episodes_done, ar->section_index, &M.st[(size_t)env * P.A + i]);
+        mcts_backfill_section_times<true>(P, T, env, i, ex, esp->episodes_done, ar->section_index, &M.st[(size_t)env * P.A + i]);
         uint32_t req = 0;
         for (int e = 0; e < P.A; e++) if (P.high_mode[e] == HK_HIGH_MCTS && !P.training_agent[e]) req |= 1u << e;
-        mcts_post_request(P, M, set, env, i, req, req, 0, envs[env].episodes_done, P.mcts_iter0, P.mcts_lat0,
+        mcts_post_request(P, M, set, env, i, req, req, 0, esp->episodes_done, P.mcts_iter0, P.mcts_lat0,
                           ar->section_index, ar->lane, ar->lane_changes, ar->final_steer, old_steer);
     }
     if (i == 0) {
-        hk_env_state* es = &envs[env];
+        hk_env_state* es = esp;
         es->experiment_num = ex;
         es->status = 0;
         es->initial_started = 1;

@@ -334,7 +334,7 @@ __device__ __forceinline__ void lq2_pair_solve(const int game, const int p, cons
 
 #ifndef HK_LQ2_HOST_CHECK
 // The 2-player queue of a round, 32 games per wave (one workgroup = one wave), grid-stride over blocks [0, nblocks)
-__device__ __forceinline__ void lq2_pair_body(const int block, const int nblocks, const EnvParams& P, hk_agent_state* agents, const GameSoA& games,
+__device__ __forceinline__ void lq2_pair_body(const int block, const int nblocks, const EnvParams& P, const HotRef hr, const GameSoA& games,
                                               const int* queue_cnt, const int* queue, hk_lq_debug* dbg_out, int* status, Lq2PairLds& S,
                                               unsigned long long* gstats)
 {
@@ -350,10 +350,7 @@ __device__ __forceinline__ void lq2_pair_body(const int block, const int nblocks
         lq2_pair_solve(game, p, lane, (double)P.dt, games, S, u0, singular);
         if (live && p == 0) {
             if (singular) atomicOr(status, 1);
-            hk_agent_state* me = &agents[game];
-            uint32_t fl = me->flags; float st = me->steering;
-            decode_controls(me->final_steer, fl, st, u0[0], u0[1], (dbg_out && (P.debug & 1)) ? &dbg_out[game] : nullptr);
-            me->flags = fl; me->steering = st;
+            decode_store(P, hr, game, u0[0], u0[1], (dbg_out && (P.debug & 1)) ? &dbg_out[game] : nullptr);
         }
     }
 }
@@ -362,7 +359,7 @@ __device__ __forceinline__ void lq2_pair_body(const int block, const int nblocks
 // n34 / sizes blocks per size; first in the grid: they are the long ones), blocks [n34, n34 + n2) the 2-player queue (pairs of
 // lanes).  Both bodies run one wave per SIMD (458 registers / 40 KB of LDS), so they share a kernel at no cost — and in a spread
 // field, where a round holds a handful of games of each kind, their latencies overlap instead of adding up.
-__global__ __launch_bounds__(64) void lqn_round_kernel(EnvParams P, hk_agent_state* agents, const GameSoA games, const int* queue_cnt,
+__global__ __launch_bounds__(64) void lqn_round_kernel(EnvParams P, const HotRef hr, const GameSoA games, const int* queue_cnt,
                                                        const int* queue, hk_lq_debug* dbg_out, int* status, int n34, int sizes, int n2,
                                                        unsigned long long* gstats, int bulk34)
 {
@@ -373,17 +370,17 @@ __global__ __launch_bounds__(64) void lqn_round_kernel(EnvParams P, hk_agent_sta
     constexpr size_t BMAX = B34 > sizeof(Lq2PairLds) ? B34 : sizeof(Lq2PairLds);
     __shared__ __align__(16) unsigned char smem[BMAX];
     const int b = blockIdx.x;
-    if (b >= n34) { lq2_pair_body(b - n34, n2, P, agents, games, queue_cnt, queue, dbg_out, status, *reinterpret_cast<Lq2PairLds*>(smem), gstats); return; }
+    if (b >= n34) { lq2_pair_body(b - n34, n2, P, hr, games, queue_cnt, queue, dbg_out, status, *reinterpret_cast<Lq2PairLds*>(smem), gstats); return; }
     const int per = n34 / sizes, which = b / per, bb = b - which * per;
     // Which solver?  The queue length decides, on the device: a round that holds a handful of games (a spread field) wants the shortest
     // latency — one game per wave; one that holds thousands (the race start, packs) wants 64 / n games per instruction of the m x m solve.
     const int cnt = queue_cnt[which == 0 ? 3 : 4];
     if (cnt > bulk34) {
-        if (which == 0) lqn_body<3, true>(bb, per, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
-        else lqn_body<4, true>(bb, per, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
+        if (which == 0) lqn_body<3, true>(bb, per, P, hr, games, queue_cnt, queue, dbg_out, status, smem, gstats);
+        else lqn_body<4, true>(bb, per, P, hr, games, queue_cnt, queue, dbg_out, status, smem, gstats);
     } else {
-        if (which == 0) lqn_body_mfma<3>(bb, per, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
-        else lqn_body_mfma<4>(bb, per, P, agents, games, queue_cnt, queue, dbg_out, status, smem, gstats);
+        if (which == 0) lqn_body_mfma<3>(bb, per, P, hr, games, queue_cnt, queue, dbg_out, status, smem, gstats);
+        else lqn_body_mfma<4>(bb, per, P, hr, games, queue_cnt, queue, dbg_out, status, smem, gstats);
     }
 }
 #endif

@@ -64,14 +64,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------------------------------
 // StackingSensor.  128 threads per (env, slot); w = ring slot that receives the newest observation.
-__global__ __launch_bounds__(256) void policy_stack_kernel(PolicyParams Q, int E, int A, const hk_env_state* envs,
+__global__ __launch_bounds__(256) void policy_stack_kernel(PolicyParams Q, int E, int A, const hk_env_state* envs_by_slot, const int* slot_of,
                                                            const float* obs, int w)
 {
     const int pair = blockIdx.x * 2 + (threadIdx.x >> 7);
     const int t = threadIdx.x & 127;
     const bool ok = pair < E * Q.n_slots;
     const int env = ok ? pair / Q.n_slots : 0, j = ok ? pair % Q.n_slots : 0;
-    const int ep = envs[env].episodes_done + envs[env].initial_started;
+    const hk_env_state* es = &envs_by_slot[slot_of[env]];      // env words are stored by lane-group slot (hk_env_device.h)
+    const int ep = es->episodes_done + es->initial_started;
     const bool stale = ok && Q.epoch[pair] != ep;
     __syncthreads();                 // everyone has read the epoch word before it is rewritten
     float* ring = Q.ring + (size_t)(ok ? pair : 0) * Q.in_dim;

@@ -212,8 +212,8 @@ typedef struct hk_mcts_state {
 
 
 /* Per-agent persistent state: the fields of KartAgent (KA:102-128), ArcadeKart (AK:190-205) and the Rigidbody that
- * survive a tick.  This IS the device record (one per [env][agent]); hk_get/set_agent_state copy it verbatim, which
- * gives snapshot/restore for free. */
+ * survive a tick.  hk_get/set_agent_state copy every field, which gives snapshot/restore for free.  (On the device the fields that
+ * change every tick live in a wave-tiled structure-of-arrays layout; this record is the host-facing view.) */
 typedef struct hk_agent_state {
     float px, pz;                 /* transform.position (x, z); y is kart_y */
     float yaw;                    /* Unity Y rotation, radians, kept in [0, 2pi) */
@@ -362,7 +362,9 @@ int hk_lq_solve_batch(hk_handle h, int batch, int N, const double* A, const doub
 int hk_lq_solve_batch_device(hk_handle h, int batch, int N, const double* dA, const double* dB, const double* dQ,
                              const double* dq, const double* dR, const double* dx0, int horizon, double* du0, void* stream);
 void* hk_device_results_ptr(hk_handle h);  /* hk_episode_result[E][A] on device: the payload of the RCCL all-gather */
-void* hk_device_agents_ptr(hk_handle h);   /* hk_agent_state[E][A] on device */
+void* hk_device_agents_ptr(hk_handle h);   /* hk_agent_state[E][A] on device: a SNAPSHOT as of this call (the library keeps the per-tick fields in a
+                                            * wave-tiled layout of its own and gathers them into these records here, asynchronously on hk_stream;
+                                            * write kart states with hk_set_agent_state, not through this pointer) */
 /* Device-resident RL loop (an external trainer that keeps its tensors on the GPU): hk_observe runs CollectObservations into
  * the library's device buffer (asynchronous, on the handle's stream; raises the HitWall / HitOpponent reward events like
  * hk_get_observations); hk_rewards_device moves m_Reward / m_GroupReward into the two device buffers and zeroes the

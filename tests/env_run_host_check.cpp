@@ -41,7 +41,9 @@ template <class T> static std::vector<T> read_n(FILE* f, size_t n)
 
 struct World {
     EnvParams P;
-    std::vector<hk_agent_state> agents;
+    std::vector<hk_agent_state> agents;   // cold fields + the staging copy of the hot ones (gathered from the tiles before every dump)
+    std::vector<uint32_t> hot;            // the hot tiles (hk_env_device.h), identity slot order: slot == env
+    std::vector<int> ident;               // perm == slot_of == identity
     std::vector<hk_env_state> envs;
     std::vector<hk_episode_result> results;
     std::vector<double> games;
@@ -60,8 +62,8 @@ static void launch_quad(World& W, int env, int round, int arm)
     for (unsigned l = 0; l < (unsigned)GA; l++)
         th[l] = std::thread([&, l] {
             threadIdx = {l, 0, 0};
-            env_run_kernel<HAS_MCTS, HAS_RW, HAS_TRAIN, false>(W.P, W.agents.data(), W.envs.data(), W.results.data(), G, W.queue_cnt.data(), W.queue.data(), round,
-                                                        nullptr, nullptr, nullptr, W.status, MctsDev{}, 0, W.RD, nullptr, W.stats.data(), env, env + 1, 0, arm, 0);
+            env_run_kernel<HAS_MCTS, HAS_RW, HAS_TRAIN, false>(W.P, W.agents.data(), W.hot.data(), W.envs.data(), W.results.data(), G, W.queue_cnt.data(), W.queue.data(), round,
+                                                        nullptr, nullptr, nullptr, W.status, MctsDev{}, 0, W.RD, W.ident.data(), W.stats.data(), env, env + 1, 0, arm, 0);
         });
     for (auto& t : th) t.join();
 }
@@ -90,6 +92,8 @@ int main(int argc, char** argv)
     W.P.eager = eager; W.P.run_cap = run_cap;
     const size_t na = (size_t)E * A;
     W.agents.assign(na, hk_agent_state{}); W.envs.assign(E, hk_env_state{}); W.results.assign(na, hk_episode_result{});
+    W.hot.assign(hot_words(E, GA), 0u); W.ident.resize(E);
+    for (int e = 0; e < E; e++) W.ident[e] = e;
     W.games.assign(na * GA * GP_FIELDS, 0.0);
     W.queue_cnt.assign(4 * 16, 0); W.queue.assign(4 * (GA - 1) * na, 0); W.stats.assign(64, 0ull);
     if (cfg.rewards) {
@@ -105,7 +109,7 @@ int main(int argc, char** argv)
     blockDim = {(unsigned)(E * GA), 1, 1};
     for (unsigned t = 0; t < (unsigned)(E * GA); t++) {
         threadIdx = {t, 0, 0};
-        env_reset_kernel(W.P, W.agents.data(), W.envs.data(), nullptr, E, -1, MctsDev{}, 0, W.RD, W.status);
+        env_reset_kernel(W.P, W.agents.data(), W.hot.data(), W.ident.data(), W.envs.data(), nullptr, E, -1, MctsDev{}, 0, W.RD, W.status);
     }
     blockDim = {(unsigned)GA, 1, 1};
 
@@ -143,9 +147,9 @@ int main(int argc, char** argv)
                     const int tick = t0 + n - es.reserved[0];         // the tick in progress (0-based): ticks finished so far
                     if (tick < 0 || tick >= n_ticks) { std::fprintf(stderr, "env %d: tick %d out of range\n", env, tick); return 4; }
                     const Ctl& c = ctl[((size_t)tick * E) * A + game];
-                    hk_agent_state& me = W.agents[game];
-                    me.flags = (me.flags & ~(uint32_t)(HK_F_ACCEL | HK_F_BRAKE)) | (c.flags & (uint32_t)(HK_F_ACCEL | HK_F_BRAKE));
-                    me.steering = c.steering;
+                    uint32_t* me = W.hot.data() + hot_base<GA>(env, game - env * A);      // what decode_store writes (hk_env_solve.h)
+                    hot_put<uint32_t>(me, HF_flags, (hot_get<uint32_t>(me, HF_flags) & ~(uint32_t)(HK_F_ACCEL | HK_F_BRAKE)) | (c.flags & (uint32_t)(HK_F_ACCEL | HK_F_BRAKE)));
+                    hot_put<float>(me, HF_steering, c.steering);
                     parked_games++;
                 }
             }
@@ -153,6 +157,7 @@ int main(int argc, char** argv)
             busy = false;
             for (int env = 0; env < E; env++) busy = busy || W.envs[env].reserved[0] != 0 || (W.envs[env].reserved[1] & ENV_PHASE_MASK) != 0;
         }
+        for (size_t t = 0; t < na; t++) store_hot(&W.agents[t], load_hot_tile(W.hot.data() + hot_base<GA>((int)(t / A), (int)(t % A))));   // hot_gather_kernel's part
         std::fwrite(W.agents.data(), sizeof(hk_agent_state), na, out);
         std::fwrite(W.envs.data(), sizeof(hk_env_state), E, out);
     }
