@@ -106,6 +106,7 @@ struct Tuning {
     int lazy_min_ticks = HK_LAZY_MIN_TICKS;    // HK_LAZY_MIN_TICKS: calls at least this long complete lazily (a look at the device instead of the worst-case rounds)
     bool fission_chunks = true;  // ... and the short fixed-round calls of planner / actor handles (HK_NO_FISSION_CHUNKS: the fused kernel)
     bool fission_mcts = true;    // ... and long calls of planner handles with LQNG low levels (HK_NO_FISSION_MCTS: the fused kernel for those)
+    bool park = false;           // HK_PARK=1: plain 3- / 4-agent handles run the fused kernel with LDS parking (hk_env_run.h PARK) instead of the fission schedule
     bool fission = true;         // plain 3- / 4-agent handles run the tick kernel without phase B1 + env_b1_kernel per solve cadence (hk_env_run.h); HK_FISSION=0: the fused kernel
     int debug_max_rounds = 0;    // HK_DEBUG_MAX_ROUNDS (diagnostic): cap on the rounds of a call, to look at the state in between
     bool debug_no_check = false; // HK_DEBUG_NO_CHECK (diagnostic): getters do not fail on the "did not complete" flag
@@ -122,7 +123,7 @@ struct Tuning {
         lazy_min_ticks = num("HK_LAZY_MIN_TICKS", HK_LAZY_MIN_TICKS, 1, 1 << 20);
         debug_max_rounds = num("HK_DEBUG_MAX_ROUNDS", 0, 0, 1 << 20);
         debug_no_check = flag("HK_DEBUG_NO_CHECK"); stamps_dump = flag("HK_STAMPS_DUMP");
-        { const char* f = std::getenv("HK_FISSION"); fission = !(f && std::atoi(f) == 0); fission_mcts = !flag("HK_NO_FISSION_MCTS"); fission_chunks = !flag("HK_NO_FISSION_CHUNKS"); }
+        { const char* f = std::getenv("HK_FISSION"); fission = !(f && std::atoi(f) == 0); fission_mcts = !flag("HK_NO_FISSION_MCTS"); fission_chunks = !flag("HK_NO_FISSION_CHUNKS"); park = flag("HK_PARK"); }
     }
 };
 
@@ -441,7 +442,7 @@ static int issue_rounds_split(hk_handle h, int rounds)
     if (!h->ev_fork) HK_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     const int E = h->cfg.num_envs;
     int cut[hk::SPLIT_WAYS_MAX + 1];                       // part k: lane groups [cut[k], cut[k + 1]) (a block of the tick kernel holds 64 lane groups)
-    for (int k = 0; k <= K; k++) cut[k] = k == K ? E : (int)(((long long)E * k / K + 63) / 64 * 64);
+    for (int k = 0; k <= K; k++) cut[k] = k == K ? E : (int)(((long long)E * k / K + 127) / 128 * 128);     // (whole blocks of the 512-thread form too)
     if ((h->dev.rounds_since_regroup += rounds) >= h->dev.regroup_rounds) {  // the periodic regroup by solve phase, here where the streams are joined
         int rcg = hk::env_launch_regroup(h->dev, h->cfg, h->stream, h->err);
         if (rcg) { g_last_error = h->err; return rcg; }
@@ -612,6 +613,8 @@ static int step_ticks(hk_handle h, int n_ticks)
     bool shaped = h->cfg.rewards != 0 || h->cfg.env_mode == HK_MODE_TRAINING;       // reward shaping / Training mode: their own instantiations of the fused kernel
     for (int i = 0; i < h->cfg.num_agents; i++) shaped = shaped || h->cfg.training_agent[i] != 0;
     h->dev.fission = h->tune.fission && plain && !shaped && h->dev.P.eager && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4;
+    h->dev.park = h->tune.park && plain && !shaped && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4 && h->dev.P.any_lqr != 0;
+    if (h->dev.park) h->dev.fission = false;
     // handles without an LQ agent (every low level an RL actor, attached or driven through hk_set_actions): the tick kernel of the fission
     // schedule alone — phase B1 has nothing to solve, no env parks for it, no B1 launch
     if (h->tune.fission && !shaped && h->dev.P.any_lqr == 0 && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4) h->dev.fission = true;     // (with a planner too: its hook stays in the tick loop)

@@ -622,6 +622,40 @@ __host__ __device__ __forceinline__ void store_hot_tile(uint32_t* p, const Hot& 
 #undef HK_X
 }
 
+// LDS parking (round 5): the fused tick kernel stores the hot fields phase B1 does not touch to the block's LDS before phase_assemble and
+// loads them back after it, between two compiler-level memory barriers, so that they are not live across the Riccati recursion: the
+// kernel's register peak is max(tick loop, phase B1), not their sum (the fused body used to spill 222 VGPRs to scratch).  Row f of the
+// parking area holds field f of every lane of the block (conflict-free: consecutive lanes, consecutive banks).
+#define HK_PARK_FIELDS(X)                                                                                                             \
+    X(float, acc_ang_v) X(float, avg_lane_diff) X(float, avg_vel_diff) X(float, contact_nx) X(float, contact_nz)                      \
+    X(int, lane) X(int, lane_changes) X(int, illegal_lane_changes) X(int, forward_collisions) X(int, last_collision_time)             \
+    X(int, time_steps) X(int, init_checkpoint_index) X(uint32_t, trig_lo) X(uint32_t, trig_hi) X(int, tele_completed_laps)            \
+    X(int, tele_lap_end_step) X(float, tele_last_lap) X(float, tele_best_lap) X(float, tele_total_time) X(float, steer_smoothed)      \
+    X(float, wheel_uf) X(float, wheel_ur)
+constexpr int PARK_ROWS = 22;
+template <int BLOCK>
+__device__ __forceinline__ void park_store(uint32_t* pk, const Hot& h)
+{
+    int r = 0;
+#define HK_X(T, n) pk[(r++) * BLOCK] = __builtin_bit_cast(uint32_t, h.n);
+    HK_PARK_FIELDS(HK_X)
+#undef HK_X
+#ifndef HK_HOST_EMU
+    __asm__ volatile("" ::: "memory");
+#endif
+}
+template <int BLOCK>
+__device__ __forceinline__ void park_load(const uint32_t* pk, Hot& h)
+{
+#ifndef HK_HOST_EMU
+    __asm__ volatile("" ::: "memory");
+#endif
+    int r = 0;
+#define HK_X(T, n) h.n = __builtin_bit_cast(T, pk[(r++) * BLOCK]);
+    HK_PARK_FIELDS(HK_X)
+#undef HK_X
+}
+
 // Sensor.Transform.forward: the kart's forward (fx, fz) turned by the sensor's local yaw (Unity Y rotation, +z toward +x)
 __device__ __forceinline__ void sensor_dir(const EnvParams& P, int si, float fx, float fz, float& dx, float& dz)
 {

@@ -63,6 +63,8 @@ struct EnvDevice {
     int* perm_alt = nullptr;
     bool b1_due = false;           // FISSION: the tick launch just issued parked its envs at their solve tick: env_b1_kernel is next on that stream
     int lqn_sparse_blocks = 1024;  // workgroups per queue of a solver launch once the field has spread (HK_LQN_SPARSE_BLOCKS)
+    bool park = false;             // plain handles run the fused kernel with LDS parking (hk_env_run.h PARK) instead of the fission schedule
+    bool park_attr_set = false;
     bool fission = false;          // the current call runs the tick kernel without phase B1 + env_b1_kernel (hk_env_run.h FISSION; hk_api.hip step_ticks)
     int arm_ticks = 0;             // > 0: the next tick launch adds these ticks to every env's count (a fixed-round call arms itself)
     bool last_solve_skippable = false;   // fixed-round call of a plain handle: no env can park in its last round, so that round queues no game (launch_lqn)

@@ -102,6 +102,22 @@ inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
     bool train = d.P.training_reset != 0;
     for (int i = 0; i < cfg.num_agents; i++) train = train || d.P.training_agent[i] != 0;
 #if HK_GA == 4
+    if (d.park && !d.fission && !train && !d.rw.sec_time && !d.mcts.st) {
+        // PARK (hk_env_run.h): the fused kernel, 512 threads a block, hot fields parked in LDS around phase B1
+        const GameSoA G{d.games, (size_t)cfg.num_envs * cfg.num_agents};
+        const unsigned blocks = (unsigned)((threads + PARK_BLOCK - 1) / PARK_BLOCK);
+        const size_t park_bytes = (size_t)PARK_ROWS * PARK_BLOCK * sizeof(uint32_t);
+        if (!d.park_attr_set) {
+            (void)hipFuncSetAttribute((const void*)env_run_kernel<false, false, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+            (void)hipFuncSetAttribute((const void*)env_run_kernel<false, false, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+            d.park_attr_set = true;
+        }
+#define HK_PARK_RUN(TL) hipLaunchKernelGGL((env_run_kernel<false, false, false, TL, false, true>), dim3(blocks), dim3(PARK_BLOCK), (TL ? d.tab_lds : 0) + park_bytes, stream, d.P, d.agents, d.hot, \
+                               d.envs, d.results, G, d.queue_cnt, d.queue, d.round, d.act_steer, d.act_branch, d.lq_debug, d.status, d.mcts, d.mset, d.rw, d.perm,   \
+                               d.game_stats, s0, s1, d.qbase, arm, guard)
+        if (d.tab_lds) HK_PARK_RUN(true); else HK_PARK_RUN(false);
+#undef HK_PARK_RUN
+    } else
     if (d.fission && !train && !d.rw.sec_time) {
         // FISSION (hk_env_run.h): the tick kernel without phase B1; launch_b1 follows on the same stream
         const GameSoA G{d.games, (size_t)cfg.num_envs * cfg.num_agents};

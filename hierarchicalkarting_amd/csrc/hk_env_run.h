@@ -176,10 +176,13 @@ __global__ __launch_bounds__(256) void envs_scatter_kernel(const hk_env_state* b
 #define HK_RUN_OCC 2
 #endif
 #ifndef HK_FIS_OCC
-#define HK_FIS_OCC 2
-#endif
-template <bool HAS_MCTS, bool HAS_RW, bool HAS_TRAIN, bool TAB_LDS, bool FISSION = false>
-__global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_run_kernel(EnvParams P, hk_agent_state* agents, uint32_t* hot, hk_env_state* envs,
+#define HK_FIS_OCC 3          // three waves per SIMD (168 VGPRs) since round 5: with the back-end switches of __graft_entry__.BACKEND_FLAGS the tick
+#endif                        // kernel needs 162 registers and no scratch; 1 632 -> 1 762 M env-steps/s (profiles/r05_a_backend_flags.txt)
+// PARK (round 5): the fused kernel in blocks of 512 threads (one per CU: the staged tables are shared by eight waves) with the hot fields
+// phase B1 does not read parked in LDS around phase_assemble (hk_env_device.h park_store / park_load).
+constexpr int PARK_BLOCK = 512;
+template <bool HAS_MCTS, bool HAS_RW, bool HAS_TRAIN, bool TAB_LDS, bool FISSION = false, bool PARK = false>
+__global__ __launch_bounds__(PARK ? PARK_BLOCK : 256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_run_kernel(EnvParams P, hk_agent_state* agents, uint32_t* hot, hk_env_state* envs,
                                                       hk_episode_result* results, GameSoA games, int* queue_cnt_all,
                                                       int* queue_all, int round, const float* act_steer, const int* act_branch,
                                                       hk_lq_debug* dbg_out, int* status, MctsDev Marg, int mset, RwDev RD, const int* perm,
@@ -193,8 +196,10 @@ __global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_ru
 #ifdef HK_LANEPROF
     hk_lp_ptr = stats;                 // (every thread stores the same value)
 #endif
-    __shared__ KartS ks[256];
+    __shared__ KartS ks[PARK ? PARK_BLOCK : 256];
     HK_DYN_SHARED(smem);
+    uint32_t* const pk = reinterpret_cast<uint32_t*>(smem + (TAB_LDS ? P.tab_stage_bytes : 0)) + threadIdx.x;      // PARK: this lane's column of the parking area
+    (void)pk;
     // this launch runs the lane groups [slot0, slot1) and uses the queue sets qbase, qbase + 1 (one launch for every env: 0, E, 0;
     // plain handles split the batch in two halves on two streams so that one half's solver launch hides behind the other's ticks)
     const int gid = slot0 * GA + blockIdx.x * blockDim.x + threadIdx.x;
@@ -288,7 +293,11 @@ __global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_ru
                                      !(!P.auto_reset && (es.inactive_mask & all_mask) == all_mask && (es.status & 4u)) &&
                                      !(P.hold_dedupe && es.episode_steps > cadence && es.episode_steps < P.hold);
                     if constexpr (FISSION) b1_pending = act && P.any_lqr != 0;      // (no LQ agent: nothing for env_b1_kernel to do, the env moves on)
-                    else qn = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
+                    else {
+                        if constexpr (PARK) park_store<PARK_BLOCK>(pk, h);
+                        qn = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
+                        if constexpr (PARK) park_load<PARK_BLOCK>(pk, h);
+                    }
                     began = true;
                     solved = act;
                 } else {
@@ -372,7 +381,7 @@ __global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_ru
 // functions (phase_assemble: sensor rays through the LDS wall grid, players within 8 m, assembly, lq1_solve in the ego's lane, multi-player
 // games to GameSoA + queues); of the kart record only what B1 reads is loaded and only what it decodes (flags, steering) is stored.
 #ifndef HK_B1_OCC
-#define HK_B1_OCC 2
+#define HK_B1_OCC 3
 #endif
 template <bool TAB_LDS, bool HAS_MCTS = false>
 __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_agent_state* agents, uint32_t* hot, hk_env_state* envs, GameSoA games, int* queue_cnt_all,

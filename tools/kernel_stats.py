@@ -13,7 +13,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 def stats(unit, defs):
     co = "/tmp/hk_stats_%s.co" % unit.replace(".hip", "")
     if not os.environ.get("HK_STATS_REUSE") or not os.path.exists(co):
-        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + ge.HIPCC_FLAGS + defs + ["--cuda-device-only", "-c", os.path.join(ge.CSRC, unit), "-o", co])
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + ge.HIPCC_FLAGS + ge._backend_flags(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) + defs + ["--cuda-device-only", "-c", os.path.join(ge.CSRC, unit), "-o", co])
     # the device-only output is an offload bundle: take the gfx950 code object out of it
     elf = co + ".elf"
     subprocess.check_call([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + co, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + elf])

@@ -28,7 +28,7 @@ def build():
     for u in ge.UNITS:
         o = os.path.join(ROOT, "build", "obj", "laneprof_" + u.replace(".hip", ".o"))
         objs.append(o)
-        procs.append(subprocess.Popen([hipcc] + ge.HIPCC_FLAGS + ["-DHK_LANEPROF", "-c", os.path.join(ge.CSRC, u), "-o", o]))
+        procs.append(subprocess.Popen([hipcc] + ge.HIPCC_FLAGS + ge._backend_flags(hipcc) + ["-DHK_LANEPROF", "-c", os.path.join(ge.CSRC, u), "-o", o]))
     assert all(p.wait() == 0 for p in procs)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs)
     print("built", LIB)
