@@ -183,6 +183,9 @@ __device__ HK_LQ1_ATTR void lq1_solve(const EnvParams& P, const GamePlayer& gp, 
 #pragma unroll
         for (int c = 0; c < 4; c++) { Pm[0][c] = b0[c]; Pm[1][c] = b1[c]; }
         alpha[0] = b0[4]; alpha[1] = b1[4];
+        // The last sweep's value update (KartLQR.cs:113-119 at t = 0) feeds nothing: u0 below reads this sweep's P and alpha only.  A quarter of
+        // the recursion's fp64 work, skipped (exact: no output depends on it; the oracle computes it and throws it away as the C# does).
+        if (t == 0) break;
         // F = A - (0 + B P): rows x, z keep A; rows v, h subtract dt * P
         double F[4][4];
 #pragma unroll

@@ -231,6 +231,10 @@ __device__ __forceinline__ void lq2_pair_solve(const int game, const int p, cons
         for (int a = 0; a < 2; a++)
 #pragma unroll
             for (int c = 0; c < n; c++) S.pp[8 * a + c][lane] = p ? Pfull[2 + a][c] : Pfull[a][c];
+
+        // The value update of the last sweep feeds nothing (u0 reads this sweep's P and alpha): skipped, as in lq1_solve.  (Written as a
+        // conditional around the rest of the sweep: a `break` here made the allocator spill 22 - 32 registers in every sweep.)
+        if (t > 0) {
         // ---------------- S5: F = A - sum_k B_k P_k; beta = -sum_k B_k alpha_k ----------------
         // position rows (x, z) of block k: F[4 k + 0 / 1][c] = A_k entries in the block's own columns, +0.0 elsewhere; dense rows
         // Fd[2 k + a][c] = F[4 k + 2 + a][c] = [c == 4 k + 2 + a] - (0.0 + dt P[2 k + a][c])
@@ -321,6 +325,7 @@ __device__ __forceinline__ void lq2_pair_solve(const int game, const int p, cons
             v2 = fma64(S.pp[8 * 1 + r][lane], ra1, v2);
             eta[r] = (qv[r] + v2) + v3;
         }
+        }       // t > 0
     }
     // :121-126 u0 = -P_0 x0 - alpha_0: rows 0, 1 of the last sweep's P are lane 0's own rows (S.pp); lane 1's value is not used
 #pragma unroll

@@ -259,6 +259,8 @@ __device__ void lq_solve_game(const int r, LqGameLds<NP>& L, const QP& qp, const
         SYNC::sync();
 #pragma unroll
         for (int i = 0; i < m; i++) alpha[i] = L.Pm[i][n];
+        // the value update of the last sweep (KartLQR.cs:113-119 at t = 0) feeds nothing: u0 below reads this sweep's P and alpha only
+        if (t == 0) break;
         // ---------------- S5: F = A - sum_k B_k P_k (column r), beta = -sum_k B_k alpha_k (row r) ----------------
 #pragma unroll
         for (int k = 0; k < NP; k++) {

@@ -228,6 +228,8 @@ __device__ void lq_solve_game_mfma(const int lane, LqMfmaLds<NP>& L, const QP& q
             alpha[i] = bv[i];
             if (g == 0) L.Pl[i][c] = bb[i];
         }
+        // the value update of the last sweep feeds nothing (u0 reads this sweep's P and alpha): skipped — a quarter of the products at horizon 3
+        if (t == 0) { X::sync(); break; }                                     // (P is in LDS)
         // ---------------- S5: F = A - sum_k B_k P_k (column c, all rows), beta = -sum_k B_k alpha_k (all rows) ----------------
         double Fcol[16], beta[16];
 #pragma unroll
