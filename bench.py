@@ -35,7 +35,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32-input MFMA = t
 STEADY_TICK = 512                      # steady state = ticks 512 .. 3584
 # HBM bytes and SQ counters cannot be read in-process: they come from the separate rocprofv3 --pmc passes of THIS command that
 # tools/pmc_summary.py folded into this file (committed with the profile it belongs to; `commit` / `command` inside say which)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
 
 
 def pmc_fields(kernel, env_steps_per_launch=None):
@@ -57,16 +57,37 @@ def pmc_fields(kernel, env_steps_per_launch=None):
     sq = (k.get("sq") or {}).get("derived")
     binding = None
     if sq:
-        binding = {"resource": "neither roof: VALU issue (two waves per SIMD) + waits at the head and tail of a launch (profiles/r04_e_launch_head_tail.txt)", "wave_issuing_valu_frac": sq.get("wave_issuing_valu_frac"), "wave_issuing_any_frac": sq.get("wave_issuing_any_frac"),
+        binding = {"resource": "neither roof: vector-instruction issue (%d waves per SIMD share one issue slot per four cycles) and the waits the resident waves cannot cover (profiles/r05_a_backend_flags.txt)" % d.get("waves_per_simd", 2), "wave_issuing_valu_frac": sq.get("wave_issuing_valu_frac"), "wave_issuing_any_frac": sq.get("wave_issuing_any_frac"),
                    "wave_waiting_frac": sq.get("wave_waiting_frac"), "waves_per_simd": d.get("waves_per_simd", 2),
                    "simd_valu_busy_frac": min(1.0, d.get("waves_per_simd", 2) * (sq.get("wave_issuing_valu_frac") or 0.0)),
                    "valu_lanes_active_of_64": sq.get("valu_lanes_active_of_64"), "valu_insts_per_launch": sq.get("valu_insts_per_launch"),
-                   "source": "SQ counters of the same PMC summary (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave; two waves share a SIMD)"}
+                   "source": "SQ counters of the same PMC summary (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave, times the waves that share a SIMD)"}
     traffic = k.get("hbm_bytes_per_launch")
     if traffic is not None and env_steps_per_launch and d.get("env_steps_per_launch"):
         prov["measured_bytes_per_env_step"] = traffic / d["env_steps_per_launch"]
         traffic = traffic * env_steps_per_launch / d["env_steps_per_launch"]
     return traffic, prov, binding
+
+
+def cadence_traffic(env_steps_per_tick_launch):
+    """HBM bytes of one solve cadence of the fission schedule = tick launch + B1 launch + solver launch of the committed PMC summary, scaled to this
+    run's env-steps per tick launch (a reader of `traffic` alone sees the tick kernel only: the B1 kernel moves about as much)"""
+    try:
+        d = json.load(open(PMC_SUMMARY))
+    except (OSError, ValueError):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from source_hash import source_hash
+    if d.get("sources_sha16") != source_hash() or not d.get("env_steps_per_launch"):
+        return None
+    parts = {k: (d.get(k) or {}).get("hbm_bytes_per_launch") for k in ("env_run_kernel", "env_b1_kernel", "lqn_round_kernel")}
+    if parts["env_run_kernel"] is None:
+        return None
+    scale = env_steps_per_tick_launch / d["env_steps_per_launch"]
+    tot = sum(v for v in parts.values() if v) * scale
+    return {"bytes_per_cadence_launch_set": tot, "bytes_per_env_step": tot / env_steps_per_tick_launch,
+            "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP, "ratio_to_algorithmic": tot / env_steps_per_tick_launch / ALGO_BYTES_PER_ENV_STEP,
+            "parts_bytes_per_launch": {k: (v * scale if v else None) for k, v in parts.items()}}
 
 
 def lq_flop(N, sweeps=4):
@@ -436,6 +457,10 @@ def bench_lqng(a, D, hk):
     env.synchronize()
     dt = timed_ticks(D, env, a.steps)                    # THE timed region: hk_prof off (its event records cost ~35 us per call)
     st = env.agent_state() if D.rank == 0 else None
+    # the same window again, back to back (up to 15 times while the race stays inside the protocol's steady stretch): how much of `value` is the
+    # noise of one short sample.  `value` stays the ONE window above.
+    n_rep = max(0, min(15, (STEADY_TICK + 3072 - (a.preroll + a.warmup + a.steps)) // max(a.steps, 1)))
+    rep_dt = [timed_ticks(D, env, a.steps) for _ in range(n_rep)]
     # the roofline's stage times come from a second, identical pass (same reset, pre-roll, warm-up, ticks) with hk_prof on; not `value`
     env.reset()
     if a.preroll > 0:
@@ -547,7 +572,10 @@ def bench_lqng(a, D, hk):
             roof = {"bound": "hbm", "kernel": "env_run_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo,
                     "traffic_provenance": prov, "binding": binding}
-            if env.split_default and a.steps >= 64:
+            cad = cadence_traffic(float(E) * a.steps / dom_n)
+            if cad:
+                roof["traffic_whole_cadence"] = cad
+            if env.split_for(a.steps):
                 # the default schedule of a long call runs the batch as two halves on two streams: two tick launches share the GPU, a launch's
                 # duration is no longer the kernel's own — the fraction of the roof is the whole job's (every kernel + the gaps), the per-launch
                 # figures (they agree with rocprofv3 --kernel-trace --stats of this command) stay beside it
@@ -591,6 +619,13 @@ def bench_lqng(a, D, hk):
                        "finished_episodes_seen": int((results["episode"] >= 0).any(axis=1).sum())},
             "roofline": roof,
         }
+        if rep_dt:
+            vals = sorted(E * D.world * a.steps / t for t in rep_dt)
+            med = vals[len(vals) // 2] if len(vals) % 2 else 0.5 * (vals[len(vals) // 2 - 1] + vals[len(vals) // 2])
+            out["window_repeats"] = {"n": len(vals), "min": vals[0], "median": med, "max": vals[-1], "unit": "env-steps/s",
+                                     "value_over_median": value / med,
+                                     "note": "the next %d back-to-back windows of the same %d ticks (race ticks %d..%d), each timed like `value`" % (
+                                         len(vals), a.steps, t_first + a.steps, t_first + a.steps * (1 + len(vals)))}
         out.update(secondary)
         if not a.no_cpu_baseline and D.world == 1:          # reported on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(A, seed, a.preroll)

@@ -59,6 +59,8 @@ def main():
         elif a[i] == "--last":
             global LAST
             LAST = int(a[i + 1]); i += 2
+        elif a[i] == "--waves-per-simd":                # waves of the tick / B1 kernels that share a SIMD (their launch bounds: HK_FIS_OCC / HK_B1_OCC)
+            meta["waves_per_simd"] = int(a[i + 1]); i += 2
         elif a[i] == "--env-steps-per-launch":          # what one full-size launch of the tick kernel advances in the profiled window (E x ticks per launch)
             meta["env_steps_per_launch"] = float(a[i + 1]); i += 2
         else:
