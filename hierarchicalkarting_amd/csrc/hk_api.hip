@@ -106,6 +106,7 @@ struct Tuning {
     int lazy_min_ticks = HK_LAZY_MIN_TICKS;    // HK_LAZY_MIN_TICKS: calls at least this long complete lazily (a look at the device instead of the worst-case rounds)
     bool fission_chunks = true;  // ... and the short fixed-round calls of planner / actor handles (HK_NO_FISSION_CHUNKS: the fused kernel)
     bool fission_mcts = true;    // ... and long calls of planner handles with LQNG low levels (HK_NO_FISSION_MCTS: the fused kernel for those)
+    bool mcts_overlap = true;    // HK_MCTS_NO_OVERLAP=1: long calls of planner handles launch a replan's searches when its stretch of rounds has ended, on the handle's stream (the schedule before round 5)
     bool park = false;           // HK_PARK=1: plain 3- / 4-agent handles run the fused kernel with LDS parking (hk_env_run.h PARK) instead of the fission schedule
     bool fission = true;         // plain 3- / 4-agent handles run the tick kernel without phase B1 + env_b1_kernel per solve cadence (hk_env_run.h); HK_FISSION=0: the fused kernel
     int debug_max_rounds = 0;    // HK_DEBUG_MAX_ROUNDS (diagnostic): cap on the rounds of a call, to look at the state in between
@@ -123,7 +124,7 @@ struct Tuning {
         lazy_min_ticks = num("HK_LAZY_MIN_TICKS", HK_LAZY_MIN_TICKS, 1, 1 << 20);
         debug_max_rounds = num("HK_DEBUG_MAX_ROUNDS", 0, 0, 1 << 20);
         debug_no_check = flag("HK_DEBUG_NO_CHECK"); stamps_dump = flag("HK_STAMPS_DUMP");
-        { const char* f = std::getenv("HK_FISSION"); fission = !(f && std::atoi(f) == 0); fission_mcts = !flag("HK_NO_FISSION_MCTS"); fission_chunks = !flag("HK_NO_FISSION_CHUNKS"); park = flag("HK_PARK"); }
+        { const char* f = std::getenv("HK_FISSION"); fission = !(f && std::atoi(f) == 0); fission_mcts = !flag("HK_NO_FISSION_MCTS"); fission_chunks = !flag("HK_NO_FISSION_CHUNKS"); park = flag("HK_PARK"); mcts_overlap = !flag("HK_MCTS_NO_OVERLAP"); }
     }
 };
 
@@ -155,6 +156,8 @@ struct hk_context {
     bool split = false;            // the current call runs the batch as two halves on two streams (issue_rounds)
     int round_half[hk::SPLIT_WAYS_MAX] = {};    // each part's own round counter (the parity picks its queue set)
     hipEvent_t ev_fork = nullptr, ev_join[hk::SPLIT_WAYS_MAX - 1] = {};
+    hipStream_t mcts_stream = nullptr;                  // the search launch of a replan runs here, beside the tick launches up to the plans' deadline (step_ticks, pause mode)
+    hipEvent_t ev_mcts_go = nullptr, ev_mcts_done = nullptr;
     int* done_host = nullptr;      // pinned: [0] max ticks left over the envs, [1] an env waits for a queued game
     void* pol_scratch = nullptr;   // hk_policy_forward staging
     size_t pol_scratch_bytes = 0;
@@ -283,6 +286,9 @@ void hk_destroy(hk_handle h)
     h->prof.fold();
     for (hipEvent_t e : h->prof.pool) (void)hipEventDestroy(e);
     for (hipStream_t q : h->qstream) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+    if (h->mcts_stream) { (void)hipStreamSynchronize(h->mcts_stream); (void)hipStreamDestroy(h->mcts_stream); }
+    if (h->ev_mcts_go) (void)hipEventDestroy(h->ev_mcts_go);
+    if (h->ev_mcts_done) (void)hipEventDestroy(h->ev_mcts_done);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (hipEvent_t e : h->ev_join) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -577,9 +583,48 @@ static int step_ticks(hk_handle h, int n_ticks)
             // a stretch: enough rounds for EVERY env to reach its next replan (<= 100 ticks away) or the end of the call, also one
             // that meets a multi-player game on every solve tick (a solve cadence per round).  The rounds in which most envs already
             // wait cost tens of microseconds; a second search launch for the late ones would cost a full search latency
-            const int reach = std::min(maxleft, 100);
-            rc = issue_rounds(h, (reach + cadence - 1) / cadence + 2);
-            if (rc) return rc;
+            int reach = std::min(maxleft, 100);
+            // Round 5: a replan's searches run BESIDE the ticks that follow it.  The reference's search thread works for T = 0.9 s while FixedUpdate
+            // goes on (HKA:172-284) and its plan is used mcts_latency_ticks after the request; an env with an outstanding search now steps on until
+            // that tick (hk_env_run.h held_now) instead of stopping at once, so the search launch — as long as ONE search whatever the batch, ~10 ms —
+            // can share the GPU with up to 44 ticks of every env.  The host does not know when requests are posted; it guesses from the ticks since the
+            // last reset of every env (a field that was reset together replans together, on episode steps that are multiples of 100): the stretch is cut
+            // to end 40 ticks after the next such step, the searches are launched on a side stream right after the round that is expected to post the
+            // requests, and the handle's stream waits for them only before the rounds that could reach the deadline.  A wrong guess costs the overlap,
+            // nothing else: every stretch still ends with a search launch for whatever is queued, and no env passes its deadline unserved (device side).
+            const int lat = std::min(h->cfg.mcts_latency_ticks, h->cfg.mcts_initial_latency_ticks);
+            { const char* sw = std::getenv("HK_MCTS_SIDE_WAVES"); if (sw) h->dev.mcts_side_waves = std::atoi(sw) == 4 ? 4 : (std::atoi(sw) == 0 ? 0 : 8); }
+            const bool overlap = h->tune.mcts_overlap && h->dev.fission && cadence == 4 && lat >= 24;
+            int r_post = -1, r_free = 0;
+            if (overlap) {
+                const long long T = (long long)h->dev.ticks_since_reset + (n_ticks - maxleft);      // episode step of a field in lock-step
+                const int k = 100 - (int)(T % 100);                                                 // ticks to the next replan step (1 .. 100)
+                const int after = ((lat - 1) / cadence - 1) * cadence;                              // whole rounds an env runs on before its deadline (45 -> 40 ticks)
+                reach = std::min(maxleft, (k + after - 1) % 100 + 1);
+                if (k <= reach) { r_post = (k + cadence - 1) / cadence + 1; r_free = after / cadence; }
+            }
+            const int stretch_rounds = (reach + cadence - 1) / cadence + 2;
+            if (r_post > 0 && r_post < stretch_rounds) {
+                if (!h->mcts_stream) HK_HIP(h, hipStreamCreateWithFlags(&h->mcts_stream, hipStreamNonBlocking));
+                if (!h->ev_mcts_go) HK_HIP(h, hipEventCreateWithFlags(&h->ev_mcts_go, hipEventDisableTiming));
+                if (!h->ev_mcts_done) HK_HIP(h, hipEventCreateWithFlags(&h->ev_mcts_done, hipEventDisableTiming));
+                rc = issue_rounds(h, r_post);
+                if (rc) return rc;
+                HK_HIP(h, hipEventRecord(h->ev_mcts_go, h->stream));
+                HK_HIP(h, hipStreamWaitEvent(h->mcts_stream, h->ev_mcts_go, 0));
+                rc = hk::env_flush_mcts_on(h->dev, h->stream, h->mcts_stream, h->err);
+                if (rc) { g_last_error = h->err; return rc; }
+                HK_HIP(h, hipEventRecord(h->ev_mcts_done, h->mcts_stream));
+                const int r2 = std::min(stretch_rounds - r_post, r_free);
+                rc = issue_rounds(h, r2);
+                if (rc) return rc;
+                HK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_mcts_done, 0));
+                rc = issue_rounds(h, stretch_rounds - r_post - r2);
+                if (rc) return rc;
+            } else {
+                rc = issue_rounds(h, stretch_rounds);
+                if (rc) return rc;
+            }
             rc = hk::env_flush_mcts(h->dev, h->stream, h->err);
             if (rc) { g_last_error = h->err; return rc; }
             rc = issue_check(h, true);

@@ -39,6 +39,14 @@ template <int J> __device__ __forceinline__ float group_get(float v) { return __
 // f(std::integral_constant<int, j>) for j = 0 .. GA - 1, unrolled
 template <class F, int... Js> __device__ __forceinline__ void for_lanes_impl(F&& f, std::integer_sequence<int, Js...>) { (f(std::integral_constant<int, Js>{}), ...); }
 template <class F> __device__ __forceinline__ void for_each_lane(F&& f) { for_lanes_impl(f, std::make_integer_sequence<int, GA>{}); }
+// minimum over the lanes of the group (every lane gets the result)
+__device__ __forceinline__ int group_min(int v)
+{
+    int o = __shfl_xor(v, 1, 64); v = o < v ? o : v;
+    o = __shfl_xor(v, 2, 64); v = o < v ? o : v;
+    if (GA > 4) { o = __shfl_xor(v, 4, 64); v = o < v ? o : v; }
+    return v;
+}
 // OR over the lanes of the group (every lane gets the result)
 __device__ __forceinline__ int group_or(int v)
 {

@@ -63,6 +63,7 @@ struct EnvDevice {
     int* perm_alt = nullptr;
     bool b1_due = false;           // FISSION: the tick launch just issued parked its envs at their solve tick: env_b1_kernel is next on that stream
     int lqn_sparse_blocks = 1024;  // workgroups per queue of a solver launch once the field has spread (HK_LQN_SPARSE_BLOCKS)
+    int mcts_side_waves = 8;       // waves per workgroup of a search launch that runs beside tick launches (HK_MCTS_SIDE_WAVES; 0: as alone)
     bool park = false;             // plain handles run the fused kernel with LDS parking (hk_env_run.h PARK) instead of the fission schedule
     bool park_attr_set = false;
     bool fission = false;          // the current call runs the tick kernel without phase B1 + env_b1_kernel (hk_env_run.h FISSION; hk_api.hip step_ticks)
@@ -110,6 +111,7 @@ struct GaOps {
     int (*launch_mcts_table)(EnvDevice& d, int ego0, int ntab, hipStream_t stream, std::string& err);
     int (*launch_mcts_invalidate)(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err);
     int (*flush_mcts)(EnvDevice& d, hipStream_t stream, std::string& err);
+    int (*flush_mcts_on)(EnvDevice& d, hipStream_t stream, hipStream_t side, std::string& err);
     int (*launch_reset)(EnvDevice& d, const int* dids, int cnt, int experiment_num, hipStream_t stream, std::string& err);
     int (*launch_regroup)(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err);
     int (*launch_run)(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err);

@@ -212,6 +212,7 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
 }
 
 inline int env_flush_mcts(EnvDevice& d, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, flush_mcts(d, stream, err)); }
+inline int env_flush_mcts_on(EnvDevice& d, hipStream_t stream, hipStream_t side, std::string& err) { return HK_GA_CALL(d, flush_mcts_on(d, stream, side, err)); }
 inline int env_mcts_invalidate(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_mcts_invalidate(d, cfg, stream, err)); }
 
 inline int env_reset(EnvDevice& d, const hk_config& cfg, const int32_t* env_ids, int n, int experiment_num, hipStream_t stream,

@@ -34,9 +34,12 @@ inline int launch_mcts_invalidate(EnvDevice& d, const hk_config& cfg, hipStream_
 // most RUN_CAP ticks per round, so flushing every MCTS_FLUSH_ROUNDS rounds with (MCTS_FLUSH_ROUNDS + 1) * RUN_CAP < latency
 // is early enough — and batching the requests of several rounds into one launch matters, because a launch takes as long
 // as its slowest search however few searches it holds.
-inline int flush_mcts(EnvDevice& d, hipStream_t stream, std::string& err)
+// (side != nullptr: the search kernels go to `side` — the caller has ordered it behind the tick launches that posted the requests — while the clearing
+// of the queue set the tick kernel fills next stays on `stream`, ahead of those launches)
+inline int flush_mcts_on(EnvDevice& d, hipStream_t stream, hipStream_t side, std::string& err)
 {
     if (!d.mcts.st) return HK_OK;
+    hipStream_t kstream = side ? side : stream;
     for (int c = 0; c < d.n_mcls; c++) {          // one launch per gameParams class: its tables ride in the workgroups' LDS, its agents' entries are searched
         const EnvDevice::MctsClass& K = d.mcls[c];
         MctsDev M = d.mcts;
@@ -44,6 +47,9 @@ inline int flush_mcts(EnvDevice& d, hipStream_t stream, std::string& err)
         // one workgroup per CU, 4 waves (one per SIMD) while the grid is at most 1 024 waves, 8 beyond; the move tables ride in its LDS
         const int total_waves = (d.mcts.grid_lanes + 63) / 64;
         int waves = total_waves <= 1024 ? 4 : 8;
+        // beside tick launches (side != nullptr): two waves per SIMD on HALF the CUs — a search workgroup's tables take ~100 KB of a CU's LDS, and
+        // beside one a CU holds a single tick / B1 block instead of three; packed two to a SIMD the searches leave the other CUs to the ticks
+        if (side && d.mcts_side_waves) waves = d.mcts_side_waves;
         while (waves > 4 && mcts_search_lds_bytes(K.ntab, d.P.L, K.na, K.lds_tier, waves) > 160 * 1024) waves -= 2;      // (8 karts: the path arrays of 8 waves do not fit beside the tables)
         const size_t lds = mcts_search_lds_bytes(K.ntab, d.P.L, K.na, K.lds_tier, waves);
         if (!d.mcts.lds_attr_set) {
@@ -51,8 +57,8 @@ inline int flush_mcts(EnvDevice& d, hipStream_t stream, std::string& err)
             (void)hipFuncSetAttribute((const void*)mcts_search_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             d.mcts.lds_attr_set = 1;
         }
-        if (K.lds_tier == 7) hipLaunchKernelGGL(mcts_search_kernel<true>, dim3((total_waves + waves - 1) / waves), dim3(waves * 64), lds, stream, d.P, M, d.mset, K.ntab, K.agents);
-        else hipLaunchKernelGGL(mcts_search_kernel<false>, dim3((total_waves + waves - 1) / waves), dim3(waves * 64), lds, stream, d.P, M, d.mset, K.ntab, K.agents);
+        if (K.lds_tier == 7) hipLaunchKernelGGL(mcts_search_kernel<true>, dim3((total_waves + waves - 1) / waves), dim3(waves * 64), lds, kstream, d.P, M, d.mset, K.ntab, K.agents);
+        else hipLaunchKernelGGL(mcts_search_kernel<false>, dim3((total_waves + waves - 1) / waves), dim3(waves * 64), lds, kstream, d.P, M, d.mset, K.ntab, K.agents);
     }
     int rc = launch_check(err, "mcts_search_kernel");
     if (rc) return rc;
@@ -62,6 +68,7 @@ inline int flush_mcts(EnvDevice& d, hipStream_t stream, std::string& err)
     if (hipMemsetAsync(d.mcts.qcnt + d.mset * 2, 0, 2 * sizeof(int), stream) != hipSuccess) { err = "mcts queue memset"; return HK_ERR_HIP; }
     return HK_OK;
 }
+inline int flush_mcts(EnvDevice& d, hipStream_t stream, std::string& err) { return flush_mcts_on(d, stream, nullptr, err); }
 
 inline int launch_reset(EnvDevice& d, const int* dids, int cnt, int experiment_num, hipStream_t stream, std::string& err)
 {
@@ -278,7 +285,7 @@ inline size_t hot_tile_words(int E) { return hot_words(E, GA); }
 inline const GaOps& make_ops()
 {
     static const GaOps ops = {mcts_req_bytes, mcts_searches_per_wave, mcts_lds_bytes, mcts_root_words, game_doubles_per_ego, queue_ints_per_set,
-                              launch_mcts_table, launch_mcts_invalidate, flush_mcts, launch_reset, launch_regroup, launch_run, launch_b1, launch_lqn,
+                              launch_mcts_table, launch_mcts_invalidate, flush_mcts, flush_mcts_on, launch_reset, launch_regroup, launch_run, launch_b1, launch_lqn,
                               launch_observe, launch_arm, launch_done_check, launch_rewards_read, launch_hot_gather, launch_hot_scatter, launch_envs_gather,
                               launch_envs_scatter, hot_tile_words};
     return ops;

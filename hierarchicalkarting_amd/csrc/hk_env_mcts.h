@@ -884,6 +884,9 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
     }
     mst->pend = plan;
     if (M.persist) R.tree_nodes = n_nodes;
+    // the plan first, device-wide, then "done": a tick launch may run BESIDE this kernel (hk_api.hip: the search of a replan overlaps the ticks up
+    // to the plan's deadline) and reads the plan only after it has read done_gen == gen
+    __threadfence();
     R.done_gen = R.gen;
 }
 
@@ -891,8 +894,17 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
 __device__ __forceinline__ bool mcts_search_outstanding(const EnvParams& P, const MctsDev& M, int env, int i)
 {
     if (i >= P.A || P.high_mode[i] != HK_HIGH_MCTS) return false;
-    const MctsReq& R = mc_reqs(M)[(size_t)env * P.A + i];
+    const volatile MctsReq& R = mc_reqs(M)[(size_t)env * P.A + i];      // (volatile: the search kernel may write done_gen while this launch runs)
     return R.gen != R.done_gen;
+}
+// P.mcts_pause: the first episode step this lane's agent must not BEGIN while its requested search has not run — the step that promotes the
+// search's result (hk_mcts_state.ready_step; mcts_consume) — or INT_MAX when nothing is outstanding.  Until then the env keeps stepping: the
+// reference's search thread runs beside FixedUpdate for T seconds (HKA:172-284), and here the search kernel runs beside the tick launches.
+__device__ __forceinline__ int mcts_hold_step(const EnvParams& P, const MctsDev& M, int env, int i)
+{
+    if (!mcts_search_outstanding(P, M, env, i)) return 0x7FFFFFFF;
+    const int rs = M.st[(size_t)env * P.A + i].ready_step;
+    return rs >= 0 ? rs : 0x7FFFFFFF;
 }
 
 // The search kernel: a fixed grid of waves (<= MCTS_ARENA_WAVES) walks the queue with a grid stride, so every wave ends when the queue

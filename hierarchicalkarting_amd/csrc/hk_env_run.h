@@ -253,7 +253,17 @@ __global__ __launch_bounds__(PARK ? PARK_BLOCK : 256, FISSION ? HK_FIS_OCC : HK_
     HK_ST(h, 0);                       // [0] prologue: (table staging,) state load
     // P.mcts_pause (long hk_step calls of planner handles): an env with a requested, not yet run search waits at the tick boundary —
     // the host launches the searches of a whole stretch of rounds in ONE batch (a launch lasts as long as one search however few it holds)
-    bool held = HAS_MCTS && P.mcts_pause && env_ok && group_or(mcts_search_outstanding(P, M, env, i) ? 1 : 0) != 0;
+    // (round 5: the env does not stop at once — it runs on until the step that would use the search's result, a replan tick or a reset, so that
+    // the search launch overlaps up to mcts_latency_ticks of stepping.  hold_at: the first episode step the env may not begin, group-uniform.)
+    int hold_at = 0x7FFFFFFF;
+    if (HAS_MCTS && P.mcts_pause && env_ok) hold_at = group_min(mcts_hold_step(P, M, env, i));
+    auto held_now = [&]() -> bool {
+        if (!(HAS_MCTS && P.mcts_pause) || hold_at == 0x7FFFFFFF) return false;
+        const int nxt = es.episode_steps + 1;
+        // (the step that promotes the result; a replan tick; the tick of an auto-reset — each would touch the request record the search kernel works on)
+        return nxt >= hold_at || nxt % 100 == 0 || (P.auto_reset && (nxt >= P.max_steps || (es.inactive_mask & all_mask) == all_mask));
+    };
+    bool held = held_now();
     // Eager assembly (P.eager, cadence 4).  A budget that ends on a solve tick would leave that tick's games to the NEXT launch:
     // an env that then meets a multi-player game parks at once and sits out the whole launch.  Instead the budget is trimmed so
     // that it ends on a solve tick (first launch of a call, after a reset), and the env runs phases A / B1 of that tick before
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(PARK ? PARK_BLOCK : 256, FISSION ? HK_FIS_OCC : HK_
             // (FISSION: on a solve tick the planner hook follows SolveLQR, i.e. it runs in env_b1_kernel)
             if (M.st && !(FISSION && b1_pending)) phase_plan(P, M, mset, env, i, es, h.flags, h.section_index, h.lane, h.lane_changes, h.final_steer, arec);
             // requests are posted on replan ticks (phase_plan) and on the reset tick (phase_begin): look again after those
-            if (HAS_MCTS && P.mcts_pause && es.episode_steps % 100 == 0) held = group_or(mcts_search_outstanding(P, M, env, i) ? 1 : 0) != 0;
+            if (HAS_MCTS && P.mcts_pause && es.episode_steps % 100 == 0) hold_at = group_min(mcts_hold_step(P, M, env, i));
             HK_ST(h, 6);           // [6] queue binning (+ planner hooks)
             // does any ego of this env wait for a queued multi-player solve?  (or was this the assembly at the end of the budget)
             const bool queued = FISSION ? false : group_or(qn ? 1 : 0) != 0;
@@ -335,6 +345,7 @@ __global__ __launch_bounds__(PARK ? PARK_BLOCK : 256, FISSION ? HK_FIS_OCC : HK_
         {
             // the assembly-only iteration at the end of the budget (see above) is taken once, by an env that just ran out of budget on a
             // solve tick; it ends the env's part in this launch
+            held = held_now();
             const bool again = left > 0 && budget > 0 && !held;
             const bool last = P.eager != 0 && cadence > 1 && !eager_it && phase == 0 && left > 0 && budget <= 0 && !held && ((es.episode_steps + 1) & cmask) == 0;
 #ifdef HK_LOOP_IFELSE
