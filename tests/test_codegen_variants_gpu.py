@@ -1,0 +1,98 @@
+"""The parity suite on more than one code generation of the env kernels.
+
+The code-generation guard (tools/check_spill_exec.py) matches ONE pattern — a spill store ahead of its block's EXEC restore — and
+profiles/r04_d_g8_3007662_resurrection.txt is a failure of this toolchain that it calls clean.  What stands between a second pattern and a
+user is the GPU parity suite, which used to run on exactly one register allocation of each unit.  Here hk_ga4.hip / hk_ga8.hip are
+rebuilt with the first two result-neutral perturbations of __graft_entry__.GUARD_VARIANTS (the ones build() itself falls back to when the
+guard flags a unit) into build/libhk_v1.so / libhk_v2.so, and the tick-by-tick env runs, the 8-agent run, a planner + actor + rewards run
+and the headline's schedules must be bit-identical to the oracle on each: a fault of the back end then has to survive three register
+allocations to ship.  The variants are compiled on this box when they are missing or older than the sources (cross-compiled by
+tools/build_variant.py wherever the tree was prepared, they travel with it).  The child process loads the variant through HK_LIB_PATH and is
+started before this process has touched the GPU with it."""
+import json
+import os
+import subprocess
+import sys
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CHILD = r"""
+import sys, os
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+import oracle_lib as O
+import hierarchicalkarting_amd as hk
+from hierarchicalkarting_amd import _lib
+from hierarchicalkarting_amd.policy import Policy
+assert os.path.samefile(_lib.LIB_PATH, %r)
+
+def cmp(g, o, t):
+    gs, os_ = g.agent_state(), o.agent_state()
+    for name in gs.dtype.names:
+        x, y = gs[name], os_[name]
+        if x.dtype.kind == "f":
+            x = x.view(np.uint32); y = y.view(np.uint32)
+        assert np.array_equal(x, y), (t, name, np.argwhere(x != y)[:3].tolist())
+
+def run(b, calls, attach=None):
+    g = hk.RacingEnv(b); o = O.OracleEnv(b)
+    if attach:
+        for e in (g, o): e.attach_policy(*attach)
+    g.reset(); o.reset()
+    t = 0
+    for n in calls:
+        g.step(n); o.step(n); t += n
+        cmp(g, o, t)
+    return g, o
+
+# the headline instantiation, tick by tick through the start, then the call shapes of every schedule (fixed rounds, lazy, split is off at this size)
+run(hk.make_config(96, 4, jitter_seed=0x5EED0000, laps=1), [1] * 90 + [4, 3, 20, 7, 64, 130, 300, 700])
+# ... on the Complex track (Trigger masks in global memory) and with 3 agents
+run(hk.make_config(64, 4, jitter_seed=3, laps=1, track="complex"), (80, 1, 1, 2, 20, 200, 400))
+run(hk.make_config(64, 3, jitter_seed=5, laps=1), (80, 20, 200, 300))
+# two agents (cadence 1, the fused kernel) and eight (the 8-lane unit)
+run(hk.make_config(128, 2, jitter_seed=7, laps=1), (80, 1, 20, 200, 300))
+run(hk.make_config(96, 8, jitter_seed=0x5EED0000, laps=1), (130, 70, 20, 7, 1, 300))
+# Training mode + rewards (the <true, true, true> instantiation), time-outs
+run(hk.make_config(24, 4, env_mode=_lib.HK_MODE_TRAINING, training_agents=[1, 1, 0, 0], laps=1, max_episode_steps=300, rewards=1, jitter_seed=0, track="complex"),
+    (100, 1, 199, 57, 243))
+# planner + attached actor + rewards (the planner and chunk schedules), and the plans themselves
+b = hk.make_config(16, 4, jitter_seed=7, rewards=1, mcts_iterations=16, tree_search_depth=[8, 8, 5, 5],
+                   high_mode=[_lib.HK_HIGH_MCTS, _lib.HK_HIGH_MCTS, _lib.HK_HIGH_FIXED, _lib.HK_HIGH_FIXED],
+                   low_mode=[_lib.HK_LOW_RL, _lib.HK_LOW_LQR, _lib.HK_LOW_LQR, _lib.HK_LOW_LQR])
+g, o = run(b, (130, 40, 131), attach=(Policy.random(hk.RacingEnv(b).obs_dim * 4, 128, 3, seed=1), [0], 2))
+assert np.array_equal(g.mcts_state()["best"]["lane"], o.mcts_state()["best"]["lane"])
+# a planner handle's long call (pause mode: searches beside the ticks up to the plans' deadline)
+b = hk.make_config(32, 4, jitter_seed=9, mcts_iterations=16, tree_search_depth=8, high_mode=_lib.HK_HIGH_MCTS, track="complex", laps=1)
+g, o = run(b, (300, 260))
+assert np.array_equal(g.mcts_state()["best"]["lane"], o.mcts_state()["best"]["lane"])
+print("variant ok")
+"""
+
+
+def _variant_lib(k):
+    import __graft_entry__ as ge
+    flags = ge.GUARD_VARIANTS[k]
+    lib = os.path.join(ROOT, "build", "libhk_v%d.so" % k)
+    src = os.path.join(ROOT, "hierarchicalkarting_amd", "csrc")
+    newest = max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src))
+    if not (os.path.exists(lib) and os.path.getmtime(lib) >= newest):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "build_variant.py"), "v%d" % k, "--units", "hk_ga4.hip,hk_ga8.hip", "--flags"] + flags,
+                           capture_output=True, text=True, timeout=1700)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    return lib, flags
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_parity_holds_on_another_register_allocation(k):
+    lib, flags = _variant_lib(k)
+    guard = json.load(open(lib[:-3] + ".guard.json"))
+    assert guard["flags"] == flags
+    if guard["spill_stores_ahead_of_exec_restore"]:
+        pytest.skip("variant %d %s is flagged by the code-generation guard itself (%d store(s)): it would never ship" % (k, flags, len(guard["spill_stores_ahead_of_exec_restore"])))
+    env = dict(os.environ, HK_LIB_PATH=lib)
+    r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, ROOT, lib)], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "variant ok" in r.stdout, "variant %d %s:\n" % (k, flags) + r.stdout[-2000:] + r.stderr[-4000:]

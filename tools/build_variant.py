@@ -20,9 +20,10 @@ def main():
     unit = "hk_ga4.hip"
     if "--unit" in sys.argv:
         unit = sys.argv[sys.argv.index("--unit") + 1]
+    unit_list = sys.argv[sys.argv.index("--units") + 1].split(",") if "--units" in sys.argv else None      # --units a.hip,b.hip: several units with the flags
     ge.build()
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    units = list(ge.UNITS) if "--all" in head else [unit]       # --all: every unit with the flags (constants the host code shares with the kernels)
+    units = list(ge.UNITS) if "--all" in head else (unit_list or [unit])       # --all: every unit with the flags (constants the host code shares with the kernels)
     objs, procs, listings = [], [], []
     import json
     try:
