@@ -134,10 +134,6 @@ def make_config(num_envs, num_agents=4, track="oval", high_mode=_lib.HK_HIGH_FIX
     eng = dict(ENGINE_PARAMS)
     if engine:
         eng.update(engine)
-    if os.environ.get("HK_ENG"):                      # model fitting (tools/fit_engine.py): "key=value,..."
-        for kv in os.environ["HK_ENG"].split(","):
-            k, v = kv.split("=")
-            eng[k] = float(v)
     for k, v in eng.items():
         setattr(cfg.engine, k, int(v) if k in ("wheel_friction", "contact_yaw", "wheel_rolling") else v)
     rules = tr["rules"]

@@ -298,6 +298,9 @@ HK_HD int hk__rem_pio2_f(double x, double* r)     /* the reduction of hk__rem_pi
 }
 HK_HD void hk__sincos_f(double x, double* s, double* c)
 {
+    /* the three-term reduction below is exact for |k| < ~2^20 and its int cast needs a finite argument: beyond 1e5 (and for inf / NaN) the
+     * double kernels with their full reduction take over (never on the hot path: headings are kept in [0, 2 pi)) */
+    if (!(hk_fabs(x) < 1.0e5)) { hk_sincos(x, s, c); return; }
     double r;
     const int q = hk__rem_pio2_f(x, &r);
     const double ks = hk__ksin_f(r), kc = hk__kcos_f(r);
@@ -319,7 +322,7 @@ HK_HD void hk_sincosf_near0(float x, float* s, float* c)
 }
 HK_HD double hk__atan01_f(double t)     /* atan(t), t in [0, 1]: the table of hk__atan01, the series of the remainder to u^9 (|u| <= 1/16: next term < 2^-47) */
 {
-    const int j = (int)(t * 8.0 + 0.5);
+    const int j = (int)((t == t ? t : 0.0) * 8.0 + 0.5);          /* (a NaN quotient — inf / inf, a NaN input — must not reach the int cast; it still propagates through u) */
     const double c = (double)j * 0.125;
     const double u = (t - c) / HK_FMA(t, c, 1.0);
     const double z = u * u;
@@ -341,7 +344,7 @@ HK_HD float hk_atan2f(float fy, float fx)
     const double a = hk__atan01_f(num / dnm);
     double r = lower ? a : PIO2 - a;
     if (x < 0.0) r = PI - r;
-    return (float)(y < 0.0 ? -r : r);
+    return (float)(__builtin_signbit(fy) ? -r : r);      /* the SIGN BIT of y, as Math.Atan2: atan2(-0, x < 0) = -pi, atan2(-0, x > 0) = -0 */
 }
 HK_HD float hk_expf(float fx)           /* x = k ln2 + r, |r| <= ln2 / 2: e^r to r^11 / 11! (next term < 2^-47), scaled by 2^k */
 {

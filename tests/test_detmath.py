@@ -172,3 +172,22 @@ def test_sincos_pair_is_bit_identical_to_sin_and_cos():
         assert s0.value == s.value and c0.value == c.value and np.signbit(s0.value) == np.signbit(s.value), x
         assert (s.value == 0.0) == (L.hko_sin(float(x)) == 0.0)          # also the sign of zero
         assert np.signbit(s.value) == np.signbit(L.hko_sin(float(x))) and np.signbit(c.value) == np.signbit(L.hko_cos(float(x)))
+
+
+def test_float_entry_points_special_cases():
+    """signed zero, huge and non-finite arguments of the float API: the sign of atan2 follows y's SIGN BIT (Math.Atan2(-0, x < 0) = -pi),
+    arguments beyond the fast reduction's range go through the double kernels, a non-finite argument gives a non-finite sine / cosine and never an out-of-range table index"""
+    L = _float_api(lib())
+    pi = float(np.float32(math.pi))
+    assert np.float32(L.hko_atan2f(-0.0, -1.0)) == np.float32(-math.pi) and np.float32(L.hko_atan2f(0.0, -1.0)) == np.float32(math.pi)
+    r = np.float32(L.hko_atan2f(-0.0, 1.0))
+    assert r == 0.0 and np.signbit(r) and not np.signbit(np.float32(L.hko_atan2f(0.0, 1.0)))
+    assert abs(L.hko_atan2f(-1e-30, -1.0) + pi) < 1e-6
+    for x in (1.5e5, -3.3e6, 1.0e9, 16777216.0):
+        xf = float(np.float32(x))
+        assert abs(L.hko_sinf(xf) - float(mp.sin(mp.mpf(xf)))) < 2e-7 and abs(L.hko_cosf(xf) - float(mp.cos(mp.mpf(xf)))) < 2e-7, x
+    for bad in (float("nan"), float("inf"), -float("inf")):
+        assert not math.isfinite(L.hko_sinf(bad)) and not math.isfinite(L.hko_cosf(bad))      # (NaN or inf: the kart's f_finite check catches either)
+        assert math.isnan(L.hko_atan2f(bad, 1.0)) or abs(L.hko_atan2f(bad, 1.0)) <= 1.6
+        v = L.hko_atan2f(bad, bad)
+        assert math.isnan(v) or abs(v) <= 3.2

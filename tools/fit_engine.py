@@ -52,7 +52,9 @@ def score(ref, ours):
 
 
 def evaluate(names, eng, verbose=True, iters=128):
-    os.environ["HK_ENG"] = ",".join("%s=%s" % kv for kv in eng.items())
+    # (the candidate constants replace the module's defaults for THIS process only: the product reads no environment override of its physics)
+    from hierarchicalkarting_amd import config as _cfg
+    _cfg.ENGINE_PARAMS.update({k: float(v) for k, v in eng.items()})
     import compare_experiment_logs as CE
     import oracle_lib as O
     total = 0.0
