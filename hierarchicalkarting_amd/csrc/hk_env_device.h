@@ -180,7 +180,8 @@ struct TabView {
     const unsigned char* near_cnt;    // [nx*nz] how many entries at the head of the cell's list lie within NEAR_REACH
     const unsigned char* cut;     // [L][5][5]: does the ray lane marker -> next lane marker hit a wall (HKA:832)
     const uint2* tmask;           // [tgrid_nx * tgrid_nz] Trigger candidates per coarse cell (bit t = section t)
-    const uint2* tmask2;          // [grid_nx * grid_nz] Triggers a kart in this 2 m cell of the wall grid can overlap (bit t = section t)
+    const unsigned short* tmask2; // [grid_nx * grid_nz] the (at most two) Triggers a kart in this 2 m cell of the wall grid can overlap: section indices in the
+                                  // low / high byte, 0xFF = none; 0xFEFE = more than two, use `tmask` (hk_env_params.h)
 };
 __host__ __device__ inline TabView tab_view(const EnvParams& P, const unsigned char* base)
 {
@@ -192,7 +193,7 @@ __host__ __device__ inline TabView tab_view(const EnvParams& P, const unsigned c
     T.near_cnt = base + P.o_ncnt;
     T.cut = base + P.o_cut;
     T.tmask = reinterpret_cast<const uint2*>(base + P.o_tmask);
-    T.tmask2 = reinterpret_cast<const uint2*>(base + P.o_tmask2);
+    T.tmask2 = reinterpret_cast<const unsigned short*>(base + P.o_tmask2);
     return T;
 }
 // copy the packed tables into dynamic LDS (all threads of the block); TAB_LDS false: the launch passed no dynamic LDS (tables
@@ -211,7 +212,7 @@ __device__ inline TabView tab_stage(const EnvParams& P, unsigned char* smem, con
     for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
     TabView T = tab_view(P, smem);
-    if (P.tab_stage_bytes < P.tab_bytes) T.tmask2 = reinterpret_cast<const uint2*>(P.tab + P.o_tmask2);
+    if (P.tab_stage_bytes < P.tab_bytes) T.tmask2 = reinterpret_cast<const unsigned short*>(P.tab + P.o_tmask2);
     return T;
 }
 
@@ -273,7 +274,7 @@ __device__ __forceinline__ int grid_cell(const EnvParams& P, float x, float z)
 // The tight version: the kart's cell of the 2 m wall grid lists the Triggers whose box, grown by the capsule's reach (1.107 m + margin),
 // meets the cell — a kart is inside such a region for a sixth of every section, so most ticks find no candidate at all (the coarse
 // masks below: 2.5 candidates per kart and tick).  Border cells stand for everything outside the grid on their side.
-__device__ __forceinline__ uint2 trig_candidates_tight(const EnvParams& P, const TabView& T, float x, float z)
+__device__ __forceinline__ unsigned trig_candidates_tight(const EnvParams& P, const TabView& T, float x, float z)
 {
     return T.tmask2[grid_cell(P, x, z)];
 }

@@ -63,8 +63,8 @@ inline int env_create(hk_config& cfg, std::vector<hk_section>& sections, std::ve
         if ((rc0 = env_build_params(cfg, sections, walls, P, pk, perms, err))) return rc0;
         if ((rc0 = detail::upload(&d.tab, pk, err))) return rc0;
         P.tab = d.tab;
-        // Oval: 42 KB per block, all of it in LDS; a longer track (Complex: 40 KB + 30 KB of tight Trigger masks) keeps the masks in global memory;
-        // beyond that the global-memory instantiation (HK_TAB_GLOBAL=1 forces it, for tests)
+        // Oval: 29 KB per block, Complex 47.5 KB (round 5: the tight Trigger candidates are two bytes per cell), all of it in LDS; a longer track keeps
+        // the candidates in global memory; beyond that the global-memory instantiation (HK_TAB_GLOBAL=1 forces it, for tests)
         const int stage = P.tab_bytes <= 48 * 1024 ? P.tab_bytes : P.o_tmask2;
         d.tab_lds = (stage <= 48 * 1024 && !std::getenv("HK_TAB_GLOBAL")) ? stage : 0;
         P.tab_stage_bytes = d.tab_lds ? d.tab_lds : P.tab_bytes;

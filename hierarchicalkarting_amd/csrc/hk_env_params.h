@@ -320,7 +320,21 @@ inline int env_build_params(hk_config& cfg, std::vector<hk_section>& sections, s
                         tm2[((size_t)iz * P.grid_nx + ix) * 2 + (t >> 5)] |= 1u << (t & 31);
                     }
                 }
-            P.o_tmask2 = seg(tm2.data(), tm2.size() * sizeof(uint32_t));
+            // Stored as TWO Trigger indices per cell, a byte each (0xFF: none): 2 bytes instead of a 64-bit mask, a third of the staged tables less
+            // (Oval 42 -> 29 KB per block and launch) and the Complex track's candidates fit the LDS at all (30 -> 7.5 KB; round 4 kept them in
+            // global memory).  Triggers are 10 m apart along the track, so a 2 m cell meets one, at a corner two; a cell that meets more (a hairpin of a
+            // track not seen yet) is marked 0xFEFE and the kernel falls back to the coarse masks above — a superset, slower, never wrong.
+            const size_t ncell = (size_t)P.grid_nx * P.grid_nz;
+            std::vector<unsigned short> tc2(ncell, (unsigned short)0xFFFF);
+            for (size_t c = 0; c < ncell; c++) {
+                int found[3], nf = 0;
+                for (int t = 0; t < L && nf < 3; t++) if (tm2[c * 2 + (t >> 5)] & (1u << (t & 31))) found[nf++] = t;
+                if (nf > 2) tc2[c] = (unsigned short)0xFEFE;
+                else if (nf == 2) tc2[c] = (unsigned short)(found[0] | (found[1] << 8));
+                else if (nf == 1) tc2[c] = (unsigned short)(found[0] | 0xFF00);
+            }
+            if (L > 0xFD) { err = "hk_create: more than 253 sections (the Trigger candidate table holds section indices in a byte)"; return HK_ERR_UNSUPPORTED; }
+            P.o_tmask2 = seg(tc2.data(), tc2.size() * sizeof(unsigned short));
         }
         P.L_magic = (uint32_t)((1ull << 32) / (unsigned long long)L) + 1u;
         pk.resize((pk.size() + 15) & ~size_t(15));

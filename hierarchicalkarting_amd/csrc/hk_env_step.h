@@ -606,7 +606,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
         uint32_t lo = 0, hi = 0;
         // only the Triggers listed for the kart's coarse cell can be within reach (the others fail the distance cull below
         // by construction): a couple of trips instead of one per section, each a dependent LDS round trip
-        const uint2 tc = trig_candidates_tight(P, T, px, pz);
+        const unsigned tcand = trig_candidates_tight(P, T, px, pz);
         auto trig_test = [&](const int t, const float tx, const float tz, const float tfx, const float tfz) {
             HK_LP(18);
             // exact cull: box half diagonal 5.03 + capsule reach 1.11 < 6.5
@@ -627,15 +627,23 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                 if (t < 32) lo |= 1u << t; else hi |= 1u << (t - 32);
             }
         };
+        if (tcand == 0xFEFEu) {
+            // (a cell that meets more than two Triggers: the coarse masks, every candidate in section order)
+            const uint2 tc = trig_candidates(P, T, px, pz);
 #pragma unroll 1
-        for (int half = 0; half < 2; half++) {
-            uint32_t bits = half ? tc.y : tc.x;
-            while (bits) {
-                const int t = (__ffs((int)bits) - 1) + 32 * half;
-                bits &= bits - 1u;
-                const SecDev& s = T.sec[t];
-                trig_test(t, s.trig_x, s.trig_z, s.fx, s.fz);
+            for (int half = 0; half < 2; half++) {
+                uint32_t bits = half ? tc.y : tc.x;
+                while (bits) {
+                    const int t = (__ffs((int)bits) - 1) + 32 * half;
+                    bits &= bits - 1u;
+                    const SecDev& s = T.sec[t];
+                    trig_test(t, s.trig_x, s.trig_z, s.fx, s.fz);
+                }
             }
+        } else if (tcand != 0xFFFFu) {
+            const int t0 = (int)(tcand & 0xFFu), t1 = (int)(tcand >> 8);
+            { const SecDev& s = T.sec[t0]; trig_test(t0, s.trig_x, s.trig_z, s.fx, s.fz); }
+            if (t1 != 0xFF) { const SecDev& s = T.sec[t1]; trig_test(t1, s.trig_x, s.trig_z, s.fx, s.fz); }
         }
         const uint32_t nlo = lo & ~h.trig_lo, nhi = hi & ~h.trig_hi;
         h.trig_lo = lo; h.trig_hi = hi;
