@@ -107,7 +107,6 @@ struct Tuning {
     bool fission_chunks = true;  // ... and the short fixed-round calls of planner / actor handles (HK_NO_FISSION_CHUNKS: the fused kernel)
     bool fission_mcts = true;    // ... and long calls of planner handles with LQNG low levels (HK_NO_FISSION_MCTS: the fused kernel for those)
     bool mcts_overlap = true;    // HK_MCTS_NO_OVERLAP=1: long calls of planner handles launch a replan's searches when its stretch of rounds has ended, on the handle's stream (the schedule before round 5)
-    bool async_lqn = false;      // HK_ASYNC_LQN=1 (experiment): the solver launch of a round on a high-priority side stream, the next tick launch beside it (issue_solver)
     bool park = false;           // HK_PARK=1: plain 3- / 4-agent handles run the fused kernel with LDS parking (hk_env_run.h PARK) instead of the fission schedule
     bool fission = true;         // plain 3- / 4-agent handles run the tick kernel without phase B1 + env_b1_kernel per solve cadence (hk_env_run.h); HK_FISSION=0: the fused kernel
     int debug_max_rounds = 0;    // HK_DEBUG_MAX_ROUNDS (diagnostic): cap on the rounds of a call, to look at the state in between
@@ -126,7 +125,6 @@ struct Tuning {
         debug_max_rounds = num("HK_DEBUG_MAX_ROUNDS", 0, 0, 1 << 20);
         debug_no_check = flag("HK_DEBUG_NO_CHECK"); stamps_dump = flag("HK_STAMPS_DUMP");
         { const char* f = std::getenv("HK_FISSION"); fission = !(f && std::atoi(f) == 0); fission_mcts = !flag("HK_NO_FISSION_MCTS"); fission_chunks = !flag("HK_NO_FISSION_CHUNKS"); park = flag("HK_PARK"); mcts_overlap = !flag("HK_MCTS_NO_OVERLAP"); }
-        async_lqn = flag("HK_ASYNC_LQN");
     }
 };
 
@@ -160,11 +158,6 @@ struct hk_context {
     hipEvent_t ev_fork = nullptr, ev_join[hk::SPLIT_WAYS_MAX - 1] = {};
     hipStream_t mcts_stream = nullptr;                  // the search launch of a replan runs here, beside the tick launches up to the plans' deadline (step_ticks, pause mode)
     hipEvent_t ev_mcts_go = nullptr, ev_mcts_done = nullptr;
-    // the asynchronous solver (issue_solver): a side stream per part of the batch, "B1 done" and "solver done" events (two in flight per part)
-    bool async_call = false;       // the current call's rounds may run their solver launches beside the next tick launch
-    hipStream_t lqstream[hk::SPLIT_WAYS_MAX] = {};
-    hipEvent_t ev_b1[hk::SPLIT_WAYS_MAX] = {}, ev_lq[hk::SPLIT_WAYS_MAX][2] = {};
-    bool lq_inflight[hk::SPLIT_WAYS_MAX][2] = {};
     int* done_host = nullptr;      // pinned: [0] max ticks left over the envs, [1] an env waits for a queued game
     void* pol_scratch = nullptr;   // hk_policy_forward staging
     size_t pol_scratch_bytes = 0;
@@ -296,9 +289,6 @@ void hk_destroy(hk_handle h)
     if (h->mcts_stream) { (void)hipStreamSynchronize(h->mcts_stream); (void)hipStreamDestroy(h->mcts_stream); }
     if (h->ev_mcts_go) (void)hipEventDestroy(h->ev_mcts_go);
     if (h->ev_mcts_done) (void)hipEventDestroy(h->ev_mcts_done);
-    for (hipStream_t q : h->lqstream) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
-    for (hipEvent_t e : h->ev_b1) if (e) (void)hipEventDestroy(e);
-    for (auto& pr : h->ev_lq) for (hipEvent_t e : pr) if (e) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (hipEvent_t e : h->ev_join) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -418,76 +408,15 @@ int hk_set_actions(hk_handle h, const float* steer, const int32_t* branch)
     return HK_OK;
 }
 
-// The asynchronous solver (round 5).  A spread field queues a few dozen games per round, each a short overtake (tools/experiments/pack_stats.py: 38 envs
-// of 65 536 per round, runs of 2.1 cadences), but the solver launch that serves them stood between every B1 launch and the next tick launch: 21 us alone
-// on the GPU, 36 - 60 us beside the other half's kernels (its waves need a drained CU).  Now part k's solver launch of round r goes to the part's side
-// stream behind an event, and the tick launch of round r + 1 does not wait for it: an env whose games are not all decoded yet (ENV_PENDING_*, counted
-// down by decode_store) sits that launch out and resumes one round later — at the latest: the tick launch of round r + 2 waits for the solver launch of
-// round r, which also frees the queue set that round's B1 launch will fill.  Envs are independent, so WHEN an env runs changes no result bit; an env
-// that fell behind is finished like every other laggard (lazy completion, or the fixed round count, which allows for one extra round per solve tick).
-// While the field stands close (env_lqn_bulk) the solver launch stays on the part's own stream: there every env waits for it.
-// In an asynchronous call the tick kernel does not clear queue sets (guard bit 1); the stream that ran a solver launch clears the set it consumed.
-static int solver_join(hk_handle h, int k, hipStream_t st)
-{
-    for (int q = 0; q < 2; q++)
-        if (h->lq_inflight[k][q]) { HK_HIP(h, hipStreamWaitEvent(st, h->ev_lq[k][q], 0)); h->lq_inflight[k][q] = false; }
-    return HK_OK;
-}
-// before part k's tick launch of round r: the solver launch of round r - 2 (same parity) must be done
-static int solver_before_tick(hk_handle h, int k, int r, hipStream_t st)
-{
-    const int q = r & 1;
-    if (h->lq_inflight[k][q]) { HK_HIP(h, hipStreamWaitEvent(st, h->ev_lq[k][q], 0)); h->lq_inflight[k][q] = false; }
-    return HK_OK;
-}
-static int issue_solver(hk_handle h, int k, int r, hipStream_t st, hipEvent_t& e)
-{
-    const bool async_call = h->dev.async_lqn;
-    const int set = h->dev.qbase + (h->dev.round & 1);
-    int* const set_cnt = h->dev.queue_cnt + set * 16;
-    if (!async_call || hk::env_lqn_bulk(h->dev, h->cfg) || (h->dev.last_solve_skippable && h->dev.guard_rounds_left == 0)) {
-        if (async_call) { int rcj = solver_join(h, k, st); if (rcj) return rcj; }
-        int rc = hk::env_launch_lqn(h->dev, h->cfg, st, h->err);          // (advances dev.round)
-        if (rc) { g_last_error = h->err; return rc; }
-        if (async_call) HK_HIP(h, hipMemsetAsync(set_cnt, 0, 16 * sizeof(int), st));
-        e = h->prof.chain(1, e, false, st);
-        return HK_OK;
-    }
-    if (!h->lqstream[k]) {
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        const char* np = std::getenv("HK_ASYNC_NO_PRIORITY");
-        HK_HIP(h, hipStreamCreateWithPriority(&h->lqstream[k], hipStreamNonBlocking, np ? least : greatest));
-    }
-    if (!h->ev_b1[k]) HK_HIP(h, hipEventCreateWithFlags(&h->ev_b1[k], hipEventDisableTiming));
-    const int q = r & 1;
-    if (!h->ev_lq[k][q]) HK_HIP(h, hipEventCreateWithFlags(&h->ev_lq[k][q], hipEventDisableTiming));
-    hipStream_t side = h->lqstream[k];
-    HK_HIP(h, hipEventRecord(h->ev_b1[k], st));
-    HK_HIP(h, hipStreamWaitEvent(side, h->ev_b1[k], 0));
-    hipEvent_t ep = h->prof.begin(side);
-    int rc = hk::env_launch_lqn(h->dev, h->cfg, side, h->err);            // (advances dev.round)
-    if (rc) { g_last_error = h->err; return rc; }
-    h->prof.end(1, ep, side);
-    HK_HIP(h, hipMemsetAsync(set_cnt, 0, 16 * sizeof(int), side));
-    HK_HIP(h, hipEventRecord(h->ev_lq[k][q], side));
-    h->lq_inflight[k][q] = true;
-    return HK_OK;
-}
-
 // `rounds` rounds of {fused tick kernel (up to RUN_CAP ticks per env), queued multi-player solves}
 static int issue_rounds_split(hk_handle h, int rounds);
 static int issue_rounds(hk_handle h, int rounds)
 {
-    h->dev.async_lqn = h->async_call && h->dev.fission;
     if (h->split && rounds > 0) return issue_rounds_split(h, rounds);
     hipEvent_t e = h->prof.begin(h->stream);
     bool first = true;
     for (int r = 0; r < rounds; r++) {
-        // (a periodic regroup inside env_launch_run moves env words and tiles: no solver launch may be in flight then)
-        int rc = !h->dev.async_lqn ? HK_OK : (h->dev.rounds_since_regroup + 1 >= h->dev.regroup_rounds ? solver_join(h, 0, h->stream) : solver_before_tick(h, 0, r, h->stream));
-        if (rc) return rc;
-        rc = hk::env_launch_run(h->dev, h->cfg, h->stream, h->err);
+        int rc = hk::env_launch_run(h->dev, h->cfg, h->stream, h->err);
         if (rc) { g_last_error = h->err; return rc; }
         e = h->prof.chain(0, e, first, h->stream);
         if (h->dev.b1_due) {
@@ -495,11 +424,11 @@ static int issue_rounds(hk_handle h, int rounds)
             if (rc) { g_last_error = h->err; return rc; }
             e = h->prof.chain(5, e, false, h->stream);
         }
-        rc = issue_solver(h, 0, r, h->stream, e);
-        if (rc) return rc;
+        rc = hk::env_launch_lqn(h->dev, h->cfg, h->stream, h->err);
+        if (rc) { g_last_error = h->err; return rc; }
+        e = h->prof.chain(1, e, false, h->stream);
         first = false;
     }
-    if (h->dev.async_lqn) { int rc = solver_join(h, 0, h->stream); if (rc) return rc; }
     if (first && e) h->prof.pool.push_back(e);          // no round issued: the opening event goes back
     return HK_OK;
 }
@@ -538,7 +467,6 @@ static int issue_rounds_split(hk_handle h, int rounds)
     for (int r = 0; r < rounds && rc == HK_OK; r++) {
         for (int k = 0; k < K && rc == HK_OK; k++) {
             h->dev.slot0 = cut[k]; h->dev.slot1 = cut[k + 1]; h->dev.qbase = 2 * k; h->dev.round = h->round_half[k];
-            if (h->dev.async_lqn && (rc = solver_before_tick(h, k, r, st[k]))) break;
             rc = hk::env_launch_run_only(h->dev, h->cfg, st[k], h->err);
             if (rc) break;
             e[k] = h->prof.chain(0, e[k], first, st[k]);
@@ -547,14 +475,14 @@ static int issue_rounds_split(hk_handle h, int rounds)
                 if (rc) break;
                 e[k] = h->prof.chain(5, e[k], false, st[k]);
             }
-            rc = issue_solver(h, k, r, st[k], e[k]);                         // (advances dev.round)
+            rc = hk::env_launch_lqn(h->dev, h->cfg, st[k], h->err);          // (advances dev.round)
             if (rc) break;
+            e[k] = h->prof.chain(1, e[k], false, st[k]);
             h->round_half[k] = h->dev.round;
         }
         first = false;
     }
     h->dev.slot0 = 0; h->dev.slot1 = 0; h->dev.qbase = 0; h->dev.round = h->round_half[0];
-    if (h->dev.async_lqn) for (int k = 0; k < K; k++) { const int rcj = solver_join(h, k, st[k]); if (rcj && !rc) rc = rcj; }
     if (first) for (int k = 0; k < K; k++) if (e[k]) h->prof.pool.push_back(e[k]);
     for (int k = 1; k < K; k++) {
         HK_HIP(h, hipEventRecord(h->ev_join[k - 1], st[k]));
@@ -586,7 +514,6 @@ static int finish_ticks(hk_handle h)
         int rc = hk::env_launch_regroup(h->dev, h->cfg, h->stream, h->err);      // the laggards into the first lane groups
         if (rc) { g_last_error = h->err; return rc; }
         h->split = false;                // ... which all lie in the first half: the tail runs as one batch on one stream
-        h->async_call = false;           // ... with its solver launches in line: a laggard does not fall behind again
         // Rounds for the slowest env if it met no further multi-player game (+ 1), not for the worst case (a round per cadence): the
         // batch ends with a look at the device anyway, and two thirds of the worst-case rounds used to find nothing to do (94 of 141 in
         // the headline's 3 072-tick call, ~18 us each).  An env that does park on every solve tick still gets a third of its ticks per batch.
@@ -610,7 +537,6 @@ static int step_ticks(hk_handle h, int n_ticks)
     // ticks have been armed since the last one — early enough, because a plan is due > MCTS_MIN_LATENCY ticks after its
     // request.  (hk_get_mcts_state launches what is pending before it reads.)
     const bool planner = h->dev.mcts.st != nullptr;
-    h->async_call = false;
     // (how long a request may wait for its launch: a request posted on armed tick 1 is searched before armed tick defer + 1 runs, and its
     // plan is due `latency` ticks after the request — so defer = the handle's smaller latency - 1, at least MCTS_DEFER_TICKS)
     const int defer = std::max(hk::MCTS_DEFER_TICKS, std::min(h->cfg.mcts_latency_ticks, h->cfg.mcts_initial_latency_ticks) - 1);
@@ -755,12 +681,7 @@ static int step_ticks(hk_handle h, int n_ticks)
     const bool want_split = split_req, no_split = h->tune.no_split;
     const bool close_field = h->dev.ticks_since_reset < hk::BULK_TICKS;
     h->split = (want_split || (close_field && !no_split)) && h->dev.P.eager && h->cfg.num_envs >= 8192;
-    // the asynchronous solver (issue_solver) for plain handles on the fission schedule
-    h->async_call = h->tune.async_lqn && plain && h->dev.fission && h->dev.P.eager && h->dev.P.any_lqr != 0;
     int rounds = lazy ? hk::env_rounds_min(h->cfg, n_ticks, run_cap) : hk::env_rounds_for(h->cfg, n_ticks, run_cap, h->dev.P.eager != 0);
-    // (a fixed count has to cover an env that queues a game on every solve tick and sits out the round after each: two rounds per solve tick; the
-    // rounds that find nothing to do are three launches whose blocks leave at once)
-    if (!lazy && h->async_call) rounds = 2 * (rounds - 1) + 1;
     if (h->tune.debug_max_rounds > 0) rounds = std::min(rounds, h->tune.debug_max_rounds);     // (diagnostic: look at the state between two rounds)
     {
         // the rounds every env needs at RUN_CAP ticks a round, then — the laggards packed into the first lane groups — the tail

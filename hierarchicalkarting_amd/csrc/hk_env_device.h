@@ -35,11 +35,6 @@ constexpr int RUN_CAP_SPREAD = 12;      // ticks per env per launch (> cadence).
                                 // queues a game idles its lanes until the launch ends, so long launches waste lanes
 // hk_env_state.reserved[1]: bits 0..3 the env's phase inside a tick (0 between calls), bit 4 a scheduling hint that survives calls
 constexpr int ENV_PHASE_MASK = 15, ENV_PACK_HINT = 16;
-// ... bits 8..11: queued multi-player games of the env's current solve tick that the solver has not decoded yet (round 5).  Phase B1 stores the count with
-// phase 1, decode_store (hk_env_solve.h) takes one off per game AFTER the controls are in the ego's tile rows (release), and a tick launch leaves an
-// env with a non-zero count alone: the solver launch may then run BESIDE the next tick launch (hk_api.hip: the asynchronous solver), and an env
-// whose game is not solved yet simply runs one round later.
-constexpr int ENV_PENDING_SHIFT = 8, ENV_PENDING_MASK = 15 << ENV_PENDING_SHIFT;
 constexpr float DEG2RAD_F = 0.0174532924f;
 constexpr float TWO_PI_F = 2.0f * HK_PI_F;
 constexpr float CAP_R = 0.45f;          // kart capsule (BaseKartClassic.prefab): radius, core segment in kart-local z

@@ -47,13 +47,6 @@ __device__ __forceinline__ int group_min(int v)
     if (GA > 4) { o = __shfl_xor(v, 4, 64); v = o < v ? o : v; }
     return v;
 }
-// sum over the lanes of the group (every lane gets the result)
-__device__ __forceinline__ int group_sum(int v)
-{
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
-    if (GA > 4) v += __shfl_xor(v, 4, 64);
-    return v;
-}
 // OR over the lanes of the group (every lane gets the result)
 __device__ __forceinline__ int group_or(int v)
 {

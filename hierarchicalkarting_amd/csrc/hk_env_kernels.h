@@ -290,8 +290,6 @@ inline int env_launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream
 inline int env_launch_run_only(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_run(d, cfg, stream, err)); }
 inline int env_launch_b1(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_b1(d, cfg, stream, err)); }
 inline int env_launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err) { return HK_GA_CALL(d, launch_lqn(d, cfg, stream, err)); }
-// does the next solver launch expect a close field (the host's guess, as launch_lqn makes it: BULK_TICKS after a reset of every env)?
-inline bool env_lqn_bulk(const EnvDevice& d, const hk_config& cfg) { return cfg.num_agents == 2 || d.ticks_since_reset + d.call_ticks_issued < BULK_TICKS; }
 // pack the envs that still have ticks to run into the first lane groups (the tail of a call; see env_regroup_count_kernel)
 inline int env_launch_regroup(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std::string& err)
 {

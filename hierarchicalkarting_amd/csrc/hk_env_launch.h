@@ -99,7 +99,7 @@ inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
 {
     const int s0 = d.slot1 > d.slot0 ? d.slot0 : 0, s1 = d.slot1 > d.slot0 ? d.slot1 : cfg.num_envs;
     const long long threads = (long long)(s1 - s0) * GA;
-    const int arm = d.arm_ticks, guard = ((d.guard_rounds_left > 0 && --d.guard_rounds_left == 0) ? 1 : 0) | (d.async_lqn ? 2 : 0);     // (bit 1: hk_env_run.h, the queue-set clear)
+    const int arm = d.arm_ticks, guard = (d.guard_rounds_left > 0 && --d.guard_rounds_left == 0) ? 1 : 0;
     d.arm_ticks = 0;
 #define HK_RUN_T(MC, RWF, TRN, TL)                                                                                            \
     hipLaunchKernelGGL((env_run_kernel<MC, RWF, TRN, TL>), dim3((unsigned)((threads + 255) / 256)), dim3(256), TL ? d.tab_lds : 0, stream, d.P, d.agents, d.hot, d.envs,   \
@@ -199,7 +199,7 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
         const int per = bulk ? 1024 : d.lqn_sparse_blocks;
         const int n34 = sizes ? std::min(ngames, per) * sizes : 0;          // `per` waves per game size walk their queue grid-stride; the queue length picks the solver (lqn_round_kernel)
         const int n2 = std::min((ngames + 31) / 32, bulk ? 4096 : per);
-        hipLaunchKernelGGL(lqn_round_kernel, dim3(n34 + n2), dim3(64), 0, stream, d.P, HotRef{d.hot, d.slot_of, d.envs}, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status,
+        hipLaunchKernelGGL(lqn_round_kernel, dim3(n34 + n2), dim3(64), 0, stream, d.P, HotRef{d.hot, d.slot_of}, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status,
                            n34, sizes ? sizes : 1, n2, d.game_stats, LQN_BULK_GAMES);
         if ((rc = launch_check(err, "lqn_round_kernel"))) return rc;
     }
@@ -207,11 +207,11 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
 #if HK_GA > 4
         {
             const int nbb = std::min((ngames + 1) / 2, 512);
-            hipLaunchKernelGGL(lqn_big_kernel<5>, dim3(nbb * (cfg.num_agents > 5 ? 2 : 1)), dim3(64), 0, stream, d.P, HotRef{d.hot, d.slot_of, d.envs}, GameSoA{d.games, (size_t)ngames}, qc, qu,
+            hipLaunchKernelGGL(lqn_big_kernel<5>, dim3(nbb * (cfg.num_agents > 5 ? 2 : 1)), dim3(64), 0, stream, d.P, HotRef{d.hot, d.slot_of}, GameSoA{d.games, (size_t)ngames}, qc, qu,
                                d.lq_debug, d.status, nbb, d.game_stats);
             if ((rc = launch_check(err, "lqn_big_kernel<5>"))) return rc;
             if (cfg.num_agents > 6) {
-                hipLaunchKernelGGL(lqn_big_kernel<7>, dim3(nbb * (cfg.num_agents > 7 ? 2 : 1)), dim3(64), 0, stream, d.P, HotRef{d.hot, d.slot_of, d.envs}, GameSoA{d.games, (size_t)ngames}, qc, qu,
+                hipLaunchKernelGGL(lqn_big_kernel<7>, dim3(nbb * (cfg.num_agents > 7 ? 2 : 1)), dim3(64), 0, stream, d.P, HotRef{d.hot, d.slot_of}, GameSoA{d.games, (size_t)ngames}, qc, qu,
                                    d.lq_debug, d.status, nbb, d.game_stats);
                 if ((rc = launch_check(err, "lqn_big_kernel<7>"))) return rc;
             }

@@ -214,17 +214,13 @@ __global__ __launch_bounds__(PARK ? PARK_BLOCK : 256, FISSION ? HK_FIS_OCC : HK_
     const int set = qbase + (round & 1);
     int* queue_cnt = queue_cnt_all + set * 16;
     int* queue = queue_all + (size_t)set * (GA - 1) * P.E * P.A;
-    // (guard bit 1: the asynchronous solver — the set this launch would clear may still be read by the previous round's solver launch, which runs beside
-    // this one and clears its set itself when it is done: hk_api.hip)
-    if (!(guard & 2) && blockIdx.x == 0 && threadIdx.x < 16) queue_cnt_all[(set ^ 1) * 16 + threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 16) queue_cnt_all[(set ^ 1) * 16 + threadIdx.x] = 0;
     hk_env_state es;
     if (env_ok) es = envs[slot];
     else { es.episode_steps = 0; es.inactive_mask = 0; es.experiment_num = 0; es.episodes_done = 0; es.status = 0; es.initial_started = 0; es.reserved[0] = 0; es.reserved[1] = 0; }
-    // an env whose queued games are not all decoded yet (ENV_PENDING_*) sits this launch out, untouched: the solver owns its phase word
-    const bool pending = env_ok && (es.reserved[1] & ENV_PENDING_MASK) != 0;
-    if (env_ok && !pending) es.reserved[0] += arm_ticks;             // the first launch of a fixed-round call arms the envs (else env_arm_kernel did)
+    if (env_ok) es.reserved[0] += arm_ticks;             // the first launch of a fixed-round call arms the envs (else env_arm_kernel did)
     // nothing to do in this block? (every env finished its ticks): skip the table staging too
-    if (__syncthreads_or(!pending && (es.reserved[0] > 0 || (es.reserved[1] & ENV_PHASE_MASK) != 0)) == 0) return;
+    if (__syncthreads_or(es.reserved[0] > 0 || (es.reserved[1] & ENV_PHASE_MASK) != 0) == 0) return;
 #ifdef HK_STAMPS
     const unsigned long long st_a = __builtin_readcyclecounter();
 #endif
@@ -245,7 +241,6 @@ __global__ __launch_bounds__(PARK ? PARK_BLOCK : 256, FISSION ? HK_FIS_OCC : HK_
     if (FISSION && phase == 2) phase = 0, left = 0;      // (cannot happen: env_b1_kernel runs between two tick launches; such an env would trip the guard)
     bool pack = (es.reserved[1] & ENV_PACK_HINT) != 0;   // did the env's last solve tick queue a multi-player game (regroup_key)
     bool dirty = false;
-    int npend = 0;                                       // multi-player games this env queued on the solve tick it parks at (ENV_PENDING_*)
 #ifdef HK_STAMPS
     for (int k = 0; k < HK_NSTAMP; k++) h.st_acc[k] = 0;
     h.st_acc[20] = (unsigned)(st_a - st_entry); h.st_acc[21] = (unsigned)(st_b - st_a);     // the head of the launch: lane group + env words; table staging
@@ -284,7 +279,7 @@ __global__ __launch_bounds__(PARK ? PARK_BLOCK : 256, FISSION ? HK_FIS_OCC : HK_
     // The loop is wave-uniform: a lane group whose env has nothing (more) to run in this launch stays in it, idle.  `go` depends on
     // the env's words only, so a lane group is in or out as a whole, and the group-wide exchanges below (group_get / group_or:
     // DPP quad permutes, which read 0 from a lane that is switched off) always run with whole groups.
-    bool go = env_ok && !pending && (phase != 0 || (left > 0 && budget > 0 && !held));
+    bool go = env_ok && (phase != 0 || (left > 0 && budget > 0 && !held));
     while (__ballot(go) != 0ull) {
         int qn = 0;                  // player count of the multi-player game this ego assembled on this tick (0: none)
         bool began = false;          // this env ran phases A / B1 in this iteration (it was at a tick boundary and not parked)
@@ -338,7 +333,6 @@ __global__ __launch_bounds__(PARK ? PARK_BLOCK : 256, FISSION ? HK_FIS_OCC : HK_
             HK_ST(h, 6);           // [6] queue binning (+ planner hooks)
             // does any ego of this env wait for a queued multi-player solve?  (or was this the assembly at the end of the budget)
             const bool queued = FISSION ? false : group_or(qn ? 1 : 0) != 0;
-            if (!FISSION && queued) npend = group_sum(qn ? 1 : 0);         // (group-uniform branch: `queued` is the same in every lane of the group)
             if (!FISSION && solved) pack = queued;
             if (queued || eager_it) { phase = 1; moving = false; go = false; }
             if (FISSION && b1_pending) { phase = 2; moving = false; go = false; }      // (quad-uniform: act depends on the env words only)
@@ -377,11 +371,11 @@ __global__ __launch_bounds__(PARK ? PARK_BLOCK : 256, FISSION ? HK_FIS_OCC : HK_
     }
     if (env_ok && dirty && i == 0) {
         es.reserved[0] = left;
-        es.reserved[1] = phase | (pack ? ENV_PACK_HINT : 0) | (phase == 1 ? (npend << ENV_PENDING_SHIFT) : 0);
+        es.reserved[1] = phase | (pack ? ENV_PACK_HINT : 0);
         envs[slot] = es;
     }
     // the last launch of a fixed-round call is its completion guard (what env_check_kernel does for the other calls)
-    if ((guard & 1) && env_ok && i == 0 && (pending || left != 0 || phase != 0)) atomicOr(status, 4);
+    if (guard && env_ok && i == 0 && (left != 0 || phase != 0)) atomicOr(status, 4);
 #ifdef HK_STAMPS
     __builtin_amdgcn_s_waitcnt(0); HK_ST(h, 22);        // [22] the record stores, waited for
     h.st_acc[24] = (unsigned)(h.st_t - st_entry);       // [24] the wave's whole life in this launch
@@ -457,8 +451,7 @@ __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_
     // the planner hook of a solve tick (HKA:330-402, after SolveLQR; every lane of the group calls it): replan request, bestStates -> plan entries
     if (HAS_MCTS && M.st && pend) phase_plan(P, M, mset, env, i, es, h.flags, h.section_index, h.lane, h.lane_changes, h.final_steer, arec);
     if (arec) { hot_put<uint32_t>(htile, HF_flags, h.flags); hot_put<float>(htile, HF_steering, h.steering); }
-    const int nq = queued ? group_sum(qn ? 1 : 0) : 0;      // (group-uniform branch)
-    if (pend && i == 0) envs[slot].reserved[1] = 1 | (queued ? ENV_PACK_HINT : 0) | (nq << ENV_PENDING_SHIFT);
+    if (pend && i == 0) envs[slot].reserved[1] = 1 | (queued ? ENV_PACK_HINT : 0);
 #ifdef HK_STAMPS
     __builtin_amdgcn_s_waitcnt(0);
     HK_ST(h, 18);                      // [18] B1 kernel: binning, stores (waited for)

@@ -89,20 +89,15 @@ __device__ inline void decode_controls(const float fs /*final_steer*/, uint32_t&
 }
 
 // The solver kernels decode into the ego's hot-tile rows (flags, steering), found through slot_of: a queued game is named by env * A + ego
-struct HotRef { uint32_t* w; const int* slot_of; hk_env_state* envs; };
+struct HotRef { uint32_t* w; const int* slot_of; };
 __device__ __forceinline__ void decode_store(const EnvParams& P, const HotRef& HR, const int game, const double u0a, const double u0b, hk_lq_debug* dbg)
 {
     const int env = game / P.A, ego = game - env * P.A;
-    const int slot = HR.slot_of[env];
-    uint32_t* p = HR.w + hot_base<GA>(slot, ego);
+    uint32_t* p = HR.w + hot_base<GA>(HR.slot_of[env], ego);
     uint32_t fl = hot_get<uint32_t>(p, HF_flags);
     float st = hot_get<float>(p, HF_steering);
     decode_controls(hot_get<float>(p, HF_final_steer), fl, st, u0a, u0b, dbg);
     hot_put<uint32_t>(p, HF_flags, fl); hot_put<float>(p, HF_steering, st);
-    // one game fewer to wait for (ENV_PENDING_*): the controls first, device-wide, then the count — a tick launch that runs beside this kernel and
-    // reads a count of zero reads these controls
-    __threadfence();
-    atomicSub(reinterpret_cast<unsigned int*>(&HR.envs[slot].reserved[1]), 1u << ENV_PENDING_SHIFT);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
