@@ -107,6 +107,7 @@ struct Tuning {
     bool fission_chunks = true;  // ... and the short fixed-round calls of planner / actor handles (HK_NO_FISSION_CHUNKS: the fused kernel)
     bool fission_mcts = true;    // ... and long calls of planner handles with LQNG low levels (HK_NO_FISSION_MCTS: the fused kernel for those)
     bool mcts_overlap = true;    // HK_MCTS_NO_OVERLAP=1: long calls of planner handles launch a replan's searches when its stretch of rounds has ended, on the handle's stream (the schedule before round 5)
+    bool fission_shaped = true;  // HK_NO_FISSION_SHAPED=1: handles with reward shaping / Training mode keep the fused kernel (round 5: they run the fission schedule too)
     bool park = false;           // HK_PARK=1: plain 3- / 4-agent handles run the fused kernel with LDS parking (hk_env_run.h PARK) instead of the fission schedule
     bool fission = true;         // plain 3- / 4-agent handles run the tick kernel without phase B1 + env_b1_kernel per solve cadence (hk_env_run.h); HK_FISSION=0: the fused kernel
     int debug_max_rounds = 0;    // HK_DEBUG_MAX_ROUNDS (diagnostic): cap on the rounds of a call, to look at the state in between
@@ -124,7 +125,7 @@ struct Tuning {
         lazy_min_ticks = num("HK_LAZY_MIN_TICKS", HK_LAZY_MIN_TICKS, 1, 1 << 20);
         debug_max_rounds = num("HK_DEBUG_MAX_ROUNDS", 0, 0, 1 << 20);
         debug_no_check = flag("HK_DEBUG_NO_CHECK"); stamps_dump = flag("HK_STAMPS_DUMP");
-        { const char* f = std::getenv("HK_FISSION"); fission = !(f && std::atoi(f) == 0); fission_mcts = !flag("HK_NO_FISSION_MCTS"); fission_chunks = !flag("HK_NO_FISSION_CHUNKS"); park = flag("HK_PARK"); mcts_overlap = !flag("HK_MCTS_NO_OVERLAP"); }
+        { const char* f = std::getenv("HK_FISSION"); fission = !(f && std::atoi(f) == 0); fission_mcts = !flag("HK_NO_FISSION_MCTS"); fission_chunks = !flag("HK_NO_FISSION_CHUNKS"); park = flag("HK_PARK"); mcts_overlap = !flag("HK_MCTS_NO_OVERLAP"); fission_shaped = !flag("HK_NO_FISSION_SHAPED"); }
     }
 };
 
@@ -574,6 +575,7 @@ static int step_ticks(hk_handle h, int n_ticks)
         // the fission schedule for planner handles too (long calls, LQNG low levels; round 4): the same two kernels with the planner hooks
         bool shaped_p = h->cfg.rewards != 0 || h->cfg.env_mode == HK_MODE_TRAINING;
         for (int i = 0; i < h->cfg.num_agents; i++) shaped_p = shaped_p || h->cfg.training_agent[i] != 0;
+        if (h->tune.fission_shaped) shaped_p = false;      // (reward shaping and the Training-mode reset live in phases A / C: the tick kernel's instantiations carry them)
         h->dev.fission = h->tune.fission && h->tune.fission_mcts && !shaped_p && h->dev.P.eager && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4;
         if (h->dev.fission) h->dev.P.run_cap = 4;
         h->dev.mcts_defer = true;                       // the rounds do not launch searches themselves
@@ -657,8 +659,10 @@ static int step_ticks(hk_handle h, int n_ticks)
     // FISSION: every env parks at every solve tick, so a round retires exactly one cadence
     bool shaped = h->cfg.rewards != 0 || h->cfg.env_mode == HK_MODE_TRAINING;       // reward shaping / Training mode: their own instantiations of the fused kernel
     for (int i = 0; i < h->cfg.num_agents; i++) shaped = shaped || h->cfg.training_agent[i] != 0;
+    const bool shaped_fused = shaped;              // (HK_PARK's fused kernel has no shaped instantiation)
+    if (h->tune.fission_shaped) shaped = false;    // round 5: reward shaping and the Training-mode reset live in phases A / C — the tick kernel's <.., HAS_RW, HAS_TRAIN, .., FISSION> instantiations carry them
     h->dev.fission = h->tune.fission && plain && !shaped && h->dev.P.eager && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4;
-    h->dev.park = h->tune.park && plain && !shaped && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4 && h->dev.P.any_lqr != 0;
+    h->dev.park = h->tune.park && plain && !shaped_fused && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4 && h->dev.P.any_lqr != 0;
     if (h->dev.park) h->dev.fission = false;
     // handles without an LQ agent (every low level an RL actor, attached or driven through hk_set_actions): the tick kernel of the fission
     // schedule alone — phase B1 has nothing to solve, no env parks for it, no B1 launch

@@ -125,16 +125,26 @@ inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
         if (d.tab_lds) HK_PARK_RUN(true); else HK_PARK_RUN(false);
 #undef HK_PARK_RUN
     } else
-    if (d.fission && !train && !d.rw.sec_time) {
+    if (d.fission) {
         // FISSION (hk_env_run.h): the tick kernel without phase B1; launch_b1 follows on the same stream
         const GameSoA G{d.games, (size_t)cfg.num_envs * cfg.num_agents};
         const unsigned blocks = (unsigned)((threads + 255) / 256);
 #define HK_FIS_RUN(MC, TL) hipLaunchKernelGGL((env_run_kernel<MC, false, false, TL, true>), dim3(blocks), dim3(256), TL ? d.tab_lds : 0, stream, d.P, d.agents, d.hot, d.envs, \
                                d.results, G, d.queue_cnt, d.queue, d.round, d.act_steer, d.act_branch, d.lq_debug, d.status, d.mcts, d.mset, d.rw, d.perm,        \
                                d.game_stats, s0, s1, d.qbase, arm, guard)
-        if (d.mcts.st) { if (d.tab_lds) HK_FIS_RUN(true, true); else HK_FIS_RUN(true, false); }
+        // (reward shaping / Training mode: phases A and C carry them, so the tick kernel has <.., HAS_RW, HAS_TRAIN, ..> twins; phase B1 knows neither)
+#define HK_FIS_RUN3(MC, RWF, TRN, TL) hipLaunchKernelGGL((env_run_kernel<MC, RWF, TRN, TL, true>), dim3(blocks), dim3(256), TL ? d.tab_lds : 0, stream, d.P, d.agents, d.hot, d.envs, \
+                               d.results, G, d.queue_cnt, d.queue, d.round, d.act_steer, d.act_branch, d.lq_debug, d.status, d.mcts, d.mset, d.rw, d.perm,        \
+                               d.game_stats, s0, s1, d.qbase, arm, guard)
+        if (train) { if (d.tab_lds) HK_FIS_RUN3(true, true, true, true); else HK_FIS_RUN3(true, true, true, false); }
+        else if (d.rw.sec_time) {
+            if (d.mcts.st) { if (d.tab_lds) HK_FIS_RUN3(true, true, false, true); else HK_FIS_RUN3(true, true, false, false); }
+            else { if (d.tab_lds) HK_FIS_RUN3(false, true, false, true); else HK_FIS_RUN3(false, true, false, false); }
+        }
+        else if (d.mcts.st) { if (d.tab_lds) HK_FIS_RUN(true, true); else HK_FIS_RUN(true, false); }
         else { if (d.tab_lds) HK_FIS_RUN(false, true); else HK_FIS_RUN(false, false); }
 #undef HK_FIS_RUN
+#undef HK_FIS_RUN3
         d.b1_due = d.P.any_lqr != 0;
     } else
 #endif

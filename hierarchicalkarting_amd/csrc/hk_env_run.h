@@ -178,6 +178,20 @@ __global__ __launch_bounds__(256) void envs_scatter_kernel(const hk_env_state* b
 #ifndef HK_FIS_OCC
 #define HK_FIS_OCC 3          // three waves per SIMD (168 VGPRs) since round 5: with the back-end switches of __graft_entry__.BACKEND_FLAGS the tick
 #endif                        // kernel needs 162 registers and no scratch; 1 632 -> 1 762 M env-steps/s (profiles/r05_a_backend_flags.txt)
+// Phase B1 as a real CALL, for the fused Training-mode instantiation only (round 5).  Inlined, phase B1's register peak makes the allocator split the long
+// live ranges of the tick loop around it (save copy before, copy back after), and this toolchain puts such save copies at the top of a join block, AHEAD of
+// the instruction that restores EXEC: lanes of the other side then get the copy back without ever having made the save (a finished kart's tele_total_time
+// read 4.6e-41; DESIGN.md section 10, the second pattern).  Across a call the ABI does the parking itself — callee-saved registers in the callee's prologue,
+// the rest next to the call — under the call site's own EXEC.  Slower (the whole kart state goes through the stack around every solve tick) and only here:
+// the instantiation serves 2-agent Training fields; everything else stays inline.
+__device__ __attribute__((noinline)) int phase_assemble_call(const EnvParams& P, const TabView& T, KartS* ks, const int env, const int ego, const bool act,
+                                                             const hk_env_state& es, Hot& h, const float hfx, const float hfz, hk_agent_state* agents,
+                                                             const GameSoA games, int* queue_cnt, int* queue, hk_lq_debug* dbg_out, int* status,
+                                                             const hk_mcts_state* mcts_all, const LaneCfg& LC)
+{
+    return phase_assemble(P, T, ks, env, ego, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, mcts_all, LC);
+}
+
 // PARK (round 5): the fused kernel in blocks of 512 threads (one per CU: the staged tables are shared by eight waves) with the hot fields
 // phase B1 does not read parked in LDS around phase_assemble (hk_env_device.h park_store / park_load).
 constexpr int PARK_BLOCK = 512;
@@ -305,7 +319,8 @@ __global__ __launch_bounds__(PARK ? PARK_BLOCK : 256, FISSION ? HK_FIS_OCC : HK_
                     if constexpr (FISSION) b1_pending = act && P.any_lqr != 0;      // (no LQ agent: nothing for env_b1_kernel to do, the env moves on)
                     else {
                         if constexpr (PARK) park_store<PARK_BLOCK>(pk, h);
-                        qn = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
+                        if constexpr (HAS_TRAIN && !PARK) qn = phase_assemble_call(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
+                        else qn = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
                         if constexpr (PARK) park_load<PARK_BLOCK>(pk, h);
                     }
                     began = true;

@@ -50,6 +50,46 @@ kern:
 """
 
 
+# the second pattern (round 5, the fused Training-mode instantiation after an unrelated change of the Trigger tables): the allocator splits a live
+# range around phase B1 — save copy, reuse of the register, copy back — and the SAVE sits at the top of a join block, ahead of its EXEC restore:
+# tele_total_time of a finished kart came back as 4.6e-41
+AFFECTED_COPY = """
+kern:
+	s_and_saveexec_b64 s[16:17], vcc
+	s_cbranch_execz .LBB29_771
+; %bb.769:
+	v_div_fixup_f32 v60, v6, v4, v5
+.LBB29_771:                             ;   in Loop: Header=BB29_73 Depth=1
+	s_or_b64 exec, exec, s[16:17]
+.LBB29_772:                             ;   in Loop: Header=BB29_73 Depth=1
+	v_mov_b32_e32 v180, v146
+	v_mov_b64_e32 v[248:249], v[130:131]
+	s_or_b64 exec, exec, s[28:29]
+	v_mov_b32_e32 v146, 0x54442d18
+	v_mov_b32_e32 v146, v180
+	s_endpgm
+"""
+# a copy AFTER the restore, a constant move before it, and a copy inside a block entered under its own narrowed mask: fine
+CLEAN_COPY = """
+kern:
+	s_and_saveexec_b64 s[16:17], vcc
+	s_cbranch_execz .LBB1_2
+; %bb.1:
+	v_mov_b32_e32 v7, v9
+.LBB1_2:
+	v_mov_b32_e32 v134, 0x3ff00000
+	s_or_b64 exec, exec, s[16:17]
+	v_mov_b32_e32 v180, v146
+	s_endpgm
+"""
+
+
+def test_second_pattern_register_copies(tmp_path):
+    bad = [ins for insts in _kernels(tmp_path, AFFECTED_COPY).values() for _, ins in G.check(insts)]
+    assert len(bad) == 2 and "v180, v146" in bad[0] and "v[248:249]" in bad[1]
+    assert all(G.check(insts) == [] for insts in _kernels(tmp_path, CLEAN_COPY).values())
+
+
 def _kernels(tmp_path, text):
     p = tmp_path / "k.s"
     p.write_text(text)

@@ -74,6 +74,9 @@ MODES.update({"chunks_fused": {"HK_NO_FISSION_CHUNKS": "1"}, "mcts_fused": {"HK_
 # round 5: the fused kernel with the hot fields parked in LDS around phase B1 (an opt-in schedule, hk_env_run.h PARK), alone and as a split batch;
 # the planner's long calls with the searches beside the ticks (the default) against the schedule that stops an env at its request
 CASES += [("plain", "park"), ("plain", "park_split"), ("plain", "park_tab_global"), ("planner", "no_overlap"), ("planner_rw", "no_overlap")]
+# reward-shaped / Training handles: the fission schedule is their default since round 5; their fused kernel stays reachable
+CASES += [("rewards", "shaped_fused"), ("planner_rw", "shaped_fused"), ("training", "shaped_fused")]
+MODES.update({"shaped_fused": {"HK_NO_FISSION_SHAPED": "1"}})
 MODES.update({"park": {"HK_PARK": "1"}, "park_split": {"HK_PARK": "1", "HK_SPLIT": "1"}, "park_tab_global": {"HK_PARK": "1", "HK_TAB_GLOBAL": "1"},
               "no_overlap": {"HK_MCTS_NO_OVERLAP": "1"}})
 MODES.update({"split": {"HK_SPLIT": "1"}, "no_pause": {"HK_MCTS_NO_PAUSE": "1"}, "fused": {"HK_FISSION": "0"}, "fused_split": {"HK_FISSION": "0", "HK_SPLIT": "1"},

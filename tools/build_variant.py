@@ -13,7 +13,7 @@ import __graft_entry__ as ge
 def main():
     name = sys.argv[1]
     head = sys.argv[2:sys.argv.index("--flags")] if "--flags" in sys.argv else sys.argv[2:]
-    head = [a for a in head if a != "--no-backend-flags"]            # --no-backend-flags: without __graft_entry__.BACKEND_FLAGS (the A/B of those switches)
+    head = [a for a in head if a not in ("--no-backend-flags", "--no-record-flags")]      # --no-record-flags: without the guard variant's flags the product's unit was built with            # --no-backend-flags: without __graft_entry__.BACKEND_FLAGS (the A/B of those switches)
     defs = [a for a in head if a.startswith("-D") or a.startswith("-m") or a.startswith("-f") or a.startswith("-O")]
     if "--flags" in sys.argv:                       # everything after --flags goes to hipcc verbatim (e.g. --flags -mllvm -some-option=1)
         defs += sys.argv[sys.argv.index("--flags") + 1:]
@@ -37,7 +37,7 @@ def main():
         o = os.path.join(ge.OBJ_DIR, "%s_%s.o" % (name, u.replace(".hip", "")))
         objs.append(o)
         listings.append(o[:-2] + ".s")
-        base = ge.HIPCC_FLAGS + ([] if "--no-backend-flags" in sys.argv else ge._backend_flags(hipcc)) + record.get(u, {}).get("flags", [])
+        base = ge.HIPCC_FLAGS + ([] if "--no-backend-flags" in sys.argv else ge._backend_flags(hipcc)) + ([] if "--no-record-flags" in sys.argv else record.get(u, {}).get("flags", []))
         procs.append(subprocess.Popen([hipcc] + base + defs + ["-c", os.path.join(ge.CSRC, u), "-o", o]))
         procs.append(subprocess.Popen([hipcc] + base + defs + ["--cuda-device-only", "-S", os.path.join(ge.CSRC, u), "-o", o[:-2] + ".s"], stderr=subprocess.DEVNULL))
     assert all(p.wait() == 0 for p in procs)

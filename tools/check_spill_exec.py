@@ -79,7 +79,16 @@ def check(insts):
             continue
         if after_label and ((op.startswith(("scratch_store", "buffer_store")) and "Spill" in ins) or (op.startswith(("scratch_load", "buffer_load")) and "Reload" in ins)):
             pending.append((n, ins))          # (a compiler listing marks its spills and reloads; a reload there leaves the other lanes' register stale)
+        # The second pattern (round 5, profiles/r05_c_variant_fault.txt): the same placement with a REGISTER COPY instead of a scratch store.  When the allocator
+        # splits a live range around a region it saves the value with `v_mov_b32 vS, vX` (or into an AGPR), reuses vX inside, and copies it back afterwards;
+        # put at the top of a join block, ahead of the EXEC restore, the save runs for the fall-through side's lanes only, while the clobber and the copy
+        # back run under wider masks: the other lanes come out with whatever vS held (a finished kart's tele_total_time read 4.6e-41 in the Training kernel).
+        elif after_label and COPIES and re.match(r"^(v_mov_b32(_e32)?|v_mov_b64(_e32)?|v_accvgpr_write_b32|v_accvgpr_read_b32|v_accvgpr_mov_b32)\s+[va](\d+|\[\d+:\d+\]),\s*[va](\d+|\[\d+:\d+\])\s*$", head):
+            pending.append((n, ins + "   ; live-range copy"))
     return bad
+
+
+COPIES = os.environ.get("HK_GUARD_NO_COPIES") is None      # HK_GUARD_NO_COPIES=1: round 3's pattern only (spill stores / reloads)
 
 
 def main(argv):
