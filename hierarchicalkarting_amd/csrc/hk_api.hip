@@ -108,6 +108,8 @@ struct Tuning {
     bool fission_mcts = true;    // ... and long calls of planner handles with LQNG low levels (HK_NO_FISSION_MCTS: the fused kernel for those)
     bool mcts_overlap = true;    // HK_MCTS_NO_OVERLAP=1: long calls of planner handles launch a replan's searches when its stretch of rounds has ended, on the handle's stream (the schedule before round 5)
     bool fission_shaped = true;  // HK_NO_FISSION_SHAPED=1: handles with reward shaping / Training mode keep the fused kernel (round 5: they run the fission schedule too)
+    bool optimistic = true;      // HK_NO_OPTIMISTIC=1: fixed-round calls always issue the worst-case round count (the schedule before round 5)
+    int optimistic_skew = 0;     // HK_OPTIMISTIC_SKEW=k (tests): the believed episode step is off by k, so the exact plans are wrong and the recovery path runs
     bool park = false;           // HK_PARK=1: plain 3- / 4-agent handles run the fused kernel with LDS parking (hk_env_run.h PARK) instead of the fission schedule
     bool fission = true;         // plain 3- / 4-agent handles run the tick kernel without phase B1 + env_b1_kernel per solve cadence (hk_env_run.h); HK_FISSION=0: the fused kernel
     int debug_max_rounds = 0;    // HK_DEBUG_MAX_ROUNDS (diagnostic): cap on the rounds of a call, to look at the state in between
@@ -126,6 +128,7 @@ struct Tuning {
         debug_max_rounds = num("HK_DEBUG_MAX_ROUNDS", 0, 0, 1 << 20);
         debug_no_check = flag("HK_DEBUG_NO_CHECK"); stamps_dump = flag("HK_STAMPS_DUMP");
         { const char* f = std::getenv("HK_FISSION"); fission = !(f && std::atoi(f) == 0); fission_mcts = !flag("HK_NO_FISSION_MCTS"); fission_chunks = !flag("HK_NO_FISSION_CHUNKS"); park = flag("HK_PARK"); mcts_overlap = !flag("HK_MCTS_NO_OVERLAP"); fission_shaped = !flag("HK_NO_FISSION_SHAPED"); }
+        optimistic = !flag("HK_NO_OPTIMISTIC"); optimistic_skew = num("HK_OPTIMISTIC_SKEW", 0, 0, 3);
     }
 };
 
@@ -153,6 +156,14 @@ struct hk_context {
     // lazy completion of hk_step (handles without planner / attached actors): the call issues the rounds a field without
     // multi-player games needs and a guard kernel that reports what is left; the NEXT entry point that touches the state
     // finishes the stragglers (finish_ticks)
+    // The optimistic round plan (step_ticks): lock_tick = the episode step every env is believed to stand on (-1: not known) — 0 after a reset of every env,
+    // + n per hk_step(n), unknown after anything else that moves episode steps.  A fixed-round call of a plain handle then issues exactly the launches a field
+    // in lock-step needs (a tick launch per stretch between solve ticks, a B1 + solver launch per solve tick inside the call) instead of the worst case, and
+    // the completion guard VERIFIES it: opt_pending = such a call has been issued and its guard not looked at yet.  The next entry point other than hk_step
+    // looks (verify_optimistic): an env the plan missed kept its ticks, the belief is dropped and the laggards are finished like those of a long call.
+    long long lock_tick = -1;
+    bool opt_pending = false;
+    int exact_idx = 0, exact_total = 0;      // round counter of the current exact plan (issue_rounds is called in pieces)
     bool step_pending = false;
     bool split = false;            // the current call runs the batch as two halves on two streams (issue_rounds)
     int round_half[hk::SPLIT_WAYS_MAX] = {};    // each part's own round counter (the parity picks its queue set)
@@ -172,6 +183,7 @@ struct hk_context {
 };
 
 static int finish_ticks(hk_context* h);      // lazy completion of the last hk_step (defined with step_ticks)
+static int verify_optimistic(hk_context* h); // the completion guard of optimistic fixed-round calls, looked at; laggards finished (defined with step_ticks)
 
 namespace {
 
@@ -304,6 +316,7 @@ int hk_synchronize(hk_handle h)
     if (!h) return HK_ERR_INVALID;
     HK_HIP(h, hipSetDevice(h->device));
     if (h->step_pending) { int rc = finish_ticks(h); if (rc) return rc; }
+    if (h->opt_pending) { int rc = verify_optimistic(h); if (rc) return rc; }
     HK_HIP(h, hipStreamSynchronize(h->stream));
     return HK_OK;
 }
@@ -380,6 +393,15 @@ int hk_lq_solve_batch(hk_handle h, int batch, int N, const double* A, const doub
         if (!(h)->env_ready) return fail((h), HK_ERR_INVALID, "handle has no environment"); \
         HK_HIP((h), hipSetDevice((h)->device));                                            \
         if ((h)->step_pending) { int rc_ = finish_ticks(h); if (rc_) return rc_; }         \
+        if ((h)->opt_pending) { int rc_ = verify_optimistic(h); if (rc_) return rc_; }     \
+    } while (0)
+// hk_step itself: the calls of a host that steps tick by tick follow each other without a look at the device
+#define HK_NEED_ENV_STEP(h)                                                                \
+    do {                                                                                   \
+        if (!(h)) return fail(nullptr, HK_ERR_INVALID, "NULL handle");                     \
+        if (!(h)->env_ready) return fail((h), HK_ERR_INVALID, "handle has no environment"); \
+        HK_HIP((h), hipSetDevice((h)->device));                                            \
+        if ((h)->step_pending) { int rc_ = finish_ticks(h); if (rc_) return rc_; }         \
     } while (0)
 
 int hk_reset(hk_handle h, const int32_t* env_ids, int n, int experiment_num)
@@ -387,6 +409,7 @@ int hk_reset(hk_handle h, const int32_t* env_ids, int n, int experiment_num)
     HK_NEED_ENV(h);
     int rc = hk::env_reset(h->dev, h->cfg, env_ids, n, experiment_num, h->stream, h->err);
     if (rc) { g_last_error = h->err; return rc; }
+    h->lock_tick = env_ids ? -1 : 0;            // every env stands on episode step 0 again / some do: the field is no longer known to be in lock-step
     // the agents were reset: their observation stacks start from zeros again (env_reset left the ids in dev.env_ids)
     for (int p = 0; p < h->n_policies; p++) {
         const int cnt = (env_ids ? n : h->cfg.num_envs) * h->policy[p].q.n_slots;
@@ -420,6 +443,7 @@ static int issue_rounds(hk_handle h, int rounds)
         int rc = hk::env_launch_run(h->dev, h->cfg, h->stream, h->err);
         if (rc) { g_last_error = h->err; return rc; }
         e = h->prof.chain(0, e, first, h->stream);
+        if (h->dev.exact_plan && ++h->exact_idx == h->exact_total) { h->dev.b1_due = false; h->dev.round += 1; first = false; continue; }     // (the plan's last round: no solve tick is left in the call)
         if (h->dev.b1_due) {
             rc = hk::env_launch_b1(h->dev, h->cfg, h->stream, h->err);
             if (rc) { g_last_error = h->err; return rc; }
@@ -471,6 +495,7 @@ static int issue_rounds_split(hk_handle h, int rounds)
             rc = hk::env_launch_run_only(h->dev, h->cfg, st[k], h->err);
             if (rc) break;
             e[k] = h->prof.chain(0, e[k], first, st[k]);
+            if (h->dev.exact_plan && h->exact_idx + 1 == h->exact_total) { h->dev.b1_due = false; h->dev.round += 1; h->round_half[k] = h->dev.round; continue; }     // (the plan's last round: the tick launch alone)
             if (h->dev.b1_due) {
                 rc = hk::env_launch_b1(h->dev, h->cfg, st[k], h->err);
                 if (rc) break;
@@ -481,6 +506,7 @@ static int issue_rounds_split(hk_handle h, int rounds)
             e[k] = h->prof.chain(1, e[k], false, st[k]);
             h->round_half[k] = h->dev.round;
         }
+        if (h->dev.exact_plan) h->exact_idx += 1;
         first = false;
     }
     h->dev.slot0 = 0; h->dev.slot1 = 0; h->dev.qbase = 0; h->dev.round = h->round_half[0];
@@ -538,6 +564,9 @@ static int step_ticks(hk_handle h, int n_ticks)
     // ticks have been armed since the last one — early enough, because a plan is due > MCTS_MIN_LATENCY ticks after its
     // request.  (hk_get_mcts_state launches what is pending before it reads.)
     const bool planner = h->dev.mcts.st != nullptr;
+    const long long T0 = h->lock_tick;                           // the episode step the field is believed to stand on before this call (-1: not known)
+    if (h->lock_tick >= 0) h->lock_tick += n_ticks;
+    h->dev.exact_plan = false;
     // (how long a request may wait for its launch: a request posted on armed tick 1 is searched before armed tick defer + 1 runs, and its
     // plan is due `latency` ticks after the request — so defer = the handle's smaller latency - 1, at least MCTS_DEFER_TICKS)
     const int defer = std::max(hk::MCTS_DEFER_TICKS, std::min(h->cfg.mcts_latency_ticks, h->cfg.mcts_initial_latency_ticks) - 1);
@@ -686,6 +715,20 @@ static int step_ticks(hk_handle h, int n_ticks)
     const bool close_field = h->dev.ticks_since_reset < hk::BULK_TICKS;
     h->split = (want_split || (close_field && !no_split)) && h->dev.P.eager && h->cfg.num_envs >= 8192;
     int rounds = lazy ? hk::env_rounds_min(h->cfg, n_ticks, run_cap) : hk::env_rounds_for(h->cfg, n_ticks, run_cap, h->dev.P.eager != 0);
+    // The optimistic plan of a fixed-round call (round 5).  If every env stands on episode step T0, the call's ticks T0 + 1 .. T0 + n hold S solve ticks
+    // (multiples of the cadence) and the field needs exactly S rounds of {tick launch up to the solve tick, B1, solver} and one more tick launch: a one-tick
+    // call off a solve tick is ONE launch, the driver's 20-tick window 6 + 5 + 5 launches per half instead of 7 + 7 + 7.  The plan is a belief, not a proof
+    // (envs finish and reset on their own; a time-out inside the call would add a solve tick): the call's completion guard verifies it, an env the plan
+    // missed keeps its ticks (and stays parked at its solve tick: hk_env_run.h `stuck`), and the next entry point that looks at the state drops the belief
+    // and finishes it (verify_optimistic).  Nothing is ever wrong, a wrong belief is only slow — so it is used only where it is cheap to check.
+    if (!lazy && plain && h->dev.fission && h->dev.P.any_lqr != 0 && h->tune.optimistic && T0 >= 0 && T0 + n_ticks < h->cfg.max_episode_steps && h->tune.debug_max_rounds == 0) {
+        const long long Tb = T0 + h->tune.optimistic_skew;
+        const int cad = h->cfg.num_agents > 2 ? 4 : 1;
+        const int S = (int)((Tb + n_ticks) / cad - Tb / cad);               // multiples of the cadence in (Tb, Tb + n]
+        rounds = S + 1;
+        h->dev.exact_plan = true;
+        h->exact_idx = 0; h->exact_total = rounds;
+    }
     if (h->tune.debug_max_rounds > 0) rounds = std::min(rounds, h->tune.debug_max_rounds);     // (diagnostic: look at the state between two rounds)
     {
         // the rounds every env needs at RUN_CAP ticks a round, then — the laggards packed into the first lane groups — the tail
@@ -715,7 +758,30 @@ static int step_ticks(hk_handle h, int n_ticks)
         if (rc) return rc;
     }
     h->step_pending = lazy;
+    if (h->dev.exact_plan) h->opt_pending = true;
+    h->dev.exact_plan = false;
     return HK_OK;
+}
+
+// The completion guard of the optimistic fixed-round calls issued since the last look (status bit 2: the last tick launch of a folded call, env_check_kernel
+// of the others).  Set: some env did not finish — the belief that the field is in lock-step was wrong (an env finished its race and reset, a time-out) — it
+// kept its leftover ticks; the belief is dropped and the laggards are finished as those of a long call are (a guard launch that reports what is left,
+// finish_ticks).  Not an error: the state every getter sees afterwards is the state the worst-case schedule would have produced.
+static int verify_optimistic(hk_handle h)
+{
+    h->opt_pending = false;
+    int st[4] = {0, 0, 0, 0};
+    HK_HIP(h, hipMemcpyAsync(st, h->dev.status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    HK_HIP(h, hipStreamSynchronize(h->stream));
+    if (!(st[0] & 4)) return HK_OK;
+    h->lock_tick = -1;
+    hipLaunchKernelGGL(hk::status_and_kernel, dim3(1), dim3(1), 0, h->stream, h->dev.status, ~4);
+    HK_HIP(h, hipGetLastError());
+    if (h->done_host == nullptr) return fail(h, HK_ERR_HIP, "hk_step: an env did not complete its ticks and the handle has no completion buffer");
+    int rc = issue_check(h, true);
+    if (rc) return rc;
+    h->step_pending = true;
+    return finish_ticks(h);
 }
 
 // Academy step of a decision tick: CollectObservations -> StackingSensor -> actor -> OnActionReceived latch
@@ -753,7 +819,7 @@ static int policy_decide(hk_handle h)
 
 int hk_step(hk_handle h, int n_ticks)
 {
-    HK_NEED_ENV(h);
+    HK_NEED_ENV_STEP(h);
     if (n_ticks < 0) return fail(h, HK_ERR_INVALID, "hk_step: n_ticks < 0");
     if (n_ticks == 0) return HK_OK;
     if (h->n_policies == 0) {
@@ -929,6 +995,7 @@ int hk_set_env_state(hk_handle h, const hk_env_state* in)
     HK_NEED_ENV(h);
     if (!in) return fail(h, HK_ERR_INVALID, "NULL pointer");
     h->dev.P.hold_dedupe = 0;          // (as hk_set_agent_state: episode_steps may be rewound into a hold whose solves were skipped)
+    h->lock_tick = -1;                 // (the host wrote episode steps)
     HK_HIP(h, hipMemcpyAsync(h->dev.envs_stage, in, (size_t)h->cfg.num_envs * sizeof(hk_env_state), hipMemcpyHostToDevice, h->stream));
     { int rc = hk::ga_ops(h->dev).launch_envs_scatter(h->dev, h->cfg, h->stream, h->err); if (rc) { g_last_error = h->err; return rc; } }   // (progress words sanitized on the way)
     HK_HIP(h, hipStreamSynchronize(h->stream));

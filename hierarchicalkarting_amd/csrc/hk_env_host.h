@@ -64,6 +64,7 @@ struct EnvDevice {
     bool b1_due = false;           // FISSION: the tick launch just issued parked its envs at their solve tick: env_b1_kernel is next on that stream
     int lqn_sparse_blocks = 1024;  // workgroups per queue of a solver launch once the field has spread (HK_LQN_SPARSE_BLOCKS)
     int mcts_side_waves = 8;       // waves per workgroup of a search launch that runs beside tick launches (HK_MCTS_SIDE_WAVES; 0: as alone)
+    bool exact_plan = false;       // the current fixed-round call follows the exact plan of a field in lock-step: its last round is the tick launch alone (hk_api.hip step_ticks)
     bool park = false;             // plain handles run the fused kernel with LDS parking (hk_env_run.h PARK) instead of the fission schedule
     bool park_attr_set = false;
     bool fission = false;          // the current call runs the tick kernel without phase B1 + env_b1_kernel (hk_env_run.h FISSION; hk_api.hip step_ticks)

@@ -252,7 +252,10 @@ __global__ __launch_bounds__(PARK ? PARK_BLOCK : 256, FISSION ? HK_FIS_OCC : HK_
     const LaneCfg LC = lane_cfg(P, i);                   // this lane's agent: modes and player list, read once
     int left = es.reserved[0];
     int phase = es.reserved[1] & ENV_PHASE_MASK;         // 0: at a tick boundary; 1: phases A / B1 of a tick done, waiting for (or holding) its controls
-    if (FISSION && phase == 2) phase = 0, left = 0;      // (cannot happen: env_b1_kernel runs between two tick launches; such an env would trip the guard)
+    // an env still parked at its solve tick (phase 2): the round plan of the call before did not foresee that tick (hk_api.hip: the optimistic plan of a
+    // field believed to be in lock-step) and launched no env_b1_kernel behind it.  It keeps its ticks and stays parked — the next B1 launch serves it, the
+    // completion guard reports it, and the next entry point that looks at the state finishes it.
+    const bool stuck = FISSION && phase == 2;
     bool pack = (es.reserved[1] & ENV_PACK_HINT) != 0;   // did the env's last solve tick queue a multi-player game (regroup_key)
     bool dirty = false;
 #ifdef HK_STAMPS
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(PARK ? PARK_BLOCK : 256, FISSION ? HK_FIS_OCC : HK_
     // The loop is wave-uniform: a lane group whose env has nothing (more) to run in this launch stays in it, idle.  `go` depends on
     // the env's words only, so a lane group is in or out as a whole, and the group-wide exchanges below (group_get / group_or:
     // DPP quad permutes, which read 0 from a lane that is switched off) always run with whole groups.
-    bool go = env_ok && (phase != 0 || (left > 0 && budget > 0 && !held));
+    bool go = env_ok && !stuck && (phase != 0 || (left > 0 && budget > 0 && !held));
     while (__ballot(go) != 0ull) {
         int qn = 0;                  // player count of the multi-player game this ego assembled on this tick (0: none)
         bool began = false;          // this env ran phases A / B1 in this iteration (it was at a tick boundary and not parked)
