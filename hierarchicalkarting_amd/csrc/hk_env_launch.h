@@ -238,7 +238,10 @@ inline int launch_observe(EnvDevice& d, const hk_config& cfg, uint32_t agent_mas
     const long long threads = (long long)cfg.num_envs * cfg.num_agents * OBS_LANES;
     // a block is only 16 agents: copying the tables into LDS pays for the Oval's 20 KB (+3 % on the RL workload), not for the
     // Complex track's 40 KB (the 8-agent workload lost 10 %), which keeps reading them through L1 / L2
-    const int lds = (d.tab_lds && d.tab_lds <= 24 * 1024) ? d.tab_lds : 0;
+#ifndef HK_OBS_LDS_MAX
+#define HK_OBS_LDS_MAX (32 * 1024)     /* round 5: the Oval tables are 29 KB now; in LDS 71.2 -> 72.8 M on the RL workload */
+#endif
+    const int lds = (d.tab_lds && d.tab_lds <= HK_OBS_LDS_MAX) ? d.tab_lds : 0;
     const uint32_t mask = d.rw.hit_code ? 0xFFFFFFFFu : agent_mask;                  // the reward replay needs every agent's hit codes
     if (lds) hipLaunchKernelGGL(env_observe_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, stream, d.P, d.agents, d.hot, d.slot_of, d.obs, d.rw.hit_code, mask);
     else hipLaunchKernelGGL(env_observe_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d.P, d.agents, d.hot, d.slot_of, d.obs, d.rw.hit_code, mask);
