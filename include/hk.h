@@ -316,6 +316,10 @@ int hk_set_actions(hk_handle h, const float* steer, const int32_t* branch);
  * touches the state (any hk_get_* / hk_set_* / hk_reset / hk_step / hk_prof_read / hk_gather_results, or hk_synchronize): it waits
  * for a two-word report of the device and issues what the laggard envs still need ("lazy completion").  hk_synchronize is the
  * completion point: a host that overlaps its own work with hk_step, or times it, calls hk_synchronize where it needs the ticks done.
+ * Round 5: a fixed-round call of a plain handle whose envs are all believed to stand on the same episode step (a reset of every env, then only hk_step
+ * calls) issues exactly the launches such a field needs — a one-tick call off a solve tick is one launch — and the completion guard verifies the
+ * belief: the next entry point other than hk_step looks at it and, if an env fell behind (it finished its race, a time-out), finishes that env the
+ * lazy way before anything is read.  Successive hk_step calls do not look; hk_synchronize does.
  * Error surface: hk_step only reports launch errors.  A completion guard (env_check_kernel) runs after the rounds of a call; if an
  * env still had ticks to run (an internal scheduling error) the next hk_get_agent_state / hk_get_env_state fails ONCE with
  * HK_ERR_HIP "an env did not complete its ticks" instead of returning stale state; the flag is sticky until that report (or
@@ -326,6 +330,9 @@ int hk_set_actions(hk_handle h, const float* steer, const int32_t* branch);
  * the tick kernel without phase B1 + env_b1_kernel per solve cadence), HK_NO_EAGER, HK_FIXED_ROUNDS,
  * HK_MCTS_NO_PAUSE, HK_SPLIT / HK_NO_SPLIT, HK_RUN_CAP_SPREAD, HK_RUN_CAP_SHORT, HK_LAZY_MIN_TICKS, HK_TAIL_WORST_CASE, HK_KEEP_LAST_SOLVE, HK_REGROUP_ROUNDS, HK_MCTS_PERSIST_GB,
  * HK_NO_HOLD_DEDUPE, HK_LQ_DEBUG, HK_TAB_GLOBAL (track tables read from global memory, as for tracks that exceed the LDS budget);
+ * round 5: HK_NO_OPTIMISTIC (fixed-round calls issue the worst-case round count instead of the verified plan of a field in lock-step), HK_NO_FISSION_SHAPED
+ * (reward-shaped / Training handles keep the fused kernel), HK_PARK (plain handles on the fused kernel with LDS parking), HK_MCTS_NO_OVERLAP / HK_MCTS_SIDE_WAVES
+ * (a replan's searches on the handle's stream after the stretch / search workgroup size beside the ticks), HK_LQN_SPARSE_BLOCKS;
  * diagnostics HK_DEBUG_MAX_ROUNDS, HK_DEBUG_NO_CHECK, HK_STAMPS_DUMP.
  * Planner handles (any HighMode MCTS agent): a call of more than 38 ticks without attached actors synchronises with the host
  * between stretches of ~100 ticks — envs wait at the tick boundary after a search request so that the searches of a stretch run
