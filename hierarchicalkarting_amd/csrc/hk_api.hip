@@ -164,6 +164,7 @@ struct hk_context {
     long long lock_tick = -1;
     bool opt_pending = false;
     int exact_idx = 0, exact_total = 0;      // round counter of the current exact plan (issue_rounds is called in pieces)
+    long long mcts_async_deadline = -1;      // short calls of planner handles: the believed episode step at which the search launch running on mcts_stream is first used (-1: none in flight)
     bool step_pending = false;
     bool split = false;            // the current call runs the batch as two halves on two streams (issue_rounds)
     int round_half[hk::SPLIT_WAYS_MAX] = {};    // each part's own round counter (the parity picks its queue set)
@@ -184,6 +185,14 @@ struct hk_context {
 
 static int finish_ticks(hk_context* h);      // lazy completion of the last hk_step (defined with step_ticks)
 static int verify_optimistic(hk_context* h); // the completion guard of optimistic fixed-round calls, looked at; laggards finished (defined with step_ticks)
+// a search launch that runs on the side stream beside the chunks of a planner + actor handle (step_ticks): the handle's stream waits for it — before another
+// search launch (they share the tree arena), before the chunk that uses its plans, before anything reads the planner state
+static inline int mcts_join_async(hk_context* h)
+{
+    if (h->mcts_async_deadline < 0) return 0;
+    h->mcts_async_deadline = -1;
+    return hipStreamWaitEvent(h->stream, h->ev_mcts_done, 0) == hipSuccess ? 0 : -1;
+}
 
 namespace {
 
@@ -394,6 +403,7 @@ int hk_lq_solve_batch(hk_handle h, int batch, int N, const double* A, const doub
         HK_HIP((h), hipSetDevice((h)->device));                                            \
         if ((h)->step_pending) { int rc_ = finish_ticks(h); if (rc_) return rc_; }         \
         if ((h)->opt_pending) { int rc_ = verify_optimistic(h); if (rc_) return rc_; }     \
+        if (mcts_join_async(h)) return fail((h), HK_ERR_HIP, "hipStreamWaitEvent (planner side stream)"); \
     } while (0)
 // hk_step itself: the calls of a host that steps tick by tick follow each other without a look at the device
 #define HK_NEED_ENV_STEP(h)                                                                \
@@ -571,7 +581,18 @@ static int step_ticks(hk_handle h, int n_ticks)
     // plan is due `latency` ticks after the request — so defer = the handle's smaller latency - 1, at least MCTS_DEFER_TICKS)
     const int defer = std::max(hk::MCTS_DEFER_TICKS, std::min(h->cfg.mcts_latency_ticks, h->cfg.mcts_initial_latency_ticks) - 1);
     const bool short_call = planner && n_ticks <= defer;
-    if (planner && h->dev.mcts_ticks > 0 && (!short_call || h->dev.mcts_ticks + n_ticks > defer)) {
+    // Round 5: the searches of a replan beside the CHUNKS that follow it (handles with attached actors step in decision chunks; round 4 launched a replan's
+    // searches up to `defer` ticks late, on the handle's stream, and every chunk behind them waited ~10 - 100 ms).  If the field is believed to be in lock-step
+    // the host knows the chunk that holds the replan step (a multiple of 100): whatever is queued is searched BEFORE that chunk, so that the launch after it
+    // holds that chunk's requests only — none older than the chunk — and may therefore run on the side stream until the chunk that reaches request +
+    // latency.  A wrong belief costs the overlap only: requests posted at other times are served by the `defer` rule exactly as before, and every
+    // search launch first waits for the one in flight (they share the tree arena).
+    const int lat_min = std::min(h->cfg.mcts_latency_ticks, h->cfg.mcts_initial_latency_ticks);
+    long long t_req = -1;
+    if (short_call && T0 >= 0 && h->tune.mcts_overlap && h->n_policies > 0) { t_req = (T0 / 100 + 1) * 100; if (t_req > T0 + n_ticks) t_req = -1; }
+    if (h->mcts_async_deadline >= 0 && (!short_call || T0 < 0 || T0 + n_ticks >= h->mcts_async_deadline)) { if (mcts_join_async(h)) return fail(h, HK_ERR_HIP, "hipStreamWaitEvent (planner side stream)"); }
+    if (planner && h->dev.mcts_ticks > 0 && (!short_call || h->dev.mcts_ticks + n_ticks > defer || t_req >= 0)) {
+        if (mcts_join_async(h)) return fail(h, HK_ERR_HIP, "hipStreamWaitEvent (planner side stream)");
         rc = hk::env_flush_mcts(h->dev, h->stream, h->err);
         if (rc) { g_last_error = h->err; return rc; }
     }
@@ -747,6 +768,20 @@ static int step_ticks(hk_handle h, int n_ticks)
             rc = issue_rounds(h, rounds - main_rounds);
             if (rc) return rc;
         }
+    }
+    if (t_req >= 0) {
+        // this chunk held the replan step: its requests (and nothing older) go to the side stream
+        if (mcts_join_async(h)) return fail(h, HK_ERR_HIP, "hipStreamWaitEvent (planner side stream)");
+        if (!h->mcts_stream) HK_HIP(h, hipStreamCreateWithFlags(&h->mcts_stream, hipStreamNonBlocking));
+        if (!h->ev_mcts_go) HK_HIP(h, hipEventCreateWithFlags(&h->ev_mcts_go, hipEventDisableTiming));
+        if (!h->ev_mcts_done) HK_HIP(h, hipEventCreateWithFlags(&h->ev_mcts_done, hipEventDisableTiming));
+        HK_HIP(h, hipEventRecord(h->ev_mcts_go, h->stream));
+        HK_HIP(h, hipStreamWaitEvent(h->mcts_stream, h->ev_mcts_go, 0));
+        rc = hk::env_flush_mcts_on(h->dev, h->stream, h->mcts_stream, h->err);
+        if (rc) { g_last_error = h->err; return rc; }
+        HK_HIP(h, hipEventRecord(h->ev_mcts_done, h->mcts_stream));
+        // the oldest request in that launch was posted on step T0 + 1 at the earliest: its plan is first used on that step + the smaller latency
+        h->mcts_async_deadline = T0 + 1 + lat_min;
     }
     if (planner && !short_call) {
         // searches requested in the last rounds of a long call run before it returns
