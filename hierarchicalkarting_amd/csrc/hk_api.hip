@@ -834,7 +834,7 @@ static int policy_decide(hk_handle h)
         const hk::PolicyDevice& pd = h->policy[p];
         const int pairs = E * pd.q.n_slots;
         const int w = (int)(decision % (unsigned long long)pd.q.stack);
-        hipLaunchKernelGGL(hk::policy_stack_kernel, dim3((pairs + 1) / 2), dim3(256), 0, h->stream, pd.q, E, A, h->dev.envs, h->dev.slot_of,
+        hipLaunchKernelGGL(hk::policy_stack_kernel, dim3((pairs + 3) / 4), dim3(256), 0, h->stream, pd.q, E, A, h->dev.envs, h->dev.slot_of,
                            h->dev.obs, w);
         HK_HIP(h, hipGetLastError());
     }

@@ -243,7 +243,17 @@ inline int launch_observe(EnvDevice& d, const hk_config& cfg, uint32_t agent_mas
 #endif
     const int lds = (d.tab_lds && d.tab_lds <= HK_OBS_LDS_MAX) ? d.tab_lds : 0;
     const uint32_t mask = d.rw.hit_code ? 0xFFFFFFFFu : agent_mask;                  // the reward replay needs every agent's hit codes
-    if (lds) hipLaunchKernelGGL(env_observe_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds, stream, d.P, d.agents, d.hot, d.slot_of, d.obs, d.rw.hit_code, mask);
+#ifndef HK_OBS_BIG_BLOCK
+#define HK_OBS_BIG_BLOCK 1024
+#endif
+#ifndef HK_OBS_LDS_BLOCK
+#define HK_OBS_LDS_BLOCK 512      /* one copy of the staged tables per 32 agents: RL workload 75.5 -> 77.5 M (256: a copy per 16; 1 024: 76.0) */
+#endif
+    if (lds) hipLaunchKernelGGL((env_observe_kernel<true, HK_OBS_LDS_BLOCK>), dim3((unsigned)((threads + HK_OBS_LDS_BLOCK - 1) / HK_OBS_LDS_BLOCK)), dim3(HK_OBS_LDS_BLOCK), lds, stream, d.P, d.agents, d.hot, d.slot_of,
+                                d.obs, d.rw.hit_code, mask);
+    else if (d.tab_lds && d.tab_lds <= 60 * 1024)      // a long track: one copy of the tables per 64 agents
+        hipLaunchKernelGGL((env_observe_kernel<true, HK_OBS_BIG_BLOCK>), dim3((unsigned)((threads + HK_OBS_BIG_BLOCK - 1) / HK_OBS_BIG_BLOCK)), dim3(HK_OBS_BIG_BLOCK), d.tab_lds, stream, d.P, d.agents, d.hot,
+                           d.slot_of, d.obs, d.rw.hit_code, mask);
     else hipLaunchKernelGGL(env_observe_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d.P, d.agents, d.hot, d.slot_of, d.obs, d.rw.hit_code, mask);
     int rc = launch_check(err, "env_observe_kernel");
     if (rc || !d.rw.hit_code) return rc;

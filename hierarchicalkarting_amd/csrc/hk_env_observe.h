@@ -48,8 +48,10 @@ __device__ inline void inv_transform_point(const float apx, const float apz, flo
 // Lane l of the group first evaluates the forward vector of kart l % A (one fp64 sin/cos pair per lane instead of A per
 // agent) and the group shares them by shuffles.
 constexpr int OBS_LANES = 16;
-template <bool TAB_LDS>
-__global__ __launch_bounds__(256) void env_observe_kernel(EnvParams P, const hk_agent_state* agents, const uint32_t* hot, const int* slot_of, float* obs, unsigned char* hit_code,
+// BLOCK: threads per workgroup = 16 x the agents that share one LDS copy of the tables (round 5: 1 024 for a long track, whose 47.5 KB per 16 agents
+// cost more to stage than they saved)
+template <bool TAB_LDS, int BLOCK = 256>
+__global__ __launch_bounds__(BLOCK) void env_observe_kernel(EnvParams P, const hk_agent_state* agents, const uint32_t* hot, const int* slot_of, float* obs, unsigned char* hit_code,
                                                           uint32_t agent_mask /* bit i: agent slot i is observed */)
 {
     // the track tables (wall grid walked by nine 20 m rays per agent) staged in LDS, as in the tick kernel

@@ -63,28 +63,27 @@ struct PolicyDevice {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------------------------------
-// StackingSensor.  128 threads per (env, slot); w = ring slot that receives the newest observation.
+// StackingSensor.  One wave per (env, slot), four to a block; w = ring slot that receives the newest observation.  (Round 5: a wave needs no block
+// barrier — the epoch word is read by every lane before lane 0 rewrites it, the zero fill precedes the copy in program order — and a pair moves
+// obs_dim <= 126 floats: with 128 threads and two __syncthreads per pair the kernel took 1.9 ms per decision beside the planner's searches.)
 __global__ __launch_bounds__(256) void policy_stack_kernel(PolicyParams Q, int E, int A, const hk_env_state* envs_by_slot, const int* slot_of,
                                                            const float* obs, int w)
 {
-    const int pair = blockIdx.x * 2 + (threadIdx.x >> 7);
-    const int t = threadIdx.x & 127;
-    const bool ok = pair < E * Q.n_slots;
-    const int env = ok ? pair / Q.n_slots : 0, j = ok ? pair % Q.n_slots : 0;
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int t = threadIdx.x & 63;
+    if (pair >= E * Q.n_slots) return;                         // (wave-uniform)
+    const int env = pair / Q.n_slots, j = pair % Q.n_slots;
     const hk_env_state* es = &envs_by_slot[slot_of[env]];      // env words are stored by lane-group slot (hk_env_device.h)
     const int ep = es->episodes_done + es->initial_started;
-    const bool stale = ok && Q.epoch[pair] != ep;
-    __syncthreads();                 // everyone has read the epoch word before it is rewritten
-    float* ring = Q.ring + (size_t)(ok ? pair : 0) * Q.in_dim;
+    const bool stale = Q.epoch[pair] != ep;                    // every lane reads the word; lane 0 rewrites it below, after this load in program order
+    float* ring = Q.ring + (size_t)pair * Q.in_dim;
     if (stale) {
-        for (int k = t; k < Q.in_dim; k += 128) ring[k] = 0.0f;
+        for (int k = t; k < Q.in_dim; k += 64) ring[k] = 0.0f;
         if (t == 0) Q.epoch[pair] = ep;
     }
-    __syncthreads();                 // zero fill before the newest observation lands in slot w
-    if (ok) {
-        const float* o = obs + ((size_t)env * A + Q.slots[j]) * Q.obs_dim;
-        for (int k = t; k < Q.obs_dim; k += 128) ring[(size_t)w * Q.obs_dim + k] = o[k];
-    }
+    // (the copy of slot w lands on addresses the zero fill may have written from other lanes of this wave: a wave's stores reach memory in program order)
+    const float* o = obs + ((size_t)env * A + Q.slots[j]) * Q.obs_dim;
+    for (int k = t; k < Q.obs_dim; k += 64) ring[(size_t)w * Q.obs_dim + k] = o[k];
 }
 
 // hk_reset: force the rings of the listed envs (all when env_ids == nullptr) to be cleared at the next decision
