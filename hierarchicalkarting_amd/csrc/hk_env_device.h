@@ -541,7 +541,7 @@ __device__ unsigned long long* hk_lp_ptr;
 // Diagnostic build only (-DHK_STAMPS, tools/stamp_profile.py): cycle stamps at the phase boundaries of the fused tick kernel,
 // accumulated per lane, reduced to the wave's maximum and added to game_stats[16 + k] when the kernel ends.
 #ifdef HK_STAMPS
-#define HK_NSTAMP 26
+#define HK_NSTAMP 30
 #define HK_ST(h, k) do { const unsigned long long n_ = __builtin_readcyclecounter(); (h).st_acc[k] += (unsigned)(n_ - (h).st_t); (h).st_t = n_; } while (0)
 #else
 #define HK_ST(h, k) do { } while (0)

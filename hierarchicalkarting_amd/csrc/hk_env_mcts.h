@@ -664,22 +664,28 @@ __global__ __launch_bounds__(256) void mcts_order_kernel(EnvParams P, MctsDev M,
 // The reference starts from the child at a random index and lets any child with a strictly larger weight replace it, walking
 // the list from the front: the result is the FIRST child holding the maximum if that maximum exceeds the random child's
 // weight, else the random child — computed here in ONE walk over the sibling list (each hop is a dependent global load).
-__device__ __forceinline__ int mc_ucs(MctsCtx& C, const MNode* nd, int first_child, int n_children, int parent_episodes)
-{
+__device__ __forceinline__ int mc_ucs(MctsCtx& C, const MNode* nd, int first_child, int n_children, int parent_episodes, MNode& chosen)
+{   // (`chosen`: the record of the returned child — the walk has loaded it already; loading it again was one more dependent round trip per level)
     const int index = mc_rand_next(C, n_children);
     int best_first = -1, idx_child = first_child;
     float best = -__builtin_inff(), u_idx = 0.0f;
+    MNode best_n, idx_n;
     int c = first_child;
     for (int q = 0; c >= 0; q++) {
         const MNode n = nd[c];
+        if (q == 0) { best_n = n; idx_n = n; }
         const float u = (n.totalValue / (float)n.numEpisodes) + sqrtf(1.0f) * hk_logf((float)(parent_episodes / n.numEpisodes));
-        if (q == index) { idx_child = c; u_idx = u; }
-        if (u > best) { best = u; best_first = c; }
+        if (q == index) { idx_child = c; u_idx = u; idx_n = n; }
+        if (u > best) { best = u; best_first = c; best_n = n; }
         c = n.next_sibling;
     }
-    return (best > u_idx) ? best_first : idx_child;
+    if (best > u_idx) { chosen = best_n; return best_first; }
+    chosen = idx_n;
+    return idx_child;
 }
 
+struct alignas(8) MStat { int n; float tv; };                    // MNode::numEpisodes, totalValue as one 8-byte access
+static_assert(offsetof(MNode, numEpisodes) % 8 == 0 && offsetof(MNode, totalValue) == offsetof(MNode, numEpisodes) + 4, "MStat overlays MNode");
 constexpr int MC_MAXPATH = HK_MCTS_MAX_DEPTH * MC_MAXP + 2;     // nodes on one root-to-leaf path (a move per player and depth level)
 constexpr int MC_ROOT_WORDS = (int)(sizeof(DGame) / sizeof(int));
 static_assert(sizeof(DGame) % sizeof(int) == 0, "DGame is all ints");
@@ -798,8 +804,7 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
         int np = cur.upnext;
         mc_eval_moves(C, g, np, mv);
         while (cur.n_children > 0 && cur.n_children == mv.n) {
-            node = mc_ucs(C, nd, cur.first_child, cur.n_children, cur.numEpisodes);
-            cur = nd[node];
+            { MNode pick; node = mc_ucs(C, nd, cur.first_child, cur.n_children, cur.numEpisodes, pick); cur = pick; }
             mc_make_move(C, g, np, cur.action);
             np = cur.upnext;
             depth++;
@@ -848,11 +853,32 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
         }
         if (out_of_nodes) break;                       // (cannot happen: hk_create sizes the arena for the worst case of every search a tree can receive)
         // backpropagate :285-293 along the remembered path, leaf to root; a node created in this iteration holds 0 / 0.0f
-        for (int d = depth; d >= 0; d--) {
-            const int b = path[d * 64];
-            const float sc = mc_score_at(scores, pup[d * 64]);
-            if (d >= first_new) { nd[b].totalValue = 0.0f + sc; nd[b].numEpisodes = 1; }
-            else { nd[b].totalValue += sc; nd[b].numEpisodes += 1; }
+        // (the nodes of a path are distinct, so the order of the updates is free: the tree's old nodes — a load, an add, a store each — go four at a
+        // time, their loads in flight together, instead of one dependent round trip per node)
+        {
+            int d = depth;
+            for (; d >= first_new; d--) {
+                const int b = path[d * 64];
+                MStat w; w.n = 1; w.tv = 0.0f + mc_score_at(scores, pup[d * 64]);
+                *reinterpret_cast<MStat*>(&nd[b].numEpisodes) = w;
+            }
+            for (; d >= 3; d -= 4) {
+                const int b0 = path[d * 64], b1 = path[(d - 1) * 64], b2 = path[(d - 2) * 64], b3 = path[(d - 3) * 64];
+                MStat w0 = *reinterpret_cast<const MStat*>(&nd[b0].numEpisodes), w1 = *reinterpret_cast<const MStat*>(&nd[b1].numEpisodes);
+                MStat w2 = *reinterpret_cast<const MStat*>(&nd[b2].numEpisodes), w3 = *reinterpret_cast<const MStat*>(&nd[b3].numEpisodes);
+                w0.tv += mc_score_at(scores, pup[d * 64]); w0.n += 1;
+                w1.tv += mc_score_at(scores, pup[(d - 1) * 64]); w1.n += 1;
+                w2.tv += mc_score_at(scores, pup[(d - 2) * 64]); w2.n += 1;
+                w3.tv += mc_score_at(scores, pup[(d - 3) * 64]); w3.n += 1;
+                *reinterpret_cast<MStat*>(&nd[b0].numEpisodes) = w0; *reinterpret_cast<MStat*>(&nd[b1].numEpisodes) = w1;
+                *reinterpret_cast<MStat*>(&nd[b2].numEpisodes) = w2; *reinterpret_cast<MStat*>(&nd[b3].numEpisodes) = w3;
+            }
+            for (; d >= 0; d--) {
+                const int b = path[d * 64];
+                MStat w = *reinterpret_cast<const MStat*>(&nd[b].numEpisodes);
+                w.tv += mc_score_at(scores, pup[d * 64]); w.n += 1;
+                *reinterpret_cast<MStat*>(&nd[b].numEpisodes) = w;
+            }
         }
     }
 
@@ -867,8 +893,9 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
         while (nd[node].n_children > 0) {
             const MNode rec = nd[node];
             const int np = rec.upnext;
-            node = mc_ucs(C, nd, rec.first_child, rec.n_children, rec.numEpisodes);
-            mc_make_move(C, g, np, nd[node].action);
+            MNode pick;
+            node = mc_ucs(C, nd, rec.first_child, rec.n_children, rec.numEpisodes, pick);
+            mc_make_move(C, g, np, pick.action);
             bool all_at = true;
 #define MC_AT(I) if (I < g.P) all_at = all_at && (mc_k<I>(g).section == g.last);
             MC_EACH(MC_AT)

@@ -607,6 +607,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
         // only the Triggers listed for the kart's coarse cell can be within reach (the others fail the distance cull below
         // by construction): a couple of trips instead of one per section, each a dependent LDS round trip
         const unsigned tcand = trig_candidates_tight(P, T, px, pz);
+        HK_ST(h, 26);                  // [26] (of [11]) finite checks, capsule core, candidate cell
         auto trig_test = [&](const int t, const float tx, const float tz, const float tfx, const float tfz) {
             HK_LP(18);
             // exact cull: box half diagonal 5.03 + capsule reach 1.11 < 6.5
@@ -645,6 +646,7 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
             { const SecDev& s = T.sec[t0]; trig_test(t0, s.trig_x, s.trig_z, s.fx, s.fz); }
             if (t1 != 0xFF) { const SecDev& s = T.sec[t1]; trig_test(t1, s.trig_x, s.trig_z, s.fx, s.fz); }
         }
+        HK_ST(h, 27);                  // [27] (of [11]) Trigger overlap tests
         const uint32_t nlo = lo & ~h.trig_lo, nhi = hi & ~h.trig_hi;
         h.trig_lo = lo; h.trig_hi = hi;
 #ifdef HK_DUMMY_NO_ENTER
@@ -660,8 +662,13 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                 HK_LP(20);
                 // this Trigger's plan entry, asked for before anything else: the two global loads used to sit behind each other and behind
                 // the section search, and the wave waited for both (two lanes of it are here on most ticks)
+#ifdef HK_DUMMY_NO_PLANMEM              // (timing experiments only: wrong results)
+                const int pl_t = 1 + (t & 1);
+                const float pv_t = 10.0f;
+#else
                 const int pl_t = a->plan_lane[t];
                 const float pv_t = a->plan_vel[t];
+#endif
                 const int L = P.L, H = P.H;
                 const int sec = h.section_index, init = h.init_checkpoint_index;
                 int index = -1, lane = -1;
@@ -693,7 +700,9 @@ __device__ inline void phase_move(const EnvParams& P, const TabView& T, const in
                         h.avg_lane_diff = (f_max(dist - 1.3f, 0.0f) + h.avg_lane_diff * (index - init - 1)) / (index - init);
                         float velocity = mag3(vx, 0.0f, vz);
                         h.avg_vel_diff = ((velocity - pv_t) + h.avg_vel_diff * (index - init - 1)) / (index - init);
+#ifndef HK_DUMMY_NO_PLANMEM
                         a->plan_lane[key] = 0; a->plan_vel[key] = 0.0f;
+#endif
                     }
                     const int cur_lane = h.lane;
                     int dl = cur_lane - lane; if (dl < 0) dl = -dl;
