@@ -209,7 +209,26 @@ __device__ inline TabView tab_stage(const EnvParams& P, unsigned char* smem, con
     const int n16 = (stage_bytes ? stage_bytes : P.tab_stage_bytes) >> 4;
     const uint4* src = reinterpret_cast<const uint4*>(P.tab);
     uint4* dst = reinterpret_cast<uint4*>(smem);
-    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    // eight loads in flight per lane: written as `dst[i] = src[i]` the loop waits for every load before its LDS write (one L2 round trip per
+    // 16 bytes and lane — 12 of them in a row on the Oval, ~12 us at the head of EVERY launch, with all the launch's waves in it at once)
+    int i = threadIdx.x;
+    const int bd = blockDim.x;
+    for (; i + 7 * bd < n16; i += 8 * bd) {
+        uint4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = src[i + k * bd];
+#pragma unroll
+        for (int k = 0; k < 8; k++) dst[i + k * bd] = v[k];
+    }
+    if (i + 3 * bd < n16) {
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = src[i + k * bd];
+#pragma unroll
+        for (int k = 0; k < 4; k++) dst[i + k * bd] = v[k];
+        i += 4 * bd;
+    }
+    for (; i < n16; i += bd) dst[i] = src[i];
     __syncthreads();
     TabView T = tab_view(P, smem);
     if (P.tab_stage_bytes < P.tab_bytes) T.tmask2 = reinterpret_cast<const unsigned short*>(P.tab + P.o_tmask2);

@@ -225,6 +225,7 @@ struct MctsCtx {
     const EnvParams* P;
     const TabView* T;
     int bucket, precision, vmax, nact;
+    uint32_t bucket_magic;      // ceil(2^16 / bucket): x / bucket == (x * bucket_magic) >> 16 exactly for 0 <= x < 64 (frac(x / b) <= 1 - 1/64 < 1 - 64 / 65536)
     uint32_t key0, key1, c1, c2, draw;
     const short* dt_tab; const float* load_tab; const float* rad_tab; int nv;      // the move tables (the search kernel's copy in LDS)
     const unsigned long long* mask_tab; const unsigned char* order_tab;      // per table row: feasible actions (dt >= 0), the nact actions in rollout order
@@ -299,10 +300,13 @@ __device__ __forceinline__ float mc_max_speed(const MctsCtx& C, float radius, fl
     if (__builtin_isinf(v) || __builtin_isnan(v)) v = st.TopSpeed;
     return v < 0.0001f ? 0.0001f : (v > st.TopSpeed ? st.TopSpeed : v);
 }
+// section % L for the sections of a discrete game (0 <= section < 2^32 / L, hk_env_device.h mod_L): the run-time `%` was a ~30-instruction
+// integer division, and a ply asks five times
+__device__ __forceinline__ int mc_mod_L(const MctsCtx& C, int section) { return mod_L(*C.P, section); }
 __device__ __forceinline__ bool mc_straight(const MctsCtx& C, int section)
 {   // (asked several times per move: from the kernel's LDS copy, not the track table in global memory)
-    if (C.sec_flags) return (C.sec_flags[section % C.P->L] & 1) != 0;
-    return C.T->sec[section % C.P->L].inside_radius == 0.0f;
+    if (C.sec_flags) return (C.sec_flags[mc_mod_L(C, section)] & 1) != 0;
+    return C.T->sec[mc_mod_L(C, section)].inside_radius == 0.0f;
 }
 __device__ inline float mc_avgv(int minv, int maxv) { return (1.0f * (float)(minv + maxv)) / 2.0f; }
 
@@ -420,7 +424,10 @@ __device__ __forceinline__ int mc_up_next(const DGame& g)
     return best;
 }
 
-__device__ __forceinline__ int mc_vb(const MctsCtx& C, int minv) { return minv == 0 ? 0 : 1 + (minv - 6) / C.bucket; }
+__device__ __forceinline__ int mc_vb(const MctsCtx& C, int minv)
+{   // minv == 0 ? 0 : 1 + (minv - 6) / bucket, with minv in {0} u [6, max speed): the division by the magic number (MctsCtx::bucket_magic)
+    return minv == 0 ? 0 : 1 + (int)(((uint32_t)(minv - 6) * C.bucket_magic) >> 16);
+}
 
 // nextMoves KDG:318-411 for the player who is up next (np): a bit per canonical action.  An action is legal when (i) it exists and is
 // feasible from this row of the move tables (dt >= 0: a precomputed 20-bit mask per row), (ii) on a straight the lane change it needs
@@ -429,7 +436,7 @@ __device__ __forceinline__ int mc_vb(const MctsCtx& C, int minv) { return minv =
 __device__ __forceinline__ void mc_eval_moves(const MctsCtx& C, const DGame& g, int np, MoveEval& mv)
 {
     const DKart cur = mc_get(g, np);
-    const int L = C.P->L, sm = cur.section % L;
+    const int sm = mc_mod_L(C, cur.section);
     const bool str = mc_straight(C, cur.section);
     const float wear = (float)cur.tire / 10000.0f;
     const float* rp = C.rad_tab + (sm * 4 + (cur.lane - 1)) * 4;
@@ -445,9 +452,17 @@ __device__ __forceinline__ void mc_eval_moves(const MctsCtx& C, const DGame& g, 
     for (int l = 0; l < 4; l++) {
         const int dl = (l + 1) > cur.lane ? (l + 1) - cur.lane : cur.lane - (l + 1);
         if (!(str && cur.lchg + dl > C.P->max_lane_changes)) lanes |= 1u << l;
+    }
+    // (bucket-major with an early exit: a launch holds one gameParams class, so nvb is the same in every lane — 5 buckets at bucket size 2 — and
+    // the 9-bucket capacity used to cost 36 predicated compares per position)
 #pragma unroll
-        for (int vi = 0; vi < MC_MAXA / 4; vi++)
-            if (vi < nvb && !(vl[l] < (float)(6 + vi * C.bucket))) speed |= 1ull << (4 * vi + l);
+    for (int vi = 0; vi < MC_MAXA / 4; vi++) {
+        if (vi >= nvb) break;
+        const float th = (float)(6 + vi * C.bucket);
+        uint32_t nib = 0;
+#pragma unroll
+        for (int l = 0; l < 4; l++) nib |= (!(vl[l] < th) ? 1u : 0u) << l;
+        speed |= (unsigned long long)nib << (4 * vi);
     }
     m &= ((unsigned long long)lanes * 0x111111111ull) & speed;
     mv.legal = m; mv.n = __builtin_popcountll(m); mv.row = row;
@@ -457,7 +472,7 @@ __device__ __forceinline__ void mc_eval_moves(const MctsCtx& C, const DGame& g, 
 __device__ __forceinline__ void mc_make_move(const MctsCtx& C, DGame& g, int np, int a)
 {
     DKart k = mc_get(g, np);
-    const int L = C.P->L, sm = k.section % L;
+    const int sm = mc_mod_L(C, k.section);
     int minv, maxv, lane;
     mc_action(C, a, minv, maxv, lane);
     const int dl = lane > k.lane ? lane - k.lane : k.lane - lane;
@@ -579,6 +594,7 @@ __device__ inline void mc_ctx_init(MctsCtx& C, const EnvParams& P, const TabView
     C.nact = 0;
     for (int i = 6; i < C.vmax; i += C.bucket) C.nact += 4;
     if (C.nact > MC_MAXA) C.nact = MC_MAXA;                // (hk_create refuses such a list)
+    C.bucket_magic = (65536u + (uint32_t)C.bucket - 1u) / (uint32_t)C.bucket;
     C.sec_flags = nullptr; C.mask_tab = nullptr; C.order_tab = nullptr;
     C.dt_tab = nullptr; C.load_tab = M.load_tab; C.rad_tab = M.rad_tab; C.nv = M.nv;       // (the search kernel points these at its LDS copies)
     C.key0 = 0; C.key1 = 0; C.c1 = 0; C.c2 = 0; C.draw = 0;
