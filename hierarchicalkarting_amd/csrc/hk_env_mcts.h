@@ -220,6 +220,7 @@ struct MoveEval {
     int n;
     unsigned long long legal;
     int row;                    // table row of the position: (section % L, lane, velocity bucket) of the player who is up next
+    DKart cur;                  // that player's kart (mc_get: ~50 mask operations) — the move that follows is made from the same position
 };
 struct MctsCtx {
     const EnvParams* P;
@@ -465,13 +466,13 @@ __device__ __forceinline__ void mc_eval_moves(const MctsCtx& C, const DGame& g, 
         speed |= (unsigned long long)nib << (4 * vi);
     }
     m &= ((unsigned long long)lanes * 0x111111111ull) & speed;
-    mv.legal = m; mv.n = __builtin_popcountll(m); mv.row = row;
+    mv.legal = m; mv.n = __builtin_popcountll(m); mv.row = row; mv.cur = cur;
 }
 
 // makeMove KDG:416-443 on the running state (applyAction through the move tables)
-__device__ __forceinline__ void mc_make_move(const MctsCtx& C, DGame& g, int np, int a)
+// (k: player np's kart as mc_get(g, np) returns it — the caller has it from mc_eval_moves of the same position)
+__device__ __forceinline__ void mc_make_move(const MctsCtx& C, DGame& g, int np, int a, DKart k)
 {
-    DKart k = mc_get(g, np);
     const int sm = mc_mod_L(C, k.section);
     int minv, maxv, lane;
     mc_action(C, a, minv, maxv, lane);
@@ -492,6 +493,7 @@ __device__ __forceinline__ void mc_make_move(const MctsCtx& C, DGame& g, int np,
 #undef MC_AHEAD
     if (allAhead) g.last += 1;
 }
+__device__ __forceinline__ void mc_make_move(const MctsCtx& C, DGame& g, int np, int a) { mc_make_move(C, g, np, a, mc_get(g, np)); }
 
 // The move the rollout picks (KM:255-270): the index-th of the legal moves ordered by
 // OrderBy(time added).ThenByDescending(max_velocity).ThenBy(|lane change|).ThenBy(sign * lane), a stable sort.  Every key is a
@@ -505,7 +507,7 @@ __device__ __forceinline__ int mc_pick_move(const MctsCtx& C, const MoveEval& mv
     const int nw = C.nact >> 2;
 #pragma unroll
     for (int w = 0; w < MC_MAXA / 4; w++) {
-        if (w >= nw) break;                                  // (uniform: every search of a launch belongs to one gameParams class)
+        if (w >= nw || seen > index) break;                  // (nw is uniform: every search of a launch belongs to one gameParams class; the rollout's index is small — |N(0, n / 6)| — so most lanes are done after two words)
         const uint32_t four = ord[w];
 #pragma unroll
         for (int b = 0; b < 4; b++) {
@@ -821,7 +823,7 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
         mc_eval_moves(C, g, np, mv);
         while (cur.n_children > 0 && cur.n_children == mv.n) {
             { MNode pick; node = mc_ucs(C, nd, cur.first_child, cur.n_children, cur.numEpisodes, pick); cur = pick; }
-            mc_make_move(C, g, np, cur.action);
+            mc_make_move(C, g, np, cur.action, mv.cur);
             np = cur.upnext;
             depth++;
             path[depth * 64] = (unsigned short)node; pup[depth * 64] = cur.upnext;
@@ -845,7 +847,7 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
                     ch = n.next_sibling;
                 }
             }
-            mc_make_move(C, g, np, move);
+            mc_make_move(C, g, np, move, mv.cur);
             const int np2 = mc_up_next(g);
             if (c < 0) {
                 if (n_nodes >= M.pool_cap || depth + 1 >= MC_MAXPATH) { out_of_nodes = true; break; }
