@@ -44,6 +44,8 @@ struct PolicyParams {
     const float* mean;
     const float* std;
     const float* Wt[HK_POLICY_MAX_LAYERS];   // [k][hidden]
+    const float4* Wq[HK_POLICY_MAX_LAYERS];  // [k / 8][2][hidden] x {4 k-steps}: element (g, half, col)[j] = W[k = 8 g + 2 j + half][col] — the B operands of four consecutive
+                                             // MFMA k-steps of one lane as ONE 16-byte load (whole groups of 8 inputs only; the remainder reads Wt)
     const float* b[HK_POLICY_MAX_LAYERS];
     const float* W_mu;                       // [hidden]
     const float* b_mu;
@@ -97,49 +99,68 @@ __global__ __launch_bounds__(256) void policy_invalidate_kernel(PolicyParams Q, 
 
 
 // One wave's share of a layer over kc inputs: acc0 (+ acc1 when HAS1) += A[32 rows][kc] * B[kc][32 cols], as MFMA
-// 32x32x2 f32 steps in ascending k.  a?p / b?p already point at this lane's first element (A from LDS, row stride PM_LD
-// per k; B from global, row stride H per k); SAMEB: both blocks use the same B columns (H = 256).
-// 8 k-steps (16 inputs) per trip with ping-pong operand sets: while the 8 / 16 MFMAs of one trip issue, the loads of the
-// next trip are in flight; then the remainder (kc % 16 inputs) one k-step at a time.
+// 32x32x2 f32 steps in ascending k.  a?p already point at this lane's first element of A (LDS, row stride PM_LD per k); B comes from
+// global memory (L2): whole groups of 8 inputs (4 k-steps) through q?p — this lane's float4 of the group-major copy Wq, 2 * H float4 per
+// group — the remainder (kc % 8 inputs) through b?p (Wt, row stride H per k), one k-step at a time.  SAMEB: both blocks use the same B
+// columns (H = 256).
+// Pipeline (round 5): the B loads run THREE groups ahead of the MFMAs that use them (four register sets), the A reads one group ahead
+// (two sets).  With the loads one group ahead only — 8 MFMAs = 512 matrix-pipe cycles, ~2 000 with four waves taking turns — a weight
+// load's ~1.5 us from L2 under load was not covered and the pipe sat at 62 % (SQ_VALU_MFMA_BUSY_CYCLES) whatever the other workgroup
+// of the CU was doing (a start stagger of the two workgroups of a CU changed nothing — f32 MFMAs and vector instructions do not
+// co-execute on gfx950, hk_swish.h — see profiles/r05_i_actor.txt).
 template <bool HAS1, bool SAMEB>
 __device__ __forceinline__ void pm_gemm(f32x16& acc0, f32x16& acc1, const float* a0p, const float* a1p,
-                                        const float* __restrict__ b0p, const float* __restrict__ b1p, int kc, int H)
+                                        const float* __restrict__ b0p, const float* __restrict__ b1p,
+                                        const float4* __restrict__ q0p, const float4* __restrict__ q1p, int kc, int H)
 {
-    auto ld = [&](int k0, float (&B0)[PM_TRIP], float (&B1)[PM_TRIP], float (&A0)[PM_TRIP], float (&A1)[PM_TRIP]) {
+    const int ng = kc >> 3;
+    const size_t qs = (size_t)2 * H;                     // float4 per group
+    auto ldB = [&](int g, float4& x0, float4& x1) {
+        x0 = q0p[(size_t)g * qs];
+        if (HAS1 && !SAMEB) x1 = q1p[(size_t)g * qs];
+    };
+    auto ldA = [&](int g, float (&x0)[4], float (&x1)[4]) {
 #pragma unroll
-        for (int j = 0; j < PM_TRIP; j++) {
-            B0[j] = b0p[(size_t)(k0 + 2 * j) * H];
-            A0[j] = a0p[(size_t)(k0 + 2 * j) * PM_LD];
-            if (HAS1) {
-                A1[j] = a1p[(size_t)(k0 + 2 * j) * PM_LD];
-                if (!SAMEB) B1[j] = b1p[(size_t)(k0 + 2 * j) * H];
-            }
+        for (int j = 0; j < 4; j++) {
+            x0[j] = a0p[(size_t)(8 * g + 2 * j) * PM_LD];
+            if (HAS1) x1[j] = a1p[(size_t)(8 * g + 2 * j) * PM_LD];
         }
     };
-    auto mm = [&](float (&B0)[PM_TRIP], float (&B1)[PM_TRIP], float (&A0)[PM_TRIP], float (&A1)[PM_TRIP]) {
+    auto mm = [&](const float4& y0, const float4& y1, const float (&x0)[4], const float (&x1)[4]) {
+        const float b0v[4] = {y0.x, y0.y, y0.z, y0.w};
+        const float b1v[4] = {y1.x, y1.y, y1.z, y1.w};
 #pragma unroll
-        for (int j = 0; j < PM_TRIP; j++) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[j], B0[j], acc0, 0, 0, 0);
-            if (HAS1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[j], SAMEB ? B0[j] : B1[j], acc1, 0, 0, 0);
+        for (int j = 0; j < 4; j++) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[j], b0v[j], acc0, 0, 0, 0);
+            if (HAS1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[j], SAMEB ? b0v[j] : b1v[j], acc1, 0, 0, 0);
         }
     };
-    const int kfull = kc - kc % (2 * PM_TRIP);
-    if (kfull > 0) {
-        float pB0[PM_TRIP], pB1[PM_TRIP], pA0[PM_TRIP], pA1[PM_TRIP], qB0[PM_TRIP], qB1[PM_TRIP], qA0[PM_TRIP], qA1[PM_TRIP];
-        ld(0, pB0, pB1, pA0, pA1);
-        int k0 = 0;
-        while (true) {
-            if (k0 + 2 * PM_TRIP < kfull) ld(k0 + 2 * PM_TRIP, qB0, qB1, qA0, qA1);
-            mm(pB0, pB1, pA0, pA1);
-            k0 += 2 * PM_TRIP;
-            if (k0 >= kfull) break;
-            if (k0 + 2 * PM_TRIP < kfull) ld(k0 + 2 * PM_TRIP, pB0, pB1, pA0, pA1);
-            mm(qB0, qB1, qA0, qA1);
-            k0 += 2 * PM_TRIP;
-            if (k0 >= kfull) break;
+    if (ng > 0) {
+        float4 B0a, B0b, B0c, B0d, B1a = {}, B1b = {}, B1c = {}, B1d = {};
+        float A0p[4], A1p[4] = {}, A0q[4], A1q[4] = {};
+        ldB(0, B0a, B1a);
+        if (ng > 1) ldB(1, B0b, B1b);
+        if (ng > 2) ldB(2, B0c, B1c);
+        ldA(0, A0p, A1p);
+        for (int g = 0; g < ng; g += 4) {
+            if (g + 3 < ng) ldB(g + 3, B0d, B1d);
+            if (g + 1 < ng) ldA(g + 1, A0q, A1q);
+            mm(B0a, B1a, A0p, A1p);
+            if (g + 1 >= ng) break;
+            if (g + 4 < ng) ldB(g + 4, B0a, B1a);
+            if (g + 2 < ng) ldA(g + 2, A0p, A1p);
+            mm(B0b, B1b, A0q, A1q);
+            if (g + 2 >= ng) break;
+            if (g + 5 < ng) ldB(g + 5, B0b, B1b);
+            if (g + 3 < ng) ldA(g + 3, A0q, A1q);
+            mm(B0c, B1c, A0p, A1p);
+            if (g + 3 >= ng) break;
+            if (g + 6 < ng) ldB(g + 6, B0c, B1c);
+            if (g + 4 < ng) ldA(g + 4, A0p, A1p);
+            mm(B0d, B1d, A0q, A1q);
         }
     }
-    for (int k0 = kfull; k0 < kc; k0 += 2) {
+    for (int k0 = ng * 8; k0 < kc; k0 += 2) {
         const float bv0 = b0p[(size_t)k0 * H];
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0p[(size_t)k0 * PM_LD], bv0, acc0, 0, 0, 0);
         if (HAS1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1p[(size_t)k0 * PM_LD], SAMEB ? bv0 : b1p[(size_t)k0 * H], acc1, 0, 0, 0);
@@ -229,11 +250,14 @@ __global__ __launch_bounds__(PM_THREADS, 4) void policy_mlp_kernel(PolicyParams 
                 const float* __restrict__ Wt = Q.Wt[l] + (size_t)kb * H;
                 const float* b0p = Wt + (size_t)half * H + cb0 * 32 + c;
                 const float* b1p = Wt + (size_t)half * H + cb1 * 32 + c;
-                if (MODE == 0) pm_gemm<false, false>(acc0, acc1, a0p, a1p, b0p, b1p, kc, H);
-                else if (MODE == 1) pm_gemm<true, true>(acc0, acc1, a0p, a1p, b0p, b1p, kc, H);
-                else if (!has1) pm_gemm<false, false>(acc0, acc1, a0p, a1p, b0p, b1p, kc, H);
-                else if (cb1 == cb0) pm_gemm<true, true>(acc0, acc1, a0p, a1p, b0p, b1p, kc, H);
-                else pm_gemm<true, false>(acc0, acc1, a0p, a1p, b0p, b1p, kc, H);
+                const float4* __restrict__ Wq = Q.Wq[l] + (size_t)(kb >> 3) * 2 * H;          // (kb is a multiple of 8: policy_upload)
+                const float4* q0p = Wq + (size_t)half * H + cb0 * 32 + c;
+                const float4* q1p = Wq + (size_t)half * H + cb1 * 32 + c;
+                if (MODE == 0) pm_gemm<false, false>(acc0, acc1, a0p, a1p, b0p, b1p, q0p, q1p, kc, H);
+                else if (MODE == 1) pm_gemm<true, true>(acc0, acc1, a0p, a1p, b0p, b1p, q0p, q1p, kc, H);
+                else if (!has1) pm_gemm<false, false>(acc0, acc1, a0p, a1p, b0p, b1p, q0p, q1p, kc, H);
+                else if (cb1 == cb0) pm_gemm<true, true>(acc0, acc1, a0p, a1p, b0p, b1p, q0p, q1p, kc, H);
+                else pm_gemm<true, false>(acc0, acc1, a0p, a1p, b0p, b1p, q0p, q1p, kc, H);
             }
         }
         if (has0) {
@@ -329,7 +353,8 @@ inline int policy_upload(PolicyDevice& pd, const hk_policy_desc* d, int index, i
     const int H = d->hidden, K0 = d->in_dim;
     std::vector<float> host;
     auto put = [&](const float* src, size_t n) { size_t off = host.size(); host.insert(host.end(), src, src + n); return off; };
-    size_t o_mean = 0, o_std = 0, o_W[HK_POLICY_MAX_LAYERS], o_b[HK_POLICY_MAX_LAYERS];
+    size_t o_mean = 0, o_std = 0, o_W[HK_POLICY_MAX_LAYERS], o_b[HK_POLICY_MAX_LAYERS], o_Wq[HK_POLICY_MAX_LAYERS];
+    while (host.size() % 4) host.push_back(0.0f);        // (everything below keeps the float4 copies 16-byte aligned: see o_Wq)
     if (d->normalize) { o_mean = put(d->norm_mean, K0); o_std = put(d->norm_std, K0); }
     for (int l = 0; l < d->n_layers; l++) {
         const int K = l == 0 ? K0 : H;
@@ -339,6 +364,17 @@ inline int policy_upload(PolicyDevice& pd, const hk_policy_desc* d, int index, i
         for (int j = 0; j < H; j++)
             for (int k = 0; k < K; k++) wt[(size_t)k * H + j] = d->W[l][(size_t)j * K + k];
         o_b[l] = put(d->b[l], H);
+        // the group-major copy (PolicyParams::Wq): whole groups of 8 inputs
+        while (host.size() % 4) host.push_back(0.0f);
+        o_Wq[l] = host.size();
+        const int ngr = K / 8;
+        host.resize(host.size() + (size_t)ngr * 2 * H * 4);
+        float* wq = host.data() + o_Wq[l];
+        const float* wt2 = host.data() + o_W[l];
+        for (int g = 0; g < ngr; g++)
+            for (int hf = 0; hf < 2; hf++)
+                for (int j = 0; j < H; j++)
+                    for (int q4 = 0; q4 < 4; q4++) wq[(((size_t)g * 2 + hf) * H + j) * 4 + q4] = wt2[(size_t)(8 * g + 2 * q4 + hf) * H + j];
     }
     const size_t o_wmu = put(d->W_mu, H), o_bmu = put(d->b_mu, 1), o_ls = put(d->log_sigma, 1);
     const size_t o_wbr = put(d->W_branch, (size_t)d->n_branch * H), o_bbr = put(d->b_branch, d->n_branch);
@@ -355,7 +391,8 @@ inline int policy_upload(PolicyDevice& pd, const hk_policy_desc* d, int index, i
     {   // equal even chunks of at most PM_KC_MAX inputs
         const int nch = (K0 + PM_KC_MAX - 1) / PM_KC_MAX;
         q.kc = (K0 + nch - 1) / nch;
-        q.kc += q.kc & 1;
+        q.kc = (q.kc + 7) & ~7;      // whole groups of 8 inputs per chunk (the float4 weight copy is read from group kb / 8 on)
+        if (q.kc > PM_KC_MAX) q.kc = PM_KC_MAX;
         if (q.kc < H) q.kc = H;      // later layers run as one chunk of `hidden`
     }
     q.n_slots = n_slots;
@@ -364,6 +401,7 @@ inline int policy_upload(PolicyDevice& pd, const hk_policy_desc* d, int index, i
     q.std = d->normalize ? pd.weights + o_std : nullptr;
     for (int l = 0; l < HK_POLICY_MAX_LAYERS; l++) {
         q.Wt[l] = l < d->n_layers ? pd.weights + o_W[l] : nullptr;
+        q.Wq[l] = l < d->n_layers ? reinterpret_cast<const float4*>(pd.weights + o_Wq[l]) : nullptr;
         q.b[l] = l < d->n_layers ? pd.weights + o_b[l] : nullptr;
     }
     q.W_mu = pd.weights + o_wmu; q.b_mu = pd.weights + o_bmu; q.log_sigma = pd.weights + o_ls;
