@@ -172,9 +172,10 @@ __device__ __forceinline__ void pm_gemm(f32x16& acc0, f32x16& acc1, const float*
 // (w = stack - 1 for plain oldest-first rows).  Outputs: mu_out / logit_out when non-null; act_steer / act_branch
 // (indexed [env][agent], row = env * n_slots + j) when non-null.
 // MODE: how the (H / 32) x 2 blocks of a layer fall on the 8 waves — 0: one block per wave (H <= 128), 1: two blocks per
-// wave sharing their B columns (H = 256), 2: mixed (other H), decided per wave.
+// wave sharing their B columns (H = 256), 2: mixed (other H), decided per wave — three inlined forms of the gemm: held to two waves per SIMD
+// instead of four (at 128 registers it spills 85), i.e. one workgroup per CU.
 template <int MODE>
-__global__ __launch_bounds__(PM_THREADS, 4) void policy_mlp_kernel(PolicyParams Q, int rows, const float* src, int w,
+__global__ __launch_bounds__(PM_THREADS, MODE == 2 ? 2 : 4) void policy_mlp_kernel(PolicyParams Q, int rows, const float* src, int w,
                                                                    unsigned long long decision, int env_id_base, int A,
                                                                    float* mu_out, float* logit_out, float* act_steer, int* act_branch)
 {
