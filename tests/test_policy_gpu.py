@@ -26,6 +26,9 @@ def _pair(E, A, low, **kw):
     (2, 4, 64, 1, 64, False),
     (2, 4, 192, 2, 1, True),
     (2, 4, 32, 4, 65, True),
+    (4, 1, 256, 2, 100, True),       # 78 inputs: 9 whole groups of 8 (the float4 weight copy) + 6 through the per-k-step remainder
+    (4, 7, 256, 2, 70, True),        # 546 inputs: three chunks of 184 / 184 / 178 (22 groups + 2)
+    (2, 3, 96, 2, 50, False),        # 162 inputs, 3 column blocks on 8 waves
 ])
 def test_actor_bit_exact(A, stack, hidden, layers, rows, normalize):
     g, o = _pair(2, A, [_lib.HK_LOW_RL] * A)
