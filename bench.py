@@ -57,16 +57,37 @@ def pmc_fields(kernel, env_steps_per_launch=None):
     sq = (k.get("sq") or {}).get("derived")
     binding = None
     if sq:
-        binding = {"resource": "neither roof: vector-instruction issue (%d waves per SIMD share one issue slot per four cycles) and the waits the resident waves cannot cover (profiles/r05_a_backend_flags.txt)" % d.get("waves_per_simd", 2), "wave_issuing_valu_frac": sq.get("wave_issuing_valu_frac"), "wave_issuing_any_frac": sq.get("wave_issuing_any_frac"),
-                   "wave_waiting_frac": sq.get("wave_waiting_frac"), "waves_per_simd": d.get("waves_per_simd", 2),
-                   "simd_valu_busy_frac": min(1.0, d.get("waves_per_simd", 2) * (sq.get("wave_issuing_valu_frac") or 0.0)),
+        # (the PMC passes run every launch ALONE on the GPU — rocprofv3 serialises dispatches while it collects counters — i.e. a half-batch launch with
+        # its two waves per SIMD; in the product schedule two streams' launches share the SIMDs, up to `waves_per_simd` resident: see valu_port_use_over_wall,
+        # which main() adds from this run's own wall time)
+        alone = 2.0
+        binding = {"resource": "neither roof: vector-instruction issue and the waits / dependent-launch gaps the resident waves do not cover (profiles/r05_a_backend_flags.txt, DESIGN.md section 2)",
+                   "wave_issuing_valu_frac": sq.get("wave_issuing_valu_frac"), "wave_issuing_any_frac": sq.get("wave_issuing_any_frac"),
+                   "wave_waiting_frac": sq.get("wave_waiting_frac"), "waves_per_simd_limit": d.get("waves_per_simd", 2),
+                   "simd_valu_busy_frac_launch_alone": min(1.0, alone * (sq.get("wave_issuing_valu_frac") or 0.0)),
                    "valu_lanes_active_of_64": sq.get("valu_lanes_active_of_64"), "valu_insts_per_launch": sq.get("valu_insts_per_launch"),
-                   "source": "SQ counters of the same PMC summary (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave, times the waves that share a SIMD)"}
+                   "source": "SQ counters of the same PMC summary (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES per wave; a launch alone on the GPU = 2 048 waves on 1 024 SIMDs)"}
     traffic = k.get("hbm_bytes_per_launch")
     if traffic is not None and env_steps_per_launch and d.get("env_steps_per_launch"):
         prov["measured_bytes_per_env_step"] = traffic / d["env_steps_per_launch"]
         traffic = traffic * env_steps_per_launch / d["env_steps_per_launch"]
     return traffic, prov, binding
+
+
+def valu_port_use(tick_launches, wall_s):
+    """Share of the SIMDs' vector-issue slots the timed region used: (vector instructions of a tick + B1 + solver launch set of the committed PMC summary,
+    four cycles each on a SIMD) x this run's launch sets / (1 024 SIMDs x this run's wall time at the peak clock).  An instruction count does not depend on
+    what else is resident, so this holds for the two-stream schedule although the counters were taken launch by launch."""
+    try:
+        d = json.load(open(PMC_SUMMARY))
+        quad = sum(float(d[k]["sq"]["SQ_ACTIVE_INST_VALU"]) for k in ("env_run_kernel", "env_b1_kernel", "lqn_round_kernel"))
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
+    if wall_s <= 0:
+        return None
+    simds, clock_hz = 1024, 2.4e9
+    return {"frac": quad * 4.0 * tick_launches / (simds * clock_hz * wall_s), "valu_busy_quad_cycles_per_launch_set": quad, "simds": simds, "clock_ghz": clock_hz / 1e9,
+            "note": "SQ_ACTIVE_INST_VALU (units of four cycles) of tick + B1 + solver launch, x launch sets of the timed region, / (SIMDs x wall cycles at the peak clock); the rest of the slots: waits no resident wave covers, the gaps between the three dependent launches of a round, ramp and tail of every launch"}
 
 
 def cadence_traffic(env_steps_per_tick_launch):
@@ -575,6 +596,10 @@ def bench_lqng(a, D, hk):
             cad = cadence_traffic(float(E) * a.steps / dom_n)
             if cad:
                 roof["traffic_whole_cadence"] = cad
+            if binding:
+                vp = valu_port_use(dom_n, dt)
+                if vp:
+                    binding["valu_port_use_over_wall"] = vp
             if env.split_for(a.steps):
                 # the default schedule of a long call runs the batch as two halves on two streams: two tick launches share the GPU, a launch's
                 # duration is no longer the kernel's own — the fraction of the roof is the whole job's (every kernel + the gaps), the per-launch
