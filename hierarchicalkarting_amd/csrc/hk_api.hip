@@ -645,7 +645,20 @@ static int step_ticks(hk_handle h, int n_ticks)
             // requests, and the handle's stream waits for them only before the rounds that could reach the deadline.  A wrong guess costs the overlap,
             // nothing else: every stretch still ends with a search launch for whatever is queued, and no env passes its deadline unserved (device side).
             const int lat = std::min(h->cfg.mcts_latency_ticks, h->cfg.mcts_initial_latency_ticks);
-            { const char* sw = std::getenv("HK_MCTS_SIDE_WAVES"); if (sw) h->dev.mcts_side_waves = std::atoi(sw) == 4 ? 4 : (std::atoi(sw) == 0 ? 0 : 8); }
+            {
+                // Search workgroups beside the ticks: 4 waves (one per SIMD) on EVERY CU when a tick block still fits a CU's LDS beside one — the searches then run
+                // a wave to a SIMD (~7 ms instead of ~10.6 at two waves per SIMD on half the CUs); phase B1 reads its tables from global memory and the solver
+                // launch takes its <= 256-register form for those rounds (b1_small; hk_env_launch.h).  Otherwise 8 waves on half the CUs (round 5's first form).
+                int sw = 4;
+                for (int c = 0; c < h->dev.n_mcls; c++) {
+                    const auto& K = h->dev.mcls[c];
+                    if (hk::ga_ops(h->dev).mcts_lds_bytes(K.ntab, h->dev.P.L, K.na, K.lds_tier, 4) + (size_t)h->dev.tab_lds + 1024 > 160 * 1024) sw = 8;
+                }
+                if (!h->dev.tab_lds) sw = 8;
+                const char* e = std::getenv("HK_MCTS_SIDE_WAVES");
+                if (e) sw = std::atoi(e) == 4 ? 4 : (std::atoi(e) == 0 ? 0 : 8);
+                h->dev.mcts_side_waves = sw;
+            }
             const bool overlap = h->tune.mcts_overlap && h->dev.fission && cadence == 4 && lat >= 24;
             int r_post = -1, r_free = 0;
             if (overlap) {
@@ -668,7 +681,9 @@ static int step_ticks(hk_handle h, int n_ticks)
                 if (rc) { g_last_error = h->err; return rc; }
                 HK_HIP(h, hipEventRecord(h->ev_mcts_done, h->mcts_stream));
                 const int r2 = std::min(stretch_rounds - r_post, r_free);
+                h->dev.b1_small = h->dev.mcts_side_waves == 4;      // (4-wave search workgroups sit on EVERY CU: what runs beside them must share its LDS and registers)
                 rc = issue_rounds(h, r2);
+                h->dev.b1_small = false;
                 if (rc) return rc;
                 HK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_mcts_done, 0));
                 rc = issue_rounds(h, stretch_rounds - r_post - r2);
@@ -777,6 +792,7 @@ static int step_ticks(hk_handle h, int n_ticks)
         if (!h->ev_mcts_done) HK_HIP(h, hipEventCreateWithFlags(&h->ev_mcts_done, hipEventDisableTiming));
         HK_HIP(h, hipEventRecord(h->ev_mcts_go, h->stream));
         HK_HIP(h, hipStreamWaitEvent(h->mcts_stream, h->ev_mcts_go, 0));
+        { const char* e = std::getenv("HK_MCTS_SIDE_WAVES"); h->dev.mcts_side_waves = e ? (std::atoi(e) == 4 ? 4 : (std::atoi(e) == 0 ? 0 : 8)) : 8; }      // (decision chunks: 8-wave workgroups on half the CUs)
         rc = hk::env_flush_mcts_on(h->dev, h->stream, h->mcts_stream, h->err);
         if (rc) { g_last_error = h->err; return rc; }
         HK_HIP(h, hipEventRecord(h->ev_mcts_done, h->mcts_stream));

@@ -168,7 +168,9 @@ inline int launch_b1(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std
     const unsigned blocks = (unsigned)((threads + 255) / 256);
 #define HK_FIS_B1(TL, MC) hipLaunchKernelGGL((env_b1_kernel<TL, MC>), dim3(blocks), dim3(256), TL ? d.P.o_tmask : 0, stream, d.P, d.agents, d.hot, d.envs, G, d.queue_cnt, d.queue, \
                            d.round, d.lq_debug, d.status, d.mcts, d.perm, d.game_stats, s0, s1, d.qbase, d.mset)
-    if (d.mcts.st) { if (d.tab_lds) HK_FIS_B1(true, true); else HK_FIS_B1(false, true); }
+    // (b1_small: beside a search launch whose 4-wave workgroups hold 108.8 KB of EVERY CU's LDS, a B1 block with its 44.5 KB copy of the Complex-track tables
+    // — 67 KB with the KartS staging — does not fit; the instantiation that reads the tables through L1 / L2 needs the 22.8 KB of staging only)
+    if (d.mcts.st) { if (d.tab_lds && !d.b1_small) HK_FIS_B1(true, true); else HK_FIS_B1(false, true); }
     else { if (d.tab_lds) HK_FIS_B1(true, false); else HK_FIS_B1(false, false); }
 #undef HK_FIS_B1
     return launch_check(err, "env_b1_kernel");
@@ -209,6 +211,10 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
         const int per = bulk ? 1024 : d.lqn_sparse_blocks;
         const int n34 = sizes ? std::min(ngames, per) * sizes : 0;          // `per` waves per game size walk their queue grid-stride; the queue length picks the solver (lqn_round_kernel)
         const int n2 = std::min((ngames + 31) / 32, bulk ? 4096 : per);
+        if (d.b1_small)     // beside a search launch (hk_lq2_pair.h: SMALL)
+            hipLaunchKernelGGL(lqn_round_small_kernel, dim3(n34 + n2), dim3(64), lqn_round_small_lds(), stream, d.P, HotRef{d.hot, d.slot_of}, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status,
+                               n34, sizes ? sizes : 1, n2, d.game_stats, LQN_BULK_GAMES);
+        else
         hipLaunchKernelGGL(lqn_round_kernel, dim3(n34 + n2), dim3(64), 0, stream, d.P, HotRef{d.hot, d.slot_of}, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status,
                            n34, sizes ? sizes : 1, n2, d.game_stats, LQN_BULK_GAMES);
         if ((rc = launch_check(err, "lqn_round_kernel"))) return rc;

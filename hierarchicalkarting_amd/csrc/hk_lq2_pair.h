@@ -364,28 +364,61 @@ __device__ __forceinline__ void lq2_pair_body(const int block, const int nblocks
 // n34 / sizes blocks per size; first in the grid: they are the long ones), blocks [n34, n34 + n2) the 2-player queue (pairs of
 // lanes).  Both bodies run one wave per SIMD (458 registers / 40 KB of LDS), so they share a kernel at no cost — and in a spread
 // field, where a round holds a handful of games of each kind, their latencies overlap instead of adding up.
-__global__ __launch_bounds__(64) void lqn_round_kernel(EnvParams P, const HotRef hr, const GameSoA games, const int* queue_cnt,
-                                                       const int* queue, hk_lq_debug* dbg_out, int* status, int n34, int sizes, int n2,
-                                                       unsigned long long* gstats, int bulk34)
+// SMALL: the form that runs BESIDE a planner's search launch (round 5).  A search wave holds 232 of a SIMD's 512 registers on every CU for ~7 ms; the
+// one-game-per-wave matrix-core solver needs a SIMD's whole register file and would wait for the search to end.  This instantiation solves the 3- / 4-player
+// queues on the lane-per-row core whatever their length (the same arithmetic by contract: hk_lq_core.h) and is held to two waves per SIMD (amdgpu_waves_per_eu 2).
+constexpr size_t lqn_round_small_lds()
+{
+    constexpr size_t B2 = (sizeof(LqGameLds<2>) + sizeof(CostRows<2>)) * LqDims<2>::SLOTS, B3 = (sizeof(LqGameLds<3>) + sizeof(CostRows<3>)) * LqDims<3>::SLOTS,
+                     B4 = (sizeof(LqGameLds<4>) + sizeof(CostRows<4>)) * LqDims<4>::SLOTS;
+    return (B2 > B3 ? (B2 > B4 ? B2 : B4) : (B3 > B4 ? B3 : B4));
+}
+template <bool SMALL>
+__device__ __forceinline__ void lqn_round_body(const EnvParams& P, const HotRef hr, const GameSoA games, const int* queue_cnt,
+                                               const int* queue, hk_lq_debug* dbg_out, int* status, int n34, int sizes, int n2,
+                                               unsigned long long* gstats, int bulk34)
 {
     constexpr size_t B3a = sizeof(LqMfmaLds<3>) + sizeof(CostRows<3>), B3b = (sizeof(LqGameLds<3>) + sizeof(CostRows<3>)) * LqDims<3>::SLOTS;
     constexpr size_t B4a = sizeof(LqMfmaLds<4>) + sizeof(CostRows<4>), B4b = (sizeof(LqGameLds<4>) + sizeof(CostRows<4>)) * LqDims<4>::SLOTS;
     constexpr size_t B3 = B3a > B3b ? B3a : B3b, B4 = B4a > B4b ? B4a : B4b;
     constexpr size_t B34 = B3 > B4 ? B3 : B4;
-    constexpr size_t BMAX = B34 > sizeof(Lq2PairLds) ? B34 : sizeof(Lq2PairLds);
-    __shared__ __align__(16) unsigned char smem[BMAX];
+    constexpr size_t B2 = (sizeof(LqGameLds<2>) + sizeof(CostRows<2>)) * LqDims<2>::SLOTS;
+    constexpr size_t BP = SMALL ? B2 : sizeof(Lq2PairLds);
+    constexpr size_t B34s = SMALL ? (B3b > B4b ? B3b : B4b) : B34;
+    constexpr size_t BMAX = B34s > BP ? B34s : BP;
+    // (SMALL: dynamic LDS of lqn_round_small_lds() bytes — with the size in the kernel's own metadata the back end derives one wave per SIMD from it and hands
+    // the kernel the whole register file whatever amdgpu_waves_per_eu says)
+    __shared__ __align__(16) unsigned char smem_static[SMALL ? 16 : BMAX];
+    HK_DYN_SHARED(smem_dyn);
+    unsigned char* smem = SMALL ? smem_dyn : smem_static;
     const int b = blockIdx.x;
-    if (b >= n34) { lq2_pair_body(b - n34, n2, P, hr, games, queue_cnt, queue, dbg_out, status, *reinterpret_cast<Lq2PairLds*>(smem), gstats); return; }
+    if (b >= n34) {
+        // (SMALL: the pair solver keeps a game in ~450 registers; beside a search wave the 2-player queue goes to the lane-per-row core too, 8 games a wave)
+        if constexpr (SMALL) lqn_body<2, false>(b - n34, n2, P, hr, games, queue_cnt, queue, dbg_out, status, smem, gstats);
+        else lq2_pair_body(b - n34, n2, P, hr, games, queue_cnt, queue, dbg_out, status, *reinterpret_cast<Lq2PairLds*>(smem), gstats);
+        return;
+    }
     const int per = n34 / sizes, which = b / per, bb = b - which * per;
     // Which solver?  The queue length decides, on the device: a round that holds a handful of games (a spread field) wants the shortest
     // latency — one game per wave; one that holds thousands (the race start, packs) wants 64 / n games per instruction of the m x m solve.
     const int cnt = queue_cnt[which == 0 ? 3 : 4];
-    if (cnt > bulk34) {
+    if (SMALL || cnt > bulk34) {
         if (which == 0) lqn_body<3, true>(bb, per, P, hr, games, queue_cnt, queue, dbg_out, status, smem, gstats);
         else lqn_body<4, true>(bb, per, P, hr, games, queue_cnt, queue, dbg_out, status, smem, gstats);
-    } else {
+    } else if constexpr (!SMALL) {
         if (which == 0) lqn_body_mfma<3>(bb, per, P, hr, games, queue_cnt, queue, dbg_out, status, smem, gstats);
         else lqn_body_mfma<4>(bb, per, P, hr, games, queue_cnt, queue, dbg_out, status, smem, gstats);
     }
+}
+__global__ __launch_bounds__(64) void lqn_round_kernel(EnvParams P, const HotRef hr, const GameSoA games, const int* queue_cnt, const int* queue, hk_lq_debug* dbg_out,
+                                                       int* status, int n34, int sizes, int n2, unsigned long long* gstats, int bulk34)
+{
+    lqn_round_body<false>(P, hr, games, queue_cnt, queue, dbg_out, status, n34, sizes, n2, gstats, bulk34);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void lqn_round_small_kernel(EnvParams P, const HotRef hr, const GameSoA games, const int* queue_cnt,
+                                                                                                   const int* queue, hk_lq_debug* dbg_out, int* status, int n34, int sizes, int n2,
+                                                                                                   unsigned long long* gstats, int bulk34)
+{
+    lqn_round_body<true>(P, hr, games, queue_cnt, queue, dbg_out, status, n34, sizes, n2, gstats, bulk34);
 }
 #endif
