@@ -79,6 +79,10 @@ CASES += [("rewards", "shaped_fused"), ("planner_rw", "shaped_fused"), ("trainin
 MODES.update({"shaped_fused": {"HK_NO_FISSION_SHAPED": "1"}})
 MODES.update({"park": {"HK_PARK": "1"}, "park_split": {"HK_PARK": "1", "HK_SPLIT": "1"}, "park_tab_global": {"HK_PARK": "1", "HK_TAB_GLOBAL": "1"},
               "no_overlap": {"HK_MCTS_NO_OVERLAP": "1"}})
+# the searches beside the ticks in 8-wave workgroups on half the CUs (the default is 4 waves on every CU wherever a tick block fits beside one, with phase B1 on
+# its global-table instantiation and lqn_round_small_kernel for those rounds): both forms of the side launch stay reachable
+CASES += [("planner", "side8"), ("planner_rw", "side8")]
+MODES.update({"side8": {"HK_MCTS_SIDE_WAVES": "8"}})
 MODES.update({"split": {"HK_SPLIT": "1"}, "no_pause": {"HK_MCTS_NO_PAUSE": "1"}, "fused": {"HK_FISSION": "0"}, "fused_split": {"HK_FISSION": "0", "HK_SPLIT": "1"},
               "fused_tab_global": {"HK_FISSION": "0", "HK_TAB_GLOBAL": "1"}})
 
