@@ -35,7 +35,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32-input MFMA = t
 STEADY_TICK = 512                      # steady state = ticks 512 .. 3584
 # HBM bytes and SQ counters cannot be read in-process: they come from the separate rocprofv3 --pmc passes of THIS command that
 # tools/pmc_summary.py folded into this file (committed with the profile it belongs to; `commit` / `command` inside say which)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r06_pmc_summary.json")
+PMC_CADENCE_KERNELS = ("env_run_kernel", "env_b1_kernel", "lqn_round_kernel", "lqn_spread_kernel")      # the launches of a solve cadence (whichever the summary holds)
 
 
 def pmc_fields(kernel, env_steps_per_launch=None):
@@ -80,7 +81,11 @@ def valu_port_use(tick_launches, wall_s):
     what else is resident, so this holds for the two-stream schedule although the counters were taken launch by launch."""
     try:
         d = json.load(open(PMC_SUMMARY))
-        quad = sum(float(d[k]["sq"]["SQ_ACTIVE_INST_VALU"]) for k in ("env_run_kernel", "env_b1_kernel", "lqn_round_kernel"))
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from source_hash import source_hash
+        if d.get("sources_sha16") != source_hash():
+            return None          # the kernels changed after the counters were taken: no stale instruction counts in the line
+        quad = sum(float(d[k]["sq"]["SQ_ACTIVE_INST_VALU"]) for k in PMC_CADENCE_KERNELS if k in d)
     except (OSError, ValueError, KeyError, TypeError):
         return None
     if wall_s <= 0:
@@ -101,7 +106,7 @@ def cadence_traffic(env_steps_per_tick_launch):
     from source_hash import source_hash
     if d.get("sources_sha16") != source_hash() or not d.get("env_steps_per_launch"):
         return None
-    parts = {k: (d.get(k) or {}).get("hbm_bytes_per_launch") for k in ("env_run_kernel", "env_b1_kernel", "lqn_round_kernel")}
+    parts = {k: (d.get(k) or {}).get("hbm_bytes_per_launch") for k in PMC_CADENCE_KERNELS if k in d}
     if parts["env_run_kernel"] is None:
         return None
     scale = env_steps_per_tick_launch / d["env_steps_per_launch"]
@@ -178,6 +183,19 @@ class Dist:
         if env is not None:
             env.synchronize()
 
+    def sync_device(self):
+        if self.backend == "nccl" or self.torch.cuda.is_initialized():
+            self.torch.cuda.synchronize()
+
+    def all_times(self, dt):
+        """every rank's value of dt, rank order"""
+        if not self.dist:
+            return [dt]
+        t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev)
+        out = [self.torch.zeros(1, dtype=self.torch.float64, device=self.dev) for _ in range(self.dist.get_world_size())]
+        self.dist.all_gather(out, t)
+        return [float(x.item()) for x in out]
+
     def max_time(self, dt):
         if not self.dist:
             return dt
@@ -191,14 +209,22 @@ class Dist:
             self.dist.destroy_process_group()
 
 
-def timed_ticks(D, env, ticks):
-    """EXACTLY `ticks` ticks of every env on every rank, barrier + synchronize on both sides, max over ranks -> seconds"""
+def timed_ticks(D, env, ticks, per_rank=None):
+    """EXACTLY `ticks` ticks of every env on every rank -> seconds = the MAX over ranks of each rank's own span.  Every rank starts from a common
+    barrier + synchronize; its span ends when ITS work is done (hk_synchronize: completion guard verified, stream drained; then the device-wide
+    synchronize of the contract); the closing barrier comes AFTER the clock is read (round 6: inside the span it put an RCCL all-reduce and two device
+    synchronisations into a window that lasts under a millisecond — at N > 1 the curve would have measured barrier latency, not the path).
+    per_rank: a list that receives every rank's span in ms (world > 1)."""
     D.barrier(env)
     t0 = time.perf_counter()
     env.step(ticks)
     env.synchronize()
+    D.sync_device()
+    dt = time.perf_counter() - t0
     D.barrier(env)
-    return D.max_time(time.perf_counter() - t0)
+    if per_rank is not None:
+        per_rank[:] = [t * 1e3 for t in D.all_times(dt)]
+    return D.max_time(dt)
 
 
 def selftest_launcher(a):
@@ -216,11 +242,12 @@ def selftest_launcher(a):
     local["time_steps"] = np.arange(lo, hi, dtype=np.int32)[:, None] * 2 + np.arange(2, dtype=np.int32)[None, :]
     D.barrier()
     dt = D.max_time(0.001 * (D.rank + 1))
+    spans = D.all_times(0.001 * (D.rank + 1))
     allres = gather_episode_results(local, D.dist)
     ok = allres.shape == (total, 2) and bool((allres["time_steps"] == np.arange(total, dtype=np.int32)[:, None] * 2 + np.arange(2)[None, :]).all())
     if D.rank == 0:
         print(json.dumps({"metric": "launcher selftest", "n_gpus": D.world, "gathered_envs": int(allres.shape[0]),
-                          "gather_ok": ok, "max_time": dt, "selftest": True}), flush=True)
+                          "gather_ok": ok, "max_time": dt, "per_rank_ms": [t * 1e3 for t in spans], "ranks_seen": int(D.dist.get_world_size()), "selftest": True}), flush=True)
     D.close()
     return 0 if ok else 1
 
@@ -476,7 +503,9 @@ def bench_lqng(a, D, hk):
     if a.warmup > 0:
         env.step(a.warmup)
     env.synchronize()
-    dt = timed_ticks(D, env, a.steps)                    # THE timed region: hk_prof off (its event records cost ~35 us per call)
+    per_rank_ms = []
+    dt = timed_ticks(D, env, a.steps, per_rank_ms)       # THE timed region: hk_prof off (its event records cost ~35 us per call)
+    sched = env.schedule_info()                          # what the library ran for that call (hk_schedule_info)
     st = env.agent_state() if D.rank == 0 else None
     # the same window again, back to back (up to 15 times while the race stays inside the protocol's steady stretch): how much of `value` is the
     # noise of one short sample.  `value` stays the ONE window above.
@@ -500,7 +529,10 @@ def bench_lqng(a, D, hk):
         for f in ("px", "pz", "yaw", "vx", "vz", "wy", "section_index", "flags"):
             assert np.array_equal(st[f], st2[f]), "the profiled pass did not reproduce the timed pass (%s)" % f
     # the path's one exchange step: all-gather of the episode results (RCCL over xGMI), off the timed region
+    D.barrier(env)
+    tg0 = time.perf_counter()
     results = gather_episode_results(env, D.dist)
+    gather_ms = (time.perf_counter() - tg0) * 1e3
     value = E * D.world * a.steps / dt
     t_first = a.preroll + a.warmup
 
@@ -600,7 +632,7 @@ def bench_lqng(a, D, hk):
                 vp = valu_port_use(dom_n, dt)
                 if vp:
                     binding["valu_port_use_over_wall"] = vp
-            if env.split_for(a.steps):
+            if sched.get("streams", 1) > 1:
                 # the default schedule of a long call runs the batch as two halves on two streams: two tick launches share the GPU, a launch's
                 # duration is no longer the kernel's own — the fraction of the roof is the whole job's (every kernel + the gaps), the per-launch
                 # figures (they agree with rocprofv3 --kernel-trace --stats of this command) stay beside it
@@ -640,10 +672,17 @@ def bench_lqng(a, D, hk):
                        "ticks": "race ticks %d..%d timed (untimed before: pre-roll 0..%d to the steady state of BASELINE.md §3, then %d warm-up ticks)"
                                 % (t_first, t_first + a.steps, a.preroll, a.warmup),
                        "timed_tick_range": [t_first, t_first + a.steps],
-                       "players_per_game_hist_N1..": hist,
+                       "players_per_game_hist_N1..": hist, "schedule": sched, "build": hk.build_info(),
                        "finished_episodes_seen": int((results["episode"] >= 0).any(axis=1).sum())},
             "roofline": roof,
         }
+        if D.dist:
+            # N ranks: every rank's own span of the timed region (value = all ranks' env-steps / the largest), the ranks the process group holds, and
+            # the path's one exchange step on its own clock (off the timed region): an all-gather of 32 B per agent from the library's device buffer
+            out["multi_gpu"] = {"per_rank_ms": per_rank_ms, "ranks_seen": int(D.dist.get_world_size()), "backend": D.backend,
+                                "result_gather": {"ms": gather_ms, "envs_gathered": int(results.shape[0]), "bytes_per_rank": int(E * A * results.dtype.itemsize),
+                                                  "note": "torch.distributed all_gather (RCCL on GPUs) straight from the device buffer of hk_episode_result[E][A]; after the timed region"},
+                                "note": "no collective and no barrier inside any timed span: a span starts at a common barrier and ends on the rank's own completion"}
         if rep_dt:
             vals = sorted(E * D.world * a.steps / t for t in rep_dt)
             med = vals[len(vals) // 2] if len(vals) % 2 else 0.5 * (vals[len(vals) // 2 - 1] + vals[len(vals) // 2])

@@ -8,3 +8,9 @@ from .lq import solve_feedback_lqr, solve_feedback_lqr_batch  # noqa: F401
 from .env import RacingEnv  # noqa: F401
 from .config import make_config  # noqa: F401
 from .policy import Policy  # noqa: F401
+
+
+def build_info():
+    """-> dict: what built the libhk.so this process loaded (hk_build_info: compiler, flags, accepted back-end switches, guard variant per unit)"""
+    import json
+    return json.loads(_lib.load().hk_build_info().decode())

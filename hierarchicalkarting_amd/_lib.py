@@ -186,6 +186,8 @@ SYMBOLS = {
     "hk_device_act_branch_ptr": (C.c_void_p, [_H]),
     "hk_stream": (C.c_void_p, [_H]),
     "hk_synchronize": (C.c_int, [_H]),
+    "hk_build_info": (C.c_char_p, []),
+    "hk_schedule_info": (C.c_char_p, [_H]),
     "hk_policy_attach": (C.c_int, [_H, C.POINTER(PolicyDesc), C.POINTER(C.c_int32), C.c_int, C.c_int]),
     "hk_policy_forward": (C.c_int, [_H, C.c_int, C.c_int, _fp, _fp, _fp]),
     "hk_get_actions": (C.c_int, [_H, _fp, C.POINTER(C.c_int32)]),

@@ -95,6 +95,8 @@ struct Tuning {
     bool want_split = false;     // HK_SPLIT=1: the batch as two halves on two streams in EVERY call of a plain handle (short ones too)
     bool split_long = true;      // the default: ... in the long (lazily completed) calls of plain handles; HK_NO_SPLIT=1 / HK_SPLIT=0 switch it off
     int lqn_sparse_blocks = 1024;   // HK_LQN_SPARSE_BLOCKS: workgroups per queue of a solver launch once the field has spread
+    int inwave = -1;                // HK_INWAVE=0: multi-player games always go through the queues and a solver launch (the schedule before round 6); 1: env_b1_kernel solves them in-wave in every round (tests); unset: in-wave while the games-per-launch meter says the field has spread
+    bool lqn_spread = true;         // HK_LQN=pair: the solver launch of a spread field stays on the pair / matrix-core kernel (the schedule before round 6)
     int split_ways = 2;          // HK_SPLIT_WAYS: parts of a split batch (2 .. SPLIT_WAYS_MAX), each on its own stream
     int split_min_ticks = 8;     // HK_SPLIT_MIN_TICKS: ... and in the calls of at least this many ticks that are not (a 20-tick call: 1 050 -> 1 120 M env-steps/s)
     bool no_split = false;       // HK_NO_SPLIT=1: one stream always, also while the field stands close
@@ -128,6 +130,8 @@ struct Tuning {
         debug_max_rounds = num("HK_DEBUG_MAX_ROUNDS", 0, 0, 1 << 20);
         debug_no_check = flag("HK_DEBUG_NO_CHECK"); stamps_dump = flag("HK_STAMPS_DUMP");
         { const char* f = std::getenv("HK_FISSION"); fission = !(f && std::atoi(f) == 0); fission_mcts = !flag("HK_NO_FISSION_MCTS"); fission_chunks = !flag("HK_NO_FISSION_CHUNKS"); park = flag("HK_PARK"); mcts_overlap = !flag("HK_MCTS_NO_OVERLAP"); fission_shaped = !flag("HK_NO_FISSION_SHAPED"); }
+        { const char* e = std::getenv("HK_LQN"); lqn_spread = !(e && std::strcmp(e, "pair") == 0); }
+        inwave = num("HK_INWAVE", -1, 0, 1);
         optimistic = !flag("HK_NO_OPTIMISTIC"); optimistic_skew = num("HK_OPTIMISTIC_SKEW", 0, 0, 3);
     }
 };
@@ -172,6 +176,15 @@ struct hk_context {
     hipStream_t mcts_stream = nullptr;                  // the search launch of a replan runs here, beside the tick launches up to the plans' deadline (step_ticks, pause mode)
     hipEvent_t ev_mcts_go = nullptr, ev_mcts_done = nullptr;
     int* done_host = nullptr;      // pinned: [0] max ticks left over the envs, [1] an env waits for a queued game
+    // the games-per-launch meter (hk_env_device.h GAME_METER): env_b1_kernel counts the multi-player games it assembles and its launches; a copy travels to
+    // pinned memory every METER_TICKS ticks, WITHOUT a sync — a heuristic may be a call late.  Few games per launch: the B1 waves solve their own (in-wave);
+    // many (envs that reset bring packs back): queues + solver launch.
+    unsigned long long* meter_host = nullptr;     // pinned [2]: games, B1 launches (cumulative)
+    hipStream_t meter_stream = nullptr;
+    unsigned long long meter_seen[2] = {0, 0};
+    int meter_ticks = 0;           // ticks issued since the last copy
+    bool meter_sparse = true;      // what the last two copies said
+    std::string sched;             // hk_schedule_info: the schedule of the last hk_step (written by step_ticks)
     void* pol_scratch = nullptr;   // hk_policy_forward staging
     size_t pol_scratch_bytes = 0;
     // RCCL communicator for hk_gather_results (librccl.so loaded lazily)
@@ -286,6 +299,8 @@ int hk_create(const hk_config* cfg, hk_handle* out)
         h->env_ready = true;
         if (hipHostMalloc((void**)&h->done_host, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) h->done_host = nullptr;   // (no pinned memory: fixed rounds)
         else { h->done_host[0] = 0; h->done_host[1] = 0; }
+        if (hipHostMalloc((void**)&h->meter_host, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) h->meter_host = nullptr;
+        else { h->meter_host[0] = 0; h->meter_host[1] = 0; }
     }
     *out = h;
     return HK_OK;
@@ -297,6 +312,8 @@ void hk_destroy(hk_handle h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->done_host) (void)hipHostFree(h->done_host);
+    if (h->meter_stream) { (void)hipStreamSynchronize(h->meter_stream); (void)hipStreamDestroy(h->meter_stream); }
+    if (h->meter_host) (void)hipHostFree(h->meter_host);
     hk::env_destroy(h->dev);
     if (h->d_status) (void)hipFree(h->d_status);
     if (h->lq_scratch) (void)hipFree(h->lq_scratch);
@@ -319,6 +336,7 @@ void hk_destroy(hk_handle h)
 }
 
 void* hk_stream(hk_handle h) { return h ? (void*)h->stream : nullptr; }
+const char* hk_schedule_info(hk_handle h) { return h ? h->sched.c_str() : ""; }
 
 int hk_synchronize(hk_handle h)
 {
@@ -461,7 +479,7 @@ static int issue_rounds(hk_handle h, int rounds)
         }
         rc = hk::env_launch_lqn(h->dev, h->cfg, h->stream, h->err);
         if (rc) { g_last_error = h->err; return rc; }
-        e = h->prof.chain(1, e, false, h->stream);
+        if (h->dev.lqn_launched) e = h->prof.chain(1, e, false, h->stream);
         first = false;
     }
     if (first && e) h->prof.pool.push_back(e);          // no round issued: the opening event goes back
@@ -513,7 +531,7 @@ static int issue_rounds_split(hk_handle h, int rounds)
             }
             rc = hk::env_launch_lqn(h->dev, h->cfg, st[k], h->err);          // (advances dev.round)
             if (rc) break;
-            e[k] = h->prof.chain(1, e[k], false, st[k]);
+            if (h->dev.lqn_launched) e[k] = h->prof.chain(1, e[k], false, st[k]);
             h->round_half[k] = h->dev.round;
         }
         if (h->dev.exact_plan) h->exact_idx += 1;
@@ -544,6 +562,7 @@ static int issue_check(hk_handle h, bool lazy)
 static int finish_ticks(hk_handle h)
 {
     const int cadence = h->cfg.num_agents > 2 ? 4 : 1;
+    h->dev.last_solve_skippable = false; h->dev.guard_rounds_left = 0; h->dev.exact_plan = false;      // (the laggards' rounds are plain rounds)
     for (int guard = 0; guard < 1024 && h->step_pending; guard++) {
         HK_HIP(h, hipStreamSynchronize(h->stream));
         const int maxleft = h->done_host[0], waiting = h->done_host[1];
@@ -564,10 +583,58 @@ static int finish_ticks(hk_handle h)
     return HK_OK;
 }
 
+// may the B1 launches of this call solve their games in-wave?  (the fission schedule of a quad handle with LQ agents; per round launch_b1 still keeps
+// the queues while the field stands close after a reset of every env)
+static bool inwave_allowed(hk_handle h)
+{
+    if (!h->dev.fission || h->dev.P.any_lqr == 0 || h->cfg.num_agents < 3 || h->cfg.num_agents > 4 || h->tune.inwave == 0) return false;
+    return h->tune.inwave == 1 || h->meter_sparse;
+}
+constexpr int METER_TICKS = 64;
+// look at the last copy of the games-per-launch meter (no sync: whatever has arrived) and ask for the next one
+static int meter_update(hk_handle h, int n_ticks)
+{
+    if (!h->meter_host || !h->dev.game_stats) return HK_OK;
+    const unsigned long long g = h->meter_host[0], l = h->meter_host[1];
+    if (l > h->meter_seen[1] && g >= h->meter_seen[0]) {
+        // games per B1 launch since the copy before, against the waves of a launch: in-wave pays while at most every other wave holds a game
+        const double per_launch = (double)(g - h->meter_seen[0]) / (double)(l - h->meter_seen[1]);
+        const double envs_per_launch = h->cfg.num_envs >= 8192 ? h->cfg.num_envs * 0.5 : h->cfg.num_envs;      // (two halves on two streams: issue_rounds_split)
+        h->meter_sparse = per_launch <= envs_per_launch / 32.0;
+    }
+    if (l != h->meter_seen[1] || g != h->meter_seen[0]) { h->meter_seen[0] = g; h->meter_seen[1] = l; }       // (also after hk_prof_reset zeroed the counters)
+    h->meter_ticks += n_ticks;
+    if (h->meter_ticks >= METER_TICKS && h->dev.fission) {
+        h->meter_ticks = 0;
+        // (on a stream of its own: the copy orders nothing and must not stand between two launches of the handle's stream)
+        if (!h->meter_stream) HK_HIP(h, hipStreamCreateWithFlags(&h->meter_stream, hipStreamNonBlocking));
+        HK_HIP(h, hipMemcpyAsync(h->meter_host, h->dev.game_stats + hk::GAME_METER, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->meter_stream));
+    }
+    return HK_OK;
+}
+
+// hk_schedule_info: what step_ticks decided for the call it just issued, in one place (the decisions themselves are spread over the function for
+// historical reasons; this record is what bench.py prints, so a measured number names its schedule)
+static void record_schedule(hk_handle h, int n_ticks, const char* rounds_mode, int rounds, bool fold, bool planner)
+{
+    char buf[640];
+    const char* kern = h->dev.fission ? "fission (tick kernel + env_b1_kernel per solve cadence)" : (h->dev.park ? "fused + LDS parking" : "fused");
+    const char* games = !h->dev.fission || h->dev.P.any_lqr == 0 ? "queues + solver launch"
+                        : (h->dev.inwave_ok ? (h->dev.inwave_always ? "in-wave (env_b1_kernel), every round" : "in-wave (env_b1_kernel) once the field has spread, queues + solver launch before")
+                                            : (h->dev.lqn_spread ? "queues + lqn_spread_kernel (lqn_round_kernel while the field stands close)" : "queues + lqn_round_kernel"));
+    std::snprintf(buf, sizeof(buf),
+                  "{\"call_ticks\": %d, \"rounds\": \"%s\", \"rounds_issued\": %d, \"kernel\": \"%s\", \"streams\": %d, \"ticks_per_launch\": %d, "
+                  "\"optimistic_plan\": %s, \"armed_in_first_launch\": %s, \"multi_player_games\": \"%s\", \"games_meter_sparse\": %s, \"planner\": %s, \"actors\": %d}",
+                  n_ticks, rounds_mode, rounds, kern, h->split ? h->tune.split_ways : 1, h->dev.P.run_cap, h->dev.exact_plan ? "true" : "false", fold ? "true" : "false",
+                  games, h->meter_sparse ? "true" : "false", planner ? "true" : "false", h->n_policies);
+    h->sched = buf;
+}
+
 // n_ticks of every env: arm, rounds of {fused tick kernel, queued multi-player solves}, check
 static int step_ticks(hk_handle h, int n_ticks)
 {
     int rc;
+    if ((rc = meter_update(h, n_ticks))) return rc;
     // Planner searches: a launch of the search kernel lasts as long as one search however few it holds, so requests are
     // batched.  A long call launches them every MCTS_FLUSH_ROUNDS rounds and once more before it returns; short calls (a
     // Unity host stepping tick by tick, or the chunks between two RL decisions) share ONE launch until MCTS_DEFER_TICKS
@@ -600,6 +667,8 @@ static int step_ticks(hk_handle h, int n_ticks)
     h->dev.mcts_defer = short_call;
     h->dev.ticks_since_reset += h->dev.call_ticks;      // the previous call's ticks
     h->dev.lqn_sparse_blocks = h->tune.lqn_sparse_blocks;
+    h->dev.lqn_spread = h->tune.lqn_spread;
+    h->dev.inwave_always = h->tune.inwave == 1;
     h->dev.call_ticks = n_ticks; h->dev.call_ticks_issued = 0;
     // Long calls of a planner handle without attached actors run in PAUSE mode: an env that requests a search stops at the next
     // tick boundary until the search has run, the host runs a stretch of rounds (every env reaches its replan tick or the end of
@@ -628,6 +697,7 @@ static int step_ticks(hk_handle h, int n_ticks)
         if (h->tune.fission_shaped) shaped_p = false;      // (reward shaping and the Training-mode reset live in phases A / C: the tick kernel's instantiations carry them)
         h->dev.fission = h->tune.fission && h->tune.fission_mcts && !shaped_p && h->dev.P.eager && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4;
         if (h->dev.fission) h->dev.P.run_cap = 4;
+        h->dev.inwave_ok = inwave_allowed(h);
         h->dev.mcts_defer = true;                       // the rounds do not launch searches themselves
         const int cadence = h->cfg.num_agents > 2 ? 4 : 1;
         int maxleft = n_ticks;
@@ -702,6 +772,7 @@ static int step_ticks(hk_handle h, int n_ticks)
         }
         h->dev.mcts_defer = false;
         h->dev.P.mcts_pause = 0;
+        record_schedule(h, n_ticks, "pause (stretches of rounds between search launches)", 0, false, true);
         if (maxleft > 0) return fail(h, HK_ERR_HIP, "hk_step: an env did not complete its ticks (internal scheduling error)");
         return HK_OK;
     }
@@ -736,6 +807,7 @@ static int step_ticks(hk_handle h, int n_ticks)
     // kernels without the eager assembly — an env parks at its solve tick, B1 + solver run, the next round resumes it; the rounds issued
     // are the worst case the fused kernel was given too (a round per solve tick of the chunk + 1)
     if (h->tune.fission && h->tune.fission_chunks && !shaped && (planner || h->n_policies > 0) && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4) h->dev.fission = true;
+    h->dev.inwave_ok = inwave_allowed(h);
     const int run_cap = (h->dev.fission && h->dev.P.any_lqr != 0) ? 4 : (lazy && h->cfg.num_agents > 2 && h->dev.ticks_since_reset >= hk::BULK_TICKS) ? spread_cap
                         : (!lazy && plain && h->dev.P.eager) ? short_cap : hk::RUN_CAP;
     h->dev.P.run_cap = run_cap;
@@ -809,8 +881,14 @@ static int step_ticks(hk_handle h, int n_ticks)
         if (rc) return rc;
     }
     h->step_pending = lazy;
+    record_schedule(h, n_ticks, lazy ? "lazy" : "fixed", rounds, fold, planner);
     if (h->dev.exact_plan) h->opt_pending = true;
     h->dev.exact_plan = false;
+    // (an exact plan's last round is the tick launch alone and never reaches the solver launch that consumes this flag: left set, the first solver launch
+    // of the rounds that finish a missed env — verify_optimistic — would be skipped and the env would resume on stale controls; found by the fold + skew
+    // modes of tests/test_optimistic_plan_gpu.py, round 6)
+    h->dev.last_solve_skippable = false;
+    h->dev.guard_rounds_left = 0;
     return HK_OK;
 }
 
@@ -1223,17 +1301,29 @@ int hk_get_lq_debug(hk_handle h, int env, int ego, hk_lq_debug* out)
     return HK_OK;
 }
 
-void* hk_device_results_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.results : nullptr; }
+// The device-pointer getters hand out the library's own buffers for zero-copy consumers (torch, the C# host's compute buffers).  Each one first SETTLES
+// the handle like every other getter — laggards of a lazily completed call, the completion guard of optimistic short calls, a search launch on the
+// planner's side stream — so that what the pointer shows, once the handle's stream has been synchronised, is the state hk_synchronize would leave.
+// The work is issued on the handle's stream; a pointer taken BEFORE a later hk_step shows that step's results only after the next getter / hk_synchronize.
+static bool settle_for_pointer(hk_handle h)
+{
+    if (!h || !h->env_ready) return false;
+    if (hipSetDevice(h->device) != hipSuccess) return false;
+    if (h->step_pending && finish_ticks(h) != HK_OK) return false;
+    if (h->opt_pending && verify_optimistic(h) != HK_OK) return false;
+    if (mcts_join_async(h)) return false;
+    return true;
+}
+void* hk_device_results_ptr(hk_handle h) { return settle_for_pointer(h) ? (void*)h->dev.results : nullptr; }
 void* hk_device_agents_ptr(hk_handle h)
 {
-    // a SNAPSHOT: the per-tick fields are gathered from the hot tiles into the records (asynchronously, on the handle's stream) by this call
-    if (!h || !h->env_ready) return nullptr;
-    if (hipSetDevice(h->device) != hipSuccess) return nullptr;
-    if (h->step_pending && finish_ticks(h) != HK_OK) return nullptr;
+    // a SNAPSHOT: the per-tick fields are gathered from the hot tiles into the records (asynchronously, on the handle's stream) by this call;
+    // after further hk_step calls the pointer has to be requested again
+    if (!settle_for_pointer(h)) return nullptr;
     if (hk::ga_ops(h->dev).launch_hot_gather(h->dev, h->cfg, h->stream, h->err) != HK_OK) { g_last_error = h->err; return nullptr; }
     return (void*)h->dev.agents;
 }
-void* hk_device_obs_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.obs : nullptr; }
+void* hk_device_obs_ptr(hk_handle h) { return settle_for_pointer(h) ? (void*)h->dev.obs : nullptr; }
 void* hk_device_act_steer_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.act_steer : nullptr; }
 void* hk_device_act_branch_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.act_branch : nullptr; }
 void* hk_device_reward_ptr(hk_handle h) { return (h && h->env_ready) ? (void*)h->dev.reward_out : nullptr; }

@@ -547,6 +547,7 @@ __device__ inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_
 }
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
+constexpr int GAME_METER = 14;         // game_stats[14], [15]: multi-player games assembled by env_b1_kernel / its launches, since hk_create or the last hk_prof_reset (the host's choice between in-wave solves and the solver launch)
 constexpr int GAME_STATS_N = 160;      // game_stats: [0, 16) games by player count, [16, 64) cycle stamps, [64, 160) lane-participation probes
 // Diagnostic build only (-DHK_LANEPROF, tools/lane_profile.py): probe k counts the waves that reach it and the lanes switched on when they do
 // (game_stats[64 + 2k] lanes, [65 + 2k] waves) — where in the tick kernel the masked half of the average vector instruction lives.

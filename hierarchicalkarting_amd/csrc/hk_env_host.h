@@ -63,6 +63,11 @@ struct EnvDevice {
     int* perm_alt = nullptr;
     bool b1_due = false;           // FISSION: the tick launch just issued parked its envs at their solve tick: env_b1_kernel is next on that stream
     int lqn_sparse_blocks = 1024;  // workgroups per queue of a solver launch once the field has spread (HK_LQN_SPARSE_BLOCKS)
+    bool lqn_spread = true;        // the solver launch of a spread field runs the lane-per-(player, row) solver (hk_lq_spread.h); HK_LQN=pair: the pair / matrix-core kernel always
+    bool inwave_ok = false;        // the current call may solve in-wave (hk_api.hip step_ticks: the handle's shape, the switches, the games-per-launch meter)
+    bool inwave_always = false;    // HK_INWAVE=1 (tests): also while the field stands close
+    bool inwave = false;           // the B1 launches of the current rounds solve their multi-player games themselves (hk_lq_spread.h lqs_inwave): no queue, no solver launch
+    bool lqn_launched = false;     // the last launch_lqn launched a kernel (or skipped a provably empty one): there is a solver stage to time
     bool b1_small = false;         // the rounds issued while a search launch runs on the side stream in 4-wave workgroups (every CU): B1 reads its tables from global memory, the solver launch is the <= 256-register form (hk_env_launch.h)
     int mcts_side_waves = 8;       // waves per workgroup of a search launch that runs beside tick launches (HK_MCTS_SIDE_WAVES; 0: as alone)
     bool exact_plan = false;       // the current fixed-round call follows the exact plan of a field in lock-step: its last round is the tick launch alone (hk_api.hip step_ticks)

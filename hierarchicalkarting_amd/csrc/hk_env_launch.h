@@ -89,9 +89,11 @@ inline int launch_regroup(EnvDevice& d, const hk_config& cfg, hipStream_t stream
     hipLaunchKernelGGL(env_regroup_count_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, d.envs, E, d.perm_counts);
     hipLaunchKernelGGL(env_regroup_scatter_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, d.envs, d.envs_alt, d.hot, d.hot_alt, d.perm, d.perm_alt, d.slot_of,
                        E, d.perm_counts);
+    const int rc = launch_check(err, "env_regroup kernels");
+    if (rc) return rc;           // (a launch that failed wrote nothing: the host pointers stay on the buffers that hold the state)
     // the move is physical: from here on the stream's kernels use the new buffers (everything is issued in stream order)
     std::swap(d.envs, d.envs_alt); std::swap(d.hot, d.hot_alt); std::swap(d.perm, d.perm_alt);
-    return launch_check(err, "env_regroup kernels");
+    return HK_OK;
 }
 
 // one round, part 1: the fused tick kernel (fills queue set round & 1)
@@ -101,6 +103,7 @@ inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
     const long long threads = (long long)(s1 - s0) * GA;
     const int arm = d.arm_ticks, guard = (d.guard_rounds_left > 0 && --d.guard_rounds_left == 0) ? 1 : 0;
     d.arm_ticks = 0;
+    d.inwave = false;            // (launch_b1 decides for the round)
 #define HK_RUN_T(MC, RWF, TRN, TL)                                                                                            \
     hipLaunchKernelGGL((env_run_kernel<MC, RWF, TRN, TL>), dim3((unsigned)((threads + 255) / 256)), dim3(256), TL ? d.tab_lds : 0, stream, d.P, d.agents, d.hot, d.envs,   \
                        d.results, GameSoA{d.games, (size_t)cfg.num_envs * cfg.num_agents}, d.queue_cnt, d.queue, d.round, d.act_steer, d.act_branch, d.lq_debug, d.status,     \
@@ -162,12 +165,15 @@ inline int launch_b1(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std
 #if HK_GA == 4
     if (!d.b1_due) return HK_OK;
     d.b1_due = false;
+    // in-wave solves (hk_lq_spread.h lqs_inwave) once the field has spread — while it stands close (BULK_TICKS after a reset of every env) nearly every ego
+    // holds a game and the queues + the pair solver's 32 games per wave are several times cheaper per game
+    d.inwave = d.inwave_ok && (d.inwave_always || !(d.ticks_since_reset + d.call_ticks_issued < BULK_TICKS));      // (HK_INWAVE=1, tests: in every round)
     const int s0 = d.slot1 > d.slot0 ? d.slot0 : 0, s1 = d.slot1 > d.slot0 ? d.slot1 : cfg.num_envs;
     const long long threads = (long long)(s1 - s0) * GA;
     const GameSoA G{d.games, (size_t)cfg.num_envs * cfg.num_agents};
     const unsigned blocks = (unsigned)((threads + 255) / 256);
 #define HK_FIS_B1(TL, MC) hipLaunchKernelGGL((env_b1_kernel<TL, MC>), dim3(blocks), dim3(256), TL ? d.P.o_tmask : 0, stream, d.P, d.agents, d.hot, d.envs, G, d.queue_cnt, d.queue, \
-                           d.round, d.lq_debug, d.status, d.mcts, d.perm, d.game_stats, s0, s1, d.qbase, d.mset)
+                           d.round, d.lq_debug, d.status, d.mcts, d.perm, d.game_stats, s0, s1, d.qbase, d.mset, d.inwave ? 1 : 0)
     // (b1_small: beside a search launch whose 4-wave workgroups hold 108.8 KB of EVERY CU's LDS, a B1 block with its 44.5 KB copy of the Complex-track tables
     // — 67 KB with the KartS staging — does not fit; the instantiation that reads the tables through L1 / L2 needs the 22.8 KB of staging only)
     if (d.mcts.st) { if (d.tab_lds && !d.b1_small) HK_FIS_B1(true, true); else HK_FIS_B1(false, true); }
@@ -189,6 +195,15 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
     const int* qc = d.queue_cnt + set * 16;
     const int* qu = d.queue + (size_t)set * queue_ints_per_set((size_t)ngames);
     int rc = HK_OK;
+    d.lqn_launched = false;
+    if (d.inwave) {
+        // IN-WAVE (round 6): the B1 launch of this round solved its multi-player games itself (hk_env_run.h, hk_lq_spread.h lqs_inwave): nothing is queued
+        if (d.last_solve_skippable && d.guard_rounds_left == 0) d.last_solve_skippable = false;
+        d.round += 1;
+        if (d.qbase == 0) d.call_ticks_issued = std::min(d.call_ticks_issued + (cfg.num_agents > 2 ? 4 : 1), d.call_ticks);
+        return HK_OK;
+    }
+    d.lqn_launched = true;
     if (d.last_solve_skippable && d.guard_rounds_left == 0) {
         // The tick launch before this one was the call's last (its completion guard): an env that queued a game there would be parked, i.e.
         // the call incomplete, which the round count rules out.  The skip is verified ON THE DEVICE by that very launch: as the guard it
@@ -211,6 +226,14 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
         const int per = bulk ? 1024 : d.lqn_sparse_blocks;
         const int n34 = sizes ? std::min(ngames, per) * sizes : 0;          // `per` waves per game size walk their queue grid-stride; the queue length picks the solver (lqn_round_kernel)
         const int n2 = std::min((ngames + 31) / 32, bulk ? 4096 : per);
+        if (d.lqn_spread && (!bulk || d.b1_small)) {
+            // A spread field (round 6): every queue on the lane-per-(player, row) solver (hk_lq_spread.h) — a third of the pair solver's registers, 2 - 11 KB of
+            // LDS per wave, ~4 x shorter per lane: its waves start beside the other half's resident tick / B1 waves (and beside a planner's search waves)
+            // instead of waiting for a CU to drain.  The pair / matrix-core kernel below keeps the rounds in which (nearly) every ego holds a game.
+            const int s2 = std::min((ngames + 3) / 4, per), s34 = sizes ? std::min(ngames, std::max(per / 8, 16)) : 0;
+            hipLaunchKernelGGL(lqn_spread_kernel, dim3(s2 + s34 * sizes), dim3(64), 0, stream, d.P, HotRef{d.hot, d.slot_of}, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status,
+                               s2, sizes >= 1 ? s34 : 0, sizes >= 2 ? s34 : 0, d.game_stats);
+        } else
         if (d.b1_small)     // beside a search launch (hk_lq2_pair.h: SMALL)
             hipLaunchKernelGGL(lqn_round_small_kernel, dim3(n34 + n2), dim3(64), lqn_round_small_lds(), stream, d.P, HotRef{d.hot, d.slot_of}, GameSoA{d.games, (size_t)ngames}, qc, qu, d.lq_debug, d.status,
                                n34, sizes ? sizes : 1, n2, d.game_stats, LQN_BULK_GAMES);

@@ -733,7 +733,8 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
 {
     const unsigned ent = (unsigned)M.queue[(size_t)set * 2 * P.E * P.A + q];
     const int pair = (int)(ent & 0xFFFFFFu);
-    if (((unsigned)mc_reqs(M)[pair].gen & 0xFFu) != (ent >> 24)) return;          // superseded by a later request of the same ego
+    const int gen0 = mc_reqs(M)[pair].gen;
+    if (((unsigned)gen0 & 0xFFu) != (ent >> 24)) return;                           // superseded by a later request of the same ego
     const int env = pair / P.A, ego = pair % P.A;
     if (!((cls_agents >> ego) & 1u)) return;                                       // another gameParams class: its own launch, with its tables
     MctsReq& R = mc_reqs(M)[pair];
@@ -927,6 +928,11 @@ __device__ __forceinline__ void mcts_search_one(const EnvParams& P, const MctsDe
             }
         }
     }
+    // A search that runs on the side stream BESIDE tick launches (hk_api.hip: the replan chunk of a planner + actor handle, pause = 0) can be overtaken by
+    // its own env: the race ends or times out, the reset posts a new request for this ego (gen + 1) and rewrites the root snapshot this search has been
+    // reading.  Whatever it computed from a torn snapshot is dropped here — every field of the record is a valid value of one of the two requests, so the
+    // search itself stays in range — and the new request's own search (queued by the reset, launched behind this one: they share the arena) supplies the plan.
+    if (__hip_atomic_load(&R.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen0) return;
     mst->pend = plan;
     if (M.persist) R.tree_nodes = n_nodes;
     // the plan first, device-wide, then "done": a tick launch may run BESIDE this kernel (hk_api.hip: the search of a replan overlaps the ticks up

@@ -387,7 +387,9 @@ __global__ __launch_bounds__(PARK ? PARK_BLOCK : 256, FISSION ? HK_FIS_OCC : HK_
         store_hot_tile(htile, h);
         if (HAS_RW && P.rewards) { arec->cum_reward = rwv.cum; arec->step_reward = rwv.step; arec->group_reward = rwv.group; }
     }
-    if (env_ok && dirty && i == 0) {
+    // (arm_ticks: the first launch of a folded call arms in registers — an env that does not enter the loop (`stuck`: parked at a solve tick the
+    // call before did not plan for) must still keep the call's ticks, or the completion guard would only ever finish what was left before them)
+    if (env_ok && (dirty || arm_ticks != 0) && i == 0) {
         es.reserved[0] = left;
         es.reserved[1] = phase | (pack ? ENV_PACK_HINT : 0);
         envs[slot] = es;
@@ -415,18 +417,18 @@ __global__ __launch_bounds__(PARK ? PARK_BLOCK : 256, FISSION ? HK_FIS_OCC : HK_
 template <bool TAB_LDS, bool HAS_MCTS = false>
 __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_agent_state* agents, uint32_t* hot, hk_env_state* envs, GameSoA games, int* queue_cnt_all,
                                                         int* queue_all, int round, hk_lq_debug* dbg_out, int* status, MctsDev Marg, const int* perm,
-                                                        unsigned long long* stats, int slot0, int slot1, int qbase, int mset)
+                                                        unsigned long long* stats, int slot0, int slot1, int qbase, int mset, int inwave)
 {
     MctsDev M{};
     if (HAS_MCTS) M = Marg;
 #ifdef HK_LANEPROF
     hk_lp_ptr = stats;
 #endif
-    (void)stats;
 #ifdef HK_STAMPS
     const unsigned long long st_entry = __builtin_readcyclecounter();
 #endif
-    __shared__ KartS ks[256];
+    __shared__ __align__(16) KartS ks[256];
+    static_assert(sizeof(KartS) * 64 == LQS_WAVE_LDS && sizeof(KartS) * 256 >= LQS_BLOCK_LDS, "the in-wave solver borrows the kart staging area");
     HK_DYN_SHARED(smem);
     const int gid = slot0 * GA + blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = gid / GA, i = gid % GA;
@@ -460,12 +462,28 @@ __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_
     hk_sincosf(h.yaw, &hfx, &hfz);
     HK_ST(h, 19);                      // [19] B1 kernel: table staging, record loads, sincos
     const int qn = phase_assemble(P, T, ks, env, i, pend, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
-#pragma unroll
-    for (int n = 2; n <= GA; n++) {
-        const int pos = wave_agg_inc(&queue_cnt[n], qn == n);
-        if (qn == n) queue[(size_t)(n - 2) * P.E * P.A + pos] = env * P.A + i;
+    // the games-per-launch meter of the host's schedule (hk_api.hip: in-wave solves or queue + solver launch), read back now and then
+    {
+        const unsigned long long mg = __ballot(qn != 0);
+        if ((threadIdx.x & 63) == 0 && mg != 0ull) atomicAdd(&stats[GAME_METER], (unsigned long long)__popcll(mg));
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[GAME_METER + 1], 1ull);
     }
-    const bool queued = group_or(qn ? 1 : 0) != 0;
+    bool queued = false;
+    if (inwave) {
+        // IN-WAVE (round 6): a spread field holds a few dozen multi-player games per solve tick; the waves that assembled them solve them here, behind
+        // their own phase_assemble — no queue, no solver launch between this launch and the next tick launch (hk_lq_spread.h lqs_inwave).  The pack hint
+        // stays clear: packs that share a wave would solve their games one pass after the other.
+        double ua = 0.0, ub = 0.0;
+        lqs_inwave(P, games, qn, env * P.A + i, reinterpret_cast<unsigned char*>(&ks[threadIdx.x & ~63]), reinterpret_cast<unsigned char*>(ks), ua, ub, status, stats);
+        if (qn != 0) decode_controls(h.final_steer, h.flags, h.steering, ua, ub, (dbg_out && (P.debug & 1)) ? &dbg_out[(size_t)env * P.A + i] : nullptr);
+    } else {
+#pragma unroll
+        for (int n = 2; n <= GA; n++) {
+            const int pos = wave_agg_inc(&queue_cnt[n], qn == n);
+            if (qn == n) queue[(size_t)(n - 2) * P.E * P.A + pos] = env * P.A + i;
+        }
+        queued = group_or(qn ? 1 : 0) != 0;
+    }
     // the planner hook of a solve tick (HKA:330-402, after SolveLQR; every lane of the group calls it): replan request, bestStates -> plan entries
     if (HAS_MCTS && M.st && pend) phase_plan(P, M, mset, env, i, es, h.flags, h.section_index, h.lane, h.lane_changes, h.final_steer, arec);
     if (arec) { hot_put<uint32_t>(htile, HF_flags, h.flags); hot_put<float>(htile, HF_steering, h.steering); }

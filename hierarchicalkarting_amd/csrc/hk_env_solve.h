@@ -853,6 +853,7 @@ __device__ __forceinline__ void lqn_body(const int block, const int nblocks, con
 // launch at the 4-player body's occupancy — 0.6 ms for the 262 144 games of a race-start tick — and a 2-player kernel of its own at
 // two waves per SIMD, 0.38 ms per 100 000 games.)
 #include "hk_lq2_pair.h"
+#include "hk_lq_spread.h"
 
 #if HK_GA > 4
 // Games with 5..8 players (only the synthetic 8-agent configuration has them).  The generic core is the same; beyond 4 players a

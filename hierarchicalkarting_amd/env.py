@@ -57,6 +57,12 @@ class RacingEnv:
         req = want or (split_long and (lazy_call or n_ticks >= num("HK_SPLIT_MIN_TICKS", 8, 1, 1 << 20)))
         return bool(req and self.E >= 8192 and 2 < self.A <= 4 and env.get("HK_NO_EAGER") is None)
 
+    def schedule_info(self):
+        """-> dict: the schedule the last hk_step of this handle ran (hk_schedule_info)"""
+        import json
+        txt = self.L.hk_schedule_info(self.h)
+        return json.loads(txt.decode()) if txt else {}
+
     def close(self):
         if getattr(self, "h", None):
             self.L.hk_destroy(self.h)
@@ -237,6 +243,20 @@ class RacingEnv:
 
     def rewards_device(self):
         self._ck(self.L.hk_rewards_device(self.h))
+
+    def results_tensor(self):
+        """-> torch CUDA uint8 tensor [E * A * 32] ALIASING the library's hk_episode_result[E][A] buffer (the payload of the result gather); the handle is
+        settled and its stream synchronised first, so the view is complete"""
+        import torch
+
+        class _Ext:
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (int(ptr), False), "version": 3, "strides": None}
+        ptr = self.L.hk_device_results_ptr(self.h)
+        if not ptr:
+            raise RuntimeError("hk_device_results_ptr: " + (self.L.hk_last_error(self.h) or b"").decode())
+        self.synchronize()
+        return torch.as_tensor(_Ext(ptr, self.E * self.A * RESULT_DT.itemsize), device="cuda:%d" % self.built.cfg.device_id)
 
     def device_results_ptr(self):
         return self.L.hk_device_results_ptr(self.h)

@@ -388,6 +388,8 @@ namespace KartGame.AI.Native
         [DllImport(Lib)] public static extern IntPtr hk_device_act_branch_ptr(IntPtr h);
         [DllImport(Lib)] public static extern IntPtr hk_stream(IntPtr h);
         [DllImport(Lib)] public static extern int hk_synchronize(IntPtr h);
+        [DllImport(Lib)] public static extern IntPtr hk_build_info();               // const char* (JSON), owned by the library: Marshal.PtrToStringAnsi
+        [DllImport(Lib)] public static extern IntPtr hk_schedule_info(IntPtr h);     // const char* (JSON), owned by the handle
         // LowMode == RL: the actor runs on device every DecisionPeriod ticks instead of Barracuda (KA:440, HKA:1371-1379)
         [DllImport(Lib)] public static extern int hk_policy_attach(IntPtr h, HkPolicyDesc* desc, int* agentSlots, int nSlots, int decisionPeriod);
         [DllImport(Lib)] public static extern int hk_policy_forward(IntPtr h, int policy, int rows, float* obs, float* mu, float* logits);

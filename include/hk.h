@@ -368,6 +368,9 @@ int hk_lq_solve_batch(hk_handle h, int batch, int N, const double* A, const doub
 /* device-resident variants used by bench.py / torch (pointers are HIP device pointers; stream = hipStream_t or NULL) */
 int hk_lq_solve_batch_device(hk_handle h, int batch, int N, const double* dA, const double* dB, const double* dQ,
                              const double* dq, const double* dR, const double* dx0, int horizon, double* du0, void* stream);
+/* The three state pointers below first settle the handle as any getter does (laggards of a lazily completed call, the completion guard of optimistic
+ * short calls, a search launch on the planner's side stream — each may synchronise with the device), then return the buffer; NULL on failure
+ * (hk_last_error).  What a pointer shows is complete once hk_stream has been synchronised; after further hk_step calls request it again. */
 void* hk_device_results_ptr(hk_handle h);  /* hk_episode_result[E][A] on device: the payload of the RCCL all-gather */
 void* hk_device_agents_ptr(hk_handle h);   /* hk_agent_state[E][A] on device: a SNAPSHOT as of this call (the library keeps the per-tick fields in a
                                             * wave-tiled layout of its own and gathers them into these records here, asynchronously on hk_stream;
@@ -385,6 +388,12 @@ void* hk_device_group_reward_ptr(hk_handle h);  /* float[E][A], valid after hk_r
 void* hk_device_act_steer_ptr(hk_handle h);     /* float[E][A]: continuous action 0 */
 void* hk_device_act_branch_ptr(hk_handle h);    /* int32[E][A]: discrete action 0 */
 void* hk_stream(hk_handle h);              /* hipStream_t the handle launches on */
+/* What built this libhk.so (round 6): a JSON string compiled into the library at link time — hipcc / clang version, the flags, the hidden back-end switches the
+ * toolchain accepted and, per translation unit, the code-generation guard variant it shipped with.  bench.py prints it in config.build. */
+const char* hk_build_info(void);
+/* The schedule the last hk_step of this handle ran (round 6; a JSON string owned by the handle, valid until the next hk_step): fixed / lazy / pause rounds,
+ * fission or fused kernel, streams, the optimistic plan, where multi-player games are solved.  bench.py prints it in config.schedule. */
+const char* hk_schedule_info(hk_handle h);
 int hk_synchronize(hk_handle h);
 
 /* ---- RL low-level policy inference on device ---------------------------------------------------------

@@ -28,6 +28,7 @@ def test_gpus_2_spawns_two_ranks_and_prints_one_line():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["gather_ok"] and out["gathered_envs"] == 11      # 6 + 5: unequal shards
     assert abs(out["max_time"] - 0.002) < 1e-12                                        # max over ranks
+    assert out["ranks_seen"] == 2 and [round(t, 9) for t in out["per_rank_ms"]] == [1.0, 2.0]      # every rank's own span, rank order
 
 
 def test_gpus_2_without_two_gpus_fails_cleanly():

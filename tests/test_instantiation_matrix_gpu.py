@@ -83,6 +83,12 @@ MODES.update({"park": {"HK_PARK": "1"}, "park_split": {"HK_PARK": "1", "HK_SPLIT
 # its global-table instantiation and lqn_round_small_kernel for those rounds): both forms of the side launch stay reachable
 CASES += [("planner", "side8"), ("planner_rw", "side8")]
 MODES.update({"side8": {"HK_MCTS_SIDE_WAVES": "8"}})
+# round 6: where the multi-player games of the fission schedule are solved — by the B1 waves that assembled them (in every round, the race start too; the
+# default does so only once the field has spread), through the queues by the spread solver's launch, through the queues by the pair / matrix-core kernel
+CASES += [(k, m) for k in ("plain", "rewards", "planner", "planner_rw", "training", "actor_lq", "planner_actor_lq") for m in ("inwave_all", "queues", "queues_pair")]
+CASES += [("plain", "inwave_all_split"), ("plain", "inwave_all_tab_global")]
+MODES.update({"inwave_all": {"HK_INWAVE": "1"}, "queues": {"HK_INWAVE": "0"}, "queues_pair": {"HK_INWAVE": "0", "HK_LQN": "pair"},
+              "inwave_all_split": {"HK_INWAVE": "1", "HK_SPLIT": "1"}, "inwave_all_tab_global": {"HK_INWAVE": "1", "HK_TAB_GLOBAL": "1"}})
 MODES.update({"split": {"HK_SPLIT": "1"}, "no_pause": {"HK_MCTS_NO_PAUSE": "1"}, "fused": {"HK_FISSION": "0"}, "fused_split": {"HK_FISSION": "0", "HK_SPLIT": "1"},
               "fused_tab_global": {"HK_FISSION": "0", "HK_TAB_GLOBAL": "1"}})
 

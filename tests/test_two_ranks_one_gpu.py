@@ -84,3 +84,8 @@ def test_bench_rank_code_with_two_ranks_on_one_gpu():
     assert out["config"]["envs_per_gpu"] == 4096 and out["config"]["same_device"] is True
     # value = the units ALL ranks processed / the max-over-ranks time
     assert abs(out["value"] - 2 * 4096 * 40 / (out["ms_per_step"] * 1e-3 * 40)) / out["value"] < 1e-6
+    # round 6: every rank's own span is in the line, the time is their maximum (no barrier inside a span), the gather has its own clock
+    mg = out["multi_gpu"]
+    assert mg["ranks_seen"] == 2 and len(mg["per_rank_ms"]) == 2 and all(t > 0 for t in mg["per_rank_ms"])
+    assert abs(max(mg["per_rank_ms"]) - out["ms_per_step"] * 40) / max(mg["per_rank_ms"]) < 1e-6
+    assert mg["result_gather"]["envs_gathered"] == 2 * 4096 and mg["result_gather"]["ms"] > 0
