@@ -183,6 +183,7 @@ struct hk_context {
     hipStream_t meter_stream = nullptr;
     unsigned long long meter_seen[2] = {0, 0};
     int meter_ticks = 0;           // ticks issued since the last copy
+    long long meter_req_tick[2] = {-1, -1};       // ticks since the last reset of every env at the last two copy requests (an interval that began in the bulk phase is ignored)
     bool meter_sparse = true;      // what the last two copies said
     std::string sched;             // hk_schedule_info: the schedule of the last hk_step (written by step_ticks)
     void* pol_scratch = nullptr;   // hk_policy_forward staging
@@ -517,26 +518,50 @@ static int issue_rounds_split(hk_handle h, int rounds)
     for (int k = 0; k < K; k++) e[k] = h->prof.begin(st[k]);
     bool first = true;
     int rc = HK_OK;
+    // Round 6, from the kernel trace of the driver's 20-tick call (profiles/r06_b_short_call_trace.txt): the HOST is what the GPU waits for at the start of a
+    // short call — a launch costs it 6 - 8 us, and with one part's whole round issued before the other's first launch the second stream began 93 us into a
+    // 895 us call.  The launches of a round are therefore issued kind by kind: every part's tick launch, then every part's B1 launch, then the solver launches.
+    // A folded call (step_ticks: fold_split) arms inside each part's first tick launch and makes each part's last tick launch its completion guard: no
+    // env_arm_kernel in front of the fork, no env_check_kernel behind the join.
+    const int arm = h->dev.arm_ticks;
+    h->dev.arm_ticks = 0;
+    bool b1due[hk::SPLIT_WAYS_MAX] = {}, inw[hk::SPLIT_WAYS_MAX] = {};
+    auto part = [&](int k) { h->dev.slot0 = cut[k]; h->dev.slot1 = cut[k + 1]; h->dev.qbase = 2 * k; h->dev.round = h->round_half[k]; };
     for (int r = 0; r < rounds && rc == HK_OK; r++) {
+        const bool plan_last = h->dev.exact_plan && h->exact_idx + 1 == h->exact_total;      // (the plan's last round: the tick launches alone)
         for (int k = 0; k < K && rc == HK_OK; k++) {
-            h->dev.slot0 = cut[k]; h->dev.slot1 = cut[k + 1]; h->dev.qbase = 2 * k; h->dev.round = h->round_half[k];
+            part(k);
+            if (r == 0) h->dev.arm_ticks = arm;
+            if (h->dev.fold_split && r == rounds - 1) h->dev.guard_rounds_left = 1;
             rc = hk::env_launch_run_only(h->dev, h->cfg, st[k], h->err);
             if (rc) break;
             e[k] = h->prof.chain(0, e[k], first, st[k]);
-            if (h->dev.exact_plan && h->exact_idx + 1 == h->exact_total) { h->dev.b1_due = false; h->dev.round += 1; h->round_half[k] = h->dev.round; continue; }     // (the plan's last round: the tick launch alone)
-            if (h->dev.b1_due) {
-                rc = hk::env_launch_b1(h->dev, h->cfg, st[k], h->err);
-                if (rc) break;
-                e[k] = h->prof.chain(5, e[k], false, st[k]);
-            }
+            b1due[k] = h->dev.b1_due; h->dev.b1_due = false;
+            if (plan_last) h->round_half[k] = h->dev.round + 1;
+        }
+        if (h->dev.exact_plan) h->exact_idx += 1;
+        first = false;
+        if (plan_last || rc) continue;
+        for (int k = 0; k < K && rc == HK_OK; k++) {
+            inw[k] = false;
+            if (!b1due[k]) continue;
+            part(k);
+            h->dev.b1_due = true;
+            rc = hk::env_launch_b1(h->dev, h->cfg, st[k], h->err);          // (decides whether this round's games are solved in-wave)
+            if (rc) break;
+            inw[k] = h->dev.inwave;
+            e[k] = h->prof.chain(5, e[k], false, st[k]);
+        }
+        for (int k = 0; k < K && rc == HK_OK; k++) {
+            part(k);
+            h->dev.inwave = inw[k];
             rc = hk::env_launch_lqn(h->dev, h->cfg, st[k], h->err);          // (advances dev.round)
             if (rc) break;
             if (h->dev.lqn_launched) e[k] = h->prof.chain(1, e[k], false, st[k]);
             h->round_half[k] = h->dev.round;
         }
-        if (h->dev.exact_plan) h->exact_idx += 1;
-        first = false;
     }
+    h->dev.inwave = false;
     h->dev.slot0 = 0; h->dev.slot1 = 0; h->dev.qbase = 0; h->dev.round = h->round_half[0];
     if (first) for (int k = 0; k < K; k++) if (e[k]) h->prof.pool.push_back(e[k]);
     for (int k = 1; k < K; k++) {
@@ -573,7 +598,7 @@ static int finish_ticks(hk_handle h)
         // Rounds for the slowest env if it met no further multi-player game (+ 1), not for the worst case (a round per cadence): the
         // batch ends with a look at the device anyway, and two thirds of the worst-case rounds used to find nothing to do (94 of 141 in
         // the headline's 3 072-tick call, ~18 us each).  An env that does park on every solve tick still gets a third of its ticks per batch.
-        const int cap = std::max(h->dev.P.run_cap, cadence);
+        const int cap = (h->dev.fission && cadence == 1) ? 1 : std::max(h->dev.P.run_cap, cadence);      // (2-agent fission: a tick per round)
         rc = issue_rounds(h, h->tune.tail_worst_case ? (maxleft + cadence - 1) / cadence + 1 : (maxleft + cap - 1) / cap + 1);
         if (rc) return rc;
         rc = issue_check(h, true);
@@ -591,21 +616,29 @@ static bool inwave_allowed(hk_handle h)
     return h->tune.inwave == 1 || h->meter_sparse;
 }
 constexpr int METER_TICKS = 64;
-// look at the last copy of the games-per-launch meter (no sync: whatever has arrived) and ask for the next one
+// look at the last copy of the games-per-launch meter (no sync: whatever has arrived) and ask for the next one.  A copy describes the launches between
+// the request before it and its own request; an interval that began while the field stood close after a reset of every env (BULK_TICKS: nearly every ego
+// holds a game, and those rounds use the queues whatever the meter says) tells nothing about the spread field and is ignored — the driver's
+// window, 517 ticks after the reset, used to run on the race start's average (profiles/r06_b_short_call_trace.txt).
 static int meter_update(hk_handle h, int n_ticks)
 {
     if (!h->meter_host || !h->dev.game_stats) return HK_OK;
+    const long long now = (long long)h->dev.ticks_since_reset + h->dev.call_ticks;          // ticks issued since the last reset of every env
+    if (now < h->meter_req_tick[1]) { h->meter_req_tick[0] = h->meter_req_tick[1] = -1; h->meter_sparse = true; }      // (a reset of every env since the last request)
     const unsigned long long g = h->meter_host[0], l = h->meter_host[1];
-    if (l > h->meter_seen[1] && g >= h->meter_seen[0]) {
-        // games per B1 launch since the copy before, against the waves of a launch: in-wave pays while at most every other wave holds a game
+    if (l > h->meter_seen[1] && g >= h->meter_seen[0] && h->meter_req_tick[0] >= hk::BULK_TICKS) {
+        // games per B1 launch over the interval, against the waves of a launch: in-wave pays while at most every other wave holds a game
         const double per_launch = (double)(g - h->meter_seen[0]) / (double)(l - h->meter_seen[1]);
         const double envs_per_launch = h->cfg.num_envs >= 8192 ? h->cfg.num_envs * 0.5 : h->cfg.num_envs;      // (two halves on two streams: issue_rounds_split)
-        h->meter_sparse = per_launch <= envs_per_launch / 32.0;
+        // (measured, profiles/r06_b_short_call_trace.txt: at 262 games per half-batch launch — ticks 517 .. 537 of the race — the two schedules are level, at 39 the in-wave
+        // one is 3.5 % ahead: the threshold sits at one game per 64 envs of a launch)
+        h->meter_sparse = per_launch <= envs_per_launch / 64.0;
     }
     if (l != h->meter_seen[1] || g != h->meter_seen[0]) { h->meter_seen[0] = g; h->meter_seen[1] = l; }       // (also after hk_prof_reset zeroed the counters)
     h->meter_ticks += n_ticks;
     if (h->meter_ticks >= METER_TICKS && h->dev.fission) {
         h->meter_ticks = 0;
+        h->meter_req_tick[0] = h->meter_req_tick[1]; h->meter_req_tick[1] = now;
         // (on a stream of its own: the copy orders nothing and must not stand between two launches of the handle's stream)
         if (!h->meter_stream) HK_HIP(h, hipStreamCreateWithFlags(&h->meter_stream, hipStreamNonBlocking));
         HK_HIP(h, hipMemcpyAsync(h->meter_host, h->dev.game_stats + hk::GAME_METER, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->meter_stream));
@@ -684,7 +717,8 @@ static int step_ticks(hk_handle h, int n_ticks)
     // last one raises the "did not complete" flag the guard kernel would (a one-tick call: 4 launches instead of 9 with round 2's tail regroup)
     const bool lazy_call = !planner && h->n_policies == 0 && h->done_host != nullptr && n_ticks >= h->tune.lazy_min_ticks && h->tune.lazy;
     const bool split_req = h->tune.want_split || (h->tune.split_long && (lazy_call || (!planner && h->n_policies == 0 && n_ticks >= h->tune.split_min_ticks)));      // (HK_SPLIT=1: every call)
-    const bool fold = !pause && !lazy_call && !(split_req || (h->dev.ticks_since_reset < hk::BULK_TICKS && !h->tune.no_split));
+    // (round 6: split calls fold too — each part's first tick launch arms its lane groups, each part's last one is the guard: issue_rounds_split)
+    const bool fold = !pause && !lazy_call;
     if (fold) h->dev.arm_ticks = n_ticks;
     else {
         rc = hk::env_launch_arm(h->dev, h->cfg, n_ticks, h->stream, h->err);
@@ -807,6 +841,10 @@ static int step_ticks(hk_handle h, int n_ticks)
     // kernels without the eager assembly — an env parks at its solve tick, B1 + solver run, the next round resumes it; the rounds issued
     // are the worst case the fused kernel was given too (a round per solve tick of the chunk + 1)
     if (h->tune.fission && h->tune.fission_chunks && !shaped && (planner || h->n_policies > 0) && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4) h->dev.fission = true;
+    // 2-agent fields (cadence 1: every tick is a solve tick and both egos hold the 2-player game, HKA:317,709) stay on the fused kernel.  Round 6 measured
+    // the fission schedule for them (bit-equal; three launches per tick, no eager assembly): 303 M env-steps/s against the fused kernel's 331 M — with a game per
+    // ego and tick the round is the pair solver's 131 072 games (98 us) and the GameSoA round trip of the assembly (B1 82 us), which a split does not shrink.
+    const bool fission_a2 = false;
     h->dev.inwave_ok = inwave_allowed(h);
     const int run_cap = (h->dev.fission && h->dev.P.any_lqr != 0) ? 4 : (lazy && h->cfg.num_agents > 2 && h->dev.ticks_since_reset >= hk::BULK_TICKS) ? spread_cap
                         : (!lazy && plain && h->dev.P.eager) ? short_cap : hk::RUN_CAP;
@@ -822,7 +860,8 @@ static int step_ticks(hk_handle h, int n_ticks)
     const bool want_split = split_req, no_split = h->tune.no_split;
     const bool close_field = h->dev.ticks_since_reset < hk::BULK_TICKS;
     h->split = (want_split || (close_field && !no_split)) && h->dev.P.eager && h->cfg.num_envs >= 8192;
-    int rounds = lazy ? hk::env_rounds_min(h->cfg, n_ticks, run_cap) : hk::env_rounds_for(h->cfg, n_ticks, run_cap, h->dev.P.eager != 0);
+    // (2-agent fission: a round retires exactly one tick whatever the launch's budget)
+    int rounds = lazy ? hk::env_rounds_min(h->cfg, n_ticks, fission_a2 ? 1 : run_cap) : hk::env_rounds_for(h->cfg, n_ticks, run_cap, h->dev.P.eager != 0 || fission_a2);
     // The optimistic plan of a fixed-round call (round 5).  If every env stands on episode step T0, the call's ticks T0 + 1 .. T0 + n hold S solve ticks
     // (multiples of the cadence) and the field needs exactly S rounds of {tick launch up to the solve tick, B1, solver} and one more tick launch: a one-tick
     // call off a solve tick is ONE launch, the driver's 20-tick window 6 + 5 + 5 launches per half instead of 7 + 7 + 7.  The plan is a belief, not a proof
@@ -840,12 +879,15 @@ static int step_ticks(hk_handle h, int n_ticks)
     if (h->tune.debug_max_rounds > 0) rounds = std::min(rounds, h->tune.debug_max_rounds);     // (diagnostic: look at the state between two rounds)
     {
         // the rounds every env needs at RUN_CAP ticks a round, then — the laggards packed into the first lane groups — the tail
-        const int main_rounds = std::min(rounds, (n_ticks + run_cap - 1) / run_cap);
-        h->dev.guard_rounds_left = fold ? rounds : 0;          // the tick launch that brings this to 0 is the call's last: it is the guard
+        const int main_rounds = std::min(rounds, fission_a2 ? n_ticks : (n_ticks + run_cap - 1) / run_cap);
+        h->dev.guard_rounds_left = (fold && !h->split) ? rounds : 0;          // the tick launch that brings this to 0 is the call's last: it is the guard
+        h->dev.fold_split = fold && h->split;
         h->dev.last_solve_skippable = fold && plain && !h->split && h->tune.debug_max_rounds == 0 && !h->tune.keep_last_solve;
-        rc = issue_rounds(h, main_rounds);
+        // (with the eager assembly there is nothing to regroup between the two: ONE issue — a split call used to join its streams and fork them again for
+        // the tail, which left the first stream idle for ~100 us of the driver's 20-tick call)
+        rc = issue_rounds(h, h->dev.P.eager ? rounds : main_rounds);
         if (rc) return rc;
-        if (rounds > main_rounds) {
+        if (rounds > main_rounds && !h->dev.P.eager) {
             // (with the eager assembly every env retires a cadence per round: there are no laggards to pack, and a one-tick call
             // would pay three more GPU operations for the regroup than for its tick)
             if (!planner && h->n_policies == 0 && !h->dev.P.eager) {

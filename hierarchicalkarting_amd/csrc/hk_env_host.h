@@ -74,6 +74,7 @@ struct EnvDevice {
     bool park = false;             // plain handles run the fused kernel with LDS parking (hk_env_run.h PARK) instead of the fission schedule
     bool park_attr_set = false;
     bool fission = false;          // the current call runs the tick kernel without phase B1 + env_b1_kernel (hk_env_run.h FISSION; hk_api.hip step_ticks)
+    bool fold_split = false;       // a folded call on the two-stream schedule: each part's last tick launch is its completion guard (hk_api.hip issue_rounds_split)
     int arm_ticks = 0;             // > 0: the next tick launch adds these ticks to every env's count (a fixed-round call arms itself)
     bool last_solve_skippable = false;   // fixed-round call of a plain handle: no env can park in its last round, so that round queues no game (launch_lqn)
     int guard_rounds_left = 0;     // > 0: fixed-round call; the tick launch that brings it to 0 flags the envs that are not done (the guard)

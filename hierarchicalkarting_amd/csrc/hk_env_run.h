@@ -428,7 +428,9 @@ __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_
     const unsigned long long st_entry = __builtin_readcyclecounter();
 #endif
     __shared__ __align__(16) KartS ks[256];
-    static_assert(sizeof(KartS) * 64 == LQS_WAVE_LDS && sizeof(KartS) * 256 >= LQS_BLOCK_LDS, "the in-wave solver borrows the kart staging area");
+#ifndef HK_HOST_EMU          // (the solvers are not part of the host emulation of the tick kernels: there the games always go to the queues)
+    static_assert(sizeof(KartS) * 64 == LQS_WAVE_LDS, "the in-wave solver borrows the wave's slice of the kart staging area");
+#endif
     HK_DYN_SHARED(smem);
     const int gid = slot0 * GA + blockIdx.x * blockDim.x + threadIdx.x;
     const int slot = gid / GA, i = gid % GA;
@@ -469,14 +471,18 @@ __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[GAME_METER + 1], 1ull);
     }
     bool queued = false;
+#ifndef HK_HOST_EMU
     if (inwave) {
         // IN-WAVE (round 6): a spread field holds a few dozen multi-player games per solve tick; the waves that assembled them solve them here, behind
-        // their own phase_assemble — no queue, no solver launch between this launch and the next tick launch (hk_lq_spread.h lqs_inwave).  The pack hint
-        // stays clear: packs that share a wave would solve their games one pass after the other.
+        // their own phase_assemble — no queue, no solver launch between this launch and the next tick launch, no barrier (hk_lq_spread.h lqs_inwave).  The
+        // pack hint stays clear: packs that share a wave would solve their games one pass after the other.
         double ua = 0.0, ub = 0.0;
-        lqs_inwave(P, games, qn, env * P.A + i, reinterpret_cast<unsigned char*>(&ks[threadIdx.x & ~63]), reinterpret_cast<unsigned char*>(ks), ua, ub, status, stats);
+        lqs_inwave(P, games, qn, env * P.A + i, reinterpret_cast<unsigned char*>(&ks[threadIdx.x & ~63]), ua, ub, status, stats);
         if (qn != 0) decode_controls(h.final_steer, h.flags, h.steering, ua, ub, (dbg_out && (P.debug & 1)) ? &dbg_out[(size_t)env * P.A + i] : nullptr);
-    } else {
+    } else
+#endif
+    {
+        (void)inwave;
 #pragma unroll
         for (int n = 2; n <= GA; n++) {
             const int pos = wave_agg_inc(&queue_cnt[n], qn == n);

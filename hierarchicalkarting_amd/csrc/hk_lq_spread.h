@@ -40,30 +40,29 @@
 #define HK_LQS_FENCE() ((void)0)
 #endif
 
-template <int NP>
+// SW ("serial W"): ONE W block that the players use in turn (S6 - S7 run player by player) — a 4-player game in 5.3 KB instead of 11.2, for the wave of
+// env_b1_kernel that solves inside its own 5 632-byte slice of the kart staging area (lqs_inwave)
+template <int NP, bool SW = false>
 struct __attribute__((aligned(16))) LqSpreadLds {
     static constexpr int n = 4 * NP, m = 2 * NP, CW = m + n + 1;
     static constexpr int WS = n * n + 2;          // doubles per player's W block (+2: the NP blocks a wave reads side by side start 4 banks apart)
+    static constexpr int SCR = (m * CW + m * m + m + 2 + 1) & ~1;      // the solve phase's scratch
     // value-update phase: the W rows of every player.  Solve phase (aliased — nothing of W is live then): rows of [LHS | RHSMat | RHSVec], U,
     // and the pivot step's broadcast ([0] pivot row, [1 .. m - 1] multipliers, [m] singular flag)
-    double wbuf[NP * WS];
+    double wbuf[SW ? (WS > SCR ? WS : SCR) : NP * WS];
     double Fd[m][n];            // dense rows of F: Fd[2 k + a][c] = F[4 k + 2 + a][c]
     double Pm[m][n];            // P rows
     double vec[NP][n];          // eta_i + Z_i beta
     double al[m];               // alpha
     double beta[m];             // dense entries of beta: beta[2 k + a] = beta_full[4 k + 2 + a]
-    double x0[n];
     double a4[NP][4];           // A[x,v], A[z,v], A[x,h], A[z,h] of every player (KartLQRDynamics.cs:45-48)
-    double rc[NP];              // control weights
-    double pad_[(NP & 1) ? 3 : 2];                // (the games of a wave start 8 banks apart)
-    __device__ __forceinline__ double* W(int i) { return wbuf + i * WS; }
+    double rc[NP + (NP & 1)];   // control weights (an even count: the struct stays a multiple of 16 bytes)
+    __device__ __forceinline__ double* W(int i) { return SW ? wbuf : wbuf + i * WS; }
     __device__ __forceinline__ double* Cm() { return wbuf; }                        // [m][CW]
     __device__ __forceinline__ double* U() { return wbuf + m * CW; }                // [m][m]
     __device__ __forceinline__ double* lu() { return wbuf + m * CW + m * m; }       // [m + 2]
 };
-static_assert(LqSpreadLds<2>::m * LqSpreadLds<2>::CW + 16 + 6 <= 2 * LqSpreadLds<2>::WS, "solve-phase scratch fits the W area");
-static_assert(LqSpreadLds<3>::m * LqSpreadLds<3>::CW + 36 + 8 <= 3 * LqSpreadLds<3>::WS, "solve-phase scratch fits the W area");
-static_assert(LqSpreadLds<4>::m * LqSpreadLds<4>::CW + 64 + 10 <= 4 * LqSpreadLds<4>::WS, "solve-phase scratch fits the W area");
+static_assert(LqSpreadLds<2>::SCR <= 2 * LqSpreadLds<2>::WS && LqSpreadLds<3>::SCR <= 3 * LqSpreadLds<3>::WS && LqSpreadLds<4>::SCR <= 4 * LqSpreadLds<4>::WS, "solve-phase scratch fits the W area");
 
 template <int NP> struct LqSpreadDims { static constexpr int n = 4 * NP, G = NP * 4 * NP, GPW = 64 / G; };
 
@@ -174,8 +173,8 @@ __device__ __forceinline__ void lqs_solve_column_2(const double* Cm, const int c
 }
 // NP = 3, 4: lane c < m also owns column c of the LHS; the pivot row and the multipliers of each step go through LDS (the steps of lq_solve_game's S3,
 // the right-looking elimination that reproduces JAMA's accumulation order).  Lanes that duplicate a column publish identical values.
-template <int NP, class X>
-__device__ __forceinline__ void lqs_solve_column_n(LqSpreadLds<NP>& L, const int cl, double x[2 * NP], int& singular)
+template <int NP, class X, class LDS>
+__device__ __forceinline__ void lqs_solve_column_n(LDS& L, const int cl, double x[2 * NP], int& singular)
 {
     constexpr int n = 4 * NP, m = 2 * NP, CW = m + n + 1;
     double col[m], sacc[m];
@@ -267,18 +266,15 @@ __device__ __forceinline__ void lqs_solve_column_n(LqSpreadLds<NP>& L, const int
 // `ln`: the calling lane's index within its game's lane set, 0 .. NP * 4 NP - 1 (lanes beyond it pass the last index: exact duplicates that
 // write the same values to the same places).  L: the game's LDS slice, not in use by any other lane of the wave.  Every lane of the set
 // must call this (and, where several sets share a wave, all of them together: X::sync is wave-wide).  u0: player 0's control at t = 0.
-template <int NP, class X>
-__device__ __forceinline__ void lq_spread_solve(const int ln, const int game, const double dt, const GameSoA& games, LqSpreadLds<NP>& L, double u0[2], int& singular)
+template <int NP, class X, bool SW = false>
+__device__ __forceinline__ void lq_spread_solve(const int ln, const int game, const double dt, const GameSoA& games, LqSpreadLds<NP, SW>& L, double u0[2], int& singular)
 {
     constexpr int n = 4 * NP, m = 2 * NP, CW = m + n + 1;
     const int i = ln / n, r = ln - i * n;
     const int br = r >> 2, rs = r & 3;
     // ---- the game's constants -> LDS; the lane's cost row
     X::sync();                  // (the slice may still be read by the previous game's last sweep)
-    if (ln < n) {
-        L.x0[ln] = games.get(game, ln >> 2, GP_X0 + (ln & 3));
-        L.a4[ln >> 2][ln & 3] = games.get(game, ln >> 2, GP_A4 + (ln & 3));
-    }
+    if (ln < n) L.a4[ln >> 2][ln & 3] = games.get(game, ln >> 2, GP_A4 + (ln & 3));
     if (ln < NP) L.rc[ln] = games.get(game, ln, GP_RC);
     double qc[NP], qv;
     lqs_cost_row<NP>(games, game, i, r, qc, qv);
@@ -334,7 +330,7 @@ __device__ __forceinline__ void lq_spread_solve(const int ln, const int game, co
         {
             int sing = 0;
             if constexpr (NP == 2) lqs_solve_column_2(L.Cm(), cl, x, sing);
-            else lqs_solve_column_n<NP, X>(L, cl, x, sing);
+            else lqs_solve_column_n<NP, X, LqSpreadLds<NP, SW>>(L, cl, x, sing);
             if (sing) singular = 1;
         }
         // ---------------- S4: P rows, alpha and the dense entries of beta = -sum_k B_k alpha_k to LDS (one copy) ----------------
@@ -363,8 +359,12 @@ __device__ __forceinline__ void lq_spread_solve(const int ln, const int game, co
         }
         const double ra0 = fma64(rci, L.al[2 * i], 0.0), ra1 = fma64(rci, L.al[2 * i + 1], 0.0);      // (R_i alpha_i)[a]
         X::sync();                               // Fd, beta, Pm are visible; nothing reads U / lu any more: the W area may be written
+        // (SW: the players take the one W block in turn)
+#pragma unroll 1
+        for (int turn = 0; turn < (SW ? NP : 1); turn++) {
+        const bool mine = !SW || i == turn;
         // ---------------- S6: W = Z_i F, row r (:113-116) -> LDS ----------------
-        {
+        if (mine) {
             double* Wi = L.W(i) + r * n;
 #pragma unroll
             for (int b = 0; b < NP; b++) {       // columns 4 b .. 4 b + 3 = the states of player b
@@ -392,7 +392,7 @@ __device__ __forceinline__ void lq_spread_solve(const int ln, const int game, co
         }
         X::sync();
         // ---------------- S7: Z_i <- (Q_i + P_i'(R_i P_i)) + F'(Z_i F), row r ----------------
-        {
+        if (mine) {
             const double* Wi = L.W(i);
             const double* wp0 = Wi + (4 * br) * n;             // the rows of the lane's own position entries of F
             const double* wp1 = Wi + (4 * br + 1) * n;
@@ -423,6 +423,8 @@ __device__ __forceinline__ void lq_spread_solve(const int ln, const int game, co
                 HK_LQS_FENCE();
             }
         }
+        if (SW) X::sync();          // (the next player's rows go into the same block)
+        }       // turn
         // ---------------- S8: eta_i <- (q_i + P_i'(R_i alpha_i)) + F'(eta_i + Z_i beta) with the NEW Z_i (Q2, :117) ----------------
         {
             double zb = 0.0;
@@ -454,7 +456,7 @@ __device__ __forceinline__ void lq_spread_solve(const int ln, const int game, co
     {
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-        for (int c = 0; c < n; c++) { const double xc = L.x0[c]; s0 = fma64(-L.Pm[0][c], xc, s0); s1 = fma64(-L.Pm[1][c], xc, s1); }
+        for (int c = 0; c < n; c++) { const double xc = games.get(game, c >> 2, GP_X0 + (c & 3)); s0 = fma64(-L.Pm[0][c], xc, s0); s1 = fma64(-L.Pm[1][c], xc, s1); }
         u0[0] = s0 - L.al[0];
         u0[1] = s1 - L.al[1];
     }
@@ -490,91 +492,99 @@ __device__ __forceinline__ void lqs_body(const int block, const int nblocks, con
 }
 
 // IN-WAVE: the multi-player games the egos of ONE wave of env_b1_kernel have just assembled (qn = the lane's player count, 0: none), solved on the spot by
-// that wave — no queue, no solver launch, the controls come back to the ego's own lane (ua, ub), which decodes them into the registers it is about to
-// store.  2-player games two at a time and 3-player games one at a time in `wave_lds`, the wave's own slice of the kart staging area (64 KartS = 5 632 B,
-// dead once phase_assemble has returned); 4-player games, whose W rows alone take 8 KB, by the block's first wave in `block_lds` (the whole staging area)
-// behind a block barrier — every thread of the block must call this.  mygame: env * A + ego of the calling lane.
+// that wave — no queue, no solver launch; the controls come back to the ego's own lane (ua, ub), which decodes them into the registers it is about to
+// store.  Everything happens in `wave_lds`, the wave's own slice of the kart staging area (64 KartS = 5 632 B, dead once phase_assemble has returned):
+// 2-player games three at a time, 3-player games one at a time, 4-player games one at a time with the players taking ONE W block in turn (SW).
+// NO workgroup barrier anywhere (profiles/r06_b_short_call_trace.txt: a barrier at the end of the B1 kernel — the first form pooled a block's games behind
+// one — cost the launch 30 us: the waves of a block finish 20 - 30 % apart, and with the barrier every one of them holds its SIMD slot until the last).
+// mygame: env * A + ego of the calling lane.
+struct LqsOut { double a, b; int sing; };
+// The solves are real CALLS: inlined into env_b1_kernel the three solver bodies made the allocator spill ~300 registers of the kernel around them (the
+// kernel is held to three waves per SIMD); across a call only the handful of values live at the call site are parked, and each body gets an allocation
+// of its own (the 3- / 4-player bodies spill inside themselves: rare games).
+template <int NP, bool SW>
+__device__ __attribute__((noinline)) LqsOut lqs_solve_call(const int ln, const int game, const double dt, const GameSoA games, LqSpreadLds<NP, SW>* L)
+{
+    LqsOut o;
+    double u0[2];
+    int sg = 0;
+    lq_spread_solve<NP, LqWaveSync, SW>(ln, game, dt, games, *L, u0, sg);
+    o.a = u0[0]; o.b = u0[1]; o.sing = sg;
+    return o;
+}
 constexpr size_t LQS_WAVE_LDS = 5632;
-static_assert(2 * sizeof(LqSpreadLds<2>) <= LQS_WAVE_LDS && sizeof(LqSpreadLds<3>) <= LQS_WAVE_LDS, "the wave's slice holds two 2-player games or one 3-player game");
-constexpr size_t LQS_BLOCK_LIST = (sizeof(LqSpreadLds<4>) + 15) & ~(size_t)15;      // block_lds: [LqSpreadLds<4>][count, 16 B][game ids, 256 x 4 B][controls, 256 x 16 B]
-constexpr size_t LQS_BLOCK_LDS = LQS_BLOCK_LIST + 16 + 256 * 4 + 256 * 16;
+static_assert(3 * sizeof(LqSpreadLds<2>) <= LQS_WAVE_LDS && 4 * sizeof(LqSpreadLds<2, true>) <= LQS_WAVE_LDS && sizeof(LqSpreadLds<3>) <= LQS_WAVE_LDS && sizeof(LqSpreadLds<4, true>) <= LQS_WAVE_LDS,
+              "the wave's slice holds three 2-player games, a 3-player game, or a 4-player game with one W block");
 __device__ __forceinline__ double lqs_readlane(const double v, const int k)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), k), hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
     return __hiloint2double(hi, lo);
 }
-// The solves are real CALLS: inlined into env_b1_kernel the three solver bodies made the allocator spill ~300 registers of the kernel around them (the
-// kernel is held to three waves per SIMD); across a call only the handful of values live at the call site are parked, and each body gets an allocation
-// of its own (the 3- / 4-player bodies spill inside themselves: rare games).
-struct LqsOut { double a, b; int sing; };
-template <int NP>
-__device__ __attribute__((noinline)) LqsOut lqs_solve_call(const int ln, const int game, const double dt, const GameSoA games, LqSpreadLds<NP>* L)
-{
-    LqsOut o;
-    double u0[2];
-    int sg = 0;
-    lq_spread_solve<NP, LqWaveSync>(ln, game, dt, games, *L, u0, sg);
-    o.a = u0[0]; o.b = u0[1]; o.sing = sg;
-    return o;
-}
-__device__ __forceinline__ void lqs_inwave(const EnvParams& P, const GameSoA& games, const int qn, const int mygame, unsigned char* wave_lds, unsigned char* block_lds,
+__device__ __forceinline__ void lqs_inwave(const EnvParams& P, const GameSoA& games, const int qn, const int mygame, unsigned char* wave_lds,
                                            double& ua, double& ub, int* status, unsigned long long* gstats)
 {
+    unsigned long long m2 = __ballot(qn == 2), m3 = __ballot(qn == 3), m4 = __ballot(qn == 4);
+    if ((m2 | m3 | m4) == 0ull) return;
     const int lane = threadIdx.x & 63;
     const double dt = (double)P.dt;
-    unsigned long long m2 = __ballot(qn == 2), m3 = __ballot(qn == 3);
-    const unsigned long long m4 = __ballot(qn == 4);
     int sing = 0;
     if (lane == 0) {          // hk_prof_games
         if (m2) atomicAdd(&gstats[2], (unsigned long long)__popcll(m2));
         if (m3) atomicAdd(&gstats[3], (unsigned long long)__popcll(m3));
         if (m4) atomicAdd(&gstats[4], (unsigned long long)__popcll(m4));
     }
-    if ((m2 | m3) != 0ull) {
-        LqSpreadLds<2>* l2 = reinterpret_cast<LqSpreadLds<2>*>(wave_lds);
-        const int slot = (lane >> 4) ? 1 : 0, ln2 = lane & 15;       // lanes 32 .. 63 duplicate the second slot's lane set
+    if (__popcll(m2) > 3) {
+        // two packs (or more) in one wave: FOUR games per pass with the players of a game taking one W block in turn (1 376 B per game) — a pass is a third
+        // longer, but the wave is done in one where three sets would need two, and the launch ends with its slowest wave
+        LqSpreadLds<2, true>* l2 = reinterpret_cast<LqSpreadLds<2, true>*>(wave_lds);
+        const int set = lane >> 4, ln2 = lane & 15;
         while (m2 != 0ull) {
-            const int e0 = __ffsll((long long)m2) - 1; m2 &= m2 - 1ull;
-            int e1 = e0;                                  // (a lone game is solved in both slices)
-            if (m2 != 0ull) { e1 = __ffsll((long long)m2) - 1; m2 &= m2 - 1ull; }
-            const int game = __shfl(mygame, slot == 0 ? e0 : e1, 64);
-            const LqsOut o = lqs_solve_call<2>(ln2, game, dt, games, &l2[slot]);
-            const double a0 = lqs_readlane(o.a, 0), b0 = lqs_readlane(o.b, 0), a1 = lqs_readlane(o.a, 16), b1 = lqs_readlane(o.b, 16);
-            if (lane == e1) { ua = a1; ub = b1; }
-            if (lane == e0) { ua = a0; ub = b0; }
+            int e[4];
+            e[0] = __ffsll((long long)m2) - 1; m2 &= m2 - 1ull;
+#pragma unroll
+            for (int q = 1; q < 4; q++) { e[q] = e[0]; if (m2 != 0ull) { e[q] = __ffsll((long long)m2) - 1; m2 &= m2 - 1ull; } }
+            const int game = __shfl(mygame, set == 0 ? e[0] : (set == 1 ? e[1] : (set == 2 ? e[2] : e[3])), 64);
+            const LqsOut o = lqs_solve_call<2, true>(ln2, game, dt, games, &l2[set]);
+#pragma unroll
+            for (int q = 3; q >= 0; q--) {
+                const double a = lqs_readlane(o.a, 16 * q), b = lqs_readlane(o.b, 16 * q);
+                if (lane == e[q]) { ua = a; ub = b; }
+            }
             sing |= o.sing;
         }
-        LqSpreadLds<3>& l3 = *reinterpret_cast<LqSpreadLds<3>*>(wave_lds);
-        while (m3 != 0ull) {
-            const int e = __ffsll((long long)m3) - 1; m3 &= m3 - 1ull;
-            const int game = __shfl(mygame, e, 64);
-            const LqsOut o = lqs_solve_call<3>(lane < 36 ? lane : 35, game, dt, games, &l3);
-            const double a0 = lqs_readlane(o.a, 0), b0 = lqs_readlane(o.b, 0);
-            if (lane == e) { ua = a0; ub = b0; }
+    } else {
+        LqSpreadLds<2>* l2 = reinterpret_cast<LqSpreadLds<2>*>(wave_lds);
+        const int grp = lane >> 4, set = grp < 3 ? grp : 2, ln2 = lane & 15;          // lanes 48 .. 63 duplicate the third set
+        while (m2 != 0ull) {
+            int e[3];
+            e[0] = __ffsll((long long)m2) - 1; m2 &= m2 - 1ull;
+            e[1] = e[0]; e[2] = e[0];                         // (a set without a game of its own solves the first one again, in its own slice)
+            if (m2 != 0ull) { e[1] = __ffsll((long long)m2) - 1; m2 &= m2 - 1ull; }
+            if (m2 != 0ull) { e[2] = __ffsll((long long)m2) - 1; m2 &= m2 - 1ull; }
+            const int game = __shfl(mygame, set == 0 ? e[0] : (set == 1 ? e[1] : e[2]), 64);
+            const LqsOut o = lqs_solve_call<2, false>(ln2, game, dt, games, &l2[set]);
+#pragma unroll
+            for (int q = 2; q >= 0; q--) {
+                const double a = lqs_readlane(o.a, 16 * q), b = lqs_readlane(o.b, 16 * q);
+                if (lane == e[q]) { ua = a; ub = b; }
+            }
             sing |= o.sing;
         }
     }
 #if HK_GA >= 4
-    if (__syncthreads_or(m4 != 0ull ? 1 : 0)) {          // (the barrier: every wave is done with its own slice of the staging area)
-        int* cnt = reinterpret_cast<int*>(block_lds + LQS_BLOCK_LIST);
-        int* list = cnt + 4;
-        double* res = reinterpret_cast<double*>(block_lds + LQS_BLOCK_LIST + 16 + 256 * 4);
-        if (threadIdx.x == 0) *cnt = 0;
-        __syncthreads();
-        int myidx = -1;
-        if (qn == 4) { myidx = atomicAdd(cnt, 1); list[myidx] = mygame; }
-        __syncthreads();
-        const int n4 = *cnt;
-        if (threadIdx.x < 64) {
-            LqSpreadLds<4>& l4 = *reinterpret_cast<LqSpreadLds<4>*>(block_lds);
-            for (int k = 0; k < n4; k++) {
-                const LqsOut o = lqs_solve_call<4>(lane, list[k], dt, games, &l4);
-                if (lane == 0) { res[2 * k] = o.a; res[2 * k + 1] = o.b; }
-                sing |= o.sing;
-            }
-        }
-        __syncthreads();
-        if (qn == 4) { ua = res[2 * myidx]; ub = res[2 * myidx + 1]; }
+    while (m3 != 0ull) {
+        const int e = __ffsll((long long)m3) - 1; m3 &= m3 - 1ull;
+        const LqsOut o = lqs_solve_call<3, false>(lane < 36 ? lane : 35, __shfl(mygame, e, 64), dt, games, reinterpret_cast<LqSpreadLds<3>*>(wave_lds));
+        const double a = lqs_readlane(o.a, 0), b = lqs_readlane(o.b, 0);
+        if (lane == e) { ua = a; ub = b; }
+        sing |= o.sing;
+    }
+    while (m4 != 0ull) {
+        const int e = __ffsll((long long)m4) - 1; m4 &= m4 - 1ull;
+        const LqsOut o = lqs_solve_call<4, true>(lane, __shfl(mygame, e, 64), dt, games, reinterpret_cast<LqSpreadLds<4, true>*>(wave_lds));
+        const double a = lqs_readlane(o.a, 0), b = lqs_readlane(o.b, 0);
+        if (lane == e) { ua = a; ub = b; }
+        sing |= o.sing;
     }
 #endif
     if (sing && lane == 0) atomicOr(status, 1);

@@ -1,7 +1,7 @@
 // Test infrastructure (tests/test_lq_spread_host.py): hk_lq_spread.h compiled for the HOST.  One thread per lane of a game's lane set (four
 // 2-player games side by side, as in a wave); the wave-level LDS ordering X::sync becomes a barrier, LDS is plain memory.  The arithmetic is the
 // header's own, so the controls must equal the C oracle's bit for bit.
-// stdin: NP n_games, then the GameSoA doubles [NP * GP_FIELDS][n_games]; stdout: u0 of each game as hex floats + the singular flag.
+// stdin: NP n_games sw, then the GameSoA doubles [NP * GP_FIELDS][n_games]; stdout: u0 of each game as hex floats + the singular flag.
 #include <cmath>
 #include <cstdio>
 #include <cstdint>
@@ -26,10 +26,10 @@ static std::unique_ptr<std::barrier<>> bar;
 struct HostSync { static void sync() { bar->arrive_and_wait(); } };
 #include "hk_lq_spread.h"
 
-template <int NP> static int run(int ng, GameSoA G)
+template <int NP, bool SW> static int run(int ng, GameSoA G)
 {
     constexpr int LANES = LqSpreadDims<NP>::G, GPW = LqSpreadDims<NP>::GPW;
-    static LqSpreadLds<NP> L[GPW];
+    static LqSpreadLds<NP, SW> L[GPW];
     const int threads = LANES * GPW;
     bar = std::make_unique<std::barrier<>>(threads);
     for (int base = 0; base < ng; base += GPW) {
@@ -41,7 +41,7 @@ template <int NP> static int run(int ng, GameSoA G)
             th.emplace_back([&, l] {
                 const int slot = l / LANES, ln = l % LANES;
                 const int game = base + slot < ng ? base + slot : ng - 1;          // idle slots recompute the last game
-                lq_spread_solve<NP, HostSync>(ln, game, (double)0.02f, G, L[slot], &u[(size_t)l * 2], sing[l]);
+                lq_spread_solve<NP, HostSync, SW>(ln, game, (double)0.02f, G, L[slot], &u[(size_t)l * 2], sing[l]);
             });
         for (auto& t : th) t.join();
         for (int s = 0; s < GPW && base + s < ng; s++) {
@@ -55,10 +55,11 @@ template <int NP> static int run(int ng, GameSoA G)
 
 int main()
 {
-    int NP = 0, ng = 0;
-    if (scanf("%d %d", &NP, &ng) != 2 || NP < 2 || NP > 4 || ng < 1) return 1;
+    int NP = 0, ng = 0, sw = 0;          // sw: the players take ONE W block in turn (LqSpreadLds<NP, true>: the in-wave form of env_b1_kernel's 4-player games)
+    if (scanf("%d %d %d", &NP, &ng, &sw) != 3 || NP < 2 || NP > 4 || ng < 1) return 1;
     std::vector<double> d((size_t)NP * GP_FIELDS * ng);
     for (auto& x : d) { if (scanf("%lf", &x) != 1) return 2; }
     GameSoA G{d.data(), (size_t)ng};
-    return NP == 2 ? run<2>(ng, G) : (NP == 3 ? run<3>(ng, G) : run<4>(ng, G));
+    if (sw) return NP == 2 ? run<2, true>(ng, G) : (NP == 3 ? run<3, true>(ng, G) : run<4, true>(ng, G));
+    return NP == 2 ? run<2, false>(ng, G) : (NP == 3 ? run<3, false>(ng, G) : run<4, false>(ng, G));
 }

@@ -65,13 +65,14 @@ def _games(rng, N, ng, inactive_others=False):
     return d, ref
 
 
-@pytest.mark.parametrize("N", [2, 3, 4])
+@pytest.mark.parametrize("N,serial_w", [(2, 0), (3, 0), (4, 0), (4, 1), (2, 1)])
 @pytest.mark.parametrize("inactive_others", [False, True])
-def test_spread_solver_arithmetic_equals_the_oracle(harness, N, inactive_others):
+def test_spread_solver_arithmetic_equals_the_oracle(harness, N, serial_w, inactive_others):
+    """serial_w: the players take one W block in turn (the form env_b1_kernel's waves use for 4-player games, 5 KB of LDS instead of 11)"""
     rng = np.random.default_rng(500 + 10 * N + inactive_others)
     ng = 10 if N == 2 else 3           # (N = 2: two full groups of four games and a ragged last one)
     d, ref = _games(rng, N, ng, inactive_others)
-    inp = "%d %d\n" % (N, ng) + "\n".join(repr(float(x)) for x in d.ravel())
+    inp = "%d %d %d\n" % (N, ng, serial_w) + "\n".join(repr(float(x)) for x in d.ravel())
     out = subprocess.run([harness], input=inp, capture_output=True, text=True, check=True).stdout.strip().splitlines()
     assert len(out) == ng
     for g, line in enumerate(out):

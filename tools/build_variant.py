@@ -42,6 +42,7 @@ def main():
         procs.append(subprocess.Popen([hipcc] + base + defs + ["--cuda-device-only", "-S", os.path.join(ge.CSRC, u), "-o", o[:-2] + ".s"], stderr=subprocess.DEVNULL))
     assert all(p.wait() == 0 for p in procs)
     lib = os.path.join(ROOT, "build", "libhk_%s.so" % name)
+    objs.append(os.path.join(ge.OBJ_DIR, "hk_build_info.o"))          # hk_build_info(): the product's record (a variant is an experiment and says so in its name)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib] + objs)
     # the code-generation guard (tools/check_spill_exec.py): a variant may be AFFECTED — it is an experiment, not the product — and says so
     import check_spill_exec as guard

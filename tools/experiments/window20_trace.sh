@@ -10,16 +10,22 @@ rows = list(csv.DictReader(open(glob.glob("$O/**/*kernel_trace.csv", recursive=T
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def nm(r):
     n = r["Kernel_Name"]
-    return "tick" if "env_run_kernel" in n else "b1" if "env_b1" in n else "lqn" if "lqn_round" in n else n.split("(")[0].split("::")[-1][:22]
-# the timed pass is the FIRST pass: find the first reset, then the pre-roll, then warm-up (5 ticks), then the 20-tick call: print the kernels between the
-# second and the third env_arm / env_check after the pre-roll... simply: print every kernel whose start lies within 3 ms after the first 'env_check' that follows > 200 tick launches
-cnt = 0; t_mark = None
-for k, r in enumerate(rows):
-    if nm(r) == "tick": cnt += 1
-    if cnt > 250 and nm(r) in ("env_check_kernel",) and t_mark is None: t_mark = int(r["End_Timestamp"]); break
-sel = [r for r in rows if t_mark is not None and t_mark <= int(r["Start_Timestamp"]) <= t_mark + 4000000]
-t0 = int(sel[0]["Start_Timestamp"]) if sel else 0
-for r in sel[:90]:
+    return "tick" if "env_run_kernel" in n else "b1" if "env_b1" in n else "lqn" if "lqn_" in n else n.split("(")[0].split("::")[-1][:22]
+# the timed pass is the FIRST pass: reset, pre-roll (one 512-tick call), warm-up, then the 20-tick call = everything from the end of the kernel before the call's
+# first launch (an env_arm_kernel, or — since round 6 folds the arming into the first tick launches — the first tick launch after the warm-up's last) to its last launch
+ticks = [k for k, r in enumerate(rows) if nm(r) == "tick"]
+# the pre-roll issues >= 250 tick launches; the warm-up (5 ticks) 2 - 4 more; the timed call begins with the next launch after a pause of the stream (host sync): find the first
+# gap > 150 us between consecutive kernels after 250 tick launches have gone by, twice (pre-roll -> warm-up is back to back: no gap; warm-up -> timed call: hk_synchronize + barrier)
+seen = 0; start = None
+for k in range(1, len(rows)):
+    if nm(rows[k - 1]) == "tick": seen += 1
+    half = str(int(d["config"]["envs_per_gpu"]) * 4 // 2)          # the timed 20-tick call runs as two halves (the 5-tick warm-up as one batch)
+    if seen >= 250 and int(rows[k]["Start_Timestamp"]) - int(rows[k - 1]["End_Timestamp"]) > 150000 and (nm(rows[k]) == "env_arm_kernel" or (nm(rows[k]) == "tick" and rows[k].get("Grid_Size_X", rows[k].get("Grid_Size")) == half)):
+        start = k; break
+if start is None: raise SystemExit("timed call not found")
+t0 = int(rows[start]["Start_Timestamp"])
+for r in rows[start:start + 60]:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
-    print("%-24s q%-2s start %8.1f us  dur %6.1f us  grid %s" % (nm(r), r.get("Queue_Id"), s / 1e3, (e - s) / 1e3, r.get("Grid_Size_X", r.get("Grid_Size"))))
+    if s > 1500000: break
+    print("%-24s q%-2s start %8.1f us  end %8.1f  dur %6.1f us  grid %s" % (nm(r), r.get("Queue_Id"), s / 1e3, e / 1e3, (e - s) / 1e3, r.get("Grid_Size_X", r.get("Grid_Size"))))
 PY
