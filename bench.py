@@ -565,15 +565,19 @@ def bench_lqng(a, D, hk):
         dt_1 = short_calls(256, 1)
         dt_2 = short_calls(128, 2)
         dt_20 = short_calls(16, 20)
-        # the same protocol window with the batch on ONE stream (HK_NO_SPLIT=1, read in hk_create): what the default schedule — two halves on
+        # the same protocol window with the batch on ONE stream (HK_SPLIT=0, read in hk_create): what the default schedule — two halves on
         # two streams, a half's solver launch hidden behind the other half's tick launch — buys; and the per-launch roofline of the tick
         # kernel with the GPU to itself
         env.close()                                       # (its streams go back first)
-        os.environ["HK_NO_SPLIT"] = "1"
+        old_split = os.environ.get("HK_SPLIT")
+        os.environ["HK_SPLIT"] = "0"
         try:
             env2 = hk.RacingEnv(hk.make_config(E, A, jitter_seed=seed, env_id_base=D.rank * E, device_id=D.local_rank))
         finally:
-            del os.environ["HK_NO_SPLIT"]
+            if old_split is None:
+                del os.environ["HK_SPLIT"]
+            else:
+                os.environ["HK_SPLIT"] = old_split
         env2.reset(); env2.step(STEADY_TICK); env2.synchronize()
         env2.prof_enable(True); env2.prof_reset()
         dt_one = timed_ticks(D, env2, 3072)
@@ -591,7 +595,7 @@ def bench_lqng(a, D, hk):
                                           "env_run_kernel": {"launches": one_run[1], "avg_launch_ms": one_ms, "algorithmic_bytes_per_launch": one_algo,
                                                              "achieved_gbs": one_algo / 1e9 / (one_ms * 1e-3) if one_ms > 0 else 0.0,
                                                              "frac_hbm_peak": (one_algo / 1e9 / (one_ms * 1e-3) / HBM_PEAK_GBS) if one_ms > 0 else 0.0},
-                                          "note": "HK_NO_SPLIT=1 (not the default): the whole batch on one stream, the tick kernel alone on the GPU — its own per-launch roofline"},
+                                          "note": "HK_SPLIT=0 (not the default): the whole batch on one stream, the tick kernel alone on the GPU — its own per-launch roofline"},
             "baseline_protocol_ticks_512_3584": {"value": E * D.world * 3072 / dt_full, "unit": "env-steps/s", "seconds": dt_full,
                                                  "kernel_total_ms": {k: v[0] for k, v in prof_full.items() if v[1]},
                                                  "launches": {k: v[1] for k, v in prof_full.items() if v[1]},

@@ -83,56 +83,40 @@ struct Prof {
 
 }  // namespace
 
-#ifndef HK_LAZY_MIN_TICKS
-#define HK_LAZY_MIN_TICKS 64      /* calls at least this long issue the rounds a spread field needs and finish the laggards after a look at the device */
-#endif
-// Scheduling switches: read from the environment ONCE, in hk_create, into the handle (listed in include/hk.h).  None of them changes a
-// result bit; they exist for the A/B measurements under profiles/ and for two tests.
+// Scheduling switches: read from the environment ONCE, in hk_create, into the handle (listed in include/hk.h).  None of them changes a result bit; they
+// exist for the same-box A/B measurements under profiles/ and for the parity tests that run every schedule against the oracle.  Round 6 retired the ones whose
+// A/B is settled (HK_PARK, HK_NO_EAGER, HK_TAIL_WORST_CASE, HK_KEEP_LAST_SOLVE, HK_RUN_CAP_SHORT / _SPREAD, HK_SPLIT_WAYS, HK_SPLIT_MIN_TICKS, HK_LAZY_MIN_TICKS,
+// HK_REGROUP_ROUNDS, HK_LQN_SPARSE_BLOCKS, HK_NO_SPLIT, HK_NO_FISSION_SHAPED / _MCTS / _CHUNKS, HK_DEBUG_NO_CHECK, HK_STAMPS_DUMP) with their code paths; the numbers
+// they were settled with are in profiles/README.md.  hk_schedule_info() reports what a call ran.
+constexpr int LAZY_MIN_TICKS = 64;        // calls at least this long issue the rounds a spread field needs and finish the laggards after a look at the device
+constexpr int SPLIT_MIN_TICKS = 8;        // calls of plain handles at least this long run as two halves on two streams (a 20-tick call: 1 050 -> 1 120 M env-steps/s, round 4)
+constexpr int SPLIT_WAYS = 2;             // parts of a split batch (three / four parts on as many streams: 1 504 / 1 107 M against 1 532, round 4)
+constexpr int LQN_SPARSE_BLOCKS = 1024;   // workgroups per queue of a solver launch once the field has spread
 struct Tuning {
-    bool eager = true;           // HK_NO_EAGER=1: no eager assembly at the end of a launch's budget (hk_env_run.h)
+    bool fission = true;         // HK_FISSION=0: every handle on the fused tick kernel (phase B1 inside the tick loop) instead of tick kernel + env_b1_kernel per solve cadence
+    int split = -1;              // HK_SPLIT=1: the batch as two halves on two streams in EVERY call of a plain handle; 0: one stream always; unset: calls of >= SPLIT_MIN_TICKS ticks, and while the field stands close
+    int inwave = -1;             // HK_INWAVE=0: multi-player games always go through the queues and a solver launch (the schedule before round 6); 1: env_b1_kernel solves them in-wave in every round (tests); unset: in-wave while the games-per-launch meter says the field has spread
+    bool lqn_spread = true;      // HK_LQN=pair: the solver launch of a spread field stays on the pair / matrix-core kernel (the schedule before round 6)
     bool lazy = true;            // HK_FIXED_ROUNDS=1: every call issues the worst-case round count up front (no look at the device)
-    bool mcts_pause = true;      // HK_MCTS_NO_PAUSE=1: long calls of planner handles keep the deadline schedule
-    bool want_split = false;     // HK_SPLIT=1: the batch as two halves on two streams in EVERY call of a plain handle (short ones too)
-    bool split_long = true;      // the default: ... in the long (lazily completed) calls of plain handles; HK_NO_SPLIT=1 / HK_SPLIT=0 switch it off
-    int lqn_sparse_blocks = 1024;   // HK_LQN_SPARSE_BLOCKS: workgroups per queue of a solver launch once the field has spread
-    int inwave = -1;                // HK_INWAVE=0: multi-player games always go through the queues and a solver launch (the schedule before round 6); 1: env_b1_kernel solves them in-wave in every round (tests); unset: in-wave while the games-per-launch meter says the field has spread
-    bool lqn_spread = true;         // HK_LQN=pair: the solver launch of a spread field stays on the pair / matrix-core kernel (the schedule before round 6)
-    int split_ways = 2;          // HK_SPLIT_WAYS: parts of a split batch (2 .. SPLIT_WAYS_MAX), each on its own stream
-    int split_min_ticks = 8;     // HK_SPLIT_MIN_TICKS: ... and in the calls of at least this many ticks that are not (a 20-tick call: 1 050 -> 1 120 M env-steps/s)
-    bool no_split = false;       // HK_NO_SPLIT=1: one stream always, also while the field stands close
-    int run_cap_spread = hk::RUN_CAP_SPREAD;   // HK_RUN_CAP_SPREAD: ticks per launch of long calls on a spread field (4 .. 64)
-    int run_cap_short = 4;       // HK_RUN_CAP_SHORT: ticks per launch of short calls of plain handles
-    int regroup_rounds = hk::REGROUP_ROUNDS;   // HK_REGROUP_ROUNDS: rounds between two re-assignments of the lane groups
-    bool keep_last_solve = false; // HK_KEEP_LAST_SOLVE=1: the last round of a fixed-round call launches its (empty) solver kernel, as before
-    bool tail_worst_case = false; // HK_TAIL_WORST_CASE=1: the laggards' batches issue a round per cadence of the slowest env (the older schedule)
-    int lazy_min_ticks = HK_LAZY_MIN_TICKS;    // HK_LAZY_MIN_TICKS: calls at least this long complete lazily (a look at the device instead of the worst-case rounds)
-    bool fission_chunks = true;  // ... and the short fixed-round calls of planner / actor handles (HK_NO_FISSION_CHUNKS: the fused kernel)
-    bool fission_mcts = true;    // ... and long calls of planner handles with LQNG low levels (HK_NO_FISSION_MCTS: the fused kernel for those)
-    bool mcts_overlap = true;    // HK_MCTS_NO_OVERLAP=1: long calls of planner handles launch a replan's searches when its stretch of rounds has ended, on the handle's stream (the schedule before round 5)
-    bool fission_shaped = true;  // HK_NO_FISSION_SHAPED=1: handles with reward shaping / Training mode keep the fused kernel (round 5: they run the fission schedule too)
     bool optimistic = true;      // HK_NO_OPTIMISTIC=1: fixed-round calls always issue the worst-case round count (the schedule before round 5)
     int optimistic_skew = 0;     // HK_OPTIMISTIC_SKEW=k (tests): the believed episode step is off by k, so the exact plans are wrong and the recovery path runs
-    bool park = false;           // HK_PARK=1: plain 3- / 4-agent handles run the fused kernel with LDS parking (hk_env_run.h PARK) instead of the fission schedule
-    bool fission = true;         // plain 3- / 4-agent handles run the tick kernel without phase B1 + env_b1_kernel per solve cadence (hk_env_run.h); HK_FISSION=0: the fused kernel
+    bool mcts_pause = true;      // HK_MCTS_NO_PAUSE=1: long calls of planner handles keep the deadline schedule
+    bool mcts_overlap = true;    // HK_MCTS_NO_OVERLAP=1: long calls of planner handles launch a replan's searches when its stretch of rounds has ended, on the handle's stream (the schedule before round 5)
+    int mcts_side_waves = -1;    // HK_MCTS_SIDE_WAVES=4 / 8 / 0: waves per workgroup of a search launch that runs beside tick launches (unset: 4 where a tick block fits beside one, else 8)
     int debug_max_rounds = 0;    // HK_DEBUG_MAX_ROUNDS (diagnostic): cap on the rounds of a call, to look at the state in between
-    bool debug_no_check = false; // HK_DEBUG_NO_CHECK (diagnostic): getters do not fail on the "did not complete" flag
-    bool stamps_dump = false;    // HK_STAMPS_DUMP (diagnostic builds, -DHK_STAMPS)
     void read()
     {
         auto flag = [](const char* n) { return std::getenv(n) != nullptr; };
         auto num = [](const char* n, int dflt, int lo, int hi) { const char* e = std::getenv(n); const int v = e ? std::atoi(e) : dflt; return v >= lo && v <= hi ? v : dflt; };
-        eager = !flag("HK_NO_EAGER"); lazy = !flag("HK_FIXED_ROUNDS"); mcts_pause = !flag("HK_MCTS_NO_PAUSE");
-        { const char* sp = std::getenv("HK_SPLIT"); want_split = sp && std::atoi(sp) != 0; no_split = flag("HK_NO_SPLIT"); split_long = !no_split && !(sp && std::atoi(sp) == 0); } split_min_ticks = num("HK_SPLIT_MIN_TICKS", 8, 1, 1 << 20); split_ways = num("HK_SPLIT_WAYS", 2, 2, hk::SPLIT_WAYS_MAX); lqn_sparse_blocks = num("HK_LQN_SPARSE_BLOCKS", 1024, 16, 4096); tail_worst_case = flag("HK_TAIL_WORST_CASE"); keep_last_solve = flag("HK_KEEP_LAST_SOLVE");
-        run_cap_spread = num("HK_RUN_CAP_SPREAD", hk::RUN_CAP_SPREAD, 4, 64);
-        run_cap_short = num("HK_RUN_CAP_SHORT", 4, 4, 64);
-        regroup_rounds = num("HK_REGROUP_ROUNDS", hk::REGROUP_ROUNDS, 1, 1 << 20);
-        lazy_min_ticks = num("HK_LAZY_MIN_TICKS", HK_LAZY_MIN_TICKS, 1, 1 << 20);
-        debug_max_rounds = num("HK_DEBUG_MAX_ROUNDS", 0, 0, 1 << 20);
-        debug_no_check = flag("HK_DEBUG_NO_CHECK"); stamps_dump = flag("HK_STAMPS_DUMP");
-        { const char* f = std::getenv("HK_FISSION"); fission = !(f && std::atoi(f) == 0); fission_mcts = !flag("HK_NO_FISSION_MCTS"); fission_chunks = !flag("HK_NO_FISSION_CHUNKS"); park = flag("HK_PARK"); mcts_overlap = !flag("HK_MCTS_NO_OVERLAP"); fission_shaped = !flag("HK_NO_FISSION_SHAPED"); }
-        { const char* e = std::getenv("HK_LQN"); lqn_spread = !(e && std::strcmp(e, "pair") == 0); }
+        fission = num("HK_FISSION", 1, 0, 1) != 0;
+        split = num("HK_SPLIT", -1, 0, 1);
         inwave = num("HK_INWAVE", -1, 0, 1);
+        { const char* e = std::getenv("HK_LQN"); lqn_spread = !(e && std::strcmp(e, "pair") == 0); }
+        lazy = !flag("HK_FIXED_ROUNDS");
         optimistic = !flag("HK_NO_OPTIMISTIC"); optimistic_skew = num("HK_OPTIMISTIC_SKEW", 0, 0, 3);
+        mcts_pause = !flag("HK_MCTS_NO_PAUSE"); mcts_overlap = !flag("HK_MCTS_NO_OVERLAP");
+        { const char* e = std::getenv("HK_MCTS_SIDE_WAVES"); mcts_side_waves = e ? (std::atoi(e) == 4 ? 4 : (std::atoi(e) == 0 ? 0 : 8)) : -1; }
+        debug_max_rounds = num("HK_DEBUG_MAX_ROUNDS", 0, 0, 1 << 20);
     }
 };
 
@@ -176,15 +160,22 @@ struct hk_context {
     hipStream_t mcts_stream = nullptr;                  // the search launch of a replan runs here, beside the tick launches up to the plans' deadline (step_ticks, pause mode)
     hipEvent_t ev_mcts_go = nullptr, ev_mcts_done = nullptr;
     int* done_host = nullptr;      // pinned: [0] max ticks left over the envs, [1] an env waits for a queued game
-    // the games-per-launch meter (hk_env_device.h GAME_METER): env_b1_kernel counts the multi-player games it assembles and its launches; a copy travels to
-    // pinned memory every METER_TICKS ticks, WITHOUT a sync — a heuristic may be a call late.  Few games per launch: the B1 waves solve their own (in-wave);
-    // many (envs that reset bring packs back): queues + solver launch.
-    unsigned long long* meter_host = nullptr;     // pinned [2]: games, B1 launches (cumulative)
+    // the games-per-launch meter (hk_env_device.h GAME_METER): env_b1_kernel keeps, per part of the batch, a decaying maximum of the multi-player games its
+    // launches assembled.  A copy travels to pinned memory with every look at the device (lazy completion, the stretches of a planner handle's long call) and,
+    // WITHOUT a sync, after a short call — a heuristic may be a call late.  Few games per launch: the B1 waves solve their own (in-wave); many (the Complex
+    // track's traffic, envs that reset and bring packs back): queues + the pair solver's launch, 32 games a wave.
+    unsigned long long* meter_host = nullptr;     // pinned [4 * GAME_METER_PARTS]
     hipStream_t meter_stream = nullptr;
-    unsigned long long meter_seen[2] = {0, 0};
-    int meter_ticks = 0;           // ticks issued since the last copy
-    long long meter_req_tick[2] = {-1, -1};       // ticks since the last reset of every env at the last two copy requests (an interval that began in the bulk phase is ignored)
-    bool meter_sparse = true;      // what the last two copies said
+    int meter_ticks = 0;           // ticks issued since the last copy of a short call
+    // Long lazily completed calls (hk_step of thousands of ticks): the host issues far ahead of the GPU and would hold the schedule it chose on entry through
+    // whatever the field turns into (second episodes: the resets bring every pack back at once).  It therefore stays at most THROTTLE_AHEAD rounds ahead — a
+    // marker event every THROTTLE_EVERY rounds, a wait for the marker two back — and looks at the meter at every marker.  The GPU never drains.
+    bool throttle = false;
+    hipEvent_t ev_thr[4] = {};
+    bool thr_valid[4] = {};
+    bool meter_sparse = true;      // what the last copy said (until one arrives: sparse once the field has had BULK_TICKS to spread — launch_b1's rule)
+    bool meter_dense = false;      // ... so many games per launch that a solver launch wants the pair solver's 32 games a wave
+    int meter_games = 0;           // ... the decaying maximum itself (sizes the spread solver's grid)
     std::string sched;             // hk_schedule_info: the schedule of the last hk_step (written by step_ticks)
     void* pol_scratch = nullptr;   // hk_policy_forward staging
     size_t pol_scratch_bytes = 0;
@@ -198,6 +189,8 @@ struct hk_context {
 };
 
 static int finish_ticks(hk_context* h);      // lazy completion of the last hk_step (defined with step_ticks)
+static int meter_copy(hk_context* h, bool in_order);      // the games-per-launch meter on its way to pinned memory (defined with step_ticks)
+static int throttle_mark(hk_context* h, int r);           // long lazy calls: stay a bounded number of rounds ahead of the GPU, look at the meter (defined with step_ticks)
 static int verify_optimistic(hk_context* h); // the completion guard of optimistic fixed-round calls, looked at; laggards finished (defined with step_ticks)
 // a search launch that runs on the side stream beside the chunks of a planner + actor handle (step_ticks): the handle's stream waits for it — before another
 // search launch (they share the tree arena), before the chunk that uses its plans, before anything reads the planner state
@@ -294,14 +287,15 @@ int hk_create(const hk_config* cfg, hk_handle* out)
     h->tune.read();
     if (cfg) {
         h->cfg = *cfg;
-        h->dev.regroup_rounds = h->tune.regroup_rounds;
+        h->dev.regroup_rounds = hk::REGROUP_ROUNDS;
         rc = hk::env_create(h->cfg, h->sections, h->walls, h->dev, h->stream, h->err);
         if (rc) { g_last_error = h->err; hk_destroy(h); return rc; }
         h->env_ready = true;
         if (hipHostMalloc((void**)&h->done_host, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) h->done_host = nullptr;   // (no pinned memory: fixed rounds)
         else { h->done_host[0] = 0; h->done_host[1] = 0; }
-        if (hipHostMalloc((void**)&h->meter_host, 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) h->meter_host = nullptr;
-        else { h->meter_host[0] = 0; h->meter_host[1] = 0; }
+        if (hipHostMalloc((void**)&h->meter_host, 4 * hk::GAME_METER_PARTS * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) h->meter_host = nullptr;
+        else std::memset(h->meter_host, 0, 4 * hk::GAME_METER_PARTS * sizeof(unsigned long long));
+        (void)hipStreamCreateWithFlags(&h->meter_stream, hipStreamNonBlocking);          // (here, not inside a call: creating a stream takes milliseconds)
     }
     *out = h;
     return HK_OK;
@@ -314,6 +308,7 @@ void hk_destroy(hk_handle h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->done_host) (void)hipHostFree(h->done_host);
     if (h->meter_stream) { (void)hipStreamSynchronize(h->meter_stream); (void)hipStreamDestroy(h->meter_stream); }
+    for (hipEvent_t e : h->ev_thr) if (e) (void)hipEventDestroy(e);
     if (h->meter_host) (void)hipHostFree(h->meter_host);
     hk::env_destroy(h->dev);
     if (h->d_status) (void)hipFree(h->d_status);
@@ -469,7 +464,9 @@ static int issue_rounds(hk_handle h, int rounds)
     hipEvent_t e = h->prof.begin(h->stream);
     bool first = true;
     for (int r = 0; r < rounds; r++) {
-        int rc = hk::env_launch_run(h->dev, h->cfg, h->stream, h->err);
+        int rc = throttle_mark(h, r);
+        if (rc) return rc;
+        rc = hk::env_launch_run(h->dev, h->cfg, h->stream, h->err);
         if (rc) { g_last_error = h->err; return rc; }
         e = h->prof.chain(0, e, first, h->stream);
         if (h->dev.exact_plan && ++h->exact_idx == h->exact_total) { h->dev.b1_due = false; h->dev.round += 1; first = false; continue; }     // (the plan's last round: no solve tick is left in the call)
@@ -494,7 +491,7 @@ static int issue_rounds(hk_handle h, int rounds)
 // else touches the state (the guard kernel, a regroup, a getter).
 static int issue_rounds_split(hk_handle h, int rounds)
 {
-    const int K = h->tune.split_ways;
+    const int K = SPLIT_WAYS;
     for (int k = 0; k < K - 1; k++) {
         if (!h->qstream[k]) HK_HIP(h, hipStreamCreateWithFlags(&h->qstream[k], hipStreamNonBlocking));
         if (!h->ev_join[k]) HK_HIP(h, hipEventCreateWithFlags(&h->ev_join[k], hipEventDisableTiming));
@@ -528,6 +525,7 @@ static int issue_rounds_split(hk_handle h, int rounds)
     bool b1due[hk::SPLIT_WAYS_MAX] = {}, inw[hk::SPLIT_WAYS_MAX] = {};
     auto part = [&](int k) { h->dev.slot0 = cut[k]; h->dev.slot1 = cut[k + 1]; h->dev.qbase = 2 * k; h->dev.round = h->round_half[k]; };
     for (int r = 0; r < rounds && rc == HK_OK; r++) {
+        if ((rc = throttle_mark(h, r))) break;
         const bool plan_last = h->dev.exact_plan && h->exact_idx + 1 == h->exact_total;      // (the plan's last round: the tick launches alone)
         for (int k = 0; k < K && rc == HK_OK; k++) {
             part(k);
@@ -579,6 +577,7 @@ static int issue_check(hk_handle h, bool lazy)
     int rc = hk::env_launch_check(h->dev, h->cfg, lazy, h->stream, h->err);
     if (rc) { g_last_error = h->err; return rc; }
     if (lazy) HK_HIP(h, hipMemcpyAsync(h->done_host, h->dev.status + 1, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (lazy) return meter_copy(h, true);          // (the caller synchronises before it looks at either)
     return HK_OK;
 }
 
@@ -587,7 +586,7 @@ static int issue_check(hk_handle h, bool lazy)
 static int finish_ticks(hk_handle h)
 {
     const int cadence = h->cfg.num_agents > 2 ? 4 : 1;
-    h->dev.last_solve_skippable = false; h->dev.guard_rounds_left = 0; h->dev.exact_plan = false;      // (the laggards' rounds are plain rounds)
+    h->dev.last_solve_skippable = false; h->dev.guard_rounds_left = 0; h->dev.exact_plan = false; h->throttle = false;      // (the laggards' rounds are plain rounds)
     for (int guard = 0; guard < 1024 && h->step_pending; guard++) {
         HK_HIP(h, hipStreamSynchronize(h->stream));
         const int maxleft = h->done_host[0], waiting = h->done_host[1];
@@ -599,7 +598,7 @@ static int finish_ticks(hk_handle h)
         // batch ends with a look at the device anyway, and two thirds of the worst-case rounds used to find nothing to do (94 of 141 in
         // the headline's 3 072-tick call, ~18 us each).  An env that does park on every solve tick still gets a third of its ticks per batch.
         const int cap = (h->dev.fission && cadence == 1) ? 1 : std::max(h->dev.P.run_cap, cadence);      // (2-agent fission: a tick per round)
-        rc = issue_rounds(h, h->tune.tail_worst_case ? (maxleft + cadence - 1) / cadence + 1 : (maxleft + cap - 1) / cap + 1);
+        rc = issue_rounds(h, (maxleft + cap - 1) / cap + 1);
         if (rc) return rc;
         rc = issue_check(h, true);
         if (rc) return rc;
@@ -615,35 +614,52 @@ static bool inwave_allowed(hk_handle h)
     if (!h->dev.fission || h->dev.P.any_lqr == 0 || h->cfg.num_agents < 3 || h->cfg.num_agents > 4 || h->tune.inwave == 0) return false;
     return h->tune.inwave == 1 || h->meter_sparse;
 }
-constexpr int METER_TICKS = 64;
-// look at the last copy of the games-per-launch meter (no sync: whatever has arrived) and ask for the next one.  A copy describes the launches between
-// the request before it and its own request; an interval that began while the field stood close after a reset of every env (BULK_TICKS: nearly every ego
-// holds a game, and those rounds use the queues whatever the meter says) tells nothing about the spread field and is ignored — the driver's
-// window, 517 ticks after the reset, used to run on the race start's average (profiles/r06_b_short_call_trace.txt).
-static int meter_update(hk_handle h, int n_ticks)
+constexpr int METER_TICKS = 16;
+// the meter's copy to pinned memory: on the handle's stream (the caller synchronises: the copy is current) or, after a short call, on a stream of its own
+// (the copy orders nothing and must not stand between two launches of the handle's stream; it shows whatever the device has reached)
+static int meter_copy(hk_handle h, bool in_order)
 {
     if (!h->meter_host || !h->dev.game_stats) return HK_OK;
-    const long long now = (long long)h->dev.ticks_since_reset + h->dev.call_ticks;          // ticks issued since the last reset of every env
-    if (now < h->meter_req_tick[1]) { h->meter_req_tick[0] = h->meter_req_tick[1] = -1; h->meter_sparse = true; }      // (a reset of every env since the last request)
-    const unsigned long long g = h->meter_host[0], l = h->meter_host[1];
-    if (l > h->meter_seen[1] && g >= h->meter_seen[0] && h->meter_req_tick[0] >= hk::BULK_TICKS) {
-        // games per B1 launch over the interval, against the waves of a launch: in-wave pays while at most every other wave holds a game
-        const double per_launch = (double)(g - h->meter_seen[0]) / (double)(l - h->meter_seen[1]);
-        const double envs_per_launch = h->cfg.num_envs >= 8192 ? h->cfg.num_envs * 0.5 : h->cfg.num_envs;      // (two halves on two streams: issue_rounds_split)
-        // (measured, profiles/r06_b_short_call_trace.txt: at 262 games per half-batch launch — ticks 517 .. 537 of the race — the two schedules are level, at 39 the in-wave
-        // one is 3.5 % ahead: the threshold sits at one game per 64 envs of a launch)
-        h->meter_sparse = per_launch <= envs_per_launch / 64.0;
+    hipStream_t st = h->stream;
+    if (!in_order) {
+        if (!h->meter_stream) return HK_OK;
+        st = h->meter_stream;
     }
-    if (l != h->meter_seen[1] || g != h->meter_seen[0]) { h->meter_seen[0] = g; h->meter_seen[1] = l; }       // (also after hk_prof_reset zeroed the counters)
-    h->meter_ticks += n_ticks;
-    if (h->meter_ticks >= METER_TICKS && h->dev.fission) {
-        h->meter_ticks = 0;
-        h->meter_req_tick[0] = h->meter_req_tick[1]; h->meter_req_tick[1] = now;
-        // (on a stream of its own: the copy orders nothing and must not stand between two launches of the handle's stream)
-        if (!h->meter_stream) HK_HIP(h, hipStreamCreateWithFlags(&h->meter_stream, hipStreamNonBlocking));
-        HK_HIP(h, hipMemcpyAsync(h->meter_host, h->dev.game_stats + hk::GAME_METER, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->meter_stream));
-    }
+    HK_HIP(h, hipMemcpyAsync(h->meter_host, h->dev.game_stats + hk::GAME_METER, 4 * hk::GAME_METER_PARTS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     return HK_OK;
+}
+// what the last copy says: at most one game per 64 envs of a launch (measured, profiles/r06_b_short_call_trace.txt: at 262 games per half-batch launch of
+// 32 768 envs the two schedules are level, at 39 the in-wave one is 3.5 % ahead; profiles/r06_c_dense_fields.txt: thousands per launch — the Complex track
+// under the planner, second episodes — want the pair solver)
+static void meter_look(hk_handle h)
+{
+    if (!h->meter_host) return;
+    unsigned long long worst = 0;
+    for (int p = 0; p < hk::GAME_METER_PARTS; p++) worst = std::max(worst, h->meter_host[4 * p + 3]);
+    // (plain handles of >= 8 192 envs run as SPLIT_WAYS parts in every call long enough to matter; planner / actor handles as one batch)
+    const double envs_per_launch = (h->cfg.num_envs >= 8192 && h->dev.mcts.st == nullptr && h->n_policies == 0) ? h->cfg.num_envs / (double)SPLIT_WAYS : (double)h->cfg.num_envs;
+    // Three regimes (same-box A/Bs of profiles/r06_b_short_call_trace.txt and r06_c_dense_fields.txt), by the games of a launch of `envs_per_launch` envs:
+    //   up to 1 per 128 envs   in-wave (39 per half-batch launch in the protocol window: 3.5 % ahead of a solver launch; level with it at 262 - 400, ticks 517 .. 537)
+    //   up to 1 per 8 envs     queues + lqn_spread_kernel, its grid sized for the count (a few hundred games: 1 567 M in the driver's window where the pair kernel gives 1 271)
+    //   beyond                 queues + the pair / matrix-core kernel, 32 games a wave (the Complex track under the planner: 101.8 against 57.5 M; second episodes: 1 412 against 772 M)
+    h->meter_sparse = (double)worst <= envs_per_launch / 128.0;
+    h->meter_dense = (double)worst > envs_per_launch / 8.0;
+    h->meter_games = (int)std::min<unsigned long long>(worst, 1u << 30);
+}
+
+static bool inwave_allowed(hk_handle h);
+constexpr int THROTTLE_EVERY = 16, THROTTLE_MIN_TICKS = 512;
+static int throttle_mark(hk_handle h, int r)
+{
+    if (!h->throttle || (r % THROTTLE_EVERY) != THROTTLE_EVERY - 1) return HK_OK;
+    const int i = (r / THROTTLE_EVERY) & 3, back = (i + 2) & 3;
+    if (h->thr_valid[back]) HK_HIP(h, hipEventSynchronize(h->ev_thr[back]));          // the GPU has passed the marker of 2 x THROTTLE_EVERY rounds ago
+    meter_look(h);
+    h->dev.inwave_ok = inwave_allowed(h); h->dev.dense = h->meter_dense; h->dev.lqn_sparse_blocks = std::min(4096, std::max(LQN_SPARSE_BLOCKS, h->meter_games));
+    if (!h->ev_thr[i]) HK_HIP(h, hipEventCreateWithFlags(&h->ev_thr[i], hipEventDisableTiming));
+    HK_HIP(h, hipEventRecord(h->ev_thr[i], h->stream));
+    h->thr_valid[i] = true;
+    return meter_copy(h, false);
 }
 
 // hk_schedule_info: what step_ticks decided for the call it just issued, in one place (the decisions themselves are spread over the function for
@@ -651,15 +667,15 @@ static int meter_update(hk_handle h, int n_ticks)
 static void record_schedule(hk_handle h, int n_ticks, const char* rounds_mode, int rounds, bool fold, bool planner)
 {
     char buf[640];
-    const char* kern = h->dev.fission ? "fission (tick kernel + env_b1_kernel per solve cadence)" : (h->dev.park ? "fused + LDS parking" : "fused");
+    const char* kern = h->dev.fission ? "fission (tick kernel + env_b1_kernel per solve cadence)" : "fused";
     const char* games = !h->dev.fission || h->dev.P.any_lqr == 0 ? "queues + solver launch"
                         : (h->dev.inwave_ok ? (h->dev.inwave_always ? "in-wave (env_b1_kernel), every round" : "in-wave (env_b1_kernel) once the field has spread, queues + solver launch before")
                                             : (h->dev.lqn_spread ? "queues + lqn_spread_kernel (lqn_round_kernel while the field stands close)" : "queues + lqn_round_kernel"));
     std::snprintf(buf, sizeof(buf),
                   "{\"call_ticks\": %d, \"rounds\": \"%s\", \"rounds_issued\": %d, \"kernel\": \"%s\", \"streams\": %d, \"ticks_per_launch\": %d, "
-                  "\"optimistic_plan\": %s, \"armed_in_first_launch\": %s, \"multi_player_games\": \"%s\", \"games_meter_sparse\": %s, \"planner\": %s, \"actors\": %d}",
-                  n_ticks, rounds_mode, rounds, kern, h->split ? h->tune.split_ways : 1, h->dev.P.run_cap, h->dev.exact_plan ? "true" : "false", fold ? "true" : "false",
-                  games, h->meter_sparse ? "true" : "false", planner ? "true" : "false", h->n_policies);
+                  "\"optimistic_plan\": %s, \"armed_in_first_launch\": %s, \"multi_player_games\": \"%s\", \"games_meter\": \"%s\", \"planner\": %s, \"actors\": %d}",
+                  n_ticks, rounds_mode, rounds, kern, h->split ? SPLIT_WAYS : 1, h->dev.P.run_cap, h->dev.exact_plan ? "true" : "false", fold ? "true" : "false",
+                  games, h->meter_sparse ? "sparse" : (h->meter_dense ? "dense" : "medium"), planner ? "true" : "false", h->n_policies);
     h->sched = buf;
 }
 
@@ -667,7 +683,7 @@ static void record_schedule(hk_handle h, int n_ticks, const char* rounds_mode, i
 static int step_ticks(hk_handle h, int n_ticks)
 {
     int rc;
-    if ((rc = meter_update(h, n_ticks))) return rc;
+    meter_look(h);
     // Planner searches: a launch of the search kernel lasts as long as one search however few it holds, so requests are
     // batched.  A long call launches them every MCTS_FLUSH_ROUNDS rounds and once more before it returns; short calls (a
     // Unity host stepping tick by tick, or the chunks between two RL decisions) share ONE launch until MCTS_DEFER_TICKS
@@ -699,7 +715,7 @@ static int step_ticks(hk_handle h, int n_ticks)
     if (short_call) h->dev.mcts_ticks += n_ticks;
     h->dev.mcts_defer = short_call;
     h->dev.ticks_since_reset += h->dev.call_ticks;      // the previous call's ticks
-    h->dev.lqn_sparse_blocks = h->tune.lqn_sparse_blocks;
+    h->dev.lqn_sparse_blocks = LQN_SPARSE_BLOCKS;
     h->dev.lqn_spread = h->tune.lqn_spread;
     h->dev.inwave_always = h->tune.inwave == 1;
     h->dev.call_ticks = n_ticks; h->dev.call_ticks_issued = 0;
@@ -712,11 +728,11 @@ static int step_ticks(hk_handle h, int n_ticks)
     h->dev.P.mcts_pause = pause ? 1 : 0;
     // the eager assembly (hk_env_run.h) in pause mode too: requests are posted on the same ticks, a round earlier at most
     // (configs[2]: 61.4 -> 63.6 M env-steps/s)
-    if (planner) h->dev.P.eager = (pause && h->tune.eager && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4) ? 1 : 0;
+    if (planner) h->dev.P.eager = (pause && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4) ? 1 : 0;
     // Arming: a kernel of its own, except in fixed-round calls that are not split, where the first tick launch adds the ticks itself and the
     // last one raises the "did not complete" flag the guard kernel would (a one-tick call: 4 launches instead of 9 with round 2's tail regroup)
-    const bool lazy_call = !planner && h->n_policies == 0 && h->done_host != nullptr && n_ticks >= h->tune.lazy_min_ticks && h->tune.lazy;
-    const bool split_req = h->tune.want_split || (h->tune.split_long && (lazy_call || (!planner && h->n_policies == 0 && n_ticks >= h->tune.split_min_ticks)));      // (HK_SPLIT=1: every call)
+    const bool lazy_call = !planner && h->n_policies == 0 && h->done_host != nullptr && n_ticks >= LAZY_MIN_TICKS && h->tune.lazy;
+    const bool split_req = h->tune.split == 1 || (h->tune.split < 0 && (lazy_call || (!planner && h->n_policies == 0 && n_ticks >= SPLIT_MIN_TICKS)));      // (HK_SPLIT=1: every call)
     // (round 6: split calls fold too — each part's first tick launch arms its lane groups, each part's last one is the guard: issue_rounds_split)
     const bool fold = !pause && !lazy_call;
     if (fold) h->dev.arm_ticks = n_ticks;
@@ -725,13 +741,15 @@ static int step_ticks(hk_handle h, int n_ticks)
         if (rc) { g_last_error = h->err; return rc; }
     }
     if (pause) {
+        h->throttle = false;
         // the fission schedule for planner handles too (long calls, LQNG low levels; round 4): the same two kernels with the planner hooks
         bool shaped_p = h->cfg.rewards != 0 || h->cfg.env_mode == HK_MODE_TRAINING;
         for (int i = 0; i < h->cfg.num_agents; i++) shaped_p = shaped_p || h->cfg.training_agent[i] != 0;
-        if (h->tune.fission_shaped) shaped_p = false;      // (reward shaping and the Training-mode reset live in phases A / C: the tick kernel's instantiations carry them)
-        h->dev.fission = h->tune.fission && h->tune.fission_mcts && !shaped_p && h->dev.P.eager && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4;
+        shaped_p = false;      // (reward shaping and the Training-mode reset live in phases A / C: the tick kernel's instantiations carry them)
+        h->dev.fission = h->tune.fission && !shaped_p && h->dev.P.eager && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4;
         if (h->dev.fission) h->dev.P.run_cap = 4;
         h->dev.inwave_ok = inwave_allowed(h);
+        h->dev.dense = h->meter_dense; h->dev.lqn_sparse_blocks = std::min(4096, std::max(LQN_SPARSE_BLOCKS, h->meter_games));
         h->dev.mcts_defer = true;                       // the rounds do not launch searches themselves
         const int cadence = h->cfg.num_agents > 2 ? 4 : 1;
         int maxleft = n_ticks;
@@ -759,8 +777,7 @@ static int step_ticks(hk_handle h, int n_ticks)
                     if (hk::ga_ops(h->dev).mcts_lds_bytes(K.ntab, h->dev.P.L, K.na, K.lds_tier, 4) + (size_t)h->dev.tab_lds + 1024 > 160 * 1024) sw = 8;
                 }
                 if (!h->dev.tab_lds) sw = 8;
-                const char* e = std::getenv("HK_MCTS_SIDE_WAVES");
-                if (e) sw = std::atoi(e) == 4 ? 4 : (std::atoi(e) == 0 ? 0 : 8);
+                if (h->tune.mcts_side_waves >= 0) sw = h->tune.mcts_side_waves;
                 h->dev.mcts_side_waves = sw;
             }
             const bool overlap = h->tune.mcts_overlap && h->dev.fission && cadence == 4 && lat >= 24;
@@ -803,6 +820,7 @@ static int step_ticks(hk_handle h, int n_ticks)
             HK_HIP(h, hipStreamSynchronize(h->stream));
             maxleft = h->done_host[0];
             if (maxleft <= 0 && !h->done_host[1]) break;
+            meter_look(h); h->dev.inwave_ok = inwave_allowed(h); h->dev.dense = h->meter_dense; h->dev.lqn_sparse_blocks = std::min(4096, std::max(LQN_SPARSE_BLOCKS, h->meter_games));      // (the copy of this stretch's check is current)
         }
         h->dev.mcts_defer = false;
         h->dev.P.mcts_pause = 0;
@@ -816,36 +834,36 @@ static int step_ticks(hk_handle h, int n_ticks)
     // multi-player games needs, and the stragglers are finished lazily by the next call that touches the state
     // (finish_ticks): most of the worst-case rounds found nothing to do, and on a 20-tick call they were 5 launches of 8.
     // (short calls — a host stepping tick by tick — keep the fixed count too: a handful of rounds, no host sync)
-    const bool lazy = !planner && h->n_policies == 0 && h->done_host != nullptr && n_ticks >= h->tune.lazy_min_ticks && h->tune.lazy;
+    const bool lazy = !planner && h->n_policies == 0 && h->done_host != nullptr && n_ticks >= LAZY_MIN_TICKS && h->tune.lazy;
     // ticks per launch: longer launches once the field has spread out (see RUN_CAP_SPREAD)
-    const int spread_cap = h->tune.run_cap_spread;
+    const int spread_cap = hk::RUN_CAP_SPREAD;
     // short calls of plain LQNG handles: one solve cadence per launch — with the eager assembly every env, in a pack or not, retires
     // it, so a 20-tick call is 6 equal rounds and no tail (at 8 ticks per launch: 3 rounds + a regroup + 5 rounds for the laggards)
-    const int short_cap = h->tune.run_cap_short;
-    const bool eager = h->tune.eager;
+    const int short_cap = 4;
+    const bool eager = true;
     const bool plain = !planner && h->n_policies == 0;
     // (planner / actor handles keep their deadline arithmetic as it was; the 8-lane groups run the older loop without it)
     h->dev.P.eager = (eager && plain && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4) ? 1 : 0;
     // FISSION: every env parks at every solve tick, so a round retires exactly one cadence
     bool shaped = h->cfg.rewards != 0 || h->cfg.env_mode == HK_MODE_TRAINING;       // reward shaping / Training mode: their own instantiations of the fused kernel
     for (int i = 0; i < h->cfg.num_agents; i++) shaped = shaped || h->cfg.training_agent[i] != 0;
-    const bool shaped_fused = shaped;              // (HK_PARK's fused kernel has no shaped instantiation)
-    if (h->tune.fission_shaped) shaped = false;    // round 5: reward shaping and the Training-mode reset live in phases A / C — the tick kernel's <.., HAS_RW, HAS_TRAIN, .., FISSION> instantiations carry them
+    shaped = false;    // round 5: reward shaping and the Training-mode reset live in phases A / C — the tick kernel's <.., HAS_RW, HAS_TRAIN, .., FISSION> instantiations carry them
     h->dev.fission = h->tune.fission && plain && !shaped && h->dev.P.eager && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4;
-    h->dev.park = h->tune.park && plain && !shaped_fused && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4 && h->dev.P.any_lqr != 0;
-    if (h->dev.park) h->dev.fission = false;
     // handles without an LQ agent (every low level an RL actor, attached or driven through hk_set_actions): the tick kernel of the fission
     // schedule alone — phase B1 has nothing to solve, no env parks for it, no B1 launch
     if (h->tune.fission && !shaped && h->dev.P.any_lqr == 0 && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4) h->dev.fission = true;     // (with a planner too: its hook stays in the tick loop)
     // handles that step in short fixed-round chunks (attached actors: a chunk per decision; planners outside their long calls): the same two
     // kernels without the eager assembly — an env parks at its solve tick, B1 + solver run, the next round resumes it; the rounds issued
     // are the worst case the fused kernel was given too (a round per solve tick of the chunk + 1)
-    if (h->tune.fission && h->tune.fission_chunks && !shaped && (planner || h->n_policies > 0) && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4) h->dev.fission = true;
+    if (h->tune.fission && !shaped && (planner || h->n_policies > 0) && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4) h->dev.fission = true;
     // 2-agent fields (cadence 1: every tick is a solve tick and both egos hold the 2-player game, HKA:317,709) stay on the fused kernel.  Round 6 measured
     // the fission schedule for them (bit-equal; three launches per tick, no eager assembly): 303 M env-steps/s against the fused kernel's 331 M — with a game per
     // ego and tick the round is the pair solver's 131 072 games (98 us) and the GameSoA round trip of the assembly (B1 82 us), which a split does not shrink.
     const bool fission_a2 = false;
     h->dev.inwave_ok = inwave_allowed(h);
+    h->dev.dense = h->meter_dense; h->dev.lqn_sparse_blocks = std::min(4096, std::max(LQN_SPARSE_BLOCKS, h->meter_games));
+    h->throttle = lazy && n_ticks >= THROTTLE_MIN_TICKS && h->dev.fission && h->dev.P.any_lqr != 0;
+    for (bool& v : h->thr_valid) v = false;
     const int run_cap = (h->dev.fission && h->dev.P.any_lqr != 0) ? 4 : (lazy && h->cfg.num_agents > 2 && h->dev.ticks_since_reset >= hk::BULK_TICKS) ? spread_cap
                         : (!lazy && plain && h->dev.P.eager) ? short_cap : hk::RUN_CAP;
     h->dev.P.run_cap = run_cap;
@@ -857,7 +875,7 @@ static int step_ticks(hk_handle h, int n_ticks)
     // kernels that share the GPU each take longer, and bench.py's per-launch roofline (bytes of a launch / its duration) would no longer
     // describe the kernel (hk_prof's stage totals then add up the spans of two concurrent streams).  While the field stands close (BULK_TICKS after a reset of every env: every ego holds a multi-player game and a round's solver
     // launch lasts hundreds of microseconds) the split is used without being asked: race start 440 -> 458 M.
-    const bool want_split = split_req, no_split = h->tune.no_split;
+    const bool want_split = split_req, no_split = h->tune.split == 0;
     const bool close_field = h->dev.ticks_since_reset < hk::BULK_TICKS;
     h->split = (want_split || (close_field && !no_split)) && h->dev.P.eager && h->cfg.num_envs >= 8192;
     // (2-agent fission: a round retires exactly one tick whatever the launch's budget)
@@ -882,7 +900,7 @@ static int step_ticks(hk_handle h, int n_ticks)
         const int main_rounds = std::min(rounds, fission_a2 ? n_ticks : (n_ticks + run_cap - 1) / run_cap);
         h->dev.guard_rounds_left = (fold && !h->split) ? rounds : 0;          // the tick launch that brings this to 0 is the call's last: it is the guard
         h->dev.fold_split = fold && h->split;
-        h->dev.last_solve_skippable = fold && plain && !h->split && h->tune.debug_max_rounds == 0 && !h->tune.keep_last_solve;
+        h->dev.last_solve_skippable = fold && plain && !h->split && h->tune.debug_max_rounds == 0;
         // (with the eager assembly there is nothing to regroup between the two: ONE issue — a split call used to join its streams and fork them again for
         // the tail, which left the first stream idle for ~100 us of the driver's 20-tick call)
         rc = issue_rounds(h, h->dev.P.eager ? rounds : main_rounds);
@@ -906,7 +924,7 @@ static int step_ticks(hk_handle h, int n_ticks)
         if (!h->ev_mcts_done) HK_HIP(h, hipEventCreateWithFlags(&h->ev_mcts_done, hipEventDisableTiming));
         HK_HIP(h, hipEventRecord(h->ev_mcts_go, h->stream));
         HK_HIP(h, hipStreamWaitEvent(h->mcts_stream, h->ev_mcts_go, 0));
-        { const char* e = std::getenv("HK_MCTS_SIDE_WAVES"); h->dev.mcts_side_waves = e ? (std::atoi(e) == 4 ? 4 : (std::atoi(e) == 0 ? 0 : 8)) : 8; }      // (decision chunks: 8-wave workgroups on half the CUs)
+        h->dev.mcts_side_waves = h->tune.mcts_side_waves >= 0 ? h->tune.mcts_side_waves : 8;      // (decision chunks: 8-wave workgroups on half the CUs)
         rc = hk::env_flush_mcts_on(h->dev, h->stream, h->mcts_stream, h->err);
         if (rc) { g_last_error = h->err; return rc; }
         HK_HIP(h, hipEventRecord(h->ev_mcts_done, h->mcts_stream));
@@ -923,6 +941,7 @@ static int step_ticks(hk_handle h, int n_ticks)
         if (rc) return rc;
     }
     h->step_pending = lazy;
+    if (!lazy && h->dev.fission && (h->meter_ticks += n_ticks) >= METER_TICKS) { h->meter_ticks = 0; if ((rc = meter_copy(h, false))) return rc; }
     record_schedule(h, n_ticks, lazy ? "lazy" : "fixed", rounds, fold, planner);
     if (h->dev.exact_plan) h->opt_pending = true;
     h->dev.exact_plan = false;
@@ -1106,7 +1125,7 @@ static int check_device_status(hk_handle h)
     int st[4] = {0, 0, 0, 0};
     HK_HIP(h, hipMemcpyAsync(st, h->dev.status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     HK_HIP(h, hipStreamSynchronize(h->stream));
-    if ((st[0] & 4) && !h->tune.debug_no_check) {
+    if (st[0] & 4) {
         // reported once: the flag is cleared here (and by hk_reset), the unfinished envs keep their leftover ticks for the next hk_step
         const int keep = ~4;
         hipLaunchKernelGGL(hk::status_and_kernel, dim3(1), dim3(1), 0, h->stream, h->dev.status, keep);
@@ -1408,7 +1427,7 @@ int hk_prof_reset(hk_handle h)
     h->prof.fold();
     for (int s = 0; s < HK_PROF_STAGES; s++) { h->prof.ms[s] = 0; h->prof.n[s] = 0; }
     if (h->env_ready && h->dev.game_stats) {
-        HK_HIP(h, hipMemsetAsync(h->dev.game_stats, 0, hk::GAME_STATS_N * sizeof(unsigned long long), h->stream));
+        HK_HIP(h, hipMemsetAsync(h->dev.game_stats, 0, hk::GAME_METER * sizeof(unsigned long long), h->stream));      // (not the games-per-launch meter behind the statistics: the schedule lives on it)
         HK_HIP(h, hipStreamSynchronize(h->stream));
     }
     return HK_OK;
@@ -1422,11 +1441,13 @@ int hk_prof_games(hk_handle h, int64_t* games)
     HK_HIP(h, hipMemcpyAsync(g, h->dev.game_stats, sizeof(g), hipMemcpyDeviceToHost, h->stream));
     HK_HIP(h, hipStreamSynchronize(h->stream));
     for (int n = 0; n <= HK_MAX_AGENTS; n++) games[n] = (int64_t)g[n];
-    if (h->tune.stamps_dump) {       // diagnostic builds (-DHK_STAMPS): the phase cycle counters of the tick kernel
+#ifdef HK_STAMPS
+    {       // diagnostic builds (-DHK_STAMPS): the phase cycle counters of the tick kernel
         std::fprintf(stderr, "HK_STAMPS");
         for (int k = 16; k < hk::GAME_STATS_N; k++) std::fprintf(stderr, " %llu", g[k]);
         std::fprintf(stderr, "\n");
     }
+#endif
     return HK_OK;
 }
 

@@ -547,8 +547,12 @@ __device__ inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_
 }
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
-constexpr int GAME_METER = 14;         // game_stats[14], [15]: multi-player games assembled by env_b1_kernel / its launches, since hk_create or the last hk_prof_reset (the host's choice between in-wave solves and the solver launch)
-constexpr int GAME_STATS_N = 160;      // game_stats: [0, 16) games by player count, [16, 64) cycle stamps, [64, 160) lane-participation probes
+// The games-per-launch meter (round 6; the host's choice between in-wave solves and queues + the pair solver's launch, hk_api.hip).  Per part of the batch p
+// (issue_rounds_split; 0 for an unsplit launch) four words at game_stats[GAME_METER + 4 p]: [0 .. 2] the multi-player games the B1 launches of rounds
+// = 0, 1, 2 mod 3 assembled — launch k counts into slot k % 3, clears slot (k + 1) % 3 and reads the finished launch's total from slot (k + 2) % 3 — and
+// [3] a decaying maximum of those totals (x 3/4 per launch: the handful of laggards' launches at the end of a call say nothing about the field).
+constexpr int GAME_METER = 160, GAME_METER_PARTS = 4;
+constexpr int GAME_STATS_N = 160 + 4 * GAME_METER_PARTS;      // game_stats: [0, 16) games by player count, [16, 64) cycle stamps, [64, 160) lane-participation probes
 // Diagnostic build only (-DHK_LANEPROF, tools/lane_profile.py): probe k counts the waves that reach it and the lanes switched on when they do
 // (game_stats[64 + 2k] lanes, [65 + 2k] waves) — where in the tick kernel the masked half of the average vector instruction lives.
 #ifdef HK_LANEPROF
@@ -643,39 +647,6 @@ __host__ __device__ __forceinline__ void store_hot_tile(uint32_t* p, const Hot& 
 #undef HK_X
 }
 
-// LDS parking (round 5): the fused tick kernel stores the hot fields phase B1 does not touch to the block's LDS before phase_assemble and
-// loads them back after it, between two compiler-level memory barriers, so that they are not live across the Riccati recursion: the
-// kernel's register peak is max(tick loop, phase B1), not their sum (the fused body used to spill 222 VGPRs to scratch).  Row f of the
-// parking area holds field f of every lane of the block (conflict-free: consecutive lanes, consecutive banks).
-#define HK_PARK_FIELDS(X)                                                                                                             \
-    X(float, acc_ang_v) X(float, avg_lane_diff) X(float, avg_vel_diff) X(float, contact_nx) X(float, contact_nz)                      \
-    X(int, lane) X(int, lane_changes) X(int, illegal_lane_changes) X(int, forward_collisions) X(int, last_collision_time)             \
-    X(int, time_steps) X(int, init_checkpoint_index) X(uint32_t, trig_lo) X(uint32_t, trig_hi) X(int, tele_completed_laps)            \
-    X(int, tele_lap_end_step) X(float, tele_last_lap) X(float, tele_best_lap) X(float, tele_total_time) X(float, steer_smoothed)      \
-    X(float, wheel_uf) X(float, wheel_ur)
-constexpr int PARK_ROWS = 22;
-template <int BLOCK>
-__device__ __forceinline__ void park_store(uint32_t* pk, const Hot& h)
-{
-    int r = 0;
-#define HK_X(T, n) pk[(r++) * BLOCK] = __builtin_bit_cast(uint32_t, h.n);
-    HK_PARK_FIELDS(HK_X)
-#undef HK_X
-#ifndef HK_HOST_EMU
-    __asm__ volatile("" ::: "memory");
-#endif
-}
-template <int BLOCK>
-__device__ __forceinline__ void park_load(const uint32_t* pk, Hot& h)
-{
-#ifndef HK_HOST_EMU
-    __asm__ volatile("" ::: "memory");
-#endif
-    int r = 0;
-#define HK_X(T, n) h.n = __builtin_bit_cast(T, pk[(r++) * BLOCK]);
-    HK_PARK_FIELDS(HK_X)
-#undef HK_X
-}
 
 // Sensor.Transform.forward: the kart's forward (fx, fz) turned by the sensor's local yaw (Unity Y rotation, +z toward +x)
 __device__ __forceinline__ void sensor_dir(const EnvParams& P, int si, float fx, float fz, float& dx, float& dz)

@@ -64,6 +64,7 @@ struct EnvDevice {
     bool b1_due = false;           // FISSION: the tick launch just issued parked its envs at their solve tick: env_b1_kernel is next on that stream
     int lqn_sparse_blocks = 1024;  // workgroups per queue of a solver launch once the field has spread (HK_LQN_SPARSE_BLOCKS)
     bool lqn_spread = true;        // the solver launch of a spread field runs the lane-per-(player, row) solver (hk_lq_spread.h); HK_LQN=pair: the pair / matrix-core kernel always
+    bool dense = false;            // the games-per-launch meter's last word: many multi-player games per launch — a solver launch takes the pair / matrix-core kernel (32 games a wave), not the spread solver
     bool inwave_ok = false;        // the current call may solve in-wave (hk_api.hip step_ticks: the handle's shape, the switches, the games-per-launch meter)
     bool inwave_always = false;    // HK_INWAVE=1 (tests): also while the field stands close
     bool inwave = false;           // the B1 launches of the current rounds solve their multi-player games themselves (hk_lq_spread.h lqs_inwave): no queue, no solver launch
@@ -71,8 +72,6 @@ struct EnvDevice {
     bool b1_small = false;         // the rounds issued while a search launch runs on the side stream in 4-wave workgroups (every CU): B1 reads its tables from global memory, the solver launch is the <= 256-register form (hk_env_launch.h)
     int mcts_side_waves = 8;       // waves per workgroup of a search launch that runs beside tick launches (HK_MCTS_SIDE_WAVES; 0: as alone)
     bool exact_plan = false;       // the current fixed-round call follows the exact plan of a field in lock-step: its last round is the tick launch alone (hk_api.hip step_ticks)
-    bool park = false;             // plain handles run the fused kernel with LDS parking (hk_env_run.h PARK) instead of the fission schedule
-    bool park_attr_set = false;
     bool fission = false;          // the current call runs the tick kernel without phase B1 + env_b1_kernel (hk_env_run.h FISSION; hk_api.hip step_ticks)
     bool fold_split = false;       // a folded call on the two-stream schedule: each part's last tick launch is its completion guard (hk_api.hip issue_rounds_split)
     int arm_ticks = 0;             // > 0: the next tick launch adds these ticks to every env's count (a fixed-round call arms itself)

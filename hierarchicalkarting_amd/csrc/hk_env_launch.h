@@ -112,22 +112,6 @@ inline int launch_run(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
     bool train = d.P.training_reset != 0;
     for (int i = 0; i < cfg.num_agents; i++) train = train || d.P.training_agent[i] != 0;
 #if HK_GA == 4
-    if (d.park && !d.fission && !train && !d.rw.sec_time && !d.mcts.st) {
-        // PARK (hk_env_run.h): the fused kernel, 512 threads a block, hot fields parked in LDS around phase B1
-        const GameSoA G{d.games, (size_t)cfg.num_envs * cfg.num_agents};
-        const unsigned blocks = (unsigned)((threads + PARK_BLOCK - 1) / PARK_BLOCK);
-        const size_t park_bytes = (size_t)PARK_ROWS * PARK_BLOCK * sizeof(uint32_t);
-        if (!d.park_attr_set) {
-            (void)hipFuncSetAttribute((const void*)env_run_kernel<false, false, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
-            (void)hipFuncSetAttribute((const void*)env_run_kernel<false, false, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
-            d.park_attr_set = true;
-        }
-#define HK_PARK_RUN(TL) hipLaunchKernelGGL((env_run_kernel<false, false, false, TL, false, true>), dim3(blocks), dim3(PARK_BLOCK), (TL ? d.tab_lds : 0) + park_bytes, stream, d.P, d.agents, d.hot, \
-                               d.envs, d.results, G, d.queue_cnt, d.queue, d.round, d.act_steer, d.act_branch, d.lq_debug, d.status, d.mcts, d.mset, d.rw, d.perm,   \
-                               d.game_stats, s0, s1, d.qbase, arm, guard)
-        if (d.tab_lds) HK_PARK_RUN(true); else HK_PARK_RUN(false);
-#undef HK_PARK_RUN
-    } else
     if (d.fission) {
         // FISSION (hk_env_run.h): the tick kernel without phase B1; launch_b1 follows on the same stream
         const GameSoA G{d.games, (size_t)cfg.num_envs * cfg.num_agents};
@@ -226,7 +210,7 @@ inline int launch_lqn(EnvDevice& d, const hk_config& cfg, hipStream_t stream, st
         const int per = bulk ? 1024 : d.lqn_sparse_blocks;
         const int n34 = sizes ? std::min(ngames, per) * sizes : 0;          // `per` waves per game size walk their queue grid-stride; the queue length picks the solver (lqn_round_kernel)
         const int n2 = std::min((ngames + 31) / 32, bulk ? 4096 : per);
-        if (d.lqn_spread && (!bulk || d.b1_small)) {
+        if (d.lqn_spread && !d.dense && (!bulk || d.b1_small)) {
             // A spread field (round 6): every queue on the lane-per-(player, row) solver (hk_lq_spread.h) — a third of the pair solver's registers, 2 - 11 KB of
             // LDS per wave, ~4 x shorter per lane: its waves start beside the other half's resident tick / B1 waves (and beside a planner's search waves)
             // instead of waiting for a CU to drain.  The pair / matrix-core kernel below keeps the rounds in which (nearly) every ego holds a game.

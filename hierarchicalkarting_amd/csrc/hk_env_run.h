@@ -192,11 +192,8 @@ __device__ __attribute__((noinline)) int phase_assemble_call(const EnvParams& P,
     return phase_assemble(P, T, ks, env, ego, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, mcts_all, LC);
 }
 
-// PARK (round 5): the fused kernel in blocks of 512 threads (one per CU: the staged tables are shared by eight waves) with the hot fields
-// phase B1 does not read parked in LDS around phase_assemble (hk_env_device.h park_store / park_load).
-constexpr int PARK_BLOCK = 512;
-template <bool HAS_MCTS, bool HAS_RW, bool HAS_TRAIN, bool TAB_LDS, bool FISSION = false, bool PARK = false>
-__global__ __launch_bounds__(PARK ? PARK_BLOCK : 256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_run_kernel(EnvParams P, hk_agent_state* agents, uint32_t* hot, hk_env_state* envs,
+template <bool HAS_MCTS, bool HAS_RW, bool HAS_TRAIN, bool TAB_LDS, bool FISSION = false>
+__global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_run_kernel(EnvParams P, hk_agent_state* agents, uint32_t* hot, hk_env_state* envs,
                                                       hk_episode_result* results, GameSoA games, int* queue_cnt_all,
                                                       int* queue_all, int round, const float* act_steer, const int* act_branch,
                                                       hk_lq_debug* dbg_out, int* status, MctsDev Marg, int mset, RwDev RD, const int* perm,
@@ -210,10 +207,8 @@ __global__ __launch_bounds__(PARK ? PARK_BLOCK : 256, FISSION ? HK_FIS_OCC : HK_
 #ifdef HK_LANEPROF
     hk_lp_ptr = stats;                 // (every thread stores the same value)
 #endif
-    __shared__ KartS ks[PARK ? PARK_BLOCK : 256];
+    __shared__ KartS ks[256];
     HK_DYN_SHARED(smem);
-    uint32_t* const pk = reinterpret_cast<uint32_t*>(smem + (TAB_LDS ? P.tab_stage_bytes : 0)) + threadIdx.x;      // PARK: this lane's column of the parking area
-    (void)pk;
     // this launch runs the lane groups [slot0, slot1) and uses the queue sets qbase, qbase + 1 (one launch for every env: 0, E, 0;
     // plain handles split the batch in two halves on two streams so that one half's solver launch hides behind the other's ticks)
     const int gid = slot0 * GA + blockIdx.x * blockDim.x + threadIdx.x;
@@ -321,10 +316,8 @@ __global__ __launch_bounds__(PARK ? PARK_BLOCK : 256, FISSION ? HK_FIS_OCC : HK_
                                      !(P.hold_dedupe && es.episode_steps > cadence && es.episode_steps < P.hold);
                     if constexpr (FISSION) b1_pending = act && P.any_lqr != 0;      // (no LQ agent: nothing for env_b1_kernel to do, the env moves on)
                     else {
-                        if constexpr (PARK) park_store<PARK_BLOCK>(pk, h);
-                        if constexpr (HAS_TRAIN && !PARK) qn = phase_assemble_call(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
+                        if constexpr (HAS_TRAIN) qn = phase_assemble_call(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
                         else qn = phase_assemble(P, T, ks, env, i, act, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
-                        if constexpr (PARK) park_load<PARK_BLOCK>(pk, h);
                     }
                     began = true;
                     solved = act;
@@ -444,6 +437,14 @@ __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_
     if (env_ok) es = envs[slot];
     else { es.episode_steps = 0; es.inactive_mask = 0; es.experiment_num = 0; es.episodes_done = 0; es.status = 0; es.initial_started = 0; es.reserved[0] = 0; es.reserved[1] = 0; }
     const bool pend = env_ok && (es.reserved[1] & ENV_PHASE_MASK) == 2;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // the meter: the launch before this one (same part, same stream) is complete — fold its total into the decaying maximum, clear the next launch's slot
+        unsigned long long* mt = stats + GAME_METER + 4 * (qbase >> 1);
+        const unsigned sl = (unsigned)round % 3u;
+        const unsigned long long prev = mt[(sl + 2u) % 3u], dec = mt[3] - (mt[3] >> 2);
+        mt[3] = prev > dec ? prev : dec;
+        mt[(sl + 1u) % 3u] = 0ull;
+    }
     if (__syncthreads_or(pend ? 1 : 0) == 0) return;
     hk_agent_state* arec = (pend && i < P.A) ? &agents[(size_t)env * P.A + i] : nullptr;
     Hot h = {};
@@ -464,11 +465,10 @@ __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_
     hk_sincosf(h.yaw, &hfx, &hfz);
     HK_ST(h, 19);                      // [19] B1 kernel: table staging, record loads, sincos
     const int qn = phase_assemble(P, T, ks, env, i, pend, es, h, hfx, hfz, agents, games, queue_cnt, queue, dbg_out, status, M.st, LC);
-    // the games-per-launch meter of the host's schedule (hk_api.hip: in-wave solves or queue + solver launch), read back now and then
+    // the games-per-launch meter of the host's schedule (hk_env_device.h GAME_METER), this launch's share
     {
         const unsigned long long mg = __ballot(qn != 0);
-        if ((threadIdx.x & 63) == 0 && mg != 0ull) atomicAdd(&stats[GAME_METER], (unsigned long long)__popcll(mg));
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[GAME_METER + 1], 1ull);
+        if ((threadIdx.x & 63) == 0 && mg != 0ull) atomicAdd(&stats[GAME_METER + 4 * (qbase >> 1) + (unsigned)round % 3u], (unsigned long long)__popcll(mg));
     }
     bool queued = false;
 #ifndef HK_HOST_EMU

@@ -28,34 +28,6 @@ class RacingEnv:
         _lib.check(rc, None)
         self.E, self.A = self.built.cfg.num_envs, self.built.cfg.num_agents
         self.obs_dim = self.L.hk_obs_dim(self.h)
-        import os
-        # what hk_create read from the environment (include/hk.h): long calls of plain handles run as two halves on two streams
-        self.split_default = self.split_for(1 << 20)
-
-    @staticmethod
-    def _atoi(s):
-        """C atoi: leading integer of the string, 0 when there is none (what hk_create's parser sees)"""
-        import re
-        m = re.match(r"\s*([+-]?\d+)", s or "")
-        return int(m.group(1)) if m else 0
-
-    def split_for(self, n_ticks):
-        """Does a call of n_ticks of THIS handle run as two halves on two streams?  The rule of hk_api.hip step_ticks for a plain handle
-        (no planner, no attached actor) once the field has spread, from the switches hk_create read: HK_SPLIT / HK_NO_SPLIT /
-        HK_SPLIT_MIN_TICKS / HK_LAZY_MIN_TICKS / HK_FIXED_ROUNDS (C parsing: atoi)."""
-        import os
-        env = os.environ
-        sp = env.get("HK_SPLIT")
-        no_split = env.get("HK_NO_SPLIT") is not None
-        want = sp is not None and self._atoi(sp) != 0
-        split_long = not no_split and not (sp is not None and self._atoi(sp) == 0)
-
-        def num(name, dflt, lo, hi):
-            v = self._atoi(env[name]) if name in env else dflt
-            return v if lo <= v <= hi else dflt
-        lazy_call = n_ticks >= num("HK_LAZY_MIN_TICKS", 64, 1, 1 << 20) and env.get("HK_FIXED_ROUNDS") is None
-        req = want or (split_long and (lazy_call or n_ticks >= num("HK_SPLIT_MIN_TICKS", 8, 1, 1 << 20)))
-        return bool(req and self.E >= 8192 and 2 < self.A <= 4 and env.get("HK_NO_EAGER") is None)
 
     def schedule_info(self):
         """-> dict: the schedule the last hk_step of this handle ran (hk_schedule_info)"""

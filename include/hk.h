@@ -326,14 +326,15 @@ int hk_set_actions(hk_handle h, const float* steer, const int32_t* branch);
  * hk_reset), and the unfinished envs keep their leftover ticks, which the next hk_step runs first.  A zero pivot in an LQ solve is
  * sticky in the same way (status bit 0) but does not fail the getters: the reference throws nothing there either (MathNet returns
  * inf / NaN), and hk_env_state.status bit 0 flags the karts whose state went non-finite.
- * Scheduling switches, read from the environment ONCE in hk_create (none changes a result bit): HK_FISSION (0: the fused tick kernel instead of
- * the tick kernel without phase B1 + env_b1_kernel per solve cadence), HK_NO_EAGER, HK_FIXED_ROUNDS,
- * HK_MCTS_NO_PAUSE, HK_SPLIT / HK_NO_SPLIT, HK_RUN_CAP_SPREAD, HK_RUN_CAP_SHORT, HK_LAZY_MIN_TICKS, HK_TAIL_WORST_CASE, HK_KEEP_LAST_SOLVE, HK_REGROUP_ROUNDS, HK_MCTS_PERSIST_GB,
- * HK_NO_HOLD_DEDUPE, HK_LQ_DEBUG, HK_TAB_GLOBAL (track tables read from global memory, as for tracks that exceed the LDS budget);
- * round 5: HK_NO_OPTIMISTIC (fixed-round calls issue the worst-case round count instead of the verified plan of a field in lock-step), HK_NO_FISSION_SHAPED
- * (reward-shaped / Training handles keep the fused kernel), HK_PARK (plain handles on the fused kernel with LDS parking), HK_MCTS_NO_OVERLAP / HK_MCTS_SIDE_WAVES
- * (a replan's searches on the handle's stream after the stretch / search workgroup size beside the ticks), HK_LQN_SPARSE_BLOCKS;
- * diagnostics HK_DEBUG_MAX_ROUNDS, HK_DEBUG_NO_CHECK, HK_STAMPS_DUMP.
+ * Scheduling switches, read from the environment ONCE in hk_create (none changes a result bit; hk_schedule_info() reports what a call ran):
+ * HK_FISSION (0: every handle on the fused tick kernel instead of the tick kernel without phase B1 + env_b1_kernel per solve cadence), HK_SPLIT (1: two halves on
+ * two streams in every call of a plain handle, 0: one stream always), HK_INWAVE (0: multi-player games through the queues and a solver launch, 1: solved by the
+ * B1 waves that assembled them in every round; unset: in-wave once the field has spread), HK_LQN (pair: the pair / matrix-core solver launch also for a spread
+ * field), HK_FIXED_ROUNDS, HK_NO_OPTIMISTIC (fixed-round calls issue the worst-case round count instead of the verified plan of a field in lock-step),
+ * HK_OPTIMISTIC_SKEW (tests), HK_MCTS_NO_PAUSE, HK_MCTS_NO_OVERLAP / HK_MCTS_SIDE_WAVES (a replan's searches on the handle's stream after the stretch / search
+ * workgroup size beside the ticks), HK_DEBUG_MAX_ROUNDS (diagnostic); read at table / buffer set-up: HK_MCTS_PERSIST_GB, HK_NO_HOLD_DEDUPE, HK_LQ_DEBUG,
+ * HK_TAB_GLOBAL (track tables read from global memory, as for tracks that exceed the LDS budget).  Round 6 retired the switches whose A/B was settled
+ * (profiles/README.md keeps their numbers).
  * Planner handles (any HighMode MCTS agent): a call of more than 38 ticks without attached actors synchronises with the host
  * between stretches of ~100 ticks — envs wait at the tick boundary after a search request so that the searches of a stretch run
  * as ONE batch (results do not depend on it; environment variable HK_MCTS_NO_PAUSE=1 restores the fully asynchronous schedule).

@@ -20,7 +20,7 @@ from hierarchicalkarting_amd import _lib
 MC, FX, LQ = _lib.HK_HIGH_MCTS, _lib.HK_HIGH_FIXED, _lib.HK_LOW_LQR
 kind = %(kind)r
 kw = dict(jitter_seed=0x5EED0000, laps=1, max_episode_steps=260)
-E = 8192 + 64 if os.environ.get("HK_SPLIT") else 160
+E = 8192 + 64 if os.environ.get("HK_SPLIT") == "1" else 160
 if kind == "plain":          cfg = hk.make_config(E, 4, **kw)                                              # <false, false, false>
 elif kind == "rewards":      cfg = hk.make_config(E, 4, rewards=1, **kw)                                   # <false, true, false>
 elif kind == "planner":      cfg = hk.make_config(E, 4, high_mode=[MC, MC, FX, FX], tree_search_depth=[8, 8, 5, 5], mcts_iterations=12, **kw)          # <true, false, false>
@@ -60,25 +60,21 @@ assert (g.env_state()["episodes_done"] >= 1).all() or kind.startswith("g8") or "
 print("matrix ok", kind)
 """
 
-MODES = {"default": {}, "no_eager": {"HK_NO_EAGER": "1"}, "tab_global": {"HK_TAB_GLOBAL": "1"}, "fixed_rounds": {"HK_FIXED_ROUNDS": "1"}}
+MODES = {"default": {}, "tab_global": {"HK_TAB_GLOBAL": "1"}, "fixed_rounds": {"HK_FIXED_ROUNDS": "1"}}
 CASES = [(k, m) for k in ("plain", "rewards", "planner", "planner_rw", "training") for m in MODES]
 CASES += [("plain", "split"), ("rewards", "split"), ("planner", "no_pause"), ("planner_rw", "no_pause"), ("training", "no_pause")]
 # the fused tick kernel of plain handles (the default since round 4 is the tick kernel without phase B1 + env_b1_kernel: hk_env_run.h FISSION)
 CASES += [("plain", "fused"), ("plain", "fused_split"), ("plain", "fused_tab_global")]
 # the 8-lane groups under the scheduling modes (VERDICT round 3, item 5)
-CASES += [(k, m) for k in ("g8_plain", "g8_planner_actor", "g8_training") for m in ("default", "no_eager", "fixed_rounds", "tab_global")]
+CASES += [(k, m) for k in ("g8_plain", "g8_planner_actor", "g8_training") for m in ("default", "fixed_rounds", "tab_global")]
 # the fission schedule of planner / actor handles against its fused alternatives (round 4)
-CASES += [(k, m) for k in ("actor_lq", "actor_only", "planner_actor_lq") for m in ("default", "fused", "chunks_fused", "tab_global")]
-CASES += [("planner", "fused"), ("planner", "mcts_fused"), ("planner", "chunks_fused")]
-MODES.update({"chunks_fused": {"HK_NO_FISSION_CHUNKS": "1"}, "mcts_fused": {"HK_NO_FISSION_MCTS": "1"}})
-# round 5: the fused kernel with the hot fields parked in LDS around phase B1 (an opt-in schedule, hk_env_run.h PARK), alone and as a split batch;
-# the planner's long calls with the searches beside the ticks (the default) against the schedule that stops an env at its request
-CASES += [("plain", "park"), ("plain", "park_split"), ("plain", "park_tab_global"), ("planner", "no_overlap"), ("planner_rw", "no_overlap")]
-# reward-shaped / Training handles: the fission schedule is their default since round 5; their fused kernel stays reachable
-CASES += [("rewards", "shaped_fused"), ("planner_rw", "shaped_fused"), ("training", "shaped_fused")]
-MODES.update({"shaped_fused": {"HK_NO_FISSION_SHAPED": "1"}})
-MODES.update({"park": {"HK_PARK": "1"}, "park_split": {"HK_PARK": "1", "HK_SPLIT": "1"}, "park_tab_global": {"HK_PARK": "1", "HK_TAB_GLOBAL": "1"},
-              "no_overlap": {"HK_MCTS_NO_OVERLAP": "1"}})
+CASES += [(k, m) for k in ("actor_lq", "actor_only", "planner_actor_lq") for m in ("default", "fused", "tab_global")]
+CASES += [("planner", "fused")]
+# round 5: the planner's long calls with the searches beside the ticks (the default) against the schedule that stops an env at its request
+CASES += [("planner", "no_overlap"), ("planner_rw", "no_overlap")]
+# reward-shaped / Training handles: the fission schedule is their default since round 5; their fused kernel stays reachable (HK_FISSION=0: every handle fused)
+CASES += [("rewards", "fused"), ("planner_rw", "fused"), ("training", "fused")]
+MODES.update({"no_overlap": {"HK_MCTS_NO_OVERLAP": "1"}})
 # the searches beside the ticks in 8-wave workgroups on half the CUs (the default is 4 waves on every CU wherever a tick block fits beside one, with phase B1 on
 # its global-table instantiation and lqn_round_small_kernel for those rounds): both forms of the side launch stay reachable
 CASES += [("planner", "side8"), ("planner_rw", "side8")]

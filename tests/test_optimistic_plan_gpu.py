@@ -40,7 +40,7 @@ def run(b, calls, look_every):
     cmp(g, o, t)
     return g, o
 
-E = 8192 + 128 if os.environ.get("HK_SPLIT") else 192
+E = 8192 + 128 if os.environ.get("HK_SPLIT") == "1" else 192
 # a host that steps tick by tick through the start hold and the race start, looking only now and then; then the driver's call shape; then odd sizes
 g, o = run(hk.make_config(E, 4, jitter_seed=0x5EED0000, laps=1), [1] * 100 + [5, 20, 20, 3, 1, 2, 7, 20, 1, 1, 1, 1, 9], 25)
 # the belief becomes wrong: 130-tick time-outs with auto-reset inside a run of short calls (a time-out adds a solve tick the plan does not know of)
@@ -65,8 +65,8 @@ print("optimistic ok")
 MODES = {"default": {}, "skew1": {"HK_OPTIMISTIC_SKEW": "1"}, "skew2": {"HK_OPTIMISTIC_SKEW": "2"}, "skew3": {"HK_OPTIMISTIC_SKEW": "3"},
          "off": {"HK_NO_OPTIMISTIC": "1"}, "split": {"HK_SPLIT": "1"}, "split_skew2": {"HK_SPLIT": "1", "HK_OPTIMISTIC_SKEW": "2"},
          # one stream always: every fixed-round call is folded (arms inside its first tick launch, its last tick launch is the guard)
-         "fold": {"HK_NO_SPLIT": "1"}, "fold_skew1": {"HK_NO_SPLIT": "1", "HK_OPTIMISTIC_SKEW": "1"}, "fold_skew2": {"HK_NO_SPLIT": "1", "HK_OPTIMISTIC_SKEW": "2"},
-         "fold_skew3": {"HK_NO_SPLIT": "1", "HK_OPTIMISTIC_SKEW": "3"}}
+         "fold": {"HK_SPLIT": "0"}, "fold_skew1": {"HK_SPLIT": "0", "HK_OPTIMISTIC_SKEW": "1"}, "fold_skew2": {"HK_SPLIT": "0", "HK_OPTIMISTIC_SKEW": "2"},
+         "fold_skew3": {"HK_SPLIT": "0", "HK_OPTIMISTIC_SKEW": "3"}}
 
 
 @pytest.mark.parametrize("mode", sorted(MODES))

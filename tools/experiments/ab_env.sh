@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-box A/B of environment switches (run on the GPU box from the repo root): each argument is a string of VAR=value pairs ("-" = defaults)
-#   tools/experiments/ab_env.sh - "HK_PARK=1" "HK_FISSION=0"      -> protocol window and the driver's 20-tick window per setting
+#   tools/experiments/ab_env.sh - "HK_INWAVE=0" "HK_FISSION=0"      -> protocol window and the driver's 20-tick window per setting
 set -o pipefail
 for v in "$@"; do
   e=""; [ "$v" != "-" ] && e="$v"

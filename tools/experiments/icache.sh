@@ -9,8 +9,8 @@ run() {  # name, env...
   env "$@" rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_IFETCH SQ_INSTS_VALU SQ_INSTS_SALU -d $out/$n.b -o pmc --output-format csv -- python3 $R/bench.py --steps 256 --warmup 0 --no-cpu-baseline --no-secondary > $out/$n.b.log 2>&1
 }
 run split HK_DUMMY=1
-run one HK_NO_SPLIT=1
-run park HK_PARK=1 HK_NO_SPLIT=1
+run one HK_SPLIT=0
+# (run park ...: HK_PARK was retired in round 6 with its kernel; profiles/r05_a_backend_flags.txt keeps the numbers)
 cd $R
 python3 - <<PY
 import csv, glob, collections

@@ -1,7 +1,7 @@
 #!/bin/bash
 # instruction-fetch stalls of the tick / B1 launches (16 steady-state ticks, one stream)
 set -e
-export HK_NO_SPLIT=1 TMPDIR=/tmp
+export HK_SPLIT=0 TMPDIR=/tmp
 out=gpurun_out/ifetch; mkdir -p $out
 python3 tools/experiments/region_cost.py dump /tmp/rc_state.npz
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_IFETCH -d $out/a -o pmc --output-format csv -- python3 tools/experiments/region_cost.py run /tmp/rc_state.npz > $out/a.log 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel durations (rocprofv3 --kernel-trace) of 16 steady-state ticks on one stream, per variant library: bash tools/experiments/ktime.sh base nostore ...
 set -e
-export HK_NO_SPLIT=1 TMPDIR=/tmp
+export HK_SPLIT=0 TMPDIR=/tmp
 out=gpurun_out/ktime; mkdir -p $out
 python3 tools/experiments/region_cost.py dump /tmp/rc_state.npz
 for v in "$@"; do

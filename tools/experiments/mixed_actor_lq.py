@@ -1,5 +1,5 @@
 """A 2v2 Oval race with one team on the RL actor (device policy, DecisionPeriod 2) and the other on the LQ game: the handle type that steps in
-decision chunks AND solves LQ games.  HK_NO_FISSION_CHUNKS=1: the fused kernel for it.  usage (GPU box): python tools/experiments/mixed_actor_lq.py"""
+decision chunks AND solves LQ games.  HK_FISSION=0: the fused kernel for it (HK_NO_FISSION_CHUNKS until round 6).  usage (GPU box): python tools/experiments/mixed_actor_lq.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import hierarchicalkarting_amd as hk

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Region-cost experiment (see region_cost.py): on the GPU box, from the repo root:   bash tools/experiments/region_cost.sh base notrig noenter ...
-# Every name is a build/libhk_<name>.so of tools/build_variant.py ("base" = a variant built with no -D).  One stream (HK_NO_SPLIT=1) so a kernel's
+# Every name is a build/libhk_<name>.so of tools/build_variant.py ("base" = a variant built with no -D).  One stream (HK_SPLIT=0) so a kernel's
 # counters are its own.  Output: gpurun_out/region_cost/<name>/ (rocprofv3 counter csv) and gpurun_out/region_cost/summary.json.
 set -e
-export HK_NO_SPLIT=1 TMPDIR=/tmp
+export HK_SPLIT=0 TMPDIR=/tmp
 out=gpurun_out/region_cost; mkdir -p $out
 python3 tools/experiments/region_cost.py dump /tmp/rc_state.npz
 for v in "$@"; do

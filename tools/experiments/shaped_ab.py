@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Reward-shaped / Training-mode handles on the fission schedule against the fused kernel (HK_NO_FISSION_SHAPED=1): env-steps/s of three set-ups (run on the GPU box)"""
+"""Reward-shaped / Training-mode handles on the fission schedule against the fused kernel (HK_FISSION=0; HK_NO_FISSION_SHAPED until round 6): env-steps/s of three set-ups (run on the GPU box)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import hierarchicalkarting_amd as hk

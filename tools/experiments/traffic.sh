@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the tick / B1 / solver launches of 16 steady-state ticks on one stream (FETCH_SIZE, WRITE_SIZE: separate passes, KiB)
 set -e
-export HK_NO_SPLIT=1 TMPDIR=/tmp
+export HK_SPLIT=0 TMPDIR=/tmp
 out=gpurun_out/traffic; mkdir -p $out
 python3 tools/experiments/region_cost.py dump /tmp/rc_state.npz
 for c in FETCH_SIZE WRITE_SIZE; do

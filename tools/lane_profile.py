@@ -44,7 +44,7 @@ def main():
     if a.build:
         return build()
     if os.environ.get("HK_LIB_PATH") != LIB:
-        env = dict(os.environ, HK_LIB_PATH=LIB, HK_STAMPS_DUMP="1")
+        env = dict(os.environ, HK_LIB_PATH=LIB)          # (a -DHK_STAMPS build dumps its counters with every hk_prof_games)
         p = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stderr=subprocess.PIPE, text=True)
         line = [l for l in p.stderr.splitlines() if l.startswith("HK_STAMPS")]
         if p.returncode or not line:
