@@ -316,6 +316,9 @@ int hk_set_actions(hk_handle h, const float* steer, const int32_t* branch);
  * touches the state (any hk_get_* / hk_set_* / hk_reset / hk_step / hk_prof_read / hk_gather_results, or hk_synchronize): it waits
  * for a two-word report of the device and issues what the laggard envs still need ("lazy completion").  hk_synchronize is the
  * completion point: a host that overlaps its own work with hk_step, or times it, calls hk_synchronize where it needs the ticks done.
+ * Round 6: a lazily completed call of >= 512 ticks paces itself: the host stays at most 32 rounds (128 ticks) of launches ahead of the GPU (a marker event
+ * every 16 rounds, a wait for the marker two back) so that it can look at the games meter and change where multi-player games are solved while the call runs —
+ * such a call returns when its LAST 32 rounds are issued, not at once.  Shorter calls return as soon as they are issued, as before.
  * Round 5: a fixed-round call of a plain handle whose envs are all believed to stand on the same episode step (a reset of every env, then only hk_step
  * calls) issues exactly the launches such a field needs — a one-tick call off a solve tick is one launch — and the completion guard verifies the
  * belief: the next entry point other than hk_step looks at it and, if an env fell behind (it finished its race, a time-out), finishes that env the

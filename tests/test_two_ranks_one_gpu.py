@@ -89,3 +89,21 @@ def test_bench_rank_code_with_two_ranks_on_one_gpu():
     assert mg["ranks_seen"] == 2 and len(mg["per_rank_ms"]) == 2 and all(t > 0 for t in mg["per_rank_ms"])
     assert abs(max(mg["per_rank_ms"]) - out["ms_per_step"] * 40) / max(mg["per_rank_ms"]) < 1e-6
     assert mg["result_gather"]["envs_gathered"] == 2 * 4096 and mg["result_gather"]["ms"] > 0
+
+
+def test_bench_rank_code_over_rccl_with_one_rank():
+    """the RCCL leg of bench.py's rank code (process group on `nccl`, per-rank spans gathered as CUDA tensors, the result gather straight from the
+    library's device buffer) with the one rank a 1-GPU box allows: HK_BENCH_FORCE_DIST=1 makes a world of 1 go through it"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HK_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (os.getpid() % 2000) + 7),
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--envs-per-gpu", "4096", "--steps", "40", "--warmup", "4", "--preroll", "300",
+                        "--no-secondary", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(line) == 1
+    out = json.loads(line[0])
+    mg = out["multi_gpu"]
+    assert mg["backend"] == "nccl" and mg["ranks_seen"] == 1 and len(mg["per_rank_ms"]) == 1
+    assert abs(mg["per_rank_ms"][0] - out["ms_per_step"] * 40) / mg["per_rank_ms"][0] < 1e-6
+    assert mg["result_gather"]["envs_gathered"] == 4096 and out["config"]["finished_episodes_seen"] >= 0
+    assert out["config"]["build"]["units"]["hk_ga4.hip"]["guard_findings"] == 0 and out["config"]["schedule"]["call_ticks"] == 40
