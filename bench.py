@@ -36,7 +36,17 @@ STEADY_TICK = 512                      # steady state = ticks 5
 # HBM bytes and SQ counters cannot be read in-process: they come from the separate rocprofv3 --pmc passes of THIS command that
 # tools/pmc_summary.py folded into this file (committed with the profile it belongs to; `commit` / `command` inside say which)
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r06_pmc_summary.json")
-PMC_CADENCE_KERNELS = ("env_run_kernel", "env_b1_kernel", "lqn_round_kernel", "lqn_spread_kernel")      # the launches of a solve cadence (whichever the summary holds)
+# the launches of a solve cadence in the steady state of the profiled run: tick + B1 (which solves the multi-player games in-wave).  lqn_spread_kernel runs in a fraction of
+# the rounds (while the games meter reads "medium") and enters weighted by its share of launches; lqn_round_kernel is the race start's solver (the first 384 ticks of the
+# profiled run) and is not part of the steady state
+PMC_CADENCE_KERNELS = ("env_run_kernel", "env_b1_kernel", "lqn_spread_kernel")
+
+
+def _cadence_weight(d, k):
+    """launches of kernel k per tick launch in the profiled run (1 for the tick and B1 kernels)"""
+    base = (d.get("env_run_kernel") or {}).get("launches_seen") or 0
+    n = (d.get(k) or {}).get("launches_seen") or 0
+    return min(1.0, n / base) if base else 0.0
 
 
 def pmc_fields(kernel, env_steps_per_launch=None):
@@ -62,7 +72,7 @@ def pmc_fields(kernel, env_steps_per_launch=None):
         # its two waves per SIMD; in the product schedule two streams' launches share the SIMDs, up to `waves_per_simd` resident: see valu_port_use_over_wall,
         # which main() adds from this run's own wall time)
         alone = 2.0
-        binding = {"resource": "neither roof: vector-instruction issue and the waits / dependent-launch gaps the resident waves do not cover (profiles/r05_a_backend_flags.txt, DESIGN.md section 2)",
+        binding = {"resource": "neither roof: vector-instruction issue and the waits / dependent-launch gaps the resident waves do not cover (profiles/r05_a_backend_flags.txt, r06_d_*, DESIGN.md section 2)",
                    "wave_issuing_valu_frac": sq.get("wave_issuing_valu_frac"), "wave_issuing_any_frac": sq.get("wave_issuing_any_frac"),
                    "wave_waiting_frac": sq.get("wave_waiting_frac"), "waves_per_simd_limit": d.get("waves_per_simd", 2),
                    "simd_valu_busy_frac_launch_alone": min(1.0, alone * (sq.get("wave_issuing_valu_frac") or 0.0)),
@@ -85,14 +95,14 @@ def valu_port_use(tick_launches, wall_s):
         from source_hash import source_hash
         if d.get("sources_sha16") != source_hash():
             return None          # the kernels changed after the counters were taken: no stale instruction counts in the line
-        quad = sum(float(d[k]["sq"]["SQ_ACTIVE_INST_VALU"]) for k in PMC_CADENCE_KERNELS if k in d)
+        quad = sum(float(d[k]["sq"]["SQ_ACTIVE_INST_VALU"]) * _cadence_weight(d, k) for k in PMC_CADENCE_KERNELS if k in d and "sq" in d[k])
     except (OSError, ValueError, KeyError, TypeError):
         return None
     if wall_s <= 0:
         return None
     simds, clock_hz = 1024, 2.4e9
     return {"frac": quad * 4.0 * tick_launches / (simds * clock_hz * wall_s), "valu_busy_quad_cycles_per_launch_set": quad, "simds": simds, "clock_ghz": clock_hz / 1e9,
-            "note": "SQ_ACTIVE_INST_VALU (units of four cycles) of tick + B1 + solver launch, x launch sets of the timed region, / (SIMDs x wall cycles at the peak clock); the rest of the slots: waits no resident wave covers, the gaps between the three dependent launches of a round, ramp and tail of every launch"}
+            "note": "SQ_ACTIVE_INST_VALU (units of four cycles) of tick + B1 launch (+ the spread solver's launch, weighted by its share of rounds), x launch sets of the timed region, / (SIMDs x wall cycles at the peak clock); the rest of the slots: waits no resident wave covers, the gaps between the three dependent launches of a round, ramp and tail of every launch"}
 
 
 def cadence_traffic(env_steps_per_tick_launch):
@@ -106,7 +116,7 @@ def cadence_traffic(env_steps_per_tick_launch):
     from source_hash import source_hash
     if d.get("sources_sha16") != source_hash() or not d.get("env_steps_per_launch"):
         return None
-    parts = {k: (d.get(k) or {}).get("hbm_bytes_per_launch") for k in PMC_CADENCE_KERNELS if k in d}
+    parts = {k: (d[k].get("hbm_bytes_per_launch") or 0.0) * _cadence_weight(d, k) for k in PMC_CADENCE_KERNELS if k in d}
     if parts["env_run_kernel"] is None:
         return None
     scale = env_steps_per_tick_launch / d["env_steps_per_launch"]
