@@ -583,25 +583,41 @@ __device__ HK_ASM_ATTR int phase_assemble(const EnvParams& P, const TabView& T, 
             }
             const int cell = grid_cell(P, ox, oz);
             const int w0 = T.grid_off[cell], w1 = T.grid_off[cell + 1];
-            auto short_rays = [&](const hk_wall_seg& ws) {
-                HK_LP(7);
-#ifndef HK_NO_SHORT_RAY_CULL
-                // the four rays are compared with 2 m and 1.5 m only (side, below): a wall whose box is further than that from the
-                // origin cannot change any of the comparisons (1 cm margin >> float rounding); most of a cell's list is
-                // (round 4: by the wall's distance from the ray origin, not by bounding boxes — tighter for the diagonal segments of the curves)
-                if (!wall_within(ws, ox, oz, 2.0f + 0.02f)) return;
-#endif
-                HK_LP(8);
+            // Two passes over the cell's list, 32 walls at a time (round 6; the wall-contact pass of phase_move has had this form since round 2): a cheap
+            // distance test marks the walls that can matter (a bit per wall), then only those get the four ray tests, in list order.  The four rays are
+            // compared with 2 m and 1.5 m only (side, below): a wall further than that from the ray origin cannot change any of the comparisons
+            // (1 - 2 cm margin >> float rounding).  In one pass — test, then the rays behind an `if` — the wave ran the four ray tests for nearly every
+            // listed wall, because with 64 lanes in as many places SOME lane's wall passes on almost every trip; now it runs them as often as the lane with
+            // the most walls in reach needs (a minimum does not depend on the order, and the order is the list's anyway).
+            for (int base = w0; base < w1; base += 32) {
+                const int nq = (w1 - base) < 32 ? (w1 - base) : 32;
+                uint32_t cand = 0;
+                for (int q = 0; q < nq; q += 4) {
+                    HK_LP(7);
+                    hk_wall_seg ws[4];         // (four index -> wall load chains in flight; slots past the end re-read the last wall and are masked out)
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    float t = ray_seg(ox, oz, ddx[q], ddz[q], ws);
-                    if (t >= 0.0f && t < best[q]) best[q] = t;
+                    for (int j = 0; j < 4; j++) ws[j] = T.walls[T.grid_idx[base + ((q + j) < nq ? (q + j) : (nq - 1))]];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+#ifndef HK_NO_SHORT_RAY_CULL
+                        const bool apart = !wall_within(ws[j], ox, oz, 2.0f + 0.02f);
+#else
+                        const bool apart = false;
+#endif
+                        cand |= ((apart || (q + j) >= nq) ? 0u : 1u) << (q + j);
+                    }
                 }
-            };
-            for (int w = w0; w < w1; w += 2) {          // (two load chains in flight, as for the forward ray)
-                const hk_wall_seg wa = T.walls[T.grid_idx[w]], wb = T.walls[T.grid_idx[w + 1 < w1 ? w + 1 : w]];
-                short_rays(wa);
-                if (w + 1 < w1) short_rays(wb);
+                while (cand) {
+                    const int q = __ffs((int)cand) - 1;
+                    cand &= cand - 1u;
+                    HK_LP(8);
+                    const hk_wall_seg ws = T.walls[T.grid_idx[base + q]];
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; r4++) {
+                        const float t = ray_seg(ox, oz, ddx[r4], ddz[r4], ws);
+                        if (t >= 0.0f && t < best[r4]) best[r4] = t;
+                    }
+                }
             }
 #pragma unroll
             for (int q = 0; q < 4; q++) k.ray[1 + q] = best[q];
