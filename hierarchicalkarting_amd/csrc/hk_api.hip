@@ -173,6 +173,7 @@ struct hk_context {
     bool throttle = false;
     hipEvent_t ev_thr[4] = {};
     bool thr_valid[4] = {};
+    bool meter_was_split = false;  // the call before ran as SPLIT_WAYS parts (their words are the current ones)
     bool meter_sparse = true;      // what the last copy said (until one arrives: sparse once the field has had BULK_TICKS to spread — launch_b1's rule)
     bool meter_dense = false;      // ... so many games per launch that a solver launch wants the pair solver's 32 games a wave
     int meter_games = 0;           // ... the decaying maximum itself (sizes the spread solver's grid)
@@ -634,10 +635,12 @@ static int meter_copy(hk_handle h, bool in_order)
 static void meter_look(hk_handle h)
 {
     if (!h->meter_host) return;
+    // (the parts the call before ran as: a part that no longer launches keeps its last word for ever — a host that steps tick by tick after a race start on two
+    // streams would read the start's counts from the idle part for the rest of the race; step_ticks clears the idle parts' words when the shape changes)
+    const int parts = h->meter_was_split ? SPLIT_WAYS : 1;
     unsigned long long worst = 0;
-    for (int p = 0; p < hk::GAME_METER_PARTS; p++) worst = std::max(worst, h->meter_host[4 * p + 3]);
-    // (plain handles of >= 8 192 envs run as SPLIT_WAYS parts in every call long enough to matter; planner / actor handles as one batch)
-    const double envs_per_launch = (h->cfg.num_envs >= 8192 && h->dev.mcts.st == nullptr && h->n_policies == 0) ? h->cfg.num_envs / (double)SPLIT_WAYS : (double)h->cfg.num_envs;
+    for (int p = 0; p < parts; p++) worst = std::max(worst, h->meter_host[4 * p + 3]);
+    const double envs_per_launch = h->cfg.num_envs / (double)parts;
     // Three regimes (same-box A/Bs of profiles/r06_b_short_call_trace.txt and r06_c_dense_fields.txt), by the games of a launch of `envs_per_launch` envs:
     //   up to 1 per 128 envs   in-wave (39 per half-batch launch in the protocol window: 3.5 % ahead of a solver launch; level with it at 262 - 400, ticks 517 .. 537)
     //   up to 1 per 8 envs     queues + lqn_spread_kernel, its grid sized for the count (a few hundred games: 1 567 M in the driver's window where the pair kernel gives 1 271)
@@ -655,7 +658,7 @@ static int throttle_mark(hk_handle h, int r)
     const int i = (r / THROTTLE_EVERY) & 3, back = (i + 2) & 3;
     if (h->thr_valid[back]) HK_HIP(h, hipEventSynchronize(h->ev_thr[back]));          // the GPU has passed the marker of 2 x THROTTLE_EVERY rounds ago
     meter_look(h);
-    h->dev.inwave_ok = inwave_allowed(h); h->dev.dense = h->meter_dense; h->dev.lqn_sparse_blocks = std::min(4096, std::max(LQN_SPARSE_BLOCKS, h->meter_games));
+    h->dev.inwave_ok = inwave_allowed(h); h->dev.dense = h->meter_dense || !h->dev.fission;      /* (the meter lives in env_b1_kernel: a handle on the fused kernel keeps round 5's solver launch) */ h->dev.lqn_sparse_blocks = std::min(4096, std::max(LQN_SPARSE_BLOCKS, h->meter_games));
     if (!h->ev_thr[i]) HK_HIP(h, hipEventCreateWithFlags(&h->ev_thr[i], hipEventDisableTiming));
     HK_HIP(h, hipEventRecord(h->ev_thr[i], h->stream));
     h->thr_valid[i] = true;
@@ -749,7 +752,7 @@ static int step_ticks(hk_handle h, int n_ticks)
         h->dev.fission = h->tune.fission && !shaped_p && h->dev.P.eager && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4;
         if (h->dev.fission) h->dev.P.run_cap = 4;
         h->dev.inwave_ok = inwave_allowed(h);
-        h->dev.dense = h->meter_dense; h->dev.lqn_sparse_blocks = std::min(4096, std::max(LQN_SPARSE_BLOCKS, h->meter_games));
+        h->dev.dense = h->meter_dense || !h->dev.fission;      /* (the meter lives in env_b1_kernel: a handle on the fused kernel keeps round 5's solver launch) */ h->dev.lqn_sparse_blocks = std::min(4096, std::max(LQN_SPARSE_BLOCKS, h->meter_games));
         h->dev.mcts_defer = true;                       // the rounds do not launch searches themselves
         const int cadence = h->cfg.num_agents > 2 ? 4 : 1;
         int maxleft = n_ticks;
@@ -820,7 +823,7 @@ static int step_ticks(hk_handle h, int n_ticks)
             HK_HIP(h, hipStreamSynchronize(h->stream));
             maxleft = h->done_host[0];
             if (maxleft <= 0 && !h->done_host[1]) break;
-            meter_look(h); h->dev.inwave_ok = inwave_allowed(h); h->dev.dense = h->meter_dense; h->dev.lqn_sparse_blocks = std::min(4096, std::max(LQN_SPARSE_BLOCKS, h->meter_games));      // (the copy of this stretch's check is current)
+            meter_look(h); h->dev.inwave_ok = inwave_allowed(h); h->dev.dense = h->meter_dense || !h->dev.fission;      /* (the meter lives in env_b1_kernel: a handle on the fused kernel keeps round 5's solver launch) */ h->dev.lqn_sparse_blocks = std::min(4096, std::max(LQN_SPARSE_BLOCKS, h->meter_games));      // (the copy of this stretch's check is current)
         }
         h->dev.mcts_defer = false;
         h->dev.P.mcts_pause = 0;
@@ -861,7 +864,7 @@ static int step_ticks(hk_handle h, int n_ticks)
     // ego and tick the round is the pair solver's 131 072 games (98 us) and the GameSoA round trip of the assembly (B1 82 us), which a split does not shrink.
     const bool fission_a2 = false;
     h->dev.inwave_ok = inwave_allowed(h);
-    h->dev.dense = h->meter_dense; h->dev.lqn_sparse_blocks = std::min(4096, std::max(LQN_SPARSE_BLOCKS, h->meter_games));
+    h->dev.dense = h->meter_dense || !h->dev.fission;      /* (the meter lives in env_b1_kernel: a handle on the fused kernel keeps round 5's solver launch) */ h->dev.lqn_sparse_blocks = std::min(4096, std::max(LQN_SPARSE_BLOCKS, h->meter_games));
     h->throttle = lazy && n_ticks >= THROTTLE_MIN_TICKS && h->dev.fission && h->dev.P.any_lqr != 0;
     for (bool& v : h->thr_valid) v = false;
     const int run_cap = (h->dev.fission && h->dev.P.any_lqr != 0) ? 4 : (lazy && h->cfg.num_agents > 2 && h->dev.ticks_since_reset >= hk::BULK_TICKS) ? spread_cap
@@ -878,6 +881,11 @@ static int step_ticks(hk_handle h, int n_ticks)
     const bool want_split = split_req, no_split = h->tune.split == 0;
     const bool close_field = h->dev.ticks_since_reset < hk::BULK_TICKS;
     h->split = (want_split || (close_field && !no_split)) && h->dev.P.eager && h->cfg.num_envs >= 8192;
+    if (h->split != h->meter_was_split && h->dev.game_stats) {
+        // the batch changes shape: the parts that stop launching (or start again after a long time) must not be read with their old words
+        HK_HIP(h, hipMemsetAsync(h->dev.game_stats + hk::GAME_METER + 4, 0, 4 * (hk::GAME_METER_PARTS - 1) * sizeof(unsigned long long), h->stream));
+        h->meter_was_split = h->split;
+    }
     // (2-agent fission: a round retires exactly one tick whatever the launch's budget)
     int rounds = lazy ? hk::env_rounds_min(h->cfg, n_ticks, fission_a2 ? 1 : run_cap) : hk::env_rounds_for(h->cfg, n_ticks, run_cap, h->dev.P.eager != 0 || fission_a2);
     // The optimistic plan of a fixed-round call (round 5).  If every env stands on episode step T0, the call's ticks T0 + 1 .. T0 + n hold S solve ticks

@@ -1,0 +1,38 @@
+"""The games meter across a change of the batch's shape (round 6).  A race start runs as two halves on two streams even in short calls; once the field has
+spread a host that steps tick by tick runs one batch on one stream, and the second half's meter word stops being written.  Read for ever with its last
+value — the race start's counts — it would keep such a host on the dense schedule (queues + the pair kernel) for the rest of the race: step_ticks clears the
+idle parts' words when the shape changes and the host only reads the parts the call before ran as.  Also: the states of the tick-by-tick host and of a host
+that steps in long calls are the same bit for bit, whatever schedule each of them was given."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_tick_by_tick_host_reaches_the_sparse_schedule_after_a_split_start():
+    import hierarchicalkarting_amd as hk
+    b = hk.make_config(8192, 4, jitter_seed=5, laps=3, max_episode_steps=4000)
+    g = hk.RacingEnv(b); ref = hk.RacingEnv(b)
+    g.reset(); ref.reset()
+    g.step(1)
+    first = g.schedule_info()
+    assert first["streams"] == 2, first                 # the close field of a race start: two halves
+    for _ in range(899):
+        g.step(1)
+    last = g.schedule_info()
+    assert last["streams"] == 1 and last["call_ticks"] == 1, last
+    assert last["games_meter"] == "sparse", last
+    assert "in-wave" in last["multi_player_games"], last
+    ref.step(900)
+    a, r = g.agent_state(), ref.agent_state()
+    for name in a.dtype.names:
+        x, y = a[name], r[name]
+        if x.dtype.kind == "f":
+            x = x.view(np.uint32); y = y.view(np.uint32)
+        assert np.array_equal(x, y), name
+    # and back: a long call (two halves again) after the tick-by-tick stretch starts from cleared words, not from the start's
+    g.step(64); ref.step(64)
+    again = g.schedule_info()
+    assert again["streams"] == 2 and again["games_meter"] in ("sparse", "medium"), again
+    assert np.array_equal(g.agent_state()["px"].view(np.uint32), ref.agent_state()["px"].view(np.uint32))
+    g.close(); ref.close()
