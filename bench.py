@@ -630,20 +630,33 @@ def bench_lqng(a, D, hk):
         hist = (hist / max(hist.sum(), 1)).round(4).tolist()
         exec_flop = sum(h * lq_flop(i + 1) for i, h in enumerate(hist)) * A / (4 if A > 2 else 1) + 2000.0 * A
         tick_ms = dt / a.steps * 1e3
-        if dom == "env_run_kernel":
-            # one launch of the fused kernel advances the envs by a variable number of ticks (<= RUN_CAP): units per launch =
-            # env-steps of the timed region / launches of the timed region; algorithmic bytes = 1 056 B x that
-            algo = ALGO_BYTES_PER_ENV_STEP * (A / 4.0) * E * a.steps / dom_n
+        if dom in ("env_run_kernel", "env_b1_kernel"):
+            # one launch of the tick kernel advances the envs by a variable number of ticks (<= RUN_CAP): units per launch =
+            # env-steps of the timed region / launches of the timed region; algorithmic bytes = 1 056 B x that.
+            # A B1 launch (sensing + assembly + the solves of a solve tick; since round 6 also the multi-player games of a spread field, so in a short
+            # window with many games it can be the larger stage) passes over the envs of its launch ONCE: state in + state out per env, not per env-step
+            if dom == "env_run_kernel":
+                algo = ALGO_BYTES_PER_ENV_STEP * (A / 4.0) * E * a.steps / dom_n
+            else:
+                algo = ALGO_BYTES_PER_ENV_STEP * (A / 4.0) * E / max(int(sched.get("streams", 1)), 1)
             achieved = algo / 1e9 / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
-            traffic, prov, binding = pmc_fields("env_run_kernel", float(E) * a.steps / dom_n)
-            roof = {"bound": "hbm", "kernel": "env_run_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            traffic, prov, binding = pmc_fields(dom, float(E) * a.steps / dom_n)
+            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo,
                     "traffic_provenance": prov, "binding": binding}
-            cad = cadence_traffic(float(E) * a.steps / dom_n)
+            if dom == "env_b1_kernel":
+                run_ms, run_n = avg["env_run_kernel"], max(prof["env_run_kernel"][1], 1)
+                run_algo = ALGO_BYTES_PER_ENV_STEP * (A / 4.0) * E * a.steps / run_n
+                roof["algorithmic_bytes_are"] = "one pass over the launch's envs (1 056 B x envs of the launch): the kernel runs once per solve cadence"
+                roof["tick_kernel"] = {"kernel": "env_run_kernel", "launches": prof["env_run_kernel"][1], "avg_launch_ms": run_ms, "algorithmic_bytes_per_launch": run_algo,
+                                       "achieved": run_algo / 1e9 / (run_ms * 1e-3) if run_ms > 0 else 0.0,
+                                       "frac": (run_algo / 1e9 / (run_ms * 1e-3) / HBM_PEAK_GBS) if run_ms > 0 else 0.0,
+                                       "note": "the tick loop's launches of the same window (the larger stage over a long region: see baseline_protocol_ticks_512_3584)"}
+            cad = cadence_traffic(float(E) * a.steps / max(prof["env_run_kernel"][1], 1))
             if cad:
                 roof["traffic_whole_cadence"] = cad
             if binding:
-                vp = valu_port_use(dom_n, dt)
+                vp = valu_port_use(max(prof["env_run_kernel"][1], 1), dt)
                 if vp:
                     binding["valu_port_use_over_wall"] = vp
             if sched.get("streams", 1) > 1:
@@ -660,7 +673,7 @@ def bench_lqng(a, D, hk):
             # dense flop count of the games it actually solved in this run (hk_prof_games)
             flop = sum(n * lq_flop(N) for N, n in games.items()) / dom_n
             achieved = flop / 1e12 / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
-            roof = {"bound": "fp64_valu", "kernel": "lqn_round_kernel (2-player pairs + lqn_body<3,4>)", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS,
+            roof = {"bound": "fp64_valu", "kernel": "the multi-player solver launch (lqn_round_kernel: pairs + lqn_body<3,4>, or lqn_spread_kernel: see config.schedule)", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "dense_flop_per_launch": flop}
         roof.update({"avg_launch_ms": dom_ms, "launches": prof[dom][1], "chosen_as": "largest total_ms among the stages of the profiled pass",
                      "profiled_pass": {"value": E * D.world * a.steps / dt_prof, "unit": "env-steps/s",

@@ -174,6 +174,7 @@ struct hk_context {
     hipEvent_t ev_thr[4] = {};
     bool thr_valid[4] = {};
     bool meter_was_split = false;  // the call before ran as SPLIT_WAYS parts (their words are the current ones)
+    bool meter_looked = false;     // meter_look has run (its band needs a previous answer)
     bool meter_sparse = true;      // what the last copy said (until one arrives: sparse once the field has had BULK_TICKS to spread — launch_b1's rule)
     bool meter_dense = false;      // ... so many games per launch that a solver launch wants the pair solver's 32 games a wave
     int meter_games = 0;           // ... the decaying maximum itself (sizes the spread solver's grid)
@@ -588,12 +589,14 @@ static int finish_ticks(hk_handle h)
 {
     const int cadence = h->cfg.num_agents > 2 ? 4 : 1;
     h->dev.last_solve_skippable = false; h->dev.guard_rounds_left = 0; h->dev.exact_plan = false; h->throttle = false;      // (the laggards' rounds are plain rounds)
+    bool packed = false;
     for (int guard = 0; guard < 1024 && h->step_pending; guard++) {
         HK_HIP(h, hipStreamSynchronize(h->stream));
         const int maxleft = h->done_host[0], waiting = h->done_host[1];
         if (maxleft <= 0 && !waiting) { h->step_pending = false; break; }
         int rc = hk::env_launch_regroup(h->dev, h->cfg, h->stream, h->err);      // the laggards into the first lane groups
         if (rc) { g_last_error = h->err; return rc; }
+        packed = true;
         h->split = false;                // ... which all lie in the first half: the tail runs as one batch on one stream
         // Rounds for the slowest env if it met no further multi-player game (+ 1), not for the worst case (a round per cadence): the
         // batch ends with a look at the device anyway, and two thirds of the worst-case rounds used to find nothing to do (94 of 141 in
@@ -605,6 +608,12 @@ static int finish_ticks(hk_handle h)
         if (rc) return rc;
     }
     if (h->step_pending) { h->step_pending = false; return fail(h, HK_ERR_HIP, "hk_step: an env did not complete its ticks (internal scheduling error)"); }
+    // The laggards — the envs that met the most multi-player games, and will meet the next ones — now sit side by side in the first lane groups.  With the
+    // games solved in-wave that is the worst order there is (a wave solves its games a pass at a time, and the whole front of the batch is one half of a
+    // split call): the next round regroups again, and with every env done that regroup spreads the envs that hold games evenly (hk_regroup_pos.h).
+    // Found in the driver's window: B1 launches of 91 us where the same games, never packed, took 73 (profiles/r06_f_spread_regroup.txt).
+    // (whatever the schedule is now: the next call decides again, and its regroup packs or spreads accordingly)
+    if (packed) h->dev.rounds_since_regroup = h->dev.regroup_rounds;
     return HK_OK;
 }
 
@@ -636,21 +645,35 @@ static void meter_look(hk_handle h)
 {
     if (!h->meter_host) return;
     // (the parts the call before ran as: a part that no longer launches keeps its last word for ever — a host that steps tick by tick after a race start on two
-    // streams would read the start's counts from the idle part for the rest of the race; step_ticks clears the idle parts' words when the shape changes)
+    // streams would read the start's counts from the idle part for the rest of the race; a part that launches again after a change of shape starts its words over)
     const int parts = h->meter_was_split ? SPLIT_WAYS : 1;
     unsigned long long worst = 0;
     for (int p = 0; p < parts; p++) worst = std::max(worst, h->meter_host[4 * p + 3]);
     const double envs_per_launch = h->cfg.num_envs / (double)parts;
-    // Three regimes (same-box A/Bs of profiles/r06_b_short_call_trace.txt and r06_c_dense_fields.txt), by the games of a launch of `envs_per_launch` envs:
-    //   up to 1 per 128 envs   in-wave (39 per half-batch launch in the protocol window: 3.5 % ahead of a solver launch; level with it at 262 - 400, ticks 517 .. 537)
-    //   up to 1 per 8 envs     queues + lqn_spread_kernel, its grid sized for the count (a few hundred games: 1 567 M in the driver's window where the pair kernel gives 1 271)
+    // Three regimes, by the games of a launch of `envs_per_launch` envs (same-box A/Bs: profiles/r06_f_spread_regroup.txt — 20-tick windows along the race
+    // start with the games solved in-wave and by a solver launch —, r06_b_short_call_trace.txt, r06_c_dense_fields.txt):
+    //   up to 1 per 40 envs    in-wave (per half-batch launch of 32 768 envs: 2 - 7 % ahead of a solver launch at 54 .. 722 games, 11 % behind at 2 779; a wave
+    //                          that holds games runs one pass while the regroup keeps such envs apart)
+    //   up to 1 per 8 envs     queues + lqn_spread_kernel, its grid sized for the count
     //   beyond                 queues + the pair / matrix-core kernel, 32 games a wave (the Complex track under the planner: 101.8 against 57.5 M; second episodes: 1 412 against 772 M)
-    h->meter_sparse = (double)worst <= envs_per_launch / 128.0;
+    // (with a band: a field that hovers at a border would change sides call by call, and every change of sides is a regroup)
+    h->meter_sparse = (double)worst <= envs_per_launch / 40.0 || (h->meter_sparse && h->meter_looked && (double)worst <= envs_per_launch / 28.0);
+    h->meter_looked = true;
     h->meter_dense = (double)worst > envs_per_launch / 8.0;
     h->meter_games = (int)std::min<unsigned long long>(worst, 1u << 30);
 }
 
 static bool inwave_allowed(hk_handle h);
+// what the meter's last look means for the launches from here on: where the multi-player games are solved, and — the two are coupled — how the regroup
+// orders the envs that hold them.  Queues want such envs PACKED (they leave their tick launches together), in-wave solves want them APART (a wave solves
+// its games a pass at a time; hk_regroup_pos.h): when the schedule changes sides the order of the last regroup is the wrong one, so the next round regroups.
+static void apply_meter(hk_handle h)
+{
+    h->dev.inwave_ok = inwave_allowed(h);
+    h->dev.dense = h->meter_dense || !h->dev.fission;      // (the meter lives in env_b1_kernel: a handle on the fused kernel keeps round 5's solver launch)
+    h->dev.lqn_sparse_blocks = std::min(4096, std::max(LQN_SPARSE_BLOCKS, h->meter_games));
+    if (h->dev.regroup_mode >= 0 && h->dev.regroup_mode != (hk::inwave_now(h->dev) ? 1 : 0)) h->dev.rounds_since_regroup = h->dev.regroup_rounds;
+}
 constexpr int THROTTLE_EVERY = 16, THROTTLE_MIN_TICKS = 512;
 static int throttle_mark(hk_handle h, int r)
 {
@@ -658,7 +681,7 @@ static int throttle_mark(hk_handle h, int r)
     const int i = (r / THROTTLE_EVERY) & 3, back = (i + 2) & 3;
     if (h->thr_valid[back]) HK_HIP(h, hipEventSynchronize(h->ev_thr[back]));          // the GPU has passed the marker of 2 x THROTTLE_EVERY rounds ago
     meter_look(h);
-    h->dev.inwave_ok = inwave_allowed(h); h->dev.dense = h->meter_dense || !h->dev.fission;      /* (the meter lives in env_b1_kernel: a handle on the fused kernel keeps round 5's solver launch) */ h->dev.lqn_sparse_blocks = std::min(4096, std::max(LQN_SPARSE_BLOCKS, h->meter_games));
+    apply_meter(h);
     if (!h->ev_thr[i]) HK_HIP(h, hipEventCreateWithFlags(&h->ev_thr[i], hipEventDisableTiming));
     HK_HIP(h, hipEventRecord(h->ev_thr[i], h->stream));
     h->thr_valid[i] = true;
@@ -751,8 +774,7 @@ static int step_ticks(hk_handle h, int n_ticks)
         shaped_p = false;      // (reward shaping and the Training-mode reset live in phases A / C: the tick kernel's instantiations carry them)
         h->dev.fission = h->tune.fission && !shaped_p && h->dev.P.eager && h->cfg.num_agents > 2 && h->cfg.num_agents <= 4;
         if (h->dev.fission) h->dev.P.run_cap = 4;
-        h->dev.inwave_ok = inwave_allowed(h);
-        h->dev.dense = h->meter_dense || !h->dev.fission;      /* (the meter lives in env_b1_kernel: a handle on the fused kernel keeps round 5's solver launch) */ h->dev.lqn_sparse_blocks = std::min(4096, std::max(LQN_SPARSE_BLOCKS, h->meter_games));
+        apply_meter(h);
         h->dev.mcts_defer = true;                       // the rounds do not launch searches themselves
         const int cadence = h->cfg.num_agents > 2 ? 4 : 1;
         int maxleft = n_ticks;
@@ -823,7 +845,7 @@ static int step_ticks(hk_handle h, int n_ticks)
             HK_HIP(h, hipStreamSynchronize(h->stream));
             maxleft = h->done_host[0];
             if (maxleft <= 0 && !h->done_host[1]) break;
-            meter_look(h); h->dev.inwave_ok = inwave_allowed(h); h->dev.dense = h->meter_dense || !h->dev.fission;      /* (the meter lives in env_b1_kernel: a handle on the fused kernel keeps round 5's solver launch) */ h->dev.lqn_sparse_blocks = std::min(4096, std::max(LQN_SPARSE_BLOCKS, h->meter_games));      // (the copy of this stretch's check is current)
+            meter_look(h); apply_meter(h);      // (the copy of this stretch's check is current)
         }
         h->dev.mcts_defer = false;
         h->dev.P.mcts_pause = 0;
@@ -863,8 +885,7 @@ static int step_ticks(hk_handle h, int n_ticks)
     // the fission schedule for them (bit-equal; three launches per tick, no eager assembly): 303 M env-steps/s against the fused kernel's 331 M — with a game per
     // ego and tick the round is the pair solver's 131 072 games (98 us) and the GameSoA round trip of the assembly (B1 82 us), which a split does not shrink.
     const bool fission_a2 = false;
-    h->dev.inwave_ok = inwave_allowed(h);
-    h->dev.dense = h->meter_dense || !h->dev.fission;      /* (the meter lives in env_b1_kernel: a handle on the fused kernel keeps round 5's solver launch) */ h->dev.lqn_sparse_blocks = std::min(4096, std::max(LQN_SPARSE_BLOCKS, h->meter_games));
+    apply_meter(h);
     h->throttle = lazy && n_ticks >= THROTTLE_MIN_TICKS && h->dev.fission && h->dev.P.any_lqr != 0;
     for (bool& v : h->thr_valid) v = false;
     const int run_cap = (h->dev.fission && h->dev.P.any_lqr != 0) ? 4 : (lazy && h->cfg.num_agents > 2 && h->dev.ticks_since_reset >= hk::BULK_TICKS) ? spread_cap
@@ -883,7 +904,8 @@ static int step_ticks(hk_handle h, int n_ticks)
     h->split = (want_split || (close_field && !no_split)) && h->dev.P.eager && h->cfg.num_envs >= 8192;
     if (h->split != h->meter_was_split && h->dev.game_stats) {
         // the batch changes shape: the parts that stop launching (or start again after a long time) must not be read with their old words
-        HK_HIP(h, hipMemsetAsync(h->dev.game_stats + hk::GAME_METER + 4, 0, 4 * (hk::GAME_METER_PARTS - 1) * sizeof(unsigned long long), h->stream));
+        // (no launch for it: the parts' next B1 launches start their words over, the host reads only the parts a call ran as — meter_look)
+        h->dev.meter_fresh |= ((1u << hk::GAME_METER_PARTS) - 1u) & ~1u;
         h->meter_was_split = h->split;
     }
     // (2-agent fission: a round retires exactly one tick whatever the launch's budget)

@@ -67,6 +67,7 @@ struct EnvDevice {
     bool dense = false;            // the games-per-launch meter's last word: many multi-player games per launch — a solver launch takes the pair / matrix-core kernel (32 games a wave), not the spread solver
     bool inwave_ok = false;        // the current call may solve in-wave (hk_api.hip step_ticks: the handle's shape, the switches, the games-per-launch meter)
     bool inwave_always = false;    // HK_INWAVE=1 (tests): also while the field stands close
+    unsigned meter_fresh = 0;      // bit p: part p's meter words are old (the batch changed shape): its next B1 launch starts them over
     bool inwave = false;           // the B1 launches of the current rounds solve their multi-player games themselves (hk_lq_spread.h lqs_inwave): no queue, no solver launch
     bool lqn_launched = false;     // the last launch_lqn launched a kernel (or skipped a provably empty one): there is a solver stage to time
     bool b1_small = false;         // the rounds issued while a search launch runs on the side stream in 4-wave workgroups (every CU): B1 reads its tables from global memory, the solver launch is the <= 256-register form (hk_env_launch.h)
@@ -80,6 +81,7 @@ struct EnvDevice {
     int* perm_counts = nullptr;    // [2 * REGROUP_KEYS]: counts, cursors
     int regroup_rounds = 48;       // rounds between two periodic re-assignments (REGROUP_ROUNDS; HK_REGROUP_ROUNDS)
     int rounds_since_regroup = 0;
+    int regroup_mode = -1;         // how the last regroup ordered the envs that hold multi-player games: 0 packed (queues), 1 spread (in-wave solves); -1: none yet
     EnvParams P{};
 };
 
@@ -88,6 +90,8 @@ constexpr int MCTS_FLUSH_ROUNDS = MCTS_MIN_LATENCY / RUN_CAP - 1;      // 4 at R
 constexpr int MCTS_ARENA_WAVES = 2048;
 constexpr int SPLIT_WAYS_MAX = 4;   // parts a split batch can have (hk_api.hip issue_rounds_split): each owns a pair of queue sets
 constexpr int BULK_TICKS = 384;        // after a full reset the field needs about this long to spread out (launch_lqn)
+// do the B1 launches issued now solve their games in-wave?  (the call may — inwave_ok — and the field has had the time to spread, or HK_INWAVE=1)
+inline bool inwave_now(const EnvDevice& d) { return d.inwave_ok && (d.inwave_always || !(d.ticks_since_reset + d.call_ticks_issued < BULK_TICKS)); }
 constexpr int REGROUP_ROUNDS = 48;     // the tick kernel's lane groups are re-assigned by solve phase every so many rounds (~200 ticks)
 constexpr int MCTS_DEFER_TICKS = 38;   // short hk_step calls share one search launch until this many ticks have been armed
 static_assert(MCTS_DEFER_TICKS < MCTS_MIN_LATENCY, "a deferred search must still finish before its plan is due");

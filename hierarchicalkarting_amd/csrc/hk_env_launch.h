@@ -88,11 +88,12 @@ inline int launch_regroup(EnvDevice& d, const hk_config& cfg, hipStream_t stream
     if (hipMemsetAsync(d.perm_counts, 0, 32 * sizeof(int), stream) != hipSuccess) { err = "regroup memset"; return HK_ERR_HIP; }
     hipLaunchKernelGGL(env_regroup_count_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, d.envs, E, d.perm_counts);
     hipLaunchKernelGGL(env_regroup_scatter_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, d.envs, d.envs_alt, d.hot, d.hot_alt, d.perm, d.perm_alt, d.slot_of,
-                       E, d.perm_counts);
+                       E, d.perm_counts, inwave_now(d) ? 1 : 0);          // (in-wave solves: the envs that hold games spread over the waves, not packed)
     const int rc = launch_check(err, "env_regroup kernels");
     if (rc) return rc;           // (a launch that failed wrote nothing: the host pointers stay on the buffers that hold the state)
     // the move is physical: from here on the stream's kernels use the new buffers (everything is issued in stream order)
     std::swap(d.envs, d.envs_alt); std::swap(d.hot, d.hot_alt); std::swap(d.perm, d.perm_alt);
+    d.regroup_mode = inwave_now(d) ? 1 : 0;
     return HK_OK;
 }
 
@@ -151,13 +152,15 @@ inline int launch_b1(EnvDevice& d, const hk_config& cfg, hipStream_t stream, std
     d.b1_due = false;
     // in-wave solves (hk_lq_spread.h lqs_inwave) once the field has spread — while it stands close (BULK_TICKS after a reset of every env) nearly every ego
     // holds a game and the queues + the pair solver's 32 games per wave are several times cheaper per game
-    d.inwave = d.inwave_ok && (d.inwave_always || !(d.ticks_since_reset + d.call_ticks_issued < BULK_TICKS));      // (HK_INWAVE=1, tests: in every round)
+    const int meter_fresh = ((d.meter_fresh >> (d.qbase >> 1)) & 1u) ? 2 : 0;
+    d.meter_fresh &= ~(1u << (d.qbase >> 1));
+    d.inwave = inwave_now(d);      // (HK_INWAVE=1, tests: in every round)
     const int s0 = d.slot1 > d.slot0 ? d.slot0 : 0, s1 = d.slot1 > d.slot0 ? d.slot1 : cfg.num_envs;
     const long long threads = (long long)(s1 - s0) * GA;
     const GameSoA G{d.games, (size_t)cfg.num_envs * cfg.num_agents};
     const unsigned blocks = (unsigned)((threads + 255) / 256);
 #define HK_FIS_B1(TL, MC) hipLaunchKernelGGL((env_b1_kernel<TL, MC>), dim3(blocks), dim3(256), TL ? d.P.o_tmask : 0, stream, d.P, d.agents, d.hot, d.envs, G, d.queue_cnt, d.queue, \
-                           d.round, d.lq_debug, d.status, d.mcts, d.perm, d.game_stats, s0, s1, d.qbase, d.mset, d.inwave ? 1 : 0)
+                           d.round, d.lq_debug, d.status, d.mcts, d.perm, d.game_stats, s0, s1, d.qbase, d.mset, (d.inwave ? 1 : 0) | meter_fresh)
     // (b1_small: beside a search launch whose 4-wave workgroups hold 108.8 KB of EVERY CU's LDS, a B1 block with its 44.5 KB copy of the Complex-track tables
     // — 67 KB with the KartS staging — does not fit; the instantiation that reads the tables through L1 / L2 needs the 22.8 KB of staging only)
     if (d.mcts.st) { if (d.tab_lds && !d.b1_small) HK_FIS_B1(true, true); else HK_FIS_B1(false, true); }

@@ -17,6 +17,7 @@
 // that still has ticks left after the last round (a bug guard: hk_get_* then fail instead of returning stale state).
 // (included once per lane-group width by hk_env_ga.h: no include guard, namespace hk::HK_GA_NS)
 #include "hk_env_device.h"
+#include "hk_regroup_pos.h"
 
 namespace hk { namespace HK_GA_NS {
 
@@ -64,7 +65,7 @@ __device__ __forceinline__ int regroup_key(const hk_env_state& e)
 // Both kernels aggregate per block: the waves' ballots go through LDS, then threads 0..7 issue ONE atomic per key, side by side
 // (per-wave atomics with their return values in series made the pair 125 us for 65 536 envs: 6 % of a 20-tick call).
 constexpr int REGROUP_KEYS = 16;
-struct RegroupLds { int cnt[4][REGROUP_KEYS]; int base[REGROUP_KEYS]; };
+struct RegroupLds { int cnt[4][REGROUP_KEYS]; int base[REGROUP_KEYS]; int cstart[REGROUP_KEYS]; int cn[REGROUP_KEYS]; int ch[REGROUP_KEYS]; };
 __device__ __forceinline__ int regroup_block_counts(RegroupLds& L, int key, int& lane_rank)
 {   // fills L.cnt[wave][k]; returns nothing useful for key < 0; lane_rank = rank of this lane among its wave's lanes of the same key
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void env_regroup_count_kernel(const hk_env_sta
 // swaps the pointers after this launch — so that a wave of the tick kernel keeps reading ONE contiguous tile.  perm / slot_of follow.
 struct alignas(16) HotPiece { uint32_t v[4]; };
 __global__ __launch_bounds__(256) void env_regroup_scatter_kernel(const hk_env_state* envs_old, hk_env_state* envs_new, const uint32_t* hot_old,
-                                                                  uint32_t* hot_new, const int* perm_old, int* perm_new, int* slot_of, int E, int* counts)
+                                                                  uint32_t* hot_new, const int* perm_old, int* perm_new, int* slot_of, int E, int* counts, int spread)
 {
     __shared__ RegroupLds L;
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -110,13 +111,29 @@ __global__ __launch_bounds__(256) void env_regroup_scatter_kernel(const hk_env_s
         const int k = threadIdx.x;
         const int tot = L.cnt[0][k] + L.cnt[1][k] + L.cnt[2][k] + L.cnt[3][k];
         int start = 0;                                   // where key k begins in the new order: the counts of the keys before it
-        for (int j = 0; j < k; j++) start += counts[j];
+        if (!spread) {
+            for (int j = 0; j < k; j++) start += counts[j];
+        } else {
+            // SPREAD (round 6, the games solved in-wave: hk_regroup_pos.h): a class = the lane groups of one phase, done or not done, hinted or not; the
+            // classes in the order (done, phase), and inside a class the hinted ones evenly spaced among the plain ones.  `base` is then the RANK inside
+            // the key, the class's start / size / hinted count ride beside it.
+            const int ck = (k & 3) | ((k & 8) >> 1), kp = k & ~4;
+            int cs = 0;
+            for (int j = 0; j < REGROUP_KEYS; j++) if (((j & 3) | ((j & 8) >> 1)) < ck) cs += counts[j];
+            L.cstart[k] = cs; L.cn[k] = counts[kp] + counts[kp | 4]; L.ch[k] = counts[kp | 4];
+        }
         L.base[k] = start + (tot ? atomicAdd(&counts[REGROUP_KEYS + k], tot) : 0);
     }
     __syncthreads();
     if (key >= 0) {
         int pos = L.base[key] + rank;
         for (int w = 0; w < wave; w++) pos += L.cnt[w][key];
+        if (spread) {
+            const long long N = L.cn[key], H = L.ch[key];
+            const bool hinted = (key & 4) != 0;
+            if (regroup_spreadable(N, H)) pos = L.cstart[key] + (int)regroup_spread_pos(pos, hinted, N, H);
+            else pos = L.cstart[key] + (hinted ? (int)(N - H) + pos : pos);          // (no hinted ones, or too many to keep apart: plain first, packs behind)
+        }
         const int env = perm_old[slot];
         perm_new[pos] = env;
         slot_of[env] = pos;              // (one writer per env; nobody reads slot_of in this launch)
@@ -441,8 +458,10 @@ __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_
         // the meter: the launch before this one (same part, same stream) is complete — fold its total into the decaying maximum, clear the next launch's slot
         unsigned long long* mt = stats + GAME_METER + 4 * (qbase >> 1);
         const unsigned sl = (unsigned)round % 3u;
+        // (bit 1 of `inwave`: this part has not launched for a long time — the batch changed shape, hk_api.hip step_ticks — and its words are old: start over.
+        // The slot this launch counts into is clean either way: the part's round counter carries on where its last launch, which cleared it, left off)
         const unsigned long long prev = mt[(sl + 2u) % 3u], dec = mt[3] - (mt[3] >> 2);
-        mt[3] = prev > dec ? prev : dec;
+        mt[3] = (inwave & 2) ? 0ull : (prev > dec ? prev : dec);
         mt[(sl + 1u) % 3u] = 0ull;
     }
     if (__syncthreads_or(pend ? 1 : 0) == 0) return;
@@ -472,10 +491,9 @@ __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_
     }
     bool queued = false;
 #ifndef HK_HOST_EMU
-    if (inwave) {
+    if (inwave & 1) {
         // IN-WAVE (round 6): a spread field holds a few dozen multi-player games per solve tick; the waves that assembled them solve them here, behind
-        // their own phase_assemble — no queue, no solver launch between this launch and the next tick launch, no barrier (hk_lq_spread.h lqs_inwave).  The
-        // pack hint stays clear: packs that share a wave would solve their games one pass after the other.
+        // their own phase_assemble — no queue, no solver launch between this launch and the next tick launch, no barrier (hk_lq_spread.h lqs_inwave).
         double ua = 0.0, ub = 0.0;
         lqs_inwave(P, games, qn, env * P.A + i, reinterpret_cast<unsigned char*>(&ks[threadIdx.x & ~63]), ua, ub, status, stats);
         if (qn != 0) decode_controls(h.final_steer, h.flags, h.steering, ua, ub, (dbg_out && (P.debug & 1)) ? &dbg_out[(size_t)env * P.A + i] : nullptr);
@@ -490,6 +508,11 @@ __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_
         }
         queued = group_or(qn ? 1 : 0) != 0;
     }
+#ifndef HK_HOST_EMU
+    // (in-wave the hint says the same thing — this env's last solve tick held a game — and the regroup reads it the other way round: such envs are kept
+    // APART, a wave solves its games a pass at a time; env_regroup_scatter_kernel, hk_regroup_pos.h)
+    if (inwave & 1) queued = group_or(qn ? 1 : 0) != 0;
+#endif
     // the planner hook of a solve tick (HKA:330-402, after SolveLQR; every lane of the group calls it): replan request, bestStates -> plan entries
     if (HAS_MCTS && M.st && pend) phase_plan(P, M, mset, env, i, es, h.flags, h.section_index, h.lane, h.lane_changes, h.final_steer, arec);
     if (arec) { hot_put<uint32_t>(htile, HF_flags, h.flags); hot_put<float>(htile, HF_steering, h.steering); }

@@ -527,7 +527,7 @@ __device__ __forceinline__ void lqs_inwave(const EnvParams& P, const GameSoA& ga
     if ((m2 | m3 | m4) == 0ull) return;
     const int lane = threadIdx.x & 63;
     const double dt = (double)P.dt;
-    int sing = 0;
+    int sing = 0, passes = 0;
     if (lane == 0) {          // hk_prof_games
         if (m2) atomicAdd(&gstats[2], (unsigned long long)__popcll(m2));
         if (m3) atomicAdd(&gstats[3], (unsigned long long)__popcll(m3));
@@ -545,6 +545,7 @@ __device__ __forceinline__ void lqs_inwave(const EnvParams& P, const GameSoA& ga
             for (int q = 1; q < 4; q++) { e[q] = e[0]; if (m2 != 0ull) { e[q] = __ffsll((long long)m2) - 1; m2 &= m2 - 1ull; } }
             const int game = __shfl(mygame, set == 0 ? e[0] : (set == 1 ? e[1] : (set == 2 ? e[2] : e[3])), 64);
             const LqsOut o = lqs_solve_call<2, true>(ln2, game, dt, games, &l2[set]);
+            passes++;
 #pragma unroll
             for (int q = 3; q >= 0; q--) {
                 const double a = lqs_readlane(o.a, 16 * q), b = lqs_readlane(o.b, 16 * q);
@@ -563,6 +564,7 @@ __device__ __forceinline__ void lqs_inwave(const EnvParams& P, const GameSoA& ga
             if (m2 != 0ull) { e[2] = __ffsll((long long)m2) - 1; m2 &= m2 - 1ull; }
             const int game = __shfl(mygame, set == 0 ? e[0] : (set == 1 ? e[1] : e[2]), 64);
             const LqsOut o = lqs_solve_call<2, false>(ln2, game, dt, games, &l2[set]);
+            passes++;
 #pragma unroll
             for (int q = 2; q >= 0; q--) {
                 const double a = lqs_readlane(o.a, 16 * q), b = lqs_readlane(o.b, 16 * q);
@@ -577,16 +579,18 @@ __device__ __forceinline__ void lqs_inwave(const EnvParams& P, const GameSoA& ga
         const LqsOut o = lqs_solve_call<3, false>(lane < 36 ? lane : 35, __shfl(mygame, e, 64), dt, games, reinterpret_cast<LqSpreadLds<3>*>(wave_lds));
         const double a = lqs_readlane(o.a, 0), b = lqs_readlane(o.b, 0);
         if (lane == e) { ua = a; ub = b; }
-        sing |= o.sing;
+        sing |= o.sing; passes++;
     }
     while (m4 != 0ull) {
         const int e = __ffsll((long long)m4) - 1; m4 &= m4 - 1ull;
         const LqsOut o = lqs_solve_call<4, true>(lane, __shfl(mygame, e, 64), dt, games, reinterpret_cast<LqSpreadLds<4, true>*>(wave_lds));
         const double a = lqs_readlane(o.a, 0), b = lqs_readlane(o.b, 0);
         if (lane == e) { ua = a; ub = b; }
-        sing |= o.sing;
+        sing |= o.sing; passes++;
     }
 #endif
+    // (hk_prof_games words 0 / 1: solver passes run in-wave, waves that ran any — their ratio says how well the regroup keeps the games apart)
+    if (lane == 0) { atomicAdd(&gstats[0], (unsigned long long)passes); atomicAdd(&gstats[1], 1ull); }
     if (sing && lane == 0) atomicOr(status, 1);
 }
 

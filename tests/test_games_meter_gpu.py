@@ -1,7 +1,7 @@
 """The games meter across a change of the batch's shape (round 6).  A race start runs as two halves on two streams even in short calls; once the field has
 spread a host that steps tick by tick runs one batch on one stream, and the second half's meter word stops being written.  Read for ever with its last
-value — the race start's counts — it would keep such a host on the dense schedule (queues + the pair kernel) for the rest of the race: step_ticks clears the
-idle parts' words when the shape changes and the host only reads the parts the call before ran as.  Also: the states of the tick-by-tick host and of a host
+value — the race start's counts — it would keep such a host on the dense schedule (queues + the pair kernel) for the rest of the race: the host only
+reads the parts the call before ran as, and a part that launches again after a change of shape starts its words over.  Also: the states of the tick-by-tick host and of a host
 that steps in long calls are the same bit for bit, whatever schedule each of them was given."""
 import numpy as np
 import pytest
