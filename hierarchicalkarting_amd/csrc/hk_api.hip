@@ -293,8 +293,13 @@ int hk_create(const hk_config* cfg, hk_handle* out)
         rc = hk::env_create(h->cfg, h->sections, h->walls, h->dev, h->stream, h->err);
         if (rc) { g_last_error = h->err; hk_destroy(h); return rc; }
         h->env_ready = true;
-        if (hipHostMalloc((void**)&h->done_host, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) h->done_host = nullptr;   // (no pinned memory: fixed rounds)
-        else { h->done_host[0] = 0; h->done_host[1] = 0; }
+        if (hipHostMalloc((void**)&h->done_host, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) h->done_host = nullptr;   // (no pinned memory: fixed rounds)
+        else {
+            h->done_host[0] = 0; h->done_host[1] = 0; h->done_host[2] = 0; h->done_host[3] = 0;
+            // word 2: the completion guards' flag, written by the kernels themselves (EnvParams::guard_flag)
+            void* dp = nullptr;
+            h->dev.P.guard_flag = hipHostGetDevicePointer(&dp, h->done_host + 2, 0) == hipSuccess ? (int*)dp : nullptr;
+        }
         if (hipHostMalloc((void**)&h->meter_host, 4 * hk::GAME_METER_PARTS * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) h->meter_host = nullptr;
         else std::memset(h->meter_host, 0, 4 * hk::GAME_METER_PARTS * sizeof(unsigned long long));
         (void)hipStreamCreateWithFlags(&h->meter_stream, hipStreamNonBlocking);          // (here, not inside a call: creating a stream takes milliseconds)
@@ -991,6 +996,13 @@ static int verify_optimistic(hk_handle h)
 {
     h->opt_pending = false;
     int st[4] = {0, 0, 0, 0};
+    if (h->dev.P.guard_flag) {
+        // the guards raise a pinned host word beside the status bit: nothing to copy back when — as good as always — the plan held (the copy to a pageable
+        // buffer was a second round trip behind the stream's completion, ~40 us of a 20-tick call's 820)
+        HK_HIP(h, hipStreamSynchronize(h->stream));
+        if (__atomic_load_n(h->done_host + 2, __ATOMIC_ACQUIRE) == 0) return HK_OK;
+        __atomic_store_n(h->done_host + 2, 0, __ATOMIC_RELEASE);
+    }
     HK_HIP(h, hipMemcpyAsync(st, h->dev.status, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     HK_HIP(h, hipStreamSynchronize(h->stream));
     if (!(st[0] & 4)) return HK_OK;

@@ -115,6 +115,9 @@ struct EnvParams {
     uint32_t L_magic;
     // tight Trigger candidates: per cell of the wall grid the Triggers whose box, grown by the capsule's reach, meets the cell
     int o_tmask2;
+    // pinned host word the completion guards raise beside status bit 2 (hk_api.hip verify_optimistic: the host looks at it after a stream sync instead of
+    // copying the status words back — one round trip less at the end of every short call); nullptr: none
+    int* guard_flag;
     int tab_stage_bytes;    // bytes of the packed tables a block copies to LDS: all of them, or (a long track) all but the last segment, tmask2, which is
                             // then read from global memory (one 8-byte load per kart and tick)
 };

@@ -286,7 +286,7 @@ inline int launch_arm(EnvDevice& d, const hk_config& cfg, int n_ticks, hipStream
 
 inline int launch_done_check(EnvDevice& d, const hk_config& cfg, int lazy, hipStream_t stream, std::string& err)
 {
-    hipLaunchKernelGGL(env_check_kernel, dim3((cfg.num_envs + 255) / 256), dim3(256), 0, stream, d.envs, cfg.num_envs, d.status, lazy);
+    hipLaunchKernelGGL(env_check_kernel, dim3((cfg.num_envs + 255) / 256), dim3(256), 0, stream, d.envs, cfg.num_envs, d.status, lazy, d.P.guard_flag);
     return launch_check(err, "env_check_kernel");
 }
 

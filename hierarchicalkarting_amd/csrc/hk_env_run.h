@@ -30,13 +30,18 @@ __global__ __launch_bounds__(256) void env_arm_kernel(hk_env_state* envs, int E,
     (void)status;
 }
 
-__global__ __launch_bounds__(256) void env_check_kernel(const hk_env_state* envs, int E, int* status, int lazy)
+__device__ __forceinline__ void raise_guard(int* status, int* guard_flag)
+{
+    atomicOr(status, 4);
+    if (guard_flag) __hip_atomic_store(guard_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ __launch_bounds__(256) void env_check_kernel(const hk_env_state* envs, int E, int* status, int lazy, int* guard_flag)
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= E) return;
     const int left = envs[env].reserved[0], phase = envs[env].reserved[1] & ENV_PHASE_MASK;
     if (left != 0 || phase != 0) {
-        if (!lazy) atomicOr(status, 4);          // sticky error for the getters (fixed-rounds mode)
+        if (!lazy) raise_guard(status, guard_flag);          // sticky error for the getters (fixed-rounds mode)
         // what the lazy completion of hk_step needs (hk_api.hip finish_ticks): the host cleared both words before this launch
         atomicMax(status + 1, left);
         if (phase != 0) atomicOr(status + 2, 1);
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_ru
         envs[slot] = es;
     }
     // the last launch of a fixed-round call is its completion guard (what env_check_kernel does for the other calls)
-    if (guard && env_ok && i == 0 && (left != 0 || phase != 0)) atomicOr(status, 4);
+    if (guard && env_ok && i == 0 && (left != 0 || phase != 0)) raise_guard(status, P.guard_flag);
 #ifdef HK_STAMPS
     __builtin_amdgcn_s_waitcnt(0); HK_ST(h, 22);        // [22] the record stores, waited for
     h.st_acc[24] = (unsigned)(h.st_t - st_entry);       // [24] the wave's whole life in this launch
