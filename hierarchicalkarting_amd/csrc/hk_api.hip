@@ -90,7 +90,7 @@ struct Prof {
 // they were settled with are in profiles/README.md.  hk_schedule_info() reports what a call ran.
 constexpr int LAZY_MIN_TICKS = 64;        // calls at least this long issue the rounds a spread field needs and finish the laggards after a look at the device
 constexpr int SPLIT_MIN_TICKS = 8;        // calls of plain handles at least this long run as two halves on two streams (a 20-tick call: 1 050 -> 1 120 M env-steps/s, round 4)
-constexpr int SPLIT_WAYS = 2;             // parts of a split batch (three / four parts on as many streams: 1 504 / 1 107 M against 1 532, round 4)
+constexpr int SPLIT_WAYS = 2;             // parts of a split batch (three / four parts on as many streams: 1 504 / 1 107 M against 1 532, round 4; three with round 6's in-wave solves: 1 410 against 2 270)
 constexpr int LQN_SPARSE_BLOCKS = 1024;   // workgroups per queue of a solver launch once the field has spread
 struct Tuning {
     bool fission = true;         // HK_FISSION=0: every handle on the fused tick kernel (phase B1 inside the tick loop) instead of tick kernel + env_b1_kernel per solve cadence
