@@ -12,7 +12,12 @@ ap.add_argument("--prof", action="store_true", help="with hk_prof events, as ben
 ap.add_argument("--ticks", type=int, default=20)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--envs", type=int, default=65536)
+ap.add_argument("--sched", type=int, default=-1, help="hipSetDeviceFlags value before the handle exists (1 spin, 2 yield, 4 blocking sync)")
 a = ap.parse_args()
+if a.sched >= 0:
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    print("hipSetDeviceFlags ->", hip.hipSetDeviceFlags(ctypes.c_uint(a.sched)))
 env = hk.RacingEnv(hk.make_config(a.envs, 4, jitter_seed=0x5EED0000))
 env.reset()
 env.step(517)
@@ -24,7 +29,8 @@ for r in range(a.reps):
     env.synchronize()
     t0 = time.perf_counter()
     env.step(a.ticks)
+    t1 = time.perf_counter()
     env.synchronize()
     dt = time.perf_counter() - t0
-    out.append(dt)
-print("ticks %d prof %d: " % (a.ticks, a.prof) + " ".join("%.3f ms (%.0f M)" % (x * 1e3, a.envs * a.ticks / x / 1e6) for x in out))
+    out.append((dt, t1 - t0))
+print("ticks %d prof %d: " % (a.ticks, a.prof) + " ".join("%.3f ms (%.0f M; hk_step returned after %.3f)" % (x * 1e3, a.envs * a.ticks / x / 1e6, i * 1e3) for x, i in out))
