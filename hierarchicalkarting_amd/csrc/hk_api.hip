@@ -89,12 +89,14 @@ struct Prof {
 // HK_REGROUP_ROUNDS, HK_LQN_SPARSE_BLOCKS, HK_NO_SPLIT, HK_NO_FISSION_SHAPED / _MCTS / _CHUNKS, HK_DEBUG_NO_CHECK, HK_STAMPS_DUMP) with their code paths; the numbers
 // they were settled with are in profiles/README.md.  hk_schedule_info() reports what a call ran.
 constexpr int LAZY_MIN_TICKS = 64;        // calls at least this long issue the rounds a spread field needs and finish the laggards after a look at the device
-constexpr int SPLIT_MIN_TICKS = 8;        // calls of plain handles at least this long run as two halves on two streams (a 20-tick call: 1 050 -> 1 120 M env-steps/s, round 4)
+constexpr int SPLIT_MIN_TICKS = 8;        // with HK_LAZY_JOIN=0: calls of plain handles at least this long run as two halves on two streams (a 20-tick call: 1 050 -> 1 120 M env-steps/s, round 4).
+                                          // Since round 6 the parts are joined lazily (split_join) and EVERY call of a plain handle of >= 8 192 envs is split: hk_step(1) 57.5 -> 45.7 us
+                                          // per call, hk_step(2) 98.3 -> 81.0 (joined at the end of every call the one-tick call took 72.6 us: the reason for the threshold)
 constexpr int SPLIT_WAYS = 2;             // parts of a split batch (three / four parts on as many streams: 1 504 / 1 107 M against 1 532, round 4; three with round 6's in-wave solves: 1 410 against 2 270)
 constexpr int LQN_SPARSE_BLOCKS = 1024;   // workgroups per queue of a solver launch once the field has spread
 struct Tuning {
     bool fission = true;         // HK_FISSION=0: every handle on the fused tick kernel (phase B1 inside the tick loop) instead of tick kernel + env_b1_kernel per solve cadence
-    int split = -1;              // HK_SPLIT=1: the batch as two halves on two streams in EVERY call of a plain handle; 0: one stream always; unset: calls of >= SPLIT_MIN_TICKS ticks, and while the field stands close
+    int split = -1;              // HK_SPLIT=1: the batch as two halves on two streams in EVERY call of a plain handle; 0: one stream always; unset: every call of a plain handle of >= 8 192 envs (with HK_LAZY_JOIN=0: calls of >= SPLIT_MIN_TICKS ticks, and while the field stands close)
     int inwave = -1;             // HK_INWAVE=0: multi-player games always go through the queues and a solver launch (the schedule before round 6); 1: env_b1_kernel solves them in-wave in every round (tests); unset: in-wave while the games-per-launch meter says the field has spread
     bool lqn_spread = true;      // HK_LQN=pair: the solver launch of a spread field stays on the pair / matrix-core kernel (the schedule before round 6)
     bool lazy = true;            // HK_FIXED_ROUNDS=1: every call issues the worst-case round count up front (no look at the device)
@@ -173,6 +175,8 @@ struct hk_context {
     bool throttle = false;
     hipEvent_t ev_thr[4] = {};
     bool thr_valid[4] = {};
+    bool lazy_join = true;         // HK_LAZY_JOIN=0: every split call joins its parts at its end (the schedule before)
+    bool split_open = false;       // the parts of the last split call have not been joined into the handle's stream yet (short folded calls: split_join)
     bool meter_was_split = false;  // the call before ran as SPLIT_WAYS parts (their words are the current ones)
     bool meter_looked = false;     // meter_look has run (its band needs a previous answer)
     bool meter_sparse = true;      // what the last copy said (until one arrives: sparse once the field has had BULK_TICKS to spread — launch_b1's rule)
@@ -196,6 +200,22 @@ static int throttle_mark(hk_context* h, int r);           // long lazy calls: st
 static int verify_optimistic(hk_context* h); // the completion guard of optimistic fixed-round calls, looked at; laggards finished (defined with step_ticks)
 // a search launch that runs on the side stream beside the chunks of a planner + actor handle (step_ticks): the handle's stream waits for it — before another
 // search launch (they share the tree arena), before the chunk that uses its plans, before anything reads the planner state
+// Two halves on two streams, JOINED LAZILY (round 6).  A short folded call used to end with its parts' streams joined into the handle's stream — and the next
+// call forked them again: a host that steps tick by tick (the reference's FixedUpdate) paid an event pair each way per call and, worse, a GPU-side barrier
+// between the calls, so the halves could never drift apart the way they do inside a long call (one half's B1 tail behind the other half's ticks).  Now a
+// folded split call leaves its parts open; the next such call just continues on both streams.  Everything else that touches the state — every entry point
+// but hk_step, an unsplit or lazily completed call, a regroup — joins first.  (The completion guard's flag is a host word, the meter's copy orders nothing.)
+static inline int split_join(hk_context* h)
+{
+    if (!h->split_open) return 0;
+    h->split_open = false;
+    for (int k = 0; k < hk::SPLIT_WAYS_MAX - 1; k++) {
+        if (!h->qstream[k] || !h->ev_join[k]) continue;
+        if (hipEventRecord(h->ev_join[k], h->qstream[k]) != hipSuccess) return -1;
+        if (hipStreamWaitEvent(h->stream, h->ev_join[k], 0) != hipSuccess) return -1;
+    }
+    return 0;
+}
 static inline int mcts_join_async(hk_context* h)
 {
     if (h->mcts_async_deadline < 0) return 0;
@@ -312,6 +332,7 @@ void hk_destroy(hk_handle h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    (void)split_join(h);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->done_host) (void)hipHostFree(h->done_host);
     if (h->meter_stream) { (void)hipStreamSynchronize(h->meter_stream); (void)hipStreamDestroy(h->meter_stream); }
@@ -338,13 +359,19 @@ void hk_destroy(hk_handle h)
     delete h;
 }
 
-void* hk_stream(hk_handle h) { return h ? (void*)h->stream : nullptr; }
+void* hk_stream(hk_handle h)
+{
+    if (!h) return nullptr;
+    if (h->split_open && (hipSetDevice(h->device) != hipSuccess || split_join(h))) return nullptr;       // (work the caller puts on the stream must come behind both parts)
+    return (void*)h->stream;
+}
 const char* hk_schedule_info(hk_handle h) { return h ? h->sched.c_str() : ""; }
 
 int hk_synchronize(hk_handle h)
 {
     if (!h) return HK_ERR_INVALID;
     HK_HIP(h, hipSetDevice(h->device));
+    if (split_join(h)) return fail(h, HK_ERR_HIP, "hipStreamWaitEvent (the parts of a split call)");
     if (h->step_pending) { int rc = finish_ticks(h); if (rc) return rc; }
     if (h->opt_pending) { int rc = verify_optimistic(h); if (rc) return rc; }
     HK_HIP(h, hipStreamSynchronize(h->stream));
@@ -422,6 +449,7 @@ int hk_lq_solve_batch(hk_handle h, int batch, int N, const double* A, const doub
         if (!(h)) return fail(nullptr, HK_ERR_INVALID, "NULL handle");                     \
         if (!(h)->env_ready) return fail((h), HK_ERR_INVALID, "handle has no environment"); \
         HK_HIP((h), hipSetDevice((h)->device));                                            \
+        if (split_join(h)) return fail((h), HK_ERR_HIP, "hipStreamWaitEvent (the parts of a split call)"); \
         if ((h)->step_pending) { int rc_ = finish_ticks(h); if (rc_) return rc_; }         \
         if ((h)->opt_pending) { int rc_ = verify_optimistic(h); if (rc_) return rc_; }     \
         if (mcts_join_async(h)) return fail((h), HK_ERR_HIP, "hipStreamWaitEvent (planner side stream)"); \
@@ -508,6 +536,7 @@ static int issue_rounds_split(hk_handle h, int rounds)
     int cut[hk::SPLIT_WAYS_MAX + 1];                       // part k: lane groups [cut[k], cut[k + 1]) (a block of the tick kernel holds 64 lane groups)
     for (int k = 0; k <= K; k++) cut[k] = k == K ? E : (int)(((long long)E * k / K + 127) / 128 * 128);     // (whole blocks of the 512-thread form too)
     if ((h->dev.rounds_since_regroup += rounds) >= h->dev.regroup_rounds) {  // the periodic regroup by solve phase, here where the streams are joined
+        if (split_join(h)) return fail(h, HK_ERR_HIP, "hipStreamWaitEvent (the parts of a split call)");
         int rcg = hk::env_launch_regroup(h->dev, h->cfg, h->stream, h->err);
         if (rcg) { g_last_error = h->err; return rcg; }
         h->dev.rounds_since_regroup = rounds;      // (the rounds issued below count toward the next one)
@@ -517,8 +546,11 @@ static int issue_rounds_split(hk_handle h, int rounds)
     st[0] = h->stream;
     for (int k = 1; k < K; k++) st[k] = h->qstream[k - 1];
     h->round_half[0] = h->dev.round;          // sets 0 / 1 are also the unsplit launches' sets: continue their parity
-    HK_HIP(h, hipEventRecord(h->ev_fork, h->stream));
-    for (int k = 1; k < K; k++) HK_HIP(h, hipStreamWaitEvent(st[k], h->ev_fork, 0));
+    if (!h->split_open) {          // (open: the call before left its parts on these streams — this one continues them)
+        HK_HIP(h, hipEventRecord(h->ev_fork, h->stream));
+        for (int k = 1; k < K; k++) HK_HIP(h, hipStreamWaitEvent(st[k], h->ev_fork, 0));
+    }
+    h->split_open = true;
     for (int k = 0; k < K; k++) e[k] = h->prof.begin(st[k]);
     bool first = true;
     int rc = HK_OK;
@@ -569,10 +601,8 @@ static int issue_rounds_split(hk_handle h, int rounds)
     h->dev.inwave = false;
     h->dev.slot0 = 0; h->dev.slot1 = 0; h->dev.qbase = 0; h->dev.round = h->round_half[0];
     if (first) for (int k = 0; k < K; k++) if (e[k]) h->prof.pool.push_back(e[k]);
-    for (int k = 1; k < K; k++) {
-        HK_HIP(h, hipEventRecord(h->ev_join[k - 1], st[k]));
-        HK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join[k - 1], 0));
-    }
+    // a folded call (nothing follows its rounds on the handle's stream: no guard kernel, no report) leaves its parts open for the next one
+    if (!(h->dev.fold_split && h->lazy_join) || rc) { if (split_join(h) && !rc) rc = fail(h, HK_ERR_HIP, "hipStreamWaitEvent (the parts of a split call)"); }
     if (rc) g_last_error = h->err;
     return rc;
 }
@@ -721,6 +751,9 @@ static int step_ticks(hk_handle h, int n_ticks)
     // ticks have been armed since the last one — early enough, because a plan is due > MCTS_MIN_LATENCY ticks after its
     // request.  (hk_get_mcts_state launches what is pending before it reads.)
     const bool planner = h->dev.mcts.st != nullptr;
+    // (the parts of the call before are still open — split_join: only a short folded call of a plain handle may continue them; whether THIS one is split
+    // and folded is known further down, everything else joins here, before it puts anything on the handle's stream)
+    if (h->split_open && (planner || h->n_policies > 0 || n_ticks >= LAZY_MIN_TICKS || !h->tune.lazy)) { if (split_join(h)) return fail(h, HK_ERR_HIP, "hipStreamWaitEvent (the parts of a split call)"); }
     const long long T0 = h->lock_tick;                           // the episode step the field is believed to stand on before this call (-1: not known)
     if (h->lock_tick >= 0) h->lock_tick += n_ticks;
     h->dev.exact_plan = false;
@@ -749,6 +782,7 @@ static int step_ticks(hk_handle h, int n_ticks)
     h->dev.lqn_sparse_blocks = LQN_SPARSE_BLOCKS;
     h->dev.lqn_spread = h->tune.lqn_spread;
     h->dev.inwave_always = h->tune.inwave == 1;
+    { const char* e = std::getenv("HK_LAZY_JOIN"); h->lazy_join = !(e && std::atoi(e) == 0); }
     h->dev.call_ticks = n_ticks; h->dev.call_ticks_issued = 0;
     // Long calls of a planner handle without attached actors run in PAUSE mode: an env that requests a search stops at the next
     // tick boundary until the search has run, the host runs a stretch of rounds (every env reaches its replan tick or the end of
@@ -763,7 +797,7 @@ static int step_ticks(hk_handle h, int n_ticks)
     // Arming: a kernel of its own, except in fixed-round calls that are not split, where the first tick launch adds the ticks itself and the
     // last one raises the "did not complete" flag the guard kernel would (a one-tick call: 4 launches instead of 9 with round 2's tail regroup)
     const bool lazy_call = !planner && h->n_policies == 0 && h->done_host != nullptr && n_ticks >= LAZY_MIN_TICKS && h->tune.lazy;
-    const bool split_req = h->tune.split == 1 || (h->tune.split < 0 && (lazy_call || (!planner && h->n_policies == 0 && n_ticks >= SPLIT_MIN_TICKS)));      // (HK_SPLIT=1: every call)
+    const bool split_req = h->tune.split == 1 || (h->tune.split < 0 && (lazy_call || (!planner && h->n_policies == 0 && n_ticks >= (h->lazy_join ? 1 : SPLIT_MIN_TICKS))));      // (HK_SPLIT=1: every call)
     // (round 6: split calls fold too — each part's first tick launch arms its lane groups, each part's last one is the guard: issue_rounds_split)
     const bool fold = !pause && !lazy_call;
     if (fold) h->dev.arm_ticks = n_ticks;
@@ -935,6 +969,7 @@ static int step_ticks(hk_handle h, int n_ticks)
         const int main_rounds = std::min(rounds, fission_a2 ? n_ticks : (n_ticks + run_cap - 1) / run_cap);
         h->dev.guard_rounds_left = (fold && !h->split) ? rounds : 0;          // the tick launch that brings this to 0 is the call's last: it is the guard
         h->dev.fold_split = fold && h->split;
+        if (h->split_open && !h->dev.fold_split) { if (split_join(h)) return fail(h, HK_ERR_HIP, "hipStreamWaitEvent (the parts of a split call)"); }
         h->dev.last_solve_skippable = fold && plain && !h->split && h->tune.debug_max_rounds == 0;
         // (with the eager assembly there is nothing to regroup between the two: ONE issue — a split call used to join its streams and fork them again for
         // the tail, which left the first stream idle for ~100 us of the driver's 20-tick call)
@@ -1412,6 +1447,7 @@ static bool settle_for_pointer(hk_handle h)
 {
     if (!h || !h->env_ready) return false;
     if (hipSetDevice(h->device) != hipSuccess) return false;
+    if (split_join(h)) return false;
     if (h->step_pending && finish_ticks(h) != HK_OK) return false;
     if (h->opt_pending && verify_optimistic(h) != HK_OK) return false;
     if (mcts_join_async(h)) return false;
@@ -1464,6 +1500,7 @@ int hk_prof_reset(hk_handle h)
 {
     if (!h) return HK_ERR_INVALID;
     HK_HIP(h, hipSetDevice(h->device));
+    if (split_join(h)) return fail(h, HK_ERR_HIP, "hipStreamWaitEvent (the parts of a split call)");
     if (h->step_pending) { int rc = finish_ticks(h); if (rc) return rc; }
     HK_HIP(h, hipStreamSynchronize(h->stream));
     h->prof.fold();
@@ -1497,6 +1534,7 @@ int hk_prof_read(hk_handle h, double* ms, int64_t* launches)
 {
     if (!h) return HK_ERR_INVALID;
     HK_HIP(h, hipSetDevice(h->device));
+    if (split_join(h)) return fail(h, HK_ERR_HIP, "hipStreamWaitEvent (the parts of a split call)");
     if (h->step_pending) { int rc = finish_ticks(h); if (rc) return rc; }
     HK_HIP(h, hipStreamSynchronize(h->stream));
     h->prof.fold();

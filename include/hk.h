@@ -331,7 +331,8 @@ int hk_set_actions(hk_handle h, const float* steer, const int32_t* branch);
  * inf / NaN), and hk_env_state.status bit 0 flags the karts whose state went non-finite.
  * Scheduling switches, read from the environment ONCE in hk_create (none changes a result bit; hk_schedule_info() reports what a call ran):
  * HK_FISSION (0: every handle on the fused tick kernel instead of the tick kernel without phase B1 + env_b1_kernel per solve cadence), HK_SPLIT (1: two halves on
- * two streams in every call of a plain handle, 0: one stream always), HK_INWAVE (0: multi-player games through the queues and a solver launch, 1: solved by the
+ * two streams in every call of a plain handle whatever its size, 0: one stream always; unset: every call of a plain handle of >= 8 192 envs), HK_LAZY_JOIN (0: the
+ * halves of a split call are joined into hk_stream at the end of every call instead of by the next entry point that needs the whole state), HK_INWAVE (0: multi-player games through the queues and a solver launch, 1: solved by the
  * B1 waves that assembled them in every round; unset: in-wave once the field has spread), HK_LQN (pair: the pair / matrix-core solver launch also for a spread
  * field), HK_FIXED_ROUNDS, HK_NO_OPTIMISTIC (fixed-round calls issue the worst-case round count instead of the verified plan of a field in lock-step),
  * HK_OPTIMISTIC_SKEW (tests), HK_MCTS_NO_PAUSE, HK_MCTS_NO_OVERLAP / HK_MCTS_SIDE_WAVES (a replan's searches on the handle's stream after the stretch / search
@@ -391,7 +392,10 @@ void* hk_device_reward_ptr(hk_handle h);        /* float[E][A], valid after hk_r
 void* hk_device_group_reward_ptr(hk_handle h);  /* float[E][A], valid after hk_rewards_device */
 void* hk_device_act_steer_ptr(hk_handle h);     /* float[E][A]: continuous action 0 */
 void* hk_device_act_branch_ptr(hk_handle h);    /* int32[E][A]: discrete action 0 */
-void* hk_stream(hk_handle h);              /* hipStream_t the handle launches on */
+void* hk_stream(hk_handle h);              /* hipStream_t the handle launches on.  Short hk_step calls of a large plain handle leave half of the batch on a second
+                                            * stream (joined lazily); this getter — like every entry point but hk_step — orders hk_stream behind it first, so work
+                                            * a caller enqueues on the returned stream AFTER this call sees every tick issued so far.  Call it again after later
+                                            * hk_step calls rather than caching the ordering (the handle itself never needs it: its own entry points join). */
 /* What built this libhk.so (round 6): a JSON string compiled into the library at link time — hipcc / clang version, the flags, the hidden back-end switches the
  * toolchain accepted and, per translation unit, the code-generation guard variant it shipped with.  bench.py prints it in config.build. */
 const char* hk_build_info(void);
