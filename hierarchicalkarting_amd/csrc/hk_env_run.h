@@ -255,13 +255,15 @@ __global__ __launch_bounds__(256, FISSION ? HK_FIS_OCC : HK_RUN_OCC) void env_ru
 #ifdef HK_STAMPS
     const unsigned long long st_a = __builtin_readcyclecounter();
 #endif
+    // (the kart's rows of the hot tile are asked for BEFORE the table staging and its barrier: 32 loads in flight behind the copy instead of after it)
+    const bool has_rec = env_ok && i < P.A;
+    Hot h;
+    if (has_rec) h = load_hot_tile(htile); else { Hot z = {}; h = z; }
     const TabView T = tab_stage<TAB_LDS>(P, smem);
 #ifdef HK_STAMPS
     const unsigned long long st_b = __builtin_readcyclecounter();
 #endif
-    hk_agent_state* arec = (env_ok && i < P.A) ? &agents[(size_t)env * P.A + i] : nullptr;
-    Hot h;
-    if (arec) h = load_hot_tile(htile); else { Hot z = {}; h = z; }
+    hk_agent_state* arec = has_rec ? &agents[(size_t)env * P.A + i] : nullptr;
     const int cadence = P.A > 2 ? 4 : 1;
     const int cmask = cadence - 1;                       // cadence is 1 or 4 and episode_steps >= 0: x % cadence == x & cmask
     const uint32_t all_mask = (1u << P.A) - 1u;
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_
     h.st_t = __builtin_readcyclecounter();
     h.st_acc[23] = (unsigned)(h.st_t - st_entry);      // [23] B1 kernel: lane group + env words
 #endif
-    const TabView T = tab_stage<TAB_LDS>(P, smem, P.o_tmask);      // (the segments before the Trigger masks: sections, walls, wall grid, cut table)
+    // (the kart's fields are asked for before the table staging and its barrier: the loads fly behind the copy)
     if (arec) {
 #define HK_B1_LOAD(T, n) h.n = hot_get<T>(htile, HF_##n)
         HK_B1_LOAD(float, px); HK_B1_LOAD(float, pz); HK_B1_LOAD(float, yaw); HK_B1_LOAD(float, vx); HK_B1_LOAD(float, vz); HK_B1_LOAD(float, wy);
@@ -484,6 +486,7 @@ __global__ __launch_bounds__(256, HK_B1_OCC) void env_b1_kernel(EnvParams P, hk_
         if (HAS_MCTS) { HK_B1_LOAD(int, lane); HK_B1_LOAD(int, lane_changes); }
 #undef HK_B1_LOAD
     }
+    const TabView T = tab_stage<TAB_LDS>(P, smem, P.o_tmask);      // (the segments before the Trigger masks: sections, walls, wall grid, cut table)
     const LaneCfg LC = lane_cfg(P, i);
     float hfx, hfz;
     hk_sincosf(h.yaw, &hfx, &hfz);

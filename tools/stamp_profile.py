@@ -35,6 +35,7 @@ def build():
         objs.append(o)
         procs.append(subprocess.Popen([hipcc] + ge.HIPCC_FLAGS + ge._backend_flags(hipcc) + ["-DHK_STAMPS"] + os.environ.get("HK_STAMPS_EXTRA", "").split() + ["-c", os.path.join(ge.CSRC, u), "-o", o]))
     assert all(p.wait() == 0 for p in procs)
+    objs.append(os.path.join(ROOT, "build", "obj", "hk_build_info.o"))          # (hk_build_info(): the product's record; ge.build() above... made it)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs)
     print("built", LIB)
 
