@@ -12,6 +12,7 @@ ap.add_argument("--prof", action="store_true", help="with hk_prof events, as ben
 ap.add_argument("--ticks", type=int, default=20)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--envs", type=int, default=65536)
+ap.add_argument("--nosync", action="store_true", help="no hk_synchronize between the calls (a host that steps tick by tick without looking): one sync at the end")
 ap.add_argument("--sched", type=int, default=-1, help="hipSetDeviceFlags value before the handle exists (1 spin, 2 yield, 4 blocking sync)")
 a = ap.parse_args()
 if a.sched >= 0:
@@ -25,6 +26,15 @@ env.synchronize()
 if a.prof:
     env.prof_enable(True)
 out = []
+if a.nosync:
+    env.synchronize()
+    t0 = time.perf_counter()
+    for r in range(a.reps):
+        env.step(a.ticks)
+    env.synchronize()
+    dt = time.perf_counter() - t0
+    print("ticks %d x %d without a look in between: %.1f us per call (%.0f M env-steps/s)" % (a.ticks, a.reps, dt / a.reps * 1e6, a.envs * a.ticks * a.reps / dt / 1e6))
+    sys.exit(0)
 for r in range(a.reps):
     env.synchronize()
     t0 = time.perf_counter()
