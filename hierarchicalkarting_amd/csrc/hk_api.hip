@@ -673,9 +673,7 @@ static int meter_copy(hk_handle h, bool in_order)
     HK_HIP(h, hipMemcpyAsync(h->meter_host, h->dev.game_stats + hk::GAME_METER, 4 * hk::GAME_METER_PARTS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     return HK_OK;
 }
-// what the last copy says: at most one game per 64 envs of a launch (measured, profiles/r06_b_short_call_trace.txt: at 262 games per half-batch launch of
-// 32 768 envs the two schedules are level, at 39 the in-wave one is 3.5 % ahead; profiles/r06_c_dense_fields.txt: thousands per launch — the Complex track
-// under the planner, second episodes — want the pair solver)
+// what the last copy says (the three regimes and their borders: below)
 static void meter_look(hk_handle h)
 {
     if (!h->meter_host) return;
