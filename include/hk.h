@@ -323,7 +323,7 @@ int hk_set_actions(hk_handle h, const float* steer, const int32_t* branch);
  * calls) issues exactly the launches such a field needs — a one-tick call off a solve tick is one launch — and the completion guard verifies the
  * belief: the next entry point other than hk_step looks at it and, if an env fell behind (it finished its race, a time-out), finishes that env the
  * lazy way before anything is read.  Successive hk_step calls do not look; hk_synchronize does.
- * Error surface: hk_step only reports launch errors.  A completion guard (env_check_kernel) runs after the rounds of a call; if an
+ * Error surface: hk_step only reports launch errors.  A completion guard (env_check_kernel, or the last tick launch of a fixed-round call) runs after the rounds of a call; if an
  * env still had ticks to run (an internal scheduling error) the next hk_get_agent_state / hk_get_env_state fails ONCE with
  * HK_ERR_HIP "an env did not complete its ticks" instead of returning stale state; the flag is sticky until that report (or
  * hk_reset), and the unfinished envs keep their leftover ticks, which the next hk_step runs first.  A zero pivot in an LQ solve is
@@ -480,7 +480,9 @@ int hk_prof_enable(hk_handle h, int on);
 int hk_prof_reset(hk_handle h);
 int hk_prof_read(hk_handle h, double* ms /*[HK_PROF_STAGES]*/, int64_t* launches /*[HK_PROF_STAGES]*/);
 /* multi-player LQ games (KartLQR.solveFeedbackLQR calls with N >= 2 players) the solver kernels ran since the last hk_prof_reset,
- * by player count: games[N], N = 2 .. HK_MAX_AGENTS ([0], [1] stay 0: single-player games are solved inside the tick kernel) */
+ * by player count: games[N], N = 2 .. HK_MAX_AGENTS (single-player games are solved inside the tick / B1 kernel and not counted).  games[0], games[1] (round 6):
+ * the solver passes the waves of env_b1_kernel ran in-wave, and the waves that ran any — their ratio says how well the regroup keeps the envs that hold
+ * games apart (1.00: one pass per wave). */
 int hk_prof_games(hk_handle h, int64_t* games /*[HK_MAX_AGENTS + 1]*/);
 
 #ifdef __cplusplus
