@@ -707,7 +707,16 @@ static void apply_meter(hk_handle h)
     h->dev.lqn_sparse_blocks = std::min(4096, std::max(LQN_SPARSE_BLOCKS, h->meter_games));
     if (h->dev.regroup_mode >= 0 && h->dev.regroup_mode != (hk::inwave_now(h->dev) ? 1 : 0)) h->dev.rounds_since_regroup = h->dev.regroup_rounds;
 }
-constexpr int THROTTLE_EVERY = 16, THROTTLE_MIN_TICKS = 512;
+// (round 6, end: a marker every 4 rounds and in every lazily completed call — every 16 rounds and in calls of >= 512 ticks before.  The races of a batch that
+// was reset together END together: within ~150 ticks the field goes from a few dozen games per launch to a game for every ego, and a host that looked every
+// 16 rounds from up to 48 rounds ahead kept the in-wave schedule through ~60 rounds of that — B1 launches of milliseconds (tools/experiments/schedule_trace.py:
+// 110 ms of B1 in the 200-tick call that held the onset, 22.7 ms now; second episodes 1 409 -> 1 626 M, the windows at ticks 20 000 / 40 000 1 342 / 1 336 ->
+// 1 565 / 1 544 M; profiles/r06_g_long_run.txt).  The host issues a round in ~25 us, the GPU runs one in ~115: 8 - 12 rounds of queued work never drain —
+// the protocol window, the race start and the short calls read the same.  Sending the games of three and more players of such a field to a solver launch of
+// their own (four of them sit in ONE quad when an env restarts) was built, parity-green, and lost to this: 1 445 - 1 463 M against 1 544 - 1 565.)
+// (a marker every 1 / 2 / 4 / 8 rounds, same box: second episodes 1 656 / 1 674 / 1 632 / 1 489 M, ticks 20 000 .. 26 000 1 589 / 1 586 / 1 575 / 1 493 M, protocol window
+// 2 279 / 2 303 / 2 314 / 2 321 M: 4 keeps a millisecond of queued work between a descheduled host thread and an idle GPU)
+constexpr int THROTTLE_EVERY = 4, THROTTLE_MIN_TICKS = 64;
 static int throttle_mark(hk_handle h, int r)
 {
     if (!h->throttle || (r % THROTTLE_EVERY) != THROTTLE_EVERY - 1) return HK_OK;
